@@ -1,0 +1,105 @@
+"""Residual conditioner network, CPU restatement of the published nflows net.
+
+Test infrastructure only (see ``oracle/__init__.py``).  Reference call sites:
+``src/nessai/flows/realnvp.py:136-146`` and ``src/nessai/flows/nsf.py:85-95``
+(``ResidualNet(in, out, hidden_features=H, context_features=None,
+num_blocks=L, activation=act, dropout_probability=p, use_batch_norm=flag)``).
+
+Structure: ``h = W0 x + b0``; ``L`` pre-activation
+residual blocks ``h += W2 act(W1 act(h) + b1) + b2`` whose last linear layer is
+initialised U(-1e-3, 1e-3); ``out = Wf h + bf``.
+"""
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+from torch.nn import init
+
+
+class ResidualBlock(nn.Module):
+    def __init__(
+        self,
+        features,
+        context_features,
+        activation=F.relu,
+        dropout_probability=0.0,
+        use_batch_norm=False,
+        zero_initialization=True,
+    ):
+        super().__init__()
+        self.activation = activation
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList(
+                [nn.BatchNorm1d(features, eps=1e-3) for _ in range(2)]
+            )
+        if context_features is not None:
+            self.context_layer = nn.Linear(context_features, features)
+        self.linear_layers = nn.ModuleList(
+            [nn.Linear(features, features) for _ in range(2)]
+        )
+        self.dropout = nn.Dropout(p=dropout_probability)
+        if zero_initialization:
+            init.uniform_(self.linear_layers[-1].weight, -1e-3, 1e-3)
+            init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
+
+    def forward(self, inputs, context=None):
+        temps = inputs
+        if self.use_batch_norm:
+            temps = self.batch_norm_layers[0](temps)
+        temps = self.activation(temps)
+        temps = self.linear_layers[0](temps)
+        if self.use_batch_norm:
+            temps = self.batch_norm_layers[1](temps)
+        temps = self.activation(temps)
+        temps = self.dropout(temps)
+        temps = self.linear_layers[1](temps)
+        if context is not None:
+            temps = F.glu(torch.cat((temps, self.context_layer(context)), dim=1), dim=1)
+        return inputs + temps
+
+
+class ResidualNet(nn.Module):
+    def __init__(
+        self,
+        in_features,
+        out_features,
+        hidden_features,
+        context_features=None,
+        num_blocks=2,
+        activation=F.relu,
+        dropout_probability=0.0,
+        use_batch_norm=False,
+    ):
+        super().__init__()
+        self.hidden_features = hidden_features
+        self.context_features = context_features
+        if context_features is not None:
+            self.initial_layer = nn.Linear(
+                in_features + context_features, hidden_features
+            )
+        else:
+            self.initial_layer = nn.Linear(in_features, hidden_features)
+        self.blocks = nn.ModuleList(
+            [
+                ResidualBlock(
+                    features=hidden_features,
+                    context_features=context_features,
+                    activation=activation,
+                    dropout_probability=dropout_probability,
+                    use_batch_norm=use_batch_norm,
+                )
+                for _ in range(num_blocks)
+            ]
+        )
+        self.final_layer = nn.Linear(hidden_features, out_features)
+
+    def forward(self, inputs, context=None):
+        if context is None:
+            temps = self.initial_layer(inputs)
+        else:
+            temps = self.initial_layer(torch.cat((inputs, context), dim=1))
+        for block in self.blocks:
+            temps = block(temps, context=context)
+        outputs = self.final_layer(temps)
+        return outputs

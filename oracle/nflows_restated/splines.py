@@ -1,0 +1,188 @@
+"""Monotonic rational-quadratic spline (Durkan et al. 2019), CPU restatement.
+
+Test infrastructure only (see ``oracle/__init__.py``).  This is the
+arithmetic behind ``PiecewiseRationalQuadraticCouplingTransform`` which the
+reference instantiates at ``src/nessai/flows/nsf.py:97-108`` with
+``tails="linear"``, ``tail_bound=5.0`` (``nsf.py:74-75``).  Semantics
+restated from the paper and the public nflows API:
+
+* bin widths/heights: ``min + (1 - min*K) * softmax(u)``; knots are the
+  cumulative sums mapped onto ``[left, right]`` with both ends forced exact;
+* derivatives: ``min_derivative + softplus(u_d)``; with linear tails the two
+  boundary derivatives are padded with ``log(exp(1 - min_derivative) - 1)``
+  so that they evaluate to exactly 1;
+* outside ``[-tail_bound, tail_bound]`` the map is the identity, log-det 0;
+* the inverse solves the quadratic with the numerically stable root
+  ``2c / (-b - sqrt(b^2 - 4ac))`` and asserts a non-negative discriminant.
+"""
+
+import numpy as np
+import torch
+from torch.nn import functional as F
+
+from .utils import searchsorted
+
+DEFAULT_MIN_BIN_WIDTH = 1e-3
+DEFAULT_MIN_BIN_HEIGHT = 1e-3
+DEFAULT_MIN_DERIVATIVE = 1e-3
+
+
+class InputOutsideDomain(Exception):
+    """Raised when a bounded spline sees inputs outside its interval."""
+
+
+def unconstrained_rational_quadratic_spline(
+    inputs,
+    unnormalized_widths,
+    unnormalized_heights,
+    unnormalized_derivatives,
+    inverse=False,
+    tails="linear",
+    tail_bound=1.0,
+    min_bin_width=DEFAULT_MIN_BIN_WIDTH,
+    min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
+    min_derivative=DEFAULT_MIN_DERIVATIVE,
+    enable_identity_init=False,
+):
+    inside = (inputs >= -tail_bound) & (inputs <= tail_bound)
+    outside = ~inside
+
+    outputs = torch.zeros_like(inputs)
+    logabsdet = torch.zeros_like(inputs)
+
+    if tails == "linear":
+        unnormalized_derivatives = F.pad(unnormalized_derivatives, pad=(1, 1))
+        constant = np.log(np.exp(1 - min_derivative) - 1)
+        unnormalized_derivatives[..., 0] = constant
+        unnormalized_derivatives[..., -1] = constant
+        outputs[outside] = inputs[outside]
+        logabsdet[outside] = 0
+    else:
+        raise RuntimeError("{} tails are not implemented.".format(tails))
+
+    if torch.any(inside):
+        outputs[inside], logabsdet[inside] = rational_quadratic_spline(
+            inputs=inputs[inside],
+            unnormalized_widths=unnormalized_widths[inside, :],
+            unnormalized_heights=unnormalized_heights[inside, :],
+            unnormalized_derivatives=unnormalized_derivatives[inside, :],
+            inverse=inverse,
+            left=-tail_bound,
+            right=tail_bound,
+            bottom=-tail_bound,
+            top=tail_bound,
+            min_bin_width=min_bin_width,
+            min_bin_height=min_bin_height,
+            min_derivative=min_derivative,
+            enable_identity_init=enable_identity_init,
+        )
+    return outputs, logabsdet
+
+
+def rational_quadratic_spline(
+    inputs,
+    unnormalized_widths,
+    unnormalized_heights,
+    unnormalized_derivatives,
+    inverse=False,
+    left=0.0,
+    right=1.0,
+    bottom=0.0,
+    top=1.0,
+    min_bin_width=DEFAULT_MIN_BIN_WIDTH,
+    min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
+    min_derivative=DEFAULT_MIN_DERIVATIVE,
+    enable_identity_init=False,
+):
+    if torch.min(inputs) < left or torch.max(inputs) > right:
+        raise InputOutsideDomain()
+
+    num_bins = unnormalized_widths.shape[-1]
+    if min_bin_width * num_bins > 1.0:
+        raise ValueError("Minimal bin width too large for the number of bins")
+    if min_bin_height * num_bins > 1.0:
+        raise ValueError("Minimal bin height too large for the number of bins")
+
+    widths = F.softmax(unnormalized_widths, dim=-1)
+    widths = min_bin_width + (1 - min_bin_width * num_bins) * widths
+    cumwidths = torch.cumsum(widths, dim=-1)
+    cumwidths = F.pad(cumwidths, pad=(1, 0), mode="constant", value=0.0)
+    cumwidths = (right - left) * cumwidths + left
+    cumwidths[..., 0] = left
+    cumwidths[..., -1] = right
+    widths = cumwidths[..., 1:] - cumwidths[..., :-1]
+
+    if enable_identity_init:
+        beta = np.log(2) / (1 - min_derivative)
+    else:
+        beta = 1
+    derivatives = min_derivative + F.softplus(unnormalized_derivatives, beta=beta)
+
+    heights = F.softmax(unnormalized_heights, dim=-1)
+    heights = min_bin_height + (1 - min_bin_height * num_bins) * heights
+    cumheights = torch.cumsum(heights, dim=-1)
+    cumheights = F.pad(cumheights, pad=(1, 0), mode="constant", value=0.0)
+    cumheights = (top - bottom) * cumheights + bottom
+    cumheights[..., 0] = bottom
+    cumheights[..., -1] = top
+    heights = cumheights[..., 1:] - cumheights[..., :-1]
+
+    if inverse:
+        bin_idx = searchsorted(cumheights, inputs)[..., None]
+    else:
+        bin_idx = searchsorted(cumwidths, inputs)[..., None]
+
+    input_cumwidths = cumwidths.gather(-1, bin_idx)[..., 0]
+    input_bin_widths = widths.gather(-1, bin_idx)[..., 0]
+
+    input_cumheights = cumheights.gather(-1, bin_idx)[..., 0]
+    delta = heights / widths
+    input_delta = delta.gather(-1, bin_idx)[..., 0]
+
+    input_derivatives = derivatives.gather(-1, bin_idx)[..., 0]
+    input_derivatives_plus_one = derivatives[..., 1:].gather(-1, bin_idx)[..., 0]
+
+    input_heights = heights.gather(-1, bin_idx)[..., 0]
+
+    if inverse:
+        shifted = inputs - input_cumheights
+        curvature = input_derivatives + input_derivatives_plus_one - 2 * input_delta
+        a = shifted * curvature + input_heights * (input_delta - input_derivatives)
+        b = input_heights * input_derivatives - shifted * curvature
+        c = -input_delta * shifted
+
+        discriminant = b.pow(2) - 4 * a * c
+        assert (discriminant >= 0).all()
+
+        root = (2 * c) / (-b - torch.sqrt(discriminant))
+        outputs = root * input_bin_widths + input_cumwidths
+
+        theta_one_minus_theta = root * (1 - root)
+        denominator = input_delta + curvature * theta_one_minus_theta
+        derivative_numerator = input_delta.pow(2) * (
+            input_derivatives_plus_one * root.pow(2)
+            + 2 * input_delta * theta_one_minus_theta
+            + input_derivatives * (1 - root).pow(2)
+        )
+        logabsdet = torch.log(derivative_numerator) - 2 * torch.log(denominator)
+        return outputs, -logabsdet
+    else:
+        theta = (inputs - input_cumwidths) / input_bin_widths
+        theta_one_minus_theta = theta * (1 - theta)
+
+        numerator = input_heights * (
+            input_delta * theta.pow(2) + input_derivatives * theta_one_minus_theta
+        )
+        denominator = input_delta + (
+            (input_derivatives + input_derivatives_plus_one - 2 * input_delta)
+            * theta_one_minus_theta
+        )
+        outputs = input_cumheights + numerator / denominator
+
+        derivative_numerator = input_delta.pow(2) * (
+            input_derivatives_plus_one * theta.pow(2)
+            + 2 * input_delta * theta_one_minus_theta
+            + input_derivatives * (1 - theta).pow(2)
+        )
+        logabsdet = torch.log(derivative_numerator) - 2 * torch.log(denominator)
+        return outputs, logabsdet
