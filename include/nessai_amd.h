@@ -1,0 +1,144 @@
+/* nessai_amd — C ABI of the MI355X (gfx950) normalising-flow proposal library.
+ *
+ * The reference (mj-will/nessai) has no native code and no FFI: its hot path is
+ * eager PyTorch called through three Python plug-in surfaces.
+ * This header is the C boundary the build adds underneath those surfaces.  Each
+ * entry point names the reference interface whose work it replaces; paths are
+ * relative to the reference tree.  All pointers named *_dev are device (HBM)
+ * pointers, everything else is host memory.  Outputs are caller-allocated.
+ * Every function returns 0 on success and a negative NSA_E_* code otherwise
+ * (nsa_last_error() gives the message); a per-row domain failure inside the
+ * spline inverse never aborts — the row is flagged (NaN log_q / status counter).
+ *
+ * INTEGRATION.md shows the ctypes binding a maintainer would add on the
+ * reference side.
+ */
+#ifndef NESSAI_AMD_H
+#define NESSAI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSA_OK 0
+#define NSA_E_ARG (-1)       /* bad argument / unsupported configuration */
+#define NSA_E_HIP (-2)       /* HIP runtime error */
+#define NSA_E_IMAGE (-3)     /* malformed flow image */
+
+#define NSA_HEADER_WORDS 32
+
+#define NSA_API __attribute__((visibility("default")))
+
+/* Library / ABI version (NSA_VERSION of the flow image format). */
+NSA_API int nsa_version(void);
+
+/* Message of the last failing call on this thread. */
+NSA_API const char* nsa_last_error(void);
+
+/* 1 if a kernel instance exists for this configuration (hidden tiles HT,
+ * transform kind NSA_T_*, spline bins), else 0.  Lets the Python flow classes
+ * reject unsupported constructor arguments up front
+ * (src/nessai/flows/utils.py:208-246, configure_model). */
+NSA_API int nsa_flow_supported(int hidden_tiles, int transform, int bins);
+
+/* Run a whole flow over n rows.
+ *
+ * Replaces NFlow.forward / NFlow.inverse / NFlow.log_prob /
+ * NFlow.forward_and_log_prob (src/nessai/flows/base.py:209-273) and under them
+ * glasflow.nflows' CompositeTransform of RandomPermutation / LULinear /
+ * {Affine,Additive,PiecewiseRationalQuadratic}CouplingTransform / BatchNorm
+ * (call sites src/nessai/flows/realnvp.py:186-213, src/nessai/flows/nsf.py:110-128).
+ *
+ *   header     first NSA_HEADER_WORDS words of the flow image (host copy)
+ *   image_dev  the flow image in HBM (built by nessai_amd.pack)
+ *   direction  0 forward (x -> z), 1 inverse (z -> x)
+ *   mode       0: x_out = T(x_in), ld_out = log|det J|
+ *              1: x_out = z (may be NULL), ld_out = log_prob(x_in)   [direction 0]
+ *   x_in_dev   [n][D] float32 row-major
+ *   x_out_dev  [n][D] float32 or NULL
+ *   ld_out_dev [n] float32 or NULL
+ *   status_dev int32[4]; [0] += rows whose spline inverse hit a negative
+ *              discriminant (nflows asserts; flowproposal.py:357-364 drops the batch)
+ *   waves_per_group  waves (32-row tiles) per workgroup, 0 = default
+ *   max_groups       grid cap, 0 = default
+ *   stream     hipStream_t
+ */
+NSA_API int nsa_flow_run(const uint32_t* header, const void* image_dev, int direction, int mode,
+                 long long n, const float* x_in_dev, float* x_out_dev, float* ld_out_dev,
+                 int* status_dev, int waves_per_group, int max_groups, void* stream);
+
+/* Fused draw -> truncate -> inverse flow -> inverse z-score -> prior bounds -> log_q.
+ *
+ * Replaces one pass of the body of FlowProposal.populate up to compute_weights
+ * (src/nessai/proposal/flowproposal/flowproposal.py:431-447), i.e.
+ * sample_latent_distribution (proposal/flowproposal/base.py:393-399),
+ * LatentRadiusTruncation.apply_latent (truncation.py:358-365),
+ * FlowProposal.backward_pass (flowproposal.py:345-389) with
+ * FlowModel.inverse (src/nessai/flowmodel/base.py:813-840),
+ * latent_log_prob (proposal/flowproposal/base.py:401-414),
+ * ScaleAndShift.inverse_reparameterise (reparameterisations/rescale.py:263-291)
+ * and Model.in_bounds (src/nessai/model.py:512-518).
+ *
+ *   z_in_dev    [n][D] float32 latents to use, or NULL to draw them on-device
+ *               with Philox4x32-10(seed; counter = row_offset + row, quad)
+ *   radius      keep rows with ||z||_2 <= radius (float64 compare)
+ *   scale/shift [D] float64 z-score sigma / mu        (x = x' * sigma + mu)
+ *   lower/upper [D] float64 prior bounds
+ *   log_j_rescale  sum_i log|sigma_i| accumulated in the reference's order
+ *   x64_out_dev [n][D] float64 samples in the physical space
+ *   log_q_out_dev [n] float64 log proposal density; NaN marks a dropped row
+ *               (outside radius / non-finite / out of bounds / spline failure)
+ *   z_out_dev   [n][D] float32 or NULL
+ */
+NSA_API int nsa_populate_draw(const uint32_t* header, const void* image_dev, long long n,
+                      const float* z_in_dev, unsigned long long seed,
+                      unsigned long long row_offset, double radius, const double* scale_dev,
+                      const double* shift_dev, const double* lower_dev, const double* upper_dev,
+                      double log_j_rescale, double* x64_out_dev, double* log_q_out_dev,
+                      float* z_out_dev, int* status_dev, int waves_per_group, int max_groups,
+                      void* stream);
+
+/* log_w = log_prior - log_q and its maximum.
+ *
+ * Replaces BaseFlowProposal.compute_weights (proposal/flowproposal/base.py:1069-1098)
+ * and `log_w.max()` (flowproposal.py:492).  log_prior_dev may be NULL, in which
+ * case log_prior_const is used for every kept row (uniform box priors).
+ * Dropped rows (NaN log_q) get log_w = -inf.  max_key_dev is an int64 holding
+ * the running maximum in a sign-magnitude-ordered encoding (initialise with
+ * nsa_max_key_init(); atomically updated, so several calls / shards accumulate).
+ */
+NSA_API int nsa_populate_weights(long long n, const double* log_q_dev, const double* log_prior_dev,
+                         double log_prior_const, double* log_w_dev, long long* max_key_dev,
+                         void* stream);
+NSA_API long long nsa_max_key_init(void);
+NSA_API long long nsa_max_key_encode(double v);
+NSA_API double nsa_max_key_decode(long long key);
+
+/* Rejection step + order-preserving compaction.
+ *
+ * Replaces `log_w -= log_w.max(); log_u = log(rng.random(n)); accept = log_w > log_u;
+ * samples[...] = x[accept][:m]` (flowproposal.py:492-498).
+ *
+ *   max_key_dev  encoded global maximum (after any cross-rank all-reduce)
+ *   u_in_dev     [n] float64 uniforms to use, or NULL to draw them on-device
+ *                (Philox stream 1, counter = row_offset + row)
+ *   capacity     rows available in x_acc_dev / idx_acc_dev
+ *   x_acc_dev    [capacity][D] float64: accepted rows, in draw order
+ *   idx_acc_dev  [capacity] int64 source row of each accepted row (may be NULL)
+ *   n_accept_dev int64[1]: total accepted (can exceed capacity)
+ *   workspace_dev / workspace_bytes   scratch, >= nsa_populate_accept_workspace(n)
+ */
+NSA_API size_t nsa_populate_accept_workspace(long long n);
+NSA_API int nsa_populate_accept(long long n, int D, const double* log_w_dev, const long long* max_key_dev,
+                        unsigned long long seed, unsigned long long row_offset,
+                        const double* u_in_dev, const double* x64_dev, long long capacity,
+                        double* x_acc_dev, long long* idx_acc_dev, long long* n_accept_dev,
+                        void* workspace_dev, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NESSAI_AMD_H */

@@ -1,0 +1,234 @@
+// C-ABI entry points (include/nessai_amd.h) and kernel dispatch.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/nessai_amd.h"
+#include "nsa_flow_kernel.h"
+
+// ---------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------
+
+static thread_local char g_err[512] = "";
+
+static int nsa_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* nsa_last_error(void) { return g_err; }
+extern "C" int nsa_version(void) { return NSA_VERSION; }
+
+// ---------------------------------------------------------------------------
+// kernel instance table (objects built from nsa_flow_inst.hip by the Makefile;
+// NSA_INSTANCES is generated there as X(ht, kind, bins) entries)
+// ---------------------------------------------------------------------------
+
+typedef hipError_t (*nsa_launch_fn)(const NsaLaunch*, unsigned, unsigned, size_t, hipStream_t);
+
+#define X(ht, kind, bins) \
+  extern "C" hipError_t nsa_launch_h##ht##_t##kind##_k##bins(const NsaLaunch*, unsigned, unsigned, size_t, hipStream_t);
+NSA_INSTANCES
+#undef X
+
+struct NsaInstance {
+  int ht, kind, bins;
+  nsa_launch_fn fn;
+};
+
+static const NsaInstance g_instances[] = {
+#define X(ht, kind, bins) {ht, kind, bins, nsa_launch_h##ht##_t##kind##_k##bins},
+    NSA_INSTANCES
+#undef X
+};
+
+static nsa_launch_fn nsa_find(int ht, int kind, int bins) {
+  if (kind != NSA_T_RQ) bins = 0;
+  for (size_t i = 0; i < sizeof(g_instances) / sizeof(g_instances[0]); ++i)
+    if (g_instances[i].ht == ht && g_instances[i].kind == kind && g_instances[i].bins == bins)
+      return g_instances[i].fn;
+  return nullptr;
+}
+
+extern "C" int nsa_flow_supported(int hidden_tiles, int transform, int bins) {
+  return nsa_find(hidden_tiles, transform, bins) != nullptr ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// launch geometry
+// ---------------------------------------------------------------------------
+
+static int g_num_cus = 0;
+static size_t g_max_lds = 0;
+
+static int nsa_device_info(void) {
+  if (g_num_cus > 0) return NSA_OK;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  g_num_cus = prop.multiProcessorCount;
+  g_max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
+  return NSA_OK;
+}
+
+static int nsa_check_header(const uint32_t* h) {
+  if (h == nullptr) return nsa_fail(NSA_E_ARG, "header is NULL");
+  if (h[NSA_H_MAGIC] != NSA_MAGIC) return nsa_fail(NSA_E_IMAGE, "bad flow image magic 0x%08x", h[NSA_H_MAGIC]);
+  if (h[NSA_H_VERSION] != NSA_VERSION)
+    return nsa_fail(NSA_E_IMAGE, "flow image version %u, library expects %d", h[NSA_H_VERSION], NSA_VERSION);
+  if (h[NSA_H_D] < 2 || h[NSA_H_D] > 1024) return nsa_fail(NSA_E_IMAGE, "unsupported feature count %u", h[NSA_H_D]);
+  if ((h[NSA_H_MAX_STAGE] & 255u) != 0) return nsa_fail(NSA_E_IMAGE, "stage size not a multiple of 256 words");
+  return NSA_OK;
+}
+
+static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group, int max_groups,
+                           hipStream_t stream) {
+  int rc = nsa_check_header(h);
+  if (rc != NSA_OK) return rc;
+  rc = nsa_device_info();
+  if (rc != NSA_OK) return rc;
+  if (p.n < 0) return nsa_fail(NSA_E_ARG, "negative row count");
+  if (p.n == 0) return NSA_OK;
+  nsa_launch_fn fn = nsa_find((int)h[NSA_H_HT], (int)h[NSA_H_TRANSFORM], (int)h[NSA_H_BINS]);
+  if (fn == nullptr)
+    return nsa_fail(NSA_E_ARG, "no kernel instance for hidden_tiles=%u transform=%u bins=%u",
+                    h[NSA_H_HT], h[NSA_H_TRANSFORM], h[NSA_H_BINS]);
+  const int D = (int)h[NSA_H_D];
+  const int XS = D | 1;
+  const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
+  int nw = waves_per_group > 0 ? waves_per_group : 4;
+  if (nw > 8) nw = 8;
+  // small batches: fewer waves per workgroup so that more CUs take part
+  while (nw > 1 && n_tiles < (long long)nw * g_num_cus) nw >>= 1;
+  size_t lds = 0;
+  for (;;) {
+    const size_t tiles_words = ((size_t)nw * NSA_ROWS * XS + 3) & ~(size_t)3;
+    lds = (tiles_words + 2 * (size_t)h[NSA_H_MAX_STAGE]) * 4;
+    if (lds <= g_max_lds || nw == 1) break;
+    nw >>= 1;
+  }
+  if (lds > g_max_lds)
+    return nsa_fail(NSA_E_ARG, "flow needs %zu bytes of LDS per workgroup (> %zu)", lds, g_max_lds);
+  const long long n_groups = (n_tiles + nw - 1) / nw;
+  long long per_cu = (long long)(g_max_lds / lds);
+  const long long by_waves = 8 / nw;  // 2 waves per SIMD
+  if (per_cu > by_waves) per_cu = by_waves;
+  if (per_cu < 1) per_cu = 1;
+  long long grid = per_cu * g_num_cus;
+  if (max_groups > 0 && grid > max_groups) grid = max_groups;
+  if (grid > n_groups) grid = n_groups;
+  hipError_t e = fn(&p, (unsigned)grid, (unsigned)(nw * 64), lds, stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "flow kernel launch: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// entry points
+// ---------------------------------------------------------------------------
+
+extern "C" int nsa_flow_run(const uint32_t* header, const void* image_dev, int direction, int mode,
+                            long long n, const float* x_in_dev, float* x_out_dev, float* ld_out_dev,
+                            int* status_dev, int waves_per_group, int max_groups, void* stream) {
+  if (image_dev == nullptr || x_in_dev == nullptr || status_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run: NULL image / input / status pointer");
+  if (direction != NSA_DIR_FORWARD && direction != NSA_DIR_INVERSE)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run: direction must be 0 or 1");
+  if (mode != NSA_MODE_APPLY && mode != NSA_MODE_LOGPROB)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run: mode must be 0 (apply) or 1 (log_prob)");
+  if (mode == NSA_MODE_LOGPROB && direction != NSA_DIR_FORWARD)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run: log_prob needs the forward direction");
+  NsaLaunch p;
+  memset(&p, 0, sizeof(p));
+  p.image = (const uint32_t*)image_dev;
+  p.direction = direction;
+  p.mode = mode;
+  p.n = n;
+  p.x_in = x_in_dev;
+  p.x_out = x_out_dev;
+  p.ld_out = ld_out_dev;
+  p.status = status_dev;
+  return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
+}
+
+extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, long long n,
+                                 const float* z_in_dev, unsigned long long seed,
+                                 unsigned long long row_offset, double radius,
+                                 const double* scale_dev, const double* shift_dev,
+                                 const double* lower_dev, const double* upper_dev,
+                                 double log_j_rescale, double* x64_out_dev, double* log_q_out_dev,
+                                 float* z_out_dev, int* status_dev, int waves_per_group,
+                                 int max_groups, void* stream) {
+  if (image_dev == nullptr || scale_dev == nullptr || shift_dev == nullptr || lower_dev == nullptr ||
+      upper_dev == nullptr || x64_out_dev == nullptr || log_q_out_dev == nullptr || status_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_draw: NULL pointer argument");
+  NsaLaunch p;
+  memset(&p, 0, sizeof(p));
+  p.image = (const uint32_t*)image_dev;
+  p.direction = NSA_DIR_INVERSE;
+  p.mode = NSA_MODE_POPULATE;
+  p.n = n;
+  p.x_in = z_in_dev;
+  p.status = status_dev;
+  p.seed = seed;
+  p.row_offset = row_offset;
+  p.radius = radius;
+  p.scale = scale_dev;
+  p.shift = shift_dev;
+  p.lower = lower_dev;
+  p.upper = upper_dev;
+  p.log_j_rescale = log_j_rescale;
+  p.x64_out = x64_out_dev;
+  p.log_q_out = log_q_out_dev;
+  p.z_out = z_out_dev;
+  return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
+}
+
+extern "C" hipError_t nsa_launch_weights(long long, const double*, const double*, double, double*,
+                                         long long*, hipStream_t);
+extern "C" size_t nsa_accept_workspace_bytes(long long);
+extern "C" hipError_t nsa_launch_accept(long long, int, const double*, const long long*,
+                                        unsigned long long, unsigned long long, const double*,
+                                        const double*, long long, double*, long long*, long long*,
+                                        void*, hipStream_t);
+
+extern "C" int nsa_populate_weights(long long n, const double* log_q_dev, const double* log_prior_dev,
+                                    double log_prior_const, double* log_w_dev, long long* max_key_dev,
+                                    void* stream) {
+  if (n < 0 || log_q_dev == nullptr || log_w_dev == nullptr || max_key_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_weights: bad argument");
+  hipError_t e = nsa_launch_weights(n, log_q_dev, log_prior_dev, log_prior_const, log_w_dev, max_key_dev,
+                                    (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "weights kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+extern "C" size_t nsa_populate_accept_workspace(long long n) {
+  return nsa_accept_workspace_bytes(n < 0 ? 0 : n);
+}
+
+extern "C" int nsa_populate_accept(long long n, int D, const double* log_w_dev,
+                                   const long long* max_key_dev, unsigned long long seed,
+                                   unsigned long long row_offset, const double* u_in_dev,
+                                   const double* x64_dev, long long capacity, double* x_acc_dev,
+                                   long long* idx_acc_dev, long long* n_accept_dev,
+                                   void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (n < 0 || D < 1 || log_w_dev == nullptr || max_key_dev == nullptr || x64_dev == nullptr ||
+      x_acc_dev == nullptr || n_accept_dev == nullptr || workspace_dev == nullptr || capacity < 0)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_accept: bad argument");
+  if (workspace_bytes < nsa_accept_workspace_bytes(n))
+    return nsa_fail(NSA_E_ARG, "nsa_populate_accept: workspace too small (%zu < %zu)", workspace_bytes,
+                    nsa_accept_workspace_bytes(n));
+  hipError_t e = nsa_launch_accept(n, D, log_w_dev, max_key_dev, seed, row_offset, u_in_dev, x64_dev,
+                                   capacity, x_acc_dev, idx_acc_dev, n_accept_dev, workspace_dev,
+                                   (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "accept kernels: %s", hipGetErrorString(e));
+  return NSA_OK;
+}

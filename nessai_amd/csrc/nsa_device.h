@@ -1,0 +1,264 @@
+// Device-side building blocks for the gfx950 flow kernels.
+//
+// Wave-level data layout (one wave = one 32-row tile, wave64):
+//   lane = 32*half + j  ->  batch row j of the tile, "half" selects which of
+//   the two k-slots / output-feature groups of the 32x32x2 f32 MFMA the lane
+//   holds.  v_mfma_f32_32x32x2_f32 computes D[i][j] += sum_k A[i][k]*B[k][j]
+//   with A[i][k] in lane 32*k+i, B[k][j] in lane 32*k+j and D[i][j] in lane
+//   32*((i>>2)&1) + j, register (i&3) + 4*(i>>3).  Because the D layout of one
+//   layer is exactly a valid B layout for the next (with the k order permuted,
+//   which the host bakes into the packed weights), conditioner activations
+//   never leave registers between layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nsa_format.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NSA_ROWS 32  // rows per wave tile
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float nsa_bits_to_float(uint32_t u) { return __uint_as_float(u); }
+
+__device__ __forceinline__ f32x16 nsa_mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// activation of the conditioner (src/nessai/flows/utils.py:200-205)
+__device__ __forceinline__ float nsa_act(float x, int kind) {
+  if (kind == NSA_ACT_RELU) return fmaxf(x, 0.0f);
+  if (kind == NSA_ACT_TANH) return tanhf(x);
+  return x * (1.0f / (1.0f + expf(-x)));  // silu: x * sigmoid(x)
+}
+
+// Async global -> LDS copy of one 1 KiB piece per wave instruction
+// (global_load_lds_dwordx4: LDS destination = wave-uniform base + lane*16).
+__device__ __forceinline__ void nsa_glds16(const uint32_t* gsrc_lane, float* lds_base_uniform) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc_lane,
+      (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator (Salmon et al. 2011) + Box-Muller.
+// Counter = (global row lo, global row hi, quad index, stream); key = seed.
+// The same function is restated in numpy in oracle/philox.py for the tests.
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ void nsa_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                  uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// u32 -> float in (0, 1]: (x + 0.5) * 2^-32 evaluated in f32
+__device__ __forceinline__ float nsa_u01(uint32_t x) {
+  return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+}
+
+// two u32 -> two standard normals
+__device__ __forceinline__ void nsa_box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+  const float u1 = nsa_u01(a), u2 = nsa_u01(b);
+  const float r = sqrtf(-2.0f * logf(u1));
+  float s, c;
+  sincospif(2.0f * u2, &s, &c);
+  n0 = r * c;
+  n1 = r * s;
+}
+
+// ---------------------------------------------------------------------------
+// Element-wise coupling transforms (one feature of one row per call).
+// Policies expose: C (MFMA tiles per chunk), FPC (features per lane per
+// chunk), NP (parameters per feature) and apply().
+// ---------------------------------------------------------------------------
+
+struct NsaTransformConsts {
+  float tail_bound, two_b;          // B and (right - left) = 2B
+  float min_bw, bw_scale;           // min_bin_width, 1 - min_bin_width*K
+  float min_bh, bh_scale;
+  float min_d, edge_raw;            // min_derivative, log(exp(1-min_d)-1)
+  float logit_div;                  // sqrt(hidden_features) or 1
+};
+
+__device__ __forceinline__ float nsa_softplus(float x) {
+  // F.softplus(x, beta=1, threshold=20)
+  return (x > 20.0f) ? x : log1pf(expf(x));
+}
+
+// Monotonic rational-quadratic spline with linear tails.  Restates the
+// arithmetic of oracle/nflows_restated/splines.py (same operation order, no
+// FMA contraction) for one scalar input.
+//   v[0..K)      unnormalised widths
+//   v[K..2K)     unnormalised heights
+//   v[2K..3K-1)  unnormalised interior derivatives
+template <int K>
+struct NsaRQ {
+  static constexpr int NP = 3 * K - 1;
+  static constexpr int FPC = (K == 8) ? 2 : 1;
+  static constexpr int C = (FPC * NP + 15) / 16;
+  static constexpr int KIND = NSA_T_RQ;
+
+  template <int OFF, int NV>
+  __device__ __forceinline__ static void apply(const float (&v)[NV], float x, bool inverse,
+                                               const NsaTransformConsts& c, float& y, float& ld,
+                                               bool& bad) {
+#pragma clang fp contract(off)
+    const float B = c.tail_bound;
+    const bool inside = (x >= -B) && (x <= B);
+    const float xin = inside ? x : 0.0f;
+
+    float cw[K + 1], ch[K + 1], dv[K + 1];
+    {
+      float u[K];
+      float m = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < K; ++i) { u[i] = v[OFF + i] / c.logit_div; m = fmaxf(m, u[i]); }
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < K; ++i) { u[i] = expf(u[i] - m); s += u[i]; }
+      float run = 0.0f;
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        const float w = c.min_bw + c.bw_scale * (u[i] / s);
+        run = run + w;
+        cw[i + 1] = c.two_b * run + (-B);
+      }
+      cw[0] = -B;
+      cw[K] = B;
+    }
+    {
+      float u[K];
+      float m = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < K; ++i) { u[i] = v[OFF + K + i] / c.logit_div; m = fmaxf(m, u[i]); }
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < K; ++i) { u[i] = expf(u[i] - m); s += u[i]; }
+      float run = 0.0f;
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        const float h = c.min_bh + c.bh_scale * (u[i] / s);
+        run = run + h;
+        ch[i + 1] = c.two_b * run + (-B);
+      }
+      ch[0] = -B;
+      ch[K] = B;
+    }
+    dv[0] = c.min_d + nsa_softplus(c.edge_raw);
+    dv[K] = dv[0];
+#pragma unroll
+    for (int i = 1; i < K; ++i) dv[i] = c.min_d + nsa_softplus(v[OFF + 2 * K + i - 1]);
+
+    // searchsorted with the last knot nudged by 1e-6
+    int bin = -1;
+#pragma unroll
+    for (int i = 0; i <= K; ++i) {
+      const float base = inverse ? ch[i] : cw[i];
+      const float kn = (i == K) ? (base + 1e-6f) : base;
+      bin += (xin >= kn) ? 1 : 0;
+    }
+    bin = min(max(bin, 0), K - 1);
+
+    float in_cw = cw[0], in_cw1 = cw[1], in_ch = ch[0], in_ch1 = ch[1], in_d = dv[0], in_d1 = dv[1];
+#pragma unroll
+    for (int i = 1; i < K; ++i) {
+      const bool sel = (bin == i);
+      in_cw = sel ? cw[i] : in_cw;
+      in_cw1 = sel ? cw[i + 1] : in_cw1;
+      in_ch = sel ? ch[i] : in_ch;
+      in_ch1 = sel ? ch[i + 1] : in_ch1;
+      in_d = sel ? dv[i] : in_d;
+      in_d1 = sel ? dv[i + 1] : in_d1;
+    }
+    const float in_w = in_cw1 - in_cw;
+    const float in_h = in_ch1 - in_ch;
+    const float delta = in_h / in_w;
+    const float curv = (in_d + in_d1) - 2.0f * delta;
+
+    float out, lad;
+    if (inverse) {
+      const float sh = xin - in_ch;
+      const float a = sh * curv + in_h * (delta - in_d);
+      const float b = in_h * in_d - sh * curv;
+      const float cc = -delta * sh;
+      const float disc = b * b - 4.0f * a * cc;
+      bad = inside && !(disc >= 0.0f);
+      const float root = (2.0f * cc) / (-b - sqrtf(disc));
+      out = root * in_w + in_cw;
+      const float tomt = root * (1.0f - root);
+      const float den = delta + curv * tomt;
+      const float omr = 1.0f - root;
+      const float dnum = (delta * delta) * ((in_d1 * (root * root) + (2.0f * delta) * tomt) + in_d * (omr * omr));
+      lad = -(logf(dnum) - 2.0f * logf(den));
+    } else {
+      bad = false;
+      const float theta = (xin - in_cw) / in_w;
+      const float tomt = theta * (1.0f - theta);
+      const float num = in_h * (delta * (theta * theta) + in_d * tomt);
+      const float den = delta + curv * tomt;
+      out = in_ch + num / den;
+      const float omt = 1.0f - theta;
+      const float dnum = (delta * delta) * ((in_d1 * (theta * theta) + (2.0f * delta) * tomt) + in_d * (omt * omt));
+      lad = logf(dnum) - 2.0f * logf(den);
+    }
+    y = inside ? out : x;
+    ld = inside ? lad : 0.0f;
+  }
+};
+
+// Affine coupling: scale = sigmoid(raw + 2) + 1e-3 (nflows default
+// scale_activation).  v[OFF] = shift, v[OFF+1] = raw scale.
+struct NsaAffine {
+  static constexpr int NP = 2;
+  static constexpr int FPC = 8;
+  static constexpr int C = 1;
+  static constexpr int KIND = NSA_T_AFFINE;
+
+  template <int OFF, int NV>
+  __device__ __forceinline__ static void apply(const float (&v)[NV], float x, bool inverse,
+                                               const NsaTransformConsts&, float& y, float& ld,
+                                               bool& bad) {
+#pragma clang fp contract(off)
+    const float shift = v[OFF];
+    const float raw = v[OFF + 1] + 2.0f;
+    const float scale = 1.0f / (1.0f + expf(-raw)) + 1e-3f;
+    const float ls = logf(scale);
+    bad = false;
+    if (inverse) { y = (x - shift) / scale; ld = -ls; }
+    else { y = x * scale + shift; ld = ls; }
+  }
+};
+
+// Additive (volume preserving) coupling: shift only.
+struct NsaAdditive {
+  static constexpr int NP = 1;
+  static constexpr int FPC = 16;
+  static constexpr int C = 1;
+  static constexpr int KIND = NSA_T_ADDITIVE;
+
+  template <int OFF, int NV>
+  __device__ __forceinline__ static void apply(const float (&v)[NV], float x, bool inverse,
+                                               const NsaTransformConsts&, float& y, float& ld,
+                                               bool& bad) {
+#pragma clang fp contract(off)
+    bad = false;
+    ld = 0.0f;
+    // scale == 1: x * 1 + shift and (x - shift) / 1 are exact
+    y = inverse ? (x - v[OFF]) : (x + v[OFF]);
+  }
+};

@@ -1,0 +1,33 @@
+// One instantiation of the fused flow kernel, selected at compile time:
+//   -DNSA_HT=<hidden tiles> -DNSA_TKIND=<NSA_T_*> -DNSA_BINS=<K or 0>
+// The Makefile builds the supported matrix as separate objects (parallel
+// compile); nsa_api.hip dispatches on the flow image header.
+#include "nsa_flow_kernel.h"
+
+#if !defined(NSA_HT) || !defined(NSA_TKIND) || !defined(NSA_BINS)
+#error "NSA_HT, NSA_TKIND and NSA_BINS must be defined"
+#endif
+
+#if NSA_TKIND == 1
+using TP = NsaRQ<NSA_BINS>;
+#elif NSA_TKIND == 2
+using TP = NsaAffine;
+#elif NSA_TKIND == 3
+using TP = NsaAdditive;
+#else
+#error "unknown NSA_TKIND"
+#endif
+
+#define NSA_CAT_(a, b, c, d, e, f) a##b##c##d##e##f
+#define NSA_CAT(a, b, c, d, e, f) NSA_CAT_(a, b, c, d, e, f)
+#define NSA_LAUNCH_NAME NSA_CAT(nsa_launch_h, NSA_HT, _t, NSA_TKIND, _k, NSA_BINS)
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t NSA_LAUNCH_NAME(
+    const NsaLaunch* p, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
+  auto kern = nsa_flow_kernel<NSA_HT, TP>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, *p);
+  return hipGetLastError();
+}

@@ -1,0 +1,534 @@
+// Fused normalising-flow kernel for gfx950 (MI355X).
+//
+// One launch runs the WHOLE flow (every coupling layer, LU-linear and
+// batch-norm transform) over a batch of rows, in either direction, with one
+// of three epilogues:
+//   mode APPLY    : x_out = T(x_in) (or T^-1), ld_out = log|det J|
+//                   (reference: NFlow.forward / NFlow.inverse,
+//                    src/nessai/flows/base.py:209-221)
+//   mode LOGPROB  : forward + base log-density
+//                   (NFlow.log_prob / forward_and_log_prob, base.py:236-273)
+//   mode POPULATE : latent draw (Philox) or injected latents -> radius
+//                   truncation -> inverse flow -> z-score inverse -> prior
+//                   bounds -> log_q, in float64 where the reference's glue is
+//                   float64 (FlowProposal.populate / backward_pass,
+//                   src/nessai/proposal/flowproposal/flowproposal.py:345-389,
+//                   431-447; truncation.py:358-365; rescale.py:263-291;
+//                   model.py:512-518)
+//
+// Work decomposition: a workgroup of NW waves; each wave owns a 32-row tile
+// whose D features live in a private LDS tile for the whole flow.  The
+// conditioner MLP of every coupling layer runs on v_mfma_f32_32x32x2_f32
+// with activations held in registers between layers; the weights of the
+// current layer are staged global(L2) -> LDS with global_load_lds,
+// double-buffered one layer ahead, and shared by all waves of the workgroup.
+// The spline / affine element-wise transform consumes the conditioner output
+// straight from the MFMA accumulators (the host permutes the rows of the last
+// layer so that every lane receives complete parameter sets).
+#pragma once
+#include <utility>
+
+#include "nsa_device.h"
+
+enum { NSA_MODE_APPLY = 0, NSA_MODE_LOGPROB = 1, NSA_MODE_POPULATE = 2 };
+
+struct NsaLaunch {
+  const uint32_t* image;  // device flow image (nsa_format.h)
+  int direction;          // NSA_DIR_*
+  int mode;               // NSA_MODE_*
+  long long n;            // rows
+  const float* x_in;      // [n][D] or null (POPULATE: null -> draw with Philox)
+  float* x_out;           // [n][D] or null
+  float* ld_out;          // [n] logabsdet (APPLY) / log_prob (LOGPROB) or null
+  int* status;            // int[4]: [0] rows with a negative spline discriminant
+  // POPULATE
+  unsigned long long seed;
+  unsigned long long row_offset;  // global index of row 0 (sharded draws)
+  double radius;                  // keep ||z|| <= radius
+  const double* scale;            // [D] z-score sigma
+  const double* shift;            // [D] z-score mu
+  const double* lower;            // [D] prior bounds
+  const double* upper;            // [D]
+  double log_j_rescale;           // sum log|sigma| accumulated as the reference does
+  double* x64_out;                // [n][D]
+  double* log_q_out;              // [n]; NaN marks a dropped row
+  float* z_out;                   // [n][D] or null
+};
+
+// double-buffered weight-stage pipeline -------------------------------------
+
+struct NsaStagePipe {
+  const uint32_t* img;
+  const uint32_t* table;  // {src word offset, n words} per stage
+  int n_stages;
+  float* buf0;
+  float* buf1;
+  int cur;      // stage index within the program
+  int parity;   // LDS buffer holding stage `cur`
+  int wave, nw, lane;
+
+  __device__ __forceinline__ void issue(int s, float* dst) {
+    const uint32_t off = table[2 * s], words = table[2 * s + 1];
+    const uint32_t* src = img + off;
+    const int pieces = (int)(words >> 8);
+    for (int c = wave; c < pieces; c += nw) nsa_glds16(src + c * 256 + lane * 4, dst + c * 256);
+  }
+  // first stage of the program for this workgroup
+  __device__ __forceinline__ void prime() {
+    cur = 0;
+    parity = 0;
+    issue(0, buf0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // current stage's data; prefetches the next stage (wrapping to stage 0 for
+  // the workgroup's next tile group)
+  __device__ __forceinline__ const float* begin() {
+    const int nxt = (cur + 1 == n_stages) ? 0 : cur + 1;
+    issue(nxt, parity ? buf0 : buf1);
+    return parity ? buf1 : buf0;
+  }
+  __device__ __forceinline__ void end() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur = (cur + 1 == n_stages) ? 0 : cur + 1;
+    parity ^= 1;
+  }
+};
+
+// dense layers on MFMA --------------------------------------------------------
+
+// acc[ot] = bias; lane reads its 16 biases for each output tile
+template <int OT>
+__device__ __forceinline__ void nsa_load_bias(const float* bias, int half, f32x16 (&acc)[OT]) {
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+    const f32x4* b = (const f32x4*)(bias + ot * 32 + half * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 t = b[q];
+      acc[ot][4 * q + 0] = t[0];
+      acc[ot][4 * q + 1] = t[1];
+      acc[ot][4 * q + 2] = t[2];
+      acc[ot][4 * q + 3] = t[3];
+    }
+  }
+}
+
+// Input from registers (D layout of the previous layer): in[16*HT] -> OT tiles.
+// W layout: [OT][4*HT][64 lanes][4].
+template <int HT, int OT>
+__device__ __forceinline__ void nsa_dense_regs(const float* w, const float (&in)[16 * HT], int lane,
+                                               f32x16 (&acc)[OT]) {
+#pragma unroll
+  for (int s4 = 0; s4 < 4 * HT; ++s4) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const f32x4 a = *(const f32x4*)(w + ((ot * (4 * HT) + s4) * 64 + lane) * 4);
+      acc[ot] = nsa_mfma(a[0], in[4 * s4 + 0], acc[ot]);
+      acc[ot] = nsa_mfma(a[1], in[4 * s4 + 1], acc[ot]);
+      acc[ot] = nsa_mfma(a[2], in[4 * s4 + 2], acc[ot]);
+      acc[ot] = nsa_mfma(a[3], in[4 * s4 + 3], acc[ot]);
+    }
+  }
+}
+
+// Input gathered from the wave's x tile through a column table
+// (tab[2*s + half] = physical column or -1), optional pre-shift.
+template <int OT, bool PRE>
+__device__ __forceinline__ void nsa_dense_tile(const float* w, const int* tab, const float* pre,
+                                               const float* xrow, int n_steps, int lane, int half,
+                                               f32x16 (&acc)[OT]) {
+  const int n_s4 = n_steps >> 2;
+  for (int s4 = 0; s4 < n_s4; ++s4) {
+    float b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = 2 * (4 * s4 + e) + half;
+      const int col = tab[idx];
+      float val = (col >= 0) ? xrow[col] : 0.0f;
+      if (PRE) val = (col >= 0) ? (val - pre[idx]) : 0.0f;
+      b[e] = val;
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const f32x4 a = *(const f32x4*)(w + ((ot * n_s4 + s4) * 64 + lane) * 4);
+      acc[ot] = nsa_mfma(a[0], b[0], acc[ot]);
+      acc[ot] = nsa_mfma(a[1], b[1], acc[ot]);
+      acc[ot] = nsa_mfma(a[2], b[2], acc[ot]);
+      acc[ot] = nsa_mfma(a[3], b[3], acc[ot]);
+    }
+  }
+}
+
+template <int HT>
+__device__ __forceinline__ void nsa_acc_to_regs(const f32x16 (&acc)[HT], float (&out)[16 * HT]) {
+#pragma unroll
+  for (int ot = 0; ot < HT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[16 * ot + r] = acc[ot][r];
+}
+
+// activation over a whole register array; the (wave-uniform) kind is tested
+// once, not per element
+template <int N>
+__device__ __forceinline__ void nsa_act_regs(float (&a)[N], int act) {
+  if (act == NSA_ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = fmaxf(a[i], 0.0f);
+  } else if (act == NSA_ACT_TANH) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = tanhf(a[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = a[i] * (1.0f / (1.0f + expf(-a[i])));
+  }
+}
+
+// element-wise transform of the features a lane owns in one chunk ------------
+
+template <class TP, int Q, int NV>
+__device__ __forceinline__ void nsa_transform_one(const float (&v)[NV], const int* tab, float* xrow,
+                                                  bool inverse, const NsaTransformConsts& tc,
+                                                  float& logdet, int& n_bad) {
+  const int col = tab[Q];
+  if (col >= 0) {
+    const float x = xrow[col];
+    float y, ld;
+    bool bad;
+    TP::template apply<Q * TP::NP, NV>(v, x, inverse, tc, y, ld, bad);
+    xrow[col] = y;
+    logdet += ld;
+    n_bad += bad ? 1 : 0;
+  }
+}
+
+template <class TP, int NV, int... Q>
+__device__ __forceinline__ void nsa_transform_features(const float (&v)[NV], const int* tab,
+                                                       float* xrow, bool inverse,
+                                                       const NsaTransformConsts& tc, float& logdet,
+                                                       int& n_bad,
+                                                       std::integer_sequence<int, Q...>) {
+  (nsa_transform_one<TP, Q, NV>(v, tab, xrow, inverse, tc, logdet, n_bad), ...);
+}
+
+// one coupling layer -----------------------------------------------------------
+
+template <int HT, class TP>
+__device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t* op, float* xrow,
+                                             int lane, int half, bool inverse, int act, int net,
+                                             int n_layers, const NsaTransformConsts& tc,
+                                             float& logdet, int& n_bad) {
+  const int n_steps0 = (int)op[1];
+  const int n_chunks = (int)op[2];
+  float h[16 * HT];
+
+  // layer 0: identity features (x tile) -> hidden
+  {
+    const float* st = pipe.begin();
+    const int* id_tab = (const int*)st;
+    const float* bias = st + 2 * n_steps0;
+    const float* w = bias + 32 * HT;
+    f32x16 acc[HT];
+    nsa_load_bias<HT>(bias, half, acc);
+    nsa_dense_tile<HT, false>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
+    nsa_acc_to_regs<HT>(acc, h);
+    pipe.end();
+  }
+
+  if (net == NSA_NET_RESNET) {
+    // pre-activation residual blocks: h += W2 act(W1 act(h) + b1) + b2
+    for (int l = 0; l < n_layers; ++l) {
+      float t[16 * HT];
+#pragma unroll
+      for (int i = 0; i < 16 * HT; ++i) t[i] = h[i];
+      nsa_act_regs<16 * HT>(t, act);
+      {
+        const float* st = pipe.begin();
+        f32x16 acc[HT];
+        nsa_load_bias<HT>(st, half, acc);
+        nsa_dense_regs<HT, HT>(st + 32 * HT, t, lane, acc);
+        nsa_acc_to_regs<HT>(acc, t);
+        nsa_act_regs<16 * HT>(t, act);
+        pipe.end();
+      }
+      {
+        const float* st = pipe.begin();
+        f32x16 acc[HT];
+        nsa_load_bias<HT>(st, half, acc);
+        nsa_dense_regs<HT, HT>(st + 32 * HT, t, lane, acc);
+#pragma unroll
+        for (int ot = 0; ot < HT; ++ot)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[16 * ot + r] = h[16 * ot + r] + acc[ot][r];
+        pipe.end();
+      }
+    }
+  } else {
+    // plain MLP (src/nessai/flows/nets.py:110-124): act after every layer but the last
+    nsa_act_regs<16 * HT>(h, act);
+    for (int l = 1; l < n_layers; ++l) {
+      const float* st = pipe.begin();
+      f32x16 acc[HT];
+      nsa_load_bias<HT>(st, half, acc);
+      nsa_dense_regs<HT, HT>(st + 32 * HT, h, lane, acc);
+      nsa_acc_to_regs<HT>(acc, h);
+      nsa_act_regs<16 * HT>(h, act);
+      pipe.end();
+    }
+  }
+
+  // last layer in chunks of TP::C tiles; every lane gets TP::FPC complete
+  // parameter sets per chunk and transforms those features in place
+  constexpr int TABW = (2 * TP::FPC + 3) & ~3;
+  for (int c = 0; c < n_chunks; ++c) {
+    const float* st = pipe.begin();
+    const int* tr_tab = (const int*)st;
+    const float* bias = st + TABW;
+    const float* w = bias + 32 * TP::C;
+    f32x16 acc[TP::C];
+    nsa_load_bias<TP::C>(bias, half, acc);
+    nsa_dense_regs<HT, TP::C>(w, h, lane, acc);
+    float v[16 * TP::C];
+#pragma unroll
+    for (int t = 0; t < TP::C; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[16 * t + r] = acc[t][r];
+    nsa_transform_features<TP>(v, tr_tab + half * TP::FPC, xrow, inverse, tc, logdet, n_bad,
+                               std::make_integer_sequence<int, TP::FPC>{});
+    pipe.end();
+  }
+}
+
+// dense (LU-linear, eval-mode cached weight) -----------------------------------
+// y = W (x - pre) + bias over all D features; D <= 64.
+__device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t* op, float* xrow,
+                                             int D, int lane, int half, float& logdet) {
+  const int n_steps = (int)op[1];
+  const int n_ot = (int)op[2];
+  const float* st = pipe.begin();
+  const int* in_tab = (const int*)st;
+  const float* pre = st + 2 * n_steps;
+  const float* bias = pre + 2 * n_steps;
+  const float* w = bias + 32 * n_ot;
+  if (n_ot == 1) {
+    f32x16 acc[1];
+    nsa_load_bias<1>(bias, half, acc);
+    nsa_dense_tile<1, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (i < D) xrow[i] = acc[0][r];
+    }
+  } else {
+    f32x16 acc[2];
+    nsa_load_bias<2>(bias, half, acc);
+    nsa_dense_tile<2, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (i < D) xrow[i] = acc[ot][r];
+      }
+  }
+  if (half == 0) logdet += nsa_bits_to_float(op[3]);
+  pipe.end();
+}
+
+// per-column ((x - a) / b) * c + d (batch norm / act norm in eval mode) ----------
+__device__ __forceinline__ void nsa_elementwise_op(NsaStagePipe& pipe, const uint32_t* op,
+                                                   float* xrow, int D, int half, float& logdet) {
+#pragma clang fp contract(off)
+  const float* st = pipe.begin();
+  const int D4 = (D + 3) & ~3;
+  for (int c = half; c < D; c += 2) {
+    const float x = xrow[c];
+    xrow[c] = ((x - st[c]) / st[D4 + c]) * st[2 * D4 + c] + st[3 * D4 + c];
+  }
+  if (half == 0) logdet += nsa_bits_to_float(op[3]);
+  pipe.end();
+}
+
+// the kernel ------------------------------------------------------------------
+
+template <int HT, class TP>
+__global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t* img = p.image;
+  const int D = (int)img[NSA_H_D];
+  const int XS = D | 1;  // odd row stride: conflict-free column reads
+  const int nw = (int)(blockDim.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const int half = lane >> 5;
+  const int j = lane & 31;
+  const bool inverse = (p.direction == NSA_DIR_INVERSE);
+
+  const int tiles_words = (nw * NSA_ROWS * XS + 3) & ~3;
+  const int max_stage = (int)img[NSA_H_MAX_STAGE];
+  float* xt = smem + wave * (NSA_ROWS * XS);
+  float* xrow = xt + j * XS;
+
+  NsaStagePipe pipe;
+  pipe.img = img;
+  pipe.table = img + (inverse ? img[NSA_H_STAGES_INV] : img[NSA_H_STAGES_FWD]);
+  pipe.n_stages = (int)(inverse ? img[NSA_H_NSTAGES_INV] : img[NSA_H_NSTAGES_FWD]);
+  pipe.buf0 = smem + tiles_words;
+  pipe.buf1 = pipe.buf0 + max_stage;
+  pipe.wave = wave;
+  pipe.nw = nw;
+  pipe.lane = lane;
+
+  const uint32_t* ops = img + (inverse ? img[NSA_H_OPS_INV] : img[NSA_H_OPS_FWD]);
+  const int n_ops = (int)(inverse ? img[NSA_H_NOPS_INV] : img[NSA_H_NOPS_FWD]);
+  const int* out_tab = (const int*)(img + (inverse ? img[NSA_H_OUT_INV] : img[NSA_H_OUT_FWD]));
+
+  NsaTransformConsts tc;
+  tc.tail_bound = nsa_bits_to_float(img[NSA_H_TAIL_BOUND]);
+  tc.two_b = tc.tail_bound + tc.tail_bound;
+  tc.min_bw = nsa_bits_to_float(img[NSA_H_MIN_BW]);
+  tc.min_bh = nsa_bits_to_float(img[NSA_H_MIN_BH]);
+  tc.min_d = nsa_bits_to_float(img[NSA_H_MIN_D]);
+  tc.edge_raw = nsa_bits_to_float(img[NSA_H_EDGE_RAW]);
+  tc.logit_div = nsa_bits_to_float(img[NSA_H_LOGIT_DIV]);
+  {
+    const int K = (int)img[NSA_H_BINS];
+    tc.bw_scale = (float)(1.0 - (double)tc.min_bw * K);
+    tc.bh_scale = (float)(1.0 - (double)tc.min_bh * K);
+  }
+  const int act = (int)img[NSA_H_ACT];
+  const int net = (int)img[NSA_H_NET];
+  const int n_layers = (int)img[NSA_H_NLAYERS];
+
+  const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
+  const long long n_groups = (n_tiles + nw - 1) / nw;
+
+  if (pipe.n_stages > 0) pipe.prime();
+
+  for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const long long row0 = (g * nw + wave) * NSA_ROWS;
+    const long long my_row = row0 + j;
+    const bool row_ok = my_row < p.n;
+
+    // ---- fill the x tile ---------------------------------------------------
+    if (p.x_in != nullptr) {
+      const long long base = row0 * D;
+      const long long limit = p.n * (long long)D;
+      for (int idx = lane; idx < NSA_ROWS * D; idx += 64) {
+        const int r = idx / D, c = idx - r * D;
+        const long long gi = base + idx;
+        xt[r * XS + c] = (gi < limit) ? p.x_in[gi] : 0.0f;
+      }
+    } else {
+      // latent draw: 4 normals per Philox call; the two lanes of a row split
+      // the quads (row-indexed counter => independent of launch geometry)
+      const unsigned long long grow = p.row_offset + (unsigned long long)my_row;
+      const int n_quads = (D + 3) >> 2;
+      for (int q = half; q < n_quads; q += 2) {
+        uint32_t r4[4];
+        nsa_philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)q, 0u,
+                          (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r4);
+        float z0, z1, z2, z3;
+        nsa_box_muller(r4[0], r4[1], z0, z1);
+        nsa_box_muller(r4[2], r4[3], z2, z3);
+        const int c = 4 * q;
+        xrow[c] = z0;
+        if (c + 1 < D) xrow[c + 1] = z1;
+        if (c + 2 < D) xrow[c + 2] = z2;
+        if (c + 3 < D) xrow[c + 3] = z3;
+      }
+    }
+
+    // ---- POPULATE prologue: latent norm, latent log-density, optional z out --
+    bool keep = true;
+    float log_pz = 0.0f;
+    if (p.mode == NSA_MODE_POPULATE) {
+      double r2 = 0.0;
+      float e = 0.0f;
+      for (int c = half; c < D; c += 2) {
+        const float z = xrow[c];
+        r2 += (double)z * (double)z;
+        e += z * z;
+      }
+      r2 += __shfl_xor(r2, 32);
+      e += __shfl_xor(e, 32);
+      keep = sqrt(r2) <= p.radius;
+      log_pz = -(0.5f * nsa_bits_to_float(img[NSA_H_BASE_INV_VAR])) * e - nsa_bits_to_float(img[NSA_H_LOG_Z]);
+      if (p.z_out != nullptr) {
+        const long long base = row0 * D;
+        const long long limit = p.n * (long long)D;
+        for (int idx = lane; idx < NSA_ROWS * D; idx += 64) {
+          const int r = idx / D, c = idx - r * D;
+          const long long gi = base + idx;
+          if (gi < limit) p.z_out[gi] = xt[r * XS + c];
+        }
+      }
+    }
+
+    // ---- run the flow --------------------------------------------------------
+    float logdet = 0.0f;
+    int n_bad = 0;
+    for (int o = 0; o < n_ops; ++o) {
+      const uint32_t* op = ops + o * NSA_OP_WORDS;
+      const int kind = (int)op[0];
+      if (kind == NSA_OP_COUPLING) {
+        nsa_coupling<HT, TP>(pipe, op, xrow, lane, half, inverse, act, net, n_layers, tc, logdet, n_bad);
+      } else if (kind == NSA_OP_DENSE) {
+        nsa_dense_op(pipe, op, xrow, D, lane, half, logdet);
+      } else {
+        nsa_elementwise_op(pipe, op, xrow, D, half, logdet);
+      }
+    }
+    logdet += __shfl_xor(logdet, 32);
+    n_bad += __shfl_xor(n_bad, 32);
+
+    // ---- epilogues -----------------------------------------------------------
+    if (p.mode == NSA_MODE_POPULATE) {
+#pragma clang fp contract(off)
+      // x = x' * sigma + mu in float64 (rescale.py:276-279), prior bounds
+      // (model.py:512-518), log_q = (log N(z) - log_j) - log_J
+      // (flowproposal.py:356, 383)
+      bool in_bounds = true;
+      for (int i = half; i < D; i += 2) {
+        const double xp = (double)xrow[out_tab[i]];
+        const double xv = (xp * p.scale[i]) + p.shift[i];
+        in_bounds = in_bounds && !((xv < p.lower[i]) || (xv > p.upper[i]));
+        if (row_ok) p.x64_out[my_row * D + i] = xv;
+      }
+      const int ib = in_bounds ? 1 : 0;
+      const bool ok = (ib + __shfl_xor(ib, 32)) == 2;
+      double lq = ((double)log_pz - (double)logdet) - p.log_j_rescale;
+      const bool finite = (lq - lq) == 0.0;
+      if (!(keep && ok && finite && n_bad == 0)) lq = __longlong_as_double(0x7ff8000000000000LL);
+      if (row_ok && half == 0) p.log_q_out[my_row] = lq;
+      if (row_ok && half == 0 && n_bad != 0) atomicAdd(p.status, 1);
+    } else {
+      float out_ld = logdet;
+      if (p.mode == NSA_MODE_LOGPROB) {
+        // log_prob = (-0.5/var * sum z^2 - log_z) + logabsdet (base.py:243-245)
+        float e = 0.0f;
+        for (int i = half; i < D; i += 2) {
+          const float z = xrow[out_tab[i]];
+          e += z * z;
+        }
+        e += __shfl_xor(e, 32);
+        const float lp = -(0.5f * nsa_bits_to_float(img[NSA_H_BASE_INV_VAR])) * e - nsa_bits_to_float(img[NSA_H_LOG_Z]);
+        out_ld = lp + logdet;
+      }
+      if (row_ok && half == 0 && p.ld_out != nullptr) p.ld_out[my_row] = out_ld;
+      if (row_ok && half == 0 && n_bad != 0) atomicAdd(p.status, 1);
+      if (p.x_out != nullptr) {
+        const long long base = row0 * D;
+        const long long limit = p.n * (long long)D;
+        for (int idx = lane; idx < NSA_ROWS * D; idx += 64) {
+          const int r = idx / D, c = idx - r * D;
+          const long long gi = base + idx;
+          if (gi < limit) p.x_out[gi] = xt[r * XS + out_tab[c]];
+        }
+      }
+    }
+  }
+  // drain the wrap-around prefetch before the workgroup exits
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}

@@ -1,0 +1,80 @@
+// Flow image format shared by the host packer (nessai_amd/pack.py) and the
+// gfx950 kernels.  A flow (RealNVP / NeuralSplineFlow of the reference,
+// src/nessai/flows/realnvp.py:76-214, src/nessai/flows/nsf.py:60-130) is
+// compiled on the host into ONE flat buffer of 32-bit words:
+//
+//   header | op table (forward) | op table (inverse) | stage table (forward)
+//   | stage table (inverse) | output column tables | stage blobs
+//
+// The kernel executes the op table of the requested direction in order.  Every
+// op reads its index tables / biases / MFMA-packed weights from "stages":
+// contiguous blobs copied global -> LDS (double-buffered) ahead of use.
+// Permutations never move data: they are folded into the column tables.
+#pragma once
+#include <stdint.h>
+
+#define NSA_MAGIC 0x3141534e /* "NSA1" */
+#define NSA_VERSION 3
+
+// header word indices
+enum {
+  NSA_H_MAGIC = 0,
+  NSA_H_VERSION = 1,
+  NSA_H_D = 2,             // features
+  NSA_H_HT = 3,            // hidden tiles: hidden width padded to 32*HT
+  NSA_H_TRANSFORM = 4,     // NSA_T_*
+  NSA_H_BINS = 5,          // spline bins K (RQ only)
+  NSA_H_NOPS_FWD = 6,
+  NSA_H_OPS_FWD = 7,       // word offset
+  NSA_H_NOPS_INV = 8,
+  NSA_H_OPS_INV = 9,
+  NSA_H_NSTAGES_FWD = 10,
+  NSA_H_STAGES_FWD = 11,   // word offset, 2 words per stage: {src word offset, n words}
+  NSA_H_NSTAGES_INV = 12,
+  NSA_H_STAGES_INV = 13,
+  NSA_H_MAX_STAGE = 14,    // words, multiple of 256
+  NSA_H_TOTAL = 15,        // total words
+  NSA_H_OUT_FWD = 16,      // word offset: D ints, physical column of logical output i
+  NSA_H_OUT_INV = 17,
+  NSA_H_LOG_Z = 18,        // float: 0.5*D*log(2*pi*var) rounded to f32
+  NSA_H_TAIL_BOUND = 19,   // float
+  NSA_H_MIN_BW = 20,       // float min_bin_width
+  NSA_H_MIN_BH = 21,       // float min_bin_height
+  NSA_H_MIN_D = 22,        // float min_derivative
+  NSA_H_EDGE_RAW = 23,     // float: log(exp(1-min_derivative)-1) rounded to f32
+  NSA_H_LOGIT_DIV = 24,    // float: sqrt(hidden_features) or 1.0 (no scaling)
+  NSA_H_ACT = 25,          // NSA_ACT_*
+  NSA_H_NET = 26,          // NSA_NET_*
+  NSA_H_NLAYERS = 27,      // residual blocks (resnet) / hidden layers (mlp)
+  NSA_H_BASE_INV_VAR = 28, // float: 1/var of the base Gaussian (1.0 for StandardNormal)
+  NSA_H_WORDS = 32
+};
+
+enum { NSA_T_NONE = 0, NSA_T_RQ = 1, NSA_T_AFFINE = 2, NSA_T_ADDITIVE = 3 };
+enum { NSA_ACT_RELU = 0, NSA_ACT_TANH = 1, NSA_ACT_SILU = 2 };
+enum { NSA_NET_RESNET = 0, NSA_NET_MLP = 1 };
+enum { NSA_OP_COUPLING = 1, NSA_OP_DENSE = 2, NSA_OP_ELEMENTWISE = 3 };
+
+// op record: 4 words
+//   COUPLING    {kind, n_steps0 (multiple of 4), n_chunks, 0}
+//   DENSE       {kind, n_steps  (multiple of 4), n_out_tiles, logdet (float bits)}
+//   ELEMENTWISE {kind, 0, 0, logdet (float bits)}
+#define NSA_OP_WORDS 4
+
+// Stage blob layouts (word offsets inside the blob; every section is padded
+// to a multiple of 4 words, every blob to a multiple of 256 words):
+//   coupling layer 0 : id_tab[2*n_steps0] | bias[32*HT] | W[HT][n_steps0/4][64][4]
+//   hidden layer     : bias[32*HT]        | W[HT][4*HT][64][4]
+//   final chunk      : tr_tab[pad4(2*FPC)] | bias[32*C] | W[C][4*HT][64][4]
+//   dense            : in_tab[2*n_steps] | pre[2*n_steps] | bias[32*OT] | W[OT][n_steps/4][64][4]
+//   elementwise      : a[D4] | b[D4] | c[D4] | d[D4]  (D4 = pad4(D); y = ((x-a)/b)*c + d per physical column)
+//
+// MFMA packing (v_mfma_f32_32x32x2_f32): W[ot][s4][lane][e] with step s = 4*s4+e,
+// lane = 32*half + i holds weight(out_row(ot, i), in_col(s, half)).
+//   in_col from registers (hidden/final): 32*(s>>4) + (r&3) + 8*(r>>2) + 4*half, r = s&15
+//   in_col from the x tile (layer 0, dense): 2*s + half
+// bias[ot][half][r] is the bias of out feature 32*ot + (r&3) + 8*(r>>2) + 4*half.
+
+// flags for nsa_flow_* entry points
+#define NSA_DIR_FORWARD 0
+#define NSA_DIR_INVERSE 1

@@ -1,0 +1,205 @@
+// Rejection-sampling kernels of the populate path: importance weights + global
+// maximum, accept test, order-preserving stream compaction.
+//
+// Reference semantics (src/nessai/proposal/flowproposal/flowproposal.py:469,
+// 492-498): log_w = log_prior(x) - log_q; log_w -= log_w.max();
+// accept = log_w > log(U[0,1)); samples[...] = x[accept][:m].
+// HBM-bound byte shuffling: one pass over log_q (8 B/row), one over log_w, and
+// D*8 B per ACCEPTED row only.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nessai_amd.h"
+#include "nsa_device.h"
+
+#define NSA_ACC_THREADS 256
+#define NSA_ACC_ITEMS 4
+#define NSA_ACC_ROWS (NSA_ACC_THREADS * NSA_ACC_ITEMS)
+
+// monotone (signed) integer encoding of a double, usable with atomicMax
+__host__ __device__ inline long long nsa_key_encode(double v) {
+  long long b;
+  __builtin_memcpy(&b, &v, 8);
+  return (b >= 0) ? b : (b ^ 0x7fffffffffffffffLL);
+}
+__host__ __device__ inline double nsa_key_decode(long long k) {
+  const long long b = (k >= 0) ? k : (k ^ 0x7fffffffffffffffLL);
+  double v;
+  __builtin_memcpy(&v, &b, 8);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) nsa_weights_kernel(long long n, const double* __restrict__ log_q,
+                                                          const double* __restrict__ log_prior,
+                                                          double log_prior_const,
+                                                          double* __restrict__ log_w,
+                                                          long long* max_key) {
+  const double ninf = -__builtin_huge_val();
+  double m = ninf;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const double lq = log_q[i];
+    const double lp = (log_prior != nullptr) ? log_prior[i] : log_prior_const;
+    double w = lp - lq;
+    if (lq != lq || w != w) w = ninf;  // dropped row (NaN log_q) or NaN weight
+    log_w[i] = w;
+    m = fmax(m, w);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+  __shared__ double sm[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sm[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    atomicMax(max_key, nsa_key_encode(m));
+  }
+}
+
+// uniform in [0,1) with 53 random bits (as numpy's Generator.random)
+__device__ __forceinline__ double nsa_uniform53(unsigned long long seed, unsigned long long grow) {
+  uint32_t r[4];
+  nsa_philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), 0u, 1u, (uint32_t)seed,
+                    (uint32_t)(seed >> 32), r);
+  const unsigned long long hi = r[0] >> 5, lo = r[1] >> 6;
+  return (double)((hi << 26) | lo) * (1.0 / 9007199254740992.0);
+}
+
+// pass 1: accept flags + per-block counts
+__global__ void __launch_bounds__(NSA_ACC_THREADS) nsa_accept_flag_kernel(
+    long long n, const double* __restrict__ log_w, const long long* __restrict__ max_key,
+    unsigned long long seed, unsigned long long row_offset, const double* __restrict__ u_in,
+    unsigned char* __restrict__ flags, int* __restrict__ block_counts) {
+  const double mx = nsa_key_decode(*max_key);
+  const long long base = (long long)blockIdx.x * NSA_ACC_ROWS;
+  int cnt = 0;
+#pragma unroll
+  for (int it = 0; it < NSA_ACC_ITEMS; ++it) {
+    const long long i = base + it * NSA_ACC_THREADS + threadIdx.x;
+    if (i < n) {
+      const double u = (u_in != nullptr) ? u_in[i] : nsa_uniform53(seed, row_offset + (unsigned long long)i);
+      const double lu = log(u);
+      const bool acc = (log_w[i] - mx) > lu;
+      flags[i] = acc ? 1 : 0;
+      cnt += acc ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  __shared__ int sm[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sm[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// pass 2: exclusive scan of the block counts (one workgroup)
+__global__ void __launch_bounds__(1024) nsa_accept_scan_kernel(int n_blocks, const int* __restrict__ counts,
+                                                               long long* __restrict__ offsets,
+                                                               long long* __restrict__ total) {
+  __shared__ long long sm[1024];
+  __shared__ long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int start = 0; start < n_blocks; start += 1024) {
+    const int i = start + threadIdx.x;
+    const long long v = (i < n_blocks) ? counts[i] : 0;
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const long long t = (threadIdx.x >= off) ? sm[threadIdx.x - off] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n_blocks) offsets[i] = carry + sm[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sm[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+// pass 3: scatter accepted rows in draw order
+__global__ void __launch_bounds__(NSA_ACC_THREADS) nsa_accept_scatter_kernel(
+    long long n, int D, const unsigned char* __restrict__ flags, const long long* __restrict__ offsets,
+    const double* __restrict__ x64, long long capacity, double* __restrict__ x_acc,
+    long long* __restrict__ idx_acc) {
+  const long long base = (long long)blockIdx.x * NSA_ACC_ROWS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ int wave_cnt[NSA_ACC_ITEMS][4];
+  int my_flag[NSA_ACC_ITEMS], my_rank[NSA_ACC_ITEMS];
+#pragma unroll
+  for (int it = 0; it < NSA_ACC_ITEMS; ++it) {
+    const long long i = base + it * NSA_ACC_THREADS + threadIdx.x;
+    const int f = (i < n) ? (int)flags[i] : 0;
+    const unsigned long long ball = __ballot(f);
+    my_flag[it] = f;
+    my_rank[it] = __popcll(ball & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[it][wave] = __popcll(ball);
+  }
+  __syncthreads();
+  long long running = offsets[blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < NSA_ACC_ITEMS; ++it) {
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) before += (w < wave) ? wave_cnt[it][w] : 0;
+    const int tot = wave_cnt[it][0] + wave_cnt[it][1] + wave_cnt[it][2] + wave_cnt[it][3];
+    if (my_flag[it]) {
+      const long long dst = running + before + my_rank[it];
+      if (dst < capacity) {
+        const long long i = base + it * NSA_ACC_THREADS + threadIdx.x;
+        for (int c = 0; c < D; ++c) x_acc[dst * D + c] = x64[i * D + c];
+        if (idx_acc != nullptr) idx_acc[dst] = i;
+      }
+    }
+    running += tot;
+  }
+}
+
+// host-side launchers ---------------------------------------------------------
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_weights(
+    long long n, const double* log_q, const double* log_prior, double log_prior_const,
+    double* log_w, long long* max_key, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(nsa_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, log_q,
+                     log_prior, log_prior_const, log_w, max_key);
+  return hipGetLastError();
+}
+
+extern "C" __attribute__((visibility("hidden"))) size_t nsa_accept_workspace_bytes(long long n) {
+  const long long nb = (n + NSA_ACC_ROWS - 1) / NSA_ACC_ROWS;
+  size_t bytes = ((size_t)n + 255) & ~(size_t)255;      // flags
+  bytes += (((size_t)nb * 4) + 255) & ~(size_t)255;     // block counts
+  bytes += (((size_t)nb * 8) + 255) & ~(size_t)255;     // block offsets
+  return bytes + 256;
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_accept(
+    long long n, int D, const double* log_w, const long long* max_key, unsigned long long seed,
+    unsigned long long row_offset, const double* u_in, const double* x64, long long capacity,
+    double* x_acc, long long* idx_acc, long long* n_accept, void* workspace, hipStream_t stream) {
+  if (n <= 0) return hipMemsetAsync(n_accept, 0, 8, stream);
+  const long long nb = (n + NSA_ACC_ROWS - 1) / NSA_ACC_ROWS;
+  unsigned char* flags = (unsigned char*)workspace;
+  size_t off = ((size_t)n + 255) & ~(size_t)255;
+  int* counts = (int*)((char*)workspace + off);
+  off += (((size_t)nb * 4) + 255) & ~(size_t)255;
+  long long* offsets = (long long*)((char*)workspace + off);
+  hipLaunchKernelGGL(nsa_accept_flag_kernel, dim3((unsigned)nb), dim3(NSA_ACC_THREADS), 0, stream, n,
+                     log_w, max_key, seed, row_offset, u_in, flags, counts);
+  hipLaunchKernelGGL(nsa_accept_scan_kernel, dim3(1), dim3(1024), 0, stream, (int)nb, counts, offsets,
+                     n_accept);
+  hipLaunchKernelGGL(nsa_accept_scatter_kernel, dim3((unsigned)nb), dim3(NSA_ACC_THREADS), 0, stream, n,
+                     D, flags, offsets, x64, capacity, x_acc, idx_acc);
+  return hipGetLastError();
+}
+
+extern "C" long long nsa_max_key_init(void) { return nsa_key_encode(-__builtin_huge_val()); }
+extern "C" long long nsa_max_key_encode(double v) { return nsa_key_encode(v); }
+extern "C" double nsa_max_key_decode(long long key) { return nsa_key_decode(key); }

@@ -1,0 +1,270 @@
+"""Flow plug-in surface and its HIP implementation.
+
+``BaseFlow`` restates the abstract interface the reference's ``FlowModel``
+programs against (``src/nessai/flows/base.py:11-167``): a flow class selected
+with ``flow_config["flow"]`` must provide these methods
+(``src/nessai/flows/utils.py:231-246``).  ``HipFlow`` is the counterpart of
+the reference's ``NFlow`` (``flows/base.py:170-316``) whose transform and base
+distribution run in the gfx950 kernels of ``nessai_amd/csrc``.
+"""
+
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+from torch.nn import Module
+
+from .. import lib, pack
+from . import modules as M
+
+
+class BaseFlow(Module, ABC):
+    """Abstract flow API (same names, arguments and return values as the reference)."""
+
+    device = None
+
+    def to(self, device):
+        """Store the device, then move the parameters (returns None, as the reference)."""
+        self.device = torch.device(device)
+        super().to(device)
+
+    @abstractmethod
+    def forward(self, x, context=None):
+        raise NotImplementedError()
+
+    @abstractmethod
+    def inverse(self, z, context=None):
+        raise NotImplementedError()
+
+    @abstractmethod
+    def sample(self, n, context=None):
+        raise NotImplementedError()
+
+    @abstractmethod
+    def log_prob(self, x, context=None):
+        raise NotImplementedError()
+
+    @abstractmethod
+    def sample_latent_distribution(self, n, context=None):
+        raise NotImplementedError
+
+    @abstractmethod
+    def base_distribution_log_prob(self, z, context=None):
+        raise NotImplementedError()
+
+    @abstractmethod
+    def forward_and_log_prob(self, x, context=None):
+        raise NotImplementedError()
+
+    @abstractmethod
+    def sample_and_log_prob(self, n, context=None):
+        raise NotImplementedError()
+
+    def finalise(self):
+        pass
+
+    def end_iteration(self):
+        pass
+
+    @abstractmethod
+    def freeze_transform(self):
+        raise NotImplementedError()
+
+    @abstractmethod
+    def unfreeze_transform(self):
+        raise NotImplementedError()
+
+
+MODE_APPLY, MODE_LOGPROB = 0, 1
+DIR_FORWARD, DIR_INVERSE = 0, 1
+
+
+class HipFlow(BaseFlow):
+    """Transform + base distribution evaluated by the fused gfx950 flow kernel.
+
+    Inputs must be contiguous float32 tensors on a ROCm device; outputs are
+    allocated on the same device.  There is no CPU path: calling a method with
+    CPU tensors raises ``RuntimeError``.
+    """
+
+    def __init__(self, transform, distribution):
+        super().__init__()
+        if not isinstance(transform, M.CompositeTransform):
+            raise TypeError("transform must be a nessai_amd CompositeTransform")
+        if not isinstance(distribution, M.StandardNormal):
+            raise TypeError(
+                "distribution must be a nessai_amd StandardNormal; other base "
+                "distributions have no gfx950 kernel"
+            )
+        self._transform = transform
+        self._distribution = distribution
+        self._image_key = None
+        self._image_host = None
+        self._image_dev = None
+        self._header = None
+        self._status = None
+        self.waves_per_group = 0
+        self.max_groups = 0
+        desc = M.describe(self)
+        self.features = desc["D"]
+        ht = pack.hidden_tiles(desc["hidden"])
+        if ht > 4 or not lib_supports(ht, desc["transform"], desc.get("bins", 0)):
+            raise ValueError(
+                "No gfx950 kernel instance for this flow configuration "
+                f"(hidden={desc['hidden']}, transform={desc['transform']}, "
+                f"bins={desc.get('bins', 0)})"
+            )
+
+    # -- device image ----------------------------------------------------------
+
+    def _fingerprint(self):
+        key = [self.training]
+        for t in list(self.parameters()) + list(self.buffers()):
+            key.append((t.data_ptr(), t._version))
+        return tuple(key)
+
+    def _device(self):
+        for p in self.parameters():
+            return p.device
+        return torch.device("cpu")
+
+    def device_image(self):
+        """(header ctypes array, image tensor on the device), repacked when weights change."""
+        device = self._device()
+        if device.type != "cuda":
+            raise RuntimeError(
+                "nessai_amd flows run on a ROCm device only; move the flow with "
+                ".to('cuda') (there is no CPU fallback)"
+            )
+        key = (device, self._fingerprint())
+        if key != self._image_key:
+            image = pack.pack_flow(M.describe(self))
+            self._image_host = image
+            self._header = (lib.ctypes.c_uint32 * pack.HEADER_WORDS)(*image[: pack.HEADER_WORDS].tolist())
+            self._image_dev = torch.from_numpy(image.view(np.int32)).to(device)
+            self._status = torch.zeros(4, dtype=torch.int32, device=device)
+            self._image_key = key
+        return self._header, self._image_dev
+
+    # -- kernel calls ----------------------------------------------------------
+
+    def _check_input(self, x):
+        if not isinstance(x, torch.Tensor):
+            raise TypeError("inputs must be torch tensors")
+        if x.device.type != "cuda":
+            raise RuntimeError(
+                "nessai_amd flows take tensors on a ROCm device (got "
+                f"{x.device}); there is no CPU fallback"
+            )
+        if x.dim() != 2 or x.shape[1] != self.features:
+            raise ValueError(
+                "Expected inputs of shape (N, {}), got {}".format(self.features, tuple(x.shape))
+            )
+        return x.detach().to(torch.float32).contiguous()
+
+    def _run(self, x, direction, mode, want_x=True):
+        if self.training and _has_batch_norm(self) :
+            raise RuntimeError(
+                "Batch-norm transforms are evaluated with running statistics; "
+                "call .eval() before using the flow for inference"
+            )
+        x = self._check_input(x)
+        header, image = self.device_image()
+        n = x.shape[0]
+        out = torch.empty_like(x) if want_x else None
+        ld = torch.empty(n, dtype=torch.float32, device=x.device)
+        status = self._status
+        status.zero_()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = lib.load().nsa_flow_run(
+            header, lib.ptr(image), direction, mode, n, lib.ptr(x), lib.ptr(out), lib.ptr(ld),
+            lib.ptr(status), self.waves_per_group, self.max_groups, lib.c_void_p(stream),
+        )
+        lib.check(rc, "nsa_flow_run")
+        return out, ld, status
+
+    def forward(self, x, context=None):
+        """x -> (z, log|det J|)  (``NFlow.forward``, flows/base.py:209-214)."""
+        _no_context(context)
+        z, ld, _ = self._run(x, DIR_FORWARD, MODE_APPLY)
+        return z, ld
+
+    def inverse(self, z, context=None):
+        """z -> (x, log|det J| of the inverse)  (flows/base.py:216-221).
+
+        Raises ``AssertionError`` if the spline inverse met a negative
+        discriminant, as the reference's arithmetic does (the caller drops the
+        batch, ``flowproposal.py:357-364``).
+        """
+        _no_context(context)
+        x, ld, status = self._run(z, DIR_INVERSE, MODE_APPLY)
+        if int(status[0].item()) != 0:
+            raise AssertionError("negative discriminant in the spline inverse")
+        return x, ld
+
+    def log_prob(self, x, context=None):
+        """log p(x)  (flows/base.py:236-245)."""
+        _no_context(context)
+        _, lp, _ = self._run(x, DIR_FORWARD, MODE_LOGPROB, want_x=False)
+        return lp
+
+    def forward_and_log_prob(self, x, context=None):
+        """(z, log p(x))  (flows/base.py:259-273)."""
+        _no_context(context)
+        z, lp, _ = self._run(x, DIR_FORWARD, MODE_LOGPROB)
+        return z, lp
+
+    def sample_latent_distribution(self, n, context=None):
+        """Draw from the base distribution on the flow's device (flows/base.py:247-250)."""
+        if context is not None:
+            raise NotImplementedError
+        std = float(np.sqrt(self._distribution.var))
+        z = torch.randn(int(n), self.features, device=self._device(), dtype=torch.float32)
+        return z if std == 1.0 else z * std
+
+    def base_distribution_log_prob(self, z, context=None):
+        """log N(z; 0, var I)  (flows/base.py:252-257).
+
+        A D-term reduction per row: evaluated with torch device ops on the
+        same stream (the fused populate kernel computes it in-kernel).
+        """
+        z = self._check_input(z)
+        var = float(self._distribution.var)
+        log_z = np.float32(0.5 * self.features * np.log(2 * np.pi * var))
+        return -(0.5 / var) * torch.sum(z * z, dim=1) - log_z
+
+    def sample(self, num_samples, context=None):
+        """(flows/base.py:223-234)."""
+        _no_context(context)
+        noise = self.sample_latent_distribution(num_samples)
+        x, _ = self.inverse(noise)
+        return x
+
+    def sample_and_log_prob(self, N, context=None):
+        """(x, log p(x)) for fresh draws  (flows/base.py:275-287)."""
+        _no_context(context)
+        z = self.sample_latent_distribution(N)
+        log_prob = self.base_distribution_log_prob(z)
+        x, logabsdet = self.inverse(z)
+        return x, log_prob - logabsdet
+
+    def freeze_transform(self):
+        self._transform.requires_grad_(False)
+
+    def unfreeze_transform(self):
+        self._transform.requires_grad_(True)
+
+
+def _no_context(context):
+    if context is not None:
+        raise NotImplementedError("conditional flows have no gfx950 kernel yet")
+
+
+def _has_batch_norm(flow):
+    return any(isinstance(m, M.BatchNorm) for m in flow.modules())
+
+
+def lib_supports(ht, transform, bins):
+    """Ask the library whether a kernel instance exists (no GPU needed)."""
+    kind = pack.TRANSFORMS[transform]
+    return bool(lib.load().nsa_flow_supported(int(ht), int(kind), int(bins if transform == "rq" else 0)))

@@ -1,0 +1,449 @@
+"""Parameter containers for the transforms of a flow.
+
+These ``torch.nn.Module`` classes hold the parameters and buffers of each
+transform under the same attribute names the reference's module tree uses
+(``_transform._transforms.N.transform_net.initial_layer.weight`` ...; the tree
+is built by ``src/nessai/flows/realnvp.py:186-213`` / ``nsf.py:110-128`` out of
+glasflow.nflows classes), so ``state_dict()`` / ``load_state_dict()`` /
+``parameters()`` / ``apply()`` behave as ``FlowModel`` expects
+(``src/nessai/flowmodel/base.py:636,685,711,729,766-769``).
+
+They contain **no arithmetic**: the maths runs in the gfx950 kernels, fed by
+``describe()`` which turns each container into an entry of the flow
+description consumed by ``nessai_amd.pack.pack_flow``.  Initial values follow
+the published nflows initialisers so that the same ``torch.manual_seed`` gives
+the same starting weights as the reference.
+"""
+
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import init
+
+ACTIVATION_NAMES = {}
+
+
+def _register_activations():
+    import torch.nn.functional as F
+
+    ACTIVATION_NAMES[F.relu] = "relu"
+    ACTIVATION_NAMES[torch.relu] = "relu"
+    ACTIVATION_NAMES[F.tanh] = "tanh"
+    ACTIVATION_NAMES[torch.tanh] = "tanh"
+    ACTIVATION_NAMES[F.silu] = "silu"
+
+
+_register_activations()
+
+
+def activation_name(activation):
+    """Map the callable the reference passes (``flows/utils.py:200-205``) to a name."""
+    if isinstance(activation, str):
+        name = activation.lower()
+        if name == "swish":
+            name = "silu"
+        if name not in ("relu", "tanh", "silu"):
+            raise ValueError(f"Unknown activation: {activation}")
+        return name
+    if activation in ACTIVATION_NAMES:
+        return ACTIVATION_NAMES[activation]
+    name = getattr(activation, "__name__", "")
+    if name in ("silu", "swish"):
+        return "silu"
+    if name in ("relu", "tanh"):
+        return name
+    raise ValueError(
+        f"Activation {activation!r} has no gfx950 kernel; choose relu, tanh or silu"
+    )
+
+
+class _Container(nn.Module):
+    """Base: holding parameters only — calling it is a bug."""
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError(
+            f"{type(self).__name__} is a parameter container; the arithmetic runs "
+            "in the nessai_amd HIP kernels (call the flow, not its parts)"
+        )
+
+
+class Linear(nn.Linear):
+    """``nn.Linear`` used purely as a (weight, bias) holder with torch's default init."""
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("Linear layers of a HIP flow are parameter containers")
+
+
+class ResidualBlock(_Container):
+    def __init__(self, features, zero_initialization=True):
+        super().__init__()
+        self.linear_layers = nn.ModuleList([Linear(features, features) for _ in range(2)])
+        if zero_initialization:
+            init.uniform_(self.linear_layers[-1].weight, -1e-3, 1e-3)
+            init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
+
+    def reset_parameters(self):
+        for layer in self.linear_layers:
+            layer.reset_parameters()
+        init.uniform_(self.linear_layers[-1].weight, -1e-3, 1e-3)
+        init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
+
+
+class ResidualNet(_Container):
+    """Conditioner: initial layer, pre-activation residual blocks, final layer."""
+
+    kind = "resnet"
+
+    def __init__(self, in_features, out_features, hidden_features, num_blocks=2,
+                 activation="relu"):
+        super().__init__()
+        self.activation_name = activation_name(activation)
+        self.hidden_features = hidden_features
+        self.initial_layer = Linear(in_features, hidden_features)
+        self.blocks = nn.ModuleList([ResidualBlock(hidden_features) for _ in range(num_blocks)])
+        self.final_layer = Linear(hidden_features, out_features)
+
+    def layers(self):
+        out = [self.initial_layer]
+        for block in self.blocks:
+            out.extend(block.linear_layers)
+        out.append(self.final_layer)
+        return out
+
+
+class MLP(_Container):
+    """Plain MLP conditioner (attribute names of ``src/nessai/flows/nets.py:55-67``)."""
+
+    kind = "mlp"
+
+    def __init__(self, in_features, out_features, hidden_sizes, activation="relu"):
+        super().__init__()
+        self.activation_name = activation_name(activation)
+        if len(hidden_sizes) == 0:
+            raise ValueError("List of hidden sizes can't be empty.")
+        if len(set(hidden_sizes)) != 1:
+            raise ValueError("The gfx950 kernels need equal hidden layer widths")
+        self._hidden_sizes = list(hidden_sizes)
+        self._input_layer = Linear(in_features, hidden_sizes[0])
+        self._hidden_layers = nn.ModuleList(
+            [Linear(i, o) for i, o in zip(hidden_sizes[:-1], hidden_sizes[1:])]
+        )
+        self._output_layer = Linear(hidden_sizes[-1], out_features)
+
+    def layers(self):
+        return [self._input_layer, *self._hidden_layers, self._output_layer]
+
+
+class RandomPermutation(_Container):
+    def __init__(self, features):
+        super().__init__()
+        self.register_buffer("_permutation", torch.randperm(features))
+
+
+class LULinear(_Container):
+    """``W = L U`` parameters (unit-diagonal L, ``diag(U) = softplus(.) + eps``)."""
+
+    def __init__(self, features, identity_init=True, eps=1e-3):
+        super().__init__()
+        self.features = features
+        self.eps = eps
+        self.bias = nn.Parameter(torch.zeros(features))
+        n_tri = ((features - 1) * features) // 2
+        self.lower_entries = nn.Parameter(torch.zeros(n_tri))
+        self.upper_entries = nn.Parameter(torch.zeros(n_tri))
+        self.unconstrained_upper_diag = nn.Parameter(torch.zeros(features))
+        self._initialize(identity_init)
+
+    def _initialize(self, identity_init=True):
+        init.zeros_(self.bias)
+        if identity_init:
+            init.zeros_(self.lower_entries)
+            init.zeros_(self.upper_entries)
+            init.constant_(
+                self.unconstrained_upper_diag, math.log(math.exp(1 - self.eps) - 1)
+            )
+        else:
+            stdv = 1.0 / math.sqrt(self.features)
+            init.uniform_(self.lower_entries, -stdv, stdv)
+            init.uniform_(self.upper_entries, -stdv, stdv)
+            init.uniform_(self.unconstrained_upper_diag, -stdv, stdv)
+
+    def host_matrices(self):
+        """(W, W^-1, bias, log|det W|) as float32 arrays.
+
+        Built the way the reference's eval-mode cache is (lower @ upper, two
+        triangular solves against the identity); a D x D host-side
+        precomputation done once per weight update, like that cache.
+        """
+        with torch.no_grad():
+            f = self.features
+            dev = self.lower_entries.device
+            lower = torch.zeros(f, f, dtype=torch.float32)
+            upper = torch.zeros(f, f, dtype=torch.float32)
+            li = np.tril_indices(f, k=-1)
+            ui = np.triu_indices(f, k=1)
+            di = np.diag_indices(f)
+            lower[li[0], li[1]] = self.lower_entries.detach().float().cpu()
+            lower[di[0], di[1]] = 1.0
+            upper[ui[0], ui[1]] = self.upper_entries.detach().float().cpu()
+            diag = (
+                torch.nn.functional.softplus(self.unconstrained_upper_diag.detach().float().cpu())
+                + self.eps
+            )
+            upper[di[0], di[1]] = diag
+            weight = lower @ upper
+            identity = torch.eye(f, f, dtype=torch.float32)
+            lower_inv = torch.linalg.solve_triangular(
+                lower, identity, upper=False, unitriangular=True
+            )
+            weight_inv = torch.linalg.solve_triangular(
+                upper, lower_inv, upper=True, unitriangular=False
+            )
+            logabsdet = torch.sum(torch.log(diag))
+            del dev
+            return (
+                weight.numpy(),
+                weight_inv.numpy(),
+                self.bias.detach().float().cpu().numpy(),
+                np.float32(logabsdet.item()),
+            )
+
+
+class BatchNorm(_Container):
+    """Batch norm between coupling layers (eval-mode statistics on the device)."""
+
+    def __init__(self, features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.momentum = momentum
+        self.eps = eps
+        constant = math.log(math.exp(1 - eps) - 1)
+        self.unconstrained_weight = nn.Parameter(constant * torch.ones(features))
+        self.bias = nn.Parameter(torch.zeros(features))
+        self.register_buffer("running_mean", torch.zeros(features))
+        self.register_buffer("running_var", torch.ones(features))
+
+    def host_tables(self):
+        """Per-feature ``((x - a) / b) * c + d`` tables for both directions."""
+        with torch.no_grad():
+            w = (
+                torch.nn.functional.softplus(self.unconstrained_weight.detach().float().cpu())
+                + self.eps
+            )
+            b = self.bias.detach().float().cpu()
+            mean = self.running_mean.detach().float().cpu()
+            var = self.running_var.detach().float().cpu()
+            std = torch.sqrt(var + self.eps)
+            ld_fwd = torch.sum(torch.log(w) - 0.5 * torch.log(var + self.eps))
+            ld_inv = torch.sum(-torch.log(w) + 0.5 * torch.log(var + self.eps))
+            fwd = (mean.numpy(), std.numpy(), w.numpy(), b.numpy(), np.float32(ld_fwd.item()))
+            inv = (b.numpy(), w.numpy(), std.numpy(), mean.numpy(), np.float32(ld_inv.item()))
+            return fwd, inv
+
+
+class ActNorm(_Container):
+    def __init__(self, features):
+        super().__init__()
+        self.register_buffer("initialized", torch.tensor(False, dtype=torch.bool))
+        self.log_scale = nn.Parameter(torch.zeros(features))
+        self.shift = nn.Parameter(torch.zeros(features))
+
+    def host_tables(self):
+        with torch.no_grad():
+            ls = self.log_scale.detach().float().cpu()
+            scale = torch.exp(ls)
+            shift = self.shift.detach().float().cpu()
+            zeros = torch.zeros_like(scale)
+            ones = torch.ones_like(scale)
+            s = torch.sum(ls)
+            fwd = (zeros.numpy(), ones.numpy(), scale.numpy(), shift.numpy(), np.float32(s.item()))
+            inv = (shift.numpy(), scale.numpy(), ones.numpy(), zeros.numpy(), np.float32(-s.item()))
+            return fwd, inv
+
+
+class CouplingTransform(_Container):
+    """Mask bookkeeping + conditioner; ``mask <= 0`` identity, ``> 0`` transformed."""
+
+    transform = None  # "rq" | "affine" | "additive"
+
+    def __init__(self, mask, transform_net_create_fn, params_per_feature):
+        super().__init__()
+        mask = torch.as_tensor(mask)
+        if mask.dim() != 1:
+            raise ValueError("Mask must be a 1-dim tensor.")
+        if mask.numel() <= 0:
+            raise ValueError("Mask can't be empty.")
+        self.features = len(mask)
+        features_vector = torch.arange(self.features)
+        self.register_buffer("identity_features", features_vector.masked_select(mask <= 0))
+        self.register_buffer("transform_features", features_vector.masked_select(mask > 0))
+        self.transform_net = transform_net_create_fn(
+            len(self.identity_features), len(self.transform_features) * params_per_feature
+        )
+
+
+class AffineCouplingTransform(CouplingTransform):
+    transform = "affine"
+
+    def __init__(self, mask, transform_net_create_fn):
+        super().__init__(mask, transform_net_create_fn, 2)
+
+
+class AdditiveCouplingTransform(CouplingTransform):
+    transform = "additive"
+
+    def __init__(self, mask, transform_net_create_fn):
+        super().__init__(mask, transform_net_create_fn, 1)
+
+
+class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
+    transform = "rq"
+
+    def __init__(self, mask, transform_net_create_fn, num_bins=10, tails="linear",
+                 tail_bound=1.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3):
+        if tails != "linear":
+            raise ValueError("The gfx950 spline kernel implements linear tails only")
+        if min_bin_width * num_bins > 1.0:
+            raise ValueError("Minimal bin width too large for the number of bins")
+        if min_bin_height * num_bins > 1.0:
+            raise ValueError("Minimal bin height too large for the number of bins")
+        self.num_bins = num_bins
+        self.tails = tails
+        self.tail_bound = tail_bound
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        super().__init__(mask, transform_net_create_fn, 3 * num_bins - 1)
+
+
+class CompositeTransform(_Container):
+    def __init__(self, transforms):
+        super().__init__()
+        self._transforms = nn.ModuleList(transforms)
+
+
+class StandardNormal(_Container):
+    """Base distribution N(0, I); no parameters."""
+
+    var = 1.0
+
+    def __init__(self, shape):
+        super().__init__()
+        self._shape = torch.Size(shape)
+
+
+def flatten_transforms(transform):
+    """Depth-first list of leaf transforms in forward order."""
+    if isinstance(transform, CompositeTransform) or hasattr(transform, "_transforms"):
+        out = []
+        for t in transform._transforms:
+            out.extend(flatten_transforms(t))
+        return out
+    return [transform]
+
+
+def _np(t):
+    return t.detach().to(torch.float32).cpu().numpy()
+
+
+def describe(flow):
+    """Module tree -> flow description for ``nessai_amd.pack.pack_flow``.
+
+    Duck-typed on attribute names, so any module tree with the reference's
+    structure can be described.
+    """
+    leaves = flatten_transforms(flow._transform)
+    desc = dict(transforms=[])
+    coupling = None
+    for t in leaves:
+        name = type(t).__name__
+        if hasattr(t, "_permutation"):
+            desc["transforms"].append(("permutation", t._permutation.detach().cpu().numpy()))
+        elif hasattr(t, "lower_entries"):
+            if hasattr(t, "host_matrices"):
+                W, W_inv, bias, ld = t.host_matrices()
+            else:  # structurally identical foreign module (tests)
+                with torch.no_grad():
+                    W = _np(t.weight())
+                    W_inv = _np(t.weight_inverse())
+                    bias = _np(t.bias)
+                    ld = np.float32(t.logabsdet().item())
+            desc["transforms"].append(("lu", W, W_inv, bias, ld))
+        elif hasattr(t, "transform_net"):
+            net = t.transform_net
+            if hasattr(net, "initial_layer"):
+                kind = "resnet"
+                layers = [net.initial_layer]
+                for block in net.blocks:
+                    if getattr(block, "use_batch_norm", False):
+                        raise ValueError("batch_norm_within_layers has no gfx950 kernel")
+                    layers.extend(block.linear_layers)
+                layers.append(net.final_layer)
+                hidden = net.initial_layer.out_features
+                scale_logits = hasattr(net, "hidden_features")
+            elif hasattr(net, "_input_layer"):
+                kind = "mlp"
+                layers = [net._input_layer, *net._hidden_layers, net._output_layer]
+                hidden = net._input_layer.out_features
+                scale_logits = hasattr(net, "hidden_features")
+            else:
+                raise ValueError(f"Unknown conditioner network {type(net).__name__}")
+            if "Rational" in name:
+                transform = "rq"
+            elif "Additive" in name:
+                transform = "additive"
+            elif "Affine" in name:
+                transform = "affine"
+            else:
+                raise ValueError(f"Unknown coupling transform {name}")
+            if hasattr(net, "activation_name"):
+                act = net.activation_name
+            elif kind == "resnet":
+                act = activation_name(net.blocks[0].activation) if len(net.blocks) else "relu"
+            else:
+                act = activation_name(net._activation)
+            this = dict(
+                D=int(len(t.identity_features) + len(t.transform_features)),
+                hidden=hidden,
+                net=kind,
+                transform=transform,
+                scale_logits=scale_logits,
+                activation=act,
+            )
+            if transform == "rq":
+                this.update(
+                    bins=t.num_bins,
+                    tail_bound=float(t.tail_bound),
+                    min_bin_width=float(t.min_bin_width),
+                    min_bin_height=float(t.min_bin_height),
+                    min_derivative=float(t.min_derivative),
+                )
+            if coupling is None:
+                coupling = this
+            elif coupling != this:
+                raise ValueError("All coupling layers of a flow must share one configuration")
+            desc["transforms"].append(
+                (
+                    "coupling",
+                    t.identity_features.detach().cpu().numpy().tolist(),
+                    t.transform_features.detach().cpu().numpy().tolist(),
+                    [(_np(l.weight), _np(l.bias)) for l in layers],
+                )
+            )
+        elif hasattr(t, "running_var") or hasattr(t, "log_scale"):
+            if hasattr(t, "host_tables"):
+                fwd, inv = t.host_tables()
+            elif hasattr(t, "running_var"):
+                fwd, inv = BatchNorm.host_tables(t)
+            else:
+                fwd, inv = ActNorm.host_tables(t)
+            desc["transforms"].append(("elementwise", fwd, inv))
+        else:
+            raise ValueError(f"Transform {name} has no gfx950 kernel")
+    if coupling is None:
+        raise ValueError("The flow has no coupling transform")
+    desc.update(coupling)
+    dist = getattr(flow, "_distribution", None)
+    desc["base_var"] = float(getattr(dist, "_var", getattr(dist, "var", 1.0)))
+    return desc

@@ -1,0 +1,81 @@
+"""ctypes binding of ``libnessai_amd.so`` (C ABI: ``include/nessai_amd.h``).
+
+The library is built in-tree by ``nessai_amd/csrc/Makefile`` (see
+``__graft_entry__.build``).  There is no fallback: if the shared object is
+missing or a call fails, a ``RuntimeError`` is raised.
+"""
+
+import ctypes
+import os
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnessai_amd.so")
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_ll = ctypes.c_longlong
+c_ull = ctypes.c_ulonglong
+c_double = ctypes.c_double
+c_size_t = ctypes.c_size_t
+
+SIGNATURES = {
+    "nsa_version": (c_int, []),
+    "nsa_last_error": (ctypes.c_char_p, []),
+    "nsa_flow_supported": (c_int, [c_int, c_int, c_int]),
+    "nsa_flow_run": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    ),
+    "nsa_populate_draw": (
+        c_int,
+        [c_void_p, c_void_p, c_ll, c_void_p, c_ull, c_ull, c_double, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    ),
+    "nsa_populate_weights": (c_int, [c_ll, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
+    "nsa_max_key_init": (c_ll, []),
+    "nsa_max_key_encode": (c_ll, [c_double]),
+    "nsa_max_key_decode": (c_double, [c_ll]),
+    "nsa_populate_accept_workspace": (c_size_t, [c_ll]),
+    "nsa_populate_accept": (
+        c_int,
+        [c_ll, c_int, c_void_p, c_void_p, c_ull, c_ull, c_void_p, c_void_p, c_ll, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+}
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (once) and declare the prototypes."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"nessai_amd HIP library not found at {_LIB_PATH}. Build it with "
+            "`make -C nessai_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().nsa_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(tensor):
+    """Device/host address of a tensor or ``None``."""
+    if tensor is None:
+        return None
+    return ctypes.c_void_p(tensor.data_ptr())

@@ -1,0 +1,424 @@
+"""Compile a flow description into the device image consumed by the HIP kernels.
+
+The image format is specified in ``nessai_amd/csrc/nsa_format.h``.  The packer
+is pure host-side bookkeeping (numpy): it folds permutations into column
+tables, lays the conditioner weights out in the lane order of
+``v_mfma_f32_32x32x2_f32`` and permutes the rows of each coupling layer's last
+linear layer so that every lane receives complete spline / affine parameter
+sets straight from the MFMA accumulators.
+
+A *flow description* is a dict::
+
+    dict(D=..., hidden=H, transform="rq"|"affine"|"additive", bins=K,
+         net="resnet"|"mlp", n_layers=L, activation="relu"|"tanh"|"silu",
+         tail_bound=5.0, min_bin_width=1e-3, min_bin_height=1e-3,
+         min_derivative=1e-3, scale_logits=True, base_var=1.0,
+         transforms=[...])           # forward order
+
+with transforms (mirroring the reference's ``CompositeTransform`` lists,
+``src/nessai/flows/realnvp.py:186-213``, ``src/nessai/flows/nsf.py:110-128``):
+
+* ``("permutation", perm)``                       out[:, i] = in[:, perm[i]]
+* ``("lu", W, W_inv, bias, logabsdet)``            y = W x + b (eval-mode cache)
+* ``("coupling", identity_idx, transform_idx, layers)`` with ``layers`` a list
+  of ``(weight, bias)`` float32 arrays: initial, hidden..., final
+* ``("elementwise", fwd, inv)`` with ``fwd = (a, b, c, d, logdet)`` meaning
+  ``y = ((x - a) / b) * c + d`` per feature (batch norm / act norm, eval mode)
+"""
+
+import math
+
+import numpy as np
+
+MAGIC = 0x3141534E
+VERSION = 3
+HEADER_WORDS = 32
+OP_WORDS = 4
+
+H_MAGIC, H_VERSION, H_D, H_HT, H_TRANSFORM, H_BINS = 0, 1, 2, 3, 4, 5
+H_NOPS_FWD, H_OPS_FWD, H_NOPS_INV, H_OPS_INV = 6, 7, 8, 9
+H_NSTAGES_FWD, H_STAGES_FWD, H_NSTAGES_INV, H_STAGES_INV = 10, 11, 12, 13
+H_MAX_STAGE, H_TOTAL, H_OUT_FWD, H_OUT_INV = 14, 15, 16, 17
+H_LOG_Z, H_TAIL_BOUND, H_MIN_BW, H_MIN_BH, H_MIN_D, H_EDGE_RAW = 18, 19, 20, 21, 22, 23
+H_LOGIT_DIV, H_ACT, H_NET, H_NLAYERS, H_BASE_INV_VAR = 24, 25, 26, 27, 28
+
+T_NONE, T_RQ, T_AFFINE, T_ADDITIVE = 0, 1, 2, 3
+TRANSFORMS = {"rq": T_RQ, "affine": T_AFFINE, "additive": T_ADDITIVE}
+ACTIVATIONS = {"relu": 0, "tanh": 1, "silu": 2, "swish": 2}
+NETS = {"resnet": 0, "mlp": 1}
+OP_COUPLING, OP_DENSE, OP_ELEMENTWISE = 1, 2, 3
+
+
+def _f32_bits(value):
+    return int(np.array([value], dtype=np.float32).view(np.uint32)[0])
+
+
+def pad4(n):
+    return (n + 3) & ~3
+
+
+def transform_policy(transform, bins):
+    """(tiles per chunk C, features per lane per chunk FPC, params per feature NP)."""
+    if transform == "rq":
+        n_params = 3 * bins - 1
+        fpc = 2 if bins == 8 else 1
+        return (fpc * n_params + 15) // 16, fpc, n_params
+    if transform == "affine":
+        return 1, 8, 2
+    if transform == "additive":
+        return 1, 16, 1
+    raise ValueError(f"unknown transform {transform}")
+
+
+def hidden_tiles(hidden):
+    ht = (hidden + 31) // 32
+    if ht == 3:
+        ht = 4
+    return ht
+
+
+def d_reg_feature(tile, reg, half):
+    """Feature index held by (tile, accumulator register, lane half) in the D layout."""
+    return 32 * tile + (reg & 3) + 8 * (reg >> 2) + 4 * half
+
+
+def _row_of_tile_row(i):
+    """Tile row i (0..31) -> (accumulator register, lane half)."""
+    return (i & 3) + 4 * (i >> 3), (i >> 2) & 1
+
+
+def pack_matrix(weight, out_rows, in_cols):
+    """Lay ``weight`` out for the MFMA A operand.
+
+    ``out_rows[ot][i]``  original output row for tile ``ot`` row ``i`` (or -1)
+    ``in_cols[s][half]`` original input column for step ``s`` (or -1)
+    Returns float32 ``[OT][n_steps/4][64][4]`` flattened.
+    """
+    n_ot = len(out_rows)
+    n_steps = len(in_cols)
+    assert n_steps % 4 == 0
+    w = np.zeros((n_ot, n_steps // 4, 64, 4), dtype=np.float32)
+    rows = np.asarray(out_rows, dtype=np.int64)  # [OT][32]
+    cols = np.asarray(in_cols, dtype=np.int64)  # [S][2]
+    for ot in range(n_ot):
+        for half in range(2):
+            r = rows[ot]  # [32]
+            c = cols[:, half]  # [S]
+            valid = (r[:, None] >= 0) & (c[None, :] >= 0)
+            block = np.where(valid, weight[np.maximum(r, 0)[:, None], np.maximum(c, 0)[None, :]], 0.0)
+            # block[i][s] -> w[ot][s//4][32*half + i][s%4]
+            w[ot, :, 32 * half : 32 * half + 32, :] = block.reshape(32, n_steps // 4, 4).transpose(1, 0, 2)
+    return w.reshape(-1)
+
+
+def pack_bias(bias, out_rows):
+    """bias laid out as [OT][half][16] following the D layout."""
+    n_ot = len(out_rows)
+    out = np.zeros((n_ot, 2, 16), dtype=np.float32)
+    for ot in range(n_ot):
+        for i in range(32):
+            row = out_rows[ot][i]
+            reg, half = _row_of_tile_row(i)
+            if row >= 0:
+                out[ot, half, reg] = bias[row]
+    return out.reshape(-1)
+
+
+def _reg_in_cols(n_tiles, limit):
+    """Input columns for layers fed from registers: step s=(tile, reg)."""
+    cols = []
+    for s in range(16 * n_tiles):
+        pair = []
+        for half in range(2):
+            f = d_reg_feature(s >> 4, s & 15, half)
+            pair.append(f if f < limit else -1)
+        cols.append(pair)
+    return cols
+
+
+def _plain_out_rows(n_tiles, limit):
+    return [[(32 * ot + i) if (32 * ot + i) < limit else -1 for i in range(32)] for ot in range(n_tiles)]
+
+
+def _stage(*sections):
+    """Concatenate sections (each padded to 4 words) and pad to 256 words."""
+    parts = []
+    for sec in sections:
+        sec = np.ascontiguousarray(sec)
+        if sec.dtype == np.float32:
+            words = sec.view(np.uint32)
+        elif sec.dtype == np.int32:
+            words = sec.view(np.uint32)
+        else:
+            raise TypeError(sec.dtype)
+        pad = pad4(len(words)) - len(words)
+        parts.append(words)
+        if pad:
+            parts.append(np.zeros(pad, dtype=np.uint32))
+    blob = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32)
+    pad = (-len(blob)) % 256
+    if pad:
+        blob = np.concatenate([blob, np.zeros(pad, dtype=np.uint32)])
+    return blob
+
+
+class _CouplingBlobs:
+    """Direction-independent packed weights of one coupling layer."""
+
+    def __init__(self, desc, identity_idx, transform_idx, layers):
+        self.d_id = len(identity_idx)
+        self.d_tr = len(transform_idx)
+        hidden = desc["hidden"]
+        ht = hidden_tiles(hidden)
+        n_tiles_c, fpc, n_params = transform_policy(desc["transform"], desc.get("bins", 0))
+        self.n_steps0 = pad4((self.d_id + 1) // 2)
+        self.n_chunks = (self.d_tr + 2 * fpc - 1) // (2 * fpc)
+        self.fpc = fpc
+
+        w0, b0 = layers[0]
+        assert w0.shape == (hidden, self.d_id), (w0.shape, hidden, self.d_id)
+        in_cols0 = [[(2 * s + h) if (2 * s + h) < self.d_id else -1 for h in range(2)] for s in range(self.n_steps0)]
+        self.layer0 = (
+            pack_bias(b0, _plain_out_rows(ht, hidden)),
+            pack_matrix(w0, _plain_out_rows(ht, hidden), in_cols0),
+        )
+
+        self.hidden_layers = []
+        for w, b in layers[1:-1]:
+            assert w.shape == (hidden, hidden)
+            self.hidden_layers.append(
+                (
+                    pack_bias(b, _plain_out_rows(ht, hidden)),
+                    pack_matrix(w, _plain_out_rows(ht, hidden), _reg_in_cols(ht, hidden)),
+                )
+            )
+
+        wf, bf = layers[-1]
+        assert wf.shape[1] == hidden
+        self.chunks = []  # (feature slots [2*fpc] (index into transform_idx or -1), bias, W)
+        for c in range(self.n_chunks):
+            out_rows = []
+            for t in range(n_tiles_c):
+                rows = []
+                for i in range(32):
+                    reg, half = _row_of_tile_row(i)
+                    v = 16 * t + reg
+                    q, p = self._decode(desc["transform"], v, n_params)
+                    m = c * 2 * fpc + half * fpc + q
+                    if q < fpc and m < self.d_tr:
+                        rows.append(self._orig_row(desc["transform"], m, p, n_params))
+                    else:
+                        rows.append(-1)
+                out_rows.append(rows)
+            slots = []
+            for half in range(2):
+                for q in range(fpc):
+                    m = c * 2 * fpc + half * fpc + q
+                    slots.append(m if m < self.d_tr else -1)
+            self.chunks.append(
+                (slots, pack_bias(bf, out_rows), pack_matrix(wf, out_rows, _reg_in_cols(ht, hidden)))
+            )
+
+    @staticmethod
+    def _decode(transform, v, n_params):
+        if transform == "rq":
+            return v // n_params, v % n_params
+        if transform == "affine":
+            return v >> 1, v & 1
+        return v, 0
+
+    def _orig_row(self, transform, m, p, n_params):
+        if transform == "rq":
+            return m * n_params + p
+        if transform == "affine":
+            return p * self.d_tr + m  # shift block first, raw-scale block second
+        return m
+
+
+def pack_flow(desc):
+    """Return the flow image as a ``numpy.uint32`` array."""
+    D = int(desc["D"])
+    hidden = int(desc["hidden"])
+    transform = desc["transform"]
+    bins = int(desc.get("bins", 0)) if transform == "rq" else 0
+    ht = hidden_tiles(hidden)
+    if ht > 4:
+        raise ValueError(f"hidden width {hidden} > 128 is not supported by the gfx950 kernels")
+    if D < 2:
+        raise ValueError("at least two features are required")
+    n_tiles_c, fpc, n_params = transform_policy(transform, bins)
+    tabw = pad4(2 * fpc)
+    D4 = pad4(D)
+
+    blobs = []  # list of uint32 arrays
+    blob_offsets = []
+
+    def add_blob(blob):
+        blobs.append(blob)
+        blob_offsets.append(None)
+        return len(blobs) - 1
+
+    def build_direction(inverse):
+        """Returns (ops [n][4] uint32, stage blob ids, out table)."""
+        cur = list(range(D))  # physical column of logical feature i
+        ops = []
+        stages = []
+        seq = list(desc["transforms"])
+        if inverse:
+            seq = seq[::-1]
+        for tr in seq:
+            kind = tr[0]
+            if kind == "permutation":
+                perm = np.asarray(tr[1], dtype=np.int64)
+                if inverse:
+                    perm = np.argsort(perm)
+                cur = [cur[int(perm[i])] for i in range(D)]
+            elif kind == "lu":
+                _, W, W_inv, bias, logabsdet = tr
+                if D > 64:
+                    raise ValueError("LU-linear transforms support at most 64 features")
+                n_steps = pad4((D + 1) // 2)
+                n_ot = (D + 31) // 32
+                in_cols = [[(2 * s + h) if (2 * s + h) < D else -1 for h in range(2)] for s in range(n_steps)]
+                in_tab = np.full(2 * n_steps, -1, dtype=np.int32)
+                pre = np.zeros(2 * n_steps, dtype=np.float32)
+                for k in range(D):
+                    in_tab[k] = cur[k]
+                if inverse:
+                    mat = np.asarray(W_inv, dtype=np.float32)
+                    pre[:D] = np.asarray(bias, dtype=np.float32)
+                    post = np.zeros(D, dtype=np.float32)
+                    ld = -np.float32(logabsdet)
+                else:
+                    mat = np.asarray(W, dtype=np.float32)
+                    post = np.asarray(bias, dtype=np.float32)
+                    ld = np.float32(logabsdet)
+                out_rows = _plain_out_rows(n_ot, D)
+                blob = _stage(in_tab, pre, pack_bias(post, out_rows), pack_matrix(mat, out_rows, in_cols))
+                stages.append(add_blob(blob))
+                ops.append([OP_DENSE, n_steps, n_ot, _f32_bits(ld)])
+                cur = list(range(D))
+            elif kind == "coupling":
+                _, identity_idx, transform_idx, packed = tr
+                id_tab = np.full(2 * packed.n_steps0, -1, dtype=np.int32)
+                for k, f in enumerate(identity_idx):
+                    id_tab[k] = cur[int(f)]
+                stages.append(add_blob(_stage(id_tab, *packed.layer0)))
+                for bias, w in packed.hidden_layers:
+                    stages.append(add_blob(_stage(bias, w)))
+                for slots, bias, w in packed.chunks:
+                    tr_tab = np.full(tabw, -1, dtype=np.int32)
+                    for k, m in enumerate(slots):
+                        if m >= 0:
+                            tr_tab[k] = cur[int(transform_idx[m])]
+                    stages.append(add_blob(_stage(tr_tab, bias, w)))
+                ops.append([OP_COUPLING, packed.n_steps0, packed.n_chunks, 0])
+            elif kind == "elementwise":
+                a, b, c, d, ld = tr[2] if inverse else tr[1]
+                tabs = np.zeros((4, D4), dtype=np.float32)
+                tabs[1, :] = 1.0
+                tabs[2, :] = 1.0
+                for i in range(D):
+                    col = cur[i]
+                    tabs[0, col] = a[i]
+                    tabs[1, col] = b[i]
+                    tabs[2, col] = c[i]
+                    tabs[3, col] = d[i]
+                stages.append(add_blob(_stage(tabs.reshape(-1))))
+                ops.append([OP_ELEMENTWISE, 0, 0, _f32_bits(ld)])
+            else:
+                raise ValueError(f"unknown transform kind {kind}")
+        return np.asarray(ops, dtype=np.uint32).reshape(-1, OP_WORDS), stages, np.asarray(cur, dtype=np.int32)
+
+    # pack the coupling weights once (shared by both directions)
+    prepared = []
+    n_net_layers = None
+    for tr in desc["transforms"]:
+        if tr[0] == "coupling":
+            _, identity_idx, transform_idx, layers = tr
+            layers = [(np.asarray(w, dtype=np.float32), np.asarray(b, dtype=np.float32)) for w, b in layers]
+            prepared.append(("coupling", list(identity_idx), list(transform_idx), _CouplingBlobs(desc, identity_idx, transform_idx, layers)))
+            n_hidden = len(layers) - 2
+            if desc["net"] == "resnet":
+                assert n_hidden % 2 == 0
+                nl = n_hidden // 2
+            else:
+                nl = n_hidden + 1
+            if n_net_layers is None:
+                n_net_layers = nl
+            elif n_net_layers != nl:
+                raise ValueError("all coupling layers must share one conditioner depth")
+        else:
+            prepared.append(tr)
+    desc = dict(desc, transforms=prepared)
+
+    ops_fwd, stages_fwd, out_fwd = build_direction(False)
+    ops_inv, stages_inv, out_inv = build_direction(True)
+
+    # layout
+    pos = HEADER_WORDS
+    off_ops_fwd = pos
+    pos += ops_fwd.size
+    off_ops_inv = pos
+    pos += ops_inv.size
+    off_st_fwd = pos
+    pos += 2 * len(stages_fwd)
+    off_st_inv = pos
+    pos += 2 * len(stages_inv)
+    off_out_fwd = pos
+    pos += D4
+    off_out_inv = pos
+    pos += D4
+    pos = (pos + 255) & ~255  # blobs start 1 KiB aligned
+    for i, blob in enumerate(blobs):
+        blob_offsets[i] = pos
+        pos += len(blob)
+    total = pos
+    max_stage = max(len(b) for b in blobs) if blobs else 256
+
+    img = np.zeros(total, dtype=np.uint32)
+    img[H_MAGIC] = MAGIC
+    img[H_VERSION] = VERSION
+    img[H_D] = D
+    img[H_HT] = ht
+    img[H_TRANSFORM] = TRANSFORMS[transform]
+    img[H_BINS] = bins
+    img[H_NOPS_FWD] = len(ops_fwd)
+    img[H_OPS_FWD] = off_ops_fwd
+    img[H_NOPS_INV] = len(ops_inv)
+    img[H_OPS_INV] = off_ops_inv
+    img[H_NSTAGES_FWD] = len(stages_fwd)
+    img[H_STAGES_FWD] = off_st_fwd
+    img[H_NSTAGES_INV] = len(stages_inv)
+    img[H_STAGES_INV] = off_st_inv
+    img[H_MAX_STAGE] = max_stage
+    img[H_TOTAL] = total
+    img[H_OUT_FWD] = off_out_fwd
+    img[H_OUT_INV] = off_out_inv
+    base_var = float(desc.get("base_var", 1.0))
+    img[H_LOG_Z] = _f32_bits(0.5 * D * math.log(2 * math.pi * base_var))
+    img[H_BASE_INV_VAR] = _f32_bits(1.0 / base_var)
+    min_d = float(desc.get("min_derivative", 1e-3))
+    img[H_TAIL_BOUND] = _f32_bits(desc.get("tail_bound", 5.0))
+    img[H_MIN_BW] = _f32_bits(desc.get("min_bin_width", 1e-3))
+    img[H_MIN_BH] = _f32_bits(desc.get("min_bin_height", 1e-3))
+    img[H_MIN_D] = _f32_bits(min_d)
+    img[H_EDGE_RAW] = _f32_bits(math.log(math.exp(1 - min_d) - 1))
+    img[H_LOGIT_DIV] = _f32_bits(math.sqrt(hidden) if desc.get("scale_logits", True) else 1.0)
+    img[H_ACT] = ACTIVATIONS[desc.get("activation", "relu")]
+    img[H_NET] = NETS[desc.get("net", "resnet")]
+    img[H_NLAYERS] = n_net_layers if n_net_layers is not None else 0
+
+    img[off_ops_fwd : off_ops_fwd + ops_fwd.size] = ops_fwd.reshape(-1)
+    img[off_ops_inv : off_ops_inv + ops_inv.size] = ops_inv.reshape(-1)
+    for k, bid in enumerate(stages_fwd):
+        img[off_st_fwd + 2 * k] = blob_offsets[bid]
+        img[off_st_fwd + 2 * k + 1] = len(blobs[bid])
+    for k, bid in enumerate(stages_inv):
+        img[off_st_inv + 2 * k] = blob_offsets[bid]
+        img[off_st_inv + 2 * k + 1] = len(blobs[bid])
+    img[off_out_fwd : off_out_fwd + D] = out_fwd.view(np.uint32)
+    img[off_out_inv : off_out_inv + D] = out_inv.view(np.uint32)
+    for i, blob in enumerate(blobs):
+        img[blob_offsets[i] : blob_offsets[i] + len(blob)] = blob
+    return img

@@ -1,0 +1,233 @@
+"""Lane-level numpy emulation of ``nsa_flow_kernel`` (test infrastructure).
+
+Interprets a flow image exactly as the gfx950 kernel does — stage blobs, column
+tables, MFMA lane layouts (A[i][k] in lane 32k+i, B[k][j] in lane 32k+j, D[i][j]
+in lane 32*((i>>2)&1)+j register (i&3)+4*(i>>3)) — so that the host packer
+(``nessai_amd/pack.py``) and the kernel's data flow can be validated against the
+oracle on a machine without a GPU.  The element-wise spline / affine maths is
+delegated to the oracle's functions: what is under test here is the layout.
+"""
+
+import numpy as np
+import torch
+
+from nessai_amd import pack as P
+from oracle.nflows_restated import splines
+
+
+def _f32(bits):
+    return np.array([bits], dtype=np.uint32).view(np.float32)[0]
+
+
+def mfma_32x32x2(a, b, c):
+    """a, b: [64] per-lane scalars; c: [64][16] accumulators -> new [64][16]."""
+    A = np.stack([a[:32], a[32:]], axis=1)  # A[i][k]
+    B = np.stack([b[:32], b[32:]], axis=0)  # B[k][j]
+    Dm = (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32)  # [i][j]
+    out = c.copy()
+    for lane in range(64):
+        half, j = lane >> 5, lane & 31
+        for r in range(16):
+            i = (r & 3) + 8 * (r >> 2) + 4 * half
+            out[lane, r] += Dm[i, j]
+    return out
+
+
+class Emulator:
+    def __init__(self, image):
+        self.img = np.asarray(image, dtype=np.uint32)
+        h = self.img
+        assert h[P.H_MAGIC] == P.MAGIC
+        self.D = int(h[P.H_D])
+        self.HT = int(h[P.H_HT])
+        self.transform = int(h[P.H_TRANSFORM])
+        self.bins = int(h[P.H_BINS])
+        self.act = int(h[P.H_ACT])
+        self.net = int(h[P.H_NET])
+        self.n_layers = int(h[P.H_NLAYERS])
+        name = {1: "rq", 2: "affine", 3: "additive"}[self.transform]
+        self.C, self.FPC, self.NP = P.transform_policy(name, self.bins)
+
+    # -- helpers ---------------------------------------------------------------
+    def _stage_words(self, inverse, s):
+        tab = int(self.img[P.H_STAGES_INV if inverse else P.H_STAGES_FWD])
+        off, n = int(self.img[tab + 2 * s]), int(self.img[tab + 2 * s + 1])
+        return self.img[off : off + n]
+
+    def _bias(self, words_f32, n_ot):
+        acc = np.zeros((n_ot, 64, 16), dtype=np.float32)
+        for ot in range(n_ot):
+            for lane in range(64):
+                half = lane >> 5
+                acc[ot, lane, :] = words_f32[ot * 32 + half * 16 : ot * 32 + half * 16 + 16]
+        return acc
+
+    def _dense(self, w, n_ot, n_steps, b_of_step, acc):
+        """w: float32 [n_ot][n_steps/4][64][4]; b_of_step(s) -> [64] per-lane B values."""
+        w = w.reshape(n_ot, n_steps // 4, 64, 4)
+        for s in range(n_steps):
+            b = b_of_step(s)
+            for ot in range(n_ot):
+                a = w[ot, s // 4, :, s % 4]
+                acc[ot] = mfma_32x32x2(a, b, acc[ot])
+        return acc
+
+    def _activate(self, x):
+        if self.act == 0:
+            return np.maximum(x, 0.0).astype(np.float32)
+        if self.act == 1:
+            return np.tanh(x).astype(np.float32)
+        return (x * (1.0 / (1.0 + np.exp(-x)))).astype(np.float32)
+
+    # -- one tile ----------------------------------------------------------------
+    def run_tile(self, x_tile, inverse):
+        """x_tile: [32][D] float32 -> (out [32][D], logdet [32])."""
+        img = self.img
+        D, HT = self.D, self.HT
+        xt = x_tile.astype(np.float32).copy()
+        ops_off = int(img[P.H_OPS_INV if inverse else P.H_OPS_FWD])
+        n_ops = int(img[P.H_NOPS_INV if inverse else P.H_NOPS_FWD])
+        out_off = int(img[P.H_OUT_INV if inverse else P.H_OUT_FWD])
+        out_tab = img[out_off : out_off + D].view(np.int32)
+        logdet = np.zeros(64, dtype=np.float32)
+        lanes = np.arange(64)
+        half_of = lanes >> 5
+        row_of = lanes & 31
+        stage = 0
+        for o in range(n_ops):
+            op = img[ops_off + 4 * o : ops_off + 4 * o + 4]
+            kind = int(op[0])
+            if kind == P.OP_COUPLING:
+                n_steps0, n_chunks = int(op[1]), int(op[2])
+                st = self._stage_words(inverse, stage)
+                stage += 1
+                id_tab = st[: 2 * n_steps0].view(np.int32)
+                fl = st.view(np.float32)
+                bias = fl[2 * n_steps0 : 2 * n_steps0 + 32 * HT]
+                w = fl[2 * n_steps0 + 32 * HT : 2 * n_steps0 + 32 * HT + HT * n_steps0 * 64]
+
+                def b0(s):
+                    cols = id_tab[2 * s + half_of]
+                    vals = xt[row_of, np.maximum(cols, 0)]
+                    return np.where(cols >= 0, vals, 0.0).astype(np.float32)
+
+                acc = self._dense(w, HT, n_steps0, b0, self._bias(bias, HT))
+                h = np.concatenate([acc[ot] for ot in range(HT)], axis=1)  # [64][16*HT]
+
+                def hidden(inp):
+                    nonlocal stage
+                    st = self._stage_words(inverse, stage).view(np.float32)
+                    stage += 1
+                    bias = st[: 32 * HT]
+                    w = st[32 * HT : 32 * HT + HT * 16 * HT * 64]
+                    acc = self._dense(w, HT, 16 * HT, lambda s: inp[:, s], self._bias(bias, HT))
+                    return np.concatenate([acc[ot] for ot in range(HT)], axis=1)
+
+                if self.net == 0:
+                    for _ in range(self.n_layers):
+                        t = self._activate(h)
+                        t = self._activate(hidden(t))
+                        h = (h + hidden(t)).astype(np.float32)
+                else:
+                    h = self._activate(h)
+                    for _ in range(1, self.n_layers):
+                        h = self._activate(hidden(h))
+
+                tabw = P.pad4(2 * self.FPC)
+                for _c in range(n_chunks):
+                    st = self._stage_words(inverse, stage)
+                    stage += 1
+                    tr_tab = st[:tabw].view(np.int32)
+                    fl = st.view(np.float32)
+                    bias = fl[tabw : tabw + 32 * self.C]
+                    w = fl[tabw + 32 * self.C : tabw + 32 * self.C + self.C * 16 * HT * 64]
+                    acc = self._dense(w, self.C, 16 * HT, lambda s: h[:, s], self._bias(bias, self.C))
+                    v = np.concatenate([acc[t] for t in range(self.C)], axis=1)  # [64][16*C]
+                    for q in range(self.FPC):
+                        cols = tr_tab[half_of * self.FPC + q]
+                        ok = cols >= 0
+                        if not ok.any():
+                            continue
+                        l_ok = lanes[ok]
+                        x = xt[row_of[ok], cols[ok]]
+                        params = v[l_ok, q * self.NP : (q + 1) * self.NP]
+                        y, ld = self._transform(params, x, inverse)
+                        xt[row_of[ok], cols[ok]] = y
+                        logdet[l_ok] += ld
+            elif kind == P.OP_DENSE:
+                n_steps, n_ot = int(op[1]), int(op[2])
+                st = self._stage_words(inverse, stage)
+                stage += 1
+                in_tab = st[: 2 * n_steps].view(np.int32)
+                fl = st.view(np.float32)
+                pre = fl[2 * n_steps : 4 * n_steps]
+                bias = fl[4 * n_steps : 4 * n_steps + 32 * n_ot]
+                w = fl[4 * n_steps + 32 * n_ot : 4 * n_steps + 32 * n_ot + n_ot * n_steps * 64]
+
+                def bd(s):
+                    idx = 2 * s + half_of
+                    cols = in_tab[idx]
+                    vals = xt[row_of, np.maximum(cols, 0)] - pre[idx]
+                    return np.where(cols >= 0, vals, 0.0).astype(np.float32)
+
+                acc = self._dense(w, n_ot, n_steps, bd, self._bias(bias, n_ot))
+                new = xt.copy()
+                for ot in range(n_ot):
+                    for lane in range(64):
+                        for r in range(16):
+                            i = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+                            if i < D:
+                                new[lane & 31, i] = acc[ot][lane, r]
+                xt = new
+                logdet[:32] += _f32(op[3])
+            else:
+                st = self._stage_words(inverse, stage).view(np.float32)
+                stage += 1
+                D4 = P.pad4(D)
+                a, b, c, d = (st[k * D4 : k * D4 + D] for k in range(4))
+                xt = (((xt - a) / b) * c + d).astype(np.float32)
+                logdet[:32] += _f32(op[3])
+        ld = logdet[:32] + logdet[32:]
+        return xt[:, out_tab], ld
+
+    def _transform(self, params, x, inverse):
+        img = self.img
+        params = torch.from_numpy(np.ascontiguousarray(params))
+        x = torch.from_numpy(np.ascontiguousarray(x))
+        if self.transform == P.T_RQ:
+            K = self.bins
+            div = float(_f32(img[P.H_LOGIT_DIV]))
+            uw = params[:, None, :K] / div
+            uh = params[:, None, K : 2 * K] / div
+            ud = params[:, None, 2 * K :]
+            y, ld = splines.unconstrained_rational_quadratic_spline(
+                x[:, None], uw, uh, ud, inverse=inverse, tails="linear",
+                tail_bound=float(_f32(img[P.H_TAIL_BOUND])),
+                min_bin_width=float(_f32(img[P.H_MIN_BW])),
+                min_bin_height=float(_f32(img[P.H_MIN_BH])),
+                min_derivative=float(_f32(img[P.H_MIN_D])),
+            )
+            return y[:, 0].numpy(), ld[:, 0].numpy()
+        if self.transform == P.T_AFFINE:
+            shift = params[:, 0]
+            scale = torch.sigmoid(params[:, 1] + 2) + 1e-3
+            if inverse:
+                return ((x - shift) / scale).numpy(), (-torch.log(scale)).numpy()
+            return (x * scale + shift).numpy(), torch.log(scale).numpy()
+        shift = params[:, 0]
+        y = x - shift if inverse else x + shift
+        return y.numpy(), np.zeros(len(x), dtype=np.float32)
+
+    def run(self, x, inverse):
+        x = np.asarray(x, dtype=np.float32)
+        n = x.shape[0]
+        out = np.zeros_like(x)
+        ld = np.zeros(n, dtype=np.float32)
+        for r0 in range(0, n, 32):
+            tile = np.zeros((32, self.D), dtype=np.float32)
+            m = min(32, n - r0)
+            tile[:m] = x[r0 : r0 + m]
+            o, l = self.run_tile(tile, inverse)
+            out[r0 : r0 + m] = o[:m]
+            ld[r0 : r0 + m] = l[:m]
+        return out, ld
