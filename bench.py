@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""Headline benchmark: accepted live points / second in ``FlowProposal.populate()``.
+
+Workload (BASELINE.json configs[2]): 32-D Rosenbrock, uniform
+prior on [-5, 5]^32, NeuralSplineFlow (8 RQ bins, 6 coupling layers, 2 residual
+blocks, 64 hidden), nlive = poolsize = 2000, populate draw batch = 1e6, default
+constant-volume truncation, z-score reparameterisation.  Weights: the flow
+trained with the reference schedule on 2000 synthetic live points
+(tests/golden/make_c3_weights.py) so that the acceptance rate is realistic.
+
+A *step* is one ``populate(n_samples=2000)`` call: draw -> truncate -> inverse
+flow -> rescale -> prior bounds -> weights -> rejection -> compaction -> live
+points, looping over 1e6-row draw batches until 2000 points are accepted.  The
+timed window is the reference's ``population_time`` window
+(flowproposal.py:400-518): the likelihood evaluation of the pool is excluded.
+
+``python bench.py --gpus N --steps K --warmup W`` (N > 1 under torchrun: one
+rank per GPU, every draw batch is sharded over the ranks - 1e6 rows per rank -
+with one all-reduce(max) + one all-gather per pass).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+DIMS = 32
+NLIVE = 2000
+DRAWSIZE = 1_000_000
+FLOPS_PER_ROW = 491_520          # conditioner GEMM FLOPs per proposed row
+PEAK_F32_MFMA_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
+FLOW_CONFIG = dict(ftype="nsf", n_neurons=64, n_blocks=6, n_layers=2, num_bins=8)
+
+
+def load_fixture():
+    data = np.load(os.path.join(ROOT, "tests", "golden", "c3_trained.npz"))
+    state = {k[len("state/"):]: torch.from_numpy(data[k]) for k in data.files if k.startswith("state/")}
+    return state, data["shift"], data["scale"]
+
+
+def build_proposal(rank, world, device):
+    from nessai_amd.model import RosenbrockModel
+    from nessai_amd.proposal import FlowProposal
+
+    state, shift, scale = load_fixture()
+    model = RosenbrockModel(DIMS)
+    prop = FlowProposal(
+        model,
+        rng=np.random.default_rng(1451),
+        flow_config=FLOW_CONFIG,
+        training_config=dict(device_tag=str(device)),
+        poolsize=NLIVE,
+        drawsize=DRAWSIZE * world,
+        device_seed=1451,
+        shard=world > 1,
+        output=os.path.join("/tmp", f"nessai_amd_bench_{os.getpid()}"),
+    )
+    prop.initialise()
+    prop.flow.model.load_state_dict(state)
+    prop.flow.model.eval()
+    prop.set_rescaling_constants(shift, scale)
+    return prop
+
+
+def time_draw_kernel(prop, launches=10):
+    """Average duration of the dominant kernel (fused draw+inverse-flow), HIP events
+    on the stream it is launched on (torch's current stream)."""
+    n = DRAWSIZE
+    buf = prop._get_buffers(n, NLIVE)
+    for _ in range(2):
+        prop._launch_draw(n, None, 0, prop.fixed_radius, buf["x64"], buf["log_q"], None)
+    torch.cuda.synchronize()
+    events = []
+    for i in range(launches):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        prop._launch_draw(n, None, i * n, prop.fixed_radius, buf["x64"], buf["log_q"], None)
+        e.record()
+        events.append((s, e))
+    torch.cuda.synchronize()
+    ms = [s.elapsed_time(e) for s, e in events]
+    return float(np.mean(ms)), float(np.min(ms))
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference path) timed on this host with
+    ONE torch thread - the reference's default (src/nessai/flowsampler.py:98)."""
+    from oracle import proposal as OP
+
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        state, shift, scale = load_fixture()
+        fm = OP.OracleFlowModel(
+            dict(n_inputs=DIMS, n_neurons=64, n_blocks=6, n_layers=2, ftype="nsf"),
+            rng=np.random.default_rng(1451),
+        )
+        fm.model.load_state_dict(state)
+        fm.model.eval()
+        model = OP.RosenbrockModel(DIMS)
+        sample_draw = 100_000
+        prop = OP.OracleFlowProposal(model, fm, rng=np.random.default_rng(1451), poolsize=NLIVE,
+                                     drawsize=sample_draw)
+        for i, n in enumerate(model.names):
+            prop.shift[n] = float(shift[i])
+            prop.scale[n] = float(scale[i])
+        torch.manual_seed(1451)
+        t = time.perf_counter()
+        prop.populate(n_samples=NLIVE, max_samples=sample_draw - 1)  # exactly one pass
+        dt = time.perf_counter() - t
+        return {
+            "value": prop.n_accepted / dt,
+            "unit": "accepted points/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"one populate pass of {sample_draw} draws (of the 1e6-row batch), "
+                      f"{prop.n_accepted} accepted in {dt:.1f} s",
+            "proposed_rows_per_s": prop.n_proposed / dt,
+            "acceptance": prop.population_acceptance,
+            "host_cpus": os.cpu_count(),
+        }
+    finally:
+        torch.set_num_threads(threads)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torchrun for --gpus > 1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    prop = build_proposal(rank, world, device)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        prop.populate(None, n_samples=NLIVE, max_samples=10**12)
+    barrier()
+    t0 = time.perf_counter()
+    accepted = proposed = 0
+    for _ in range(args.steps):
+        prop.populate(None, n_samples=NLIVE, max_samples=10**12)
+        accepted += prop.n_accepted
+        proposed += prop.n_proposed
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # likelihood evaluation of the pool is outside the reference's window: subtract nothing,
+    # report the conservative wall time of whole populate() calls (it includes logL of 2000 rows)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms, kernel_ms_min = time_draw_kernel(prop)
+    achieved = FLOPS_PER_ROW * DRAWSIZE / (kernel_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "accepted live points/sec in FlowProposal.populate(), 32-D Rosenbrock nlive=2000",
+            "value": accepted / elapsed,
+            "unit": "accepted points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "32-D Rosenbrock, NeuralSplineFlow (8 RQ bins, 6 coupling layers, "
+                            "2x64 residual conditioner), nlive=poolsize=2000, populate batch=1e6 per GPU",
+                "drawsize_per_gpu": DRAWSIZE,
+                "n_samples": NLIVE,
+                "weights": "trained on 2000 synthetic live points (tests/golden/c3_trained.npz)",
+                "parallelism": f"draw batch sharded over {world} GPU(s)",
+            },
+            "proposed_rows_per_s": proposed / elapsed,
+            "acceptance": accepted / proposed,
+            "passes_per_step": proposed / (DRAWSIZE * world) / args.steps,
+            "roofline": {
+                "kernel": "nsa_flow_kernel<2, NsaRQ<8>> (fused draw + inverse flow + rescale + bounds + log_q)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None,
+                "kernel_ms_avg": kernel_ms,
+                "kernel_ms_min": kernel_ms_min,
+                "rows_per_launch": DRAWSIZE,
+                "flops_per_row": FLOPS_PER_ROW,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

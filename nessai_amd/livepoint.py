@@ -1,0 +1,72 @@
+"""Live-point structured arrays — the wire format between proposal and sampler.
+
+Same layout as the reference (``src/nessai/livepoint.py:74-155``,
+``src/nessai/config.py:22-60``): one ``f8`` field per model parameter followed
+by the non-sampling fields ``logP`` (f8), ``logL`` (f8) and ``it`` (i4).
+"""
+
+import numpy as np
+
+NON_SAMPLING_PARAMETERS = ["logP", "logL", "it"]
+NON_SAMPLING_DTYPES = ["f8", "f8", "i4"]
+NON_SAMPLING_DEFAULTS = [np.nan, np.nan, 0]
+DEFAULT_FLOAT_DTYPE = "f8"
+
+
+def get_dtype(names, array_dtype=DEFAULT_FLOAT_DTYPE, non_sampling_parameters=True):
+    dtype = [(n, array_dtype) for n in names]
+    if non_sampling_parameters:
+        dtype += list(zip(NON_SAMPLING_PARAMETERS, NON_SAMPLING_DTYPES))
+    return np.dtype(dtype)
+
+
+def empty_structured_array(n, names=None, dtype=None, non_sampling_parameters=True):
+    """Structured array with parameters NaN and non-sampling fields at their defaults."""
+    if dtype is None:
+        dtype = get_dtype(names, non_sampling_parameters=non_sampling_parameters)
+    else:
+        dtype = np.dtype(dtype)
+        names = [nm for nm in dtype.names if nm not in NON_SAMPLING_PARAMETERS]
+    out = np.empty(n, dtype=dtype)
+    if n == 0:
+        return out
+    for nm in names:
+        out[nm] = np.nan
+    if non_sampling_parameters:
+        for nm, v in zip(NON_SAMPLING_PARAMETERS, NON_SAMPLING_DEFAULTS):
+            out[nm] = v
+    return out
+
+
+def live_points_to_array(live_points, names=None, copy=False):
+    """Structured -> plain ``(N, D)`` float64 array (``livepoint.py:158-190``)."""
+    if names is None:
+        names = [n for n in live_points.dtype.names if n not in NON_SAMPLING_PARAMETERS]
+    live_points = np.atleast_1d(live_points)
+    return np.stack([np.asarray(live_points[n], dtype=np.float64) for n in names], axis=-1)
+
+
+def numpy_array_to_live_points(array, names):
+    """Plain ``(N, D)`` array -> structured live points (``livepoint.py:227-258``)."""
+    array = np.atleast_2d(np.asarray(array, dtype=np.float64))
+    out = empty_structured_array(array.shape[0], names=names)
+    for i, n in enumerate(names):
+        out[n] = array[:, i]
+    return out
+
+
+def array_to_live_points_fast(array, names):
+    """Accepted rows ``(M, D)`` float64 -> structured array in one copy.
+
+    The (D f8 | logP f8 | logL f8 | it i4) record is filled through an
+    unstructured float64 view of the parameter block instead of a Python loop
+    over fields.
+    """
+    array = np.ascontiguousarray(array, dtype=np.float64)
+    m, d = array.shape
+    out = empty_structured_array(m, names=names)
+    if m:
+        itemsize = out.dtype.itemsize
+        block = np.ndarray((m, d), dtype=np.float64, buffer=out.data, strides=(itemsize, 8))
+        block[:] = array
+    return out

@@ -1,0 +1,609 @@
+"""``FlowProposal`` with the populate loop fused on the MI355X.
+
+Counterpart of the reference's ``nessai.proposal.FlowProposal``
+(``src/nessai/proposal/flowproposal/flowproposal.py:29`` and its base
+``proposal/flowproposal/base.py:40``) for the default configuration of the
+benchmark configs: z-score reparameterisation
+(``reparameterisations/rescale.py:119-312``), latent-radius truncation
+(``truncation.py:201-365``, constant-volume by default, ``truncation.py:15-21``)
+and rejection sampling against the prior.  The sampler-facing protocol is the
+reference's (SURVEY.md §8b surface B3): ``initialise()``, ``train(live_points)``,
+``draw(worst_point)``, ``populate(...)``, ``populated``, ``indices``,
+``samples``, ``x``, ``population_acceptance``, ``population_time``.
+
+One pass of the populate loop is three device steps and one small copy:
+
+1. ``nsa_populate_draw``  — Philox latent draw, radius truncation, inverse
+   flow, inverse z-score, prior bounds, ``log_q`` (one fused kernel);
+2. ``nsa_populate_weights`` — ``log_w = log_prior - log_q`` and its maximum
+   (all-reduced over ranks when the draw batch is sharded);
+3. ``nsa_populate_accept`` — ``log_w - max > log(u)`` and order-preserving
+   compaction;
+4. the accepted rows only are copied to the host and packed into live points.
+"""
+
+import datetime
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import lib
+from .flowmodel import FlowModel
+from .livepoint import (
+    array_to_live_points_fast,
+    empty_structured_array,
+    get_dtype,
+    live_points_to_array,
+)
+from .utils import compute_radius, rescale_log_jacobian
+
+logger = logging.getLogger(__name__)
+
+
+class FlowProposal:
+    """Draw live points from a trained flow by rejection sampling.
+
+    Parameters mirror the reference where they exist there: ``model``, ``rng``,
+    ``flow_config``, ``training_config``, ``output``, ``poolsize``,
+    ``drawsize``, ``volume_fraction``, ``fixed_radius``, ``radius_mode``
+    ({'constant_volume', 'fixed', 'adaptive'}), ``min_radius``, ``max_radius``,
+    ``accumulate_weights``, ``max_poolsize_scale``, ``update_poolsize``.
+
+    Additional parameters
+    ---------------------
+    device_seed : int, optional
+        Seed of the on-device Philox streams (default: drawn from ``rng``).
+    prior : {'auto', 'device', 'host'}
+        ``'device'`` evaluates a uniform-in-bounds prior as a constant on the
+        GPU; ``'host'`` copies every candidate to the host and calls
+        ``model.log_prior`` (any prior); ``'auto'`` picks ``'device'`` when
+        ``model.uniform_prior`` is true.
+    shard : bool
+        When ``torch.distributed`` is initialised, split every draw batch over
+        the ranks (one all-reduce(max) + one all-gather per pass).
+    """
+
+    _FlowModelClass = FlowModel
+
+    def __init__(
+        self,
+        model,
+        rng=None,
+        flow_config=None,
+        training_config=None,
+        output=None,
+        poolsize=None,
+        drawsize=None,
+        latent_temperature=None,
+        volume_fraction=0.95,
+        fixed_radius=False,
+        radius_mode="constant_volume",
+        min_radius=False,
+        max_radius=50.0,
+        accumulate_weights=False,
+        update_poolsize=True,
+        max_poolsize_scale=10,
+        check_acceptance=False,
+        device_seed=None,
+        prior="auto",
+        shard=False,
+        plot=False,
+        **kwargs,
+    ):
+        if kwargs:
+            raise TypeError(f"Unknown FlowProposal arguments: {sorted(kwargs)}")
+        if latent_temperature not in (None, 1.0):
+            raise NotImplementedError("latent_temperature has no gfx950 kernel yet")
+        self.model = model
+        self.rng = rng if rng is not None else np.random.default_rng()
+        self.output = output if output is not None else os.getcwd()
+        self.flow_config = dict(flow_config or {})
+        self.training_config = dict(training_config or {})
+        if poolsize is None:
+            raise RuntimeError("Must specify a poolsize!")
+        self._poolsize = int(poolsize)
+        self._poolsize_scale = 1.0
+        self.update_poolsize = update_poolsize
+        self.max_poolsize_scale = max_poolsize_scale
+        self.drawsize = int(drawsize) if drawsize is not None else self._poolsize
+        self.latent_temperature = None
+        self.accumulate_weights = accumulate_weights
+        self.check_acceptance = check_acceptance
+        self.volume_fraction = float(volume_fraction)
+        if radius_mode not in {"adaptive", "fixed", "constant_volume"}:
+            raise ValueError(
+                f"Unknown radius mode: {radius_mode}. Choose from: adaptive, fixed, constant_volume"
+            )
+        if radius_mode == "fixed" and fixed_radius is False:
+            raise ValueError("Fixed radius mode requires `fixed_radius` to be specified")
+        self.radius_mode = radius_mode
+        self.fixed_radius = float(fixed_radius) if fixed_radius is not False else False
+        self.min_radius = min_radius
+        self.max_radius = max_radius
+        self.fuzz = 1.0
+        if prior not in ("auto", "device", "host"):
+            raise ValueError("prior must be 'auto', 'device' or 'host'")
+        self._prior_mode = prior
+        self.shard = shard
+        self.device_seed = (
+            int(device_seed) if device_seed is not None else int(self.rng.integers(0, 2**63 - 1))
+        )
+
+        self.flow = None
+        self.initialised = False
+        self.populated = False
+        self.populating = False
+        self.indices = []
+        self.samples = None
+        self.x = None
+        self.training_data = None
+        self.training_count = 0
+        self.populated_count = 0
+        self.population_acceptance = None
+        self.population_time = datetime.timedelta()
+        self.acceptance = []
+        self.ns_acceptance = 1.0
+        self.r = np.nan
+        self._checked_population = True
+        self._draw_counter = 0  # rows drawn so far: Philox row offset
+        self._buffers = None
+        self.n_proposed = 0
+        self.n_accepted = 0
+
+    # -- configuration ---------------------------------------------------------
+
+    @property
+    def poolsize(self):
+        return int(self._poolsize_scale * self._poolsize)
+
+    @property
+    def dims(self):
+        return len(self.model.names)
+
+    @property
+    def names(self):
+        return list(self.model.names)
+
+    @property
+    def prime_parameters(self):
+        return [n + "_prime" for n in self.model.names]
+
+    @property
+    def x_dtype(self):
+        return get_dtype(self.names)
+
+    def update_poolsize_scale(self, acceptance):
+        """(``proposal/flowproposal/base.py:416-435``)."""
+        if not acceptance:
+            self._poolsize_scale = self.max_poolsize_scale
+        else:
+            self._poolsize_scale = 1.0 / acceptance
+            if self._poolsize_scale > self.max_poolsize_scale:
+                self._poolsize_scale = self.max_poolsize_scale
+            if self._poolsize_scale < 1.0:
+                self._poolsize_scale = 1.0
+
+    def initialise(self):
+        """Set up the z-score rescaling and the flow (``base.py:358-391``)."""
+        self.scale = {n: 1.0 for n in self.names}
+        self.shift = {n: 0.0 for n in self.names}
+        if self.radius_mode == "constant_volume":  # truncation.py:292-308
+            self.fixed_radius = compute_radius(self.dims, self.volume_fraction)
+            self.fuzz = 1.0
+            if self.max_radius and self.max_radius < self.fixed_radius:
+                self.max_radius = False
+            if self.min_radius and self.min_radius > self.fixed_radius:
+                self.min_radius = False
+        config = dict(self.flow_config)
+        config["n_inputs"] = self.dims
+        self.flow = self._FlowModelClass(
+            flow_config=config, training_config=self.training_config, output=self.output,
+            rng=self.rng,
+        )
+        self.flow.initialise()
+        self.device = self.flow.device
+        mode = self._prior_mode
+        if mode == "auto":
+            mode = "device" if getattr(self.model, "uniform_prior", False) else "host"
+        self.prior_mode = mode
+        self._upload_constants()
+        self.populated = False
+        self.initialised = True
+
+    # -- z-score reparameterisation --------------------------------------------
+
+    def check_state(self, x):
+        """Update sigma / mu from the live points (``rescale.py:293-304``)."""
+        for n in self.names:
+            self.scale[n] = float(np.std(x[n]))
+            self.shift[n] = float(np.mean(x[n]))
+        self._upload_constants()
+
+    def set_rescaling_constants(self, shift, scale):
+        """Set mu / sigma directly (arrays over ``model.names``)."""
+        for i, n in enumerate(self.names):
+            self.shift[n] = float(shift[i])
+            self.scale[n] = float(scale[i])
+        self._upload_constants()
+
+    def _upload_constants(self):
+        dev = self.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        self._scale_dev = torch.tensor([self.scale[n] for n in self.names], **f64)
+        self._shift_dev = torch.tensor([self.shift[n] for n in self.names], **f64)
+        self._lower_dev = torch.tensor(self.model.lower_bounds, **f64)
+        self._upper_dev = torch.tensor(self.model.upper_bounds, **f64)
+        self._log_j_rescale = rescale_log_jacobian([self.scale[n] for n in self.names])
+
+    def rescale(self, x):
+        """x -> (x', log|J|)   with x' = (x - mu) / sigma (``rescale.py:233-261``)."""
+        x_prime = empty_structured_array(x.size, names=self.prime_parameters)
+        log_J = np.zeros(x_prime.size)
+        for p, pp in zip(self.names, self.prime_parameters):
+            x_prime[pp] = (x[p] - self.shift[p]) / self.scale[p]
+            log_J -= np.log(np.abs(self.scale[p]))
+        for p in ("logP", "logL", "it"):
+            x_prime[p] = x[p]
+        return x_prime, log_J
+
+    def inverse_rescale(self, x_prime):
+        """x' -> (x, log|J|)  (``rescale.py:263-291``)."""
+        x = empty_structured_array(x_prime.size, names=self.names)
+        log_J = np.zeros(x.size)
+        for p, pp in zip(self.names, self.prime_parameters):
+            x[p] = (x_prime[pp] * self.scale[p]) + self.shift[p]
+            log_J += np.log(np.abs(self.scale[p]))
+        for p in ("logP", "logL", "it"):
+            x[p] = x_prime[p]
+        return x, log_J
+
+    # -- training ----------------------------------------------------------------
+
+    def train(self, x, plot=False):
+        """Fit the flow to the live points (``base.py:870-925``)."""
+        if not self.initialised:
+            raise RuntimeError("FlowProposal is not initialised.")
+        self.training_data = x.copy()
+        self.check_state(self.training_data)
+        x_prime, _ = self.rescale(x)
+        x_prime_array = live_points_to_array(x_prime, self.prime_parameters)
+        self.flow.train(x_prime_array, output=self.output, plot=False)
+        self.populated = False
+        self.training_count += 1
+
+    # -- passes through the flow ---------------------------------------------------
+
+    def forward_pass(self, x, rescale=True):
+        """Live points -> (z, log_prob incl. rescaling Jacobian) (``base.py:961-994``)."""
+        log_J = 0
+        if rescale:
+            x, log_J = self.rescale(x)
+        arr = live_points_to_array(x, self.prime_parameters)
+        z, log_prob = self.flow.forward_and_log_prob(arr)
+        return z, log_prob + log_J
+
+    def backward_pass(self, z, return_z=False):
+        """Latents -> (x, log_q[, z]) for the kept rows (``flowproposal.py:345-389``).
+
+        Array-level entry point of the fused draw kernel with injected latents.
+        """
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        n = z.shape[0]
+        dev = self.device
+        z_dev = torch.from_numpy(z).to(torch.float32).to(dev)
+        x64 = torch.empty((n, self.dims), dtype=torch.float64, device=dev)
+        log_q = torch.empty(n, dtype=torch.float64, device=dev)
+        self._launch_draw(n, z_dev, 0, np.inf, x64, log_q, None)
+        log_q_h = log_q.cpu().numpy()
+        keep = np.isfinite(log_q_h)
+        x = array_to_live_points_fast(x64.cpu().numpy()[keep], self.names)
+        if return_z:
+            return x, log_q_h[keep], z[keep]
+        return x, log_q_h[keep]
+
+    def log_prior(self, x):
+        return self.model.batch_evaluate_log_prior(x)
+
+    def compute_weights(self, x, log_q):
+        """``log_prior(x) - log_q`` (``base.py:1069-1098``)."""
+        return self.log_prior(x) - log_q
+
+    def convert_to_samples(self, x, plot=False):
+        """Attach ``logP`` (``base.py:1100-1128``)."""
+        x = x.copy()
+        x["logP"] = self.model.batch_evaluate_log_prior(x)
+        return x
+
+    # -- device plumbing --------------------------------------------------------------
+
+    def _launch_draw(self, n, z_in, row_offset, radius, x64, log_q, z_out):
+        flow = self.flow.model
+        flow.eval()
+        header, image = flow.device_image()
+        status = flow._status
+        status.zero_()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = lib.load().nsa_populate_draw(
+            header, lib.ptr(image), n, lib.ptr(z_in), self.device_seed, int(row_offset),
+            float(radius), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
+            lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
+            lib.ptr(x64), lib.ptr(log_q), lib.ptr(z_out), lib.ptr(status),
+            flow.waves_per_group, flow.max_groups, lib.c_void_p(stream),
+        )
+        lib.check(rc, "nsa_populate_draw")
+
+    def _get_buffers(self, n, capacity):
+        key = (n, capacity, self.dims)
+        if self._buffers is not None and self._buffers["key"] == key:
+            return self._buffers
+        dev = self.device
+        L = lib.load()
+        ws_bytes = int(L.nsa_populate_accept_workspace(n))
+        self._buffers = dict(
+            key=key,
+            x64=torch.empty((n, self.dims), dtype=torch.float64, device=dev),
+            log_q=torch.empty(n, dtype=torch.float64, device=dev),
+            log_w=torch.empty(n, dtype=torch.float64, device=dev),
+            max_key=torch.empty(1, dtype=torch.int64, device=dev),
+            x_acc=torch.empty((capacity, self.dims), dtype=torch.float64, device=dev),
+            n_acc=torch.zeros(1, dtype=torch.int64, device=dev),
+            workspace=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
+            ws_bytes=ws_bytes,
+        )
+        return self._buffers
+
+    def _weights_and_max(self, buf, n, reset_max=True):
+        L = lib.load()
+        stream = lib.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if reset_max:
+            buf["max_key"].fill_(int(L.nsa_max_key_init()))
+        if self.prior_mode == "device":
+            log_prior_const = self._uniform_log_prior_constant()
+            rc = L.nsa_populate_weights(
+                n, lib.ptr(buf["log_q"]), None, log_prior_const, lib.ptr(buf["log_w"]),
+                lib.ptr(buf["max_key"]), stream,
+            )
+        else:
+            # general prior: evaluate the user's numpy log_prior on the host
+            x_host = array_to_live_points_fast(buf["x64"][:n].cpu().numpy(), self.names)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                log_p = np.asarray(self.log_prior(x_host), dtype=np.float64)
+            log_p_dev = torch.from_numpy(log_p).to(self.device)
+            rc = L.nsa_populate_weights(
+                n, lib.ptr(buf["log_q"]), lib.ptr(log_p_dev), 0.0, lib.ptr(buf["log_w"]),
+                lib.ptr(buf["max_key"]), stream,
+            )
+        lib.check(rc, "nsa_populate_weights")
+
+    def _uniform_log_prior_constant(self):
+        """-sum log(width), subtracted bound by bound like ``examples/rosenbrock.py:28-31``."""
+        log_p = np.float64(0.0)
+        for n in self.names:
+            lo, hi = self.model.bounds[n]
+            log_p -= np.log(hi - lo)
+        return float(log_p)
+
+    def _accept(self, buf, n, capacity, row_offset, u_in=None, log_w=None, x64=None):
+        L = lib.load()
+        stream = lib.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = L.nsa_populate_accept(
+            n, self.dims, lib.ptr(buf["log_w"] if log_w is None else log_w), lib.ptr(buf["max_key"]),
+            self.device_seed, int(row_offset), lib.ptr(u_in),
+            lib.ptr(buf["x64"] if x64 is None else x64), capacity, lib.ptr(buf["x_acc"]), None,
+            lib.ptr(buf["n_acc"]), lib.ptr(buf["workspace"]), buf["ws_bytes"], stream,
+        )
+        lib.check(rc, "nsa_populate_accept")
+
+    # -- population ----------------------------------------------------------------
+
+    def compute_population_radius(self, worst_point, r=None):
+        """(``truncation.py:323-356``)."""
+        if r is not None:
+            return float(r)
+        if self.radius_mode in {"fixed", "constant_volume"}:
+            return float(self.fixed_radius)
+        worst_z = self.forward_pass(worst_point, rescale=True)[0]
+        radius = float(np.sqrt(np.sum(worst_z**2.0, axis=-1)).max())
+        if self.max_radius and radius > self.max_radius:
+            radius = self.max_radius
+        if self.min_radius and radius < self.min_radius:
+            radius = self.min_radius
+        return float(radius)
+
+    def populate(self, worst_point=None, n_samples=10000, plot=False, r=None,
+                 max_samples=1_000_000, injected=None):
+        """Fill the pool with ``n_samples`` accepted draws (``flowproposal.py:391-534``).
+
+        ``injected`` (parity tests) is an iterator of ``(z, u)`` host arrays used
+        in place of the on-device draws, the analogue of the reference test's
+        mocked ``rng.random`` / latent draws.
+        """
+        st = datetime.datetime.now()
+        if not self.initialised:
+            raise RuntimeError(
+                "Proposal has not been initialised. Try calling `initialise()` first."
+            )
+        radius = self.compute_population_radius(worst_point, r)
+        self.r = radius
+        threshold = self.fuzz * radius
+        self.indices = []
+        n_samples = int(n_samples)
+
+        world, rank = 1, 0
+        if self.shard and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size()
+            rank = torch.distributed.get_rank()
+
+        n_local = self.drawsize if injected is None else None
+        if world > 1:
+            n_local = (self.drawsize + world - 1) // world
+        n_proposed = 0
+        n_accepted = 0
+        rows = []  # accepted blocks (host, float64)
+        if self.accumulate_weights:
+            return self._populate_accumulate(st, threshold, n_samples, max_samples, injected)
+
+        while n_accepted < n_samples:
+            z_in = u_in = None
+            if injected is not None:
+                z_np, u_np = next(injected)
+                n_local = int(len(z_np))
+                z_in = torch.from_numpy(np.ascontiguousarray(z_np)).to(torch.float32).to(self.device)
+                u_in = torch.from_numpy(np.ascontiguousarray(u_np, dtype=np.float64)).to(self.device)
+            buf = self._get_buffers(n_local, n_samples)
+            row_offset = self._draw_counter + rank * n_local
+            self._launch_draw(n_local, z_in, row_offset, threshold, buf["x64"], buf["log_q"], None)
+            self._weights_and_max(buf, n_local)
+            if world > 1:
+                torch.distributed.all_reduce(buf["max_key"], op=torch.distributed.ReduceOp.MAX)
+            self._accept(buf, n_local, n_samples, row_offset, u_in=u_in)
+            n_acc_local = int(buf["n_acc"].item())  # the pass's only device->host sync
+            m_local = min(n_acc_local, n_samples)
+            block = buf["x_acc"][:m_local]
+            if world > 1:
+                n_acc_batch, block = _gather_accepted(block, n_acc_local, n_samples, self.dims)
+            else:
+                n_acc_batch = n_acc_local
+            n_proposed += n_local * world
+            self._draw_counter += n_local * world
+            m = min(n_samples - n_accepted, n_acc_batch)
+            if m > 0:
+                rows.append(block[:m].cpu().numpy())
+            n_accepted += n_acc_batch
+            if n_proposed > max_samples:
+                logger.warning("Reached max samples (%s)", max_samples)
+                break
+
+        accepted = np.concatenate(rows, axis=0) if rows else np.empty((0, self.dims))
+        self.x = array_to_live_points_fast(accepted[: min(n_accepted, n_samples)], self.names)
+        self._finish_population(st, n_accepted, n_proposed)
+
+    def _populate_accumulate(self, st, threshold, n_samples, max_samples, injected):
+        """``accumulate_weights=True`` variant (``flowproposal.py:471-490, 504-510``)."""
+        L = lib.load()
+        log_n = np.log(n_samples)
+        xs, lws = [], []
+        first_row = self._draw_counter
+        n_proposed = 0
+        n_accepted = 0
+        accept_done = False
+        buf = None
+        u_all = []
+        while n_accepted < n_samples:
+            z_in = None
+            n_local = self.drawsize
+            if injected is not None:
+                z_np, u_np = next(injected)
+                n_local = int(len(z_np))
+                z_in = torch.from_numpy(np.ascontiguousarray(z_np)).to(torch.float32).to(self.device)
+                u_all.append(np.asarray(u_np, dtype=np.float64))
+            fresh = buf is None
+            buf = self._get_buffers(n_local, n_samples)
+            self._launch_draw(n_local, z_in, self._draw_counter, threshold, buf["x64"], buf["log_q"], None)
+            self._weights_and_max(buf, n_local, reset_max=fresh)
+            n_proposed += n_local
+            self._draw_counter += n_local
+            valid = torch.isfinite(buf["log_w"][:n_local])
+            xs.append(buf["x64"][:n_local][valid].clone())
+            lws.append(buf["log_w"][:n_local][valid].clone())
+            log_weights = torch.cat(lws)
+            log_constant = float(L.nsa_max_key_decode(int(buf["max_key"].item())))
+            log_n_expected = float(torch.logsumexp(log_weights - log_constant, dim=0).item())
+            if log_n_expected >= log_n:
+                n_accepted, block = self._accept_accumulated(
+                    buf, torch.cat(xs), log_weights, n_samples, first_row, u_all, injected
+                )
+                accept_done = True
+            if n_proposed > max_samples:
+                logger.warning("Reached max samples (%s)", max_samples)
+                break
+        if not accept_done:
+            if lws:
+                n_accepted, block = self._accept_accumulated(
+                    buf, torch.cat(xs), torch.cat(lws), n_samples, first_row, u_all, injected
+                )
+            else:
+                n_accepted, block = 0, np.empty((0, self.dims))
+        self.x = array_to_live_points_fast(block[:n_samples], self.names)
+        self._finish_population(st, n_accepted, n_proposed)
+
+    def _accept_accumulated(self, buf, x_all, log_w_all, n_samples, first_row, u_all, injected):
+        n = int(log_w_all.shape[0])
+        L = lib.load()
+        ws_bytes = int(L.nsa_populate_accept_workspace(n))
+        if ws_bytes > buf["ws_bytes"]:
+            buf["workspace"] = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+            buf["ws_bytes"] = ws_bytes
+        u_in = None
+        if injected is not None:
+            u_in = torch.from_numpy(np.concatenate(u_all)[:n].copy()).to(self.device)
+        self._accept(buf, n, n_samples, first_row, u_in=u_in, log_w=log_w_all.contiguous(),
+                     x64=x_all.contiguous())
+        n_acc = int(buf["n_acc"].item())
+        return n_acc, buf["x_acc"][: min(n_acc, n_samples)].cpu().numpy()
+
+    def _finish_population(self, st, n_accepted, n_proposed):
+        self.samples = self.convert_to_samples(self.x)
+        self.population_time += datetime.datetime.now() - st
+        self.samples["logL"] = self.model.batch_evaluate_log_likelihood(self.samples)
+        self.indices = self.rng.permutation(self.samples.size).tolist()
+        self.n_accepted = int(n_accepted)
+        self.n_proposed = int(n_proposed)
+        self.population_acceptance = n_accepted / n_proposed if n_proposed else 0.0
+        self.populated_count += 1
+        self.populated = True
+        self._checked_population = False
+
+    def draw(self, worst_point):
+        """Pop one pooled sample, repopulating when the pool is empty (``base.py:1152-1183``)."""
+        if not self.populated:
+            self.populating = True
+            if self.update_poolsize:
+                self.update_poolsize_scale(self.ns_acceptance)
+            while not self.populated:
+                self.populate(worst_point, n_samples=self.poolsize)
+            self.populating = False
+        index = self.indices.pop()
+        new_sample = self.samples[index]
+        if not self.indices:
+            self.populated = False
+        return new_sample
+
+    def reset_model_weights(self, **kwargs):
+        self.flow.reset_model(**kwargs)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["initialised"] = False
+        state["_buffers"] = None
+        for k in ("_scale_dev", "_shift_dev", "_lower_dev", "_upper_dev"):
+            state.pop(k, None)
+        state["weights_file"] = getattr(self.flow, "weights_file", None) if self.flow else None
+        state["flow"] = None
+        return state
+
+
+def _gather_accepted(block, n_acc_local, capacity, dims):
+    """All-gather the accepted rows of every rank, rank-major then draw order.
+
+    One collective for the counts, one for the rows padded to a common length
+    (SURVEY.md §8e); payloads are a few hundred KB, i.e. latency-bound on xGMI.
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    dev = block.device
+    mine = torch.tensor([n_acc_local], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(counts, mine)
+    counts_h = torch.cat(counts).cpu().numpy()
+    kept = np.minimum(counts_h, capacity)
+    pad = int(kept.max()) if kept.max() > 0 else 1
+    send = torch.zeros((pad, dims), dtype=torch.float64, device=dev)
+    send[: block.shape[0]] = block
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    parts = [recv[r][: int(kept[r])] for r in range(world)]
+    return int(counts_h.sum()), torch.cat(parts, dim=0)

@@ -1,0 +1,209 @@
+"""Parity of the gfx950 flow kernels against the CPU oracle (runs on a real MI355X).
+
+Bar (BASELINE.json north_star): ``flow.log_prob`` within 1e-5 relative of the
+reference CPU path on identical weights and inputs; the reference's own
+property tests for the flows (``tests/test_flows/test_included_flows.py``)
+are restated on the device path.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import DEV, make_pair, rel_err
+from nessai_amd.flows import NeuralSplineFlow, RealNVP, configure_model
+from oracle import flows as O
+
+pytestmark = pytest.mark.gpu
+
+LOG_PROB_RTOL = 1e-5  # north_star tolerance, relative
+X_ATOL = 2e-4  # float32 coupling stack, |x| <= ~15
+
+CONFIGS = {
+    "nsf_d2": (NeuralSplineFlow, O.NeuralSplineFlow, (2, 8, 2, 2), {}),
+    "nsf_d4": (NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2), {}),
+    "nsf_d5_k10_bn": (NeuralSplineFlow, O.NeuralSplineFlow, (5, 40, 2, 1),
+                      dict(num_bins=10, batch_norm_between_layers=True)),
+    "nsf_c3": (NeuralSplineFlow, O.NeuralSplineFlow, (32, 64, 6, 2), {}),
+    "nsf_c5_d15": (NeuralSplineFlow, O.NeuralSplineFlow, (15, 30, 4, 2), {}),
+    "nsf_c4_d64": (NeuralSplineFlow, O.NeuralSplineFlow, (64, 128, 3, 2), {}),
+    "nsf_k4_lu_tanh": (NeuralSplineFlow, O.NeuralSplineFlow, (8, 16, 2, 2),
+                       dict(num_bins=4, linear_transform="lu", activation=torch.tanh)),
+    "nsf_k16": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 12, 2, 2), dict(num_bins=16)),
+    "rnvp_c2": (RealNVP, O.RealNVP, (16, 32, 4, 2), {}),
+    "rnvp_c2_mlp": (RealNVP, O.RealNVP, (16, 32, 4, 2), dict(net="mlp")),
+    "rnvp_d2": (RealNVP, O.RealNVP, (2, 8, 2, 2), dict(batch_norm_between_layers=False)),
+    "rnvp_additive_actnorm": (RealNVP, O.RealNVP, (6, 16, 2, 2),
+                              dict(use_volume_preserving=True, actnorm=True,
+                                   batch_norm_between_layers=False, linear_transform=None)),
+    "rnvp_silu_perm": (RealNVP, O.RealNVP, (7, 33, 3, 1),
+                       dict(linear_transform="permutation", activation=torch.nn.functional.silu)),
+    "rnvp_pre_bn": (RealNVP, O.RealNVP, (4, 8, 2, 2), dict(pre_transform="batch_norm")),
+}
+
+
+@pytest.fixture(params=sorted(CONFIGS))
+def pair(request):
+    P, Oc, args, kw = CONFIGS[request.param]
+    ref, flow = make_pair(P, Oc, args, kw)
+    return ref, flow, args[0]
+
+
+@pytest.mark.parametrize("scale", [0.5, 1.0, 3.0])
+def test_log_prob_matches_oracle(pair, scale):
+    ref, flow, D = pair
+    x = torch.randn(4000, D) * scale  # scale 3 puts rows beyond the spline tail bound
+    with torch.no_grad():
+        lp_ref = ref.log_prob(x)
+    lp = flow.log_prob(x.to(DEV)).cpu()
+    assert rel_err(lp, lp_ref) <= LOG_PROB_RTOL
+
+
+def test_forward_inverse_match_oracle(pair):
+    ref, flow, D = pair
+    x = torch.randn(3000, D) * 1.5
+    with torch.no_grad():
+        z_ref, ld_ref = ref.forward(x)
+        xi_ref, ldi_ref = ref.inverse(x)
+    z, ld = flow.forward(x.to(DEV))
+    xi, ldi = flow.inverse(x.to(DEV))
+    assert rel_err(z.cpu(), z_ref) <= X_ATOL
+    assert rel_err(ld.cpu(), ld_ref) <= 1e-4
+    assert rel_err(xi.cpu(), xi_ref) <= X_ATOL
+    assert rel_err(ldi.cpu(), ldi_ref) <= 1e-4
+
+
+def test_forward_and_log_prob_consistent(pair):
+    """forward_and_log_prob == (forward, log_prob) exactly
+    (reference tests/test_flows/test_included_flows.py:114-126)."""
+    _, flow, D = pair
+    x = torch.randn(1000, D, device=DEV)
+    z, lp = flow.forward_and_log_prob(x)
+    z2, _ = flow.forward(x)
+    lp2 = flow.log_prob(x)
+    assert torch.equal(z, z2)
+    assert torch.equal(lp, lp2)
+
+
+def test_invertibility(pair):
+    """x -> z -> x and log_J = -log_J_inv to 5 decimals
+    (reference tests/test_flows/test_included_flows.py:144-154)."""
+    _, flow, D = pair
+    x = torch.randn(1000, D, device=DEV)
+    z, log_J = flow.forward(x)
+    x_out, log_J_out = flow.inverse(z)
+    np.testing.assert_array_almost_equal(x.cpu().numpy(), x_out.cpu().numpy(), decimal=4)
+    np.testing.assert_array_almost_equal(log_J.cpu().numpy(), -log_J_out.cpu().numpy(), decimal=4)
+
+
+def test_sample_and_log_prob(pair):
+    """sample_and_log_prob agrees with log_prob of the samples
+    (reference tests/test_flows/test_included_flows.py:129-141)."""
+    _, flow, D = pair
+    x, lp = flow.sample_and_log_prob(1000)
+    assert x.shape == (1000, D) and lp.shape == (1000,)
+    lp2 = flow.log_prob(x)
+    assert rel_err(lp.cpu(), lp2.cpu()) <= 1e-4
+
+
+def test_shapes_and_api(pair):
+    _, flow, D = pair
+    assert flow.sample(10).shape == (10, D)
+    z = flow.sample_latent_distribution(7)
+    assert z.shape == (7, D) and z.device.type == "cuda"
+    assert flow.base_distribution_log_prob(z).shape == (7,)
+    flow.freeze_transform()
+    assert not any(p.requires_grad for p in flow._transform.parameters())
+    flow.unfreeze_transform()
+    assert all(p.requires_grad for p in flow._transform.parameters())
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 257])
+def test_ragged_batches(n):
+    """Batches that do not fill a 32-row tile / a workgroup."""
+    ref, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 3, 2))
+    x = torch.randn(n, 6) * 2
+    with torch.no_grad():
+        lp_ref = ref.log_prob(x)
+        xi_ref, _ = ref.inverse(x)
+    assert rel_err(flow.log_prob(x.to(DEV)).cpu(), lp_ref) <= LOG_PROB_RTOL
+    assert rel_err(flow.inverse(x.to(DEV))[0].cpu(), xi_ref) <= X_ATOL
+
+
+def test_empty_batch():
+    _, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2))
+    z, ld = flow.forward(torch.empty(0, 4, device=DEV))
+    assert z.shape == (0, 4) and ld.shape == (0,)
+
+
+def test_weights_update_repacks_image():
+    """The device image follows in-place weight updates and load_state_dict."""
+    ref, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2))
+    x = torch.randn(200, 4)
+    before = flow.log_prob(x.to(DEV)).cpu()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.mul_(1.1)
+    flow.load_state_dict(ref.state_dict())
+    after = flow.log_prob(x.to(DEV)).cpu()
+    with torch.no_grad():
+        lp_ref = ref.log_prob(x)
+    assert not torch.equal(before, after)
+    assert rel_err(after, lp_ref) <= LOG_PROB_RTOL
+
+
+def test_spline_tails_and_knots():
+    """Analytic known answers of the spline: identity outside
+    [-B, B] with zero log-det; with all-zero conditioner output the bins are
+    equal and the boundary derivative is 1."""
+    _, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (2, 8, 1, 1),
+                        dict(linear_transform=None))
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.zero_()
+    x = torch.tensor([[0.3, 7.0], [-6.0, -0.2], [5.0, 5.0], [-5.0, 2.5]], device=DEV)
+    z, ld = flow.forward(x)
+    # features beyond the tail bound are untouched
+    assert z[0, 1].item() == 7.0 and z[1, 0].item() == -6.0
+    # zero parameters: knots at multiples of 10/8 map to themselves
+    xk = torch.tensor([[1.25, 0.0], [-2.5, 0.0], [3.75, 0.0]], device=DEV)
+    zk, _ = flow.forward(xk)
+    np.testing.assert_allclose(zk.cpu().numpy()[:, 0], [1.25, -2.5, 3.75], atol=2e-6)
+
+
+def test_cpu_tensors_fail_loudly():
+    _, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        flow.log_prob(torch.randn(4, 4))
+
+
+def test_configure_model_factory():
+    """flows/utils.py:208-246 argument order and custom flow class plug-in
+    (reference tests/test_flows/test_flow_utils.py:274-293)."""
+    flow = configure_model(dict(n_inputs=4, n_neurons=8, n_blocks=3, n_layers=1, ftype="nsf",
+                                activation="relu", num_bins=4))
+    leaves = [t for t in flow._transform._transforms]
+    assert sum("RationalQuadratic" in type(t).__name__ for t in leaves) == 3
+    assert len(flow._transform._transforms[1].transform_net.blocks) == 1
+
+    class Custom(RealNVP):
+        pass
+
+    flow = configure_model(dict(n_inputs=4, n_neurons=8, n_blocks=2, n_layers=2, flow=Custom))
+    assert isinstance(flow, Custom)
+    with pytest.raises(RuntimeError, match="Must specify either 'flow' or 'ftype'"):
+        configure_model(dict(n_inputs=4, n_neurons=8, n_blocks=2, n_layers=2))
+
+
+def test_full_size_properties_c3():
+    """Size-independent properties at the benchmark batch (1e6 x 32): round trip and
+    log-det antisymmetry hold for every row."""
+    torch.manual_seed(1451)
+    flow = NeuralSplineFlow(32, 64, 6, 2)
+    flow.to(DEV)
+    flow.eval()
+    z = torch.randn(1_000_000, 32, device=DEV)
+    x, ld = flow.inverse(z)
+    z2, ld2 = flow.forward(x)
+    assert torch.isfinite(x).all() and torch.isfinite(ld).all()
+    assert (z - z2).abs().max().item() < 5e-4
+    assert (ld + ld2).abs().max().item() < 5e-3

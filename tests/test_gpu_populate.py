@@ -1,0 +1,241 @@
+"""Parity of the fused populate path against the CPU oracle (runs on a real MI355X).
+
+The oracle (``oracle/proposal.py``) restates ``FlowProposal.populate`` /
+``backward_pass``; the device path must reproduce it on identical weights,
+latents and uniforms.  The glue arithmetic is float64 on both sides, so apart
+from the float32 flow outputs (summation order) the results are identical;
+accept decisions can only differ for draws within ~1e-6 of the threshold.
+"""
+import numpy as np
+import pytest
+import torch
+from scipy import stats
+
+from helpers import DEV, load_c3_fixture
+from nessai_amd.model import GaussianModel, Model, RosenbrockModel
+from nessai_amd.proposal import FlowProposal
+from oracle import philox
+from oracle import proposal as OP
+
+pytestmark = pytest.mark.gpu
+
+
+def build(dims, ftype, flow_kwargs, model_cls=RosenbrockModel, seed=3, poolsize=500, drawsize=4000,
+          state=None, shift=None, scale=None, **kwargs):
+    """(device proposal, oracle proposal) sharing weights and z-score constants."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    model = model_cls(dims)
+    omodel = {RosenbrockModel: OP.RosenbrockModel, GaussianModel: OP.GaussianModel}[model_cls](dims)
+    cfg = dict(ftype=ftype, **flow_kwargs)
+    prop = FlowProposal(model, rng=np.random.default_rng(seed), flow_config=cfg, poolsize=poolsize,
+                        drawsize=drawsize, device_seed=1451, **kwargs)
+    prop.initialise()
+    ocfg = dict(cfg, n_inputs=dims)
+    ocfg.setdefault("n_neurons", 2 * dims)
+    ocfg.setdefault("n_blocks", 4)
+    ocfg.setdefault("n_layers", 2)
+    ofm = OP.OracleFlowModel(ocfg, rng=np.random.default_rng(seed))
+    if state is None:
+        state = ofm.model.state_dict()
+    ofm.model.load_state_dict(state)
+    ofm.model.eval()
+    prop.flow.model.load_state_dict(state)
+    prop.flow.model.eval()
+    oprop = OP.OracleFlowProposal(omodel, ofm, rng=rng, poolsize=poolsize, drawsize=drawsize,
+                                  accumulate_weights=kwargs.get("accumulate_weights", False))
+    if shift is None:
+        shift = rng.normal(size=dims) * 0.3
+        scale = rng.uniform(0.5, 1.5, size=dims)
+    prop.set_rescaling_constants(shift, scale)
+    for i, n in enumerate(omodel.names):
+        oprop.shift[n] = float(shift[i])
+        oprop.scale[n] = float(scale[i])
+    return prop, oprop
+
+
+def test_backward_pass_matches_oracle():
+    """x, log_q and the kept rows of backward_pass (flowproposal.py:345-389)."""
+    prop, oprop = build(6, "nsf", dict(n_neurons=16, n_blocks=3))
+    z = np.random.default_rng(0).normal(size=(5000, 6)).astype(np.float32).astype(np.float64) * 1.3
+    x, log_q, z_kept = prop.backward_pass(z, return_z=True)
+    x_o, log_q_o, z_o = oprop.backward_pass(z)
+    assert len(x) == len(x_o) and np.array_equal(z_kept, z_o)
+    for n in prop.names:
+        np.testing.assert_allclose(x[n], x_o[n], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(log_q, log_q_o, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("cfg", [
+    ("nsf", dict(n_neurons=16, n_blocks=3), 6, RosenbrockModel),
+    ("realnvp", dict(n_neurons=16, n_blocks=3), 8, GaussianModel),
+])
+def test_populate_injected_matches_oracle(cfg):
+    """Same latents and uniforms in -> same accepted set out (flowproposal.py:431-512)."""
+    ftype, fk, dims, mcls = cfg
+    prop, oprop = build(dims, ftype, fk, model_cls=mcls, poolsize=300, drawsize=3000)
+    g = np.random.default_rng(11)
+    batches = [(g.normal(size=(3000, dims)).astype(np.float32).astype(np.float64), g.random(3000)) for _ in range(40)]
+    radius = OP.compute_radius(dims, 0.95)
+
+    # oracle run, remembering how many uniforms each pass consumed
+    used = []
+
+    class Rng:
+        def __init__(self):
+            self.k = 0
+
+        def random(self, n):
+            z, u = batches[self.k]
+            kept = used[self.k]
+            self.k += 1
+            return u[kept]
+
+        def permutation(self, n):
+            return np.arange(n)
+
+    # the reference draws uniforms only for rows that survive the cuts; map each
+    # surviving row back to its draw index so both sides see the same u per draw
+    def oracle_batches():
+        for z, _ in batches:
+            yield z
+
+    orig_backward = oprop.backward_pass
+
+    def tracking_backward(z_trunc):
+        x, lq, zk = orig_backward(z_trunc)
+        zb = batches[len(used)][0]
+        lookup = {row.tobytes(): i for i, row in enumerate(zb)}
+        used.append(np.array([lookup[row.tobytes()] for row in zk], dtype=np.int64))
+        return x, lq, zk
+
+    oprop.backward_pass = tracking_backward
+    oprop.injected_latents = oracle_batches()
+    oprop.rng = Rng()
+    oprop.populate(n_samples=300, r=radius)
+
+    prop.populate(None, n_samples=300, r=radius, injected=iter(batches))
+    assert prop.n_proposed == oprop.n_proposed
+    # accept decisions agree except for draws within float32 round-off of the threshold
+    assert abs(prop.n_accepted - oprop.n_accepted) <= max(2, int(0.01 * oprop.n_accepted))
+    a = np.stack([prop.x[n] for n in prop.names], axis=1)
+    b = np.stack([oprop.x[n] for n in oprop.names], axis=1)
+    if prop.n_accepted == oprop.n_accepted:
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(prop.samples["logP"], oprop.model.log_prior(oprop.samples)[0], rtol=0, atol=1e-12)
+    assert np.isfinite(prop.samples["logL"]).all()
+    assert prop.populated and sorted(prop.indices) == list(range(prop.samples.size))
+
+
+def test_device_latents_match_numpy_philox():
+    """The in-kernel Philox4x32-10 + Box-Muller stream equals its numpy restatement."""
+    prop, _ = build(7, "nsf", dict(n_neurons=16, n_blocks=2))
+    n = 3000
+    z_out = torch.empty((n, 7), dtype=torch.float32, device=DEV)
+    x64 = torch.empty((n, 7), dtype=torch.float64, device=DEV)
+    log_q = torch.empty(n, dtype=torch.float64, device=DEV)
+    prop._launch_draw(n, None, 12345, 1e9, x64, log_q, z_out)
+    z_ref = philox.latents(1451, 12345, n, 7)
+    np.testing.assert_allclose(z_out.cpu().numpy(), z_ref, rtol=0, atol=3e-6)
+    z = z_out.cpu().numpy().ravel()
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+
+
+def test_populate_device_rng_statistics():
+    """With on-device draws: acceptance rate and accepted distribution agree with
+    the oracle fed the SAME latents/uniforms through the numpy Philox restatement."""
+    state, shift, scale, _ = load_c3_fixture()
+    prop, oprop = build(32, "nsf", dict(n_neurons=64, n_blocks=6), poolsize=400, drawsize=20000,
+                        state=state, shift=shift, scale=scale)
+    prop.populate(None, n_samples=400, max_samples=400_000)
+    assert prop.populated and prop.samples.size > 0
+    assert 0 < prop.population_acceptance < 1
+    # oracle on the identical stream
+    n_pass = prop.n_proposed // 20000
+    zs = (philox.latents(1451, k * 20000, 20000, 32).astype(np.float64) for k in range(n_pass))
+    oprop.injected_latents = zs
+    acc = 0
+    radius = OP.compute_radius(32, 0.95)
+    for k in range(n_pass):
+        z = oprop.sample_latent_distribution(20000)
+        keep_idx = np.where(np.sqrt(np.sum(z**2, axis=-1)) <= radius)[0]
+        x, lq, zk = oprop.backward_pass(z[keep_idx])
+        lookup = {row.tobytes(): i for i, row in enumerate(z)}
+        idx = np.array([lookup[r.tobytes()] for r in zk], dtype=np.int64)
+        lw = oprop.compute_weights(x, lq)
+        lw -= lw.max()
+        u = philox.uniforms(1451, k * 20000, 20000)[idx]
+        acc += int((lw > np.log(u)).sum())
+    assert abs(acc - prop.n_accepted) <= max(3, int(0.02 * acc))
+
+
+def test_populate_all_truncated_hits_max_samples():
+    """Every draw outside the radius: loop exits on max_samples with an empty pool
+    (flowproposal.py:434-438)."""
+    prop, _ = build(4, "nsf", dict(n_neurons=8, n_blocks=2), poolsize=50, drawsize=1000)
+    prop.populate(None, n_samples=50, r=1e-6, max_samples=3000)
+    assert prop.samples.size == 0 and prop.n_accepted == 0
+    assert prop.n_proposed == 4000
+
+
+def test_populate_host_prior_matches_device_prior():
+    """The general (host-evaluated) prior path gives the same pool as the constant
+    device prior for a uniform model."""
+    p1, _ = build(5, "nsf", dict(n_neurons=16, n_blocks=2), poolsize=200, drawsize=5000, prior="device")
+    p2, _ = build(5, "nsf", dict(n_neurons=16, n_blocks=2), poolsize=200, drawsize=5000, prior="host")
+    p1.populate(None, n_samples=200)
+    p2.populate(None, n_samples=200)
+    assert p1.n_accepted == p2.n_accepted and p1.n_proposed == p2.n_proposed
+    for n in p1.names:
+        np.testing.assert_array_equal(p1.x[n], p2.x[n])
+
+
+def test_populate_accumulate_weights():
+    """accumulate_weights=True (flowproposal.py:471-490, 504-510): pool of n_samples
+    drawn from all accumulated candidates."""
+    prop, oprop = build(4, "nsf", dict(n_neurons=8, n_blocks=2), poolsize=100, drawsize=2000,
+                        accumulate_weights=True)
+    prop.populate(None, n_samples=100, max_samples=200_000)
+    assert prop.populated
+    assert 0 < prop.samples.size <= 100
+    assert prop.model.in_bounds(prop.samples).all()
+
+
+def test_draw_pops_until_empty():
+    """draw() repopulates when the pool is empty and pops one row per call
+    (proposal/flowproposal/base.py:1152-1183)."""
+    prop, _ = build(4, "nsf", dict(n_neurons=8, n_blocks=2), poolsize=20, drawsize=2000)
+    prop.update_poolsize = False
+    first = prop.draw(None)
+    assert first.dtype.names[-3:] == ("logP", "logL", "it")
+    n_left = len(prop.indices)
+    for _ in range(n_left):
+        prop.draw(None)
+    assert not prop.populated
+
+
+def test_adaptive_radius_uses_forward_pass():
+    """radius_mode='adaptive': r = |z(worst point)| (truncation.py:343-351)."""
+    prop, oprop = build(4, "nsf", dict(n_neurons=8, n_blocks=2), poolsize=20, drawsize=2000,
+                        radius_mode="adaptive")
+    from nessai_amd.livepoint import numpy_array_to_live_points
+
+    worst = numpy_array_to_live_points(np.array([[0.4, -0.3, 0.2, 0.1]]), prop.names)
+    r = prop.compute_population_radius(worst)
+    oworst = OP.empty_structured_array(1, oprop.names)
+    for i, n in enumerate(oprop.names):
+        oworst[n] = [0.4, -0.3, 0.2, 0.1][i]
+    z_o, _ = oprop.forward_pass(oworst)
+    assert abs(r - float(np.sqrt(np.sum(z_o**2)))) < 1e-4
+
+
+def test_full_size_c3_populate():
+    """BASELINE config 3 at full size: drawsize 1e6, n_samples 2000, realistic weights."""
+    state, shift, scale, _ = load_c3_fixture()
+    prop, _ = build(32, "nsf", dict(n_neurons=64, n_blocks=6), poolsize=2000, drawsize=1_000_000,
+                    state=state, shift=shift, scale=scale)
+    prop.populate(None, n_samples=2000, max_samples=20_000_000)
+    assert prop.samples.size == 2000
+    assert prop.model.in_bounds(prop.samples).all()
+    assert np.isfinite(prop.samples["logP"]).all() and np.isfinite(prop.samples["logL"]).all()
+    assert prop.n_accepted >= 2000 and prop.n_proposed % 1_000_000 == 0
