@@ -171,6 +171,10 @@ class HipFlow(BaseFlow):
         x = self._check_input(x)
         header, image = self.device_image()
         n = x.shape[0]
+        if n == 0:
+            empty = torch.empty(0, dtype=torch.float32, device=x.device)
+            self._status.zero_()
+            return (torch.empty_like(x) if want_x else None), empty, self._status
         out = torch.empty_like(x) if want_x else None
         ld = torch.empty(n, dtype=torch.float32, device=x.device)
         status = self._status

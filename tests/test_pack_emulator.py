@@ -1,0 +1,119 @@
+"""Host packer + kernel data flow (lane-level emulation) against the oracle, on the CPU.
+
+``tests/emulator.py`` interprets the flow image exactly like ``nsa_flow_kernel``
+(stage blobs, column tables, MFMA lane layouts); agreement with the oracle
+validates ``nessai_amd/pack.py`` and the image format without a GPU.
+"""
+import numpy as np
+import pytest
+import torch
+
+from emulator import Emulator, mfma_32x32x2
+from helpers import randomise
+from nessai_amd import pack as P
+from nessai_amd.flows import NeuralSplineFlow, RealNVP
+from nessai_amd.flows.modules import describe
+from oracle import flows as O
+
+CONFIGS = {
+    "nsf_d4": (O.NeuralSplineFlow, (4, 8, 2, 2), {}),
+    "nsf_d5_k10_bn": (O.NeuralSplineFlow, (5, 40, 2, 1), dict(num_bins=10, batch_norm_between_layers=True)),
+    "rnvp_lu_bn": (O.RealNVP, (6, 16, 3, 2), {}),
+    "rnvp_mlp_tanh": (O.RealNVP, (7, 33, 2, 2), dict(net="mlp", linear_transform="permutation",
+                                                     batch_norm_between_layers=False, activation=torch.tanh)),
+    "rnvp_additive_actnorm": (O.RealNVP, (4, 8, 2, 2), dict(use_volume_preserving=True, linear_transform=None,
+                                                            actnorm=True, batch_norm_between_layers=False)),
+    "nsf_d32": (O.NeuralSplineFlow, (32, 64, 2, 2), {}),
+}
+
+
+def test_mfma_emulation_matches_matmul():
+    """A=I check with an ASYMMETRIC B catches transposed layouts."""
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(32, 2)).astype(np.float32)
+    B = rng.normal(size=(2, 32)).astype(np.float32)
+    a = np.concatenate([A[:, 0], A[:, 1]])
+    b = np.concatenate([B[0], B[1]])
+    d = mfma_32x32x2(a, b, np.zeros((64, 16), dtype=np.float32))
+    ref = A @ B
+    for lane in range(64):
+        for r in range(16):
+            i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+            assert abs(d[lane, r] - ref[i, lane & 31]) < 1e-6
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_emulated_kernel_matches_oracle(name):
+    cls, args, kw = CONFIGS[name]
+    torch.manual_seed(3)
+    flow = cls(*args, **kw)
+    randomise(flow, 3)
+    flow.train()
+    flow.eval()
+    em = Emulator(P.pack_flow(describe(flow)))
+    n = 40 if args[0] >= 32 else 70
+    x = torch.randn(n, args[0]) * 2.5
+    with torch.no_grad():
+        z, ld = flow.forward(x)
+        xi, ldi = flow.inverse(x)
+    ze, lde = em.run(x.numpy(), False)
+    xe, ldie = em.run(x.numpy(), True)
+    scale = max(1.0, float(xi.abs().max()))
+    assert np.abs(ze - z.numpy()).max() < 5e-5
+    assert np.abs(lde - ld.numpy()).max() < 1e-4
+    assert np.abs(xe - xi.numpy()).max() < 5e-5 * scale
+    assert np.abs(ldie - ldi.numpy()).max() < 1e-4
+
+
+def test_product_and_oracle_trees_pack_identically():
+    """Same seed -> same initial weights -> identical device image."""
+    for Pc, Oc, args, kw in [
+        (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 3, 2), {}),
+        (RealNVP, O.RealNVP, (6, 16, 3, 2), {}),
+        (RealNVP, O.RealNVP, (5, 16, 2, 2), dict(net="mlp", linear_transform="permutation")),
+    ]:
+        torch.manual_seed(11)
+        a = Pc(*args, **kw)
+        torch.manual_seed(11)
+        b = Oc(*args, **kw)
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa) == list(sb)
+        assert all(torch.equal(sa[k], sb[k]) for k in sa)
+        a.eval()
+        b.eval()
+        assert np.array_equal(P.pack_flow(describe(a)), P.pack_flow(describe(b)))
+
+
+def test_image_header_and_alignment():
+    torch.manual_seed(0)
+    flow = O.NeuralSplineFlow(32, 64, 6, 2).eval()
+    img = P.pack_flow(describe(flow))
+    assert img[P.H_MAGIC] == P.MAGIC and img[P.H_VERSION] == P.VERSION
+    assert img[P.H_D] == 32 and img[P.H_HT] == 2 and img[P.H_BINS] == 8
+    assert img[P.H_TOTAL] == len(img)
+    assert img[P.H_MAX_STAGE] % 256 == 0
+    # 6 couplings x (1 + 4 + 4) stages per direction
+    assert img[P.H_NSTAGES_FWD] == 54 and img[P.H_NSTAGES_INV] == 54
+    tab = int(img[P.H_STAGES_FWD])
+    for s in range(54):
+        off, n = int(img[tab + 2 * s]), int(img[tab + 2 * s + 1])
+        assert off % 256 == 0 and n % 256 == 0 and off + n <= len(img)
+
+
+def test_unsupported_configurations_fail_loudly():
+    with pytest.raises(ValueError, match="No gfx950 kernel instance"):
+        NeuralSplineFlow(4, 8, 2, 2, num_bins=7)
+    with pytest.raises(ValueError):
+        NeuralSplineFlow(4, 300, 2, 2)
+    with pytest.raises(NotImplementedError):
+        NeuralSplineFlow(4, 8, 2, 2, context_features=2)
+    with pytest.raises(NotImplementedError):
+        RealNVP(4, 8, 2, 2, linear_transform="svd")
+    with pytest.raises(ValueError, match="at least 2"):
+        RealNVP(1, 8, 2, 2)
+    with pytest.raises(RuntimeError, match="actnorm and batchnorm"):
+        RealNVP(4, 8, 2, 2, actnorm=True)
+    with pytest.raises(ValueError, match="Unknown nn type"):
+        RealNVP(4, 8, 2, 2, net="cnn")
+    with pytest.raises(ValueError, match="Mask does not match number of features"):
+        RealNVP(4, 8, 2, 2, mask=[1, -1, 1])
