@@ -38,7 +38,7 @@ OUT = {}
 
 
 def put(key, value):
-    OUT[key] = np.asarray(value)
+    OUT[key] = np.array(value, copy=True)
 
 
 def put_state(prefix, state):

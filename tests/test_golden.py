@@ -1,0 +1,178 @@
+"""The oracle against golden vectors captured from the reference's own code (CPU suite).
+
+``tests/golden/reference_goldens.npz`` was produced by ``tests/golden/make_golden.py``
+running ``/root/reference``'s ``RealNVP`` / ``NeuralSplineFlow`` / ``FlowModel`` /
+``FlowProposal`` / ``LatentRadiusTruncation`` (with the absent ``glasflow``
+arithmetic supplied by ``oracle.nflows_restated``).  These tests pin the oracle's
+*own* restatement of the assembly and of the float64 proposal glue
+(``oracle/flows.py``, ``oracle/proposal.py``) to those outputs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flows as O
+from oracle import proposal as OP
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_goldens.npz"))
+
+FLOW_CASES = {
+    "nsf_d4": (O.NeuralSplineFlow, (4, 8, 2, 2), {}),
+    "nsf_d6_k10": (O.NeuralSplineFlow, (6, 16, 3, 1), dict(num_bins=10)),
+    "rnvp_d4": (O.RealNVP, (4, 8, 2, 2), {}),
+    "rnvp_d5_mlp": (O.RealNVP, (5, 16, 3, 2), dict(net="mlp", linear_transform="permutation")),
+}
+
+
+def state_of(prefix):
+    pre = prefix + "/state/"
+    return {k[len(pre):]: torch.from_numpy(GOLD[k]) for k in GOLD.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("name", sorted(FLOW_CASES))
+def test_flow_assembly_matches_reference(name):
+    """Same state_dict keys, same outputs as the reference's flow classes (bit-exact)."""
+    cls, args, kw = FLOW_CASES[name]
+    flow = cls(*args, **kw)
+    state = state_of(f"flows/{name}")
+    assert list(flow.state_dict()) == list(state)
+    flow.load_state_dict(state)
+    flow.eval()
+    x = torch.from_numpy(GOLD[f"flows/{name}/x"])
+    with torch.no_grad():
+        z, ld = flow.forward(x)
+        xi, ldi = flow.inverse(x)
+        lp = flow.log_prob(x)
+    assert np.array_equal(z.numpy(), GOLD[f"flows/{name}/z"])
+    assert np.array_equal(ld.numpy(), GOLD[f"flows/{name}/logdet"])
+    assert np.array_equal(xi.numpy(), GOLD[f"flows/{name}/x_inv"])
+    assert np.array_equal(ldi.numpy(), GOLD[f"flows/{name}/logdet_inv"])
+    assert np.array_equal(lp.numpy(), GOLD[f"flows/{name}/log_prob"])
+
+
+def test_truncation_radius_and_mask():
+    """G1: constant-volume radius and the latent-radius mask (truncation.py:353-365)."""
+    for d, r in zip(GOLD["truncation/dims"], GOLD["truncation/radius"]):
+        assert OP.compute_radius(int(d), 0.95) == r
+    z = GOLD["truncation/z"]
+    dummy = OP.OracleFlowProposal.__new__(OP.OracleFlowProposal)
+    kept = OP.OracleFlowProposal.apply_latent(dummy, z, 2.5)
+    assert np.array_equal(kept, GOLD["truncation/kept"])
+
+
+def make_oracle_proposal(accumulate=False):
+    dims = 4
+    model = OP.RosenbrockModel(dims)
+    fm = OP.OracleFlowModel(dict(n_inputs=dims, n_neurons=8, n_blocks=2, n_layers=2, ftype="nsf"),
+                            rng=np.random.default_rng(0))
+    fm.model.load_state_dict(state_of("proposal"))
+    fm.model.eval()
+    prop = OP.OracleFlowProposal(model, fm, rng=np.random.default_rng(0), poolsize=100, drawsize=1000,
+                                 accumulate_weights=accumulate)
+    live = OP.empty_structured_array(200, model.names)
+    for i, n in enumerate(model.names):
+        live[n] = GOLD["proposal/live_points"][:, i]
+    prop.update_rescaling(live)
+    return prop, live
+
+
+def test_zscore_rescaling_matches_reference():
+    """G5: ScaleAndShift forward / inverse and their log-Jacobians (rescale.py:233-291)."""
+    prop, live = make_oracle_proposal()
+    x_prime, log_j = prop.rescale(live)
+    got = np.stack([x_prime[p] for p in prop.prime_names], axis=1)
+    assert np.array_equal(got, GOLD["proposal/rescaled"])
+    assert np.array_equal(log_j, GOLD["proposal/rescale_log_j"])
+    x_back, log_j_inv = prop.inverse_rescale(x_prime)
+    got = np.stack([x_back[p] for p in prop.names], axis=1)
+    assert np.array_equal(got, GOLD["proposal/inverse_rescaled"])
+    assert np.array_equal(log_j_inv, GOLD["proposal/inverse_rescale_log_j"])
+    assert np.allclose(log_j, -log_j_inv)
+
+
+def test_forward_pass_matches_reference():
+    prop, live = make_oracle_proposal()
+    z, lp = prop.forward_pass(live)
+    assert np.array_equal(z, GOLD["proposal/forward_z"])
+    assert np.array_equal(lp, GOLD["proposal/forward_log_prob"])
+
+
+def test_backward_pass_matches_reference():
+    """G2: x, log_q and kept rows of FlowProposal.backward_pass (flowproposal.py:345-389)."""
+    prop, _ = make_oracle_proposal()
+    x, log_q, z = prop.backward_pass(GOLD["proposal/bp_z"])
+    assert np.array_equal(z, GOLD["proposal/bp_z_kept"])
+    assert np.array_equal(np.stack([x[n] for n in prop.names], axis=1), GOLD["proposal/bp_x"])
+    assert np.array_equal(log_q, GOLD["proposal/bp_log_q"])
+
+
+@pytest.mark.parametrize("tag", ["std", "acc"])
+def test_populate_matches_reference(tag):
+    """G3: FlowProposal.populate with injected latents and uniforms, both
+    accumulate_weights modes (flowproposal.py:391-534)."""
+    accumulate = tag == "acc"
+    prop, _ = make_oracle_proposal(accumulate)
+    zs, us = GOLD[f"populate_{tag}/z"], GOLD[f"populate_{tag}/u"]
+    used = []
+    orig = prop.backward_pass
+
+    def tracking(zt):
+        res = orig(zt)
+        zb = zs[len(used)]
+        lookup = {row.tobytes(): i for i, row in enumerate(zb)}
+        used.append(np.array([lookup[r.tobytes()] for r in res[2]], dtype=np.int64))
+        return res
+
+    class Rng:
+        def random(self, n):
+            if accumulate:
+                return np.concatenate([us[b][ix] for b, ix in enumerate(used)])
+            b = len(used) - 1
+            return us[b][used[b]]
+
+        def permutation(self, n):
+            return np.arange(n)
+
+    prop.backward_pass = tracking
+    prop.injected_latents = iter(zs)
+    prop.rng = Rng()
+    prop.populate(n_samples=100, r=float(GOLD["proposal/radius"]))
+    assert len(used) == int(GOLD[f"populate_{tag}/n_passes"])
+    assert np.array_equal(np.stack([prop.x[n] for n in prop.names], axis=1), GOLD[f"populate_{tag}/x"])
+    assert np.array_equal(prop.samples["logP"], GOLD[f"populate_{tag}/logP"])
+    assert prop.population_acceptance == float(GOLD[f"populate_{tag}/population_acceptance"])
+    np.testing.assert_allclose(prop.model.log_likelihood(prop.samples), GOLD[f"populate_{tag}/logL"], rtol=1e-12)
+
+
+def test_batch_size_table_matches_reference():
+    """G4: FlowModel.check_batch_size (flowmodel/base.py:195-236)."""
+    for (n, b), out in zip(GOLD["flowmodel/batch_table"], GOLD["flowmodel/batch_out"]):
+        assert OP.check_batch_size(np.arange(int(n)), int(b)) == int(out)
+
+
+def test_prep_data_and_one_training_step_match_reference():
+    """G4: prep_data split and one optimiser step (loss, gradients, clip 5.0, AdamW)."""
+    torch.manual_seed(170817)
+    fm = OP.OracleFlowModel(dict(n_inputs=4, n_neurons=8, n_blocks=2, n_layers=2, ftype="nsf"),
+                            training_config=dict(batch_size=100, val_size=0.1),
+                            rng=np.random.default_rng(170817))
+    fm.model.load_state_dict(state_of("flowmodel/before"))
+    train, val, bs = fm.prep_data(GOLD["flowmodel/data"], val_size=0.1, batch_size=100)
+    assert bs == int(GOLD["flowmodel/batch_size"])
+    assert np.array_equal(train.numpy(), GOLD["flowmodel/train_data"])
+    assert np.array_equal(val.numpy(), GOLD["flowmodel/val_data"])
+    x = torch.from_numpy(GOLD["flowmodel/step_x"])
+    fm.model.train()
+    loss = -fm.model.log_prob(x).mean()
+    loss.backward()
+    assert loss.item() == float(GOLD["flowmodel/step_loss"])
+    for k, p in fm.model.named_parameters():
+        assert np.array_equal(p.grad.numpy(), GOLD[f"flowmodel/grad/{k}"]), k
+    norm = torch.nn.utils.clip_grad_norm_(fm.model.parameters(), 5.0)
+    assert float(norm) == float(GOLD["flowmodel/step_grad_norm"])
+    fm._optimiser.step()
+    after = state_of("flowmodel/after")
+    for k, v in fm.model.state_dict().items():
+        assert np.array_equal(v.numpy(), after[k].numpy()), k

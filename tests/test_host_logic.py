@@ -1,0 +1,94 @@
+"""Host-side logic of the product package that needs no GPU."""
+import numpy as np
+import pytest
+
+from nessai_amd import livepoint, pack
+from nessai_amd.flowmodel import FlowModel, update_config
+from nessai_amd.model import GaussianModel, RosenbrockModel
+from nessai_amd.utils import compute_radius, rescale_log_jacobian
+
+
+def test_live_point_dtype_and_defaults():
+    """Field layout of the reference (config.py:22-60, livepoint.py:74-155)."""
+    names = ["a", "b"]
+    dt = livepoint.get_dtype(names)
+    assert dt.names == ("a", "b", "logP", "logL", "it")
+    assert [dt[n].str for n in dt.names] == ["<f8", "<f8", "<f8", "<f8", "<i4"]
+    x = livepoint.empty_structured_array(3, names=names)
+    assert np.isnan(x["a"]).all() and np.isnan(x["logL"]).all() and (x["it"] == 0).all()
+    assert livepoint.empty_structured_array(0, names=names).size == 0
+
+
+def test_fast_live_point_builder_equals_field_loop():
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(17, 5))
+    names = [f"p{i}" for i in range(5)]
+    fast = livepoint.array_to_live_points_fast(a, names)
+    slow = livepoint.numpy_array_to_live_points(a, names)
+    for n in names + ["it"]:
+        assert np.array_equal(fast[n], slow[n])
+    assert np.isnan(fast["logP"]).all()
+    assert np.array_equal(livepoint.live_points_to_array(fast, names), a)
+    assert livepoint.array_to_live_points_fast(np.empty((0, 5)), names).size == 0
+
+
+def test_models_follow_the_reference_examples():
+    m = RosenbrockModel(3)
+    x = livepoint.numpy_array_to_live_points(np.array([[1.0, 1.0, 1.0], [0.0, 0.0, 6.0]]), m.names)
+    assert m.in_bounds(x).tolist() == [True, False]
+    lp = m.log_prior(x)
+    assert lp[0] == pytest.approx(-3 * np.log(10.0)) and lp[1] == -np.inf
+    assert m.log_likelihood(x)[0] == 0.0  # Rosenbrock minimum at (1, 1, 1)
+    g = GaussianModel(2)
+    y = livepoint.numpy_array_to_live_points(np.zeros((1, 2)), g.names)
+    assert g.log_likelihood(y)[0] == pytest.approx(-np.log(2 * np.pi))
+    assert g.bounds["x_0"] == [-10.0, 10.0]
+
+
+def test_radius_and_rescale_jacobian():
+    assert round(float(compute_radius(2, 0.8647)), 3) == 2.000
+    assert abs(compute_radius(32, 0.95) - 6.7966) < 1e-3
+    scales = [0.5, 2.0, 3.0]
+    assert rescale_log_jacobian(scales) == pytest.approx(np.log(3.0))
+
+
+def test_check_batch_size():
+    """FlowModel.check_batch_size (flowmodel/base.py:195-236; reference
+    tests/test_flowmodel/test_flowmodel_base.py:145-183)."""
+    for data_size, batch_size in [(4010, 1000), (106, 21), (1000, 1000), (2000, 1000)]:
+        out = FlowModel.check_batch_size(np.arange(data_size), batch_size)
+        assert out >= int(0.1 * batch_size)
+        if not data_size % batch_size:
+            assert out == batch_size
+    assert FlowModel.check_batch_size(np.arange(25), 10, min_fraction=0.8) == 7
+    with pytest.raises(RuntimeError, match="Could not find a valid batch size"):
+        FlowModel.check_batch_size(np.arange(3), 2, min_fraction=1.0)
+    with pytest.raises(ValueError, match="Cannot use a batch size of 1"):
+        FlowModel.check_batch_size(np.arange(2), 1, min_fraction=1.0)
+
+
+def test_update_config_defaults():
+    fc, tc = update_config(dict(n_inputs=16), None)
+    assert fc["n_neurons"] == 32 and fc["n_blocks"] == 4 and fc["n_layers"] == 2
+    assert tc["lr"] == 1e-3 and tc["batch_size"] == 1000 and tc["patience"] == 20
+    assert tc["clip_grad_norm"] == 5.0 and tc["optimiser"] == "adamw"
+    with pytest.raises(RuntimeError, match="noise_scale"):
+        update_config(dict(n_inputs=2), dict(noise_type="constant"))
+
+
+def test_transform_policy_table():
+    """(tiles per chunk, features per lane per chunk, params per feature) the kernels are built for."""
+    assert pack.transform_policy("rq", 8) == (3, 2, 23)
+    assert pack.transform_policy("rq", 4) == (1, 1, 11)
+    assert pack.transform_policy("rq", 10) == (2, 1, 29)
+    assert pack.transform_policy("rq", 16) == (3, 1, 47)
+    assert pack.transform_policy("affine", 0) == (1, 8, 2)
+    assert pack.transform_policy("additive", 0) == (1, 16, 1)
+    assert [pack.hidden_tiles(h) for h in (8, 32, 33, 64, 65, 96, 128)] == [1, 1, 2, 2, 4, 4, 4]
+
+
+def test_flow_model_requires_rocm_device(tmp_path):
+    fm = FlowModel(flow_config=dict(n_inputs=4, n_neurons=8, n_blocks=2, n_layers=2, ftype="nsf"),
+                   training_config=dict(device_tag="cpu"), output=str(tmp_path))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fm.initialise()
