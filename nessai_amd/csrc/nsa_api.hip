@@ -102,7 +102,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     return nsa_fail(NSA_E_ARG, "no kernel instance for hidden_tiles=%u transform=%u bins=%u",
                     h[NSA_H_HT], h[NSA_H_TRANSFORM], h[NSA_H_BINS]);
   const int D = (int)h[NSA_H_D];
-  const int XS = D | 1;
+  const int XS = (D + 1) | 1;
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
   int nw = waves_per_group > 0 ? waves_per_group : 4;
   if (nw > 8) nw = 8;

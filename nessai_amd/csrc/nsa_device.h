@@ -91,18 +91,42 @@ struct NsaTransformConsts {
   float tail_bound, two_b;          // B and (right - left) = 2B
   float min_bw, bw_scale;           // min_bin_width, 1 - min_bin_width*K
   float min_bh, bh_scale;
-  float min_d, edge_raw;            // min_derivative, log(exp(1-min_d)-1)
-  float logit_div;                  // sqrt(hidden_features) or 1
+  float min_d, edge_d;              // min_derivative, boundary derivative (== 1 up to f32 rounding)
+  float inv_logit_div;              // 1/sqrt(hidden_features) or 1
 };
 
+// Fast-but-accurate scalar helpers.  The spline's arithmetic *structure* follows
+// oracle/nflows_restated/splines.py; transcendental pieces use the hardware
+// v_exp/v_log/v_rcp units (<= 2 ulp) instead of the multi-instruction IEEE
+// sequences, which keeps log_prob within the 1e-5 relative parity bar (measured
+// in tests/test_gpu_flows.py) at a third of the VALU instruction count.
+__device__ __forceinline__ float nsa_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float nsa_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float nsa_log(float x) { return __logf(x); }
+
+// log(1 + u) for u in [0, 1]: 2*atanh(u / (2 + u)) as an odd series, relative
+// error < 1e-7 over the whole range (no cancellation for tiny u).
+__device__ __forceinline__ float nsa_log1p_unit(float u) {
+  const float s = u * nsa_rcp(2.0f + u);  // <= 1/3
+  const float t = s * s;
+  float p = fmaf(t, 1.0f / 15.0f, 1.0f / 13.0f);
+  p = fmaf(t, p, 1.0f / 11.0f);
+  p = fmaf(t, p, 1.0f / 9.0f);
+  p = fmaf(t, p, 1.0f / 7.0f);
+  p = fmaf(t, p, 1.0f / 5.0f);
+  p = fmaf(t, p, 1.0f / 3.0f);
+  p = fmaf(t, p, 1.0f);
+  return 2.0f * s * p;
+}
+
+// F.softplus(x) = max(x, 0) + log1p(exp(-|x|)); equals x for x > 20 in f32,
+// which is torch's threshold behaviour.
 __device__ __forceinline__ float nsa_softplus(float x) {
-  // F.softplus(x, beta=1, threshold=20)
-  return (x > 20.0f) ? x : log1pf(expf(x));
+  return fmaxf(x, 0.0f) + nsa_log1p_unit(nsa_exp(-fabsf(x)));
 }
 
 // Monotonic rational-quadratic spline with linear tails.  Restates the
-// arithmetic of oracle/nflows_restated/splines.py (same operation order, no
-// FMA contraction) for one scalar input.
+// arithmetic of oracle/nflows_restated/splines.py for one scalar input.
 //   v[0..K)      unnormalised widths
 //   v[K..2K)     unnormalised heights
 //   v[2K..3K-1)  unnormalised interior derivatives
@@ -112,85 +136,64 @@ struct NsaRQ {
   static constexpr int FPC = (K == 8) ? 2 : 1;
   static constexpr int C = (FPC * NP + 15) / 16;
   static constexpr int KIND = NSA_T_RQ;
+  static constexpr int VALU_EST = 60 + 46 * K;  // VALU instructions per feature (scheduling hint)
+
+  // knots of one axis: softmax -> min + scale*p -> cumulative sum mapped to [-B, B]
+  template <int OFF, int NV>
+  __device__ __forceinline__ static void knots(const float (&v)[NV], float inv_div, float mn,
+                                               float sc, float two_b, float B, float (&cum)[K + 1]) {
+    float u[K];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { u[i] = v[OFF + i] * inv_div; m = fmaxf(m, u[i]); }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { u[i] = nsa_exp(u[i] - m); s += u[i]; }
+    const float inv_s = nsa_rcp(s);
+    float run = 0.0f;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      run += fmaf(sc, u[i] * inv_s, mn);
+      cum[i + 1] = fmaf(two_b, run, -B);
+    }
+    cum[0] = -B;
+    cum[K] = B;
+  }
 
   template <int OFF, int NV>
   __device__ __forceinline__ static void apply(const float (&v)[NV], float x, bool inverse,
                                                const NsaTransformConsts& c, float& y, float& ld,
                                                bool& bad) {
-#pragma clang fp contract(off)
     const float B = c.tail_bound;
     const bool inside = (x >= -B) && (x <= B);
     const float xin = inside ? x : 0.0f;
 
     float cw[K + 1], ch[K + 1], dv[K + 1];
-    {
-      float u[K];
-      float m = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < K; ++i) { u[i] = v[OFF + i] / c.logit_div; m = fmaxf(m, u[i]); }
-      float s = 0.0f;
-#pragma unroll
-      for (int i = 0; i < K; ++i) { u[i] = expf(u[i] - m); s += u[i]; }
-      float run = 0.0f;
-#pragma unroll
-      for (int i = 0; i < K; ++i) {
-        const float w = c.min_bw + c.bw_scale * (u[i] / s);
-        run = run + w;
-        cw[i + 1] = c.two_b * run + (-B);
-      }
-      cw[0] = -B;
-      cw[K] = B;
-    }
-    {
-      float u[K];
-      float m = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < K; ++i) { u[i] = v[OFF + K + i] / c.logit_div; m = fmaxf(m, u[i]); }
-      float s = 0.0f;
-#pragma unroll
-      for (int i = 0; i < K; ++i) { u[i] = expf(u[i] - m); s += u[i]; }
-      float run = 0.0f;
-#pragma unroll
-      for (int i = 0; i < K; ++i) {
-        const float h = c.min_bh + c.bh_scale * (u[i] / s);
-        run = run + h;
-        ch[i + 1] = c.two_b * run + (-B);
-      }
-      ch[0] = -B;
-      ch[K] = B;
-    }
-    dv[0] = c.min_d + nsa_softplus(c.edge_raw);
-    dv[K] = dv[0];
+    knots<OFF, NV>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw);
+    knots<OFF + K, NV>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch);
+    dv[0] = c.edge_d;
+    dv[K] = c.edge_d;
 #pragma unroll
     for (int i = 1; i < K; ++i) dv[i] = c.min_d + nsa_softplus(v[OFF + 2 * K + i - 1]);
 
-    // searchsorted with the last knot nudged by 1e-6
-    int bin = -1;
-#pragma unroll
-    for (int i = 0; i <= K; ++i) {
-      const float base = inverse ? ch[i] : cw[i];
-      const float kn = (i == K) ? (base + 1e-6f) : base;
-      bin += (xin >= kn) ? 1 : 0;
-    }
-    bin = min(max(bin, 0), K - 1);
-
+    // searchsorted with the last knot nudged by 1e-6; select the bin's knots
     float in_cw = cw[0], in_cw1 = cw[1], in_ch = ch[0], in_ch1 = ch[1], in_d = dv[0], in_d1 = dv[1];
 #pragma unroll
     for (int i = 1; i < K; ++i) {
-      const bool sel = (bin == i);
-      in_cw = sel ? cw[i] : in_cw;
-      in_cw1 = sel ? cw[i + 1] : in_cw1;
-      in_ch = sel ? ch[i] : in_ch;
-      in_ch1 = sel ? ch[i + 1] : in_ch1;
-      in_d = sel ? dv[i] : in_d;
-      in_d1 = sel ? dv[i + 1] : in_d1;
+      const bool ge = inverse ? (xin >= ch[i]) : (xin >= cw[i]);
+      in_cw = ge ? cw[i] : in_cw;
+      in_cw1 = ge ? cw[i + 1] : in_cw1;
+      in_ch = ge ? ch[i] : in_ch;
+      in_ch1 = ge ? ch[i + 1] : in_ch1;
+      in_d = ge ? dv[i] : in_d;
+      in_d1 = ge ? dv[i + 1] : in_d1;
     }
     const float in_w = in_cw1 - in_cw;
     const float in_h = in_ch1 - in_ch;
     const float delta = in_h / in_w;
     const float curv = (in_d + in_d1) - 2.0f * delta;
 
-    float out, lad;
+    float out, dnum, den;
     if (inverse) {
       const float sh = xin - in_ch;
       const float a = sh * curv + in_h * (delta - in_d);
@@ -201,21 +204,20 @@ struct NsaRQ {
       const float root = (2.0f * cc) / (-b - sqrtf(disc));
       out = root * in_w + in_cw;
       const float tomt = root * (1.0f - root);
-      const float den = delta + curv * tomt;
       const float omr = 1.0f - root;
-      const float dnum = (delta * delta) * ((in_d1 * (root * root) + (2.0f * delta) * tomt) + in_d * (omr * omr));
-      lad = -(logf(dnum) - 2.0f * logf(den));
+      den = delta + curv * tomt;
+      dnum = (delta * delta) * ((in_d1 * (root * root) + (2.0f * delta) * tomt) + in_d * (omr * omr));
     } else {
       bad = false;
       const float theta = (xin - in_cw) / in_w;
       const float tomt = theta * (1.0f - theta);
-      const float num = in_h * (delta * (theta * theta) + in_d * tomt);
-      const float den = delta + curv * tomt;
-      out = in_ch + num / den;
       const float omt = 1.0f - theta;
-      const float dnum = (delta * delta) * ((in_d1 * (theta * theta) + (2.0f * delta) * tomt) + in_d * (omt * omt));
-      lad = logf(dnum) - 2.0f * logf(den);
+      den = delta + curv * tomt;
+      out = in_ch + (in_h * (delta * (theta * theta) + in_d * tomt)) / den;
+      dnum = (delta * delta) * ((in_d1 * (theta * theta) + (2.0f * delta) * tomt) + in_d * (omt * omt));
     }
+    float lad = nsa_log(dnum) - 2.0f * nsa_log(den);
+    lad = inverse ? -lad : lad;
     y = inside ? out : x;
     ld = inside ? lad : 0.0f;
   }
@@ -228,16 +230,16 @@ struct NsaAffine {
   static constexpr int FPC = 8;
   static constexpr int C = 1;
   static constexpr int KIND = NSA_T_AFFINE;
+  static constexpr int VALU_EST = 24;
 
   template <int OFF, int NV>
   __device__ __forceinline__ static void apply(const float (&v)[NV], float x, bool inverse,
                                                const NsaTransformConsts&, float& y, float& ld,
                                                bool& bad) {
-#pragma clang fp contract(off)
     const float shift = v[OFF];
     const float raw = v[OFF + 1] + 2.0f;
-    const float scale = 1.0f / (1.0f + expf(-raw)) + 1e-3f;
-    const float ls = logf(scale);
+    const float scale = nsa_rcp(1.0f + nsa_exp(-raw)) + 1e-3f;
+    const float ls = nsa_log(scale);
     bad = false;
     if (inverse) { y = (x - shift) / scale; ld = -ls; }
     else { y = x * scale + shift; ld = ls; }
@@ -250,6 +252,7 @@ struct NsaAdditive {
   static constexpr int FPC = 16;
   static constexpr int C = 1;
   static constexpr int KIND = NSA_T_ADDITIVE;
+  static constexpr int VALU_EST = 6;
 
   template <int OFF, int NV>
   __device__ __forceinline__ static void apply(const float (&v)[NV], float x, bool inverse,

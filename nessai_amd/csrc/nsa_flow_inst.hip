@@ -24,7 +24,8 @@ using TP = NsaAdditive;
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t NSA_LAUNCH_NAME(
     const NsaLaunch* p, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
-  auto kern = nsa_flow_kernel<NSA_HT, TP>;
+  auto kern = (p->direction == NSA_DIR_INVERSE) ? nsa_flow_kernel<NSA_HT, TP, true>
+                                                : nsa_flow_kernel<NSA_HT, TP, false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

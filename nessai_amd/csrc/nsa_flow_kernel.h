@@ -187,36 +187,67 @@ __device__ __forceinline__ void nsa_act_regs(float (&a)[N], int act) {
 
 // element-wise transform of the features a lane owns in one chunk ------------
 
-template <class TP, int Q, int NV>
-__device__ __forceinline__ void nsa_transform_one(const float (&v)[NV], const int* tab, float* xrow,
-                                                  bool inverse, const NsaTransformConsts& tc,
-                                                  float& logdet, int& n_bad) {
-  const int col = tab[Q];
-  if (col >= 0) {
-    const float x = xrow[col];
-    float y, ld;
-    bool bad;
-    TP::template apply<Q * TP::NP, NV>(v, x, inverse, tc, y, ld, bad);
-    xrow[col] = y;
-    logdet += ld;
-    n_bad += bad ? 1 : 0;
-  }
+template <class TP, bool INV, int Q, int NV>
+__device__ __forceinline__ void nsa_transform_one(const float (&v)[NV], const int (&cols)[TP::FPC],
+                                                  float* xrow, int dummy_col,
+                                                  const NsaTransformConsts& tc, float& logdet,
+                                                  int& n_bad) {
+  // unused feature slots (col < 0) run on the tile's spare column and add nothing
+  const int col = cols[Q];
+  const bool live = col >= 0;
+  const int c = live ? col : dummy_col;
+  const float x = xrow[c];
+  float y, ld;
+  bool bad;
+  TP::template apply<Q * TP::NP, NV>(v, x, INV, tc, y, ld, bad);
+  xrow[c] = y;
+  logdet += live ? ld : 0.0f;
+  n_bad += (live && bad) ? 1 : 0;
 }
 
-template <class TP, int NV, int... Q>
-__device__ __forceinline__ void nsa_transform_features(const float (&v)[NV], const int* tab,
-                                                       float* xrow, bool inverse,
+template <class TP, bool INV, int NV, int... Q>
+__device__ __forceinline__ void nsa_transform_features(const float (&v)[NV],
+                                                       const int (&cols)[TP::FPC], float* xrow,
+                                                       int dummy_col,
                                                        const NsaTransformConsts& tc, float& logdet,
                                                        int& n_bad,
                                                        std::integer_sequence<int, Q...>) {
-  (nsa_transform_one<TP, Q, NV>(v, tab, xrow, inverse, tc, logdet, n_bad), ...);
+  (nsa_transform_one<TP, INV, Q, NV>(v, cols, xrow, dummy_col, tc, logdet, n_bad), ...);
+}
+
+// Scheduling recipe for a block holding N_MFMA matrix instructions and an
+// independent stream of VALU work: ask the machine scheduler for the pattern
+// {1 MFMA, VALU_PER VALU/TRANS} (+ one LDS read per four MFMAs, their shared A
+// operand) instead of its default "all MFMAs back to back".
+template <int N_MFMA, int VALU_PER>
+__device__ __forceinline__ void nsa_sched_interleave() {
+#pragma unroll
+  for (int i = 0; i < N_MFMA; ++i) {
+    if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);             // VALU
+  }
+}
+
+// MFMAs of one chunk of the last conditioner layer + the lane's column table
+template <int HT, class TP>
+__device__ __forceinline__ void nsa_chunk_gemm(const float* st, const float (&h)[16 * HT], int lane,
+                                               int half, f32x16 (&acc)[TP::C], int (&cols)[TP::FPC]) {
+  constexpr int TABW = (2 * TP::FPC + 3) & ~3;
+  const int* tr_tab = (const int*)st;
+  const float* bias = st + TABW;
+  const float* w = bias + 32 * TP::C;
+#pragma unroll
+  for (int q = 0; q < TP::FPC; ++q) cols[q] = tr_tab[half * TP::FPC + q];
+  nsa_load_bias<TP::C>(bias, half, acc);
+  nsa_dense_regs<HT, TP::C>(w, h, lane, acc);
 }
 
 // one coupling layer -----------------------------------------------------------
 
-template <int HT, class TP>
+template <int HT, class TP, bool INV>
 __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t* op, float* xrow,
-                                             int lane, int half, bool inverse, int act, int net,
+                                             int dummy_col, int lane, int half, int act, int net,
                                              int n_layers, const NsaTransformConsts& tc,
                                              float& logdet, int& n_bad) {
   const int n_steps0 = (int)op[1];
@@ -278,25 +309,42 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     }
   }
 
-  // last layer in chunks of TP::C tiles; every lane gets TP::FPC complete
-  // parameter sets per chunk and transforms those features in place
-  constexpr int TABW = (2 * TP::FPC + 3) & ~3;
-  for (int c = 0; c < n_chunks; ++c) {
+  // Last layer in chunks of TP::C tiles: every lane gets TP::FPC complete
+  // parameter sets per chunk and transforms those features in place.  The loop
+  // is software-pipelined: the MFMAs of chunk c+1 are issued in the same basic
+  // block as the element-wise transform of chunk c (registers only), so the
+  // matrix pipe works under the spline's VALU instructions.
+  f32x16 acc[TP::C];
+  int cols[TP::FPC];
+  {
     const float* st = pipe.begin();
-    const int* tr_tab = (const int*)st;
-    const float* bias = st + TABW;
-    const float* w = bias + 32 * TP::C;
-    f32x16 acc[TP::C];
-    nsa_load_bias<TP::C>(bias, half, acc);
-    nsa_dense_regs<HT, TP::C>(w, h, lane, acc);
+    nsa_chunk_gemm<HT, TP>(st, h, lane, half, acc, cols);
+    pipe.end();
+  }
+  for (int c = 0; c + 1 < n_chunks; ++c) {
+    float v[16 * TP::C];
+    int vcols[TP::FPC];
+#pragma unroll
+    for (int t = 0; t < TP::C; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[16 * t + r] = acc[t][r];
+#pragma unroll
+    for (int q = 0; q < TP::FPC; ++q) vcols[q] = cols[q];
+    const float* st = pipe.begin();
+    nsa_chunk_gemm<HT, TP>(st, h, lane, half, acc, cols);
+    nsa_transform_features<TP, INV>(v, vcols, xrow, dummy_col, tc, logdet, n_bad,
+                               std::make_integer_sequence<int, TP::FPC>{});
+    nsa_sched_interleave<TP::C * 16 * HT, (TP::VALU_EST * TP::FPC) / (TP::C * 16 * HT)>();
+    pipe.end();
+  }
+  {
     float v[16 * TP::C];
 #pragma unroll
     for (int t = 0; t < TP::C; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[16 * t + r] = acc[t][r];
-    nsa_transform_features<TP>(v, tr_tab + half * TP::FPC, xrow, inverse, tc, logdet, n_bad,
+    nsa_transform_features<TP, INV>(v, cols, xrow, dummy_col, tc, logdet, n_bad,
                                std::make_integer_sequence<int, TP::FPC>{});
-    pipe.end();
   }
 }
 
@@ -352,18 +400,18 @@ __device__ __forceinline__ void nsa_elementwise_op(NsaStagePipe& pipe, const uin
 
 // the kernel ------------------------------------------------------------------
 
-template <int HT, class TP>
+template <int HT, class TP, bool INV>
 __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const uint32_t* img = p.image;
   const int D = (int)img[NSA_H_D];
-  const int XS = D | 1;  // odd row stride: conflict-free column reads
+  const int XS = (D + 1) | 1;  // odd row stride (conflict-free column reads) with >= 1 spare column
   const int nw = (int)(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
   const int half = lane >> 5;
   const int j = lane & 31;
-  const bool inverse = (p.direction == NSA_DIR_INVERSE);
+  constexpr bool inverse = INV;  // p.direction selects the instantiation on the host
 
   const int tiles_words = (nw * NSA_ROWS * XS + 3) & ~3;
   const int max_stage = (int)img[NSA_H_MAX_STAGE];
@@ -390,8 +438,8 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
   tc.min_bw = nsa_bits_to_float(img[NSA_H_MIN_BW]);
   tc.min_bh = nsa_bits_to_float(img[NSA_H_MIN_BH]);
   tc.min_d = nsa_bits_to_float(img[NSA_H_MIN_D]);
-  tc.edge_raw = nsa_bits_to_float(img[NSA_H_EDGE_RAW]);
-  tc.logit_div = nsa_bits_to_float(img[NSA_H_LOGIT_DIV]);
+  tc.edge_d = tc.min_d + nsa_softplus(nsa_bits_to_float(img[NSA_H_EDGE_RAW]));
+  tc.inv_logit_div = 1.0f / nsa_bits_to_float(img[NSA_H_LOGIT_DIV]);
   {
     const int K = (int)img[NSA_H_BINS];
     tc.bw_scale = (float)(1.0 - (double)tc.min_bw * K);
@@ -473,7 +521,7 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
       const uint32_t* op = ops + o * NSA_OP_WORDS;
       const int kind = (int)op[0];
       if (kind == NSA_OP_COUPLING) {
-        nsa_coupling<HT, TP>(pipe, op, xrow, lane, half, inverse, act, net, n_layers, tc, logdet, n_bad);
+        nsa_coupling<HT, TP, INV>(pipe, op, xrow, D, lane, half, act, net, n_layers, tc, logdet, n_bad);
       } else if (kind == NSA_OP_DENSE) {
         nsa_dense_op(pipe, op, xrow, D, lane, half, logdet);
       } else {

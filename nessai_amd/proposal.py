@@ -498,7 +498,6 @@ class FlowProposal:
                 z_np, u_np = next(injected)
                 n_local = int(len(z_np))
                 z_in = torch.from_numpy(np.ascontiguousarray(z_np)).to(torch.float32).to(self.device)
-                u_all.append(np.asarray(u_np, dtype=np.float64))
             fresh = buf is None
             buf = self._get_buffers(n_local, n_samples)
             self._launch_draw(n_local, z_in, self._draw_counter, threshold, buf["x64"], buf["log_q"], None)
@@ -506,6 +505,8 @@ class FlowProposal:
             n_proposed += n_local
             self._draw_counter += n_local
             valid = torch.isfinite(buf["log_w"][:n_local])
+            if injected is not None:  # uniforms belong to draws: keep those of the kept rows
+                u_all.append(np.asarray(u_np, dtype=np.float64)[valid.cpu().numpy()])
             xs.append(buf["x64"][:n_local][valid].clone())
             lws.append(buf["log_w"][:n_local][valid].clone())
             log_weights = torch.cat(lws)

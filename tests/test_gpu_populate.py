@@ -234,7 +234,7 @@ def test_full_size_c3_populate():
     state, shift, scale, _ = load_c3_fixture()
     prop, _ = build(32, "nsf", dict(n_neurons=64, n_blocks=6), poolsize=2000, drawsize=1_000_000,
                     state=state, shift=shift, scale=scale)
-    prop.populate(None, n_samples=2000, max_samples=20_000_000)
+    prop.populate(None, n_samples=2000, max_samples=10**9)
     assert prop.samples.size == 2000
     assert prop.model.in_bounds(prop.samples).all()
     assert np.isfinite(prop.samples["logP"]).all() and np.isfinite(prop.samples["logL"]).all()
