@@ -125,6 +125,12 @@ __device__ __forceinline__ float nsa_softplus(float x) {
   return fmaxf(x, 0.0f) + nsa_log1p_unit(nsa_exp(-fabsf(x)));
 }
 
+// Element-wise transforms are written as PHASES so that the kernel can issue
+// one phase between two groups of MFMAs of the next chunk (manual MFMA/VALU
+// interleave, see nsa_coupling).  A policy provides
+//   C, FPC, NP, NPH (phases per feature), State, and phase<P, OFF>(...);
+// running phases 0..NPH-1 in order transforms one feature of one row.
+
 // Monotonic rational-quadratic spline with linear tails.  Restates the
 // arithmetic of oracle/nflows_restated/splines.py for one scalar input.
 //   v[0..K)      unnormalised widths
@@ -136,7 +142,12 @@ struct NsaRQ {
   static constexpr int FPC = (K == 8) ? 2 : 1;
   static constexpr int C = (FPC * NP + 15) / 16;
   static constexpr int KIND = NSA_T_RQ;
-  static constexpr int VALU_EST = 60 + 46 * K;  // VALU instructions per feature (scheduling hint)
+  static constexpr int NPH = 4;
+
+  struct State {
+    float cw[K + 1], ch[K + 1], dv[K + 1];
+    float x;
+  };
 
   // knots of one axis: softmax -> min + scale*p -> cumulative sum mapped to [-B, B]
   template <int OFF, int NV>
@@ -160,66 +171,71 @@ struct NsaRQ {
     cum[K] = B;
   }
 
-  template <int OFF, int NV>
-  __device__ __forceinline__ static void apply(const float (&v)[NV], float x, bool inverse,
+  // phases 0..2 fill the state from the parameters; phase 3 evaluates the spline
+  template <int P, int OFF, bool INV, int NV>
+  __device__ __forceinline__ static void phase(State& st, const float (&v)[NV], float x_in,
                                                const NsaTransformConsts& c, float& y, float& ld,
                                                bool& bad) {
     const float B = c.tail_bound;
-    const bool inside = (x >= -B) && (x <= B);
-    const float xin = inside ? x : 0.0f;
-
-    float cw[K + 1], ch[K + 1], dv[K + 1];
-    knots<OFF, NV>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw);
-    knots<OFF + K, NV>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch);
-    dv[0] = c.edge_d;
-    dv[K] = c.edge_d;
+    if constexpr (P == 0) {
+      st.x = x_in;
+      knots<OFF, NV>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, st.cw);
+    } else if constexpr (P == 1) {
+      knots<OFF + K, NV>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, st.ch);
+    } else if constexpr (P == 2) {
+      st.dv[0] = c.edge_d;
+      st.dv[K] = c.edge_d;
 #pragma unroll
-    for (int i = 1; i < K; ++i) dv[i] = c.min_d + nsa_softplus(v[OFF + 2 * K + i - 1]);
-
-    // searchsorted with the last knot nudged by 1e-6; select the bin's knots
-    float in_cw = cw[0], in_cw1 = cw[1], in_ch = ch[0], in_ch1 = ch[1], in_d = dv[0], in_d1 = dv[1];
-#pragma unroll
-    for (int i = 1; i < K; ++i) {
-      const bool ge = inverse ? (xin >= ch[i]) : (xin >= cw[i]);
-      in_cw = ge ? cw[i] : in_cw;
-      in_cw1 = ge ? cw[i + 1] : in_cw1;
-      in_ch = ge ? ch[i] : in_ch;
-      in_ch1 = ge ? ch[i + 1] : in_ch1;
-      in_d = ge ? dv[i] : in_d;
-      in_d1 = ge ? dv[i + 1] : in_d1;
-    }
-    const float in_w = in_cw1 - in_cw;
-    const float in_h = in_ch1 - in_ch;
-    const float delta = in_h / in_w;
-    const float curv = (in_d + in_d1) - 2.0f * delta;
-
-    float out, dnum, den;
-    if (inverse) {
-      const float sh = xin - in_ch;
-      const float a = sh * curv + in_h * (delta - in_d);
-      const float b = in_h * in_d - sh * curv;
-      const float cc = -delta * sh;
-      const float disc = b * b - 4.0f * a * cc;
-      bad = inside && !(disc >= 0.0f);
-      const float root = (2.0f * cc) / (-b - sqrtf(disc));
-      out = root * in_w + in_cw;
-      const float tomt = root * (1.0f - root);
-      const float omr = 1.0f - root;
-      den = delta + curv * tomt;
-      dnum = (delta * delta) * ((in_d1 * (root * root) + (2.0f * delta) * tomt) + in_d * (omr * omr));
+      for (int i = 1; i < K; ++i) st.dv[i] = c.min_d + nsa_softplus(v[OFF + 2 * K + i - 1]);
     } else {
-      bad = false;
-      const float theta = (xin - in_cw) / in_w;
-      const float tomt = theta * (1.0f - theta);
-      const float omt = 1.0f - theta;
-      den = delta + curv * tomt;
-      out = in_ch + (in_h * (delta * (theta * theta) + in_d * tomt)) / den;
-      dnum = (delta * delta) * ((in_d1 * (theta * theta) + (2.0f * delta) * tomt) + in_d * (omt * omt));
+      const float x = st.x;
+      const bool inside = (x >= -B) && (x <= B);
+      const float xin = inside ? x : 0.0f;
+      // searchsorted (knots are increasing): keep the last knot <= x
+      float in_cw = st.cw[0], in_cw1 = st.cw[1], in_ch = st.ch[0], in_ch1 = st.ch[1];
+      float in_d = st.dv[0], in_d1 = st.dv[1];
+#pragma unroll
+      for (int i = 1; i < K; ++i) {
+        const bool ge = INV ? (xin >= st.ch[i]) : (xin >= st.cw[i]);
+        in_cw = ge ? st.cw[i] : in_cw;
+        in_cw1 = ge ? st.cw[i + 1] : in_cw1;
+        in_ch = ge ? st.ch[i] : in_ch;
+        in_ch1 = ge ? st.ch[i + 1] : in_ch1;
+        in_d = ge ? st.dv[i] : in_d;
+        in_d1 = ge ? st.dv[i + 1] : in_d1;
+      }
+      const float in_w = in_cw1 - in_cw;
+      const float in_h = in_ch1 - in_ch;
+      const float delta = in_h / in_w;
+      const float curv = (in_d + in_d1) - 2.0f * delta;
+      float out, dnum, den;
+      if constexpr (INV) {
+        const float sh = xin - in_ch;
+        const float a = sh * curv + in_h * (delta - in_d);
+        const float b = in_h * in_d - sh * curv;
+        const float cc = -delta * sh;
+        const float disc = b * b - 4.0f * a * cc;
+        bad = inside && !(disc >= 0.0f);
+        const float root = (2.0f * cc) / (-b - sqrtf(disc));
+        out = root * in_w + in_cw;
+        const float tomt = root * (1.0f - root);
+        const float omr = 1.0f - root;
+        den = delta + curv * tomt;
+        dnum = (delta * delta) * ((in_d1 * (root * root) + (2.0f * delta) * tomt) + in_d * (omr * omr));
+      } else {
+        bad = false;
+        const float theta = (xin - in_cw) / in_w;
+        const float tomt = theta * (1.0f - theta);
+        const float omt = 1.0f - theta;
+        den = delta + curv * tomt;
+        out = in_ch + (in_h * (delta * (theta * theta) + in_d * tomt)) / den;
+        dnum = (delta * delta) * ((in_d1 * (theta * theta) + (2.0f * delta) * tomt) + in_d * (omt * omt));
+      }
+      float lad = nsa_log(dnum) - 2.0f * nsa_log(den);
+      lad = INV ? -lad : lad;
+      y = inside ? out : x;
+      ld = inside ? lad : 0.0f;
     }
-    float lad = nsa_log(dnum) - 2.0f * nsa_log(den);
-    lad = inverse ? -lad : lad;
-    y = inside ? out : x;
-    ld = inside ? lad : 0.0f;
   }
 };
 
@@ -230,10 +246,11 @@ struct NsaAffine {
   static constexpr int FPC = 8;
   static constexpr int C = 1;
   static constexpr int KIND = NSA_T_AFFINE;
-  static constexpr int VALU_EST = 24;
+  static constexpr int NPH = 1;
+  struct State {};
 
-  template <int OFF, int NV>
-  __device__ __forceinline__ static void apply(const float (&v)[NV], float x, bool inverse,
+  template <int P, int OFF, bool INV, int NV>
+  __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
                                                const NsaTransformConsts&, float& y, float& ld,
                                                bool& bad) {
     const float shift = v[OFF];
@@ -241,8 +258,8 @@ struct NsaAffine {
     const float scale = nsa_rcp(1.0f + nsa_exp(-raw)) + 1e-3f;
     const float ls = nsa_log(scale);
     bad = false;
-    if (inverse) { y = (x - shift) / scale; ld = -ls; }
-    else { y = x * scale + shift; ld = ls; }
+    if constexpr (INV) { y = (x - shift) / scale; ld = -ls; }
+    else { y = fmaf(x, scale, shift); ld = ls; }
   }
 };
 
@@ -252,16 +269,15 @@ struct NsaAdditive {
   static constexpr int FPC = 16;
   static constexpr int C = 1;
   static constexpr int KIND = NSA_T_ADDITIVE;
-  static constexpr int VALU_EST = 6;
+  static constexpr int NPH = 1;
+  struct State {};
 
-  template <int OFF, int NV>
-  __device__ __forceinline__ static void apply(const float (&v)[NV], float x, bool inverse,
+  template <int P, int OFF, bool INV, int NV>
+  __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
                                                const NsaTransformConsts&, float& y, float& ld,
                                                bool& bad) {
-#pragma clang fp contract(off)
     bad = false;
     ld = 0.0f;
-    // scale == 1: x * 1 + shift and (x - shift) / 1 are exact
-    y = inverse ? (x - v[OFF]) : (x + v[OFF]);
+    y = INV ? (x - v[OFF]) : (x + v[OFF]);  // scale == 1: exact
   }
 };

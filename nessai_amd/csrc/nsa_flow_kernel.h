@@ -186,61 +186,100 @@ __device__ __forceinline__ void nsa_act_regs(float (&a)[N], int act) {
 }
 
 // element-wise transform of the features a lane owns in one chunk ------------
+//
+// A chunk holds TP::FPC features per lane, each transformed in TP::NPH phases;
+// global phase index PH = feature * NPH + phase.
 
-template <class TP, bool INV, int Q, int NV>
-__device__ __forceinline__ void nsa_transform_one(const float (&v)[NV], const int (&cols)[TP::FPC],
-                                                  float* xrow, int dummy_col,
-                                                  const NsaTransformConsts& tc, float& logdet,
-                                                  int& n_bad) {
+template <class TP, bool INV, int PH, int NV>
+__device__ __forceinline__ void nsa_run_phase(typename TP::State (&st)[TP::FPC], const float (&v)[NV],
+                                              const int (&cols)[TP::FPC], float* xrow,
+                                              int dummy_col, const NsaTransformConsts& tc,
+                                              float& logdet, int& n_bad) {
+  constexpr int Q = PH / TP::NPH, P = PH % TP::NPH;
   // unused feature slots (col < 0) run on the tile's spare column and add nothing
   const int col = cols[Q];
   const bool live = col >= 0;
   const int c = live ? col : dummy_col;
-  const float x = xrow[c];
-  float y, ld;
-  bool bad;
-  TP::template apply<Q * TP::NP, NV>(v, x, INV, tc, y, ld, bad);
-  xrow[c] = y;
-  logdet += live ? ld : 0.0f;
-  n_bad += (live && bad) ? 1 : 0;
-}
-
-template <class TP, bool INV, int NV, int... Q>
-__device__ __forceinline__ void nsa_transform_features(const float (&v)[NV],
-                                                       const int (&cols)[TP::FPC], float* xrow,
-                                                       int dummy_col,
-                                                       const NsaTransformConsts& tc, float& logdet,
-                                                       int& n_bad,
-                                                       std::integer_sequence<int, Q...>) {
-  (nsa_transform_one<TP, INV, Q, NV>(v, cols, xrow, dummy_col, tc, logdet, n_bad), ...);
-}
-
-// Scheduling recipe for a block holding N_MFMA matrix instructions and an
-// independent stream of VALU work: ask the machine scheduler for the pattern
-// {1 MFMA, VALU_PER VALU/TRANS} (+ one LDS read per four MFMAs, their shared A
-// operand) instead of its default "all MFMAs back to back".
-template <int N_MFMA, int VALU_PER>
-__device__ __forceinline__ void nsa_sched_interleave() {
-#pragma unroll
-  for (int i = 0; i < N_MFMA; ++i) {
-    if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // MFMA
-    __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);             // VALU
+  float x_in = 0.0f;
+  if constexpr (P == 0) x_in = xrow[c];
+  float y = 0.0f, ld = 0.0f;
+  bool bad = false;
+  TP::template phase<P, Q * TP::NP, INV, NV>(st[Q], v, x_in, tc, y, ld, bad);
+  if constexpr (P == TP::NPH - 1) {
+    xrow[c] = y;
+    logdet += live ? ld : 0.0f;
+    n_bad += (live && bad) ? 1 : 0;
   }
 }
 
-// MFMAs of one chunk of the last conditioner layer + the lane's column table
-template <int HT, class TP>
-__device__ __forceinline__ void nsa_chunk_gemm(const float* st, const float (&h)[16 * HT], int lane,
-                                               int half, f32x16 (&acc)[TP::C], int (&cols)[TP::FPC]) {
+template <class TP, bool INV, int LO, int NV, int... I>
+__device__ __forceinline__ void nsa_run_phases(typename TP::State (&st)[TP::FPC], const float (&v)[NV],
+                                               const int (&cols)[TP::FPC], float* xrow,
+                                               int dummy_col, const NsaTransformConsts& tc,
+                                               float& logdet, int& n_bad,
+                                               std::integer_sequence<int, I...>) {
+  (nsa_run_phase<TP, INV, LO + I, NV>(st, v, cols, xrow, dummy_col, tc, logdet, n_bad), ...);
+}
+
+template <class F, int... G>
+__device__ __forceinline__ void nsa_static_for(F&& body, std::integer_sequence<int, G...>) {
+  (body(std::integral_constant<int, G>{}), ...);
+}
+
+// MFMAs of one chunk of the last conditioner layer (-> acc, cols), optionally
+// interleaved with the element-wise phases of the PREVIOUS chunk (v, vcols):
+// the MFMAs are issued in 4*HT groups of 4*TP::C, each followed by its share
+// of the phases and a scheduling fence, so that on a SIMD shared by two waves
+// one wave's VALU phase runs under the other wave's MFMA group.  The A
+// operands (LDS) of group g+1 are fetched before the MFMAs of group g.
+template <int HT, class TP, bool INV, bool WITH_PHASES>
+__device__ __forceinline__ void nsa_chunk_gemm(const float* stg, const float (&h)[16 * HT], int lane,
+                                               int half, f32x16 (&acc)[TP::C], int (&cols)[TP::FPC],
+                                               const float (&v)[16 * TP::C],
+                                               const int (&vcols)[TP::FPC], float* xrow,
+                                               int dummy_col, const NsaTransformConsts& tc,
+                                               float& logdet, int& n_bad) {
   constexpr int TABW = (2 * TP::FPC + 3) & ~3;
-  const int* tr_tab = (const int*)st;
-  const float* bias = st + TABW;
+  constexpr int G = 4 * HT;
+  constexpr int TOT = TP::NPH * TP::FPC;
+  const int* tr_tab = (const int*)stg;
+  const float* bias = stg + TABW;
   const float* w = bias + 32 * TP::C;
 #pragma unroll
   for (int q = 0; q < TP::FPC; ++q) cols[q] = tr_tab[half * TP::FPC + q];
   nsa_load_bias<TP::C>(bias, half, acc);
-  nsa_dense_regs<HT, TP::C>(w, h, lane, acc);
+  typename TP::State st[TP::FPC];
+  f32x4 a_cur[TP::C];
+#pragma unroll
+  for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = *(const f32x4*)(w + ((ot * G + 0) * 64 + lane) * 4);
+  nsa_static_for(
+      [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        f32x4 a_nxt[TP::C];
+        if constexpr (g + 1 < G) {
+#pragma unroll
+          for (int ot = 0; ot < TP::C; ++ot)
+            a_nxt[ot] = *(const f32x4*)(w + ((ot * G + g + 1) * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int ot = 0; ot < TP::C; ++ot) {
+          acc[ot] = nsa_mfma(a_cur[ot][0], h[4 * g + 0], acc[ot]);
+          acc[ot] = nsa_mfma(a_cur[ot][1], h[4 * g + 1], acc[ot]);
+          acc[ot] = nsa_mfma(a_cur[ot][2], h[4 * g + 2], acc[ot]);
+          acc[ot] = nsa_mfma(a_cur[ot][3], h[4 * g + 3], acc[ot]);
+        }
+        if constexpr (WITH_PHASES) {
+          constexpr int LO = g * TOT / G, HI = (g + 1) * TOT / G;
+          nsa_run_phases<TP, INV, LO>(st, v, vcols, xrow, dummy_col, tc, logdet, n_bad,
+                                      std::make_integer_sequence<int, HI - LO>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (g + 1 < G) {
+#pragma unroll
+          for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = a_nxt[ot];
+        }
+      },
+      std::make_integer_sequence<int, G>{});
 }
 
 // one coupling layer -----------------------------------------------------------
@@ -311,19 +350,19 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
 
   // Last layer in chunks of TP::C tiles: every lane gets TP::FPC complete
   // parameter sets per chunk and transforms those features in place.  The loop
-  // is software-pipelined: the MFMAs of chunk c+1 are issued in the same basic
-  // block as the element-wise transform of chunk c (registers only), so the
-  // matrix pipe works under the spline's VALU instructions.
+  // is software-pipelined: the MFMAs of chunk c+1 are interleaved with the
+  // element-wise phases of chunk c (registers + the lane's own x-tile cells).
   f32x16 acc[TP::C];
   int cols[TP::FPC];
+  float v[16 * TP::C];
+  int vcols[TP::FPC];
   {
     const float* st = pipe.begin();
-    nsa_chunk_gemm<HT, TP>(st, h, lane, half, acc, cols);
+    nsa_chunk_gemm<HT, TP, INV, false>(st, h, lane, half, acc, cols, v, vcols, xrow, dummy_col, tc,
+                                       logdet, n_bad);
     pipe.end();
   }
   for (int c = 0; c + 1 < n_chunks; ++c) {
-    float v[16 * TP::C];
-    int vcols[TP::FPC];
 #pragma unroll
     for (int t = 0; t < TP::C; ++t)
 #pragma unroll
@@ -331,20 +370,18 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
 #pragma unroll
     for (int q = 0; q < TP::FPC; ++q) vcols[q] = cols[q];
     const float* st = pipe.begin();
-    nsa_chunk_gemm<HT, TP>(st, h, lane, half, acc, cols);
-    nsa_transform_features<TP, INV>(v, vcols, xrow, dummy_col, tc, logdet, n_bad,
-                               std::make_integer_sequence<int, TP::FPC>{});
-    nsa_sched_interleave<TP::C * 16 * HT, (TP::VALU_EST * TP::FPC) / (TP::C * 16 * HT)>();
+    nsa_chunk_gemm<HT, TP, INV, true>(st, h, lane, half, acc, cols, v, vcols, xrow, dummy_col, tc,
+                                      logdet, n_bad);
     pipe.end();
   }
   {
-    float v[16 * TP::C];
 #pragma unroll
     for (int t = 0; t < TP::C; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[16 * t + r] = acc[t][r];
-    nsa_transform_features<TP, INV>(v, cols, xrow, dummy_col, tc, logdet, n_bad,
-                               std::make_integer_sequence<int, TP::FPC>{});
+    typename TP::State sts[TP::FPC];
+    nsa_run_phases<TP, INV, 0>(sts, v, cols, xrow, dummy_col, tc, logdet, n_bad,
+                               std::make_integer_sequence<int, TP::NPH * TP::FPC>{});
   }
 }
 
