@@ -138,6 +138,38 @@ NSA_API int nsa_populate_accept(long long n, int D, const double* log_w_dev, con
                         double* x_acc_dev, long long* idx_acc_dev, long long* n_accept_dev,
                         void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ---- training (nessai_amd/csrc/nsa_train.hip) ---------------------------------
+ *
+ * One minibatch of FlowModel._train (src/nessai/flowmodel/base.py:365-452):
+ * forward, loss = -mean(log_prob(x)) (flows/base.py:236-245), backward,
+ * clip_grad_norm_(clip_norm) and torch.optim.AdamW.step(), enqueued on `stream`
+ * with no host round trip.
+ *
+ *   plan        int64 host array describing the flow: header {D, hidden, residual
+ *               blocks, coupling layers, transform, bins, activation, params per
+ *               feature, n trainable floats, record words} then one record per
+ *               coupling layer {d_id, d_tr, id table offset, tr table offset,
+ *               flat-buffer offsets of W0, b0, {W1, b1, W2, b2} x blocks, Wf, bf}
+ *   tables_dev  int32 physical column tables (permutations folded in)
+ *   consts      float host array {tail_bound, min_bin_width, min_bin_height,
+ *               min_derivative, boundary derivative, 1/sqrt(hidden), 1/var, log_z}
+ *   params/grads/adam_m/adam_v   flat float32 buffers (n trainable floats)
+ *   x_dev       [n][D] float32 minibatch;  step = 1-based optimiser step count
+ *   loss_acc_dev  float[1], the minibatch loss is ADDED (read once per epoch)
+ */
+NSA_API size_t nsa_train_workspace_floats(const long long* plan, long long n);
+NSA_API int nsa_train_step(const long long* plan, const int* tables_dev, const float* consts,
+                           float* params_dev, float* grads_dev, float* adam_m_dev, float* adam_v_dev,
+                           const float* x_dev, long long n, float* workspace_dev, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, float clip_norm, long long step,
+                           float* loss_acc_dev, void* stream);
+/* Forward only (FlowModel._validate, flowmodel/base.py:454-523):
+ * loss_acc_dev[0] += -mean(log_prob(x)); log_prob_out_dev [n] may be NULL. */
+NSA_API int nsa_train_eval(const long long* plan, const int* tables_dev, const float* consts,
+                           const float* params_dev, const float* x_dev, long long n,
+                           float* workspace_dev, float* loss_acc_dev, float* log_prob_out_dev,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

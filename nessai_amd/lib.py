@@ -17,6 +17,7 @@ c_ll = ctypes.c_longlong
 c_ull = ctypes.c_ulonglong
 c_double = ctypes.c_double
 c_size_t = ctypes.c_size_t
+c_float = ctypes.c_float
 
 SIGNATURES = {
     "nsa_version": (c_int, []),
@@ -36,6 +37,15 @@ SIGNATURES = {
     "nsa_max_key_encode": (c_ll, [c_double]),
     "nsa_max_key_decode": (c_double, [c_ll]),
     "nsa_populate_accept_workspace": (c_size_t, [c_ll]),
+    "nsa_train_workspace_floats": (c_size_t, [c_void_p, c_ll]),
+    "nsa_train_step": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p,
+         c_float, c_float, c_float, c_float, c_float, c_float, c_ll, c_void_p, c_void_p],
+    ),
+    "nsa_train_eval": (
+        c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "nsa_populate_accept": (
         c_int,
         [c_ll, c_int, c_void_p, c_void_p, c_ull, c_ull, c_void_p, c_void_p, c_ll, c_void_p, c_void_p,

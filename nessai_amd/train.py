@@ -1,9 +1,212 @@
-"""Training loop of ``FlowModel.train`` (placeholder until the backward kernels land)."""
+"""Training loop of ``FlowModel.train`` on the gfx950 training kernels.
+
+Follows the reference's schedule (``src/nessai/flowmodel/base.py:530-696`` and
+``_train`` / ``_validate``, ``base.py:365-523``): per epoch the training set is
+re-shuffled with ``torch.randperm`` and split into minibatches; every minibatch
+is one ``nsa_train_step`` call (forward, ``-mean(log_prob)``, backward,
+``clip_grad_norm_``, AdamW — all enqueued on the stream by the C side, no host
+round trip); the validation loss is one ``nsa_train_eval`` call; the best
+weights (lowest validation loss) are kept on the device and restored at the
+end; training stops ``patience`` epochs after the best one.  The host reads two
+scalars per epoch.
+
+Trainable scope of this round: flows made of permutations and coupling layers
+with a residual conditioner (the reference's NeuralSplineFlow defaults, RealNVP
+with ``linear_transform="permutation", batch_norm_between_layers=False``).
+LU-linear and batch-norm *training* have no kernels yet and raise.
+"""
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import lib, pack
+from .flows import modules as M
+
+
+class Trainer:
+    """Flat parameter / gradient / Adam-moment buffers + the layer plan."""
+
+    def __init__(self, flow, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.flow = flow
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
+        self.step_count = 0
+        device = next(flow.parameters()).device
+        if device.type != "cuda":
+            raise RuntimeError("nessai_amd training needs the flow on a ROCm device (no CPU fallback)")
+        self.device = device
+        desc = M.describe(flow)
+        if desc["net"] != "resnet":
+            raise NotImplementedError("training kernels support the residual conditioner only")
+        leaves = M.flatten_transforms(flow._transform)
+        D = desc["D"]
+        cur = list(range(D))
+        tables, records = [], []
+        params = list(flow.parameters())
+        if not all(p.dtype == torch.float32 for p in params):
+            raise TypeError("float32 parameters expected")
+        # one flat buffer; every Parameter becomes a view of it
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        offsets, pos = {}, 0
+        with torch.no_grad():
+            for p in params:
+                flat[pos : pos + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = flat[pos : pos + p.numel()].view(p.shape)
+                offsets[id(p)] = pos
+                pos += p.numel()
+        self.params = flat
+        self.grads = torch.zeros_like(flat)
+        self.adam_m = torch.zeros_like(flat)
+        self.adam_v = torch.zeros_like(flat)
+        self.best = torch.empty_like(flat)
+        n_res = None
+        for t in leaves:
+            if hasattr(t, "_permutation"):
+                perm = t._permutation.detach().cpu().numpy()
+                cur = [cur[int(perm[i])] for i in range(D)]
+            elif hasattr(t, "transform_net"):
+                net = t.transform_net
+                layers = [net.initial_layer]
+                for block in net.blocks:
+                    layers.extend(block.linear_layers)
+                layers.append(net.final_layer)
+                n_res = len(net.blocks) if n_res is None else n_res
+                if len(net.blocks) != n_res:
+                    raise ValueError("all coupling layers must share one conditioner depth")
+                id_cols = [cur[int(f)] for f in t.identity_features.tolist()]
+                tr_cols = [cur[int(f)] for f in t.transform_features.tolist()]
+                rec = [len(id_cols), len(tr_cols), len(tables), len(tables) + len(id_cols)]
+                tables.extend(id_cols)
+                tables.extend(tr_cols)
+                for layer in layers:
+                    rec.append(offsets[id(layer.weight)])
+                    rec.append(offsets[id(layer.bias)])
+                records.append(rec)
+            else:
+                raise NotImplementedError(
+                    f"{type(t).__name__} has no training kernel yet (LU-linear / batch-norm "
+                    "training is planned); use linear_transform='permutation' and "
+                    "batch_norm_between_layers=False"
+                )
+        n_tr = pack.transform_policy(desc["transform"], desc.get("bins", 0))[2]
+        rec_words = len(records[0])
+        header = [D, desc["hidden"], n_res, len(records), pack.TRANSFORMS[desc["transform"]],
+                  desc.get("bins", 0) if desc["transform"] == "rq" else 0,
+                  pack.ACTIVATIONS[desc["activation"]], n_tr, total, rec_words]
+        plan = header + [w for rec in records for w in rec]
+        self.plan = (ctypes.c_longlong * len(plan))(*plan)
+        self.tables = torch.tensor(tables, dtype=torch.int32, device=device)
+        min_d = np.float32(desc.get("min_derivative", 1e-3))
+        edge_raw = np.float32(math.log(math.exp(1 - float(min_d)) - 1))
+        edge_d = np.float32(min_d + np.float32(max(edge_raw, 0)) + np.float32(np.log1p(np.exp(-abs(edge_raw)))))
+        var = float(desc.get("base_var", 1.0))
+        inv_div = 1.0 / math.sqrt(desc["hidden"]) if desc.get("scale_logits", True) else 1.0
+        consts = [desc.get("tail_bound", 5.0), desc.get("min_bin_width", 1e-3),
+                  desc.get("min_bin_height", 1e-3), float(min_d), float(edge_d), inv_div,
+                  1.0 / var, 0.5 * D * math.log(2 * math.pi * var)]
+        self.consts = (ctypes.c_float * len(consts))(*consts)
+        self.features = D
+        self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)
+        self._ws = None
+        self._ws_rows = 0
+
+    def _workspace(self, n):
+        if self._ws is None or n > self._ws_rows:
+            words = int(lib.load().nsa_train_workspace_floats(self.plan, n))
+            self._ws = torch.empty(words, dtype=torch.float32, device=self.device)
+            self._ws_rows = n
+        return self._ws
+
+    def step(self, x, clip_norm=5.0, lr=None):
+        """One optimiser step on a ``(n, D)`` float32 device batch; the loss is added to ``loss_acc``."""
+        self.step_count += 1
+        ws = self._workspace(x.shape[0])
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = lib.load().nsa_train_step(
+            self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(self.grads),
+            lib.ptr(self.adam_m), lib.ptr(self.adam_v), lib.ptr(x), x.shape[0], lib.ptr(ws),
+            self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+            float(clip_norm or 0.0), self.step_count, lib.ptr(self.loss_acc), lib.c_void_p(stream),
+        )
+        lib.check(rc, "nsa_train_step")
+
+    def evaluate(self, x, log_prob_out=None):
+        """``loss_acc += -mean(log_prob(x))`` without touching the weights."""
+        ws = self._workspace(x.shape[0])
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = lib.load().nsa_train_eval(
+            self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(x), x.shape[0],
+            lib.ptr(ws), lib.ptr(self.loss_acc), lib.ptr(log_prob_out), lib.c_void_p(stream),
+        )
+        lib.check(rc, "nsa_train_eval")
+
+
+def get_trainer(flow_model):
+    tc = flow_model.training_config
+    if flow_model._trainer is None or flow_model._trainer.flow is not flow_model.model:
+        name = (tc.get("optimiser") or "adamw").lower()
+        kwargs = dict(tc.get("optimiser_kwargs") or {})
+        if name == "adamw":
+            weight_decay = kwargs.pop("weight_decay", 0.01)
+        elif name == "adam":
+            raise NotImplementedError("Adam (L2 weight decay) has no gfx950 kernel; use 'adamw'")
+        else:
+            raise NotImplementedError(f"optimiser {name!r} has no gfx950 kernel")
+        flow_model._trainer = Trainer(
+            flow_model.model, lr=tc["lr"], betas=kwargs.pop("betas", (0.9, 0.999)),
+            eps=kwargs.pop("eps", 1e-8), weight_decay=weight_decay,
+        )
+    return flow_model._trainer
 
 
 def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=None):
-    raise NotImplementedError(
-        "nessai_amd training kernels are not built yet (FlowModel.train, "
-        "src/nessai/flowmodel/base.py:530-696); load trained weights with "
-        "FlowModel.load_weights / model.load_state_dict"
+    tc = flow_model.training_config
+    if tc.get("annealing"):
+        raise NotImplementedError("cosine annealing has no gfx950 kernel yet")
+    if tc.get("noise_type"):
+        raise NotImplementedError("training noise has no gfx950 kernel yet")
+    trainer = get_trainer(flow_model)
+    model = flow_model.model
+    validate = val_size != 0.0
+    train_data, val_data, batch_size = flow_model.prep_data(
+        samples, val_size=val_size, batch_size=tc["batch_size"]
     )
+    if max_epochs is None:
+        max_epochs = tc["max_epochs"]
+    if patience is None:
+        patience = tc["patience"]
+    clip = tc["clip_grad_norm"]
+    best_epoch, best_val_loss = 0, np.inf
+    trainer.best.copy_(trainer.params)
+    history = dict(loss=[], val_loss=[])
+    model.train()
+    for epoch in range(1, max_epochs + 1):
+        p = torch.randperm(train_data.shape[0]).to(train_data.device)
+        batches = train_data[p, :].split(batch_size)
+        trainer.loss_acc.zero_()
+        for x in batches:
+            trainer.step(x.contiguous(), clip_norm=clip)
+        if validate and len(val_data):
+            val_acc = torch.zeros_like(trainer.loss_acc)
+            keep, trainer.loss_acc = trainer.loss_acc, val_acc
+            trainer.evaluate(val_data)
+            trainer.loss_acc = keep
+            both = torch.cat([trainer.loss_acc, val_acc]).cpu().numpy()  # the epoch's one sync
+            loss, val_loss = float(both[0]) / len(batches), float(both[1])
+        else:
+            loss, val_loss = float(trainer.loss_acc.item()) / len(batches), np.nan
+        history["loss"].append(loss)
+        history["val_loss"].append(val_loss)
+        if validate and (val_loss < best_val_loss):
+            best_epoch, best_val_loss = epoch, val_loss
+            trainer.best.copy_(trainer.params)
+        if validate and (epoch - best_epoch > patience):
+            break
+    if validate:
+        trainer.params.copy_(trainer.best)
+    model._image_key = None  # weights changed behind torch's version counters
+    model.eval()
+    return history

