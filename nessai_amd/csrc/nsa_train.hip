@@ -15,6 +15,7 @@
 // the layer in place (only the transformed columns are saved).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/nessai_amd.h"
 #include "nsa_device.h"
@@ -71,7 +72,8 @@ __global__ void __launch_bounds__(64) tr_gemm_nt(int n, int I, int O, const floa
 }
 
 // Gin[n][I] (op)= (Gout[n][O] . W[O][I]) * act'(Z[n][I])
-//   mode 0: Gin = value; mode 1: Gin += value; mode 2: Gx[:, cols[i]] += value (scatter-add)
+//   mode 0: Gin = value; mode 1: Gin += value; mode 2: Gx[:, cols[i]] += value (scatter-add);
+//   mode 3: Gx[:, cols[i]] = value (scatter-assign)
 __global__ void __launch_bounds__(64) tr_gemm_nn(int n, int O, int I, const float* __restrict__ Gout, int ldg,
                                                  const float* __restrict__ W, const float* __restrict__ Z,
                                                  int ldz, int act, float* __restrict__ Gin, int ldi,
@@ -97,7 +99,8 @@ __global__ void __launch_bounds__(64) tr_gemm_nn(int n, int O, int I, const floa
       if (Z) v *= tr_act_grad(Z[(long long)row * ldz + i], act);
       if (mode == 0) Gin[(long long)row * ldi + i] = v;
       else if (mode == 1) Gin[(long long)row * ldi + i] += v;
-      else Gin[(long long)row * ldi + cols[i]] += v;
+      else if (mode == 2) Gin[(long long)row * ldi + cols[i]] += v;
+      else Gin[(long long)row * ldi + cols[i]] = v;
     }
   }
 }
@@ -368,13 +371,187 @@ __global__ void tr_affine_backward(int n, int d_tr, int additive, const int* __r
 }
 
 // ---------------------------------------------------------------------------
+// batch norm between coupling layers (nflows BatchNorm transform, training mode:
+// batch mean / unbiased variance, running statistics updated with `momentum`)
+// ---------------------------------------------------------------------------
+
+// one workgroup per feature: mean and unbiased variance over the batch
+__global__ void __launch_bounds__(256) tr_bn_stats(int n, const float* __restrict__ X, int ldx,
+                                                   const int* __restrict__ cols, float* __restrict__ mean,
+                                                   float* __restrict__ var) {
+  __shared__ float sm[256];
+  const int i = blockIdx.x, col = cols[i];
+  float s = 0.0f;
+  for (int r = threadIdx.x; r < n; r += 256) s += X[(long long)r * ldx + col];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off]; __syncthreads(); }
+  const float mu = sm[0] / (float)n;
+  __syncthreads();
+  float q = 0.0f;
+  for (int r = threadIdx.x; r < n; r += 256) { const float d = X[(long long)r * ldx + col] - mu; q += d * d; }
+  sm[threadIdx.x] = q;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) { mean[i] = mu; var[i] = sm[0] / (float)(n - 1); }
+}
+
+// y = w * (x - mean) / sqrt(var + eps) + b;  w = softplus(uw) + eps
+// (thread 0 also updates the running statistics and adds the layer's constant log|det J|)
+__global__ void tr_bn_forward(int n, int D, float* __restrict__ X, int ldx, const int* __restrict__ cols,
+                              const float* __restrict__ uw, const float* __restrict__ bias,
+                              const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                              float* __restrict__ xsave, float* __restrict__ run_mean,
+                              float* __restrict__ run_var, float momentum, int update_running,
+                              float* __restrict__ ld_const) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    float ld = 0.0f;
+    for (int i = 0; i < D; ++i) {
+      const float w = nsa_softplus(uw[i]) + eps;
+      ld += logf(w) - 0.5f * logf(var[i] + eps);
+      if (update_running) {
+        run_mean[i] = run_mean[i] * (1.0f - momentum) + mean[i] * momentum;
+        run_var[i] = run_var[i] * (1.0f - momentum) + var[i] * momentum;
+      }
+    }
+    ld_const[0] += ld;
+  }
+  if (t >= n * D) return;
+  const int row = t / D, i = t - row * D;
+  const int col = cols[i];
+  const float x = X[(long long)row * ldx + col];
+  xsave[t] = x;
+  const float w = nsa_softplus(uw[i]) + eps;
+  X[(long long)row * ldx + col] = w * ((x - mean[i]) / sqrtf(var[i] + eps)) + bias[i];
+}
+
+// per feature: T1 = sum gy, T2 = sum gy * xhat
+__global__ void __launch_bounds__(256) tr_bn_backward_reduce(int n, const float* __restrict__ Gx, int ldx,
+                                                             const int* __restrict__ cols, const float* __restrict__ xsave,
+                                                             int D, const float* __restrict__ mean,
+                                                             const float* __restrict__ var, float eps,
+                                                             float* __restrict__ T1, float* __restrict__ T2) {
+  __shared__ float s1[256], s2[256];
+  const int i = blockIdx.x, col = cols[i];
+  const float mu = mean[i], istd = 1.0f / sqrtf(var[i] + eps);
+  float a = 0.0f, b = 0.0f;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const float gy = Gx[(long long)r * ldx + col];
+    a += gy;
+    b += gy * ((xsave[(long long)r * D + i] - mu) * istd);
+  }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { s1[threadIdx.x] += s1[threadIdx.x + off]; s2[threadIdx.x] += s2[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { T1[i] = s1[0]; T2[i] = s2[0]; }
+}
+
+// gl = d loss / d (constant log|det J|) = -1
+__global__ void tr_bn_backward_apply(int n, int D, float* __restrict__ X, float* __restrict__ Gx, int ldx,
+                                     const int* __restrict__ cols, const float* __restrict__ xsave,
+                                     const float* __restrict__ uw, const float* __restrict__ mean,
+                                     const float* __restrict__ var, float eps, const float* __restrict__ T1,
+                                     const float* __restrict__ T2, float* __restrict__ g_uw,
+                                     float* __restrict__ g_bias) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * D) return;
+  const int row = t / D, i = t - row * D;
+  const int col = cols[i];
+  const float w = nsa_softplus(uw[i]) + eps;
+  const float ve = var[i] + eps, istd = 1.0f / sqrtf(ve);
+  const float x = xsave[t], xc = x - mean[i];
+  const float S1 = w * T1[i], S2 = w * T2[i];
+  const float g_var = (-0.5f * S2 + 0.5f) / ve;
+  const float g_mean = -S1 * istd;
+  const float g = Gx[(long long)row * ldx + col] * w;
+  Gx[(long long)row * ldx + col] = g * istd + g_var * 2.0f * xc / (float)(n - 1) + g_mean / (float)n;
+  X[(long long)row * ldx + col] = x;
+  if (row == 0) {
+    const float sig = 1.0f / (1.0f + expf(-uw[i]));
+    g_uw[i] = (T2[i] - 1.0f / w) * sig;
+    g_bias[i] = T1[i];
+  }
+}
+
+// eval-mode batch norm (running statistics), used by the validation pass
+__global__ void tr_bn_eval(int n, int D, float* __restrict__ X, int ldx, const int* __restrict__ cols,
+                           const float* __restrict__ uw, const float* __restrict__ bias,
+                           const float* __restrict__ run_mean, const float* __restrict__ run_var, float eps,
+                           float* __restrict__ ld_const) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    float ld = 0.0f;
+    for (int i = 0; i < D; ++i) ld += logf(nsa_softplus(uw[i]) + eps) - 0.5f * logf(run_var[i] + eps);
+    ld_const[0] += ld;
+  }
+  if (t >= n * D) return;
+  const int row = t / D, i = t - row * D;
+  const int col = cols[i];
+  const float w = nsa_softplus(uw[i]) + eps;
+  const float x = X[(long long)row * ldx + col];
+  X[(long long)row * ldx + col] = w * ((x - run_mean[i]) / sqrtf(run_var[i] + eps)) + bias[i];
+}
+
+// ---------------------------------------------------------------------------
+// LU-linear layer: W = L U, unit-diagonal L, diag(U) = softplus(raw) + eps
+// ---------------------------------------------------------------------------
+
+__global__ void tr_lu_build(int D, const float* __restrict__ lower, const float* __restrict__ upper,
+                            const float* __restrict__ raw, float eps, float* __restrict__ Lm,
+                            float* __restrict__ Um, float* __restrict__ ld_const) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    float ld = 0.0f;
+    for (int i = 0; i < D; ++i) ld += logf(nsa_softplus(raw[i]) + eps);
+    ld_const[0] += ld;
+  }
+  if (t >= D * D) return;
+  const int i = t / D, j = t - i * D;
+  float l = 0.0f, u = 0.0f;
+  if (j < i) l = lower[i * (i - 1) / 2 + j];
+  else if (j == i) { l = 1.0f; u = nsa_softplus(raw[i]) + eps; }
+  else u = upper[i * D - i * (i + 1) / 2 + (j - i - 1)];
+  Lm[t] = l;
+  Um[t] = u;
+}
+
+// dst[row][k] = src[row][cols[k]]  (gather)  /  dst[row][cols[k]] = src[row][k]  (scatter)
+__global__ void tr_gather_cols(int n, int D, const float* __restrict__ src, int lds_, const int* __restrict__ cols,
+                               float* __restrict__ dst, int scatter) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * D) return;
+  const int row = t / D, k = t - row * D;
+  if (scatter) dst[(long long)row * lds_ + cols[k]] = src[t];
+  else dst[t] = src[(long long)row * lds_ + cols[k]];
+}
+
+__global__ void tr_lu_grads(int D, const float* __restrict__ gL, const float* __restrict__ gU,
+                            const float* __restrict__ raw, float eps, float* __restrict__ g_lower,
+                            float* __restrict__ g_upper, float* __restrict__ g_raw) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= D * D) return;
+  const int i = t / D, j = t - i * D;
+  if (j < i) g_lower[i * (i - 1) / 2 + j] = gL[t];
+  else if (j > i) g_upper[i * D - i * (i + 1) / 2 + (j - i - 1)] = gU[t];
+  else {
+    const float d = nsa_softplus(raw[i]) + eps;
+    g_raw[i] = (gU[t] - 1.0f / d) / (1.0f + expf(-raw[i]));
+  }
+}
+
+// ---------------------------------------------------------------------------
 // loss, gradient seed, gradient norm, AdamW
 // ---------------------------------------------------------------------------
 
 // per row: log_prob = -0.5/var * sum z^2 - log_z + logdet;  Gx = z / (var * n)
 // loss_acc[0] += -sum(log_prob) / n   (one workgroup, fixed summation order)
 __global__ void __launch_bounds__(256) tr_loss(int n, int D, const float* __restrict__ X, int ldx,
-                                               const float* __restrict__ logdet, float inv_var, float log_z,
+                                               const float* __restrict__ logdet,
+                                               const float* __restrict__ ld_const, float inv_var, float log_z,
                                                float* __restrict__ Gx, float* __restrict__ loss_acc,
                                                float* __restrict__ log_prob_out, int want_grad) {
   __shared__ float sm[256];
@@ -386,7 +563,7 @@ __global__ void __launch_bounds__(256) tr_loss(int n, int D, const float* __rest
       e += z * z;
       if (want_grad) Gx[(long long)row * ldx + c] = z * inv_var / (float)n;
     }
-    const float lp = -0.5f * inv_var * e - log_z + logdet[row];
+    const float lp = -0.5f * inv_var * e - log_z + (logdet[row] + ld_const[0]);
     if (log_prob_out) log_prob_out[row] = lp;
     local += lp;
   }
@@ -445,46 +622,58 @@ __global__ void tr_copy_rows(long long n, const float* __restrict__ src, float* 
 // host orchestration
 // ---------------------------------------------------------------------------
 
-// plan (int64, host): header then one record per coupling layer
-//   [0] D  [1] H  [2] L (residual blocks)  [3] n_layers (coupling)  [4] transform  [5] bins
+// plan (int64, host): header then one fixed-size record per layer, forward order
+//   [0] D  [1] H  [2] L (residual blocks)  [3] n_layers  [4] transform  [5] bins
 //   [6] activation  [7] params per transformed feature  [8] n trainable floats  [9] record words
-//   record: d_id, d_tr, id_cols offset, tr_cols offset (into the int32 device table),
-//           offsets (into the flat parameter buffer) of W0, b0, {W1, b1, W2, b2} x L, Wf, bf
+//   coupling  : {1, d_id, d_tr, id_cols offset, tr_cols offset (int32 device table),
+//                flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf}
+//   batch norm: {2, cols offset, off unconstrained_weight, off bias, off running_mean,
+//                off running_var, eps (float bits), momentum (float bits)}
+//   LU linear : {3, cols offset, off lower_entries, off upper_entries, off unconstrained_upper_diag,
+//                off bias, eps (float bits)}
 #define TR_HDR 10
-static thread_local char g_terr[256];
+enum { TR_COUPLING = 1, TR_BATCHNORM = 2, TR_LU = 3 };
+
+static inline float tr_bits(long long v) {
+  const uint32_t u = (uint32_t)v;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
 
 struct TrWs {  // workspace carve (floats)
-  float *x, *gx, *logdet, *gp, *gh, *gu, *scal;
+  float *scal;      // [0] grad sq-norm, [1] constant log|det J| of the pass
+  float *x, *gx, *logdet, *gp, *gh, *gu;
   float* layer_base;
   long long per_layer;
-  long long xsave_words;  // n * max(d_tr): size of a layer's saved-input block
+  long long xsave_words;  // n * max(d_tr): size of a coupling layer's saved-input block
 };
 
-static long long tr_per_layer(long long n, long long d_tr_max, long long H, long long L, long long np_max) {
-  return n * d_tr_max + (L + 1) * n * H + L * n * H + n * np_max;
+static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, long long& np_max,
+                     long long& per_layer) {
+  const long long D = plan[0], H = plan[1], L = plan[2], NL = plan[3], rec = plan[9];
+  d_tr_max = 1;
+  for (long long b = 0; b < NL; ++b) {
+    const long long* r = plan + TR_HDR + b * rec;
+    if (r[0] == TR_COUPLING && r[2] > d_tr_max) d_tr_max = r[2];
+  }
+  np_max = d_tr_max * plan[7];
+  const long long coupling = n * d_tr_max + (2 * L + 1) * n * H + n * np_max;
+  const long long linear = 3 * n * D + 4 * D * D + 8 * D;  // x, t, gt | L, U, gL, gU | small vectors
+  per_layer = coupling > linear ? coupling : linear;
 }
 
 extern "C" NSA_API size_t nsa_train_workspace_floats(const long long* plan, long long n) {
-  const long long D = plan[0], H = plan[1], L = plan[2], NL = plan[3], rec = plan[9];
-  long long d_tr_max = 0;
-  for (long long b = 0; b < NL; ++b) {
-    const long long d_tr = plan[TR_HDR + b * rec + 1];
-    if (d_tr > d_tr_max) d_tr_max = d_tr;
-  }
-  const long long np_max = d_tr_max * plan[7];
-  long long total = 2 * n * D + n + n * np_max + 2 * n * H + 64;
-  total += NL * tr_per_layer(n, d_tr_max, H, L, np_max);
-  return (size_t)total;
+  long long d_tr_max, np_max, per_layer;
+  tr_sizes(plan, n, d_tr_max, np_max, per_layer);
+  const long long D = plan[0], H = plan[1], NL = plan[3];
+  return (size_t)(64 + 2 * n * D + n + n * np_max + 2 * n * H + NL * per_layer);
 }
 
 static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
-  const long long D = plan[0], H = plan[1], L = plan[2], NL = plan[3], rec = plan[9];
-  long long d_tr_max = 0;
-  for (long long b = 0; b < NL; ++b) {
-    const long long d_tr = plan[TR_HDR + b * rec + 1];
-    if (d_tr > d_tr_max) d_tr_max = d_tr;
-  }
-  const long long np_max = d_tr_max * plan[7];
+  long long d_tr_max, np_max, per_layer;
+  tr_sizes(plan, n, d_tr_max, np_max, per_layer);
+  const long long D = plan[0], H = plan[1];
   float* p = ws;
   w.scal = p; p += 64;
   w.x = p; p += n * D;
@@ -494,13 +683,14 @@ static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
   w.gh = p; p += n * H;
   w.gu = p; p += n * H;
   w.layer_base = p;
-  w.per_layer = tr_per_layer(n, d_tr_max, H, L, np_max);
+  w.per_layer = per_layer;
   w.xsave_words = n * d_tr_max;
 }
 
 static inline dim3 tiles(long long rows, long long cols) {
   return dim3((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32));
 }
+static inline dim3 blocks_for(long long work) { return dim3((unsigned)((work + 255) / 256)); }
 
 #define TR_SPLINE_DISPATCH(KERNEL, K, ...)                                                          \
   do {                                                                                              \
@@ -510,49 +700,91 @@ static inline dim3 tiles(long long rows, long long cols) {
     else hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__);                                               \
   } while (0)
 
-// forward of the whole flow over a batch already copied into w.x; fills the
-// per-layer activations when `train` (they are needed by the backward pass)
-static void tr_forward(const long long* plan, const int* tabs, const float* params, const float* consts,
-                       long long n, TrWs& w, hipStream_t s) {
+// linear-layer block of the workspace
+struct TrLin {
+  float *xin, *t, *gt, *Lm, *Um, *gL, *gU, *vec;  // vec: 8*D floats (mean, var, T1, T2, zero bias, ...)
+};
+static inline TrLin tr_lin(float* lay, long long n, long long D) {
+  TrLin q;
+  q.xin = lay; q.t = q.xin + n * D; q.gt = q.t + n * D;
+  q.Lm = q.gt + n * D; q.Um = q.Lm + D * D; q.gL = q.Um + D * D; q.gU = q.gL + D * D;
+  q.vec = q.gU + D * D;
+  return q;
+}
+
+// forward of the whole flow over the batch in w.x; keeps what the backward pass needs.
+// training != 0: batch-norm uses batch statistics and updates the running ones.
+static void tr_forward(const long long* plan, const int* tabs, float* params, const float* consts,
+                       long long n, TrWs& w, int training, hipStream_t s) {
   const int D = (int)plan[0], H = (int)plan[1], L = (int)plan[2], NL = (int)plan[3];
   const int transform = (int)plan[4], K = (int)plan[5], act = (int)plan[6], npf = (int)plan[7];
   const long long rec = plan[9];
   TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5]};
-  hipMemsetAsync(w.logdet, 0, n * sizeof(float), s);
+  (void)hipMemsetAsync(w.logdet, 0, n * sizeof(float), s);
+  (void)hipMemsetAsync(w.scal, 0, 64 * sizeof(float), s);
   for (int b = 0; b < NL; ++b) {
     const long long* r = plan + TR_HDR + b * rec;
-    const int d_id = (int)r[0], d_tr = (int)r[1];
-    const int* id_cols = tabs + r[2];
-    const int* tr_cols = tabs + r[3];
-    const long long* off = r + 4;
     float* lay = w.layer_base + b * w.per_layer;
-    // layer block: xsave[n*d_tr_max] | h[L+1][n*H] | u[L][n*H] | p[n*np_max]
-    float* xsave = lay;
-    float* h = xsave + w.xsave_words;
-    float* u = h + (long long)(L + 1) * n * H;
-    float* p = u + (long long)L * n * H;
-    const int np = d_tr * npf;
-    // initial layer
-    hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, d_id, H, w.x, D, id_cols, ACT_NONE,
-                       params + off[0], params + off[1], (const float*)nullptr, h, H);
-    for (int l = 0; l < L; ++l) {
-      float* hl = h + (long long)l * n * H;
-      float* ul = u + (long long)l * n * H;
-      hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, hl, H, (const int*)nullptr, act,
-                         params + off[2 + 4 * l], params + off[3 + 4 * l], (const float*)nullptr, ul, H);
-      hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, ul, H, (const int*)nullptr, act,
-                         params + off[4 + 4 * l], params + off[5 + 4 * l], hl, hl + (long long)n * H, H);
-    }
-    float* hL = h + (long long)L * n * H;
-    hipLaunchKernelGGL(tr_gemm_nt, tiles(n, np), dim3(64), 0, s, (int)n, H, np, hL, H, (const int*)nullptr,
-                       ACT_NONE, params + off[2 + 4 * L], params + off[3 + 4 * L], (const float*)nullptr, p, np);
-    const int threads = 256, blocks = (int)((n * d_tr + threads - 1) / threads);
-    if (transform == NSA_T_RQ) {
-      TR_SPLINE_DISPATCH(tr_rq_forward, K, dim3(blocks), dim3(threads), 0, s, (int)n, d_tr, tr_cols, p, w.x, D,
-                         xsave, w.logdet, c);
-    } else {
-      hipLaunchKernelGGL(tr_affine_forward, dim3(blocks), dim3(threads), 0, s, (int)n, d_tr,
-                         transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, w.x, D, xsave, w.logdet);
+    if (r[0] == TR_COUPLING) {
+      const int d_id = (int)r[1], d_tr = (int)r[2];
+      const int* id_cols = tabs + r[3];
+      const int* tr_cols = tabs + r[4];
+      const long long* off = r + 5;
+      // layer block: xsave[n*d_tr_max] | h[L+1][n*H] | u[L][n*H] | p[n*np_max]
+      float* xsave = lay;
+      float* h = xsave + w.xsave_words;
+      float* u = h + (long long)(L + 1) * n * H;
+      float* p = u + (long long)L * n * H;
+      const int np = d_tr * npf;
+      hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, d_id, H, w.x, D, id_cols, ACT_NONE,
+                         params + off[0], params + off[1], (const float*)nullptr, h, H);
+      for (int l = 0; l < L; ++l) {
+        float* hl = h + (long long)l * n * H;
+        float* ul = u + (long long)l * n * H;
+        hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, hl, H, (const int*)nullptr,
+                           act, params + off[2 + 4 * l], params + off[3 + 4 * l], (const float*)nullptr, ul, H);
+        hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, ul, H, (const int*)nullptr,
+                           act, params + off[4 + 4 * l], params + off[5 + 4 * l], hl, hl + (long long)n * H, H);
+      }
+      float* hL = h + (long long)L * n * H;
+      hipLaunchKernelGGL(tr_gemm_nt, tiles(n, np), dim3(64), 0, s, (int)n, H, np, hL, H, (const int*)nullptr,
+                         ACT_NONE, params + off[2 + 4 * L], params + off[3 + 4 * L], (const float*)nullptr, p,
+                         np);
+      if (transform == NSA_T_RQ) {
+        TR_SPLINE_DISPATCH(tr_rq_forward, K, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr, tr_cols, p,
+                           w.x, D, xsave, w.logdet, c);
+      } else {
+        hipLaunchKernelGGL(tr_affine_forward, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr,
+                           transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, w.x, D, xsave, w.logdet);
+      }
+    } else if (r[0] == TR_BATCHNORM) {
+      const int* cols = tabs + r[1];
+      const float eps = tr_bits(r[6]), momentum = tr_bits(r[7]);
+      TrLin q = tr_lin(lay, n, D);
+      float* mean = q.vec;
+      float* var = q.vec + D;
+      if (training) {
+        hipLaunchKernelGGL(tr_bn_stats, dim3(D), dim3(256), 0, s, (int)n, w.x, D, cols, mean, var);
+        hipLaunchKernelGGL(tr_bn_forward, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, D, cols,
+                           params + r[2], params + r[3], mean, var, eps, q.xin, params + r[4], params + r[5],
+                           momentum, 1, w.scal + 1);
+      } else {
+        hipLaunchKernelGGL(tr_bn_eval, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, D, cols,
+                           params + r[2], params + r[3], params + r[4], params + r[5], eps, w.scal + 1);
+      }
+    } else {  // TR_LU: y = (x U^T) L^T + b, outputs in logical order
+      const int* cols = tabs + r[1];
+      const float eps = tr_bits(r[6]);
+      TrLin q = tr_lin(lay, n, D);
+      float* zero = q.vec;  // zero bias for the first product
+      (void)hipMemsetAsync(zero, 0, D * sizeof(float), s);
+      hipLaunchKernelGGL(tr_lu_build, blocks_for(D * D), dim3(256), 0, s, D, params + r[2], params + r[3],
+                         params + r[4], eps, q.Lm, q.Um, w.scal + 1);
+      hipLaunchKernelGGL(tr_gather_cols, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, D, cols, q.xin, 0);
+      hipLaunchKernelGGL(tr_gemm_nt, tiles(n, D), dim3(64), 0, s, (int)n, D, D, q.xin, D, (const int*)nullptr,
+                         ACT_NONE, q.Um, zero, (const float*)nullptr, q.t, D);
+      hipLaunchKernelGGL(tr_gemm_nt, tiles(n, D), dim3(64), 0, s, (int)n, D, D, q.t, D, (const int*)nullptr,
+                         ACT_NONE, q.Lm, params + r[5], (const float*)nullptr, w.x, D);
     }
   }
 }
@@ -563,52 +795,79 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
   const int transform = (int)plan[4], K = (int)plan[5], act = (int)plan[6], npf = (int)plan[7];
   const long long rec = plan[9];
   TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5]};
-  const float gld = -1.0f / (float)n;  // d loss / d logdet
+  const float gld = -1.0f / (float)n;  // d loss / d (per-row log|det J|)
   for (int b = NL - 1; b >= 0; --b) {
     const long long* r = plan + TR_HDR + b * rec;
-    const int d_id = (int)r[0], d_tr = (int)r[1];
-    const int* id_cols = tabs + r[2];
-    const int* tr_cols = tabs + r[3];
-    const long long* off = r + 4;
     float* lay = w.layer_base + b * w.per_layer;
-    float* xsave = lay;
-    float* h = xsave + w.xsave_words;
-    float* u = h + (long long)(L + 1) * n * H;
-    float* p = u + (long long)L * n * H;
-    const int np = d_tr * npf;
-    const int threads = 256, blocks = (int)((n * d_tr + threads - 1) / threads);
-    if (transform == NSA_T_RQ) {
-      TR_SPLINE_DISPATCH(tr_rq_backward, K, dim3(blocks), dim3(threads), 0, s, (int)n, d_tr, tr_cols, p, xsave,
-                         w.x, D, w.gx, gld, w.gp, c);
-    } else {
-      hipLaunchKernelGGL(tr_affine_backward, dim3(blocks), dim3(threads), 0, s, (int)n, d_tr,
-                         transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, xsave, w.x, D, w.gx, gld, w.gp);
+    if (r[0] == TR_COUPLING) {
+      const int d_id = (int)r[1], d_tr = (int)r[2];
+      const int* id_cols = tabs + r[3];
+      const int* tr_cols = tabs + r[4];
+      const long long* off = r + 5;
+      float* xsave = lay;
+      float* h = xsave + w.xsave_words;
+      float* u = h + (long long)(L + 1) * n * H;
+      float* p = u + (long long)L * n * H;
+      const int np = d_tr * npf;
+      if (transform == NSA_T_RQ) {
+        TR_SPLINE_DISPATCH(tr_rq_backward, K, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr, tr_cols, p,
+                           xsave, w.x, D, w.gx, gld, w.gp, c);
+      } else {
+        hipLaunchKernelGGL(tr_affine_backward, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr,
+                           transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, xsave, w.x, D, w.gx, gld, w.gp);
+      }
+      // final layer: dWf, dbf, gh = gp . Wf
+      float* hL = h + (long long)L * n * H;
+      hipLaunchKernelGGL(tr_gemm_tn, tiles(np, H), dim3(64), 0, s, (int)n, np, H, w.gp, np, hL, H,
+                         (const int*)nullptr, ACT_NONE, grads + off[2 + 4 * L], grads + off[3 + 4 * L]);
+      hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, np, H, w.gp, np,
+                         params + off[2 + 4 * L], (const float*)nullptr, 0, ACT_NONE, w.gh, H,
+                         (const int*)nullptr, 0);
+      for (int l = L - 1; l >= 0; --l) {
+        float* hl = h + (long long)l * n * H;
+        float* ul = u + (long long)l * n * H;
+        // second linear of the block: h_{l+1} = h_l + W2 act(u_l) + b2
+        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(64), 0, s, (int)n, H, H, w.gh, H, ul, H,
+                           (const int*)nullptr, act, grads + off[4 + 4 * l], grads + off[5 + 4 * l]);
+        hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gh, H,
+                           params + off[4 + 4 * l], ul, H, act, w.gu, H, (const int*)nullptr, 0);
+        // first linear: u_l = W1 act(h_l) + b1
+        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(64), 0, s, (int)n, H, H, w.gu, H, hl, H,
+                           (const int*)nullptr, act, grads + off[2 + 4 * l], grads + off[3 + 4 * l]);
+        hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gu, H,
+                           params + off[2 + 4 * l], hl, H, act, w.gh, H, (const int*)nullptr, 1);
+      }
+      // initial layer: dW0, db0, g_x[:, id_cols] += gh . W0 (x was restored by the transform's backward)
+      hipLaunchKernelGGL(tr_gemm_tn, tiles(H, d_id), dim3(64), 0, s, (int)n, H, d_id, w.gh, H, w.x, D, id_cols,
+                         ACT_NONE, grads + off[0], grads + off[1]);
+      hipLaunchKernelGGL(tr_gemm_nn, tiles(n, d_id), dim3(64), 0, s, (int)n, H, d_id, w.gh, H, params + off[0],
+                         (const float*)nullptr, 0, ACT_NONE, w.gx, D, id_cols, 2);
+    } else if (r[0] == TR_BATCHNORM) {
+      const int* cols = tabs + r[1];
+      const float eps = tr_bits(r[6]);
+      TrLin q = tr_lin(lay, n, D);
+      float *mean = q.vec, *var = q.vec + D, *T1 = q.vec + 2 * D, *T2 = q.vec + 3 * D;
+      hipLaunchKernelGGL(tr_bn_backward_reduce, dim3(D), dim3(256), 0, s, (int)n, w.gx, D, cols, q.xin, D, mean,
+                         var, eps, T1, T2);
+      hipLaunchKernelGGL(tr_bn_backward_apply, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, w.gx, D, cols,
+                         q.xin, params + r[2], mean, var, eps, T1, T2, grads + r[2], grads + r[3]);
+    } else {  // TR_LU
+      const int* cols = tabs + r[1];
+      const float eps = tr_bits(r[6]);
+      TrLin q = tr_lin(lay, n, D);
+      // gy = w.gx (logical order).  dL = gy^T t, db = colsum gy;  gt = gy L;  dU = gt^T x;  gx = gt U
+      hipLaunchKernelGGL(tr_gemm_tn, tiles(D, D), dim3(64), 0, s, (int)n, D, D, w.gx, D, q.t, D,
+                         (const int*)nullptr, ACT_NONE, q.gL, grads + r[5]);
+      hipLaunchKernelGGL(tr_gemm_nn, tiles(n, D), dim3(64), 0, s, (int)n, D, D, w.gx, D, q.Lm,
+                         (const float*)nullptr, 0, ACT_NONE, q.gt, D, (const int*)nullptr, 0);
+      hipLaunchKernelGGL(tr_gemm_tn, tiles(D, D), dim3(64), 0, s, (int)n, D, D, q.gt, D, q.xin, D,
+                         (const int*)nullptr, ACT_NONE, q.gU, q.vec + D);
+      hipLaunchKernelGGL(tr_gemm_nn, tiles(n, D), dim3(64), 0, s, (int)n, D, D, q.gt, D, q.Um,
+                         (const float*)nullptr, 0, ACT_NONE, w.gx, D, cols, 3);
+      hipLaunchKernelGGL(tr_lu_grads, blocks_for(D * D), dim3(256), 0, s, D, q.gL, q.gU, params + r[4], eps,
+                         grads + r[2], grads + r[3], grads + r[4]);
+      hipLaunchKernelGGL(tr_gather_cols, blocks_for(n * D), dim3(256), 0, s, (int)n, D, q.xin, D, cols, w.x, 1);
     }
-    // final layer: dWf, dbf, gh = gp . Wf
-    float* hL = h + (long long)L * n * H;
-    hipLaunchKernelGGL(tr_gemm_tn, tiles(np, H), dim3(64), 0, s, (int)n, np, H, w.gp, np, hL, H,
-                       (const int*)nullptr, ACT_NONE, grads + off[2 + 4 * L], grads + off[3 + 4 * L]);
-    hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, np, H, w.gp, np, params + off[2 + 4 * L],
-                       (const float*)nullptr, 0, ACT_NONE, w.gh, H, (const int*)nullptr, 0);
-    for (int l = L - 1; l >= 0; --l) {
-      float* hl = h + (long long)l * n * H;
-      float* ul = u + (long long)l * n * H;
-      // second linear of the block: h_{l+1} = h_l + W2 act(u_l) + b2
-      hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(64), 0, s, (int)n, H, H, w.gh, H, ul, H,
-                         (const int*)nullptr, act, grads + off[4 + 4 * l], grads + off[5 + 4 * l]);
-      hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gh, H, params + off[4 + 4 * l], ul,
-                         H, act, w.gu, H, (const int*)nullptr, 0);
-      // first linear: u_l = W1 act(h_l) + b1
-      hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(64), 0, s, (int)n, H, H, w.gu, H, hl, H,
-                         (const int*)nullptr, act, grads + off[2 + 4 * l], grads + off[3 + 4 * l]);
-      hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gu, H, params + off[2 + 4 * l], hl,
-                         H, act, w.gh, H, (const int*)nullptr, 1);
-    }
-    // initial layer: dW0, db0, g_x[:, id_cols] += gh . W0   (x already restored by the spline backward)
-    hipLaunchKernelGGL(tr_gemm_tn, tiles(H, d_id), dim3(64), 0, s, (int)n, H, d_id, w.gh, H, w.x, D, id_cols,
-                       ACT_NONE, grads + off[0], grads + off[1]);
-    hipLaunchKernelGGL(tr_gemm_nn, tiles(n, d_id), dim3(64), 0, s, (int)n, H, d_id, w.gh, H, params + off[0],
-                       (const float*)nullptr, 0, ACT_NONE, w.gx, D, id_cols, 2);
   }
 }
 
@@ -619,28 +878,27 @@ extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_d
                                       float* workspace_dev, float lr, float beta1, float beta2, float eps,
                                       float weight_decay, float clip_norm, long long step,
                                       float* loss_acc_dev, void* stream) {
-  if (!plan || !tables_dev || !params_dev || !grads_dev || !x_dev || !workspace_dev || !loss_acc_dev || n <= 0)
+  if (!plan || !tables_dev || !params_dev || !grads_dev || !x_dev || !workspace_dev || !loss_acc_dev || n <= 1)
     return NSA_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const long long D = plan[0], n_params = plan[8];
   TrWs w;
   tr_carve(plan, n, workspace_dev, w);
-  hipLaunchKernelGGL(tr_copy_rows, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, s, n * D, x_dev, w.x);
-  tr_forward(plan, tables_dev, params_dev, consts, n, w, s);
-  hipLaunchKernelGGL(tr_loss, dim3(1), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, consts[6], consts[7],
-                     w.gx, loss_acc_dev, (float*)nullptr, 1);
+  hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, x_dev, w.x);
+  tr_forward(plan, tables_dev, params_dev, consts, n, w, 1, s);
+  hipLaunchKernelGGL(tr_loss, dim3(1), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
+                     consts[6], consts[7], w.gx, loss_acc_dev, (float*)nullptr, 1);
   tr_backward(plan, tables_dev, params_dev, grads_dev, consts, n, w, s);
   hipLaunchKernelGGL(tr_grad_sqnorm, dim3(1), dim3(1024), 0, s, n_params, grads_dev, w.scal);
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(tr_adamw, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, s, n_params, params_dev,
-                     grads_dev, adam_m_dev, adam_v_dev, w.scal, clip_norm, lr, beta1, beta2, eps, weight_decay, bc1,
-                     bc2s);
+  hipLaunchKernelGGL(tr_adamw, blocks_for(n_params), dim3(256), 0, s, n_params, params_dev, grads_dev, adam_m_dev,
+                     adam_v_dev, w.scal, clip_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? NSA_OK : NSA_E_HIP;
 }
 
-// Forward only: loss_acc_dev[0] += -mean(log_prob(x)); optional per-row log_prob.
+// Forward only, eval mode: loss_acc_dev[0] += -mean(log_prob(x)); optional per-row log_prob.
 extern "C" NSA_API int nsa_train_eval(const long long* plan, const int* tables_dev, const float* consts,
                                       const float* params_dev, const float* x_dev, long long n,
                                       float* workspace_dev, float* loss_acc_dev, float* log_prob_out_dev,
@@ -651,10 +909,10 @@ extern "C" NSA_API int nsa_train_eval(const long long* plan, const int* tables_d
   const long long D = plan[0];
   TrWs w;
   tr_carve(plan, n, workspace_dev, w);
-  hipLaunchKernelGGL(tr_copy_rows, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, s, n * D, x_dev, w.x);
-  tr_forward(plan, tables_dev, params_dev, consts, n, w, s);
-  hipLaunchKernelGGL(tr_loss, dim3(1), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, consts[6], consts[7],
-                     w.gx, loss_acc_dev, log_prob_out_dev, 0);
+  hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, x_dev, w.x);
+  tr_forward(plan, tables_dev, const_cast<float*>(params_dev), consts, n, w, 0, s);
+  hipLaunchKernelGGL(tr_loss, dim3(1), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
+                     consts[6], consts[7], w.gx, loss_acc_dev, log_prob_out_dev, 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? NSA_OK : NSA_E_HIP;
 }

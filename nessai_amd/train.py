@@ -10,10 +10,12 @@ weights (lowest validation loss) are kept on the device and restored at the
 end; training stops ``patience`` epochs after the best one.  The host reads two
 scalars per epoch.
 
-Trainable scope of this round: flows made of permutations and coupling layers
-with a residual conditioner (the reference's NeuralSplineFlow defaults, RealNVP
-with ``linear_transform="permutation", batch_norm_between_layers=False``).
-LU-linear and batch-norm *training* have no kernels yet and raise.
+Trainable scope: permutations, LU-linear layers, coupling layers (affine,
+additive, rational-quadratic spline) with a residual conditioner, and batch
+norm between layers - i.e. the reference's RealNVP and NeuralSplineFlow
+defaults;
+act norm, the MLP conditioner and conditional inputs have no training kernels
+and raise.
 """
 
 import ctypes
@@ -47,22 +49,29 @@ class Trainer:
         params = list(flow.parameters())
         if not all(p.dtype == torch.float32 for p in params):
             raise TypeError("float32 parameters expected")
-        # one flat buffer; every Parameter becomes a view of it
+        # one flat buffer [trainable parameters | running statistics]; every Parameter and
+        # batch-norm buffer becomes a view of it
+        stats = [b for name, b in flow.named_buffers() if name.endswith(("running_mean", "running_var"))]
         total = sum(p.numel() for p in params)
-        flat = torch.empty(total, dtype=torch.float32, device=device)
+        flat = torch.empty(total + sum(b.numel() for b in stats), dtype=torch.float32, device=device)
         offsets, pos = {}, 0
         with torch.no_grad():
-            for p in params:
+            for p in params + stats:
                 flat[pos : pos + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = flat[pos : pos + p.numel()].view(p.shape)
                 offsets[id(p)] = pos
                 pos += p.numel()
-        self.params = flat
-        self.grads = torch.zeros_like(flat)
-        self.adam_m = torch.zeros_like(flat)
-        self.adam_v = torch.zeros_like(flat)
+        self.flat = flat
+        self.params = flat[:total]
+        self.grads = torch.zeros(total, dtype=torch.float32, device=device)
+        self.adam_m = torch.zeros_like(self.grads)
+        self.adam_v = torch.zeros_like(self.grads)
         self.best = torch.empty_like(flat)
         n_res = None
+
+        def f32_bits(value):
+            return int(np.array([value], dtype=np.float32).view(np.uint32)[0])
+
         for t in leaves:
             if hasattr(t, "_permutation"):
                 perm = t._permutation.detach().cpu().numpy()
@@ -78,19 +87,36 @@ class Trainer:
                     raise ValueError("all coupling layers must share one conditioner depth")
                 id_cols = [cur[int(f)] for f in t.identity_features.tolist()]
                 tr_cols = [cur[int(f)] for f in t.transform_features.tolist()]
-                rec = [len(id_cols), len(tr_cols), len(tables), len(tables) + len(id_cols)]
+                rec = [1, len(id_cols), len(tr_cols), len(tables), len(tables) + len(id_cols)]
                 tables.extend(id_cols)
                 tables.extend(tr_cols)
                 for layer in layers:
                     rec.append(offsets[id(layer.weight)])
                     rec.append(offsets[id(layer.bias)])
                 records.append(rec)
+            elif isinstance(t, M.BatchNorm):
+                rec = [2, len(tables), offsets[id(t.unconstrained_weight)], offsets[id(t.bias)],
+                       offsets[id(t.running_mean)], offsets[id(t.running_var)], f32_bits(t.eps),
+                       f32_bits(t.momentum)]
+                tables.extend(cur)
+                records.append(rec)
+            elif isinstance(t, M.LULinear):
+                if D > 64:
+                    raise ValueError("LU-linear transforms support at most 64 features")
+                rec = [3, len(tables), offsets[id(t.lower_entries)], offsets[id(t.upper_entries)],
+                       offsets[id(t.unconstrained_upper_diag)], offsets[id(t.bias)], f32_bits(t.eps)]
+                tables.extend(cur)
+                records.append(rec)
+                cur = list(range(D))
             else:
                 raise NotImplementedError(
-                    f"{type(t).__name__} has no training kernel yet (LU-linear / batch-norm "
-                    "training is planned); use linear_transform='permutation' and "
-                    "batch_norm_between_layers=False"
+                    f"{type(t).__name__} has no training kernel (supported: permutation, LU-linear, "
+                    "coupling with a residual conditioner, batch norm)"
                 )
+        if n_res is None:
+            raise ValueError("the flow has no coupling layer")
+        rec_len = max(len(r) for r in records)
+        records = [r + [0] * (rec_len - len(r)) for r in records]
         n_tr = pack.transform_policy(desc["transform"], desc.get("bins", 0))[2]
         rec_words = len(records[0])
         header = [D, desc["hidden"], n_res, len(records), pack.TRANSFORMS[desc["transform"]],
@@ -180,7 +206,7 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
         patience = tc["patience"]
     clip = tc["clip_grad_norm"]
     best_epoch, best_val_loss = 0, np.inf
-    trainer.best.copy_(trainer.params)
+    trainer.best.copy_(trainer.flat)
     history = dict(loss=[], val_loss=[])
     model.train()
     for epoch in range(1, max_epochs + 1):
@@ -202,11 +228,11 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
         history["val_loss"].append(val_loss)
         if validate and (val_loss < best_val_loss):
             best_epoch, best_val_loss = epoch, val_loss
-            trainer.best.copy_(trainer.params)
+            trainer.best.copy_(trainer.flat)
         if validate and (epoch - best_epoch > patience):
             break
     if validate:
-        trainer.params.copy_(trainer.best)
+        trainer.flat.copy_(trainer.best)
     model._image_key = None  # weights changed behind torch's version counters
     model.eval()
     return history

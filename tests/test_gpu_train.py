@@ -26,6 +26,10 @@ CASES = {
     "rnvp_additive": (RealNVP, O.RealNVP, (5, 8, 2, 1),
                       dict(linear_transform="permutation", batch_norm_between_layers=False,
                            use_volume_preserving=True)),
+    "rnvp_c2_default": (RealNVP, O.RealNVP, (16, 32, 4, 2), {}),  # LU-linear + batch norm
+    "rnvp_lu_only": (RealNVP, O.RealNVP, (5, 8, 2, 2), dict(batch_norm_between_layers=False)),
+    "nsf_bn_lu": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 3, 2),
+                  dict(batch_norm_between_layers=True, linear_transform="lu")),
 }
 
 
@@ -38,6 +42,10 @@ def pair(name, seed=3):
         for n_, p in ref.named_parameters():
             if "linear_layers.1" in n_:
                 p.mul_(200.0)
+        g = torch.Generator().manual_seed(seed)
+        for n_, p in ref.named_parameters():  # LU / batch-norm parameters off their trivial values
+            if "entries" in n_ or "unconstrained" in n_:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
     flow = P(*args, **kw)
     flow.load_state_dict(ref.state_dict())
     flow.to(DEV)
@@ -149,8 +157,29 @@ def test_flowmodel_train_end_to_end(tmp_path):
     del x_val
 
 
+def test_batch_norm_running_statistics_follow_the_reference():
+    """Training-mode batch norm updates running_mean / running_var with momentum 0.1 and the
+    unbiased batch variance, exactly as the oracle's transform does."""
+    ref, flow, D = pair("rnvp_c2_default")
+    x = torch.randn(400, D) * 1.3 + 0.2
+    ref.train()
+    ref.log_prob(x)
+    tr = Trainer(flow)
+    tr.step(x.to(DEV), clip_norm=5.0, lr=0.0)
+    torch.cuda.synchronize()
+    ref_stats = {k: v for k, v in ref.state_dict().items() if "running" in k}
+    got = {k: v.cpu() for k, v in flow.state_dict().items() if "running" in k}
+    assert ref_stats and set(ref_stats) == set(got)
+    for k in ref_stats:
+        assert torch.allclose(got[k], ref_stats[k], rtol=1e-4, atol=1e-5), k
+
+
 def test_unsupported_training_configurations_raise():
-    flow = RealNVP(4, 8, 2, 2)  # LU-linear + batch norm
+    flow = RealNVP(4, 8, 2, 2, actnorm=True, batch_norm_between_layers=False)
     flow.to(DEV)
     with pytest.raises(NotImplementedError, match="no training kernel"):
+        Trainer(flow)
+    flow = RealNVP(4, 8, 2, 2, net="mlp", batch_norm_between_layers=False)
+    flow.to(DEV)
+    with pytest.raises(NotImplementedError, match="residual conditioner"):
         Trainer(flow)
