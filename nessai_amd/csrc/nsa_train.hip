@@ -50,15 +50,26 @@ __global__ void __launch_bounds__(64) tr_gemm_nt(int n, int I, int O, const floa
   const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
   const int row = row0 + j, col = col0 + j;
   f32x16 acc = {0};
-  for (int k = 0; k < I; k += 2) {
-    const int kk = k + half;
-    float a = 0.0f, bb = 0.0f;
-    if (kk < I) {
-      if (row < n) a = tr_act(X[(long long)row * ldx + (cols ? cols[kk] : kk)], act_in);
-      if (col < O) bb = W[(long long)col * I + kk];
+  const long long xrow = (long long)(row < n ? row : n - 1) * ldx;
+  const long long wrow = (long long)(col < O ? col : O - 1) * I;
+  const bool row_ok = row < n, col_ok = col < O;
+  for (int k0 = 0; k0 < I; k0 += 16) {  // 8 MFMA steps per trip: all 16 loads issued before use
+    float xv[8], wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = k0 + 2 * u + half;
+      const int kc = kk < I ? kk : I - 1;  // clamped: loads are unconditional
+      xv[u] = X[xrow + (cols ? cols[kc] : kc)];
+      wv[u] = W[wrow + kc];
     }
-    // D[i][jj] = sum_k A[i][k] B[k][jj]: i = output column (W row), jj = batch row
-    acc = nsa_mfma(bb, a, acc);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = k0 + 2 * u + half;
+      const float a = (row_ok && kk < I) ? tr_act(xv[u], act_in) : 0.0f;
+      const float bb = (col_ok && kk < I) ? wv[u] : 0.0f;
+      // D[i][jj] = sum_k A[i][k] B[k][jj]: i = output column (W row), jj = batch row
+      acc = nsa_mfma(bb, a, acc);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -82,14 +93,25 @@ __global__ void __launch_bounds__(64) tr_gemm_nn(int n, int O, int I, const floa
   const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
   const int row = row0 + j, col = col0 + j;
   f32x16 acc = {0};
-  for (int k = 0; k < O; k += 2) {
-    const int kk = k + half;
-    float a = 0.0f, bb = 0.0f;
-    if (kk < O) {
-      if (row < n) a = Gout[(long long)row * ldg + kk];
-      if (col < I) bb = W[(long long)kk * I + col];
+  const long long grow = (long long)(row < n ? row : n - 1) * ldg;
+  const int wc = col < I ? col : I - 1;
+  const bool row_ok = row < n, col_ok = col < I;
+  for (int k0 = 0; k0 < O; k0 += 16) {
+    float gv[8], wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = k0 + 2 * u + half;
+      const int kc = kk < O ? kk : O - 1;
+      gv[u] = Gout[grow + kc];
+      wv[u] = W[(long long)kc * I + wc];
     }
-    acc = nsa_mfma(bb, a, acc);  // D[i = input feature][jj = batch row]
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = k0 + 2 * u + half;
+      const float a = (row_ok && kk < O) ? gv[u] : 0.0f;
+      const float bb = (col_ok && kk < O) ? wv[u] : 0.0f;
+      acc = nsa_mfma(bb, a, acc);  // D[i = input feature][jj = batch row]
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -106,34 +128,63 @@ __global__ void __launch_bounds__(64) tr_gemm_nn(int n, int O, int I, const floa
 }
 
 // dW[O][I] = sum_rows Gout[row][o] * act_in(X[row][cols[i]]);  db[o] = sum_rows Gout[row][o]
-__global__ void __launch_bounds__(64) tr_gemm_tn(int n, int O, int I, const float* __restrict__ Gout, int ldg,
-                                                 const float* __restrict__ X, int ldx,
-                                                 const int* __restrict__ cols, int act_in,
-                                                 float* __restrict__ dW, float* __restrict__ db) {
-  const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+// One workgroup = one 32x32 tile of dW; its 4 waves split the batch (the K dimension of
+// this product) and reduce through LDS in a fixed order (deterministic).
+__global__ void __launch_bounds__(256) tr_gemm_tn(int n, int O, int I, const float* __restrict__ Gout, int ldg,
+                                                  const float* __restrict__ X, int ldx,
+                                                  const int* __restrict__ cols, int act_in,
+                                                  float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[3][64][17];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
   const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
   const int o = o0 + j, i = i0 + j;
-  const int xcol = (i < I) ? (cols ? cols[i] : i) : 0;
+  const int oc = o < O ? o : O - 1;
+  const int xcol = (i < I) ? (cols ? cols[i] : i) : (cols ? cols[0] : 0);
+  const bool o_ok = o < O, i_ok = i < I;
+  const int per = (((n + 3) / 4) + 1) & ~1;  // rows per wave, even
+  const int k_lo = wave * per, k_hi = (k_lo + per < n) ? (k_lo + per) : n;
   f32x16 acc = {0};
   float bsum = 0.0f;
-  for (int k = 0; k < n; k += 2) {
-    const int row = k + half;
-    float a = 0.0f, bb = 0.0f;
-    if (row < n) {
-      if (o < O) a = Gout[(long long)row * ldg + o];
-      if (i < I) bb = tr_act(X[(long long)row * ldx + xcol], act_in);
-    }
-    bsum += a;
-    acc = nsa_mfma(a, bb, acc);  // D[ii = o][jj = i]
-  }
+  for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+    float gv[8], xv[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int oo = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (oo < O && i < I) dW[(long long)oo * I + i] = acc[r];
+    for (int u = 0; u < 8; ++u) {
+      const int row = k0 + 2 * u + half;
+      const int rc = row < n ? row : n - 1;
+      gv[u] = Gout[(long long)rc * ldg + oc];
+      xv[u] = X[(long long)rc * ldx + xcol];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = k0 + 2 * u + half;
+      const float a = (o_ok && row < k_hi) ? gv[u] : 0.0f;
+      const float bb = (i_ok && row < k_hi) ? tr_act(xv[u], act_in) : 0.0f;
+      bsum += a;
+      acc = nsa_mfma(a, bb, acc);  // D[ii = o][jj = i]
+    }
   }
-  if (blockIdx.y == 0) {
-    bsum += __shfl_xor(bsum, 32);
-    if (half == 0 && o < O) db[o] = bsum;
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][lane][r] = acc[r];
+    red[wave - 1][lane][16] = bsum;
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[w][lane][r];
+      bsum += red[w][lane][16];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oo = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (oo < O && i_ok) dW[(long long)oo * I + i] = acc[r];
+    }
+    if (blockIdx.y == 0) {
+      bsum += __shfl_xor(bsum, 32);
+      if (half == 0 && o_ok) db[o] = bsum;
+    }
   }
 }
 
@@ -818,7 +869,7 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       }
       // final layer: dWf, dbf, gh = gp . Wf
       float* hL = h + (long long)L * n * H;
-      hipLaunchKernelGGL(tr_gemm_tn, tiles(np, H), dim3(64), 0, s, (int)n, np, H, w.gp, np, hL, H,
+      hipLaunchKernelGGL(tr_gemm_tn, tiles(np, H), dim3(256), 0, s, (int)n, np, H, w.gp, np, hL, H,
                          (const int*)nullptr, ACT_NONE, grads + off[2 + 4 * L], grads + off[3 + 4 * L]);
       hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, np, H, w.gp, np,
                          params + off[2 + 4 * L], (const float*)nullptr, 0, ACT_NONE, w.gh, H,
@@ -827,18 +878,18 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
         float* hl = h + (long long)l * n * H;
         float* ul = u + (long long)l * n * H;
         // second linear of the block: h_{l+1} = h_l + W2 act(u_l) + b2
-        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(64), 0, s, (int)n, H, H, w.gh, H, ul, H,
+        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, w.gh, H, ul, H,
                            (const int*)nullptr, act, grads + off[4 + 4 * l], grads + off[5 + 4 * l]);
         hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gh, H,
                            params + off[4 + 4 * l], ul, H, act, w.gu, H, (const int*)nullptr, 0);
         // first linear: u_l = W1 act(h_l) + b1
-        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(64), 0, s, (int)n, H, H, w.gu, H, hl, H,
+        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, w.gu, H, hl, H,
                            (const int*)nullptr, act, grads + off[2 + 4 * l], grads + off[3 + 4 * l]);
         hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gu, H,
                            params + off[2 + 4 * l], hl, H, act, w.gh, H, (const int*)nullptr, 1);
       }
       // initial layer: dW0, db0, g_x[:, id_cols] += gh . W0 (x was restored by the transform's backward)
-      hipLaunchKernelGGL(tr_gemm_tn, tiles(H, d_id), dim3(64), 0, s, (int)n, H, d_id, w.gh, H, w.x, D, id_cols,
+      hipLaunchKernelGGL(tr_gemm_tn, tiles(H, d_id), dim3(256), 0, s, (int)n, H, d_id, w.gh, H, w.x, D, id_cols,
                          ACT_NONE, grads + off[0], grads + off[1]);
       hipLaunchKernelGGL(tr_gemm_nn, tiles(n, d_id), dim3(64), 0, s, (int)n, H, d_id, w.gh, H, params + off[0],
                          (const float*)nullptr, 0, ACT_NONE, w.gx, D, id_cols, 2);
@@ -856,11 +907,11 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       const float eps = tr_bits(r[6]);
       TrLin q = tr_lin(lay, n, D);
       // gy = w.gx (logical order).  dL = gy^T t, db = colsum gy;  gt = gy L;  dU = gt^T x;  gx = gt U
-      hipLaunchKernelGGL(tr_gemm_tn, tiles(D, D), dim3(64), 0, s, (int)n, D, D, w.gx, D, q.t, D,
+      hipLaunchKernelGGL(tr_gemm_tn, tiles(D, D), dim3(256), 0, s, (int)n, D, D, w.gx, D, q.t, D,
                          (const int*)nullptr, ACT_NONE, q.gL, grads + r[5]);
       hipLaunchKernelGGL(tr_gemm_nn, tiles(n, D), dim3(64), 0, s, (int)n, D, D, w.gx, D, q.Lm,
                          (const float*)nullptr, 0, ACT_NONE, q.gt, D, (const int*)nullptr, 0);
-      hipLaunchKernelGGL(tr_gemm_tn, tiles(D, D), dim3(64), 0, s, (int)n, D, D, q.gt, D, q.xin, D,
+      hipLaunchKernelGGL(tr_gemm_tn, tiles(D, D), dim3(256), 0, s, (int)n, D, D, q.gt, D, q.xin, D,
                          (const int*)nullptr, ACT_NONE, q.gU, q.vec + D);
       hipLaunchKernelGGL(tr_gemm_nn, tiles(n, D), dim3(64), 0, s, (int)n, D, D, q.gt, D, q.Um,
                          (const float*)nullptr, 0, ACT_NONE, w.gx, D, cols, 3);
