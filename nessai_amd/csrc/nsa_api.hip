@@ -101,6 +101,9 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   if (fn == nullptr)
     return nsa_fail(NSA_E_ARG, "no kernel instance for hidden_tiles=%u transform=%u bins=%u",
                     h[NSA_H_HT], h[NSA_H_TRANSFORM], h[NSA_H_BINS]);
+  if (h[NSA_H_PREC] != NSA_PREC_F32 && h[NSA_H_PREC] != NSA_PREC_BF16X3)
+    return nsa_fail(NSA_E_IMAGE, "unknown precision code %u", h[NSA_H_PREC]);
+  p.precision = (int)h[NSA_H_PREC];
   const int D = (int)h[NSA_H_D];
   const int XS = (D + 1) | 1;
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;

@@ -17,6 +17,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define NSA_ROWS 32  // rows per wave tile
 
@@ -28,6 +29,28 @@ __device__ __forceinline__ float nsa_bits_to_float(uint32_t u) { return __uint_a
 
 __device__ __forceinline__ f32x16 nsa_mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// bf16 matrix core: D[i][j] += sum_k A[i][k] B[k][j], k = 8*half + e (16 per instruction)
+__device__ __forceinline__ f32x16 nsa_mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi)   (round to nearest even)
+__device__ __forceinline__ void nsa_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+}
+
+// three-product split-bf16 multiply-accumulate: a*b ~ ah*bh + ah*bl + al*bh
+__device__ __forceinline__ f32x16 nsa_mfma_x3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
+  c = nsa_mfma16(al, bh, c);
+  c = nsa_mfma16(ah, bl, c);
+  return nsa_mfma16(ah, bh, c);
 }
 
 // activation of the conditioner (src/nessai/flows/utils.py:200-205)

@@ -24,8 +24,12 @@ using TP = NsaAdditive;
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t NSA_LAUNCH_NAME(
     const NsaLaunch* p, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
-  auto kern = (p->direction == NSA_DIR_INVERSE) ? nsa_flow_kernel<NSA_HT, TP, true>
-                                                : nsa_flow_kernel<NSA_HT, TP, false>;
+  const bool inv = p->direction == NSA_DIR_INVERSE;
+  auto kern = (p->precision == NSA_PREC_BF16X3)
+                  ? (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_BF16X3>
+                         : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_BF16X3>)
+                  : (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_F32>
+                         : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_F32>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

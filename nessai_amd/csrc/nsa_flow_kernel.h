@@ -36,6 +36,7 @@ struct NsaLaunch {
   const uint32_t* image;  // device flow image (nsa_format.h)
   int direction;          // NSA_DIR_*
   int mode;               // NSA_MODE_*
+  int precision;          // NSA_PREC_* (copied from the image header by the host)
   long long n;            // rows
   const float* x_in;      // [n][D] or null (POPULATE: null -> draw with Philox)
   float* x_out;           // [n][D] or null
@@ -169,6 +170,67 @@ __device__ __forceinline__ void nsa_acc_to_regs(const f32x16 (&acc)[HT], float (
     for (int r = 0; r < 16; ++r) out[16 * ot + r] = acc[ot][r];
 }
 
+// ---- split-bf16 (NSA_PREC_BF16X3) variants --------------------------------------
+
+// activations of one layer, split once and reused for every output tile
+template <int HT>
+struct NsaSplit {
+  bf16x8 hi[2 * HT], lo[2 * HT];
+};
+
+template <int HT>
+__device__ __forceinline__ void nsa_split_regs(const float (&in)[16 * HT], NsaSplit<HT>& sp) {
+#pragma unroll
+  for (int s = 0; s < 2 * HT; ++s) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = in[8 * s + e];
+    nsa_split8(v, sp.hi[s], sp.lo[s]);
+  }
+}
+
+// W layout: [OT][2*HT steps][part][64 lanes][8 bf16]  (4 words per lane and part)
+template <int HT, int OT>
+__device__ __forceinline__ void nsa_dense_regs16(const float* w, const NsaSplit<HT>& sp, int lane,
+                                                 f32x16 (&acc)[OT]) {
+  constexpr int S = 2 * HT;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const bf16x8 ah = *(const bf16x8*)(w + (((ot * S + s) * 2 + 0) * 64 + lane) * 4);
+      const bf16x8 al = *(const bf16x8*)(w + (((ot * S + s) * 2 + 1) * 64 + lane) * 4);
+      acc[ot] = nsa_mfma_x3(ah, al, sp.hi[s], sp.lo[s], acc[ot]);
+    }
+  }
+}
+
+// input gathered from the x tile: tab[16*s + 8*half + e]
+template <int OT, bool PRE>
+__device__ __forceinline__ void nsa_dense_tile16(const float* w, const int* tab, const float* pre,
+                                                 const float* xrow, int n_steps, int lane, int half,
+                                                 f32x16 (&acc)[OT]) {
+  for (int s = 0; s < n_steps; ++s) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = 16 * s + 8 * half + e;
+      const int col = tab[idx];
+      float val = (col >= 0) ? xrow[col] : 0.0f;
+      if (PRE) val = (col >= 0) ? (val - pre[idx]) : 0.0f;
+      v[e] = val;
+    }
+    bf16x8 bh, bl;
+    nsa_split8(v, bh, bl);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const bf16x8 ah = *(const bf16x8*)(w + (((ot * n_steps + s) * 2 + 0) * 64 + lane) * 4);
+      const bf16x8 al = *(const bf16x8*)(w + (((ot * n_steps + s) * 2 + 1) * 64 + lane) * 4);
+      acc[ot] = nsa_mfma_x3(ah, al, bh, bl, acc[ot]);
+    }
+  }
+}
+
 // activation over a whole register array; the (wave-uniform) kind is tested
 // once, not per element
 template <int N>
@@ -232,15 +294,16 @@ __device__ __forceinline__ void nsa_static_for(F&& body, std::integer_sequence<i
 // of the phases and a scheduling fence, so that on a SIMD shared by two waves
 // one wave's VALU phase runs under the other wave's MFMA group.  The A
 // operands (LDS) of group g+1 are fetched before the MFMAs of group g.
-template <int HT, class TP, bool INV, bool WITH_PHASES>
-__device__ __forceinline__ void nsa_chunk_gemm(const float* stg, const float (&h)[16 * HT], int lane,
-                                               int half, f32x16 (&acc)[TP::C], int (&cols)[TP::FPC],
+template <int HT, class TP, bool INV, bool WITH_PHASES, int PREC>
+__device__ __forceinline__ void nsa_chunk_gemm(const float* stg, const float (&h)[16 * HT],
+                                               const NsaSplit<HT>& hs, int lane, int half,
+                                               f32x16 (&acc)[TP::C], int (&cols)[TP::FPC],
                                                const float (&v)[16 * TP::C],
                                                const int (&vcols)[TP::FPC], float* xrow,
                                                int dummy_col, const NsaTransformConsts& tc,
                                                float& logdet, int& n_bad) {
   constexpr int TABW = (2 * TP::FPC + 3) & ~3;
-  constexpr int G = 4 * HT;
+  constexpr int G = (PREC == NSA_PREC_BF16X3) ? 2 * HT : 4 * HT;  // k-step groups
   constexpr int TOT = TP::NPH * TP::FPC;
   const int* tr_tab = (const int*)stg;
   const float* bias = stg + TABW;
@@ -249,59 +312,94 @@ __device__ __forceinline__ void nsa_chunk_gemm(const float* stg, const float (&h
   for (int q = 0; q < TP::FPC; ++q) cols[q] = tr_tab[half * TP::FPC + q];
   nsa_load_bias<TP::C>(bias, half, acc);
   typename TP::State st[TP::FPC];
-  f32x4 a_cur[TP::C];
+  if constexpr (PREC == NSA_PREC_BF16X3) {
+    nsa_static_for(
+        [&](auto gc) {
+          constexpr int g = decltype(gc)::value;
 #pragma unroll
-  for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = *(const f32x4*)(w + ((ot * G + 0) * 64 + lane) * 4);
-  nsa_static_for(
-      [&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        f32x4 a_nxt[TP::C];
-        if constexpr (g + 1 < G) {
+          for (int ot = 0; ot < TP::C; ++ot) {
+            const bf16x8 ah = *(const bf16x8*)(w + (((ot * G + g) * 2 + 0) * 64 + lane) * 4);
+            const bf16x8 al = *(const bf16x8*)(w + (((ot * G + g) * 2 + 1) * 64 + lane) * 4);
+            acc[ot] = nsa_mfma_x3(ah, al, hs.hi[g], hs.lo[g], acc[ot]);
+          }
+          if constexpr (WITH_PHASES) {
+            constexpr int LO = g * TOT / G, HI = (g + 1) * TOT / G;
+            nsa_run_phases<TP, INV, LO>(st, v, vcols, xrow, dummy_col, tc, logdet, n_bad,
+                                        std::make_integer_sequence<int, HI - LO>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        },
+        std::make_integer_sequence<int, G>{});
+  } else {
+    f32x4 a_cur[TP::C];
 #pragma unroll
-          for (int ot = 0; ot < TP::C; ++ot)
-            a_nxt[ot] = *(const f32x4*)(w + ((ot * G + g + 1) * 64 + lane) * 4);
-        }
+    for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = *(const f32x4*)(w + ((ot * G + 0) * 64 + lane) * 4);
+    nsa_static_for(
+        [&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          f32x4 a_nxt[TP::C];
+          if constexpr (g + 1 < G) {
 #pragma unroll
-        for (int ot = 0; ot < TP::C; ++ot) {
-          acc[ot] = nsa_mfma(a_cur[ot][0], h[4 * g + 0], acc[ot]);
-          acc[ot] = nsa_mfma(a_cur[ot][1], h[4 * g + 1], acc[ot]);
-          acc[ot] = nsa_mfma(a_cur[ot][2], h[4 * g + 2], acc[ot]);
-          acc[ot] = nsa_mfma(a_cur[ot][3], h[4 * g + 3], acc[ot]);
-        }
-        if constexpr (WITH_PHASES) {
-          constexpr int LO = g * TOT / G, HI = (g + 1) * TOT / G;
-          nsa_run_phases<TP, INV, LO>(st, v, vcols, xrow, dummy_col, tc, logdet, n_bad,
-                                      std::make_integer_sequence<int, HI - LO>{});
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (g + 1 < G) {
+            for (int ot = 0; ot < TP::C; ++ot)
+              a_nxt[ot] = *(const f32x4*)(w + ((ot * G + g + 1) * 64 + lane) * 4);
+          }
 #pragma unroll
-          for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = a_nxt[ot];
-        }
-      },
-      std::make_integer_sequence<int, G>{});
+          for (int ot = 0; ot < TP::C; ++ot) {
+            acc[ot] = nsa_mfma(a_cur[ot][0], h[4 * g + 0], acc[ot]);
+            acc[ot] = nsa_mfma(a_cur[ot][1], h[4 * g + 1], acc[ot]);
+            acc[ot] = nsa_mfma(a_cur[ot][2], h[4 * g + 2], acc[ot]);
+            acc[ot] = nsa_mfma(a_cur[ot][3], h[4 * g + 3], acc[ot]);
+          }
+          if constexpr (WITH_PHASES) {
+            constexpr int LO = g * TOT / G, HI = (g + 1) * TOT / G;
+            nsa_run_phases<TP, INV, LO>(st, v, vcols, xrow, dummy_col, tc, logdet, n_bad,
+                                        std::make_integer_sequence<int, HI - LO>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (g + 1 < G) {
+#pragma unroll
+            for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = a_nxt[ot];
+          }
+        },
+        std::make_integer_sequence<int, G>{});
+  }
 }
 
 // one coupling layer -----------------------------------------------------------
 
-template <int HT, class TP, bool INV>
+template <int HT, class TP, bool INV, int PREC>
 __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t* op, float* xrow,
                                              int dummy_col, int lane, int half, int act, int net,
                                              int n_layers, const NsaTransformConsts& tc,
                                              float& logdet, int& n_bad) {
+  constexpr bool BF = (PREC == NSA_PREC_BF16X3);
   const int n_steps0 = (int)op[1];
   const int n_chunks = (int)op[2];
   float h[16 * HT];
+
+  // one H -> H layer from registers: out = W in + b
+  auto hidden_layer = [&](const float (&in)[16 * HT], f32x16 (&acc)[HT]) {
+    const float* st = pipe.begin();
+    nsa_load_bias<HT>(st, half, acc);
+    if constexpr (BF) {
+      NsaSplit<HT> sp;
+      nsa_split_regs<HT>(in, sp);
+      nsa_dense_regs16<HT, HT>(st + 32 * HT, sp, lane, acc);
+    } else {
+      nsa_dense_regs<HT, HT>(st + 32 * HT, in, lane, acc);
+    }
+  };
 
   // layer 0: identity features (x tile) -> hidden
   {
     const float* st = pipe.begin();
     const int* id_tab = (const int*)st;
-    const float* bias = st + 2 * n_steps0;
+    const float* bias = st + (BF ? 16 : 2) * n_steps0;
     const float* w = bias + 32 * HT;
     f32x16 acc[HT];
     nsa_load_bias<HT>(bias, half, acc);
-    nsa_dense_tile<HT, false>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
+    if constexpr (BF) nsa_dense_tile16<HT, false>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
+    else nsa_dense_tile<HT, false>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
     nsa_acc_to_regs<HT>(acc, h);
     pipe.end();
   }
@@ -314,19 +412,15 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
       for (int i = 0; i < 16 * HT; ++i) t[i] = h[i];
       nsa_act_regs<16 * HT>(t, act);
       {
-        const float* st = pipe.begin();
         f32x16 acc[HT];
-        nsa_load_bias<HT>(st, half, acc);
-        nsa_dense_regs<HT, HT>(st + 32 * HT, t, lane, acc);
+        hidden_layer(t, acc);
         nsa_acc_to_regs<HT>(acc, t);
         nsa_act_regs<16 * HT>(t, act);
         pipe.end();
       }
       {
-        const float* st = pipe.begin();
         f32x16 acc[HT];
-        nsa_load_bias<HT>(st, half, acc);
-        nsa_dense_regs<HT, HT>(st + 32 * HT, t, lane, acc);
+        hidden_layer(t, acc);
 #pragma unroll
         for (int ot = 0; ot < HT; ++ot)
 #pragma unroll
@@ -338,10 +432,8 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     // plain MLP (src/nessai/flows/nets.py:110-124): act after every layer but the last
     nsa_act_regs<16 * HT>(h, act);
     for (int l = 1; l < n_layers; ++l) {
-      const float* st = pipe.begin();
       f32x16 acc[HT];
-      nsa_load_bias<HT>(st, half, acc);
-      nsa_dense_regs<HT, HT>(st + 32 * HT, h, lane, acc);
+      hidden_layer(h, acc);
       nsa_acc_to_regs<HT>(acc, h);
       nsa_act_regs<16 * HT>(h, act);
       pipe.end();
@@ -352,14 +444,16 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
   // parameter sets per chunk and transforms those features in place.  The loop
   // is software-pipelined: the MFMAs of chunk c+1 are interleaved with the
   // element-wise phases of chunk c (registers + the lane's own x-tile cells).
+  NsaSplit<HT> hs;
+  if constexpr (BF) nsa_split_regs<HT>(h, hs);
   f32x16 acc[TP::C];
   int cols[TP::FPC];
   float v[16 * TP::C];
   int vcols[TP::FPC];
   {
     const float* st = pipe.begin();
-    nsa_chunk_gemm<HT, TP, INV, false>(st, h, lane, half, acc, cols, v, vcols, xrow, dummy_col, tc,
-                                       logdet, n_bad);
+    nsa_chunk_gemm<HT, TP, INV, false, PREC>(st, h, hs, lane, half, acc, cols, v, vcols, xrow, dummy_col,
+                                             tc, logdet, n_bad);
     pipe.end();
   }
   for (int c = 0; c + 1 < n_chunks; ++c) {
@@ -370,8 +464,8 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
 #pragma unroll
     for (int q = 0; q < TP::FPC; ++q) vcols[q] = cols[q];
     const float* st = pipe.begin();
-    nsa_chunk_gemm<HT, TP, INV, true>(st, h, lane, half, acc, cols, v, vcols, xrow, dummy_col, tc,
-                                      logdet, n_bad);
+    nsa_chunk_gemm<HT, TP, INV, true, PREC>(st, h, hs, lane, half, acc, cols, v, vcols, xrow, dummy_col,
+                                            tc, logdet, n_bad);
     pipe.end();
   }
   {
@@ -387,19 +481,23 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
 
 // dense (LU-linear, eval-mode cached weight) -----------------------------------
 // y = W (x - pre) + bias over all D features; D <= 64.
+template <int PREC>
 __device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t* op, float* xrow,
                                              int D, int lane, int half, float& logdet) {
+  constexpr bool BF = (PREC == NSA_PREC_BF16X3);
   const int n_steps = (int)op[1];
   const int n_ot = (int)op[2];
+  const int tab_len = (BF ? 16 : 2) * n_steps;
   const float* st = pipe.begin();
   const int* in_tab = (const int*)st;
-  const float* pre = st + 2 * n_steps;
-  const float* bias = pre + 2 * n_steps;
+  const float* pre = st + tab_len;
+  const float* bias = pre + tab_len;
   const float* w = bias + 32 * n_ot;
   if (n_ot == 1) {
     f32x16 acc[1];
     nsa_load_bias<1>(bias, half, acc);
-    nsa_dense_tile<1, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+    if constexpr (BF) nsa_dense_tile16<1, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+    else nsa_dense_tile<1, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -408,7 +506,8 @@ __device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t*
   } else {
     f32x16 acc[2];
     nsa_load_bias<2>(bias, half, acc);
-    nsa_dense_tile<2, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+    if constexpr (BF) nsa_dense_tile16<2, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+    else nsa_dense_tile<2, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -437,7 +536,7 @@ __device__ __forceinline__ void nsa_elementwise_op(NsaStagePipe& pipe, const uin
 
 // the kernel ------------------------------------------------------------------
 
-template <int HT, class TP, bool INV>
+template <int HT, class TP, bool INV, int PREC>
 __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const uint32_t* img = p.image;
@@ -558,9 +657,9 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
       const uint32_t* op = ops + o * NSA_OP_WORDS;
       const int kind = (int)op[0];
       if (kind == NSA_OP_COUPLING) {
-        nsa_coupling<HT, TP, INV>(pipe, op, xrow, D, lane, half, act, net, n_layers, tc, logdet, n_bad);
+        nsa_coupling<HT, TP, INV, PREC>(pipe, op, xrow, D, lane, half, act, net, n_layers, tc, logdet, n_bad);
       } else if (kind == NSA_OP_DENSE) {
-        nsa_dense_op(pipe, op, xrow, D, lane, half, logdet);
+        nsa_dense_op<PREC>(pipe, op, xrow, D, lane, half, logdet);
       } else {
         nsa_elementwise_op(pipe, op, xrow, D, half, logdet);
       }

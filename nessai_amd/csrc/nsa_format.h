@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define NSA_MAGIC 0x3141534e /* "NSA1" */
-#define NSA_VERSION 3
+#define NSA_VERSION 4
 
 // header word indices
 enum {
@@ -47,6 +47,7 @@ enum {
   NSA_H_NET = 26,          // NSA_NET_*
   NSA_H_NLAYERS = 27,      // residual blocks (resnet) / hidden layers (mlp)
   NSA_H_BASE_INV_VAR = 28, // float: 1/var of the base Gaussian (1.0 for StandardNormal)
+  NSA_H_PREC = 29,         // NSA_PREC_*: arithmetic of the conditioner GEMMs
   NSA_H_WORDS = 32
 };
 
@@ -54,6 +55,11 @@ enum { NSA_T_NONE = 0, NSA_T_RQ = 1, NSA_T_AFFINE = 2, NSA_T_ADDITIVE = 3 };
 enum { NSA_ACT_RELU = 0, NSA_ACT_TANH = 1, NSA_ACT_SILU = 2 };
 enum { NSA_NET_RESNET = 0, NSA_NET_MLP = 1 };
 enum { NSA_OP_COUPLING = 1, NSA_OP_DENSE = 2, NSA_OP_ELEMENTWISE = 3 };
+// NSA_PREC_F32   : v_mfma_f32_32x32x2_f32, exact f32 products (runs on the f32 vector ALUs)
+// NSA_PREC_BF16X3: operands split x = hi + lo (two bf16), products hi*hi + hi*lo + lo*hi on
+//                  v_mfma_f32_32x32x16_bf16 with f32 accumulation (relative error ~2^-16 per
+//                  product; log_prob stays within the 1e-5 parity bar)
+enum { NSA_PREC_F32 = 0, NSA_PREC_BF16X3 = 1 };
 
 // op record: 4 words
 //   COUPLING    {kind, n_steps0 (multiple of 4), n_chunks, 0}
@@ -74,6 +80,12 @@ enum { NSA_OP_COUPLING = 1, NSA_OP_DENSE = 2, NSA_OP_ELEMENTWISE = 3 };
 //   in_col from registers (hidden/final): 32*(s>>4) + (r&3) + 8*(r>>2) + 4*half, r = s&15
 //   in_col from the x tile (layer 0, dense): 2*s + half
 // bias[ot][half][r] is the bias of out feature 32*ot + (r&3) + 8*(r>>2) + 4*half.
+//
+// NSA_PREC_BF16X3 images keep the same tables and biases but count k in steps of 16
+// (v_mfma_f32_32x32x16_bf16: lane = 32*half + i holds 8 consecutive k of its half) and
+// store W as bf16 pairs: W[ot][s][part][64][8], part 0 = hi, part 1 = lo, with
+//   in_col from registers: 32*(s>>1) + (r&3) + 8*(r>>2) + 4*half, r = 8*(s&1) + e
+//   in_col from the x tile: 16*s + 8*half + e            (tables hold 16 entries per step)
 
 // flags for nsa_flow_* entry points
 #define NSA_DIR_FORWARD 0

@@ -8,6 +8,7 @@ the reference's ``NFlow`` (``flows/base.py:170-316``) whose transform and base
 distribution run in the gfx950 kernels of ``nessai_amd/csrc``.
 """
 
+import os
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -78,6 +79,12 @@ class BaseFlow(Module, ABC):
 MODE_APPLY, MODE_LOGPROB = 0, 1
 DIR_FORWARD, DIR_INVERSE = 0, 1
 
+#: arithmetic of the conditioner GEMMs (see ``nsa_format.h``): ``"bf16x3"`` = split-bf16
+#: operands on the bf16 matrix cores with float32 accumulation (default), ``"f32"`` = exact
+#: float32 products.  Override per flow (``flow.precision = ...``) or with the environment
+#: variable ``NESSAI_AMD_PRECISION``.
+DEFAULT_PRECISION = os.environ.get("NESSAI_AMD_PRECISION", "bf16x3")
+
 
 class HipFlow(BaseFlow):
     """Transform + base distribution evaluated by the fused gfx950 flow kernel.
@@ -105,6 +112,9 @@ class HipFlow(BaseFlow):
         self._status = None
         self.waves_per_group = 0
         self.max_groups = 0
+        self.precision = DEFAULT_PRECISION
+        if self.precision not in pack.PRECISIONS:
+            raise ValueError(f"unknown precision {self.precision!r}; choose from {sorted(pack.PRECISIONS)}")
         desc = M.describe(self)
         self.features = desc["D"]
         ht = pack.hidden_tiles(desc["hidden"])
@@ -136,9 +146,9 @@ class HipFlow(BaseFlow):
                 "nessai_amd flows run on a ROCm device only; move the flow with "
                 ".to('cuda') (there is no CPU fallback)"
             )
-        key = (device, self._fingerprint())
+        key = (device, self.precision, self._fingerprint())
         if key != self._image_key:
-            image = pack.pack_flow(M.describe(self))
+            image = pack.pack_flow(dict(M.describe(self), precision=self.precision))
             self._image_host = image
             self._header = (lib.ctypes.c_uint32 * pack.HEADER_WORDS)(*image[: pack.HEADER_WORDS].tolist())
             self._image_dev = torch.from_numpy(image.view(np.int32)).to(device)

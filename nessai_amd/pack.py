@@ -31,7 +31,7 @@ import math
 import numpy as np
 
 MAGIC = 0x3141534E
-VERSION = 3
+VERSION = 4
 HEADER_WORDS = 32
 OP_WORDS = 4
 
@@ -40,13 +40,14 @@ H_NOPS_FWD, H_OPS_FWD, H_NOPS_INV, H_OPS_INV = 6, 7, 8, 9
 H_NSTAGES_FWD, H_STAGES_FWD, H_NSTAGES_INV, H_STAGES_INV = 10, 11, 12, 13
 H_MAX_STAGE, H_TOTAL, H_OUT_FWD, H_OUT_INV = 14, 15, 16, 17
 H_LOG_Z, H_TAIL_BOUND, H_MIN_BW, H_MIN_BH, H_MIN_D, H_EDGE_RAW = 18, 19, 20, 21, 22, 23
-H_LOGIT_DIV, H_ACT, H_NET, H_NLAYERS, H_BASE_INV_VAR = 24, 25, 26, 27, 28
+H_LOGIT_DIV, H_ACT, H_NET, H_NLAYERS, H_BASE_INV_VAR, H_PREC = 24, 25, 26, 27, 28, 29
 
 T_NONE, T_RQ, T_AFFINE, T_ADDITIVE = 0, 1, 2, 3
 TRANSFORMS = {"rq": T_RQ, "affine": T_AFFINE, "additive": T_ADDITIVE}
 ACTIVATIONS = {"relu": 0, "tanh": 1, "silu": 2, "swish": 2}
 NETS = {"resnet": 0, "mlp": 1}
 OP_COUPLING, OP_DENSE, OP_ELEMENTWISE = 1, 2, 3
+PRECISIONS = {"f32": 0, "bf16x3": 1}
 
 
 def _f32_bits(value):
@@ -124,6 +125,66 @@ def pack_bias(bias, out_rows):
     return out.reshape(-1)
 
 
+def bf16_bits(x):
+    """float32 -> bfloat16 bit patterns, round-to-nearest-even (v_cvt_pk_bf16_f32)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_to_f32(bits):
+    return (bits.astype(np.uint32) << 16).view(np.float32)
+
+
+def split_bf16(x):
+    """x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi); returns the two bit arrays."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    hi = bf16_bits(x)
+    lo = bf16_bits(x - bf16_to_f32(hi))
+    return hi, lo
+
+
+def pack_matrix_bf16(weight, out_rows, in_cols):
+    """A operand of v_mfma_f32_32x32x16_bf16, split in hi/lo parts.
+
+    ``in_cols[s][half][e]`` original input column of k-step ``s`` (or -1).
+    Returns uint32 words of the layout ``[OT][S][part][64 lanes][8 bf16]``.
+    """
+    n_ot, n_steps = len(out_rows), len(in_cols)
+    w = np.zeros((n_ot, n_steps, 64, 8), dtype=np.float32)
+    rows = np.asarray(out_rows, dtype=np.int64)  # [OT][32]
+    cols = np.asarray(in_cols, dtype=np.int64).reshape(n_steps, 2, 8)
+    for ot in range(n_ot):
+        for half in range(2):
+            r = rows[ot]
+            c = cols[:, half, :]  # [S][8]
+            valid = (r[:, None, None] >= 0) & (c[None, :, :] >= 0)
+            block = np.where(valid, weight[np.maximum(r, 0)[:, None, None], np.maximum(c, 0)[None, :, :]], 0.0)
+            w[ot, :, 32 * half : 32 * half + 32, :] = block.transpose(1, 0, 2)  # [S][32][8]
+    hi, lo = split_bf16(w)
+    parts = np.stack([hi, lo], axis=2)  # [OT][S][2][64][8] uint16
+    return np.ascontiguousarray(parts).reshape(-1).view(np.uint32)
+
+
+def _reg_in_cols16(n_tiles, limit):
+    """Input columns for register-fed layers in k-steps of 16: [s][half][e]."""
+    cols = []
+    for s in range(2 * n_tiles):
+        step = []
+        for half in range(2):
+            step.append([
+                (f if f < limit else -1)
+                for f in (d_reg_feature(s >> 1, 8 * (s & 1) + e, half) for e in range(8))
+            ])
+        cols.append(step)
+    return cols
+
+
+def _tile_in_cols16(n_steps, limit):
+    """Input columns for layers fed from the x tile in k-steps of 16: [s][half][e]."""
+    return [[[(16 * s + 8 * h + e) if (16 * s + 8 * h + e) < limit else -1 for e in range(8)]
+             for h in range(2)] for s in range(n_steps)]
+
+
 def _reg_in_cols(n_tiles, limit):
     """Input columns for layers fed from registers: step s=(tile, reg)."""
     cols = []
@@ -149,6 +210,8 @@ def _stage(*sections):
             words = sec.view(np.uint32)
         elif sec.dtype == np.int32:
             words = sec.view(np.uint32)
+        elif sec.dtype == np.uint32:
+            words = sec
         else:
             raise TypeError(sec.dtype)
         pad = pad4(len(words)) - len(words)
@@ -171,16 +234,27 @@ class _CouplingBlobs:
         hidden = desc["hidden"]
         ht = hidden_tiles(hidden)
         n_tiles_c, fpc, n_params = transform_policy(desc["transform"], desc.get("bins", 0))
-        self.n_steps0 = pad4((self.d_id + 1) // 2)
+        bf16 = desc.get("precision", "f32") == "bf16x3"
+        self.bf16 = bf16
+        self.n_steps0 = (self.d_id + 15) // 16 if bf16 else pad4((self.d_id + 1) // 2)
         self.n_chunks = (self.d_tr + 2 * fpc - 1) // (2 * fpc)
         self.fpc = fpc
+        if bf16:
+            pack_w = pack_matrix_bf16
+            reg_cols = _reg_in_cols16(ht, hidden)
+        else:
+            pack_w = pack_matrix
+            reg_cols = _reg_in_cols(ht, hidden)
 
         w0, b0 = layers[0]
         assert w0.shape == (hidden, self.d_id), (w0.shape, hidden, self.d_id)
-        in_cols0 = [[(2 * s + h) if (2 * s + h) < self.d_id else -1 for h in range(2)] for s in range(self.n_steps0)]
+        if bf16:
+            in_cols0 = _tile_in_cols16(self.n_steps0, self.d_id)
+        else:
+            in_cols0 = [[(2 * s + h) if (2 * s + h) < self.d_id else -1 for h in range(2)] for s in range(self.n_steps0)]
         self.layer0 = (
             pack_bias(b0, _plain_out_rows(ht, hidden)),
-            pack_matrix(w0, _plain_out_rows(ht, hidden), in_cols0),
+            pack_w(w0, _plain_out_rows(ht, hidden), in_cols0),
         )
 
         self.hidden_layers = []
@@ -189,7 +263,7 @@ class _CouplingBlobs:
             self.hidden_layers.append(
                 (
                     pack_bias(b, _plain_out_rows(ht, hidden)),
-                    pack_matrix(w, _plain_out_rows(ht, hidden), _reg_in_cols(ht, hidden)),
+                    pack_w(w, _plain_out_rows(ht, hidden), reg_cols),
                 )
             )
 
@@ -215,9 +289,7 @@ class _CouplingBlobs:
                 for q in range(fpc):
                     m = c * 2 * fpc + half * fpc + q
                     slots.append(m if m < self.d_tr else -1)
-            self.chunks.append(
-                (slots, pack_bias(bf, out_rows), pack_matrix(wf, out_rows, _reg_in_cols(ht, hidden)))
-            )
+            self.chunks.append((slots, pack_bias(bf, out_rows), pack_w(wf, out_rows, reg_cols)))
 
     @staticmethod
     def _decode(transform, v, n_params):
@@ -249,6 +321,10 @@ def pack_flow(desc):
     n_tiles_c, fpc, n_params = transform_policy(transform, bins)
     tabw = pad4(2 * fpc)
     D4 = pad4(D)
+    precision = desc.get("precision", "f32")
+    if precision not in PRECISIONS:
+        raise ValueError(f"unknown precision {precision!r}; choose from {sorted(PRECISIONS)}")
+    bf16 = precision == "bf16x3"
 
     blobs = []  # list of uint32 arrays
     blob_offsets = []
@@ -277,11 +353,17 @@ def pack_flow(desc):
                 _, W, W_inv, bias, logabsdet = tr
                 if D > 64:
                     raise ValueError("LU-linear transforms support at most 64 features")
-                n_steps = pad4((D + 1) // 2)
                 n_ot = (D + 31) // 32
-                in_cols = [[(2 * s + h) if (2 * s + h) < D else -1 for h in range(2)] for s in range(n_steps)]
-                in_tab = np.full(2 * n_steps, -1, dtype=np.int32)
-                pre = np.zeros(2 * n_steps, dtype=np.float32)
+                if bf16:
+                    n_steps = (D + 15) // 16
+                    in_cols = _tile_in_cols16(n_steps, D)
+                    tab_len = 16 * n_steps
+                else:
+                    n_steps = pad4((D + 1) // 2)
+                    in_cols = [[(2 * s + h) if (2 * s + h) < D else -1 for h in range(2)] for s in range(n_steps)]
+                    tab_len = 2 * n_steps
+                in_tab = np.full(tab_len, -1, dtype=np.int32)
+                pre = np.zeros(tab_len, dtype=np.float32)
                 for k in range(D):
                     in_tab[k] = cur[k]
                 if inverse:
@@ -294,13 +376,14 @@ def pack_flow(desc):
                     post = np.asarray(bias, dtype=np.float32)
                     ld = np.float32(logabsdet)
                 out_rows = _plain_out_rows(n_ot, D)
-                blob = _stage(in_tab, pre, pack_bias(post, out_rows), pack_matrix(mat, out_rows, in_cols))
+                pack_w = pack_matrix_bf16 if bf16 else pack_matrix
+                blob = _stage(in_tab, pre, pack_bias(post, out_rows), pack_w(mat, out_rows, in_cols))
                 stages.append(add_blob(blob))
                 ops.append([OP_DENSE, n_steps, n_ot, _f32_bits(ld)])
                 cur = list(range(D))
             elif kind == "coupling":
                 _, identity_idx, transform_idx, packed = tr
-                id_tab = np.full(2 * packed.n_steps0, -1, dtype=np.int32)
+                id_tab = np.full((16 if bf16 else 2) * packed.n_steps0, -1, dtype=np.int32)
                 for k, f in enumerate(identity_idx):
                     id_tab[k] = cur[int(f)]
                 stages.append(add_blob(_stage(id_tab, *packed.layer0)))
@@ -408,6 +491,7 @@ def pack_flow(desc):
     img[H_ACT] = ACTIVATIONS[desc.get("activation", "relu")]
     img[H_NET] = NETS[desc.get("net", "resnet")]
     img[H_NLAYERS] = n_net_layers if n_net_layers is not None else 0
+    img[H_PREC] = PRECISIONS[precision]
 
     img[off_ops_fwd : off_ops_fwd + ops_fwd.size] = ops_fwd.reshape(-1)
     img[off_ops_inv : off_ops_inv + ops_inv.size] = ops_inv.reshape(-1)

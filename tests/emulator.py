@@ -33,6 +33,30 @@ def mfma_32x32x2(a, b, c):
     return out
 
 
+def mfma_32x32x16_x3(a_hi, a_lo, b_hi, b_lo, c):
+    """Split-bf16 product on v_mfma_f32_32x32x16_bf16: operands [64][8] float32 values that are
+    exactly representable in bf16; lane 32*half + i holds k = 8*half + e."""
+    def mat_a(a):  # A[i][k]
+        return np.concatenate([a[:32], a[32:]], axis=1).astype(np.float64)  # [32][16]
+
+    def mat_b(b):  # B[k][j]
+        return np.concatenate([b[:32].T, b[32:].T], axis=0).astype(np.float64)  # [16][32]
+
+    Dm = (mat_a(a_lo) @ mat_b(b_hi) + mat_a(a_hi) @ mat_b(b_lo) + mat_a(a_hi) @ mat_b(b_hi)).astype(np.float32)
+    out = c.copy()
+    for lane in range(64):
+        half, j = lane >> 5, lane & 31
+        for r in range(16):
+            i = (r & 3) + 8 * (r >> 2) + 4 * half
+            out[lane, r] += Dm[i, j]
+    return out
+
+
+def split_f32(x):
+    hi, lo = P.split_bf16(x)
+    return P.bf16_to_f32(hi), P.bf16_to_f32(lo)
+
+
 class Emulator:
     def __init__(self, image):
         self.img = np.asarray(image, dtype=np.uint32)
@@ -45,6 +69,7 @@ class Emulator:
         self.act = int(h[P.H_ACT])
         self.net = int(h[P.H_NET])
         self.n_layers = int(h[P.H_NLAYERS])
+        self.bf16 = int(h[P.H_PREC]) == 1
         name = {1: "rq", 2: "affine", 3: "additive"}[self.transform]
         self.C, self.FPC, self.NP = P.transform_policy(name, self.bins)
 
@@ -70,6 +95,16 @@ class Emulator:
             for ot in range(n_ot):
                 a = w[ot, s // 4, :, s % 4]
                 acc[ot] = mfma_32x32x2(a, b, acc[ot])
+        return acc
+
+    def _dense16(self, w_words, n_ot, n_steps, b_of_step, acc):
+        """w_words: uint32 [n_ot][n_steps][2][64][4]; b_of_step(s) -> [64][8] float32."""
+        w16 = np.ascontiguousarray(w_words).view(np.uint16).reshape(n_ot, n_steps, 2, 64, 8)
+        wf = P.bf16_to_f32(w16)
+        for s in range(n_steps):
+            b_hi, b_lo = split_f32(b_of_step(s))
+            for ot in range(n_ot):
+                acc[ot] = mfma_32x32x16_x3(wf[ot, s, 0], wf[ot, s, 1], b_hi, b_lo, acc[ot])
         return acc
 
     def _activate(self, x):
@@ -101,26 +136,40 @@ class Emulator:
                 n_steps0, n_chunks = int(op[1]), int(op[2])
                 st = self._stage_words(inverse, stage)
                 stage += 1
-                id_tab = st[: 2 * n_steps0].view(np.int32)
+                tl = (16 if self.bf16 else 2) * n_steps0
+                id_tab = st[:tl].view(np.int32)
                 fl = st.view(np.float32)
-                bias = fl[2 * n_steps0 : 2 * n_steps0 + 32 * HT]
-                w = fl[2 * n_steps0 + 32 * HT : 2 * n_steps0 + 32 * HT + HT * n_steps0 * 64]
+                bias = fl[tl : tl + 32 * HT]
 
-                def b0(s):
-                    cols = id_tab[2 * s + half_of]
-                    vals = xt[row_of, np.maximum(cols, 0)]
+                def gather(tab, idx, pre=None):
+                    cols = tab[idx]
+                    vals = xt[row_of[:, None] if idx.ndim == 2 else row_of, np.maximum(cols, 0)]
+                    if pre is not None:
+                        vals = vals - pre[idx]
                     return np.where(cols >= 0, vals, 0.0).astype(np.float32)
 
-                acc = self._dense(w, HT, n_steps0, b0, self._bias(bias, HT))
+                if self.bf16:
+                    w = st[tl + 32 * HT : tl + 32 * HT + HT * n_steps0 * 512]
+                    b0 = lambda s: gather(id_tab, 16 * s + 8 * half_of[:, None] + np.arange(8)[None, :])  # noqa: E731
+                    acc = self._dense16(w, HT, n_steps0, b0, self._bias(bias, HT))
+                else:
+                    w = fl[tl + 32 * HT : tl + 32 * HT + HT * n_steps0 * 64]
+                    acc = self._dense(w, HT, n_steps0, lambda s: gather(id_tab, 2 * s + half_of), self._bias(bias, HT))
                 h = np.concatenate([acc[ot] for ot in range(HT)], axis=1)  # [64][16*HT]
+
+                def from_regs(words, n_ot, inp, bias):
+                    if self.bf16:
+                        return self._dense16(words[: n_ot * 2 * HT * 512], n_ot, 2 * HT,
+                                             lambda s: inp[:, 8 * s : 8 * s + 8], self._bias(bias, n_ot))
+                    return self._dense(words.view(np.float32)[: n_ot * 16 * HT * 64], n_ot, 16 * HT,
+                                       lambda s: inp[:, s], self._bias(bias, n_ot))
 
                 def hidden(inp):
                     nonlocal stage
-                    st = self._stage_words(inverse, stage).view(np.float32)
+                    st = self._stage_words(inverse, stage)
                     stage += 1
-                    bias = st[: 32 * HT]
-                    w = st[32 * HT : 32 * HT + HT * 16 * HT * 64]
-                    acc = self._dense(w, HT, 16 * HT, lambda s: inp[:, s], self._bias(bias, HT))
+                    bias = st.view(np.float32)[: 32 * HT]
+                    acc = from_regs(st[32 * HT :], HT, inp, bias)
                     return np.concatenate([acc[ot] for ot in range(HT)], axis=1)
 
                 if self.net == 0:
@@ -140,8 +189,7 @@ class Emulator:
                     tr_tab = st[:tabw].view(np.int32)
                     fl = st.view(np.float32)
                     bias = fl[tabw : tabw + 32 * self.C]
-                    w = fl[tabw + 32 * self.C : tabw + 32 * self.C + self.C * 16 * HT * 64]
-                    acc = self._dense(w, self.C, 16 * HT, lambda s: h[:, s], self._bias(bias, self.C))
+                    acc = from_regs(st[tabw + 32 * self.C :], self.C, h, bias)
                     v = np.concatenate([acc[t] for t in range(self.C)], axis=1)  # [64][16*C]
                     for q in range(self.FPC):
                         cols = tr_tab[half_of * self.FPC + q]
@@ -158,19 +206,25 @@ class Emulator:
                 n_steps, n_ot = int(op[1]), int(op[2])
                 st = self._stage_words(inverse, stage)
                 stage += 1
-                in_tab = st[: 2 * n_steps].view(np.int32)
+                tl = (16 if self.bf16 else 2) * n_steps
+                in_tab = st[:tl].view(np.int32)
                 fl = st.view(np.float32)
-                pre = fl[2 * n_steps : 4 * n_steps]
-                bias = fl[4 * n_steps : 4 * n_steps + 32 * n_ot]
-                w = fl[4 * n_steps + 32 * n_ot : 4 * n_steps + 32 * n_ot + n_ot * n_steps * 64]
+                pre = fl[tl : 2 * tl]
+                bias = fl[2 * tl : 2 * tl + 32 * n_ot]
 
-                def bd(s):
-                    idx = 2 * s + half_of
+                def gather_d(idx):
                     cols = in_tab[idx]
-                    vals = xt[row_of, np.maximum(cols, 0)] - pre[idx]
+                    vals = xt[row_of[:, None] if idx.ndim == 2 else row_of, np.maximum(cols, 0)] - pre[idx]
                     return np.where(cols >= 0, vals, 0.0).astype(np.float32)
 
-                acc = self._dense(w, n_ot, n_steps, bd, self._bias(bias, n_ot))
+                if self.bf16:
+                    w = st[2 * tl + 32 * n_ot : 2 * tl + 32 * n_ot + n_ot * n_steps * 512]
+                    acc = self._dense16(w, n_ot, n_steps,
+                                        lambda s: gather_d(16 * s + 8 * half_of[:, None] + np.arange(8)[None, :]),
+                                        self._bias(bias, n_ot))
+                else:
+                    w = fl[2 * tl + 32 * n_ot : 2 * tl + 32 * n_ot + n_ot * n_steps * 64]
+                    acc = self._dense(w, n_ot, n_steps, lambda s: gather_d(2 * s + half_of), self._bias(bias, n_ot))
                 new = xt.copy()
                 for ot in range(n_ot):
                     for lane in range(64):

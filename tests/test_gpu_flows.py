@@ -42,10 +42,13 @@ CONFIGS = {
 }
 
 
-@pytest.fixture(params=sorted(CONFIGS))
+@pytest.fixture(params=[(name, prec) for name in sorted(CONFIGS) for prec in ("bf16x3", "f32")],
+                ids=lambda p: f"{p[0]}-{p[1]}")
 def pair(request):
-    P, Oc, args, kw = CONFIGS[request.param]
+    name, precision = request.param
+    P, Oc, args, kw = CONFIGS[name]
     ref, flow = make_pair(P, Oc, args, kw)
+    flow.precision = precision
     return ref, flow, args[0]
 
 
@@ -193,6 +196,18 @@ def test_configure_model_factory():
     assert isinstance(flow, Custom)
     with pytest.raises(RuntimeError, match="Must specify either 'flow' or 'ftype'"):
         configure_model(dict(n_inputs=4, n_neurons=8, n_blocks=2, n_layers=2))
+
+
+def test_default_precision_is_split_bf16_on_the_matrix_cores():
+    from nessai_amd import pack
+
+    _, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2))
+    assert flow.precision == "bf16x3"
+    header, _ = flow.device_image()
+    assert header[pack.H_PREC] == pack.PRECISIONS["bf16x3"]
+    flow.precision = "f32"
+    header, _ = flow.device_image()
+    assert header[pack.H_PREC] == pack.PRECISIONS["f32"]
 
 
 def test_full_size_properties_c3():

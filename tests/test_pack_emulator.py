@@ -42,15 +42,16 @@ def test_mfma_emulation_matches_matmul():
             assert abs(d[lane, r] - ref[i, lane & 31]) < 1e-6
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("name", sorted(CONFIGS))
-def test_emulated_kernel_matches_oracle(name):
+def test_emulated_kernel_matches_oracle(name, precision):
     cls, args, kw = CONFIGS[name]
     torch.manual_seed(3)
     flow = cls(*args, **kw)
     randomise(flow, 3)
     flow.train()
     flow.eval()
-    em = Emulator(P.pack_flow(describe(flow)))
+    em = Emulator(P.pack_flow(dict(describe(flow), precision=precision)))
     n = 40 if args[0] >= 32 else 70
     x = torch.randn(n, args[0]) * 2.5
     with torch.no_grad():
@@ -59,10 +60,11 @@ def test_emulated_kernel_matches_oracle(name):
     ze, lde = em.run(x.numpy(), False)
     xe, ldie = em.run(x.numpy(), True)
     scale = max(1.0, float(xi.abs().max()))
-    assert np.abs(ze - z.numpy()).max() < 5e-5
-    assert np.abs(lde - ld.numpy()).max() < 1e-4
-    assert np.abs(xe - xi.numpy()).max() < 5e-5 * scale
-    assert np.abs(ldie - ldi.numpy()).max() < 1e-4
+    tol = 1.0 if precision == "f32" else 10.0  # split-bf16 products carry ~2^-16 relative error
+    assert np.abs(ze - z.numpy()).max() < 5e-5 * tol
+    assert np.abs(lde - ld.numpy()).max() < 1e-4 * tol
+    assert np.abs(xe - xi.numpy()).max() < 5e-5 * scale * tol
+    assert np.abs(ldie - ldi.numpy()).max() < 1e-4 * tol
 
 
 def test_product_and_oracle_trees_pack_identically():
@@ -89,6 +91,9 @@ def test_image_header_and_alignment():
     flow = O.NeuralSplineFlow(32, 64, 6, 2).eval()
     img = P.pack_flow(describe(flow))
     assert img[P.H_MAGIC] == P.MAGIC and img[P.H_VERSION] == P.VERSION
+    assert img[P.H_PREC] == 0
+    img16 = P.pack_flow(dict(describe(flow), precision="bf16x3"))
+    assert img16[P.H_PREC] == 1 and img16[P.H_MAX_STAGE] == img[P.H_MAX_STAGE]
     assert img[P.H_D] == 32 and img[P.H_HT] == 2 and img[P.H_BINS] == 8
     assert img[P.H_TOTAL] == len(img)
     assert img[P.H_MAX_STAGE] % 256 == 0
