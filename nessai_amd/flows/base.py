@@ -79,11 +79,25 @@ class BaseFlow(Module, ABC):
 MODE_APPLY, MODE_LOGPROB = 0, 1
 DIR_FORWARD, DIR_INVERSE = 0, 1
 
-#: arithmetic of the conditioner GEMMs (see ``nsa_format.h``): ``"bf16x3"`` = split-bf16
-#: operands on the bf16 matrix cores with float32 accumulation (default), ``"f32"`` = exact
-#: float32 products.  Override per flow (``flow.precision = ...``) or with the environment
-#: variable ``NESSAI_AMD_PRECISION``.
-DEFAULT_PRECISION = os.environ.get("NESSAI_AMD_PRECISION", "bf16x3")
+#: Arithmetic of the conditioner GEMMs (see ``nsa_format.h``).
+#: ``"f32"`` (default): exact float32 products on ``v_mfma_f32_32x32x2_f32`` - meets the
+#: 1e-5 relative ``log_prob`` parity bar for every configuration.
+#: ``"bf16x3"``: operands split ``x = hi + lo`` into two bf16, products ``hi*hi + hi*lo + lo*hi``
+#: on the bf16 matrix cores with float32 accumulation - 2x faster; measured ``log_prob`` error
+#: 1e-6..7e-5 relative depending on the flow (within the bar for the spline flows of the
+#: benchmark configs, outside it for small or affine flows; table in DESIGN.md).
+#: Override per flow (``flow.precision = ...``) or with ``NESSAI_AMD_PRECISION``.
+DEFAULT_PRECISION = os.environ.get("NESSAI_AMD_PRECISION", "f32")
+
+
+def populate_precision(flow):
+    """Precision the fused populate kernel uses when the proposal asks for ``"auto"``:
+    split-bf16 inside its validated envelope (rational-quadratic flows with >= 30 hidden
+    units - configs 3, 4 and 5: <= 3.3e-6 relative), exact float32 otherwise."""
+    desc = M.describe(flow)
+    if desc["transform"] == "rq" and desc["hidden"] >= 30:
+        return "bf16x3"
+    return "f32"
 
 
 class HipFlow(BaseFlow):

@@ -63,6 +63,11 @@ class FlowProposal:
     shard : bool
         When ``torch.distributed`` is initialised, split every draw batch over
         the ranks (one all-reduce(max) + one all-gather per pass).
+    precision : {'auto', 'f32', 'bf16x3'}
+        Arithmetic of the conditioner GEMMs inside the fused draw kernel.
+        ``'auto'`` uses split-bf16 on the bf16 matrix cores where it is validated
+        to stay within the 1e-5 relative parity bar (see
+        ``nessai_amd.flows.base.populate_precision``) and exact float32 elsewhere.
     """
 
     _FlowModelClass = FlowModel
@@ -89,6 +94,7 @@ class FlowProposal:
         device_seed=None,
         prior="auto",
         shard=False,
+        precision="auto",
         plot=False,
         **kwargs,
     ):
@@ -127,6 +133,9 @@ class FlowProposal:
             raise ValueError("prior must be 'auto', 'device' or 'host'")
         self._prior_mode = prior
         self.shard = shard
+        if precision not in ("auto", "f32", "bf16x3"):
+            raise ValueError("precision must be 'auto', 'f32' or 'bf16x3'")
+        self.precision = precision
         self.device_seed = (
             int(device_seed) if device_seed is not None else int(self.rng.integers(0, 2**63 - 1))
         )
@@ -319,8 +328,13 @@ class FlowProposal:
     # -- device plumbing --------------------------------------------------------------
 
     def _launch_draw(self, n, z_in, row_offset, radius, x64, log_q, z_out):
+        from .flows.base import populate_precision
+
         flow = self.flow.model
         flow.eval()
+        wanted = populate_precision(flow) if self.precision == "auto" else self.precision
+        if flow.precision != wanted:
+            flow.precision = wanted
         header, image = flow.device_image()
         status = flow._status
         status.zero_()
