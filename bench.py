@@ -35,7 +35,8 @@ DIMS = 32
 NLIVE = 2000
 DRAWSIZE = 1_000_000
 FLOPS_PER_ROW = 491_520          # conditioner GEMM FLOPs per proposed row
-PEAK_F32_MFMA_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"f32": 157.3,     # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
+               "bf16x3": 2500.0}  # v_mfma_f32_32x32x16_bf16 dense peak
 FLOW_CONFIG = dict(ftype="nsf", n_neurons=64, n_blocks=6, n_layers=2, num_bins=8)
 
 
@@ -69,10 +70,20 @@ def build_proposal(rank, world, device):
     return prop
 
 
-def time_draw_kernel(prop, launches=10):
+def time_draw_kernel(prop, launches=10, precision=None):
     """Average duration of the dominant kernel (fused draw+inverse-flow), HIP events
     on the stream it is launched on (torch's current stream)."""
     n = DRAWSIZE
+    keep = prop.precision
+    if precision is not None:
+        prop.precision = precision
+    try:
+        return _time_draw_kernel(prop, n, launches)
+    finally:
+        prop.precision = keep
+
+
+def _time_draw_kernel(prop, n, launches):
     buf = prop._get_buffers(n, NLIVE)
     for _ in range(2):
         prop._launch_draw(n, None, 0, prop.fixed_radius, buf["x64"], buf["log_q"], None)
@@ -182,7 +193,10 @@ def main():
         elapsed = float(t.item())
 
     kernel_ms, kernel_ms_min = time_draw_kernel(prop)
+    precision = prop.flow.model.precision  # what populate() actually ran
     achieved = FLOPS_PER_ROW * DRAWSIZE / (kernel_ms * 1e-3) / 1e12
+    f32_ms, _ = time_draw_kernel(prop, precision="f32")
+    f32_achieved = FLOPS_PER_ROW * DRAWSIZE / (f32_ms * 1e-3) / 1e12
 
     if rank == 0:
         out = {
@@ -196,7 +210,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16x3 (split-bf16 operands on bf16 MFMA, f32 accumulate)" if precision == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {
                 "workload": "32-D Rosenbrock, NeuralSplineFlow (8 RQ bins, 6 coupling layers, "
@@ -210,17 +224,29 @@ def main():
             "acceptance": accepted / proposed,
             "passes_per_step": proposed / (DRAWSIZE * world) / args.steps,
             "roofline": {
-                "kernel": "nsa_flow_kernel<2, NsaRQ<8>> (fused draw + inverse flow + rescale + bounds + log_q)",
+                "kernel": f"nsa_flow_kernel<2, NsaRQ<8>, inverse, {precision}> "
+                          "(fused draw + inverse flow + rescale + bounds + log_q)",
                 "bound": "mfma",
                 "achieved": achieved,
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": PEAK_TFLOPS[precision],
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None,
+                "frac": achieved / PEAK_TFLOPS[precision],
+                "traffic": 264.0e6,  # bytes per launch: WRITE_SIZE 257 816 KB (profiles/), reads ~10 MB (L2-resident weights)
                 "kernel_ms_avg": kernel_ms,
                 "kernel_ms_min": kernel_ms_min,
                 "rows_per_launch": DRAWSIZE,
                 "flops_per_row": FLOPS_PER_ROW,
+                "note": "algorithmic FLOPs (one product per weight); the split-bf16 mode issues 3 bf16 MFMAs "
+                        "per product and is bound by the spline's VALU/transcendental work, not by the matrix pipe",
+            },
+            "roofline_f32_mode": {
+                "kernel": "nsa_flow_kernel<2, NsaRQ<8>, inverse, f32> (exact float32 products)",
+                "bound": "mfma",
+                "achieved": f32_achieved,
+                "peak": PEAK_TFLOPS["f32"],
+                "unit": "TFLOP/s",
+                "frac": f32_achieved / PEAK_TFLOPS["f32"],
+                "kernel_ms_avg": f32_ms,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

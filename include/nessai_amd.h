@@ -155,20 +155,23 @@ NSA_API int nsa_populate_accept(long long n, int D, const double* log_w_dev, con
  *               min_derivative, boundary derivative, 1/sqrt(hidden), 1/var, log_z}
  *   params/grads/adam_m/adam_v   flat float32 buffers (n trainable floats)
  *   x_dev       [n][D] float32 minibatch;  step = 1-based optimiser step count
+ *   weights_dev [n] float32 sample weights for the weighted loss
+ *               -sum(w log_prob) / sum(w) (flowmodel/base.py:404-407), or NULL
  *   loss_acc_dev  float[1], the minibatch loss is ADDED (read once per epoch)
  */
 NSA_API size_t nsa_train_workspace_floats(const long long* plan, long long n);
 NSA_API int nsa_train_step(const long long* plan, const int* tables_dev, const float* consts,
                            float* params_dev, float* grads_dev, float* adam_m_dev, float* adam_v_dev,
-                           const float* x_dev, long long n, float* workspace_dev, float lr, float beta1,
-                           float beta2, float eps, float weight_decay, float clip_norm, long long step,
-                           float* loss_acc_dev, void* stream);
+                           const float* x_dev, const float* weights_dev, long long n,
+                           float* workspace_dev, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, float clip_norm, long long step, float* loss_acc_dev,
+                           void* stream);
 /* Forward only (FlowModel._validate, flowmodel/base.py:454-523):
  * loss_acc_dev[0] += -mean(log_prob(x)); log_prob_out_dev [n] may be NULL. */
 NSA_API int nsa_train_eval(const long long* plan, const int* tables_dev, const float* consts,
-                           const float* params_dev, const float* x_dev, long long n,
-                           float* workspace_dev, float* loss_acc_dev, float* log_prob_out_dev,
-                           void* stream);
+                           const float* params_dev, const float* x_dev, const float* weights_dev,
+                           long long n, float* workspace_dev, float* loss_acc_dev,
+                           float* log_prob_out_dev, void* stream);
 
 #ifdef __cplusplus
 }

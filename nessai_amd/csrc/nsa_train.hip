@@ -235,11 +235,13 @@ __global__ void tr_rq_forward(int n, int d_tr, const int* __restrict__ tr_cols, 
 template <int K>
 __global__ void tr_rq_backward(int n, int d_tr, const int* __restrict__ tr_cols, const float* __restrict__ P,
                                const float* __restrict__ xsave, float* __restrict__ X, int ldx,
-                               float* __restrict__ Gx, float gld, float* __restrict__ GP, TrConsts c) {
+                               float* __restrict__ Gx, const float* __restrict__ gld_rows,
+                               float* __restrict__ GP, TrConsts c) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * d_tr) return;
   const int row = t / d_tr, m = t - row * d_tr;
   constexpr int NP = 3 * K - 1;
+  const float gld = gld_rows[row];
   const int col = tr_cols[m];
   const float x = xsave[t];
   const float gy = Gx[(long long)row * ldx + col];
@@ -402,11 +404,12 @@ __global__ void tr_affine_forward(int n, int d_tr, int additive, const int* __re
 
 __global__ void tr_affine_backward(int n, int d_tr, int additive, const int* __restrict__ tr_cols,
                                    const float* __restrict__ P, const float* __restrict__ xsave,
-                                   float* __restrict__ X, int ldx, float* __restrict__ Gx, float gld,
-                                   float* __restrict__ GP) {
+                                   float* __restrict__ X, int ldx, float* __restrict__ Gx,
+                                   const float* __restrict__ gld_rows, float* __restrict__ GP) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * d_tr) return;
   const int row = t / d_tr, m = t - row * d_tr;
+  const float gld = gld_rows[row];
   const int np = additive ? d_tr : 2 * d_tr;
   const int col = tr_cols[m];
   const float x = xsave[t];
@@ -598,25 +601,41 @@ __global__ void tr_lu_grads(int D, const float* __restrict__ gL, const float* __
 // loss, gradient seed, gradient norm, AdamW
 // ---------------------------------------------------------------------------
 
-// per row: log_prob = -0.5/var * sum z^2 - log_z + logdet;  Gx = z / (var * n)
-// loss_acc[0] += -sum(log_prob) / n   (one workgroup, fixed summation order)
+// per row: log_prob = -0.5/var * sum z^2 - log_z + logdet
+// loss = -sum_i w_i log_prob_i / sum_i w_i   (w_i = 1 when `weights` is NULL: -mean(log_prob),
+// flowmodel/base.py:404-412); seeds the backward pass: Gx = z * w_i / (var * W),
+// gld_rows[i] = d loss / d logdet_i = -w_i / W.  One workgroup, fixed summation order.
 __global__ void __launch_bounds__(256) tr_loss(int n, int D, const float* __restrict__ X, int ldx,
                                                const float* __restrict__ logdet,
-                                               const float* __restrict__ ld_const, float inv_var, float log_z,
-                                               float* __restrict__ Gx, float* __restrict__ loss_acc,
+                                               const float* __restrict__ ld_const,
+                                               const float* __restrict__ weights, float inv_var, float log_z,
+                                               float* __restrict__ Gx, float* __restrict__ gld_rows,
+                                               float* __restrict__ loss_acc,
                                                float* __restrict__ log_prob_out, int want_grad) {
   __shared__ float sm[256];
+  float wsum = 0.0f;
+  for (int row = threadIdx.x; row < n; row += 256) wsum += weights ? weights[row] : 1.0f;
+  sm[threadIdx.x] = wsum;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  const float W = sm[0];
+  __syncthreads();
   float local = 0.0f;
   for (int row = threadIdx.x; row < n; row += 256) {
+    const float wi = (weights ? weights[row] : 1.0f) / W;
     float e = 0.0f;
     for (int c = 0; c < D; ++c) {
       const float z = X[(long long)row * ldx + c];
       e += z * z;
-      if (want_grad) Gx[(long long)row * ldx + c] = z * inv_var / (float)n;
+      if (want_grad) Gx[(long long)row * ldx + c] = z * inv_var * wi;
     }
+    if (want_grad) gld_rows[row] = -wi;
     const float lp = -0.5f * inv_var * e - log_z + (logdet[row] + ld_const[0]);
     if (log_prob_out) log_prob_out[row] = lp;
-    local += lp;
+    local += lp * wi;
   }
   sm[threadIdx.x] = local;
   __syncthreads();
@@ -624,7 +643,7 @@ __global__ void __launch_bounds__(256) tr_loss(int n, int D, const float* __rest
     if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) loss_acc[0] += -sm[0] / (float)n;
+  if (threadIdx.x == 0) loss_acc[0] += -sm[0];
 }
 
 // sum of squares of the flat gradient (one workgroup => deterministic)
@@ -694,7 +713,7 @@ static inline float tr_bits(long long v) {
 
 struct TrWs {  // workspace carve (floats)
   float *scal;      // [0] grad sq-norm, [1] constant log|det J| of the pass
-  float *x, *gx, *logdet, *gp, *gh, *gu;
+  float *x, *gx, *logdet, *gld, *gp, *gh, *gu;
   float* layer_base;
   long long per_layer;
   long long xsave_words;  // n * max(d_tr): size of a coupling layer's saved-input block
@@ -718,7 +737,7 @@ extern "C" NSA_API size_t nsa_train_workspace_floats(const long long* plan, long
   long long d_tr_max, np_max, per_layer;
   tr_sizes(plan, n, d_tr_max, np_max, per_layer);
   const long long D = plan[0], H = plan[1], NL = plan[3];
-  return (size_t)(64 + 2 * n * D + n + n * np_max + 2 * n * H + NL * per_layer);
+  return (size_t)(64 + 2 * n * D + 2 * n + n * np_max + 2 * n * H + NL * per_layer);
 }
 
 static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
@@ -730,6 +749,7 @@ static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
   w.x = p; p += n * D;
   w.gx = p; p += n * D;
   w.logdet = p; p += n;
+  w.gld = p; p += n;
   w.gp = p; p += n * np_max;
   w.gh = p; p += n * H;
   w.gu = p; p += n * H;
@@ -846,7 +866,6 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
   const int transform = (int)plan[4], K = (int)plan[5], act = (int)plan[6], npf = (int)plan[7];
   const long long rec = plan[9];
   TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5]};
-  const float gld = -1.0f / (float)n;  // d loss / d (per-row log|det J|)
   for (int b = NL - 1; b >= 0; --b) {
     const long long* r = plan + TR_HDR + b * rec;
     float* lay = w.layer_base + b * w.per_layer;
@@ -862,10 +881,10 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       const int np = d_tr * npf;
       if (transform == NSA_T_RQ) {
         TR_SPLINE_DISPATCH(tr_rq_backward, K, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr, tr_cols, p,
-                           xsave, w.x, D, w.gx, gld, w.gp, c);
+                           xsave, w.x, D, w.gx, w.gld, w.gp, c);
       } else {
         hipLaunchKernelGGL(tr_affine_backward, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr,
-                           transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, xsave, w.x, D, w.gx, gld, w.gp);
+                           transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, xsave, w.x, D, w.gx, w.gld, w.gp);
       }
       // final layer: dWf, dbf, gh = gp . Wf
       float* hL = h + (long long)L * n * H;
@@ -925,8 +944,9 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
 // One minibatch: forward, loss, backward, clip, AdamW.  loss_acc_dev[0] += loss.
 extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_dev, const float* consts,
                                       float* params_dev, float* grads_dev, float* adam_m_dev,
-                                      float* adam_v_dev, const float* x_dev, long long n,
-                                      float* workspace_dev, float lr, float beta1, float beta2, float eps,
+                                      float* adam_v_dev, const float* x_dev, const float* weights_dev,
+                                      long long n, float* workspace_dev, float lr, float beta1, float beta2,
+                                      float eps,
                                       float weight_decay, float clip_norm, long long step,
                                       float* loss_acc_dev, void* stream) {
   if (!plan || !tables_dev || !params_dev || !grads_dev || !x_dev || !workspace_dev || !loss_acc_dev || n <= 1)
@@ -938,7 +958,7 @@ extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_d
   hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, x_dev, w.x);
   tr_forward(plan, tables_dev, params_dev, consts, n, w, 1, s);
   hipLaunchKernelGGL(tr_loss, dim3(1), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
-                     consts[6], consts[7], w.gx, loss_acc_dev, (float*)nullptr, 1);
+                     weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, (float*)nullptr, 1);
   tr_backward(plan, tables_dev, params_dev, grads_dev, consts, n, w, s);
   hipLaunchKernelGGL(tr_grad_sqnorm, dim3(1), dim3(1024), 0, s, n_params, grads_dev, w.scal);
   const float bc1 = 1.0f - powf(beta1, (float)step);
@@ -951,9 +971,9 @@ extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_d
 
 // Forward only, eval mode: loss_acc_dev[0] += -mean(log_prob(x)); optional per-row log_prob.
 extern "C" NSA_API int nsa_train_eval(const long long* plan, const int* tables_dev, const float* consts,
-                                      const float* params_dev, const float* x_dev, long long n,
-                                      float* workspace_dev, float* loss_acc_dev, float* log_prob_out_dev,
-                                      void* stream) {
+                                      const float* params_dev, const float* x_dev, const float* weights_dev,
+                                      long long n, float* workspace_dev, float* loss_acc_dev,
+                                      float* log_prob_out_dev, void* stream) {
   if (!plan || !tables_dev || !params_dev || !x_dev || !workspace_dev || !loss_acc_dev || n <= 0)
     return NSA_E_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -963,7 +983,7 @@ extern "C" NSA_API int nsa_train_eval(const long long* plan, const int* tables_d
   hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, x_dev, w.x);
   tr_forward(plan, tables_dev, const_cast<float*>(params_dev), consts, n, w, 0, s);
   hipLaunchKernelGGL(tr_loss, dim3(1), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
-                     consts[6], consts[7], w.gx, loss_acc_dev, log_prob_out_dev, 0);
+                     weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, log_prob_out_dev, 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? NSA_OK : NSA_E_HIP;
 }

@@ -177,14 +177,20 @@ class FlowModel:
 
     # -- training --------------------------------------------------------------
 
-    def prep_data(self, samples, val_size, batch_size):
-        """Shuffle, split train/validation, fix the batch size (``base.py:238-352``)."""
+    def prep_data(self, samples, val_size, batch_size, weights=None):
+        """Shuffle, split train/validation, fix the batch size (``base.py:238-352``).
+
+        With ``weights`` returns ``((x_train, w_train), (x_val, w_val), batch_size)``."""
         if not self.initialised:
             self.initialise()
         if not np.isfinite(samples).all():
             raise ValueError("Cannot train with non-finite samples!")
         idx = self.rng.permutation(samples.shape[0])
         samples = samples[idx]
+        if weights is not None:
+            if not np.isfinite(weights).all():
+                raise ValueError("Weights contain non-finite values!")
+            weights = np.asarray(weights, dtype=np.float64)[idx]
         if val_size is None:
             val_size = 0
         n = int((1 - val_size) * samples.shape[0])
@@ -196,6 +202,12 @@ class FlowModel:
                 raise RuntimeError(f"Unknown batch size: {batch_size}")
         batch_size = self.check_batch_size(x_train, batch_size)
         self._batch_size = batch_size
+        if weights is not None:
+            return (
+                (self.numpy_array_to_tensor(x_train), self.numpy_array_to_tensor(weights[:n])),
+                (self.numpy_array_to_tensor(x_val), self.numpy_array_to_tensor(weights[n:])),
+                batch_size,
+            )
         return (
             self.numpy_array_to_tensor(x_train),
             self.numpy_array_to_tensor(x_val),
@@ -216,15 +228,16 @@ class FlowModel:
             self.initialise()
         if not np.isfinite(samples).all():
             raise ValueError("Training data is not finite")
-        if weights is not None or conditional is not None:
-            raise NotImplementedError("weighted / conditional training has no gfx950 kernel yet")
+        if conditional is not None:
+            raise NotImplementedError("conditional training has no gfx950 kernel yet")
         if output is None:
             output = self.output
         else:
             os.makedirs(output, exist_ok=True)
         if val_size is None:
             val_size = self.training_config["val_size"]
-        history = train_flow(self, samples, max_epochs=max_epochs, patience=patience, val_size=val_size)
+        history = train_flow(self, samples, max_epochs=max_epochs, patience=patience, val_size=val_size,
+                             weights=weights)
         current_weights_file = os.path.join(output, "model.pt")
         self.save_weights(current_weights_file)
         self.model.eval()

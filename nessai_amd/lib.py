@@ -40,11 +40,12 @@ SIGNATURES = {
     "nsa_train_workspace_floats": (c_size_t, [c_void_p, c_ll]),
     "nsa_train_step": (
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p,
-         c_float, c_float, c_float, c_float, c_float, c_float, c_ll, c_void_p, c_void_p],
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll,
+         c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_ll, c_void_p, c_void_p],
     ),
     "nsa_train_eval": (
-        c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p],
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "nsa_populate_accept": (
         c_int,

@@ -146,26 +146,29 @@ class Trainer:
             self._ws_rows = n
         return self._ws
 
-    def step(self, x, clip_norm=5.0, lr=None):
-        """One optimiser step on a ``(n, D)`` float32 device batch; the loss is added to ``loss_acc``."""
+    def step(self, x, clip_norm=5.0, lr=None, weights=None):
+        """One optimiser step on a ``(n, D)`` float32 device batch; the loss is added to ``loss_acc``.
+
+        ``weights`` (``(n,)`` float32 device tensor) selects the weighted loss
+        ``-sum(w log_prob) / sum(w)`` (``flowmodel/base.py:404-407``)."""
         self.step_count += 1
         ws = self._workspace(x.shape[0])
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = lib.load().nsa_train_step(
             self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(self.grads),
-            lib.ptr(self.adam_m), lib.ptr(self.adam_v), lib.ptr(x), x.shape[0], lib.ptr(ws),
+            lib.ptr(self.adam_m), lib.ptr(self.adam_v), lib.ptr(x), lib.ptr(weights), x.shape[0], lib.ptr(ws),
             self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
             float(clip_norm or 0.0), self.step_count, lib.ptr(self.loss_acc), lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_train_step")
 
-    def evaluate(self, x, log_prob_out=None):
+    def evaluate(self, x, log_prob_out=None, weights=None):
         """``loss_acc += -mean(log_prob(x))`` without touching the weights."""
         ws = self._workspace(x.shape[0])
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = lib.load().nsa_train_eval(
-            self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(x), x.shape[0],
-            lib.ptr(ws), lib.ptr(self.loss_acc), lib.ptr(log_prob_out), lib.c_void_p(stream),
+            self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(x), lib.ptr(weights),
+            x.shape[0], lib.ptr(ws), lib.ptr(self.loss_acc), lib.ptr(log_prob_out), lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_train_eval")
 
@@ -188,7 +191,7 @@ def get_trainer(flow_model):
     return flow_model._trainer
 
 
-def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=None):
+def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=None, weights=None):
     tc = flow_model.training_config
     if tc.get("annealing"):
         raise NotImplementedError("cosine annealing has no gfx950 kernel yet")
@@ -198,8 +201,11 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
     model = flow_model.model
     validate = val_size != 0.0
     train_data, val_data, batch_size = flow_model.prep_data(
-        samples, val_size=val_size, batch_size=tc["batch_size"]
+        samples, val_size=val_size, batch_size=tc["batch_size"], weights=weights
     )
+    w_train = w_val = None
+    if weights is not None:
+        (train_data, w_train), (val_data, w_val) = train_data, val_data
     if max_epochs is None:
         max_epochs = tc["max_epochs"]
     if patience is None:
@@ -212,13 +218,14 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
     for epoch in range(1, max_epochs + 1):
         p = torch.randperm(train_data.shape[0]).to(train_data.device)
         batches = train_data[p, :].split(batch_size)
+        w_batches = w_train[p].split(batch_size) if w_train is not None else [None] * len(batches)
         trainer.loss_acc.zero_()
-        for x in batches:
-            trainer.step(x.contiguous(), clip_norm=clip)
+        for x, w in zip(batches, w_batches):
+            trainer.step(x.contiguous(), clip_norm=clip, weights=None if w is None else w.contiguous())
         if validate and len(val_data):
             val_acc = torch.zeros_like(trainer.loss_acc)
             keep, trainer.loss_acc = trainer.loss_acc, val_acc
-            trainer.evaluate(val_data)
+            trainer.evaluate(val_data, weights=w_val)
             trainer.loss_acc = keep
             both = torch.cat([trainer.loss_acc, val_acc]).cpu().numpy()  # the epoch's one sync
             loss, val_loss = float(both[0]) / len(batches), float(both[1])

@@ -157,6 +157,51 @@ def test_flowmodel_train_end_to_end(tmp_path):
     del x_val
 
 
+def test_weighted_loss_and_gradients_match_autograd():
+    """Weighted KL of the importance sampler: -sum(w log_prob) / sum(w) (flowmodel/base.py:404-407)."""
+    ref, flow, D = pair("nsf_d4")
+    x = torch.randn(200, D)
+    w = torch.rand(200) + 0.1
+    ref.train()
+    loss_ref = -torch.sum(ref.log_prob(x) * w) / torch.sum(w)
+    loss_ref.backward()
+    g_ref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    tr = Trainer(flow)
+    tr.step(x.to(DEV), clip_norm=5.0, lr=0.0, weights=w.to(DEV))
+    torch.cuda.synchronize()
+    assert abs(tr.loss_acc.item() - loss_ref.item()) <= 1e-5 * max(1.0, abs(loss_ref.item()))
+    g = tr.grads.cpu()
+    assert float((g - g_ref).abs().max()) <= 2e-4 * max(1e-3, float(g_ref.abs().max()))
+
+
+def test_importance_flow_model(tmp_path):
+    """ImportanceFlowModel: add flows, log_prob_all == per-flow log_prob, sample_ith, weighted train."""
+    from nessai_amd.flowmodel_importance import ImportanceFlowModel
+
+    rng = np.random.default_rng(1)
+    torch.manual_seed(1)
+    ifm = ImportanceFlowModel(
+        flow_config=dict(n_inputs=3, n_neurons=8, n_blocks=2, n_layers=1, ftype="nsf"),
+        training_config=dict(batch_size=100, max_epochs=5, patience=5), output=str(tmp_path), rng=rng,
+    )
+    assert ifm.model is None and ifm.n_models == 0
+    ifm.add_new_flow()
+    data = rng.normal(size=(300, 3))
+    hist = ifm.train(data, weights=rng.uniform(0.5, 1.5, size=300))
+    assert len(hist["loss"]) >= 1 and np.isfinite(hist["loss"]).all()
+    ifm.add_new_flow()  # copy of the previous level
+    ifm.add_new_flow(reset=True)
+    assert ifm.n_models == 3
+    x = rng.normal(size=(50, 3))
+    all_lp = ifm.log_prob_all(x)
+    assert all_lp.shape == (50, 3)
+    for i in range(3):
+        np.testing.assert_allclose(all_lp[:, i], ifm.log_prob_ith(x, i), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(all_lp[:, 0], all_lp[:, 1], rtol=0, atol=1e-6)  # level 1 copied level 0
+    assert ifm.sample_ith(2, 7).shape == (7, 3)
+    assert len(ifm.weights_files) == 1
+
+
 def test_batch_norm_running_statistics_follow_the_reference():
     """Training-mode batch norm updates running_mean / running_var with momentum 0.1 and the
     unbiased batch variance, exactly as the oracle's transform does."""
