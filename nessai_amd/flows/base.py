@@ -94,8 +94,7 @@ def populate_precision(flow):
     """Precision the fused populate kernel uses when the proposal asks for ``"auto"``:
     split-bf16 inside its validated envelope (rational-quadratic flows with >= 30 hidden
     units - configs 3, 4 and 5: <= 3.3e-6 relative), exact float32 otherwise."""
-    desc = M.describe(flow)
-    if desc["transform"] == "rq" and desc["hidden"] >= 30:
+    if flow.transform_kind == "rq" and flow.hidden_features >= 30:
         return "bf16x3"
     return "f32"
 
@@ -131,6 +130,8 @@ class HipFlow(BaseFlow):
             raise ValueError(f"unknown precision {self.precision!r}; choose from {sorted(pack.PRECISIONS)}")
         desc = M.describe(self)
         self.features = desc["D"]
+        self.transform_kind = desc["transform"]
+        self.hidden_features = desc["hidden"]
         ht = pack.hidden_tiles(desc["hidden"])
         if ht > 4 or not lib_supports(ht, desc["transform"], desc.get("bins", 0)):
             raise ValueError(
