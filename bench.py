@@ -161,16 +161,23 @@ def main():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_shard = os.environ.get("NESSAI_AMD_FORCE_SHARD") == "1"  # exercise the RCCL path on 1 rank
+    if world > 1 or force_shard:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if force_shard and "RANK" not in os.environ:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     prop = build_proposal(rank, world, device)
+    if force_shard:
+        prop.shard = True
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_shard:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -253,7 +260,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_shard:
         torch.distributed.destroy_process_group()
 
 

@@ -446,7 +446,8 @@ class FlowProposal:
         n_samples = int(n_samples)
 
         world, rank = 1, 0
-        if self.shard and torch.distributed.is_available() and torch.distributed.is_initialized():
+        sharded = self.shard and torch.distributed.is_available() and torch.distributed.is_initialized()
+        if sharded:
             world = torch.distributed.get_world_size()
             rank = torch.distributed.get_rank()
 
@@ -470,13 +471,13 @@ class FlowProposal:
             row_offset = self._draw_counter + rank * n_local
             self._launch_draw(n_local, z_in, row_offset, threshold, buf["x64"], buf["log_q"], None)
             self._weights_and_max(buf, n_local)
-            if world > 1:
+            if sharded:
                 torch.distributed.all_reduce(buf["max_key"], op=torch.distributed.ReduceOp.MAX)
             self._accept(buf, n_local, n_samples, row_offset, u_in=u_in)
             n_acc_local = int(buf["n_acc"].item())  # the pass's only device->host sync
             m_local = min(n_acc_local, n_samples)
             block = buf["x_acc"][:m_local]
-            if world > 1:
+            if sharded:
                 n_acc_batch, block = _gather_accepted(block, n_acc_local, n_samples, self.dims)
             else:
                 n_acc_batch = n_acc_local

@@ -11,6 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (ROCm device)")
+    # the suites need the in-tree HIP library (hipcc cross-compiles without a GPU)
+    lib_path = os.path.join(ROOT, "nessai_amd", "libnessai_amd.so")
+    if not os.path.exists(lib_path):
+        import __graft_entry__
+
+        __graft_entry__.build()
 
 
 def pytest_collection_modifyitems(config, items):
