@@ -55,6 +55,36 @@ class Model:
     def batch_evaluate_log_likelihood(self, x):
         return np.asarray(self.log_likelihood(x), dtype=np.float64)
 
+    # -- unit hypercube (importance sampler; ``src/nessai/model.py:520-620``) ---------------
+
+    def in_unit_hypercube(self, x):
+        """True where every parameter is in [0, 1]."""
+        return ~np.any([(x[n] < 0.0) | (x[n] > 1.0) for n in self.names], axis=0)
+
+    def from_unit_hypercube(self, x):
+        """Unit hypercube -> physical space (uniform priors: an affine map)."""
+        if not self.uniform_prior:
+            raise NotImplementedError("from_unit_hypercube needs a user implementation")
+        out = x.copy()
+        for n in self.names:
+            lo, hi = self.bounds[n]
+            out[n] = lo + (hi - lo) * x[n]
+        return out
+
+    def to_unit_hypercube(self, x):
+        if not self.uniform_prior:
+            raise NotImplementedError("to_unit_hypercube needs a user implementation")
+        out = x.copy()
+        for n in self.names:
+            lo, hi = self.bounds[n]
+            out[n] = (x[n] - lo) / (hi - lo)
+        return out
+
+    def batch_evaluate_log_prior_unit_hypercube(self, x):
+        """Log-prior density in the unit hypercube: 0 inside, -inf outside."""
+        with np.errstate(divide="ignore"):
+            return np.log(self.in_unit_hypercube(x), dtype="float")
+
     def new_point(self, N=1, rng=None):
         """Draw from the prior box (uniform models)."""
         rng = rng if rng is not None else np.random.default_rng()

@@ -202,6 +202,35 @@ def test_importance_flow_model(tmp_path):
     assert len(ifm.weights_files) == 1
 
 
+def test_importance_flow_proposal_levels(tmp_path):
+    """Two levels of the importance sampler's proposal: train on weighted samples, draw, meta-proposal."""
+    from nessai_amd.model import GaussianModel
+    from nessai_amd.proposal_importance import ImportanceFlowProposal
+
+    rng = np.random.default_rng(2)
+    torch.manual_seed(2)
+    model = GaussianModel(3)
+    prop = ImportanceFlowProposal(
+        model, output=str(tmp_path), rng=rng,
+        flow_config=dict(n_neurons=8, n_blocks=2, n_layers=1, ftype="nsf"),
+        training_config=dict(batch_size=200, max_epochs=5, patience=5),
+    )
+    prop.initialise()
+    samples, log_q0 = prop.draw_from_prior(400)
+    assert log_q0.shape == (400, 1) and np.allclose(samples["logQ"], 0.0)
+    prop.train(samples)  # weighted KL with exp(logW)
+    prop.update_proposal_weights({-1: 0.5, 0: 0.5})
+    new, log_q = prop.draw(100)
+    assert new.size == 100 and log_q.shape == (100, 2)
+    assert model.in_unit_hypercube(new).all()
+    assert np.isfinite(new["logQ"]).all() and np.isfinite(new["logW"]).all()
+    old_q = prop.update_log_q(samples, log_q0)
+    assert old_q.shape == (400, 2)
+    np.testing.assert_allclose(prop.compute_meta_proposal_from_log_q(log_q), new["logQ"], rtol=1e-12)
+    prop.train(new)
+    assert prop.flow.n_models == 2 and prop.level_count == 1
+
+
 def test_batch_norm_running_statistics_follow_the_reference():
     """Training-mode batch norm updates running_mean / running_var with momentum 0.1 and the
     unbiased batch variance, exactly as the oracle's transform does."""

@@ -92,3 +92,45 @@ def test_flow_model_requires_rocm_device(tmp_path):
                    training_config=dict(device_tag="cpu"), output=str(tmp_path))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         fm.initialise()
+
+
+def test_importance_proposal_glue():
+    """logit / sigmoid maps, their Jacobians and the meta-proposal logsumexp
+    (src/nessai/proposal/importance.py:203-257, 382-441; utils/rescaling.py:290-336)."""
+    from scipy.special import logsumexp
+
+    from nessai_amd.proposal_importance import EPS, ImportanceFlowProposal, ins_dtype, logit, sigmoid
+
+    x = np.array([[0.25, 0.5], [1e-12, 1.0]])
+    xp, lj = logit(x, eps=EPS)
+    assert np.isfinite(xp).all()
+    np.testing.assert_allclose(xp[0], np.log(x[0] / (1 - x[0])))
+    np.testing.assert_allclose(lj[0], -np.log(x[0]) - np.log1p(-x[0]))
+    xb, ljb = sigmoid(xp)
+    np.testing.assert_allclose(xb[0], x[0])
+    np.testing.assert_allclose(ljb[0], -lj[0])
+    assert ins_dtype(["a"]).names == ("a", "logP", "logL", "it", "logQ", "logW", "logU")
+
+    class FakeFlows:
+        n_models = 2
+        models = []
+
+        def log_prob_all(self, x):
+            return np.stack([-np.sum(x**2, axis=1), -0.5 * np.sum(x**2, axis=1)], axis=1)
+
+    m = RosenbrockModel(2)
+    prop = ImportanceFlowProposal(m, output="/tmp")
+    prop.flow = FakeFlows()
+    prop._weights = {-1: 0.2, 0: 0.3, 1: 0.5}
+    xp = np.random.default_rng(0).normal(size=(7, 2))
+    lj = np.random.default_rng(1).normal(size=7)
+    log_Q, log_q = prop.compute_log_Q(xp, log_j=lj)
+    assert log_q.shape == (7, 3) and np.all(log_q[:, 0] == 0)
+    expect = logsumexp(np.concatenate([np.zeros((7, 1)), FakeFlows().log_prob_all(xp) + lj[:, None]], axis=1),
+                       b=np.array([0.2, 0.3, 0.5]), axis=1)
+    np.testing.assert_allclose(log_Q, expect)
+    with pytest.raises(RuntimeError, match="Weights must sum to 1"):
+        prop.update_proposal_weights({1: 0.9})
+    prop._weights[2] = np.nan
+    with pytest.raises(RuntimeError, match="Some weights are not set"):
+        prop.compute_log_Q(xp, log_j=lj)
