@@ -92,14 +92,22 @@ NSA_API int nsa_flow_run(const uint32_t* header, const void* image_dev, int dire
  *   log_q_out_dev [n] float64 log proposal density; NaN marks a dropped row
  *               (outside radius / non-finite / out of bounds / spline failure)
  *   z_out_dev   [n][D] float32 or NULL
+ *   prior_kind_dev / prior_par_dev / log_prior_out_dev   optional separable analytic prior
+ *               evaluated in float64 in the same pass (replaces the user's vectorised
+ *               Model.log_prior for the common bilby-style cases): per dimension a kind
+ *               (0 uniform, 1 sine, 2 cosine, 3 power law, 4 Gaussian) and three doubles
+ *               {a, b, log normalisation}; log_prior_out_dev [n] receives sum_i log p_i(x_i).
+ *               Pass NULL to skip (then give nsa_populate_weights a constant or a host-
+ *               evaluated per-row prior).
  */
 NSA_API int nsa_populate_draw(const uint32_t* header, const void* image_dev, long long n,
                       const float* z_in_dev, unsigned long long seed,
                       unsigned long long row_offset, double radius, const double* scale_dev,
                       const double* shift_dev, const double* lower_dev, const double* upper_dev,
                       double log_j_rescale, double* x64_out_dev, double* log_q_out_dev,
-                      float* z_out_dev, int* status_dev, int waves_per_group, int max_groups,
-                      void* stream);
+                      float* z_out_dev, const int* prior_kind_dev, const double* prior_par_dev,
+                      double* log_prior_out_dev, int* status_dev, int waves_per_group,
+                      int max_groups, void* stream);
 
 /* log_w = log_prior - log_q and its maximum.
  *

@@ -167,8 +167,9 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
                                  const double* scale_dev, const double* shift_dev,
                                  const double* lower_dev, const double* upper_dev,
                                  double log_j_rescale, double* x64_out_dev, double* log_q_out_dev,
-                                 float* z_out_dev, int* status_dev, int waves_per_group,
-                                 int max_groups, void* stream) {
+                                 float* z_out_dev, const int* prior_kind_dev,
+                                 const double* prior_par_dev, double* log_prior_out_dev,
+                                 int* status_dev, int waves_per_group, int max_groups, void* stream) {
   if (image_dev == nullptr || scale_dev == nullptr || shift_dev == nullptr || lower_dev == nullptr ||
       upper_dev == nullptr || x64_out_dev == nullptr || log_q_out_dev == nullptr || status_dev == nullptr)
     return nsa_fail(NSA_E_ARG, "nsa_populate_draw: NULL pointer argument");
@@ -191,6 +192,13 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
   p.x64_out = x64_out_dev;
   p.log_q_out = log_q_out_dev;
   p.z_out = z_out_dev;
+  if (prior_kind_dev != nullptr) {
+    if (prior_par_dev == nullptr || log_prior_out_dev == nullptr)
+      return nsa_fail(NSA_E_ARG, "nsa_populate_draw: prior parameters / output missing");
+    p.prior_kind = prior_kind_dev;
+    p.prior_par = prior_par_dev;
+    p.log_prior_out = log_prior_out_dev;
+  }
   return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
 }
 

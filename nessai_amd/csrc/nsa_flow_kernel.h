@@ -54,7 +54,26 @@ struct NsaLaunch {
   double* x64_out;                // [n][D]
   double* log_q_out;              // [n]; NaN marks a dropped row
   float* z_out;                   // [n][D] or null
+  // optional separable analytic prior evaluated in the epilogue (float64):
+  // log_prior = sum_i f_kind[i](x_i); kinds NSA_PRIOR_*, 3 doubles per dimension
+  const int* prior_kind;          // [D] or null
+  const double* prior_par;        // [D][3]
+  double* log_prior_out;          // [n]
 };
+
+enum { NSA_PRIOR_UNIFORM = 0, NSA_PRIOR_SINE = 1, NSA_PRIOR_COSINE = 2, NSA_PRIOR_POWER_LAW = 3,
+       NSA_PRIOR_GAUSSIAN = 4 };
+
+// log density of one separable prior term; par = {a, b, log normalisation}
+__device__ __forceinline__ double nsa_log_prior_term(int kind, double x, const double* par) {
+  switch (kind) {
+    case NSA_PRIOR_SINE: return log(sin(x)) + par[2];
+    case NSA_PRIOR_COSINE: return log(cos(x)) + par[2];
+    case NSA_PRIOR_POWER_LAW: return par[0] * log(x) + par[2];
+    case NSA_PRIOR_GAUSSIAN: { const double t = (x - par[0]) / par[1]; return -0.5 * t * t + par[2]; }
+    default: return par[2];  // uniform: -log(width)
+  }
+}
 
 // double-buffered weight-stage pipeline -------------------------------------
 
@@ -674,11 +693,17 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
       // (model.py:512-518), log_q = (log N(z) - log_j) - log_J
       // (flowproposal.py:356, 383)
       bool in_bounds = true;
+      double log_prior = 0.0;
       for (int i = half; i < D; i += 2) {
         const double xp = (double)xrow[out_tab[i]];
         const double xv = (xp * p.scale[i]) + p.shift[i];
         in_bounds = in_bounds && !((xv < p.lower[i]) || (xv > p.upper[i]));
         if (row_ok) p.x64_out[my_row * D + i] = xv;
+        if (p.prior_kind != nullptr) log_prior += nsa_log_prior_term(p.prior_kind[i], xv, p.prior_par + 3 * i);
+      }
+      if (p.prior_kind != nullptr) {
+        log_prior += __shfl_xor(log_prior, 32);
+        if (row_ok && half == 0) p.log_prior_out[my_row] = log_prior;
       }
       const int ib = in_bounds ? 1 : 0;
       const bool ok = (ib + __shfl_xor(ib, 32)) == 2;

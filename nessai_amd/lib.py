@@ -30,7 +30,8 @@ SIGNATURES = {
     "nsa_populate_draw": (
         c_int,
         [c_void_p, c_void_p, c_ll, c_void_p, c_ull, c_ull, c_double, c_void_p, c_void_p, c_void_p,
-         c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+         c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_int, c_int, c_void_p],
     ),
     "nsa_populate_weights": (c_int, [c_ll, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "nsa_max_key_init": (c_ll, []),

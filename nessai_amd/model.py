@@ -8,18 +8,77 @@ benchmark models of BASELINE.json's configs.
 
 A model whose prior is uniform inside its bounds can say so with
 ``uniform_prior = True``; the proposal then evaluates ``log_prior`` as a
-constant on the device instead of copying every candidate to the host.
+constant on the device instead of copying every candidate to the host.  A model
+with a *separable* analytic prior can declare it per parameter in
+``device_prior`` (``{"name": ("uniform",) | ("sine",) | ("cosine",) |
+("power_law", alpha) | ("gaussian", mu, sigma)}``, densities normalised on the
+parameter's bounds as bilby's priors are); the fused populate kernel then
+evaluates it in float64 in the same pass.
 """
+
+import math
 
 import numpy as np
 
 from .livepoint import live_points_to_array
 
 
+PRIOR_KINDS = {"uniform": 0, "sine": 1, "cosine": 2, "power_law": 3, "gaussian": 4}
+
+
+def prior_term(spec, lo, hi):
+    """(kind code, [a, b, log normalisation]) of one separable prior term on [lo, hi]."""
+    kind = spec[0]
+    if kind == "uniform":
+        return 0, [0.0, 0.0, -math.log(hi - lo)]
+    if kind == "sine":
+        return 1, [0.0, 0.0, -math.log(math.cos(lo) - math.cos(hi))]
+    if kind == "cosine":
+        return 2, [0.0, 0.0, -math.log(math.sin(hi) - math.sin(lo))]
+    if kind == "power_law":
+        alpha = float(spec[1])
+        if alpha == -1.0:
+            norm = math.log(hi / lo)
+        else:
+            norm = (hi ** (alpha + 1) - lo ** (alpha + 1)) / (alpha + 1)
+        return 3, [alpha, 0.0, -math.log(norm)]
+    if kind == "gaussian":
+        mu, sigma = float(spec[1]), float(spec[2])
+        return 4, [mu, sigma, -math.log(sigma * math.sqrt(2 * math.pi))]
+    raise ValueError(f"unknown device prior {kind!r}; choose from {sorted(PRIOR_KINDS)}")
+
+
+def log_prior_term(spec, x, lo, hi):
+    """numpy evaluation of the same term (host reference of the device formula)."""
+    kind, par = prior_term(spec, lo, hi)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if kind == 1:
+            return np.log(np.sin(x)) + par[2]
+        if kind == 2:
+            return np.log(np.cos(x)) + par[2]
+        if kind == 3:
+            return par[0] * np.log(x) + par[2]
+        if kind == 4:
+            return -0.5 * ((x - par[0]) / par[1]) ** 2 + par[2]
+        return np.full_like(np.asarray(x, dtype=np.float64), par[2])
+
+
 class Model:
     names = None
     bounds = None
     uniform_prior = False
+    device_prior = None
+
+    def device_prior_tables(self):
+        """(kinds int32 [D], params float64 [D][3]) or None when no device prior is declared."""
+        if self.device_prior is None:
+            return None
+        kinds, pars = [], []
+        for n in self.names:
+            k, par = prior_term(self.device_prior[n], *self.bounds[n])
+            kinds.append(k)
+            pars.append(par)
+        return np.asarray(kinds, dtype=np.int32), np.asarray(pars, dtype=np.float64)
 
     @property
     def dims(self):
@@ -133,3 +192,73 @@ class GaussianModel(UniformBoxModel):
     def log_likelihood(self, x):
         a = self.unstructured_view(x)
         return -0.5 * np.sum(a**2, axis=-1) - 0.5 * self.dims * np.log(2 * np.pi)
+
+
+class SeparablePriorModel(Model):
+    """Model whose prior is a product of the 1-D densities declared in ``device_prior``."""
+
+    def log_prior(self, x):
+        with np.errstate(divide="ignore"):
+            log_p = np.log(self.in_bounds(x), dtype="float")
+        for n in self.names:
+            log_p = log_p + log_prior_term(self.device_prior[n], x[n], *self.bounds[n])
+        return log_p
+
+
+class GWSurrogateModel(SeparablePriorModel):
+    """15-D analytic surrogate of a compact-binary likelihood (BASELINE.json config 5).
+
+    Gaussian log-likelihood around a fiducial binary in bilby-style parameters with
+    bilby-style priors: uniform (masses, phases, time), power-law luminosity distance,
+    sine inclinations/tilts, cosine declination.  A stand-in for the reference's GW examples
+    (``examples/gw/*.py``), whose bilby / lalsuite dependencies are not available.
+    """
+
+    def __init__(self):
+        spec = [
+            ("chirp_mass", (25.0, 35.0), ("uniform",), 30.0, 0.3),
+            ("mass_ratio", (0.125, 1.0), ("uniform",), 0.8, 0.08),
+            ("a_1", (0.0, 0.99), ("uniform",), 0.3, 0.15),
+            ("a_2", (0.0, 0.99), ("uniform",), 0.3, 0.2),
+            ("tilt_1", (0.0, np.pi), ("sine",), 1.0, 0.4),
+            ("tilt_2", (0.0, np.pi), ("sine",), 1.5, 0.5),
+            ("phi_12", (0.0, 2 * np.pi), ("uniform",), 3.0, 1.0),
+            ("phi_jl", (0.0, 2 * np.pi), ("uniform",), 3.0, 1.0),
+            ("luminosity_distance", (100.0, 5000.0), ("power_law", 2.0), 1500.0, 300.0),
+            ("dec", (-np.pi / 2, np.pi / 2), ("cosine",), -0.3, 0.15),
+            ("ra", (0.0, 2 * np.pi), ("uniform",), 1.4, 0.2),
+            ("theta_jn", (0.0, np.pi), ("sine",), 0.6, 0.25),
+            ("psi", (0.0, np.pi), ("uniform",), 1.5, 0.5),
+            ("phase", (0.0, 2 * np.pi), ("uniform",), 3.0, 1.2),
+            ("geocent_time", (-0.1, 0.1), ("uniform",), 0.0, 0.005),
+        ]
+        self.names = [s[0] for s in spec]
+        self.bounds = {s[0]: [float(s[1][0]), float(s[1][1])] for s in spec}
+        self.device_prior = {s[0]: s[2] for s in spec}
+        self._mu = np.array([s[3] for s in spec])
+        self._sigma = np.array([s[4] for s in spec])
+
+    def log_likelihood(self, x):
+        a = self.unstructured_view(x)
+        return -0.5 * np.sum(((a - self._mu) / self._sigma) ** 2, axis=-1)
+
+    def new_point(self, N=1, rng=None):
+        """Rejection-sample the separable prior inside the bounds."""
+        rng = rng if rng is not None else np.random.default_rng()
+        from .livepoint import numpy_array_to_live_points
+
+        lo, hi = self.lower_bounds, self.upper_bounds
+        out = np.empty((0, self.dims))
+        while len(out) < N:
+            u = rng.uniform(lo, hi, size=(4 * N, self.dims))
+            pts = numpy_array_to_live_points(u, self.names)
+            lp = self.log_prior(pts)
+            lp_max = sum(
+                np.max(log_prior_term(self.device_prior[n], np.linspace(*self.bounds[n], 513)[1:-1], *self.bounds[n]))
+                for n in self.names
+            )
+            keep = np.log(rng.random(len(u))) < lp - lp_max
+            out = np.concatenate([out, u[keep]])
+        pts = numpy_array_to_live_points(out[:N], self.names)
+        pts["logP"] = self.log_prior(pts)
+        return pts

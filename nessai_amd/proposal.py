@@ -56,10 +56,11 @@ class FlowProposal:
     device_seed : int, optional
         Seed of the on-device Philox streams (default: drawn from ``rng``).
     prior : {'auto', 'device', 'host'}
-        ``'device'`` evaluates a uniform-in-bounds prior as a constant on the
-        GPU; ``'host'`` copies every candidate to the host and calls
-        ``model.log_prior`` (any prior); ``'auto'`` picks ``'device'`` when
-        ``model.uniform_prior`` is true.
+        ``'device'`` evaluates the prior on the GPU: a constant for a
+        uniform-in-bounds prior (``model.uniform_prior``) or the separable
+        analytic densities declared in ``model.device_prior``; ``'host'`` copies
+        every candidate to the host and calls ``model.log_prior`` (any prior);
+        ``'auto'`` picks ``'device'`` when the model declares either.
     shard : bool
         When ``torch.distributed`` is initialised, split every draw batch over
         the ranks (one all-reduce(max) + one all-gather per pass).
@@ -214,9 +215,19 @@ class FlowProposal:
         self.flow.initialise()
         self.device = self.flow.device
         mode = self._prior_mode
+        has_device_prior = getattr(self.model, "uniform_prior", False) or (
+            getattr(self.model, "device_prior", None) is not None
+        )
         if mode == "auto":
-            mode = "device" if getattr(self.model, "uniform_prior", False) else "host"
+            mode = "device" if has_device_prior else "host"
+        if mode == "device" and not has_device_prior:
+            raise ValueError("prior='device' needs model.uniform_prior or model.device_prior")
         self.prior_mode = mode
+        self._prior_kind_dev = self._prior_par_dev = None
+        if mode == "device" and not getattr(self.model, "uniform_prior", False):
+            kinds, pars = self.model.device_prior_tables()
+            self._prior_kind_dev = torch.from_numpy(kinds).to(self.device)
+            self._prior_par_dev = torch.from_numpy(pars).to(self.device)
         self._upload_constants()
         self.populated = False
         self.initialised = True
@@ -327,7 +338,7 @@ class FlowProposal:
 
     # -- device plumbing --------------------------------------------------------------
 
-    def _launch_draw(self, n, z_in, row_offset, radius, x64, log_q, z_out):
+    def _launch_draw(self, n, z_in, row_offset, radius, x64, log_q, z_out, log_prior=None):
         from .flows.base import populate_precision
 
         flow = self.flow.model
@@ -343,8 +354,10 @@ class FlowProposal:
             header, lib.ptr(image), n, lib.ptr(z_in), self.device_seed, int(row_offset),
             float(radius), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
             lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
-            lib.ptr(x64), lib.ptr(log_q), lib.ptr(z_out), lib.ptr(status),
-            flow.waves_per_group, flow.max_groups, lib.c_void_p(stream),
+            lib.ptr(x64), lib.ptr(log_q), lib.ptr(z_out),
+            lib.ptr(self._prior_kind_dev if log_prior is not None else None),
+            lib.ptr(self._prior_par_dev if log_prior is not None else None), lib.ptr(log_prior),
+            lib.ptr(status), flow.waves_per_group, flow.max_groups, lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_populate_draw")
 
@@ -361,6 +374,7 @@ class FlowProposal:
             log_q=torch.empty(n, dtype=torch.float64, device=dev),
             log_w=torch.empty(n, dtype=torch.float64, device=dev),
             max_key=torch.empty(1, dtype=torch.int64, device=dev),
+            log_p=torch.empty(n, dtype=torch.float64, device=dev),
             x_acc=torch.empty((capacity, self.dims), dtype=torch.float64, device=dev),
             n_acc=torch.zeros(1, dtype=torch.int64, device=dev),
             workspace=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
@@ -373,7 +387,13 @@ class FlowProposal:
         stream = lib.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if reset_max:
             buf["max_key"].fill_(int(L.nsa_max_key_init()))
-        if self.prior_mode == "device":
+        if self.prior_mode == "device" and self._prior_kind_dev is not None:
+            # separable analytic prior, evaluated by the draw kernel into buf["log_p"]
+            rc = L.nsa_populate_weights(
+                n, lib.ptr(buf["log_q"]), lib.ptr(buf["log_p"]), 0.0, lib.ptr(buf["log_w"]),
+                lib.ptr(buf["max_key"]), stream,
+            )
+        elif self.prior_mode == "device":
             log_prior_const = self._uniform_log_prior_constant()
             rc = L.nsa_populate_weights(
                 n, lib.ptr(buf["log_q"]), None, log_prior_const, lib.ptr(buf["log_w"]),
@@ -469,7 +489,8 @@ class FlowProposal:
                 u_in = torch.from_numpy(np.ascontiguousarray(u_np, dtype=np.float64)).to(self.device)
             buf = self._get_buffers(n_local, n_samples)
             row_offset = self._draw_counter + rank * n_local
-            self._launch_draw(n_local, z_in, row_offset, threshold, buf["x64"], buf["log_q"], None)
+            self._launch_draw(n_local, z_in, row_offset, threshold, buf["x64"], buf["log_q"], None,
+                              log_prior=buf["log_p"] if self._prior_kind_dev is not None else None)
             self._weights_and_max(buf, n_local)
             if sharded:
                 torch.distributed.all_reduce(buf["max_key"], op=torch.distributed.ReduceOp.MAX)
@@ -515,7 +536,8 @@ class FlowProposal:
                 z_in = torch.from_numpy(np.ascontiguousarray(z_np)).to(torch.float32).to(self.device)
             fresh = buf is None
             buf = self._get_buffers(n_local, n_samples)
-            self._launch_draw(n_local, z_in, self._draw_counter, threshold, buf["x64"], buf["log_q"], None)
+            self._launch_draw(n_local, z_in, self._draw_counter, threshold, buf["x64"], buf["log_q"], None,
+                              log_prior=buf["log_p"] if self._prior_kind_dev is not None else None)
             self._weights_and_max(buf, n_local, reset_max=fresh)
             n_proposed += n_local
             self._draw_counter += n_local

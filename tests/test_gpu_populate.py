@@ -190,6 +190,44 @@ def test_populate_host_prior_matches_device_prior():
         np.testing.assert_array_equal(p1.x[n], p2.x[n])
 
 
+def test_device_separable_prior_matches_host_prior():
+    """Config-5 style priors (sine / cosine / power law / uniform) evaluated in the fused kernel
+    give the same pool as the user's numpy log_prior on the host."""
+    from nessai_amd.model import GWSurrogateModel
+
+    pools = []
+    for mode in ("device", "host"):
+        model = GWSurrogateModel()
+        rng = np.random.default_rng(4)
+        torch.manual_seed(4)
+        prop = FlowProposal(model, rng=rng, flow_config=dict(ftype="nsf", n_neurons=30, n_blocks=4),
+                            poolsize=300, drawsize=20000, device_seed=9, prior=mode, precision="f32")
+        prop.initialise()
+        torch.manual_seed(4)
+        prop.flow.model.load_state_dict(
+            {k: v for k, v in _fresh_state(prop.flow.model).items()})
+        live = model.new_point(500, rng=np.random.default_rng(5))
+        prop.check_state(live)
+        prop.populate(None, n_samples=300, max_samples=2_000_000)
+        pools.append(prop)
+    dev, host = pools
+    assert dev.prior_mode == "device" and host.prior_mode == "host"
+    assert dev.n_proposed == host.n_proposed and abs(dev.n_accepted - host.n_accepted) <= 1
+    if dev.n_accepted == host.n_accepted:
+        for n in dev.names:
+            np.testing.assert_array_equal(dev.x[n], host.x[n])
+    np.testing.assert_allclose(dev.samples["logP"], dev.model.log_prior(dev.samples), rtol=1e-12)
+    assert dev.model.in_bounds(dev.samples).all()
+
+
+def _fresh_state(flow):
+    torch.manual_seed(123)
+    from nessai_amd.flows import NeuralSplineFlow
+
+    ref = NeuralSplineFlow(15, 30, 4, 2)
+    return ref.state_dict()
+
+
 def test_populate_accumulate_weights():
     """accumulate_weights=True (flowproposal.py:471-490, 504-510): pool of n_samples
     drawn from all accumulated candidates."""

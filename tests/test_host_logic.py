@@ -134,3 +134,21 @@ def test_importance_proposal_glue():
     prop._weights[2] = np.nan
     with pytest.raises(RuntimeError, match="Some weights are not set"):
         prop.compute_log_Q(xp, log_j=lj)
+
+
+def test_separable_prior_terms_are_normalised():
+    """Each device prior term integrates to one on its bounds (bilby-style densities)."""
+    from nessai_amd.model import GWSurrogateModel, log_prior_term
+
+    m = GWSurrogateModel()
+    assert len(m.names) == 15
+    for n in m.names:
+        lo, hi = m.bounds[n]
+        x = np.linspace(lo, hi, 200001)[1:-1]
+        p = np.exp(log_prior_term(m.device_prior[n], x, lo, hi))
+        assert abs(np.trapezoid(p, x) - 1.0) < 1e-3, n
+    kinds, pars = m.device_prior_tables()
+    assert kinds.dtype == np.int32 and pars.shape == (15, 3)
+    pts = m.new_point(50, rng=np.random.default_rng(0))
+    assert m.in_bounds(pts).all() and np.isfinite(m.log_prior(pts)).all()
+    assert np.isfinite(m.log_likelihood(pts)).all()
