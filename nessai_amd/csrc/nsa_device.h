@@ -115,6 +115,7 @@ struct NsaTransformConsts {
   float min_bw, bw_scale;           // min_bin_width, 1 - min_bin_width*K
   float min_bh, bh_scale;
   float min_d, edge_d;              // min_derivative, boundary derivative (== 1 up to f32 rounding)
+  float edge_raw;                   // its logit log(exp(1 - min_d) - 1): edge_d == min_d + softplus(edge_raw)
   float inv_logit_div;              // 1/sqrt(hidden_features) or 1
 };
 
@@ -168,8 +169,10 @@ struct NsaRQ {
   static constexpr int NPH = 4;
 
   struct State {
-    float cw[K + 1], ch[K + 1], dv[K + 1];
+    float cw[K + 1], ch[K + 1];
     float x;
+    // the bin selected by phase 2
+    float in_cw, in_cw1, in_ch, in_ch1, in_d, in_d1;
   };
 
   // knots of one axis: softmax -> min + scale*p -> cumulative sum mapped to [-B, B]
@@ -194,7 +197,8 @@ struct NsaRQ {
     cum[K] = B;
   }
 
-  // phases 0..2 fill the state from the parameters; phase 3 evaluates the spline
+  // phase 0: width knots; 1: height knots; 2: bin search + the bin's two derivatives
+  // (only the two softplus values that are used are evaluated); 3: spline evaluation
   template <int P, int OFF, bool INV, int NV>
   __device__ __forceinline__ static void phase(State& st, const float (&v)[NV], float x_in,
                                                const NsaTransformConsts& c, float& y, float& ld,
@@ -206,17 +210,13 @@ struct NsaRQ {
     } else if constexpr (P == 1) {
       knots<OFF + K, NV>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, st.ch);
     } else if constexpr (P == 2) {
-      st.dv[0] = c.edge_d;
-      st.dv[K] = c.edge_d;
-#pragma unroll
-      for (int i = 1; i < K; ++i) st.dv[i] = c.min_d + nsa_softplus(v[OFF + 2 * K + i - 1]);
-    } else {
       const float x = st.x;
       const bool inside = (x >= -B) && (x <= B);
       const float xin = inside ? x : 0.0f;
       // searchsorted (knots are increasing): keep the last knot <= x
       float in_cw = st.cw[0], in_cw1 = st.cw[1], in_ch = st.ch[0], in_ch1 = st.ch[1];
-      float in_d = st.dv[0], in_d1 = st.dv[1];
+      float r0 = 0.0f, r1 = v[OFF + 2 * K];  // raw derivative logits of knots k and k+1
+      bool first = true, last = false;
 #pragma unroll
       for (int i = 1; i < K; ++i) {
         const bool ge = INV ? (xin >= st.ch[i]) : (xin >= st.cw[i]);
@@ -224,11 +224,24 @@ struct NsaRQ {
         in_cw1 = ge ? st.cw[i + 1] : in_cw1;
         in_ch = ge ? st.ch[i] : in_ch;
         in_ch1 = ge ? st.ch[i + 1] : in_ch1;
-        in_d = ge ? st.dv[i] : in_d;
-        in_d1 = ge ? st.dv[i + 1] : in_d1;
+        r0 = ge ? v[OFF + 2 * K + i - 1] : r0;
+        if (i + 1 < K) r1 = ge ? v[OFF + 2 * K + i] : r1;
+        if (i == 1) first = !ge;
+        if (i == K - 1) last = ge;
       }
-      const float in_w = in_cw1 - in_cw;
-      const float in_h = in_ch1 - in_ch;
+      st.in_cw = in_cw; st.in_cw1 = in_cw1; st.in_ch = in_ch; st.in_ch1 = in_ch1;
+      // boundary knots: select the boundary LOGIT (cheap), then one unconditional softplus each
+      r0 = first ? c.edge_raw : r0;
+      r1 = last ? c.edge_raw : r1;
+      st.in_d = c.min_d + nsa_softplus(r0);
+      st.in_d1 = c.min_d + nsa_softplus(r1);
+    } else {
+      const float x = st.x;
+      const bool inside = (x >= -B) && (x <= B);
+      const float xin = inside ? x : 0.0f;
+      const float in_cw = st.in_cw, in_ch = st.in_ch, in_d = st.in_d, in_d1 = st.in_d1;
+      const float in_w = st.in_cw1 - in_cw;
+      const float in_h = st.in_ch1 - in_ch;
       const float delta = in_h / in_w;
       const float curv = (in_d + in_d1) - 2.0f * delta;
       float out, dnum, den;

@@ -593,7 +593,8 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
   tc.min_bw = nsa_bits_to_float(img[NSA_H_MIN_BW]);
   tc.min_bh = nsa_bits_to_float(img[NSA_H_MIN_BH]);
   tc.min_d = nsa_bits_to_float(img[NSA_H_MIN_D]);
-  tc.edge_d = tc.min_d + nsa_softplus(nsa_bits_to_float(img[NSA_H_EDGE_RAW]));
+  tc.edge_raw = nsa_bits_to_float(img[NSA_H_EDGE_RAW]);
+  tc.edge_d = tc.min_d + nsa_softplus(tc.edge_raw);
   tc.inv_logit_div = 1.0f / nsa_bits_to_float(img[NSA_H_LOGIT_DIV]);
   {
     const int K = (int)img[NSA_H_BINS];

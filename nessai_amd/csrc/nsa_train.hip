@@ -217,6 +217,7 @@ __global__ void tr_rq_forward(int n, int d_tr, const int* __restrict__ tr_cols, 
   tc.min_bw = c.min_bw; tc.bw_scale = (float)(1.0 - (double)c.min_bw * K);
   tc.min_bh = c.min_bh; tc.bh_scale = (float)(1.0 - (double)c.min_bh * K);
   tc.min_d = c.min_d; tc.edge_d = c.edge_d; tc.inv_logit_div = c.inv_div;
+  tc.edge_raw = logf(expf(1.0f - c.min_d) - 1.0f);
   typename NsaRQ<K>::State st;
   float y = 0.0f, ld = 0.0f;
   bool bad = false;
