@@ -175,23 +175,27 @@ struct NsaRQ {
     float in_cw, in_cw1, in_ch, in_ch1, in_d, in_d1;
   };
 
-  // knots of one axis: softmax -> min + scale*p -> cumulative sum mapped to [-B, B]
+  // knots of one axis: softmax -> min + scale*p -> cumulative sum mapped to [-B, B].
+  // Constant factors are folded: logits are scaled by log2(e)/sqrt(H) once so that the
+  // exponentials are bare v_exp_f32, and (right-left)*scale/sum multiplies each of them once.
   template <int OFF, int NV>
   __device__ __forceinline__ static void knots(const float (&v)[NV], float inv_div, float mn,
                                                float sc, float two_b, float B, float (&cum)[K + 1]) {
     float u[K];
+    const float k2 = inv_div * 1.4426950408889634f;
     float m = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < K; ++i) { u[i] = v[OFF + i] * inv_div; m = fmaxf(m, u[i]); }
+    for (int i = 0; i < K; ++i) { u[i] = v[OFF + i] * k2; m = fmaxf(m, u[i]); }
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < K; ++i) { u[i] = nsa_exp(u[i] - m); s += u[i]; }
-    const float inv_s = nsa_rcp(s);
-    float run = 0.0f;
+    for (int i = 0; i < K; ++i) { u[i] = __builtin_amdgcn_exp2f(u[i] - m); s += u[i]; }
+    const float g = (two_b * sc) * nsa_rcp(s);
+    const float c0 = two_b * mn;
+    float run = -B;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      run += fmaf(sc, u[i] * inv_s, mn);
-      cum[i + 1] = fmaf(two_b, run, -B);
+      run += fmaf(g, u[i], c0);
+      cum[i + 1] = run;
     }
     cum[0] = -B;
     cum[K] = B;
@@ -242,7 +246,8 @@ struct NsaRQ {
       const float in_cw = st.in_cw, in_ch = st.in_ch, in_d = st.in_d, in_d1 = st.in_d1;
       const float in_w = st.in_cw1 - in_cw;
       const float in_h = st.in_ch1 - in_ch;
-      const float delta = in_h / in_w;
+      const float inv_w = nsa_rcp(in_w);
+      const float delta = in_h * inv_w;
       const float curv = (in_d + in_d1) - 2.0f * delta;
       float out, dnum, den;
       if constexpr (INV) {
@@ -252,7 +257,7 @@ struct NsaRQ {
         const float cc = -delta * sh;
         const float disc = b * b - 4.0f * a * cc;
         bad = inside && !(disc >= 0.0f);
-        const float root = (2.0f * cc) / (-b - sqrtf(disc));
+        const float root = (2.0f * cc) * nsa_rcp(-b - __builtin_amdgcn_sqrtf(disc));
         out = root * in_w + in_cw;
         const float tomt = root * (1.0f - root);
         const float omr = 1.0f - root;
@@ -260,11 +265,11 @@ struct NsaRQ {
         dnum = (delta * delta) * ((in_d1 * (root * root) + (2.0f * delta) * tomt) + in_d * (omr * omr));
       } else {
         bad = false;
-        const float theta = (xin - in_cw) / in_w;
+        const float theta = (xin - in_cw) * inv_w;
         const float tomt = theta * (1.0f - theta);
         const float omt = 1.0f - theta;
         den = delta + curv * tomt;
-        out = in_ch + (in_h * (delta * (theta * theta) + in_d * tomt)) / den;
+        out = in_ch + (in_h * (delta * (theta * theta) + in_d * tomt)) * nsa_rcp(den);
         dnum = (delta * delta) * ((in_d1 * (theta * theta) + (2.0f * delta) * tomt) + in_d * (omt * omt));
       }
       float lad = nsa_log(dnum) - 2.0f * nsa_log(den);
