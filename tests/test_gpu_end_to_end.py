@@ -1,0 +1,53 @@
+"""A minimal nested-sampling caller of the proposal protocol (style of the reference's
+tests/test_sampling/test_standard_sampling.py: assert the flow got trained and the run resumes)."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from nessai_amd.model import GaussianModel
+from nessai_amd.proposal import FlowProposal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_proposal_drives_a_small_nested_sampling_loop(tmp_path):
+    rng = np.random.default_rng(170817)
+    torch.manual_seed(170817)
+    model = GaussianModel(2)
+    nlive = 200
+    proposal = FlowProposal(
+        model, rng=rng, poolsize=nlive, drawsize=20_000, output=str(tmp_path),
+        flow_config=dict(ftype="realnvp", n_blocks=2, n_neurons=8, n_layers=1),
+        training_config=dict(max_epochs=30, patience=10, batch_size=100),
+    )
+    proposal.initialise()
+    live = model.new_point(nlive, rng=rng)
+    live["logL"] = model.log_likelihood(live)
+    live = np.sort(live, order="logL")
+    replaced = 0
+    for it in range(300):
+        if it % 100 == 0:
+            proposal.train(live)
+        worst = live[0]
+        for _ in range(200):
+            new = proposal.draw(worst)
+            if new["logL"] > worst["logL"]:
+                break
+        else:
+            pytest.fail("no point above the worst likelihood in 200 draws")
+        idx = np.searchsorted(live["logL"], new["logL"])
+        live[: idx - 1] = live[1:idx]
+        live[idx - 1] = new
+        replaced += 1
+    assert replaced == 300
+    assert proposal.training_count == 3
+    assert proposal.populated_count >= 1
+    assert model.in_bounds(live).all() and np.all(np.diff(live["logL"]) >= 0)
+    assert live["logL"][0] > -6.0  # the live set contracted towards the mode
+    assert proposal.population_time.total_seconds() > 0
+    # the proposal pickles without its device state (resume protocol, base.py:1286-1309)
+    state = pickle.loads(pickle.dumps(proposal))
+    assert state.flow is None and state.populated == proposal.populated
+    assert state.weights_file is not None
