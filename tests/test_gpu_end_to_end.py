@@ -26,6 +26,7 @@ def test_proposal_drives_a_small_nested_sampling_loop(tmp_path):
     live = model.new_point(nlive, rng=rng)
     live["logL"] = model.log_likelihood(live)
     live = np.sort(live, order="logL")
+    first_worst = float(live["logL"][0])
     replaced = 0
     for it in range(300):
         if it % 100 == 0:
@@ -45,7 +46,7 @@ def test_proposal_drives_a_small_nested_sampling_loop(tmp_path):
     assert proposal.training_count == 3
     assert proposal.populated_count >= 1
     assert model.in_bounds(live).all() and np.all(np.diff(live["logL"]) >= 0)
-    assert live["logL"][0] > -6.0  # the live set contracted towards the mode
+    assert live["logL"][0] > first_worst + 10.0  # the live set contracted towards the mode
     assert proposal.population_time.total_seconds() > 0
     # the proposal pickles without its device state (resume protocol, base.py:1286-1309)
     state = pickle.loads(pickle.dumps(proposal))
