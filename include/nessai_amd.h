@@ -70,6 +70,25 @@ NSA_API int nsa_flow_run(const uint32_t* header, const void* image_dev, int dire
                  long long n, const float* x_in_dev, float* x_out_dev, float* ld_out_dev,
                  int* status_dev, int waves_per_group, int max_groups, void* stream);
 
+/* The same batch through n_flows flows of identical structure in ONE launch.
+ *
+ * Replaces the loop over flows of ImportanceFlowModel.log_prob_all
+ * (src/nessai/flowmodel/importance.py:114-129: ``for i, m in enumerate(self.models):
+ * log_prob[:, i] = m.log_prob(x)``), the dominant cost of the importance nested sampler's
+ * meta-proposal (proposal/importance.py:585-606, 694-735).
+ *   header           host copy of flow 0's header; every flow must share its structure
+ *                    (D, hidden tiles, transform, bins, precision, stage sizes)
+ *   image_list_dev   device array of n_flows device pointers, one flow image each
+ *   x_in_dev   [n][D] float32, shared by all flows
+ *   x_out_dev  [n_flows][n][D] float32 or NULL
+ *   ld_out_dev [n_flows][n] float32 or NULL
+ *   other arguments as nsa_flow_run.
+ */
+NSA_API int nsa_flow_run_many(const uint32_t* header, const void* const* image_list_dev, int n_flows,
+                      int direction, int mode, long long n, const float* x_in_dev,
+                      float* x_out_dev, float* ld_out_dev, int* status_dev,
+                      int waves_per_group, int max_groups, void* stream);
+
 /* Fused draw -> truncate -> inverse flow -> inverse z-score -> prior bounds -> log_q.
  *
  * Replaces one pass of the body of FlowProposal.populate up to compute_weights

@@ -29,10 +29,10 @@ extern "C" int nsa_version(void) { return NSA_VERSION; }
 // NSA_INSTANCES is generated there as X(ht, kind, bins) entries)
 // ---------------------------------------------------------------------------
 
-typedef hipError_t (*nsa_launch_fn)(const NsaLaunch*, unsigned, unsigned, size_t, hipStream_t);
+typedef hipError_t (*nsa_launch_fn)(const NsaLaunch*, unsigned, unsigned, unsigned, size_t, hipStream_t);
 
 #define X(ht, kind, bins) \
-  extern "C" hipError_t nsa_launch_h##ht##_t##kind##_k##bins(const NsaLaunch*, unsigned, unsigned, size_t, hipStream_t);
+  extern "C" hipError_t nsa_launch_h##ht##_t##kind##_k##bins(const NsaLaunch*, unsigned, unsigned, unsigned, size_t, hipStream_t);
 NSA_INSTANCES
 #undef X
 
@@ -90,7 +90,7 @@ static int nsa_check_header(const uint32_t* h) {
 }
 
 static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group, int max_groups,
-                           hipStream_t stream) {
+                           hipStream_t stream, int n_flows = 1) {
   int rc = nsa_check_header(h);
   if (rc != NSA_OK) return rc;
   rc = nsa_device_info();
@@ -110,7 +110,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   int nw = waves_per_group > 0 ? waves_per_group : 4;
   if (nw > 8) nw = 8;
   // small batches: fewer waves per workgroup so that more CUs take part
-  while (nw > 1 && n_tiles < (long long)nw * g_num_cus) nw >>= 1;
+  while (nw > 1 && n_tiles * n_flows < (long long)nw * g_num_cus) nw >>= 1;
   size_t lds = 0;
   for (;;) {
     const size_t tiles_words = ((size_t)nw * NSA_ROWS * XS + 3) & ~(size_t)3;
@@ -125,10 +125,10 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   const long long by_waves = 8 / nw;  // 2 waves per SIMD
   if (per_cu > by_waves) per_cu = by_waves;
   if (per_cu < 1) per_cu = 1;
-  long long grid = per_cu * g_num_cus;
+  long long grid = (per_cu * g_num_cus + n_flows - 1) / n_flows;
   if (max_groups > 0 && grid > max_groups) grid = max_groups;
   if (grid > n_groups) grid = n_groups;
-  hipError_t e = fn(&p, (unsigned)grid, (unsigned)(nw * 64), lds, stream);
+  hipError_t e = fn(&p, (unsigned)grid, (unsigned)n_flows, (unsigned)(nw * 64), lds, stream);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "flow kernel launch: %s", hipGetErrorString(e));
   return NSA_OK;
 }
@@ -159,6 +159,32 @@ extern "C" int nsa_flow_run(const uint32_t* header, const void* image_dev, int d
   p.ld_out = ld_out_dev;
   p.status = status_dev;
   return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
+}
+
+extern "C" int nsa_flow_run_many(const uint32_t* header, const void* const* image_list_dev, int n_flows,
+                                 int direction, int mode, long long n, const float* x_in_dev,
+                                 float* x_out_dev, float* ld_out_dev, int* status_dev,
+                                 int waves_per_group, int max_groups, void* stream) {
+  if (image_list_dev == nullptr || x_in_dev == nullptr || status_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run_many: NULL image list / input / status pointer");
+  if (n_flows < 1 || n_flows > 65535) return nsa_fail(NSA_E_ARG, "nsa_flow_run_many: n_flows must be in [1, 65535]");
+  if (direction != NSA_DIR_FORWARD && direction != NSA_DIR_INVERSE)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run_many: direction must be 0 or 1");
+  if (mode != NSA_MODE_APPLY && mode != NSA_MODE_LOGPROB)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run_many: mode must be 0 (apply) or 1 (log_prob)");
+  if (mode == NSA_MODE_LOGPROB && direction != NSA_DIR_FORWARD)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run_many: log_prob needs the forward direction");
+  NsaLaunch p;
+  memset(&p, 0, sizeof(p));
+  p.image_list = (const uint32_t* const*)image_list_dev;
+  p.direction = direction;
+  p.mode = mode;
+  p.n = n;
+  p.x_in = x_in_dev;
+  p.x_out = x_out_dev;
+  p.ld_out = ld_out_dev;
+  p.status = status_dev;
+  return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream, n_flows);
 }
 
 extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, long long n,

@@ -23,7 +23,7 @@ using TP = NsaAdditive;
 #define NSA_LAUNCH_NAME NSA_CAT(nsa_launch_h, NSA_HT, _t, NSA_TKIND, _k, NSA_BINS)
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t NSA_LAUNCH_NAME(
-    const NsaLaunch* p, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
+    const NsaLaunch* p, unsigned grid, unsigned grid_y, unsigned block, size_t lds, hipStream_t stream) {
   const bool inv = p->direction == NSA_DIR_INVERSE;
   auto kern = (p->precision == NSA_PREC_BF16X3)
                   ? (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_BF16X3>
@@ -33,6 +33,6 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t NSA_LAUNCH_NAME(
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, *p);
+  hipLaunchKernelGGL(kern, dim3(grid, grid_y), dim3(block), lds, stream, *p);
   return hipGetLastError();
 }

@@ -59,6 +59,9 @@ struct NsaLaunch {
   const int* prior_kind;          // [D] or null
   const double* prior_par;        // [D][3]
   double* log_prior_out;          // [n]
+  // grouped launch (APPLY / LOGPROB): gridDim.y flows of identical structure on the same
+  // input; flow f reads image_list[f] and writes x_out + f*n*D, ld_out + f*n
+  const uint32_t* const* image_list;  // device array of n_flows image pointers, or null
 };
 
 enum { NSA_PRIOR_UNIFORM = 0, NSA_PRIOR_SINE = 1, NSA_PRIOR_COSINE = 2, NSA_PRIOR_POWER_LAW = 3,
@@ -558,8 +561,13 @@ __device__ __forceinline__ void nsa_elementwise_op(NsaStagePipe& pipe, const uin
 template <int HT, class TP, bool INV, int PREC>
 __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (p.image_list != nullptr) {
+    p.image = p.image_list[blockIdx.y];
+    if (p.ld_out != nullptr) p.ld_out += (long long)blockIdx.y * p.n;
+  }
   const uint32_t* img = p.image;
   const int D = (int)img[NSA_H_D];
+  if (p.image_list != nullptr && p.x_out != nullptr) p.x_out += (long long)blockIdx.y * p.n * D;
   const int XS = (D + 1) | 1;  // odd row stride (conflict-free column reads) with >= 1 spare column
   const int nw = (int)(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

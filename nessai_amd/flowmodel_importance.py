@@ -4,8 +4,9 @@ Counterpart of the reference's ``nessai.flowmodel.importance.ImportanceFlowModel
 (``src/nessai/flowmodel/importance.py:22``): every level of the importance sampler adds a
 flow; ``log_prob_all`` evaluates every stored flow on the same batch (the dominant cost of
 config 4) and ``sample_ith`` draws from one of them.  Here each flow is a
-``HipFlow``: the batch is uploaded once, each flow's log-density is one fused-kernel launch
-writing a column of an ``(N, n_flows)`` device matrix, and the matrix comes back in one copy.
+``HipFlow``: the batch is uploaded once, all flows are evaluated by ONE grouped launch
+(``nsa_flow_run_many``: gridDim.y = flow index, so a 5000-row batch under 8 flows fills the chip)
+writing an ``(n_flows, N)`` device matrix, and the matrix comes back in one copy.
 """
 
 import copy
@@ -18,6 +19,7 @@ import torch
 
 from .flowmodel import FlowModel
 from .flows import configure_model
+from .flows.base import log_prob_many
 
 logger = logging.getLogger(__name__)
 
@@ -80,9 +82,7 @@ class ImportanceFlowModel(FlowModel):
         """``(N, n_flows)`` log-densities, every flow on the same batch (``importance.py:114-129``)."""
         xt = self._tensor(x)
         self.models.eval()
-        out = torch.empty((self.n_models, xt.shape[0]), dtype=torch.float32, device=self.device)
-        for i, m in enumerate(self.models):
-            out[i] = m.log_prob(xt)
+        out = log_prob_many(self.models, xt)
         return self._to_numpy(out.t())
 
     def sample_ith(self, i, N=1):

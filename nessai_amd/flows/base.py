@@ -297,3 +297,45 @@ def lib_supports(ht, transform, bins):
     """Ask the library whether a kernel instance exists (no GPU needed)."""
     kind = pack.TRANSFORMS[transform]
     return bool(lib.load().nsa_flow_supported(int(ht), int(kind), int(bins if transform == "rq" else 0)))
+
+
+_STRUCT_WORDS = (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 25, 26, 27, 29)  # nsa_format.h ints
+
+
+def log_prob_many(flows, x):
+    """``(n_flows, N)`` log-densities of one batch under several flows.
+
+    The loop of ``ImportanceFlowModel.log_prob_all`` (``flowmodel/importance.py:114-129``)
+    as ONE grouped launch (``nsa_flow_run_many``) when the flows share their structure -
+    they do in the importance sampler, every level is built from one ``flow_config`` -
+    and one launch per flow otherwise.
+    """
+    flows = list(flows)
+    if not flows:
+        raise ValueError("no flows")
+    first = flows[0]
+    for f in flows:
+        if f.training and _has_batch_norm(f):
+            raise RuntimeError("call .eval() before using batch-norm flows for inference")
+    x = first._check_input(x)
+    n = x.shape[0]
+    out = torch.empty((len(flows), n), dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out
+    images = [f.device_image() for f in flows]
+    h0 = images[0][0]
+    same = all(all(h[w] == h0[w] for w in _STRUCT_WORDS) for h, _ in images)
+    if not same or len(flows) == 1:
+        for i, f in enumerate(flows):
+            out[i] = f.log_prob(x)
+        return out
+    ptrs = torch.tensor([im.data_ptr() for _, im in images], dtype=torch.int64, device=x.device)
+    status = first._status
+    status.zero_()
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    rc = lib.load().nsa_flow_run_many(
+        h0, lib.ptr(ptrs), len(flows), DIR_FORWARD, MODE_LOGPROB, n, lib.ptr(x), None, lib.ptr(out),
+        lib.ptr(status), first.waves_per_group, first.max_groups, lib.c_void_p(stream),
+    )
+    lib.check(rc, "nsa_flow_run_many")
+    return out

@@ -27,6 +27,11 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     ),
+    "nsa_flow_run_many": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+         c_void_p],
+    ),
     "nsa_populate_draw": (
         c_int,
         [c_void_p, c_void_p, c_ll, c_void_p, c_ull, c_ull, c_double, c_void_p, c_void_p, c_void_p,

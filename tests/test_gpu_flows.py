@@ -267,3 +267,35 @@ def test_full_size_properties_c3():
     assert torch.isfinite(x).all() and torch.isfinite(ld).all()
     assert (z - z2).abs().max().item() < 5e-4
     assert (ld + ld2).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("name,n_flows,n", [("nsf_c4_d64", 5, 1000), ("nsf_d4", 3, 77), ("rnvp_c2", 4, 2500)])
+def test_log_prob_many_is_the_per_flow_loop(name, n_flows, n):
+    """One grouped launch == the loop of ImportanceFlowModel.log_prob_all
+    (flowmodel/importance.py:114-129), bit for bit, and within the bar of the oracle."""
+    from nessai_amd.flows.base import log_prob_many
+
+    P, Oc, args, kw = CONFIGS[name]
+    pairs = []
+    for i in range(n_flows):
+        pairs.append(make_pair(P, Oc, args, kw, seed=100 + i))
+    x = torch.randn(n, args[0], generator=torch.Generator().manual_seed(3)).to(DEV)
+    many = log_prob_many([f for _, f in pairs], x)
+    assert many.shape == (n_flows, n)
+    for i, (ref, flow) in enumerate(pairs):
+        single = flow.log_prob(x)
+        assert torch.equal(many[i], single)
+        with torch.no_grad():
+            expected = ref.log_prob(x.cpu()).numpy()
+        assert rel_err(many[i].cpu().numpy(), expected) < LOG_PROB_RTOL
+
+
+def test_log_prob_many_mixed_structures_falls_back_to_per_flow_launches():
+    from nessai_amd.flows.base import log_prob_many
+
+    _, a = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2), {})
+    _, b = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (4, 16, 2, 2), {})
+    x = torch.randn(50, 4).to(DEV)
+    out = log_prob_many([a, b], x)
+    assert torch.equal(out[0], a.log_prob(x)) and torch.equal(out[1], b.log_prob(x))
+    assert log_prob_many([a], x[:0]).shape == (1, 0)
