@@ -118,6 +118,16 @@ NSA_API int nsa_flow_run_many(const uint32_t* header, const void* const* image_l
  *               {a, b, log normalisation}; log_prior_out_dev [n] receives sum_i log p_i(x_i).
  *               Pass NULL to skip (then give nsa_populate_weights a constant or a host-
  *               evaluated per-row prior).
+ *   rp_kind_dev / rp_par_dev   optional per-dimension reparameterisation table (NULL = the
+ *               z-score map above for every dimension): kind 0 scale-and-shift (uses
+ *               scale/shift), 1 null (null.py), 2 rescale-to-bounds
+ *               x = (hi - lo) * (x' - rs) / rf + lo + offset
+ *               (RescaleToBounds._inverse_rescale_to_bounds, rescale.py:537-547, 673-700),
+ *               3 the same after u = sigmoid(x') with log|J| += log u + log1p(-u)
+ *               (utils/rescaling.py:318-337: the registry's "logit" entry,
+ *               reparameterisations/__init__.py:62-70); rp_par_dev [D][5] float64
+ *               {lo, hi, rs, rf, offset}.  log_j_rescale then carries the row-independent
+ *               terms only; the sigmoid terms are added per row in float64.
  */
 NSA_API int nsa_populate_draw(const uint32_t* header, const void* image_dev, long long n,
                       const float* z_in_dev, unsigned long long seed,
@@ -125,8 +135,8 @@ NSA_API int nsa_populate_draw(const uint32_t* header, const void* image_dev, lon
                       const double* shift_dev, const double* lower_dev, const double* upper_dev,
                       double log_j_rescale, double* x64_out_dev, double* log_q_out_dev,
                       float* z_out_dev, const int* prior_kind_dev, const double* prior_par_dev,
-                      double* log_prior_out_dev, int* status_dev, int waves_per_group,
-                      int max_groups, void* stream);
+                      double* log_prior_out_dev, const int* rp_kind_dev, const double* rp_par_dev,
+                      int* status_dev, int waves_per_group, int max_groups, void* stream);
 
 /* log_w = log_prior - log_q and its maximum.
  *

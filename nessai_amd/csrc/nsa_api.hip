@@ -107,23 +107,33 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   const int D = (int)h[NSA_H_D];
   const int XS = (D + 1) | 1;
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
+  const size_t stage_bytes = 2 * (size_t)h[NSA_H_MAX_STAGE] * 4;
+  auto lds_of = [&](int w) { return ((((size_t)w * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + stage_bytes; };
+  auto per_cu_of = [&](int w) {
+    long long c = (long long)(g_max_lds / lds_of(w));
+    const long long by_waves = 8 / w;  // 2 waves per SIMD
+    if (c > by_waves) c = by_waves;
+    return c;
+  };
+  auto groups_of = [&](int w) { return (n_tiles + w - 1) / w; };
   int nw = waves_per_group > 0 ? waves_per_group : 4;
   if (nw > 8) nw = 8;
-  // small batches: fewer waves per workgroup so that more CUs take part
-  while (nw > 1 && n_tiles * n_flows < (long long)nw * g_num_cus) nw >>= 1;
-  size_t lds = 0;
-  for (;;) {
-    const size_t tiles_words = ((size_t)nw * NSA_ROWS * XS + 3) & ~(size_t)3;
-    lds = (tiles_words + 2 * (size_t)h[NSA_H_MAX_STAGE]) * 4;
-    if (lds <= g_max_lds || nw == 1) break;
-    nw >>= 1;
+  if (waves_per_group <= 0) {
+    // small batches: fewer waves per workgroup so that more CUs take part ...
+    while (nw > 1 && n_tiles * n_flows < (long long)nw * g_num_cus) nw >>= 1;
+    // ... unless that leaves a mostly idle second round which wider workgroups avoid
+    while (nw < 8 && per_cu_of(2 * nw) >= 1 &&
+           groups_of(nw) * n_flows > per_cu_of(nw) * g_num_cus &&
+           groups_of(nw) * n_flows <= 2 * per_cu_of(nw) * g_num_cus &&
+           groups_of(2 * nw) * n_flows <= per_cu_of(2 * nw) * g_num_cus)
+      nw <<= 1;
   }
+  while (nw > 1 && lds_of(nw) > g_max_lds) nw >>= 1;
+  const size_t lds = lds_of(nw);
   if (lds > g_max_lds)
     return nsa_fail(NSA_E_ARG, "flow needs %zu bytes of LDS per workgroup (> %zu)", lds, g_max_lds);
-  const long long n_groups = (n_tiles + nw - 1) / nw;
-  long long per_cu = (long long)(g_max_lds / lds);
-  const long long by_waves = 8 / nw;  // 2 waves per SIMD
-  if (per_cu > by_waves) per_cu = by_waves;
+  const long long n_groups = groups_of(nw);
+  long long per_cu = per_cu_of(nw);
   if (per_cu < 1) per_cu = 1;
   long long grid = (per_cu * g_num_cus + n_flows - 1) / n_flows;
   if (max_groups > 0 && grid > max_groups) grid = max_groups;
@@ -195,6 +205,7 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
                                  double log_j_rescale, double* x64_out_dev, double* log_q_out_dev,
                                  float* z_out_dev, const int* prior_kind_dev,
                                  const double* prior_par_dev, double* log_prior_out_dev,
+                                 const int* rp_kind_dev, const double* rp_par_dev,
                                  int* status_dev, int waves_per_group, int max_groups, void* stream) {
   if (image_dev == nullptr || scale_dev == nullptr || shift_dev == nullptr || lower_dev == nullptr ||
       upper_dev == nullptr || x64_out_dev == nullptr || log_q_out_dev == nullptr || status_dev == nullptr)
@@ -224,6 +235,11 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
     p.prior_kind = prior_kind_dev;
     p.prior_par = prior_par_dev;
     p.log_prior_out = log_prior_out_dev;
+  }
+  if (rp_kind_dev != nullptr) {
+    if (rp_par_dev == nullptr) return nsa_fail(NSA_E_ARG, "nsa_populate_draw: reparameterisation constants missing");
+    p.rp_kind = rp_kind_dev;
+    p.rp_par = rp_par_dev;
   }
   return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
 }

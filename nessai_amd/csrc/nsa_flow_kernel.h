@@ -59,10 +59,21 @@ struct NsaLaunch {
   const int* prior_kind;          // [D] or null
   const double* prior_par;        // [D][3]
   double* log_prior_out;          // [n]
+  // optional per-dimension reparameterisation table (NSA_RP_*); null = z-score everywhere
+  const int* rp_kind;             // [D]
+  const double* rp_par;           // [D][5] {lo, hi, rescale shift, rescale factor, offset}
   // grouped launch (APPLY / LOGPROB): gridDim.y flows of identical structure on the same
   // input; flow f reads image_list[f] and writes x_out + f*n*D, ld_out + f*n
   const uint32_t* const* image_list;  // device array of n_flows image pointers, or null
 };
+
+// x' -> x maps of the populate epilogue (inverse_reparameterise of the reference):
+//   SCALE_SHIFT  x = x' * scale + shift                       (rescale.py:263-291; z-score)
+//   NULL         x = x'                                       (null.py)
+//   TO_BOUNDS    x = (hi - lo) * (x' - rs) / rf + lo + offset (rescale.py:537-547, 673-700)
+//   TO_BOUNDS_LOGIT  the same after u = sigmoid(x'), log|J| += log u + log1p(-u)
+//                (utils/rescaling.py:318-337; the "logit" entry of reparameterisations/__init__.py:62-70)
+enum { NSA_RP_SCALE_SHIFT = 0, NSA_RP_NULL = 1, NSA_RP_TO_BOUNDS = 2, NSA_RP_TO_BOUNDS_LOGIT = 3 };
 
 enum { NSA_PRIOR_UNIFORM = 0, NSA_PRIOR_SINE = 1, NSA_PRIOR_COSINE = 2, NSA_PRIOR_POWER_LAW = 3,
        NSA_PRIOR_GAUSSIAN = 4 };
@@ -619,11 +630,12 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
   if (pipe.n_stages > 0) pipe.prime();
 
   for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    // ---- fill the x tile ---------------------------------------------------
+    bool keep = true;
+    float log_pz = 0.0f;
+    {
     const long long row0 = (g * nw + wave) * NSA_ROWS;
     const long long my_row = row0 + j;
-    const bool row_ok = my_row < p.n;
-
-    // ---- fill the x tile ---------------------------------------------------
     if (p.x_in != nullptr) {
       const long long base = row0 * D;
       const long long limit = p.n * (long long)D;
@@ -653,8 +665,6 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
     }
 
     // ---- POPULATE prologue: latent norm, latent log-density, optional z out --
-    bool keep = true;
-    float log_pz = 0.0f;
     if (p.mode == NSA_MODE_POPULATE) {
       double r2 = 0.0;
       float e = 0.0f;
@@ -678,6 +688,7 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
       }
     }
 
+    }
     // ---- run the flow --------------------------------------------------------
     float logdet = 0.0f;
     int n_bad = 0;
@@ -696,30 +707,59 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
     n_bad += __shfl_xor(n_bad, 32);
 
     // ---- epilogues -----------------------------------------------------------
+    // row indices are recomputed from the (opaque) group counter instead of staying live in
+    // VGPRs through the whole flow, where they were spilled to scratch
+    long long g_epi = g;
+    asm volatile("" : "+s"(g_epi));
+    const long long row0 = (g_epi * nw + wave) * NSA_ROWS;
+    const long long my_row = row0 + j;
+    const bool row_ok = my_row < p.n;
     if (p.mode == NSA_MODE_POPULATE) {
 #pragma clang fp contract(off)
+      const NsaLaunch& e = p;
       // x = x' * sigma + mu in float64 (rescale.py:276-279), prior bounds
       // (model.py:512-518), log_q = (log N(z) - log_j) - log_J
       // (flowproposal.py:356, 383)
       bool in_bounds = true;
       double log_prior = 0.0;
+      double log_j_row = 0.0;  // row-dependent part of the rescaling log-Jacobian
       for (int i = half; i < D; i += 2) {
         const double xp = (double)xrow[out_tab[i]];
-        const double xv = (xp * p.scale[i]) + p.shift[i];
-        in_bounds = in_bounds && !((xv < p.lower[i]) || (xv > p.upper[i]));
-        if (row_ok) p.x64_out[my_row * D + i] = xv;
-        if (p.prior_kind != nullptr) log_prior += nsa_log_prior_term(p.prior_kind[i], xv, p.prior_par + 3 * i);
+        double xv;
+        const int kind = (e.rp_kind != nullptr) ? e.rp_kind[i] : NSA_RP_SCALE_SHIFT;
+        if (kind == NSA_RP_SCALE_SHIFT) {
+          xv = (xp * e.scale[i]) + e.shift[i];
+        } else if (kind == NSA_RP_NULL) {
+          xv = xp;
+        } else {
+          const double* c = e.rp_par + 5 * i;
+          double u = xp;
+          if (kind == NSA_RP_TO_BOUNDS_LOGIT) {
+            u = 1.0 / (1.0 + exp(-xp));
+            log_j_row += log(u) + log1p(-u);
+          }
+          xv = (c[1] - c[0]) * (u - c[2]) / c[3] + c[0];
+          xv = xv + c[4];
+        }
+        in_bounds = in_bounds && !((xv < e.lower[i]) || (xv > e.upper[i]));
+        if (row_ok) e.x64_out[my_row * D + i] = xv;
+        if (e.prior_kind != nullptr) log_prior += nsa_log_prior_term(e.prior_kind[i], xv, e.prior_par + 3 * i);
       }
-      if (p.prior_kind != nullptr) {
+      if (e.prior_kind != nullptr) {
         log_prior += __shfl_xor(log_prior, 32);
-        if (row_ok && half == 0) p.log_prior_out[my_row] = log_prior;
+        if (row_ok && half == 0) e.log_prior_out[my_row] = log_prior;
       }
+      if (e.rp_kind != nullptr) log_j_row += __shfl_xor(log_j_row, 32);
       const int ib = in_bounds ? 1 : 0;
       const bool ok = (ib + __shfl_xor(ib, 32)) == 2;
-      double lq = ((double)log_pz - (double)logdet) - p.log_j_rescale;
+      // finite check on the flow's log_q (flowproposal.py:366-372), THEN the rescaling
+      // Jacobian (flowproposal.py:383): a saturated sigmoid gives log_q = +inf, kept as the
+      // reference keeps it (never accepted, still counted as proposed)
+      double lq = (double)log_pz - (double)logdet;
       const bool finite = (lq - lq) == 0.0;
+      lq -= (e.log_j_rescale + log_j_row);
       if (!(keep && ok && finite && n_bad == 0)) lq = __longlong_as_double(0x7ff8000000000000LL);
-      if (row_ok && half == 0) p.log_q_out[my_row] = lq;
+      if (row_ok && half == 0) e.log_q_out[my_row] = lq;
       if (row_ok && half == 0 && n_bad != 0) atomicAdd(p.status, 1);
     } else {
       float out_ld = logdet;

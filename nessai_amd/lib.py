@@ -9,7 +9,10 @@ import ctypes
 import os
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnessai_amd.so")
+# NESSAI_AMD_LIBRARY points at another build of the same library (A/B timing of kernel variants)
+_LIB_PATH = os.environ.get("NESSAI_AMD_LIBRARY") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "libnessai_amd.so"
+)
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -35,8 +38,8 @@ SIGNATURES = {
     "nsa_populate_draw": (
         c_int,
         [c_void_p, c_void_p, c_ll, c_void_p, c_ull, c_ull, c_double, c_void_p, c_void_p, c_void_p,
-         c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-         c_int, c_int, c_void_p],
+         c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_int, c_int, c_void_p],
     ),
     "nsa_populate_weights": (c_int, [c_ll, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "nsa_max_key_init": (c_ll, []),

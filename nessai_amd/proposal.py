@@ -2,9 +2,9 @@
 
 Counterpart of the reference's ``nessai.proposal.FlowProposal``
 (``src/nessai/proposal/flowproposal/flowproposal.py:29`` and its base
-``proposal/flowproposal/base.py:40``) for the default configuration of the
-benchmark configs: z-score reparameterisation
-(``reparameterisations/rescale.py:119-312``), latent-radius truncation
+``proposal/flowproposal/base.py:40``): per-parameter reparameterisations (z-score by
+default, ``reparameterisations/rescale.py:119-312``; rescale-to-bounds / logit / null through
+``nessai_amd.reparam``), latent-radius truncation
 (``truncation.py:201-365``, constant-volume by default, ``truncation.py:15-21``)
 and rejection sampling against the prior.  The sampler-facing protocol is the
 reference's (SURVEY.md §8b surface B3): ``initialise()``, ``train(live_points)``,
@@ -14,7 +14,7 @@ reference's (SURVEY.md §8b surface B3): ``initialise()``, ``train(live_points)`
 One pass of the populate loop is three device steps and one small copy:
 
 1. ``nsa_populate_draw``  — Philox latent draw, radius truncation, inverse
-   flow, inverse z-score, prior bounds, ``log_q`` (one fused kernel);
+   flow, inverse reparameterisation, prior bounds, ``log_q`` (one fused kernel);
 2. ``nsa_populate_weights`` — ``log_w = log_prior - log_q`` and its maximum
    (all-reduced over ranks when the draw batch is sharded);
 3. ``nsa_populate_accept`` — ``log_w - max > log(u)`` and order-preserving
@@ -37,7 +37,8 @@ from .livepoint import (
     get_dtype,
     live_points_to_array,
 )
-from .utils import compute_radius, rescale_log_jacobian
+from .reparam import ReparameterisationTable
+from .utils import compute_radius
 
 logger = logging.getLogger(__name__)
 
@@ -96,6 +97,8 @@ class FlowProposal:
         prior="auto",
         shard=False,
         precision="auto",
+        reparameterisations=None,
+        fallback_reparameterisation="z-score",
         plot=False,
         **kwargs,
     ):
@@ -137,6 +140,8 @@ class FlowProposal:
         if precision not in ("auto", "f32", "bf16x3"):
             raise ValueError("precision must be 'auto', 'f32' or 'bf16x3'")
         self.precision = precision
+        self.reparameterisations = reparameterisations
+        self.fallback_reparameterisation = fallback_reparameterisation
         self.device_seed = (
             int(device_seed) if device_seed is not None else int(self.rng.integers(0, 2**63 - 1))
         )
@@ -196,9 +201,13 @@ class FlowProposal:
                 self._poolsize_scale = 1.0
 
     def initialise(self):
-        """Set up the z-score rescaling and the flow (``base.py:358-391``)."""
-        self.scale = {n: 1.0 for n in self.names}
-        self.shift = {n: 0.0 for n in self.names}
+        """Set up the rescaling and the flow (``base.py:358-391``, ``:578-653``)."""
+        config = self.reparameterisations
+        if getattr(self.model, "reparameterisations", None) is not None:  # base.py:639-640
+            config = self.model.reparameterisations
+        self._reparam = ReparameterisationTable(
+            self.names, getattr(self.model, "bounds", None), config, fallback=self.fallback_reparameterisation
+        )
         if self.radius_mode == "constant_volume":  # truncation.py:292-308
             self.fixed_radius = compute_radius(self.dims, self.volume_fraction)
             self.fuzz = 1.0
@@ -232,52 +241,61 @@ class FlowProposal:
         self.populated = False
         self.initialised = True
 
-    # -- z-score reparameterisation --------------------------------------------
+    # -- reparameterisation (nessai_amd.reparam) -----------------------------------
+
+    @property
+    def scale(self):
+        """sigma of the scale-and-shift (z-score) parameters."""
+        return {p: g.scale[p] for g in self._reparam.groups if g.kind == "scale_shift" for p in g.parameters}
+
+    @property
+    def shift(self):
+        """mu of the scale-and-shift (z-score) parameters."""
+        return {p: (g.shift[p] if g.shift else 0.0) for g in self._reparam.groups if g.kind == "scale_shift"
+                for p in g.parameters}
 
     def check_state(self, x):
-        """Update sigma / mu from the live points (``rescale.py:293-304``)."""
-        for n in self.names:
-            self.scale[n] = float(np.std(x[n]))
-            self.shift[n] = float(np.mean(x[n]))
+        """Update the data-dependent constants from the live points (``base.py:850-868``):
+        z-score mean / std (``rescale.py:293-304``), rescale-to-bounds limits (``:720-741``)."""
+        if self._reparam.should_update:
+            self._reparam.update(x)
         self._upload_constants()
 
     def set_rescaling_constants(self, shift, scale):
-        """Set mu / sigma directly (arrays over ``model.names``)."""
-        for i, n in enumerate(self.names):
-            self.shift[n] = float(shift[i])
-            self.scale[n] = float(scale[i])
+        """Set mu / sigma of the z-score parameters directly (arrays over ``model.names``)."""
+        col = {n: i for i, n in enumerate(self.names)}
+        for g in self._reparam.groups:
+            if g.kind != "scale_shift":
+                continue
+            if g.shift is None:
+                g.shift = {}
+            for p in g.parameters:
+                g.shift[p] = float(shift[col[p]])
+                g.scale[p] = float(scale[col[p]])
         self._upload_constants()
 
     def _upload_constants(self):
         dev = self.device
         f64 = dict(dtype=torch.float64, device=dev)
-        self._scale_dev = torch.tensor([self.scale[n] for n in self.names], **f64)
-        self._shift_dev = torch.tensor([self.shift[n] for n in self.names], **f64)
+        kind, par, scale, shift, log_j = self._reparam.device_tables()
+        self._scale_dev = torch.tensor(scale, **f64)
+        self._shift_dev = torch.tensor(shift, **f64)
         self._lower_dev = torch.tensor(self.model.lower_bounds, **f64)
         self._upper_dev = torch.tensor(self.model.upper_bounds, **f64)
-        self._log_j_rescale = rescale_log_jacobian([self.scale[n] for n in self.names])
+        self._log_j_rescale = log_j
+        if self._reparam.all_scale_shift:
+            self._rp_kind_dev = self._rp_par_dev = None
+        else:
+            self._rp_kind_dev = torch.from_numpy(kind).to(dev)
+            self._rp_par_dev = torch.from_numpy(par).to(dev)
 
     def rescale(self, x):
-        """x -> (x', log|J|)   with x' = (x - mu) / sigma (``rescale.py:233-261``)."""
-        x_prime = empty_structured_array(x.size, names=self.prime_parameters)
-        log_J = np.zeros(x_prime.size)
-        for p, pp in zip(self.names, self.prime_parameters):
-            x_prime[pp] = (x[p] - self.shift[p]) / self.scale[p]
-            log_J -= np.log(np.abs(self.scale[p]))
-        for p in ("logP", "logL", "it"):
-            x_prime[p] = x[p]
-        return x_prime, log_J
+        """x -> (x', log|J|)  (``base.py:996-1030``)."""
+        return self._reparam.rescale(x)
 
     def inverse_rescale(self, x_prime):
-        """x' -> (x, log|J|)  (``rescale.py:263-291``)."""
-        x = empty_structured_array(x_prime.size, names=self.names)
-        log_J = np.zeros(x.size)
-        for p, pp in zip(self.names, self.prime_parameters):
-            x[p] = (x_prime[pp] * self.scale[p]) + self.shift[p]
-            log_J += np.log(np.abs(self.scale[p]))
-        for p in ("logP", "logL", "it"):
-            x[p] = x_prime[p]
-        return x, log_J
+        """x' -> (x, log|J|)  (``base.py:755-784``)."""
+        return self._reparam.inverse_rescale(x_prime)
 
     # -- training ----------------------------------------------------------------
 
@@ -317,7 +335,7 @@ class FlowProposal:
         log_q = torch.empty(n, dtype=torch.float64, device=dev)
         self._launch_draw(n, z_dev, 0, np.inf, x64, log_q, None)
         log_q_h = log_q.cpu().numpy()
-        keep = np.isfinite(log_q_h)
+        keep = ~np.isnan(log_q_h)  # NaN marks a dropped row; +inf (saturated logit) is kept as in the reference
         x = array_to_live_points_fast(x64.cpu().numpy()[keep], self.names)
         if return_z:
             return x, log_q_h[keep], z[keep]
@@ -357,7 +375,7 @@ class FlowProposal:
             lib.ptr(x64), lib.ptr(log_q), lib.ptr(z_out),
             lib.ptr(self._prior_kind_dev if log_prior is not None else None),
             lib.ptr(self._prior_par_dev if log_prior is not None else None), lib.ptr(log_prior),
-            lib.ptr(status), flow.waves_per_group, flow.max_groups, lib.c_void_p(stream),
+            lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), lib.ptr(status), flow.waves_per_group, flow.max_groups, lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_populate_draw")
 
@@ -541,7 +559,7 @@ class FlowProposal:
             self._weights_and_max(buf, n_local, reset_max=fresh)
             n_proposed += n_local
             self._draw_counter += n_local
-            valid = torch.isfinite(buf["log_w"][:n_local])
+            valid = ~torch.isnan(buf["log_q"][:n_local])  # every row backward_pass returns, weight -inf included
             if injected is not None:  # uniforms belong to draws: keep those of the kept rows
                 u_all.append(np.asarray(u_np, dtype=np.float64)[valid.cpu().numpy()])
             xs.append(buf["x64"][:n_local][valid].clone())
@@ -616,7 +634,8 @@ class FlowProposal:
         state = self.__dict__.copy()
         state["initialised"] = False
         state["_buffers"] = None
-        for k in ("_scale_dev", "_shift_dev", "_lower_dev", "_upper_dev"):
+        for k in ("_scale_dev", "_shift_dev", "_lower_dev", "_upper_dev", "_rp_kind_dev", "_rp_par_dev",
+                  "_prior_kind_dev", "_prior_par_dev"):
             state.pop(k, None)
         state["weights_file"] = getattr(self.flow, "weights_file", None) if self.flow else None
         state["flow"] = None

@@ -1,0 +1,375 @@
+"""Per-parameter reparameterisations of the proposal, host side and device tables.
+
+Counterpart of the part of the reference's reparameterisation registry
+(``src/nessai/reparameterisations/__init__.py:28-110``) that is a per-parameter, one-to-one
+map and therefore fits the epilogue of the fused draw kernel:
+
+====================================  =========================================================
+registry name                         map (x -> x')
+====================================  =========================================================
+``z-score`` ``zscore`` ``standardize``  ``ScaleAndShift`` with estimated mean / std
+                                      (``rescale.py:119-312``)
+``scaleandshift`` ``scale`` ``rescale``  ``ScaleAndShift`` / ``Rescale`` with fixed constants
+``default`` ``rescaletobounds``        ``RescaleToBounds`` to [-1, 1], bounds updated from the live
+``rescale-to-bounds``                  points (``rescale.py:321-731``)
+``offset``                            the same with the prior mid-point subtracted first
+``logit``                             ``RescaleToBounds`` to [0, 1] with the prior bounds, then
+                                      ``logit`` (``utils/rescaling.py:290-337``)
+``null`` ``none``                     ``NullReparameterisation`` (``null.py``)
+====================================  =========================================================
+
+Boundary inversion, angles, dequantisation and user-defined classes change the number of rows
+or couple parameters; they are not per-column maps and raise ``NotImplementedError`` here.
+
+The configuration forms are the reference's (``reparameterisations/utils.py:120-268``):
+``None`` | ``"name"`` | ``{parameter: "name"}`` | ``{parameter: {"reparameterisation": "name",
+**kwargs}}`` | ``{"name": {"parameters": [...], **kwargs}}`` | ``{"name": [patterns]}``;
+parameters without an entry get the fallback (``z-score``, ``proposal/flowproposal/base.py:115``).
+
+The x'-columns keep the order of ``model.names`` (the reference orders them by group, which is
+not observable by a flow trained from scratch).  The log-Jacobian is accumulated group by group
+and parameter by parameter in the reference's order (``combined.py:154-192``).
+"""
+
+import re
+
+import numpy as np
+
+from .livepoint import empty_structured_array
+
+# kinds of nsa_populate_draw's rp_kind table (nsa_flow_kernel.h NSA_RP_*)
+RP_SCALE_SHIFT, RP_NULL, RP_TO_BOUNDS, RP_TO_BOUNDS_LOGIT = 0, 1, 2, 3
+
+_KNOWN = {
+    "z-score": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
+    "zscore": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
+    "standardize": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
+    "scaleandshift": ("scale_shift", {}),
+    "scale": ("scale_shift", {}),
+    "rescale": ("scale_shift", {}),
+    "default": ("to_bounds", {}),
+    "rescaletobounds": ("to_bounds", {}),
+    "rescale-to-bounds": ("to_bounds", {}),
+    "offset": ("to_bounds", dict(offset=True)),
+    "logit": ("to_bounds", dict(rescale_bounds=[0.0, 1.0], update_bounds=False, post_rescaling="logit")),
+    "null": ("null", {}),
+    "none": ("null", {}),
+}
+_NON_SAMPLING = ("logP", "logL", "it")
+
+
+def _logit(x):
+    """(``utils/rescaling.py:290-315``, no clamping: the registry passes no eps)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        log_j = -np.log(x) - np.log1p(-x)
+        return np.log(x) - np.log1p(-x), log_j
+
+
+def _sigmoid(x):
+    """(``utils/rescaling.py:318-337``)."""
+    with np.errstate(over="ignore", divide="ignore"):
+        x = np.divide(1, 1 + np.exp(-x))
+        log_j = np.log(x) + np.log1p(-x)
+    return x, log_j
+
+
+class _Group:
+    """One reparameterisation instance of the reference: a kind and its parameters."""
+
+    def __init__(self, name, kind, parameters, prior_bounds, kwargs):
+        self.name = name
+        self.kind = kind
+        self.parameters = list(parameters)
+        kw = dict(kwargs)
+        if kind == "scale_shift":
+            self.estimate_scale = bool(kw.pop("estimate_scale", False))
+            self.estimate_shift = bool(kw.pop("estimate_shift", False))
+            scale, shift = kw.pop("scale", None), kw.pop("shift", None)
+            if scale is None and not self.estimate_scale:
+                raise RuntimeError("Must specify a scale or enable estimate_scale")  # rescale.py:176
+            self.scale = {p: 1.0 for p in self.parameters} if self.estimate_scale else self._values(scale, "scale")
+            if self.estimate_shift:
+                self.shift = {p: 0.0 for p in self.parameters}
+            elif shift:
+                self.shift = self._values(shift, "shift")
+            else:
+                self.shift = None
+            self.update_enabled = self.estimate_scale or self.estimate_shift
+        elif kind == "to_bounds":
+            missing = [p for p in self.parameters if p not in prior_bounds or not np.all(np.isfinite(prior_bounds[p]))]
+            if missing:
+                raise RuntimeError(f"{name} requires finite prior bounds, missing for {missing}")
+            self.prior_bounds = {p: np.asarray(prior_bounds[p], dtype=np.float64) for p in self.parameters}
+            rb = kw.pop("rescale_bounds", None)
+            if rb is None:
+                self.rescale_bounds = {p: [-1, 1] for p in self.parameters}
+            elif isinstance(rb, dict):
+                self.rescale_bounds = {p: list(rb[p]) for p in self.parameters}
+            else:
+                self.rescale_bounds = {p: list(rb) for p in self.parameters}
+            self.update_enabled = bool(kw.pop("update_bounds", True))
+            self.post = kw.pop("post_rescaling", None)
+            if self.post not in (None, "logit"):
+                raise NotImplementedError(f"post_rescaling={self.post!r} has no device map")
+            if self.post == "logit":
+                if self.update_enabled:
+                    raise RuntimeError("Cannot use log or logit with update bounds")  # rescale.py:491-495
+                self.rescale_bounds = {p: [0, 1] for p in self.parameters}
+            if kw.pop("boundary_inversion", None) or kw.pop("detect_edges", False):
+                raise NotImplementedError("boundary inversion changes the row count; not a per-column map")
+            if kw.pop("offset", False):  # rescale.py:467-475
+                self.offsets = {p: b[0] + np.ptp(b) / 2 for p, b in self.prior_bounds.items()}
+            else:
+                self.offsets = {p: 0.0 for p in self.parameters}
+            self.set_bounds()
+        elif kind == "null":
+            self.update_enabled = False
+        if kw:
+            raise TypeError(f"Unknown arguments for reparameterisation {name}: {sorted(kw)}")
+
+    def _values(self, value, what):
+        """(``rescale.py:206-231``)."""
+        if isinstance(value, (int, float)):
+            return {p: float(value) for p in self.parameters}
+        if isinstance(value, list):
+            if len(value) != len(self.parameters):
+                raise RuntimeError(f"{what} list is a different length to the parameters.")
+            return {p: float(v) for p, v in zip(self.parameters, value)}
+        if isinstance(value, dict):
+            if set(value) != set(self.parameters):
+                raise RuntimeError(f"Mismatched parameters with {what} dict")
+            return {p: float(v) for p, v in value.items()}
+        raise TypeError(f"{what} input must be an instance of int, list or dict")
+
+    def set_bounds(self):
+        """(``rescale.py:702-718``)."""
+        self.factor = {p: np.ptp(self.rescale_bounds[p]) for p in self.parameters}
+        self.rshift = {p: self.rescale_bounds[p][0] for p in self.parameters}
+        self.bounds = {p: self.prior_bounds[p] - self.offsets[p] for p in self.parameters}
+
+    def update(self, x):
+        if not self.update_enabled:
+            return
+        if self.kind == "scale_shift":  # rescale.py:293-304
+            for p in self.parameters:
+                if self.estimate_scale:
+                    self.scale[p] = np.std(x[p])
+                if self.estimate_shift:
+                    self.shift[p] = np.mean(x[p])
+        elif self.kind == "to_bounds":  # rescale.py:720-741
+            self.bounds = {
+                p: [np.min(x[p]) - self.offsets[p], np.max(x[p]) - self.offsets[p]] for p in self.parameters
+            }
+
+    def reset(self):
+        if self.kind == "scale_shift":  # rescale.py:306-312
+            for p in self.parameters:
+                if self.estimate_scale:
+                    self.scale[p] = 1.0
+                if self.estimate_shift:
+                    self.shift[p] = 0.0
+        elif self.kind == "to_bounds":
+            self.set_bounds()
+
+    # x -> x'
+    def forward(self, x, x_prime, log_j):
+        for p in self.parameters:
+            pp = p + "_prime"
+            if self.kind == "null":
+                x_prime[pp] = x[p]
+            elif self.kind == "scale_shift":  # rescale.py:233-261
+                if self.shift:
+                    x_prime[pp] = (x[p] - self.shift[p]) / self.scale[p]
+                else:
+                    x_prime[pp] = x[p] / self.scale[p]
+                log_j -= np.log(np.abs(self.scale[p]))
+            else:  # rescale.py:515-535, 639-671
+                lo, hi = self.bounds[p]
+                v = self.factor[p] * ((x[p] - self.offsets[p] - lo) / (hi - lo)) + self.rshift[p]
+                log_j += -np.log(hi - lo) + np.log(self.factor[p])
+                if self.post == "logit":
+                    v, lj = _logit(v)
+                    log_j += lj
+                x_prime[pp] = v
+        return log_j
+
+    # x' -> x
+    def inverse(self, x_prime, x, log_j):
+        if self.kind == "to_bounds":
+            params = reversed(self.parameters)  # rescale.py:674-677
+        else:
+            params = self.parameters
+        for p in params:
+            pp = p + "_prime"
+            if self.kind == "null":
+                x[p] = x_prime[pp]
+            elif self.kind == "scale_shift":  # rescale.py:263-291
+                if self.shift:
+                    x[p] = (x_prime[pp] * self.scale[p]) + self.shift[p]
+                else:
+                    x[p] = x_prime[pp] * self.scale[p]
+                log_j += np.log(np.abs(self.scale[p]))
+            else:  # rescale.py:537-547, 673-700
+                v = x_prime[pp]
+                if self.post == "logit":
+                    v, lj = _sigmoid(v)
+                    log_j += lj
+                lo, hi = self.bounds[p]
+                v = (hi - lo) * (v - self.rshift[p]) / self.factor[p] + lo
+                log_j += np.log(hi - lo) - np.log(self.factor[p])
+                x[p] = v + self.offsets[p]
+        return log_j
+
+
+def _resolve(patterns, names):
+    """Exact names or full-match regular expressions (``utils.py:271-299``)."""
+    if isinstance(patterns, str):
+        patterns = [patterns]
+    out = []
+    for pat in patterns:
+        if pat in names:
+            out.append(pat)
+        else:
+            out.extend(n for n in names if re.fullmatch(pat, n))
+    return list(dict.fromkeys(out))
+
+
+def _lookup(name):
+    if not isinstance(name, str) or name.lower() not in _KNOWN:
+        raise NotImplementedError(
+            f"Reparameterisation {name!r} is not a per-parameter device map; supported: {sorted(_KNOWN)}"
+        )
+    kind, kwargs = _KNOWN[name.lower()]
+    return kind, dict(kwargs)
+
+
+class ReparameterisationTable:
+    """The proposal's x <-> x' map: ordered groups + the tables the draw kernel reads."""
+
+    def __init__(self, names, bounds, reparameterisations=None, fallback="z-score"):
+        self.names = list(names)
+        self.prime_names = [n + "_prime" for n in self.names]
+        bounds = {n: np.asarray(bounds[n], dtype=np.float64) for n in self.names} if bounds else {}
+        self.groups = []
+        cfg = reparameterisations
+        if cfg is None:
+            cfg = {}
+        elif isinstance(cfg, str):
+            cfg = {cfg: {"parameters": list(self.names)}}
+        elif not isinstance(cfg, dict):
+            raise TypeError(
+                f"Reparameterisations must be a dictionary, string or None, received {type(cfg).__name__}"
+            )
+        for key, spec in cfg.items():
+            if key in self.names:  # {parameter: name | dict}
+                if isinstance(spec, str) or spec is None:
+                    name, kwargs, params = spec, {}, [key]
+                elif isinstance(spec, dict):
+                    spec = dict(spec)
+                    name = spec.pop("reparameterisation", None)
+                    if name is None:
+                        raise RuntimeError(f"No reparameterisation found for {key}.")
+                    params = spec.pop("input_parameters", spec.pop("parameters", [key]))
+                    params, kwargs = _resolve(params, self.names), spec
+                else:
+                    raise TypeError(f"Unknown config type for: {key}.")
+                if name is None:
+                    name = "null"
+            else:  # {name: parameter | [patterns] | dict}
+                name = key
+                if isinstance(spec, (str, list)):
+                    params, kwargs = _resolve(spec, self.names), {}
+                elif isinstance(spec, dict):
+                    spec = dict(spec)
+                    spec.pop("reparameterisation", None)
+                    params = _resolve(spec.pop("input_parameters", spec.pop("parameters", [])), self.names)
+                    kwargs = spec
+                else:
+                    raise TypeError(f"Unknown config type for: {key}.")
+            self._add(name, params, bounds, kwargs)
+        others = [n for n in self.names if n not in self.parameters]
+        if others:
+            self._add(fallback, others, bounds, {})
+
+    @property
+    def parameters(self):
+        return [p for g in self.groups for p in g.parameters]
+
+    def _add(self, name, params, bounds, kwargs):
+        kind, defaults = _lookup(name)
+        taken = set(self.parameters)
+        clash = [p for p in params if p in taken]
+        if clash:
+            raise RuntimeError(f"Parameters {clash} already have a reparameterisation")
+        if not params:
+            return
+        defaults.update(kwargs)
+        self.groups.append(_Group(name, kind, params, bounds, defaults))
+
+    @property
+    def should_update(self):
+        return any(g.update_enabled for g in self.groups)
+
+    def update(self, x):
+        for g in self.groups:
+            g.update(x)
+
+    def reset(self):
+        for g in self.groups:
+            g.reset()
+
+    def rescale(self, x):
+        """x -> (x', log|J|)  (``proposal/flowproposal/base.py:996-1030``)."""
+        x_prime = empty_structured_array(x.size, names=self.prime_names)
+        log_j = np.zeros(x_prime.size)
+        for g in self.groups:
+            log_j = g.forward(x, x_prime, log_j)
+        for f in _NON_SAMPLING:
+            x_prime[f] = x[f]
+        return x_prime, log_j
+
+    def inverse_rescale(self, x_prime):
+        x = empty_structured_array(x_prime.size, names=self.names)
+        log_j = np.zeros(x.size)
+        for g in reversed(self.groups):
+            log_j = g.inverse(x_prime, x, log_j)
+        for f in _NON_SAMPLING:
+            x[f] = x_prime[f]
+        return x, log_j
+
+    # -- device tables ------------------------------------------------------------
+
+    @property
+    def all_scale_shift(self):
+        return all(g.kind == "scale_shift" for g in self.groups)
+
+    def device_tables(self):
+        """(kind int32[D], par float64[D,5], scale[D], shift[D], constant log|J|).
+
+        The constant is the row-independent part of ``inverse_rescale``'s log-Jacobian,
+        accumulated in the same order; the sigmoid terms are added per row by the kernel.
+        """
+        D = len(self.names)
+        kind = np.zeros(D, dtype=np.int32)
+        par = np.zeros((D, 5), dtype=np.float64)
+        scale = np.ones(D)
+        shift = np.zeros(D)
+        col = {n: i for i, n in enumerate(self.names)}
+        log_j = np.float64(0.0)
+        for g in reversed(self.groups):
+            params = list(reversed(g.parameters)) if g.kind == "to_bounds" else g.parameters
+            for p in params:
+                i = col[p]
+                if g.kind == "null":
+                    kind[i] = RP_NULL
+                elif g.kind == "scale_shift":
+                    kind[i] = RP_SCALE_SHIFT
+                    scale[i] = g.scale[p]
+                    shift[i] = g.shift[p] if g.shift else 0.0
+                    log_j += np.log(np.abs(g.scale[p]))
+                else:
+                    kind[i] = RP_TO_BOUNDS_LOGIT if g.post == "logit" else RP_TO_BOUNDS
+                    lo, hi = g.bounds[p]
+                    par[i] = [lo, hi, g.rshift[p], g.factor[p], g.offsets[p]]
+                    log_j += np.log(hi - lo) - np.log(g.factor[p])
+        return kind, par, scale, shift, float(log_j)

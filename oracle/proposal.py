@@ -312,16 +312,27 @@ class OracleFlowProposal:
         self.n_proposed = 0
         self.n_accepted = 0
         self.injected_latents = None  # iterator of (N, D) arrays, for parity tests
+        self.reparam = None  # optional oracle.reparam.OracleCombined replacing the z-score
 
     # -- reparameterisation (z-score) ---------------------------------------
 
     def update_rescaling(self, live_points):  # rescale.py:293-304
+        if self.reparam is not None:
+            self.reparam.update(live_points)
+            return
         for n in self.names:
             self.scale[n] = np.std(live_points[n])
             self.shift[n] = np.mean(live_points[n])
 
     def rescale(self, x):  # rescale.py:233-261
         x_prime = empty_structured_array(x.size, self.prime_names)
+        if self.reparam is not None:
+            cols, log_J = self.reparam.rescale(x, x.size)
+            for pp in self.prime_names:
+                x_prime[pp] = cols[pp]
+            for p in NON_SAMPLING:
+                x_prime[p] = x[p]
+            return x_prime, log_J
         log_J = np.zeros(x_prime.size)
         for p, pp in zip(self.names, self.prime_names):
             x_prime[pp] = (x[p] - self.shift[p]) / self.scale[p]
@@ -332,6 +343,13 @@ class OracleFlowProposal:
 
     def inverse_rescale(self, x_prime):  # rescale.py:263-291, base.py:755-784
         x = empty_structured_array(x_prime.size, self.names)
+        if self.reparam is not None:
+            cols, log_J = self.reparam.inverse_rescale(x_prime, x_prime.size)
+            for p in self.names:
+                x[p] = cols[p]
+            for p in NON_SAMPLING:
+                x[p] = x_prime[p]
+            return x, log_J
         log_J = np.zeros(x.size)
         for p, pp in zip(self.names, self.prime_names):
             value = x_prime[pp]

@@ -127,6 +127,121 @@ def test_populate_injected_matches_oracle(cfg):
     assert prop.populated and sorted(prop.indices) == list(range(prop.samples.size))
 
 
+REPARAM_CONFIG = {"logit": ["x_0", "x_3"], "default": ["x_1"], "offset": ["x_5"], "null": ["x_2"]}  # x_4: z-score
+
+
+def build_with_reparameterisations(seed=3, **kwargs):
+    """6-D Rosenbrock proposal pair with a mixed reparameterisation table."""
+    from oracle import reparam as OR
+
+    prop, oprop = build(6, "nsf", dict(n_neurons=16, n_blocks=3), reparameterisations=REPARAM_CONFIG, **kwargs)
+    b = {n: [-5.0, 5.0] for n in prop.names}
+    oprop.reparam = OR.OracleCombined([
+        OR.OracleRescaleToBounds(["x_0", "x_3"], b, rescale_bounds=[0.0, 1.0], update_bounds=False,
+                                 post_rescaling="logit"),
+        OR.OracleRescaleToBounds(["x_1"], b),
+        OR.OracleRescaleToBounds(["x_5"], b, offset=True),
+        OR.OracleNull(["x_2"]),
+        OR.OracleScaleAndShift(["x_4"], estimate_scale=True, estimate_shift=True),
+    ])
+    live = prop.model.new_point(400, rng=np.random.default_rng(seed))
+    for n in prop.names:  # concentrate the live points so that the flow's unit-scale output is inside the prior
+        live[n] = 0.4 * live[n]
+    live["x_2"] = 0.1 * live["x_2"]
+    prop.check_state(live)
+    oprop.update_rescaling(live)
+    return prop, oprop, live
+
+
+def test_backward_pass_with_reparameterisation_table_matches_oracle():
+    """rescale-to-bounds / logit / null / z-score columns in the draw kernel's epilogue
+    (rescale.py:673-700, utils/rescaling.py:318-337) against the CPU restatement."""
+    prop, oprop, live = build_with_reparameterisations()
+    assert prop._rp_kind_dev is not None
+    z = np.random.default_rng(0).normal(size=(6000, 6)).astype(np.float32).astype(np.float64) * 1.2
+    x, log_q, z_kept = prop.backward_pass(z, return_z=True)
+    x_o, log_q_o, z_o = oprop.backward_pass(z)
+    assert len(x_o) > 1000
+    assert len(x) == len(x_o) and np.array_equal(z_kept, z_o)
+    for n in prop.names:
+        np.testing.assert_allclose(x[n], x_o[n], rtol=0, atol=1e-3 if n in ("x_0", "x_3") else 2e-4)
+    np.testing.assert_allclose(log_q, log_q_o, rtol=1e-5, atol=2e-4)
+    # host rescale is the reference arithmetic: forward_pass agrees with the oracle too
+    zf, lp = prop.forward_pass(live[:200])
+    zf_o, lp_o = oprop.forward_pass(live[:200])
+    np.testing.assert_allclose(zf, zf_o, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(lp, lp_o, rtol=1e-5, atol=2e-4)
+
+
+def test_saturated_sigmoid_rows_are_kept_with_infinite_log_q():
+    """sigmoid(x') == 1.0 in float64: log|J| = -inf, log_q = +inf; the reference keeps the row
+    (in bounds, never accepted) - flowproposal.py:366-389.  Every parameter uses the logit map so
+    that the saturated rows cannot leave the prior bounds through another column."""
+    from oracle import reparam as OR
+
+    prop, oprop = build(6, "nsf", dict(n_neurons=16, n_blocks=3), reparameterisations="logit")
+    names = list(prop.names)
+    oprop.reparam = OR.OracleCombined([
+        OR.OracleRescaleToBounds(names, {n: [-5.0, 5.0] for n in names}, rescale_bounds=[0.0, 1.0],
+                                 update_bounds=False, post_rescaling="logit"),
+    ])
+    z = np.random.default_rng(1).normal(size=(200, 6)).astype(np.float32).astype(np.float64) * 0.3
+    z[:7, 2] = 40.0  # linear tails: the value passes through the flow unchanged
+    x, log_q, z_kept = prop.backward_pass(z, return_z=True)
+    x_o, log_q_o, z_o = oprop.backward_pass(z)
+    assert len(x_o) == 200 and np.array_equal(z_kept, z_o)
+    sat_o = np.isposinf(log_q_o)
+    assert sat_o.sum() == 7
+    assert np.array_equal(np.isposinf(log_q), sat_o)
+    for n in names:
+        np.testing.assert_allclose(x[n], x_o[n], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(log_q[~sat_o], log_q_o[~sat_o], rtol=1e-5, atol=2e-4)
+    log_w = prop.compute_weights(x, log_q)  # such rows are proposed but can never be accepted
+    assert np.all(np.isneginf(log_w[sat_o]))
+
+
+def test_populate_with_reparameterisation_table_matches_oracle():
+    prop, oprop, _ = build_with_reparameterisations(poolsize=200, drawsize=3000)
+    g = np.random.default_rng(12)
+    batches = [(g.normal(size=(3000, 6)).astype(np.float32).astype(np.float64), g.random(3000)) for _ in range(60)]
+    radius = OP.compute_radius(6, 0.95)
+    used = []
+
+    class Rng:
+        def __init__(self):
+            self.k = 0
+
+        def random(self, n):
+            z, u = batches[self.k]
+            kept = used[self.k]
+            self.k += 1
+            return u[kept]
+
+        def permutation(self, n):
+            return np.arange(n)
+
+    orig_backward = oprop.backward_pass
+
+    def tracking_backward(z_trunc):
+        x, lq, zk = orig_backward(z_trunc)
+        zb = batches[len(used)][0]
+        lookup = {row.tobytes(): i for i, row in enumerate(zb)}
+        used.append(np.array([lookup[row.tobytes()] for row in zk], dtype=np.int64))
+        return x, lq, zk
+
+    oprop.backward_pass = tracking_backward
+    oprop.injected_latents = (z for z, _ in batches)
+    oprop.rng = Rng()
+    oprop.populate(n_samples=200, r=radius)
+    prop.populate(None, n_samples=200, r=radius, injected=iter(batches))
+    assert prop.n_proposed == oprop.n_proposed
+    assert abs(prop.n_accepted - oprop.n_accepted) <= max(2, int(0.01 * oprop.n_accepted))
+    if prop.n_accepted == oprop.n_accepted:
+        a = np.stack([prop.x[n] for n in prop.names], axis=1)
+        b = np.stack([oprop.x[n] for n in oprop.names], axis=1)
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-3)
+
+
 def test_device_latents_match_numpy_philox():
     """The in-kernel Philox4x32-10 + Box-Muller stream equals its numpy restatement."""
     prop, _ = build(7, "nsf", dict(n_neurons=16, n_blocks=2))
