@@ -15,6 +15,7 @@
 // the layer in place (only the transformed columns are saved).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/nessai_amd.h"
@@ -199,12 +200,11 @@ struct TrConsts {
 // one thread per (row, transformed feature).  Forward: saves x, writes y in place,
 // atomically accumulates log|det J| per row.
 template <int K>
-__global__ void tr_rq_forward(int n, int d_tr, const int* __restrict__ tr_cols, const float* __restrict__ P,
-                              float* __restrict__ X, int ldx, float* __restrict__ xsave,
-                              float* __restrict__ logdet, TrConsts c) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * d_tr) return;
-  const int row = t / d_tr, m = t - row * d_tr;
+__device__ __forceinline__ void tr_rq_forward_item(int row, int m, int d_tr, const int* __restrict__ tr_cols,
+                                                   const float* __restrict__ P, float* __restrict__ X, int ldx,
+                                                   float* __restrict__ xsave, float* __restrict__ logdet,
+                                                   const TrConsts& c) {
+  const int t = row * d_tr + m;
   constexpr int NP = 3 * K - 1;
   float v[NP];
 #pragma unroll
@@ -229,18 +229,27 @@ __global__ void tr_rq_forward(int n, int d_tr, const int* __restrict__ tr_cols, 
   atomicAdd(&logdet[row], ld);
 }
 
+template <int K>
+__global__ void tr_rq_forward(int n, int d_tr, const int* __restrict__ tr_cols, const float* __restrict__ P,
+                              float* __restrict__ X, int ldx, float* __restrict__ xsave,
+                              float* __restrict__ logdet, TrConsts c) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * d_tr) return;
+  const int row = t / d_tr;
+  tr_rq_forward_item<K>(row, t - row * d_tr, d_tr, tr_cols, P, X, ldx, xsave, logdet, c);
+}
+
 // Backward of the spline (hand-derived reverse mode of NsaRQ::phase, forward
 // direction).  Inputs: saved x, parameters, upstream gy = dL/dy (read from
 // Gx[row][col]) and gld = dL/dlogdet (same for every row).  Outputs: dL/dx
 // (overwrites Gx[row][col]), dL/dparams (GP), and X[row][col] restored to x.
 template <int K>
-__global__ void tr_rq_backward(int n, int d_tr, const int* __restrict__ tr_cols, const float* __restrict__ P,
-                               const float* __restrict__ xsave, float* __restrict__ X, int ldx,
-                               float* __restrict__ Gx, const float* __restrict__ gld_rows,
-                               float* __restrict__ GP, TrConsts c) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * d_tr) return;
-  const int row = t / d_tr, m = t - row * d_tr;
+__device__ __forceinline__ void tr_rq_backward_item(int row, int m, int d_tr, const int* __restrict__ tr_cols,
+                                                    const float* __restrict__ P, const float* __restrict__ xsave,
+                                                    float* __restrict__ X, int ldx, float* __restrict__ Gx,
+                                                    const float* __restrict__ gld_rows, float* __restrict__ GP,
+                                                    const TrConsts& c) {
+  const int t = row * d_tr + m;
   constexpr int NP = 3 * K - 1;
   const float gld = gld_rows[row];
   const int col = tr_cols[m];
@@ -382,13 +391,23 @@ __global__ void tr_rq_backward(int n, int d_tr, const int* __restrict__ tr_cols,
   for (int i = 0; i < NP; ++i) GP[(long long)t * NP + i] = gp[i];
 }
 
-// affine coupling: P row-major [n][2*d_tr] = [shift block | raw-scale block]
-__global__ void tr_affine_forward(int n, int d_tr, int additive, const int* __restrict__ tr_cols,
-                                  const float* __restrict__ P, float* __restrict__ X, int ldx,
-                                  float* __restrict__ xsave, float* __restrict__ logdet) {
+template <int K>
+__global__ void tr_rq_backward(int n, int d_tr, const int* __restrict__ tr_cols, const float* __restrict__ P,
+                               const float* __restrict__ xsave, float* __restrict__ X, int ldx,
+                               float* __restrict__ Gx, const float* __restrict__ gld_rows,
+                               float* __restrict__ GP, TrConsts c) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * d_tr) return;
-  const int row = t / d_tr, m = t - row * d_tr;
+  const int row = t / d_tr;
+  tr_rq_backward_item<K>(row, t - row * d_tr, d_tr, tr_cols, P, xsave, X, ldx, Gx, gld_rows, GP, c);
+}
+
+// affine coupling: P row-major [n][2*d_tr] = [shift block | raw-scale block]
+__device__ __forceinline__ void tr_affine_forward_item(int row, int m, int d_tr, int additive,
+                                                       const int* __restrict__ tr_cols,
+                                                       const float* __restrict__ P, float* __restrict__ X, int ldx,
+                                                       float* __restrict__ xsave, float* __restrict__ logdet) {
+  const int t = row * d_tr + m;
   const int np = additive ? d_tr : 2 * d_tr;
   const int col = tr_cols[m];
   const float x = X[(long long)row * ldx + col];
@@ -403,13 +422,23 @@ __global__ void tr_affine_forward(int n, int d_tr, int additive, const int* __re
   if (!additive) atomicAdd(&logdet[row], ls);
 }
 
-__global__ void tr_affine_backward(int n, int d_tr, int additive, const int* __restrict__ tr_cols,
-                                   const float* __restrict__ P, const float* __restrict__ xsave,
-                                   float* __restrict__ X, int ldx, float* __restrict__ Gx,
-                                   const float* __restrict__ gld_rows, float* __restrict__ GP) {
+__global__ void tr_affine_forward(int n, int d_tr, int additive, const int* __restrict__ tr_cols,
+                                  const float* __restrict__ P, float* __restrict__ X, int ldx,
+                                  float* __restrict__ xsave, float* __restrict__ logdet) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * d_tr) return;
-  const int row = t / d_tr, m = t - row * d_tr;
+  const int row = t / d_tr;
+  tr_affine_forward_item(row, t - row * d_tr, d_tr, additive, tr_cols, P, X, ldx, xsave, logdet);
+}
+
+__device__ __forceinline__ void tr_affine_backward_item(int row, int m, int d_tr, int additive,
+                                                        const int* __restrict__ tr_cols,
+                                                        const float* __restrict__ P,
+                                                        const float* __restrict__ xsave, float* __restrict__ X,
+                                                        int ldx, float* __restrict__ Gx,
+                                                        const float* __restrict__ gld_rows,
+                                                        float* __restrict__ GP) {
+  const int t = row * d_tr + m;
   const float gld = gld_rows[row];
   const int np = additive ? d_tr : 2 * d_tr;
   const int col = tr_cols[m];
@@ -423,6 +452,16 @@ __global__ void tr_affine_backward(int n, int d_tr, int additive, const int* __r
   const float s_b = gy * x + gld / scale;
   GP[(long long)row * np + d_tr + m] = s_b * sig * (1.0f - sig);
   Gx[(long long)row * ldx + col] = gy * scale;
+}
+
+__global__ void tr_affine_backward(int n, int d_tr, int additive, const int* __restrict__ tr_cols,
+                                   const float* __restrict__ P, const float* __restrict__ xsave,
+                                   float* __restrict__ X, int ldx, float* __restrict__ Gx,
+                                   const float* __restrict__ gld_rows, float* __restrict__ GP) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * d_tr) return;
+  const int row = t / d_tr;
+  tr_affine_backward_item(row, t - row * d_tr, d_tr, additive, tr_cols, P, xsave, X, ldx, Gx, gld_rows, GP);
 }
 
 // ---------------------------------------------------------------------------
@@ -689,6 +728,8 @@ __global__ void tr_copy_rows(long long n, const float* __restrict__ src, float* 
   if (i < n) dst[i] = src[i];
 }
 
+#include "nsa_train_fused.h"
+
 // ---------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------
@@ -696,13 +737,14 @@ __global__ void tr_copy_rows(long long n, const float* __restrict__ src, float* 
 // plan (int64, host): header then one fixed-size record per layer, forward order
 //   [0] D  [1] H  [2] L (residual blocks)  [3] n_layers  [4] transform  [5] bins
 //   [6] activation  [7] params per transformed feature  [8] n trainable floats  [9] record words
+//   [10] offset (in the int32 device table) of the transposition map of the trainable floats
 //   coupling  : {1, d_id, d_tr, id_cols offset, tr_cols offset (int32 device table),
 //                flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf}
 //   batch norm: {2, cols offset, off unconstrained_weight, off bias, off running_mean,
 //                off running_var, eps (float bits), momentum (float bits)}
 //   LU linear : {3, cols offset, off lower_entries, off upper_entries, off unconstrained_upper_diag,
 //                off bias, eps (float bits)}
-#define TR_HDR 10
+#define TR_HDR 11
 enum { TR_COUPLING = 1, TR_BATCHNORM = 2, TR_LU = 3 };
 
 static inline float tr_bits(long long v) {
@@ -715,6 +757,7 @@ static inline float tr_bits(long long v) {
 struct TrWs {  // workspace carve (floats)
   float *scal;      // [0] grad sq-norm, [1] constant log|det J| of the pass
   float *x, *gx, *logdet, *gld, *gp, *gh, *gu;
+  float* wt;        // transposed copy of the weight matrices (fused kernels)
   float* layer_base;
   long long per_layer;
   long long xsave_words;  // n * max(d_tr): size of a coupling layer's saved-input block
@@ -738,7 +781,7 @@ extern "C" NSA_API size_t nsa_train_workspace_floats(const long long* plan, long
   long long d_tr_max, np_max, per_layer;
   tr_sizes(plan, n, d_tr_max, np_max, per_layer);
   const long long D = plan[0], H = plan[1], NL = plan[3];
-  return (size_t)(64 + 2 * n * D + 2 * n + n * np_max + 2 * n * H + NL * per_layer);
+  return (size_t)(64 + 2 * n * D + 2 * n + n * np_max + 2 * n * H + NL * per_layer + plan[8]);
 }
 
 static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
@@ -754,7 +797,8 @@ static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
   w.gp = p; p += n * np_max;
   w.gh = p; p += n * H;
   w.gu = p; p += n * H;
-  w.layer_base = p;
+  w.layer_base = p; p += plan[3] * per_layer;
+  w.wt = p;
   w.per_layer = per_layer;
   w.xsave_words = n * d_tr_max;
 }
@@ -771,6 +815,36 @@ static inline dim3 blocks_for(long long work) { return dim3((unsigned)((work + 2
     else if ((K) == 10) hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__);                                \
     else hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__);                                               \
   } while (0)
+
+// fused coupling kernels (nsa_train_fused.h): used when the conditioner fits their LDS tiles;
+// NESSAI_AMD_TRAIN_FUSED=0 selects the layer-wise kernels (kept as the cross-check of the tests)
+static bool tr_use_fused(const long long* plan) {
+  const char* e = getenv("NESSAI_AMD_TRAIN_FUSED");  // read per call: the tests flip it
+  const bool enabled = !(e != nullptr && e[0] == '0');
+  return enabled && plan[1] <= 128 && plan[2] <= TRF_MAX_L;  // H <= 128: at most 8 tiles of gh per workgroup
+}
+
+template <int K>
+static hipError_t tr_launch_fused(bool backward, const TrfArgs& a, hipStream_t s) {
+  const size_t floats = backward ? (size_t)(4 * TRF_ROWS * a.ld + TRF_ROWS * (a.ch + 1))
+                                 : (size_t)(2 * TRF_ROWS * a.ld);
+  const size_t lds = floats * sizeof(float);
+  auto kern = backward ? trf_backward<K> : trf_forward<K>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)((a.n + TRF_ROWS - 1) / TRF_ROWS);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(TRF_THREADS), lds, s, a);
+  return hipGetLastError();
+}
+
+static hipError_t tr_fused_coupling(bool backward, int transform, int K, const TrfArgs& a, hipStream_t s) {
+  if (transform != NSA_T_RQ) return tr_launch_fused<0>(backward, a, s);
+  if (K == 4) return tr_launch_fused<4>(backward, a, s);
+  if (K == 8) return tr_launch_fused<8>(backward, a, s);
+  if (K == 10) return tr_launch_fused<10>(backward, a, s);
+  return tr_launch_fused<16>(backward, a, s);
+}
 
 // linear-layer block of the workspace
 struct TrLin {
@@ -808,6 +882,19 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
       float* u = h + (long long)(L + 1) * n * H;
       float* p = u + (long long)L * n * H;
       const int np = d_tr * npf;
+      if (tr_use_fused(plan)) {
+        TrfArgs a;
+        memset(&a, 0, sizeof(a));
+        a.n = (int)n; a.D = D; a.H = H; a.L = L; a.d_id = d_id; a.d_tr = d_tr; a.np = np; a.act = act;
+        a.transform = transform;
+        a.ld = ((H > d_id ? H : d_id) + 1) | 1;
+        a.wt = w.wt;
+        a.id_cols = id_cols; a.tr_cols = tr_cols; a.params = params; a.X = w.x; a.xsave = xsave;
+        a.h = h; a.u = u; a.p = p; a.logdet = w.logdet; a.c = c;
+        for (int i = 0; i < 4 + 4 * L; ++i) a.off[i] = off[i];
+        (void)tr_fused_coupling(false, transform, K, a, s);
+        continue;
+      }
       hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, d_id, H, w.x, D, id_cols, ACT_NONE,
                          params + off[0], params + off[1], (const float*)nullptr, h, H);
       for (int l = 0; l < L; ++l) {
@@ -880,6 +967,19 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       float* u = h + (long long)(L + 1) * n * H;
       float* p = u + (long long)L * n * H;
       const int np = d_tr * npf;
+      if (tr_use_fused(plan)) {
+        TrfArgs a;
+        memset(&a, 0, sizeof(a));
+        a.n = (int)n; a.D = D; a.H = H; a.L = L; a.d_id = d_id; a.d_tr = d_tr; a.np = np; a.act = act;
+        a.transform = transform;
+        a.ld = ((H > d_id ? H : d_id) + 1) | 1;
+        a.ch = H > 96 ? 64 : 128;  // keeps the backward workgroup inside 160 KB of LDS
+        a.id_cols = id_cols; a.tr_cols = tr_cols; a.params = params; a.grads = grads; a.X = w.x; a.Gx = w.gx;
+        a.xsave = xsave; a.h = h; a.u = u; a.p = p; a.gp = w.gp; a.gld = w.gld; a.c = c;
+        for (int i = 0; i < 4 + 4 * L; ++i) a.off[i] = off[i];
+        (void)tr_fused_coupling(true, transform, K, a, s);
+        continue;
+      }
       if (transform == NSA_T_RQ) {
         TR_SPLINE_DISPATCH(tr_rq_backward, K, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr, tr_cols, p,
                            xsave, w.x, D, w.gx, w.gld, w.gp, c);
@@ -957,6 +1057,11 @@ extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_d
   TrWs w;
   tr_carve(plan, n, workspace_dev, w);
   hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, x_dev, w.x);
+  if (tr_use_fused(plan)) {
+    (void)hipMemsetAsync(grads_dev, 0, n_params * sizeof(float), s);  // atomics accumulate
+    hipLaunchKernelGGL(tr_transpose_weights, blocks_for(n_params), dim3(256), 0, s, n_params, params_dev,
+                       tables_dev + plan[10], w.wt);
+  }
   tr_forward(plan, tables_dev, params_dev, consts, n, w, 1, s);
   hipLaunchKernelGGL(tr_loss, dim3(1), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
                      weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, (float*)nullptr, 1);
@@ -982,6 +1087,9 @@ extern "C" NSA_API int nsa_train_eval(const long long* plan, const int* tables_d
   TrWs w;
   tr_carve(plan, n, workspace_dev, w);
   hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, x_dev, w.x);
+  if (tr_use_fused(plan))
+    hipLaunchKernelGGL(tr_transpose_weights, blocks_for(plan[8]), dim3(256), 0, s, plan[8], params_dev,
+                       tables_dev + plan[10], w.wt);
   tr_forward(plan, tables_dev, const_cast<float*>(params_dev), consts, n, w, 0, s);
   hipLaunchKernelGGL(tr_loss, dim3(1), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
                      weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, log_prob_out_dev, 0);

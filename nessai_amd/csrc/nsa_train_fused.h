@@ -1,0 +1,376 @@
+// Fused training kernels of one coupling layer (included by nsa_train.hip).
+//
+// The layer-wise path of nsa_train.hip spends a minibatch step in ~150 launches of
+// 5-15 us kernels.  Here one workgroup (8 waves) owns 64 batch rows and runs a whole coupling
+// layer - conditioner (residual net), transform, and their reverse mode - with the
+// activations of the 64 rows in LDS:
+//
+//   trf_forward   x_id -> h_0 -> {u_l, h_{l+1}} -> parameters -> spline/affine forward
+//                 (saves h_l, u_l, parameters and the transformed inputs for the backward pass,
+//                  exactly the workspace layout of the layer-wise path)
+//   trf_backward  transform backward -> final layer -> residual blocks -> initial layer:
+//                 dX chains stay in LDS, weight gradients are 64-row partial products
+//                 added to the flat gradient with float atomics (the flat gradient is
+//                 zeroed once per step)
+//
+// GEMMs are v_mfma_f32_32x32x2_f32 with exact float32 products (training keeps full
+// precision).  Operand roles are chosen so that LDS reads are conflict-free (odd row
+// stride) and global accesses run along rows:
+//   forward  D[i = row][jj = out]   A = act(LDS[row][k])         B = W^T[k][out] (global, coalesced;
+//                                                                    the transposed copy is rebuilt once per step)
+//   dX       D[i = row][jj = in]    A = G LDS[row][out]          B = W[out][in]  (global, coalesced)
+//   dW       D[i = out][jj = in]    A = G LDS[row][out] (k=row)  B = act(LDS[row][in])
+// Reference semantics: glasflow.nflows ResidualNet (call sites src/nessai/flows/nsf.py:85-95,
+// realnvp.py:136-146) under FlowModel._train (src/nessai/flowmodel/base.py:365-452).
+#pragma once
+
+#define TRF_ROWS 64
+#define TRF_THREADS 512
+#define TRF_WAVES 8
+#define TRF_MAX_L 8
+
+struct TrfArgs {
+  int n, D, H, L, d_id, d_tr, np, act, transform, ld;  // ld: odd LDS row stride >= max(H, d_id) + 1
+  int ch;  // parameters per chunk of the last layer's backward pass (64 or 128)
+  const int* id_cols;
+  const int* tr_cols;
+  const float* params;
+  const float* wt;  // the weight matrices transposed ([in][out]) at the same flat offsets
+  float* grads;
+  float* X;       // [n][D] current values (in/out)
+  float* Gx;      // [n][D] dL/dX (backward)
+  float* xsave;   // [n][d_tr]
+  float* h;       // [L + 1][n][H]
+  float* u;       // [L][n][H]
+  float* p;       // [n][np] transform parameters
+  float* gp;      // [n][np] their gradient
+  float* logdet;  // [n]
+  const float* gld;  // [n] dL/dlogdet
+  TrConsts c;
+  long long off[2 + 4 * TRF_MAX_L + 2];  // flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf
+};
+
+// wt[tmap[i]] = params[i]: every weight matrix [out][in] lands transposed at its own offset
+__global__ void tr_transpose_weights(long long n, const float* __restrict__ p, const int* __restrict__ tmap,
+                                     float* __restrict__ wt) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) wt[tmap[i]] = p[i];
+}
+
+// rows [r0, r0 + 64) x cols [c0, c0 + nc) of a row-major global matrix -> LDS tile[r][c], zero padded
+__device__ __forceinline__ void trf_stage(float* __restrict__ tile, int ld, const float* __restrict__ src,
+                                          int src_ld, int r0, int n, int c0, int nc, int nc_valid,
+                                          const int* __restrict__ cols, int tid) {
+  // flattened (row, col) index; 4 loads in flight per thread before the LDS stores
+  const int total = TRF_ROWS * nc;
+  for (int base = tid; base < total; base += TRF_THREADS * 4) {
+    float v[4];
+    int dst[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = base + TRF_THREADS * q;
+      const int r = idx / nc, c = idx - r * nc;
+      const int row = r0 + r;
+      dst[q] = (idx < total) ? r * ld + c : -1;
+      v[q] = 0.0f;
+      if (idx < total && row < n && c < nc_valid)
+        v[q] = src[(unsigned)row * (unsigned)src_ld + (unsigned)(cols ? cols[c0 + c] : c0 + c)];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (dst[q] >= 0) tile[dst[q]] = v[q];
+  }
+}
+
+// out[row][o] = sum_k act(Ain[row][k]) W[o][k] + b[o] (+ R[row][o]); rows of the workgroup.
+// Wt = W^T [Kd][O].  out_lds / R may be null; out_lds == R is allowed (in-place residual update).
+__device__ __forceinline__ void trf_linear(const float* __restrict__ Ain, int Kd, int act_in,
+                                           const float* __restrict__ Wt, const float* __restrict__ b, int O,
+                                           const float* R, float* out_lds, float* __restrict__ out_glb,
+                                           int ld_glb, int ld, int r0, int n, int wave, int lane) {
+  const int half = lane >> 5, j = lane & 31;
+  const int OT = (O + 31) >> 5;
+  const int pairs = (Kd + 1) >> 1;
+  for (int t = wave; t < 2 * OT; t += TRF_WAVES) {
+    const int rt = t & 1, ot = t >> 1;
+    const int o = ot * 32 + j;
+    const bool o_ok = o < O;
+    const unsigned oc = (unsigned)(o_ok ? o : O - 1);
+    f32x16 acc = {0};
+    const float* ax = Ain + (rt * 32 + j) * ld;
+    for (int u0 = 0; u0 < pairs; u0 += 16) {
+      float wv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k = 2 * (u0 + q) + half;
+        wv[q] = Wt[(unsigned)(k < Kd ? k : Kd - 1) * (unsigned)O + oc];  // lanes along the row: coalesced
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (u0 + q < pairs) {  // wave-uniform
+          const int k = 2 * (u0 + q) + half;
+          const bool ok = k < Kd;
+          const float av = ok ? tr_act(ax[k < Kd ? k : 0], act_in) : 0.0f;
+          acc = nsa_mfma(av, (ok && o_ok) ? wv[q] : 0.0f, acc);
+        }
+      }
+    }
+    if (o_ok) {
+      const float bias = b[o];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r] + bias;
+        if (R) v += R[rl * ld + o];
+        if (out_lds) out_lds[rl * ld + o] = v;
+        if (r0 + rl < n) out_glb[(unsigned)(r0 + rl) * (unsigned)ld_glb + (unsigned)o] = v;
+      }
+    }
+  }
+}
+
+// out[row][k] (op)= (sum_o G[row][g-col o] W[o][k]) * act'(Z[row][k]);  add != 0: out += value
+// G, Z, out: LDS tiles of the workgroup's rows; W global [O][Kd].  Run by waves [w0, w0 + nw).
+__device__ __forceinline__ void trf_dx(const float* __restrict__ G, int g_ld, int O, const float* __restrict__ W,
+                                       int Kd, const float* Z, int act, float* out, int add, int ld, int wave,
+                                       int nw, int lane) {
+  const int half = lane >> 5, j = lane & 31;
+  const int KT = (Kd + 31) >> 5;
+  const int pairs = (O + 1) >> 1;
+  for (int t = wave; t < 2 * KT; t += nw) {
+    const int rt = t & 1, kt = t >> 1;
+    const int kcol = kt * 32 + j;
+    const unsigned wc = (unsigned)(kcol < Kd ? kcol : Kd - 1);
+    const bool col_ok = kcol < Kd;
+    f32x16 acc = {0};
+    const float* ag = G + (rt * 32 + j) * g_ld;
+    for (int u0 = 0; u0 < pairs; u0 += 16) {
+      float wv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int o = 2 * (u0 + q) + half;
+        wv[q] = W[(unsigned)(o < O ? o : O - 1) * (unsigned)Kd + wc];  // lanes along the row: coalesced
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (u0 + q < pairs) {  // wave-uniform
+          const int o = 2 * (u0 + q) + half;
+          const bool ok = o < O;
+          acc = nsa_mfma(ok ? ag[o] : 0.0f, (ok && col_ok) ? wv[q] : 0.0f, acc);
+        }
+      }
+    }
+    if (col_ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r];
+        if (Z) v *= tr_act_grad(Z[rl * ld + kcol], act);
+        if (add) v += out[rl * ld + kcol];
+        out[rl * ld + kcol] = v;
+      }
+    }
+  }
+}
+
+// gW[o][k] += sum_rows G[row][o] act(Ain[row][k]);  gb[o] += sum_rows G[row][o]
+// (64-row partial sums, float atomics).  o < O, k < Kd.  Run by waves [w0, w0 + nw).
+__device__ __forceinline__ void trf_dw(const float* __restrict__ G, int g_ld, int O, const float* __restrict__ Ain,
+                                       int a_ld, int Kd, int act_in, float* __restrict__ gW,
+                                       float* __restrict__ gb, int wave, int nw, int lane) {
+  const int half = lane >> 5, j = lane & 31;
+  const int OT = (O + 31) >> 5, KT = (Kd + 31) >> 5;
+  for (int t = wave; t < OT * KT; t += nw) {
+    const int ot = t / KT, kt = t - ot * KT;
+    const int oc = ot * 32 + j, kc = kt * 32 + j;
+    const bool o_ok = oc < O, k_ok = kc < Kd;
+    f32x16 acc = {0};
+#pragma unroll 4
+    for (int u_ = 0; u_ < TRF_ROWS / 2; ++u_) {
+      const int row = 2 * u_ + half;
+      const float av = o_ok ? G[row * g_ld + oc] : 0.0f;
+      const float bb = k_ok ? tr_act(Ain[row * a_ld + kc], act_in) : 0.0f;
+      acc = nsa_mfma(av, bb, acc);  // D[i = o][jj = k]
+    }
+    if (k_ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < O) atomicAdd(&gW[(unsigned)o * (unsigned)Kd + (unsigned)kc], acc[r]);
+      }
+    }
+  }
+  for (int o = wave * 64 + lane; o < O; o += nw * 64) {
+    float s = 0.0f;
+    for (int row = 0; row < TRF_ROWS; ++row) s += G[row * g_ld + o];
+    atomicAdd(&gb[o], s);
+  }
+}
+
+template <int K>  // spline bins; 0: affine / additive (a.transform)
+__global__ void __launch_bounds__(TRF_THREADS) trf_forward(TrfArgs a) {
+  extern __shared__ float trf_sm[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r0 = blockIdx.x * TRF_ROWS;
+  const int ld = a.ld, n = a.n, H = a.H;
+  float* A0 = trf_sm;
+  float* A1 = A0 + TRF_ROWS * ld;
+  const float* P = a.params;
+  const float* WT = a.wt;
+  const long long nH = (long long)n * H;
+
+  trf_stage(A0, ld, a.X, a.D, r0, n, 0, a.d_id, a.d_id, a.id_cols, tid);
+  __syncthreads();
+  // h_0 = W0 x_id + b0
+  trf_linear(A0, a.d_id, ACT_NONE, WT + a.off[0], P + a.off[1], H, nullptr, A1, a.h, H, ld, r0, n, wave, lane);
+  __syncthreads();
+  for (int l = 0; l < a.L; ++l) {
+    // u_l = W1 act(h_l) + b1;  h_{l+1} = h_l + W2 act(u_l) + b2
+    trf_linear(A1, H, a.act, WT + a.off[2 + 4 * l], P + a.off[3 + 4 * l], H, nullptr, A0, a.u + l * nH, H, ld, r0,
+               n, wave, lane);
+    __syncthreads();
+    trf_linear(A0, H, a.act, WT + a.off[4 + 4 * l], P + a.off[5 + 4 * l], H, A1, A1, a.h + (l + 1) * nH, H, ld,
+               r0, n, wave, lane);
+    __syncthreads();
+  }
+  // parameters = Wf h_L + bf (global only)
+  trf_linear(A1, H, ACT_NONE, WT + a.off[2 + 4 * a.L], P + a.off[3 + 4 * a.L], a.np, nullptr, nullptr, a.p, a.np,
+             ld, r0, n, wave, lane);
+  __syncthreads();  // the parameters of this workgroup's rows are visible to all its threads
+  const int items = TRF_ROWS * a.d_tr;
+  for (int e = tid; e < items; e += TRF_THREADS) {
+    const int r = e / a.d_tr, m = e - r * a.d_tr;
+    const int row = r0 + r;
+    if (row >= n) continue;
+    if constexpr (K > 0) {
+      tr_rq_forward_item<K>(row, m, a.d_tr, a.tr_cols, a.p, a.X, a.D, a.xsave, a.logdet, a.c);
+    } else {
+      tr_affine_forward_item(row, m, a.d_tr, a.transform == NSA_T_ADDITIVE ? 1 : 0, a.tr_cols, a.p, a.X, a.D,
+                             a.xsave, a.logdet);
+    }
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
+  extern __shared__ float trf_sm[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int r0 = blockIdx.x * TRF_ROWS;
+  const int ld = a.ld, n = a.n, H = a.H, np = a.np;
+  float* A0 = trf_sm;
+  float* A1 = A0 + TRF_ROWS * ld;
+  float* G0 = A1 + TRF_ROWS * ld;
+  float* G1 = G0 + TRF_ROWS * ld;
+  float* gc = G1 + TRF_ROWS * ld;  // [64][ch + 1] chunk of the parameter gradient
+  const float* P = a.params;
+  float* GR = a.grads;
+  const long long nH = (long long)n * H;
+  // the waves split into a dX group (0-3) and a dW group (4-7): the two products of every layer
+  // read the same tiles and write disjoint ones
+  const bool dx_group = wave < 4;
+  const int gw = wave & 3;
+
+  // transform backward: dL/dparameters -> a.gp, dL/dx_tr -> a.Gx, x restored in a.X
+  const int items = TRF_ROWS * a.d_tr;
+  for (int e = tid; e < items; e += TRF_THREADS) {
+    const int r = e / a.d_tr, m = e - r * a.d_tr;
+    const int row = r0 + r;
+    if (row >= n) continue;
+    if constexpr (K > 0) {
+      tr_rq_backward_item<K>(row, m, a.d_tr, a.tr_cols, a.p, a.xsave, a.X, a.D, a.Gx, a.gld, a.gp, a.c);
+    } else {
+      tr_affine_backward_item(row, m, a.d_tr, a.transform == NSA_T_ADDITIVE ? 1 : 0, a.tr_cols, a.p, a.xsave, a.X,
+                              a.D, a.Gx, a.gld, a.gp);
+    }
+  }
+  trf_stage(A1, ld, a.h + a.L * nH, H, r0, n, 0, H, H, nullptr, tid);  // h_L
+  __syncthreads();
+
+  // final layer, a.ch parameters at a time: dWf, dbf (waves 4-7) and gh = gp . Wf (waves 0-3)
+  const int KT = (H + 31) >> 5;  // <= 4: 2 KT <= 8 tiles of gh, two per wave of the dX group
+  f32x16 acc_dx[2];
+  acc_dx[0] = f32x16{0};
+  acc_dx[1] = f32x16{0};
+  const float* Wf = P + a.off[2 + 4 * a.L];
+  const int CH = a.ch, CLD = a.ch + 1;
+  for (int c0 = 0; c0 < np; c0 += CH) {
+    const int nc = (np - c0 < CH) ? (np - c0) : CH;
+    if (c0 > 0) __syncthreads();
+    trf_stage(gc, CLD, a.gp, np, r0, n, c0, CH, nc, nullptr, tid);
+    __syncthreads();
+    if (dx_group) {
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const int t = gw + 4 * s_;
+        if (t < 2 * KT) {
+          const int rt = t & 1, kt = t >> 1;
+          const int kcol = kt * 32 + j;
+          const unsigned wc = (unsigned)(kcol < H ? kcol : H - 1);
+          const bool col_ok = kcol < H;
+          const float* ag = gc + (rt * 32 + j) * CLD;
+          for (int u0 = 0; u0 < CH / 2; u0 += 16) {
+            if (2 * u0 < nc) {  // wave-uniform
+              float wv[16];
+#pragma unroll
+              for (int q = 0; q < 16; ++q) {
+                const int o = c0 + 2 * (u0 + q) + half;
+                wv[q] = Wf[(unsigned)(o < np ? o : np - 1) * (unsigned)H + wc];
+              }
+#pragma unroll
+              for (int q = 0; q < 16; ++q) {
+                const int oc = 2 * (u0 + q) + half;
+                const bool ok = oc < nc;
+                acc_dx[s_] = nsa_mfma(ok ? ag[oc] : 0.0f, (ok && col_ok) ? wv[q] : 0.0f, acc_dx[s_]);
+              }
+            }
+          }
+        }
+      }
+    } else {
+      trf_dw(gc, CLD, nc, A1, ld, H, ACT_NONE, GR + a.off[2 + 4 * a.L] + (long long)c0 * H,
+             GR + a.off[3 + 4 * a.L] + c0, gw, 4, lane);
+    }
+  }
+  if (dx_group) {
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int t = gw + 4 * s_;
+      if (t < 2 * KT) {
+        const int rt = t & 1, kt = t >> 1;
+        const int kcol = kt * 32 + j;
+        if (kcol < H) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            G0[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ld + kcol] = acc_dx[s_][r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int l = a.L - 1; l >= 0; --l) {
+    trf_stage(A0, ld, a.u + l * nH, H, r0, n, 0, H, H, nullptr, tid);  // u_l
+    trf_stage(A1, ld, a.h + l * nH, H, r0, n, 0, H, H, nullptr, tid);  // h_l
+    __syncthreads();
+    // h_{l+1} = h_l + W2 act(u_l) + b2
+    if (dx_group) trf_dx(G0, ld, H, P + a.off[4 + 4 * l], H, A0, a.act, G1, 0, ld, gw, 4, lane);
+    else trf_dw(G0, ld, H, A0, ld, H, a.act, GR + a.off[4 + 4 * l], GR + a.off[5 + 4 * l], gw, 4, lane);
+    __syncthreads();
+    // u_l = W1 act(h_l) + b1
+    if (dx_group) trf_dx(G1, ld, H, P + a.off[2 + 4 * l], H, A1, a.act, G0, 1, ld, gw, 4, lane);
+    else trf_dw(G1, ld, H, A1, ld, H, a.act, GR + a.off[2 + 4 * l], GR + a.off[3 + 4 * l], gw, 4, lane);
+    __syncthreads();
+  }
+
+  // initial layer: dW0, db0 and g_x[:, id_cols] += gh . W0 (x was restored above)
+  trf_stage(A0, ld, a.X, a.D, r0, n, 0, a.d_id, a.d_id, a.id_cols, tid);
+  __syncthreads();
+  if (dx_group) trf_dx(G0, ld, H, P + a.off[0], a.d_id, nullptr, ACT_NONE, G1, 0, ld, gw, 4, lane);
+  else trf_dw(G0, ld, H, A0, ld, a.d_id, ACT_NONE, GR + a.off[0], GR + a.off[1], gw, 4, lane);
+  __syncthreads();
+  for (int idx = tid; idx < TRF_ROWS * a.d_id; idx += TRF_THREADS) {
+    const int r = idx / a.d_id, k = idx - r * a.d_id;
+    const int row = r0 + r;
+    if (row < n) a.Gx[(unsigned)row * (unsigned)a.D + (unsigned)a.id_cols[k]] += G1[r * ld + k];
+  }
+}

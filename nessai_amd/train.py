@@ -72,6 +72,8 @@ class Trainer:
         def f32_bits(value):
             return int(np.array([value], dtype=np.float32).view(np.uint32)[0])
 
+        tmap = np.arange(total, dtype=np.int64)  # transposition map of the weight matrices
+
         for t in leaves:
             if hasattr(t, "_permutation"):
                 perm = t._permutation.detach().cpu().numpy()
@@ -93,6 +95,10 @@ class Trainer:
                 for layer in layers:
                     rec.append(offsets[id(layer.weight)])
                     rec.append(offsets[id(layer.bias)])
+                    o_, k_ = layer.weight.shape  # W[o][k] -> W^T[k][o] at the same offset
+                    base = offsets[id(layer.weight)]
+                    idx = np.arange(o_ * k_)
+                    tmap[base : base + o_ * k_] = base + (idx % k_) * o_ + idx // k_
                 records.append(rec)
             elif isinstance(t, M.BatchNorm):
                 rec = [2, len(tables), offsets[id(t.unconstrained_weight)], offsets[id(t.bias)],
@@ -121,7 +127,8 @@ class Trainer:
         rec_words = len(records[0])
         header = [D, desc["hidden"], n_res, len(records), pack.TRANSFORMS[desc["transform"]],
                   desc.get("bins", 0) if desc["transform"] == "rq" else 0,
-                  pack.ACTIVATIONS[desc["activation"]], n_tr, total, rec_words]
+                  pack.ACTIVATIONS[desc["activation"]], n_tr, total, rec_words, len(tables)]
+        tables = list(tables) + tmap.tolist()
         plan = header + [w for rec in records for w in rec]
         self.plan = (ctypes.c_longlong * len(plan))(*plan)
         self.tables = torch.tensor(tables, dtype=torch.int32, device=device)

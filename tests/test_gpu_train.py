@@ -257,3 +257,27 @@ def test_unsupported_training_configurations_raise():
     flow.to(DEV)
     with pytest.raises(NotImplementedError, match="residual conditioner"):
         Trainer(flow)
+
+
+@pytest.mark.parametrize("name", ["nsf_c3", "nsf_d7_k4", "nsf_d6_tanh", "rnvp_perm", "rnvp_additive", "nsf_bn_lu"])
+def test_fused_coupling_kernels_match_the_layer_wise_kernels(name, monkeypatch):
+    """The fused per-coupling kernels (nsa_train_fused.h) and the layer-wise kernels are two
+    implementations of the same step: loss identical, gradients equal up to summation order."""
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NESSAI_AMD_TRAIN_FUSED", mode)
+        ref, flow, D = pair(name)
+        x = (torch.randn(333, D, generator=torch.Generator().manual_seed(9)) * 1.5).to(DEV)
+        tr = Trainer(flow)
+        tr.step(x, clip_norm=5.0, lr=0.0)
+        torch.cuda.synchronize()
+        lp = torch.empty(333, dtype=torch.float32, device=DEV)
+        loss = tr.loss_acc.item()
+        tr.evaluate(x, log_prob_out=lp)
+        results[mode] = (loss, tr.grads.cpu().clone(), lp.cpu().clone())
+    (l0, g0, lp0), (l1, g1, lp1) = results["0"], results["1"]
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0))
+    scale = max(1e-3, float(g0.abs().max()))
+    assert float((g0 - g1).abs().max()) <= 5e-5 * scale
+    if name != "nsf_bn_lu":  # eval mode only differs for batch norm (running statistics after one step)
+        assert rel_err(lp0, lp1) <= 2e-6
