@@ -644,7 +644,10 @@ __global__ void tr_lu_grads(int D, const float* __restrict__ gL, const float* __
 // per row: log_prob = -0.5/var * sum z^2 - log_z + logdet
 // loss = -sum_i w_i log_prob_i / sum_i w_i   (w_i = 1 when `weights` is NULL: -mean(log_prob),
 // flowmodel/base.py:404-412); seeds the backward pass: Gx = z * w_i / (var * W),
-// gld_rows[i] = d loss / d logdet_i = -w_i / W.  One workgroup, fixed summation order.
+// gld_rows[i] = d loss / d logdet_i = -w_i / W.
+// One workgroup per 64 rows, 4 threads per row (coalesced row segments); every workgroup sums
+// the weights itself (fixed order) and adds its part of the loss with one atomic.
+#define TR_LOSS_ROWS 64
 __global__ void __launch_bounds__(256) tr_loss(int n, int D, const float* __restrict__ X, int ldx,
                                                const float* __restrict__ logdet,
                                                const float* __restrict__ ld_const,
@@ -653,29 +656,37 @@ __global__ void __launch_bounds__(256) tr_loss(int n, int D, const float* __rest
                                                float* __restrict__ loss_acc,
                                                float* __restrict__ log_prob_out, int want_grad) {
   __shared__ float sm[256];
-  float wsum = 0.0f;
-  for (int row = threadIdx.x; row < n; row += 256) wsum += weights ? weights[row] : 1.0f;
-  sm[threadIdx.x] = wsum;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+  float W = (float)n;
+  if (weights != nullptr) {
+    float wsum = 0.0f;
+    for (int row = threadIdx.x; row < n; row += 256) wsum += weights[row];
+    sm[threadIdx.x] = wsum;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+      __syncthreads();
+    }
+    W = sm[0];
     __syncthreads();
   }
-  const float W = sm[0];
-  __syncthreads();
+  const int row = blockIdx.x * TR_LOSS_ROWS + (threadIdx.x >> 2), part = threadIdx.x & 3;
   float local = 0.0f;
-  for (int row = threadIdx.x; row < n; row += 256) {
+  if (row < n) {
     const float wi = (weights ? weights[row] : 1.0f) / W;
     float e = 0.0f;
-    for (int c = 0; c < D; ++c) {
+    for (int c = part; c < D; c += 4) {
       const float z = X[(long long)row * ldx + c];
       e += z * z;
       if (want_grad) Gx[(long long)row * ldx + c] = z * inv_var * wi;
     }
-    if (want_grad) gld_rows[row] = -wi;
-    const float lp = -0.5f * inv_var * e - log_z + (logdet[row] + ld_const[0]);
-    if (log_prob_out) log_prob_out[row] = lp;
-    local += lp * wi;
+    e += __shfl_xor(e, 1);
+    e += __shfl_xor(e, 2);
+    if (part == 0) {
+      if (want_grad) gld_rows[row] = -wi;
+      const float lp = -0.5f * inv_var * e - log_z + (logdet[row] + ld_const[0]);
+      if (log_prob_out) log_prob_out[row] = lp;
+      local = lp * wi;
+    }
   }
   sm[threadIdx.x] = local;
   __syncthreads();
@@ -683,33 +694,37 @@ __global__ void __launch_bounds__(256) tr_loss(int n, int D, const float* __rest
     if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) loss_acc[0] += -sm[0];
+  if (threadIdx.x == 0) atomicAdd(&loss_acc[0], -sm[0]);
 }
 
-// sum of squares of the flat gradient (one workgroup => deterministic)
-__global__ void __launch_bounds__(1024) tr_grad_sqnorm(long long n, const float* __restrict__ g,
-                                                       float* __restrict__ out) {
-  __shared__ float sm[1024];
+// sum of squares of the flat gradient: TR_SQ_BLOCKS partial sums, added up in a fixed order by
+// the consumer (tr_adamw) => deterministic
+#define TR_SQ_BLOCKS 64
+__global__ void __launch_bounds__(256) tr_grad_sqnorm(long long n, const float* __restrict__ g,
+                                                      float* __restrict__ partial) {
+  __shared__ float sm[256];
   float s = 0.0f;
-  for (long long i = threadIdx.x; i < n; i += 1024) s += g[i] * g[i];
+  for (long long i = blockIdx.x * 256 + threadIdx.x; i < n; i += 256LL * TR_SQ_BLOCKS) s += g[i] * g[i];
   sm[threadIdx.x] = s;
   __syncthreads();
-  for (int off = 512; off > 0; off >>= 1) {
+  for (int off = 128; off > 0; off >>= 1) {
     if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = sm[0];
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
 }
 
 // clip_grad_norm_ (coef = min(1, max_norm / (norm + 1e-6))) fused with torch.optim.AdamW
 __global__ void tr_adamw(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                         float* __restrict__ v, const float* __restrict__ sqnorm, float max_norm, float lr,
+                         float* __restrict__ v, const float* __restrict__ sq_partial, float max_norm, float lr,
                          float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= n) return;
   float coef = 1.0f;
   if (max_norm > 0.0f) {
-    coef = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
+    float sq = 0.0f;
+    for (int b = 0; b < TR_SQ_BLOCKS; ++b) sq += sq_partial[b];
+    coef = max_norm / (sqrtf(sq) + 1e-6f);
     coef = coef < 1.0f ? coef : 1.0f;
   }
   const float grad = g[i] * coef;
@@ -755,7 +770,7 @@ static inline float tr_bits(long long v) {
 }
 
 struct TrWs {  // workspace carve (floats)
-  float *scal;      // [0] grad sq-norm, [1] constant log|det J| of the pass
+  float *scal;      // [1] constant log|det J| of the pass, [64..127] phase timestamps, [128..191] sq-norm partials
   float *x, *gx, *logdet, *gld, *gp, *gh, *gu;
   float* wt;        // transposed copy of the weight matrices (fused kernels)
   float* layer_base;
@@ -781,7 +796,7 @@ extern "C" NSA_API size_t nsa_train_workspace_floats(const long long* plan, long
   long long d_tr_max, np_max, per_layer;
   tr_sizes(plan, n, d_tr_max, np_max, per_layer);
   const long long D = plan[0], H = plan[1], NL = plan[3];
-  return (size_t)(64 + 2 * n * D + 2 * n + n * np_max + 2 * n * H + NL * per_layer + plan[8]);
+  return (size_t)(192 + 2 * n * D + 2 * n + n * np_max + 2 * n * H + NL * per_layer + plan[8]);
 }
 
 static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
@@ -789,7 +804,7 @@ static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
   tr_sizes(plan, n, d_tr_max, np_max, per_layer);
   const long long D = plan[0], H = plan[1];
   float* p = ws;
-  w.scal = p; p += 64;
+  w.scal = p; p += 192;  // [0..63] scalars, [64..191] optional phase timestamps
   w.x = p; p += n * D;
   w.gx = p; p += n * D;
   w.logdet = p; p += n;
@@ -889,6 +904,7 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
         a.transform = transform;
         a.ld = ((H > d_id ? H : d_id) + 1) | 1;
         a.wt = w.wt;
+        a.dbg = getenv("NESSAI_AMD_TRAIN_TIMING") ? w.scal + 64 : nullptr;
         a.id_cols = id_cols; a.tr_cols = tr_cols; a.params = params; a.X = w.x; a.xsave = xsave;
         a.h = h; a.u = u; a.p = p; a.logdet = w.logdet; a.c = c;
         for (int i = 0; i < 4 + 4 * L; ++i) a.off[i] = off[i];
@@ -974,6 +990,7 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
         a.transform = transform;
         a.ld = ((H > d_id ? H : d_id) + 1) | 1;
         a.ch = H > 96 ? 64 : 128;  // keeps the backward workgroup inside 160 KB of LDS
+        a.dbg = getenv("NESSAI_AMD_TRAIN_TIMING") ? w.scal + 64 : nullptr;
         a.id_cols = id_cols; a.tr_cols = tr_cols; a.params = params; a.grads = grads; a.X = w.x; a.Gx = w.gx;
         a.xsave = xsave; a.h = h; a.u = u; a.p = p; a.gp = w.gp; a.gld = w.gld; a.c = c;
         for (int i = 0; i < 4 + 4 * L; ++i) a.off[i] = off[i];
@@ -1063,14 +1080,14 @@ extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_d
                        tables_dev + plan[10], w.wt);
   }
   tr_forward(plan, tables_dev, params_dev, consts, n, w, 1, s);
-  hipLaunchKernelGGL(tr_loss, dim3(1), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
+  hipLaunchKernelGGL(tr_loss, dim3((unsigned)((n + TR_LOSS_ROWS - 1) / TR_LOSS_ROWS)), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
                      weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, (float*)nullptr, 1);
   tr_backward(plan, tables_dev, params_dev, grads_dev, consts, n, w, s);
-  hipLaunchKernelGGL(tr_grad_sqnorm, dim3(1), dim3(1024), 0, s, n_params, grads_dev, w.scal);
+  hipLaunchKernelGGL(tr_grad_sqnorm, dim3(TR_SQ_BLOCKS), dim3(256), 0, s, n_params, grads_dev, w.scal + 128);
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
   hipLaunchKernelGGL(tr_adamw, blocks_for(n_params), dim3(256), 0, s, n_params, params_dev, grads_dev, adam_m_dev,
-                     adam_v_dev, w.scal, clip_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+                     adam_v_dev, w.scal + 128, clip_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? NSA_OK : NSA_E_HIP;
 }
@@ -1091,7 +1108,7 @@ extern "C" NSA_API int nsa_train_eval(const long long* plan, const int* tables_d
     hipLaunchKernelGGL(tr_transpose_weights, blocks_for(plan[8]), dim3(256), 0, s, plan[8], params_dev,
                        tables_dev + plan[10], w.wt);
   tr_forward(plan, tables_dev, const_cast<float*>(params_dev), consts, n, w, 0, s);
-  hipLaunchKernelGGL(tr_loss, dim3(1), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
+  hipLaunchKernelGGL(tr_loss, dim3((unsigned)((n + TR_LOSS_ROWS - 1) / TR_LOSS_ROWS)), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
                      weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, log_prob_out_dev, 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? NSA_OK : NSA_E_HIP;

@@ -46,9 +46,39 @@ struct TrfArgs {
   float* gp;      // [n][np] their gradient
   float* logdet;  // [n]
   const float* gld;  // [n] dL/dlogdet
+  float* dbg;        // optional: 32 phase timestamps (cycles since kernel start) of workgroup 0
   TrConsts c;
   long long off[2 + 4 * TRF_MAX_L + 2];  // flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf
 };
+
+#define TRF_MARK(i)                                                              \
+  do {                                                                           \
+    if (a.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0)                 \
+      a.dbg[i] = (float)(long long)(clock64() - t_start);                        \
+  } while (0)
+
+// activation of a register batch with the (wave-uniform) kind tested ONCE: a per-element
+// tr_act() is if-converted into evaluating tanh AND the sigmoid for every element
+template <int N>
+__device__ __forceinline__ void trf_act_batch(float (&v)[N], int act) {
+  if (act == ACT_NONE) return;
+  if (act == NSA_ACT_RELU) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = fmaxf(v[q], 0.0f);
+  } else if (act == NSA_ACT_TANH) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = tanhf(v[q]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = v[q] * (1.0f / (1.0f + expf(-v[q])));
+  }
+}
+
+// barrier that publishes LDS tiles only: global stores / loads in flight (activation saves,
+// weight preloads) are NOT waited for, unlike __syncthreads()
+__device__ __forceinline__ void trf_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // wt[tmap[i]] = params[i]: every weight matrix [out][in] lands transposed at its own offset
 __global__ void tr_transpose_weights(long long n, const float* __restrict__ p, const int* __restrict__ tmap,
@@ -82,12 +112,35 @@ __device__ __forceinline__ void trf_stage(float* __restrict__ tile, int ld, cons
   }
 }
 
+// The weights of a layer do not depend on the previous layer's result: every wave loads the first
+// 64 k of its first tile BEFORE the barrier that publishes its input tile (TrfPre), so the global
+// latency overlaps the previous layer's tail instead of sitting on the critical path.
+struct TrfPre {
+  float v[16];
+};
+
+// first batch (k < 32) of W^T[k][o] for tile t = wave of trf_linear
+__device__ __forceinline__ void trf_linear_preload(TrfPre& pre, const float* __restrict__ Wt, int Kd, int O,
+                                                   int wave, int lane) {
+  const int half = lane >> 5, j = lane & 31;
+  const int OT = (O + 31) >> 5;
+  if (wave >= 2 * OT) return;
+  const int o = (wave >> 1) * 32 + j;
+  const unsigned oc = (unsigned)(o < O ? o : O - 1);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int k = 2 * q + half;
+    pre.v[q] = Wt[(unsigned)(k < Kd ? k : Kd - 1) * (unsigned)O + oc];
+  }
+}
+
 // out[row][o] = sum_k act(Ain[row][k]) W[o][k] + b[o] (+ R[row][o]); rows of the workgroup.
 // Wt = W^T [Kd][O].  out_lds / R may be null; out_lds == R is allowed (in-place residual update).
 __device__ __forceinline__ void trf_linear(const float* __restrict__ Ain, int Kd, int act_in,
                                            const float* __restrict__ Wt, const float* __restrict__ b, int O,
                                            const float* R, float* out_lds, float* __restrict__ out_glb,
-                                           int ld_glb, int ld, int r0, int n, int wave, int lane) {
+                                           int ld_glb, int ld, int r0, int n, int wave, int lane,
+                                           const TrfPre& pre) {
   const int half = lane >> 5, j = lane & 31;
   const int OT = (O + 31) >> 5;
   const int pairs = (Kd + 1) >> 1;
@@ -100,19 +153,35 @@ __device__ __forceinline__ void trf_linear(const float* __restrict__ Ain, int Kd
     const float* ax = Ain + (rt * 32 + j) * ld;
     for (int u0 = 0; u0 < pairs; u0 += 16) {
       float wv[16];
+      if (t == wave && u0 == 0) {  // wave-uniform
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wv[q] = pre.v[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int k = 2 * (u0 + q) + half;
+          wv[q] = Wt[(unsigned)(k < Kd ? k : Kd - 1) * (unsigned)O + oc];  // lanes along the row: coalesced
+        }
+      }
+      // all LDS reads of the batch are issued before the first MFMA (a dependent read per step
+      // would serialise the chain on the LDS latency)
+      float av[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int k = 2 * (u0 + q) + half;
-        wv[q] = Wt[(unsigned)(k < Kd ? k : Kd - 1) * (unsigned)O + oc];  // lanes along the row: coalesced
+        av[q] = ax[k < Kd ? k : 0];
+      }
+      trf_act_batch(av, act_in);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k = 2 * (u0 + q) + half;
+        const bool ok = k < Kd;
+        av[q] = ok ? av[q] : 0.0f;
+        wv[q] = (ok && o_ok) ? wv[q] : 0.0f;
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        if (u0 + q < pairs) {  // wave-uniform
-          const int k = 2 * (u0 + q) + half;
-          const bool ok = k < Kd;
-          const float av = ok ? tr_act(ax[k < Kd ? k : 0], act_in) : 0.0f;
-          acc = nsa_mfma(av, (ok && o_ok) ? wv[q] : 0.0f, acc);
-        }
+        if (u0 + q < pairs) acc = nsa_mfma(av[q], wv[q], acc);  // wave-uniform guard
       }
     }
     if (o_ok) {
@@ -165,7 +234,11 @@ __device__ __forceinline__ void trf_dx(const float* __restrict__ G, int g_ld, in
       for (int r = 0; r < 16; ++r) {
         const int rl = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = acc[r];
-        if (Z) v *= tr_act_grad(Z[rl * ld + kcol], act);
+        if (Z) {
+          const float z = Z[rl * ld + kcol];
+          if (act == NSA_ACT_RELU) v = z > 0.0f ? v : 0.0f;  // wave-uniform kind test first
+          else v *= tr_act_grad(z, act);
+        }
         if (add) v += out[rl * ld + kcol];
         out[rl * ld + kcol] = v;
       }
@@ -185,12 +258,23 @@ __device__ __forceinline__ void trf_dw(const float* __restrict__ G, int g_ld, in
     const int oc = ot * 32 + j, kc = kt * 32 + j;
     const bool o_ok = oc < O, k_ok = kc < Kd;
     f32x16 acc = {0};
-#pragma unroll 4
-    for (int u_ = 0; u_ < TRF_ROWS / 2; ++u_) {
-      const int row = 2 * u_ + half;
-      const float av = o_ok ? G[row * g_ld + oc] : 0.0f;
-      const float bb = k_ok ? tr_act(Ain[row * a_ld + kc], act_in) : 0.0f;
-      acc = nsa_mfma(av, bb, acc);  // D[i = o][jj = k]
+    const int ocl = o_ok ? oc : 0, kcl = k_ok ? kc : 0;
+    for (int ub = 0; ub < TRF_ROWS / 2; ub += 16) {  // 32 LDS reads issued before each 16-MFMA chain
+      float av[16], bv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 2 * (ub + q) + half;
+        av[q] = G[row * g_ld + ocl];
+        bv[q] = Ain[row * a_ld + kcl];
+      }
+      trf_act_batch(bv, act_in);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        av[q] = o_ok ? av[q] : 0.0f;
+        bv[q] = k_ok ? bv[q] : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc = nsa_mfma(av[q], bv[q], acc);  // D[i = o][jj = k]
     }
     if (k_ok) {
 #pragma unroll
@@ -219,24 +303,36 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_forward(TrfArgs a) {
   const float* WT = a.wt;
   const long long nH = (long long)n * H;
 
+  const long long t_start = clock64();
+  TrfPre pre;
+  trf_linear_preload(pre, WT + a.off[0], a.d_id, H, wave, lane);
   trf_stage(A0, ld, a.X, a.D, r0, n, 0, a.d_id, a.d_id, a.id_cols, tid);
-  __syncthreads();
+  trf_barrier_lds();
+  TRF_MARK(0);
   // h_0 = W0 x_id + b0
-  trf_linear(A0, a.d_id, ACT_NONE, WT + a.off[0], P + a.off[1], H, nullptr, A1, a.h, H, ld, r0, n, wave, lane);
-  __syncthreads();
+  trf_linear(A0, a.d_id, ACT_NONE, WT + a.off[0], P + a.off[1], H, nullptr, A1, a.h, H, ld, r0, n, wave, lane, pre);
+  TRF_MARK(1);
   for (int l = 0; l < a.L; ++l) {
     // u_l = W1 act(h_l) + b1;  h_{l+1} = h_l + W2 act(u_l) + b2
+    trf_linear_preload(pre, WT + a.off[2 + 4 * l], H, H, wave, lane);
+    trf_barrier_lds();
     trf_linear(A1, H, a.act, WT + a.off[2 + 4 * l], P + a.off[3 + 4 * l], H, nullptr, A0, a.u + l * nH, H, ld, r0,
-               n, wave, lane);
-    __syncthreads();
+               n, wave, lane, pre);
+    TRF_MARK(2 + 2 * l);
+    trf_linear_preload(pre, WT + a.off[4 + 4 * l], H, H, wave, lane);
+    trf_barrier_lds();
     trf_linear(A0, H, a.act, WT + a.off[4 + 4 * l], P + a.off[5 + 4 * l], H, A1, A1, a.h + (l + 1) * nH, H, ld,
-               r0, n, wave, lane);
-    __syncthreads();
+               r0, n, wave, lane, pre);
+    TRF_MARK(3 + 2 * l);
   }
   // parameters = Wf h_L + bf (global only)
+  trf_linear_preload(pre, WT + a.off[2 + 4 * a.L], H, a.np, wave, lane);
+  trf_barrier_lds();
   trf_linear(A1, H, ACT_NONE, WT + a.off[2 + 4 * a.L], P + a.off[3 + 4 * a.L], a.np, nullptr, nullptr, a.p, a.np,
-             ld, r0, n, wave, lane);
+             ld, r0, n, wave, lane, pre);
+  TRF_MARK(20);
   __syncthreads();  // the parameters of this workgroup's rows are visible to all its threads
+  TRF_MARK(21);
   const int items = TRF_ROWS * a.d_tr;
   for (int e = tid; e < items; e += TRF_THREADS) {
     const int r = e / a.d_tr, m = e - r * a.d_tr;
@@ -249,6 +345,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_forward(TrfArgs a) {
                              a.xsave, a.logdet);
     }
   }
+  TRF_MARK(22);
 }
 
 template <int K>
@@ -269,6 +366,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
   // read the same tiles and write disjoint ones
   const bool dx_group = wave < 4;
   const int gw = wave & 3;
+  const long long t_start = clock64();
 
   // transform backward: dL/dparameters -> a.gp, dL/dx_tr -> a.Gx, x restored in a.X
   const int items = TRF_ROWS * a.d_tr;
@@ -351,26 +449,27 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
   for (int l = a.L - 1; l >= 0; --l) {
     trf_stage(A0, ld, a.u + l * nH, H, r0, n, 0, H, H, nullptr, tid);  // u_l
     trf_stage(A1, ld, a.h + l * nH, H, r0, n, 0, H, H, nullptr, tid);  // h_l
-    __syncthreads();
+    trf_barrier_lds();
     // h_{l+1} = h_l + W2 act(u_l) + b2
     if (dx_group) trf_dx(G0, ld, H, P + a.off[4 + 4 * l], H, A0, a.act, G1, 0, ld, gw, 4, lane);
     else trf_dw(G0, ld, H, A0, ld, H, a.act, GR + a.off[4 + 4 * l], GR + a.off[5 + 4 * l], gw, 4, lane);
-    __syncthreads();
+    trf_barrier_lds();
     // u_l = W1 act(h_l) + b1
     if (dx_group) trf_dx(G1, ld, H, P + a.off[2 + 4 * l], H, A1, a.act, G0, 1, ld, gw, 4, lane);
     else trf_dw(G1, ld, H, A1, ld, H, a.act, GR + a.off[2 + 4 * l], GR + a.off[3 + 4 * l], gw, 4, lane);
-    __syncthreads();
+    trf_barrier_lds();
   }
 
   // initial layer: dW0, db0 and g_x[:, id_cols] += gh . W0 (x was restored above)
   trf_stage(A0, ld, a.X, a.D, r0, n, 0, a.d_id, a.d_id, a.id_cols, tid);
-  __syncthreads();
+  trf_barrier_lds();
   if (dx_group) trf_dx(G0, ld, H, P + a.off[0], a.d_id, nullptr, ACT_NONE, G1, 0, ld, gw, 4, lane);
   else trf_dw(G0, ld, H, A0, ld, a.d_id, ACT_NONE, GR + a.off[0], GR + a.off[1], gw, 4, lane);
-  __syncthreads();
+  trf_barrier_lds();
   for (int idx = tid; idx < TRF_ROWS * a.d_id; idx += TRF_THREADS) {
     const int r = idx / a.d_id, k = idx - r * a.d_id;
     const int row = r0 + r;
     if (row < n) a.Gx[(unsigned)row * (unsigned)a.D + (unsigned)a.id_cols[k]] += G1[r * ld + k];
   }
+  TRF_MARK(60);
 }

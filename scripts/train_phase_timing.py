@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Phase timestamps of the fused training kernels (workgroup 0, last coupling layer).
+
+    NESSAI_AMD_TRAIN_TIMING=1 python scripts/train_phase_timing.py
+
+Prints the cycle counter (s_memtime, 100 MHz constant clock on gfx950 -> 10 ns units) at the
+marks of nsa_train_fused.h: forward 0..22, backward 60 (end)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["NESSAI_AMD_TRAIN_TIMING"] = "1"
+
+from nessai_amd.flows import NeuralSplineFlow  # noqa: E402
+from nessai_amd.train import Trainer  # noqa: E402
+
+torch.manual_seed(1)
+flow = NeuralSplineFlow(32, 64, 6, 2)
+flow.to("cuda")
+tr = Trainer(flow)
+x = torch.randn(1000, 32, device="cuda")
+for _ in range(3):
+    tr.step(x, clip_norm=5.0)
+torch.cuda.synchronize()
+marks = tr._ws[64:128].cpu().numpy()
+names = {0: "x staged", 1: "layer 0", 2: "u_0", 3: "h_1", 4: "u_1", 5: "h_2", 20: "params", 21: "barrier",
+         22: "transform fwd", 32: "transform bwd", 33: "h_L staged", 34: "final layer", 38: "blk1 staged",
+         39: "blk1 second", 40: "blk1 first", 35: "blk0 staged", 36: "blk0 second", 37: "blk0 first",
+         60: "initial layer + end"}
+prev = 0.0
+for group in (range(0, 23), [60]):
+    prev = 0.0
+    for i in group:
+        if marks[i] > 0:
+            print(f"mark {i:2d} {names.get(i, ''):22s} t = {marks[i]:9.0f}  (+{marks[i] - prev:7.0f})")
+            prev = marks[i]
+    print()
