@@ -1,15 +1,15 @@
 // Fused training kernels of one coupling layer (included by nsa_train.hip).
 //
 // The layer-wise path of nsa_train.hip spends a minibatch step in ~150 launches of
-// 5-15 us kernels.  Here one workgroup (8 waves) owns 64 batch rows and runs a whole coupling
+// 5-15 us kernels.  Here one workgroup (8 waves) owns 32 batch rows and runs a whole coupling
 // layer - conditioner (residual net), transform, and their reverse mode - with the
-// activations of the 64 rows in LDS:
+// activations of its rows in LDS:
 //
 //   trf_forward   x_id -> h_0 -> {u_l, h_{l+1}} -> parameters -> spline/affine forward
 //                 (saves h_l, u_l, parameters and the transformed inputs for the backward pass,
 //                  exactly the workspace layout of the layer-wise path)
 //   trf_backward  transform backward -> final layer -> residual blocks -> initial layer:
-//                 dX chains stay in LDS, weight gradients are 64-row partial products
+//                 dX chains stay in LDS, weight gradients are per-workgroup partial products
 //                 added to the flat gradient with float atomics (the flat gradient is
 //                 zeroed once per step)
 //
@@ -24,7 +24,10 @@
 // realnvp.py:136-146) under FlowModel._train (src/nessai/flowmodel/base.py:365-452).
 #pragma once
 
-#define TRF_ROWS 64
+#ifndef TRF_ROWS
+#define TRF_ROWS 32
+#endif
+#define TRF_RT (TRF_ROWS / 32)  // MFMA row tiles per workgroup
 #define TRF_THREADS 512
 #define TRF_WAVES 8
 #define TRF_MAX_L 8
@@ -124,8 +127,8 @@ __device__ __forceinline__ void trf_linear_preload(TrfPre& pre, const float* __r
                                                    int wave, int lane) {
   const int half = lane >> 5, j = lane & 31;
   const int OT = (O + 31) >> 5;
-  if (wave >= 2 * OT) return;
-  const int o = (wave >> 1) * 32 + j;
+  if (wave >= TRF_RT * OT) return;
+  const int o = (wave / TRF_RT) * 32 + j;
   const unsigned oc = (unsigned)(o < O ? o : O - 1);
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
@@ -144,8 +147,8 @@ __device__ __forceinline__ void trf_linear(const float* __restrict__ Ain, int Kd
   const int half = lane >> 5, j = lane & 31;
   const int OT = (O + 31) >> 5;
   const int pairs = (Kd + 1) >> 1;
-  for (int t = wave; t < 2 * OT; t += TRF_WAVES) {
-    const int rt = t & 1, ot = t >> 1;
+  for (int t = wave; t < TRF_RT * OT; t += TRF_WAVES) {
+    const int rt = t % TRF_RT, ot = t / TRF_RT;
     const int o = ot * 32 + j;
     const bool o_ok = o < O;
     const unsigned oc = (unsigned)(o_ok ? o : O - 1);
@@ -206,8 +209,8 @@ __device__ __forceinline__ void trf_dx(const float* __restrict__ G, int g_ld, in
   const int half = lane >> 5, j = lane & 31;
   const int KT = (Kd + 31) >> 5;
   const int pairs = (O + 1) >> 1;
-  for (int t = wave; t < 2 * KT; t += nw) {
-    const int rt = t & 1, kt = t >> 1;
+  for (int t = wave; t < TRF_RT * KT; t += nw) {
+    const int rt = t % TRF_RT, kt = t / TRF_RT;
     const int kcol = kt * 32 + j;
     const unsigned wc = (unsigned)(kcol < Kd ? kcol : Kd - 1);
     const bool col_ok = kcol < Kd;
@@ -400,8 +403,8 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
         const int t = gw + 4 * s_;
-        if (t < 2 * KT) {
-          const int rt = t & 1, kt = t >> 1;
+        if (t < TRF_RT * KT) {
+          const int rt = t % TRF_RT, kt = t / TRF_RT;
           const int kcol = kt * 32 + j;
           const unsigned wc = (unsigned)(kcol < H ? kcol : H - 1);
           const bool col_ok = kcol < H;
@@ -433,8 +436,8 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
       const int t = gw + 4 * s_;
-      if (t < 2 * KT) {
-        const int rt = t & 1, kt = t >> 1;
+      if (t < TRF_RT * KT) {
+        const int rt = t % TRF_RT, kt = t / TRF_RT;
         const int kcol = kt * 32 + j;
         if (kcol < H) {
 #pragma unroll
