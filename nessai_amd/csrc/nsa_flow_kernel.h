@@ -569,6 +569,13 @@ __device__ __forceinline__ void nsa_elementwise_op(NsaStagePipe& pipe, const uin
 
 // the kernel ------------------------------------------------------------------
 
+// an int the optimiser cannot trace back: keeps the per-lane 64-bit addresses of the tile copy
+// loops from being hoisted out of the persistent loop (they were spilled to scratch there)
+__device__ __forceinline__ int nsa_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 template <int HT, class TP, bool INV, int PREC>
 __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -639,7 +646,7 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
     if (p.x_in != nullptr) {
       const long long base = row0 * D;
       const long long limit = p.n * (long long)D;
-      for (int idx = lane; idx < NSA_ROWS * D; idx += 64) {
+      for (int idx = nsa_opaque(lane); idx < NSA_ROWS * D; idx += 64) {
         const int r = idx / D, c = idx - r * D;
         const long long gi = base + idx;
         xt[r * XS + c] = (gi < limit) ? p.x_in[gi] : 0.0f;
@@ -680,7 +687,7 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
       if (p.z_out != nullptr) {
         const long long base = row0 * D;
         const long long limit = p.n * (long long)D;
-        for (int idx = lane; idx < NSA_ROWS * D; idx += 64) {
+        for (int idx = nsa_opaque(lane); idx < NSA_ROWS * D; idx += 64) {
           const int r = idx / D, c = idx - r * D;
           const long long gi = base + idx;
           if (gi < limit) p.z_out[gi] = xt[r * XS + c];
@@ -779,7 +786,7 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
       if (p.x_out != nullptr) {
         const long long base = row0 * D;
         const long long limit = p.n * (long long)D;
-        for (int idx = lane; idx < NSA_ROWS * D; idx += 64) {
+        for (int idx = nsa_opaque(lane); idx < NSA_ROWS * D; idx += 64) {
           const int r = idx / D, c = idx - r * D;
           const long long gi = base + idx;
           if (gi < limit) p.x_out[gi] = xt[r * XS + out_tab[c]];
