@@ -104,6 +104,10 @@ NSA_API int nsa_flow_run_many(const uint32_t* header, const void* const* image_l
  *   z_in_dev    [n][D] float32 latents to use, or NULL to draw them on-device
  *               with Philox4x32-10(seed; counter = row_offset + row, quad)
  *   radius      keep rows with ||z||_2 <= radius (float64 compare)
+ *   latent_temperature  T > 0 (1.0 = off): drawn latents are scaled by sqrt(T) and the latent
+ *               density is evaluated at z / sqrt(T) minus D log sqrt(T)
+ *               (BaseFlowProposal.sample_latent_distribution / latent_log_prob,
+ *               proposal/flowproposal/base.py:393-414)
  *   scale/shift [D] float64 z-score sigma / mu        (x = x' * sigma + mu)
  *   lower/upper [D] float64 prior bounds
  *   log_j_rescale  sum_i log|sigma_i| accumulated in the reference's order
@@ -131,7 +135,8 @@ NSA_API int nsa_flow_run_many(const uint32_t* header, const void* const* image_l
  */
 NSA_API int nsa_populate_draw(const uint32_t* header, const void* image_dev, long long n,
                       const float* z_in_dev, unsigned long long seed,
-                      unsigned long long row_offset, double radius, const double* scale_dev,
+                      unsigned long long row_offset, double radius, double latent_temperature,
+                      const double* scale_dev,
                       const double* shift_dev, const double* lower_dev, const double* upper_dev,
                       double log_j_rescale, double* x64_out_dev, double* log_q_out_dev,
                       float* z_out_dev, const int* prior_kind_dev, const double* prior_par_dev,

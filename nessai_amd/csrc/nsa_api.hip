@@ -1,5 +1,6 @@
 // C-ABI entry points (include/nessai_amd.h) and kernel dispatch.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -199,7 +200,7 @@ extern "C" int nsa_flow_run_many(const uint32_t* header, const void* const* imag
 
 extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, long long n,
                                  const float* z_in_dev, unsigned long long seed,
-                                 unsigned long long row_offset, double radius,
+                                 unsigned long long row_offset, double radius, double latent_temperature,
                                  const double* scale_dev, const double* shift_dev,
                                  const double* lower_dev, const double* upper_dev,
                                  double log_j_rescale, double* x64_out_dev, double* log_q_out_dev,
@@ -221,6 +222,10 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
   p.seed = seed;
   p.row_offset = row_offset;
   p.radius = radius;
+  if (!(latent_temperature > 0.0)) return nsa_fail(NSA_E_ARG, "nsa_populate_draw: latent_temperature must be > 0");
+  p.latent_scale = sqrt(latent_temperature);
+  if (header == nullptr) return nsa_fail(NSA_E_ARG, "header is NULL");
+  p.log_j_latent = (latent_temperature == 1.0) ? 0.0 : (double)header[NSA_H_D] * log(p.latent_scale);
   p.scale = scale_dev;
   p.shift = shift_dev;
   p.lower = lower_dev;

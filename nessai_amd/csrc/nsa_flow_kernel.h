@@ -46,6 +46,8 @@ struct NsaLaunch {
   unsigned long long seed;
   unsigned long long row_offset;  // global index of row 0 (sharded draws)
   double radius;                  // keep ||z|| <= radius
+  double latent_scale;            // sqrt(latent_temperature); 1.0 = off
+  double log_j_latent;            // D * log(latent_scale)
   const double* scale;            // [D] z-score sigma
   const double* shift;            // [D] z-score mu
   const double* lower;            // [D] prior bounds
@@ -673,12 +675,25 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
 
     // ---- POPULATE prologue: latent norm, latent log-density, optional z out --
     if (p.mode == NSA_MODE_POPULATE) {
+      // latent temperature (proposal/flowproposal/base.py:393-414): the flow sees sqrt(T) z0,
+      // the latent density is evaluated at z / sqrt(T) (= z0 exactly for drawn latents)
+      const double ls = p.latent_scale;
+      const bool tempered = ls != 1.0;
       double r2 = 0.0;
       float e = 0.0f;
       for (int c = half; c < D; c += 2) {
-        const float z = xrow[c];
+        float z = xrow[c];
+        float zin = z;
+        if (tempered) {
+          if (p.x_in == nullptr) {
+            z = (float)((double)z * ls);
+            xrow[c] = z;
+          } else {
+            zin = (float)((double)z / ls);
+          }
+        }
         r2 += (double)z * (double)z;
-        e += z * z;
+        e += zin * zin;
       }
       r2 += __shfl_xor(r2, 32);
       e += __shfl_xor(e, 32);
@@ -762,7 +777,7 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
       // finite check on the flow's log_q (flowproposal.py:366-372), THEN the rescaling
       // Jacobian (flowproposal.py:383): a saturated sigmoid gives log_q = +inf, kept as the
       // reference keeps it (never accepted, still counted as proposed)
-      double lq = (double)log_pz - (double)logdet;
+      double lq = ((double)log_pz - p.log_j_latent) - (double)logdet;
       const bool finite = (lq - lq) == 0.0;
       lq -= (e.log_j_rescale + log_j_row);
       if (!(keep && ok && finite && n_bad == 0)) lq = __longlong_as_double(0x7ff8000000000000LL);

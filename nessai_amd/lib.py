@@ -37,7 +37,7 @@ SIGNATURES = {
     ),
     "nsa_populate_draw": (
         c_int,
-        [c_void_p, c_void_p, c_ll, c_void_p, c_ull, c_ull, c_double, c_void_p, c_void_p, c_void_p,
+        [c_void_p, c_void_p, c_ll, c_void_p, c_ull, c_ull, c_double, c_double, c_void_p, c_void_p, c_void_p,
          c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
          c_void_p, c_int, c_int, c_void_p],
     ),

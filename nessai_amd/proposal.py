@@ -104,8 +104,11 @@ class FlowProposal:
     ):
         if kwargs:
             raise TypeError(f"Unknown FlowProposal arguments: {sorted(kwargs)}")
-        if latent_temperature not in (None, 1.0):
-            raise NotImplementedError("latent_temperature has no gfx950 kernel yet")
+        if latent_temperature is not None:  # flowproposal.py:263-272
+            if isinstance(latent_temperature, bool) or not isinstance(latent_temperature, (int, float)):
+                raise TypeError("latent_temperature must be a positive float")
+            if not latent_temperature > 0.0:
+                raise ValueError("latent_temperature must be a positive float")
         self.model = model
         self.rng = rng if rng is not None else np.random.default_rng()
         self.output = output if output is not None else os.getcwd()
@@ -118,7 +121,7 @@ class FlowProposal:
         self.update_poolsize = update_poolsize
         self.max_poolsize_scale = max_poolsize_scale
         self.drawsize = int(drawsize) if drawsize is not None else self._poolsize
-        self.latent_temperature = None
+        self.latent_temperature = None if latent_temperature is None else float(latent_temperature)
         self.accumulate_weights = accumulate_weights
         self.check_acceptance = check_acceptance
         self.volume_fraction = float(volume_fraction)
@@ -370,7 +373,7 @@ class FlowProposal:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = lib.load().nsa_populate_draw(
             header, lib.ptr(image), n, lib.ptr(z_in), self.device_seed, int(row_offset),
-            float(radius), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
+            float(radius), float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
             lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
             lib.ptr(x64), lib.ptr(log_q), lib.ptr(z_out),
             lib.ptr(self._prior_kind_dev if log_prior is not None else None),

@@ -313,6 +313,7 @@ class OracleFlowProposal:
         self.n_accepted = 0
         self.injected_latents = None  # iterator of (N, D) arrays, for parity tests
         self.reparam = None  # optional oracle.reparam.OracleCombined replacing the z-score
+        self.latent_temperature = None  # base.py:393-414
 
     # -- reparameterisation (z-score) ---------------------------------------
 
@@ -377,7 +378,17 @@ class OracleFlowProposal:
     def sample_latent_distribution(self, n):  # base.py:393-399
         if self.injected_latents is not None:
             return np.asarray(next(self.injected_latents), dtype=np.float64)
-        return self.flow.sample_latent_distribution(n)
+        z = self.flow.sample_latent_distribution(n)
+        if self.latent_temperature in (None, 1.0):
+            return z
+        return np.sqrt(self.latent_temperature) * z
+
+    def latent_log_prob(self, z):  # base.py:401-414
+        z = np.asarray(z)
+        if self.latent_temperature in (None, 1.0):
+            return self.flow.base_distribution_log_prob(z)
+        scale = np.sqrt(float(self.latent_temperature))
+        return self.flow.base_distribution_log_prob(z / scale) - z.shape[-1] * np.log(scale)
 
     def apply_latent(self, z, threshold):  # truncation.py:358-365
         radius = np.sqrt(np.sum(z**2.0, axis=-1))
@@ -387,7 +398,7 @@ class OracleFlowProposal:
     def backward_pass(self, z):  # flowproposal.py:345-389
         try:
             x, log_j = self.flow.inverse(z)
-            log_prob = self.flow.base_distribution_log_prob(z) - log_j
+            log_prob = self.latent_log_prob(z) - log_j
         except AssertionError:
             return np.array([]), np.array([]), np.array([])
         valid = np.isfinite(log_prob)

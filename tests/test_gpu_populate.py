@@ -392,3 +392,39 @@ def test_full_size_c3_populate():
     assert prop.model.in_bounds(prop.samples).all()
     assert np.isfinite(prop.samples["logP"]).all() and np.isfinite(prop.samples["logL"]).all()
     assert prop.n_accepted >= 2000 and prop.n_proposed % 1_000_000 == 0
+
+
+def test_latent_temperature_matches_oracle():
+    """Tempered latents (base.py:393-414): injected z through backward_pass, and the on-device draw
+    is sqrt(T) times the Philox normals with the density evaluated at the untempered values."""
+    T = 0.7
+    prop, oprop = build(6, "nsf", dict(n_neurons=16, n_blocks=3), latent_temperature=T)
+    oprop.latent_temperature = T
+    z = np.random.default_rng(0).normal(size=(4000, 6)).astype(np.float32).astype(np.float64)
+    x, log_q, z_kept = prop.backward_pass(z, return_z=True)
+    x_o, log_q_o, z_o = oprop.backward_pass(z)
+    assert len(x) == len(x_o) and np.array_equal(z_kept, z_o)
+    np.testing.assert_allclose(log_q, log_q_o, rtol=1e-5, atol=1e-4)
+    # device draw: z_out = f32(sqrt(T) * z0), log_q consistent with the oracle fed those latents
+    n, dev = 2048, prop.device
+    x64 = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    lq = torch.empty(n, dtype=torch.float64, device=dev)
+    z_out = torch.empty((n, 6), dtype=torch.float32, device=dev)
+    prop._launch_draw(n, None, 100, np.inf, x64, lq, z_out)
+    z0 = philox.latents(prop.device_seed, 100, n, 6)
+    expected = (z0.astype(np.float64) * np.sqrt(T)).astype(np.float32)
+    z_dev = z_out.cpu().numpy()
+    np.testing.assert_allclose(z_dev, expected, rtol=0, atol=3e-6)  # Box-Muller differs by ulps
+    # feed the oracle the device's own tempered latents; the reference keeps sqrt(T) z0 in float64
+    x_d, lq_d, zk = oprop.backward_pass(z_dev.astype(np.float64))
+    lq_h = lq.cpu().numpy()
+    keep = ~np.isnan(lq_h)
+    assert keep.sum() == len(lq_d)
+    np.testing.assert_allclose(lq_h[keep], lq_d, rtol=1e-5, atol=1e-4)
+
+
+def test_latent_temperature_validation():
+    with pytest.raises(ValueError):
+        FlowProposal(RosenbrockModel(2), poolsize=10, latent_temperature=0.0)
+    with pytest.raises(TypeError):
+        FlowProposal(RosenbrockModel(2), poolsize=10, latent_temperature=True)
