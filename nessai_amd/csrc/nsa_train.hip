@@ -753,13 +753,15 @@ __global__ void tr_copy_rows(long long n, const float* __restrict__ src, float* 
 //   [0] D  [1] H  [2] L (residual blocks)  [3] n_layers  [4] transform  [5] bins
 //   [6] activation  [7] params per transformed feature  [8] n trainable floats  [9] record words
 //   [10] offset (in the int32 device table) of the transposition map of the trainable floats
+//   [11] conditioner: 0 residual net {W0, b0, {W1, b1, W2, b2} x L, Wf, bf};
+//        1 plain MLP {W_in, b_in, {W_h, b_h} x L, W_out, b_out} (src/nessai/flows/nets.py:12-126)
 //   coupling  : {1, d_id, d_tr, id_cols offset, tr_cols offset (int32 device table),
 //                flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf}
 //   batch norm: {2, cols offset, off unconstrained_weight, off bias, off running_mean,
 //                off running_var, eps (float bits), momentum (float bits)}
 //   LU linear : {3, cols offset, off lower_entries, off upper_entries, off unconstrained_upper_diag,
 //                off bias, eps (float bits)}
-#define TR_HDR 11
+#define TR_HDR 12
 enum { TR_COUPLING = 1, TR_BATCHNORM = 2, TR_LU = 3 };
 
 static inline float tr_bits(long long v) {
@@ -836,7 +838,7 @@ static inline dim3 blocks_for(long long work) { return dim3((unsigned)((work + 2
 static bool tr_use_fused(const long long* plan) {
   const char* e = getenv("NESSAI_AMD_TRAIN_FUSED");  // read per call: the tests flip it
   const bool enabled = !(e != nullptr && e[0] == '0');
-  return enabled && plan[1] <= 128 && plan[2] <= TRF_MAX_L;  // H <= 128: at most 8 tiles of gh per workgroup
+  return enabled && plan[11] == NSA_NET_RESNET && plan[1] <= 128 && plan[2] <= TRF_MAX_L;  // H <= 128: <= 8 gh tiles
 }
 
 template <int K>
@@ -913,6 +915,16 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
       }
       hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, d_id, H, w.x, D, id_cols, ACT_NONE,
                          params + off[0], params + off[1], (const float*)nullptr, h, H);
+      if (plan[11] == NSA_NET_MLP) {
+        // z_0 = W_in x_id + b_in;  z_{l+1} = W_h act(z_l) + b_h;  parameters = W_out act(z_L) + b_out
+        for (int l = 0; l < L; ++l)
+          hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, h + (long long)l * n * H, H,
+                             (const int*)nullptr, act, params + off[2 + 2 * l], params + off[3 + 2 * l],
+                             (const float*)nullptr, h + (long long)(l + 1) * n * H, H);
+        hipLaunchKernelGGL(tr_gemm_nt, tiles(n, np), dim3(64), 0, s, (int)n, H, np, h + (long long)L * n * H, H,
+                           (const int*)nullptr, act, params + off[2 + 2 * L], params + off[3 + 2 * L],
+                           (const float*)nullptr, p, np);
+      } else {
       for (int l = 0; l < L; ++l) {
         float* hl = h + (long long)l * n * H;
         float* ul = u + (long long)l * n * H;
@@ -925,6 +937,7 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
       hipLaunchKernelGGL(tr_gemm_nt, tiles(n, np), dim3(64), 0, s, (int)n, H, np, hL, H, (const int*)nullptr,
                          ACT_NONE, params + off[2 + 4 * L], params + off[3 + 4 * L], (const float*)nullptr, p,
                          np);
+      }
       if (transform == NSA_T_RQ) {
         TR_SPLINE_DISPATCH(tr_rq_forward, K, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr, tr_cols, p,
                            w.x, D, xsave, w.logdet, c);
@@ -1003,6 +1016,28 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       } else {
         hipLaunchKernelGGL(tr_affine_backward, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr,
                            transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, xsave, w.x, D, w.gx, w.gld, w.gp);
+      }
+      if (plan[11] == NSA_NET_MLP) {
+        float* zL = h + (long long)L * n * H;
+        hipLaunchKernelGGL(tr_gemm_tn, tiles(np, H), dim3(256), 0, s, (int)n, np, H, w.gp, np, zL, H,
+                           (const int*)nullptr, act, grads + off[2 + 2 * L], grads + off[3 + 2 * L]);
+        hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, np, H, w.gp, np,
+                           params + off[2 + 2 * L], zL, H, act, w.gh, H, (const int*)nullptr, 0);
+        float* gcur = w.gh;
+        float* gnext = w.gu;
+        for (int l = L - 1; l >= 0; --l) {  // z_{l+1} = W_h act(z_l) + b_h
+          float* zl = h + (long long)l * n * H;
+          hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, gcur, H, zl, H,
+                             (const int*)nullptr, act, grads + off[2 + 2 * l], grads + off[3 + 2 * l]);
+          hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, gcur, H,
+                             params + off[2 + 2 * l], zl, H, act, gnext, H, (const int*)nullptr, 0);
+          float* t_ = gcur; gcur = gnext; gnext = t_;
+        }
+        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, d_id), dim3(256), 0, s, (int)n, H, d_id, gcur, H, w.x, D, id_cols,
+                           ACT_NONE, grads + off[0], grads + off[1]);
+        hipLaunchKernelGGL(tr_gemm_nn, tiles(n, d_id), dim3(64), 0, s, (int)n, H, d_id, gcur, H, params + off[0],
+                           (const float*)nullptr, 0, ACT_NONE, w.gx, D, id_cols, 2);
+        continue;
       }
       // final layer: dWf, dbf, gh = gp . Wf
       float* hL = h + (long long)L * n * H;

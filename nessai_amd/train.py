@@ -40,8 +40,7 @@ class Trainer:
             raise RuntimeError("nessai_amd training needs the flow on a ROCm device (no CPU fallback)")
         self.device = device
         desc = M.describe(flow)
-        if desc["net"] != "resnet":
-            raise NotImplementedError("training kernels support the residual conditioner only")
+        is_mlp = desc["net"] == "mlp"
         leaves = M.flatten_transforms(flow._transform)
         D = desc["D"]
         cur = list(range(D))
@@ -80,12 +79,17 @@ class Trainer:
                 cur = [cur[int(perm[i])] for i in range(D)]
             elif hasattr(t, "transform_net"):
                 net = t.transform_net
-                layers = [net.initial_layer]
-                for block in net.blocks:
-                    layers.extend(block.linear_layers)
-                layers.append(net.final_layer)
-                n_res = len(net.blocks) if n_res is None else n_res
-                if len(net.blocks) != n_res:
+                if is_mlp:  # input, hidden x (n - 1), output (src/nessai/flows/nets.py:55-126)
+                    layers = net.layers()
+                    depth = len(layers) - 2
+                else:
+                    layers = [net.initial_layer]
+                    for block in net.blocks:
+                        layers.extend(block.linear_layers)
+                    layers.append(net.final_layer)
+                    depth = len(net.blocks)
+                n_res = depth if n_res is None else n_res
+                if depth != n_res:
                     raise ValueError("all coupling layers must share one conditioner depth")
                 id_cols = [cur[int(f)] for f in t.identity_features.tolist()]
                 tr_cols = [cur[int(f)] for f in t.transform_features.tolist()]
@@ -127,7 +131,8 @@ class Trainer:
         rec_words = len(records[0])
         header = [D, desc["hidden"], n_res, len(records), pack.TRANSFORMS[desc["transform"]],
                   desc.get("bins", 0) if desc["transform"] == "rq" else 0,
-                  pack.ACTIVATIONS[desc["activation"]], n_tr, total, rec_words, len(tables)]
+                  pack.ACTIVATIONS[desc["activation"]], n_tr, total, rec_words, len(tables),
+                  pack.NETS[desc["net"]]]
         tables = list(tables) + tmap.tolist()
         plan = header + [w for rec in records for w in rec]
         self.plan = (ctypes.c_longlong * len(plan))(*plan)

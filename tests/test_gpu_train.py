@@ -30,6 +30,11 @@ CASES = {
     "rnvp_lu_only": (RealNVP, O.RealNVP, (5, 8, 2, 2), dict(batch_norm_between_layers=False)),
     "nsf_bn_lu": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 3, 2),
                   dict(batch_norm_between_layers=True, linear_transform="lu")),
+    # plain MLP conditioner (src/nessai/flows/nets.py:12-126), the "MLP" variant of config 2
+    "rnvp_c2_mlp": (RealNVP, O.RealNVP, (16, 32, 4, 2), dict(net="mlp")),
+    "rnvp_mlp_deep_tanh": (RealNVP, O.RealNVP, (5, 12, 2, 3),
+                           dict(net="mlp", linear_transform="permutation", batch_norm_between_layers=False,
+                                activation=torch.tanh)),
 }
 
 
@@ -252,10 +257,6 @@ def test_unsupported_training_configurations_raise():
     flow = RealNVP(4, 8, 2, 2, actnorm=True, batch_norm_between_layers=False)
     flow.to(DEV)
     with pytest.raises(NotImplementedError, match="no training kernel"):
-        Trainer(flow)
-    flow = RealNVP(4, 8, 2, 2, net="mlp", batch_norm_between_layers=False)
-    flow.to(DEV)
-    with pytest.raises(NotImplementedError, match="residual conditioner"):
         Trainer(flow)
 
 
