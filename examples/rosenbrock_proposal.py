@@ -10,9 +10,13 @@ the current flow is exhausted, retraining every ``nlive`` iterations.
     python examples/rosenbrock_proposal.py --dims 8 --nlive 1000 --iterations 3000
 """
 import argparse
+import os
+import sys
 import time
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from nessai_amd.model import RosenbrockModel
 from nessai_amd.proposal import FlowProposal
