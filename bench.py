@@ -85,15 +85,16 @@ def time_draw_kernel(prop, launches=10, precision=None):
 
 def _time_draw_kernel(prop, n, launches):
     buf = prop._get_buffers(n, NLIVE)
+    prepared = prop._prepare_flow()
     for _ in range(2):
-        prop._launch_draw(n, None, 0, prop.fixed_radius, buf["x64"], buf["log_q"], None)
+        prop._launch_draw(n, None, 0, prop.fixed_radius, buf["x64"], buf["log_q"], None, prepared=prepared)
     torch.cuda.synchronize()
     events = []
     for i in range(launches):
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
-        prop._launch_draw(n, None, i * n, prop.fixed_radius, buf["x64"], buf["log_q"], None)
+        prop._launch_draw(n, None, i * n, prop.fixed_radius, buf["x64"], buf["log_q"], None, prepared=prepared)
         e.record()
         events.append((s, e))
     torch.cuda.synchronize()

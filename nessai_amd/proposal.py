@@ -359,7 +359,10 @@ class FlowProposal:
 
     # -- device plumbing --------------------------------------------------------------
 
-    def _launch_draw(self, n, z_in, row_offset, radius, x64, log_q, z_out, log_prior=None):
+    def _prepare_flow(self):
+        """(flow, header, image, status) for the draw kernel: eval mode, precision policy and the
+        packed device image.  Costs ~0.3 ms of host time (it walks the module tree), so
+        ``populate`` does it once per call, not once per pass."""
         from .flows.base import populate_precision
 
         flow = self.flow.model
@@ -368,17 +371,21 @@ class FlowProposal:
         if flow.precision != wanted:
             flow.precision = wanted
         header, image = flow.device_image()
-        status = flow._status
+        return flow, header, image, flow._status
+
+    def _launch_draw(self, n, z_in, row_offset, radius, x64, log_q, z_out, log_prior=None, prepared=None):
+        flow, header, image, status = prepared if prepared is not None else self._prepare_flow()
         status.zero_()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = lib.load().nsa_populate_draw(
             header, lib.ptr(image), n, lib.ptr(z_in), self.device_seed, int(row_offset),
-            float(radius), float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
-            lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
-            lib.ptr(x64), lib.ptr(log_q), lib.ptr(z_out),
+            float(radius), float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev),
+            lib.ptr(self._shift_dev), lib.ptr(self._lower_dev), lib.ptr(self._upper_dev),
+            float(self._log_j_rescale), lib.ptr(x64), lib.ptr(log_q), lib.ptr(z_out),
             lib.ptr(self._prior_kind_dev if log_prior is not None else None),
             lib.ptr(self._prior_par_dev if log_prior is not None else None), lib.ptr(log_prior),
-            lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), lib.ptr(status), flow.waves_per_group, flow.max_groups, lib.c_void_p(stream),
+            lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), lib.ptr(status), flow.waves_per_group,
+            flow.max_groups, lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_populate_draw")
 
@@ -501,6 +508,7 @@ class FlowProposal:
         if self.accumulate_weights:
             return self._populate_accumulate(st, threshold, n_samples, max_samples, injected)
 
+        prepared = self._prepare_flow()
         while n_accepted < n_samples:
             z_in = u_in = None
             if injected is not None:
@@ -511,7 +519,8 @@ class FlowProposal:
             buf = self._get_buffers(n_local, n_samples)
             row_offset = self._draw_counter + rank * n_local
             self._launch_draw(n_local, z_in, row_offset, threshold, buf["x64"], buf["log_q"], None,
-                              log_prior=buf["log_p"] if self._prior_kind_dev is not None else None)
+                              log_prior=buf["log_p"] if self._prior_kind_dev is not None else None,
+                              prepared=prepared)
             self._weights_and_max(buf, n_local)
             if sharded:
                 torch.distributed.all_reduce(buf["max_key"], op=torch.distributed.ReduceOp.MAX)
@@ -548,6 +557,7 @@ class FlowProposal:
         accept_done = False
         buf = None
         u_all = []
+        prepared = self._prepare_flow()
         while n_accepted < n_samples:
             z_in = None
             n_local = self.drawsize
@@ -558,7 +568,8 @@ class FlowProposal:
             fresh = buf is None
             buf = self._get_buffers(n_local, n_samples)
             self._launch_draw(n_local, z_in, self._draw_counter, threshold, buf["x64"], buf["log_q"], None,
-                              log_prior=buf["log_p"] if self._prior_kind_dev is not None else None)
+                              log_prior=buf["log_p"] if self._prior_kind_dev is not None else None,
+                              prepared=prepared)
             self._weights_and_max(buf, n_local, reset_max=fresh)
             n_proposed += n_local
             self._draw_counter += n_local
