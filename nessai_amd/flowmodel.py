@@ -8,7 +8,6 @@ the ROCm device (``numpy_array_to_tensor``, ``base.py:774-780``); results come
 back as float64 numpy arrays (``base.py:809-810``).
 """
 
-import copy
 import logging
 import os
 

@@ -33,7 +33,6 @@ from . import lib
 from .flowmodel import FlowModel
 from .livepoint import (
     array_to_live_points_fast,
-    empty_structured_array,
     get_dtype,
     live_points_to_array,
 )

@@ -22,7 +22,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from nessai_amd.flowmodel_importance import ImportanceFlowModel  # noqa: E402
-from nessai_amd.livepoint import numpy_array_to_live_points  # noqa: E402
 from nessai_amd.model import GaussianModel, GWSurrogateModel  # noqa: E402
 from nessai_amd.proposal import FlowProposal  # noqa: E402
 from oracle import proposal as OP  # noqa: E402

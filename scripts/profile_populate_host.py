@@ -1,6 +1,9 @@
+#!/usr/bin/env python
+"""cProfile of the host side of ``FlowProposal.populate`` on the benchmark configuration
+(run from the repo root on a GPU box): shows what the CPU does between kernel launches."""
 import cProfile, pstats, sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-import torch, numpy as np
+import torch
 import bench
 prop = bench.build_proposal(0, 1, torch.device("cuda", 0))
 for _ in range(2):

@@ -8,7 +8,6 @@ marks of nsa_train_fused.h: forward 0..22, backward 60 (end)."""
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -3,7 +3,6 @@ import ctypes
 import os
 import re
 
-import pytest
 
 from nessai_amd import lib
 

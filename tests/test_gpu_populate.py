@@ -12,7 +12,7 @@ import torch
 from scipy import stats
 
 from helpers import DEV, load_c3_fixture
-from nessai_amd.model import GaussianModel, Model, RosenbrockModel
+from nessai_amd.model import GaussianModel, RosenbrockModel
 from nessai_amd.proposal import FlowProposal
 from oracle import philox
 from oracle import proposal as OP
