@@ -524,13 +524,12 @@ class FlowProposal:
             if sharded:
                 torch.distributed.all_reduce(buf["max_key"], op=torch.distributed.ReduceOp.MAX)
             self._accept(buf, n_local, n_samples, row_offset, u_in=u_in)
-            n_acc_local = int(buf["n_acc"].item())  # the pass's only device->host sync
-            m_local = min(n_acc_local, n_samples)
-            block = buf["x_acc"][:m_local]
             if sharded:
-                n_acc_batch, block = _gather_accepted(block, n_acc_local, n_samples, self.dims)
+                # counts of all ranks in one collective + one device->host copy (also this rank's)
+                n_acc_batch, block = _gather_accepted(buf["x_acc"], buf["n_acc"], n_samples, self.dims)
             else:
-                n_acc_batch = n_acc_local
+                n_acc_batch = int(buf["n_acc"].item())  # the pass's only device->host sync
+                block = buf["x_acc"][: min(n_acc_batch, n_samples)]
             n_proposed += n_local * world
             self._draw_counter += n_local * world
             m = min(n_samples - n_accepted, n_acc_batch)
@@ -655,25 +654,24 @@ class FlowProposal:
         return state
 
 
-def _gather_accepted(block, n_acc_local, capacity, dims):
+def _gather_accepted(x_acc, n_acc_dev, capacity, dims):
     """All-gather the accepted rows of every rank, rank-major then draw order.
 
-    One collective for the counts, one for the rows padded to a common length
-    (SURVEY.md §8e); payloads are a few hundred KB, i.e. latency-bound on xGMI.
+    ``x_acc``: this rank's compaction buffer ``(capacity, dims)``; ``n_acc_dev``: its accepted
+    count, still on the device.  One collective for the counts (whose host copy is the pass's
+    first synchronisation), one for the rows padded to the largest count (SURVEY.md §8e);
+    payloads are a few tens of KB, i.e. latency-bound on xGMI.
     """
     import torch.distributed as dist
 
     world = dist.get_world_size()
-    dev = block.device
-    mine = torch.tensor([n_acc_local], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(counts, mine)
-    counts_h = torch.cat(counts).cpu().numpy()
+    counts = torch.empty(world, dtype=torch.int64, device=x_acc.device)
+    dist.all_gather_into_tensor(counts, n_acc_dev.reshape(1))
+    counts_h = counts.cpu().numpy()
     kept = np.minimum(counts_h, capacity)
-    pad = int(kept.max()) if kept.max() > 0 else 1
-    send = torch.zeros((pad, dims), dtype=torch.float64, device=dev)
-    send[: block.shape[0]] = block
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send)
-    parts = [recv[r][: int(kept[r])] for r in range(world)]
+    pad = max(int(kept.max()), 1)
+    send = x_acc[:pad].contiguous()  # rows beyond this rank's count are ignored by the receivers
+    recv = torch.empty((world * pad, dims), dtype=torch.float64, device=x_acc.device)  # concatenated form
+    dist.all_gather_into_tensor(recv, send)
+    parts = [recv[r * pad : r * pad + int(kept[r])] for r in range(world)]
     return int(counts_h.sum()), torch.cat(parts, dim=0)

@@ -48,8 +48,11 @@ def _worker(rank, world, port, out_dir):
     # (2) local accept against the GLOBAL maximum with the global-row-indexed uniforms
     u = philox.uniforms(7, rank * n_local, n_local)
     accept = (log_w - gmax) > np.log(u)
-    rows = torch.from_numpy(z[accept][:capacity].copy())
-    total, gathered = _gather_accepted(rows, int(accept.sum()), capacity, dims)
+    x_acc = torch.zeros((capacity, dims), dtype=torch.float64)  # the rank's compaction buffer
+    rows = z[accept][:capacity]
+    x_acc[: len(rows)] = torch.from_numpy(rows.copy())
+    n_acc = torch.tensor([int(accept.sum())], dtype=torch.int64)  # may exceed the capacity
+    total, gathered = _gather_accepted(x_acc, n_acc, capacity, dims)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), gathered.numpy())
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
         f.write(f"{total} {gmax!r}")
