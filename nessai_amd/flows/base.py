@@ -143,8 +143,16 @@ class HipFlow(BaseFlow):
     # -- device image ----------------------------------------------------------
 
     def _fingerprint(self):
+        """Changes whenever a weight or buffer may have changed.  The tensor list is collected
+        once (the module tree is fixed after construction; ``.to()`` / ``load_state_dict`` /
+        the trainer's flat buffer rebind ``.data`` of the same objects): walking the tree costs
+        ~0.3 ms per call, the cached list ~20 us."""
+        tensors = self.__dict__.get("_fp_tensors")
+        if tensors is None:
+            tensors = list(self.parameters()) + list(self.buffers())
+            self.__dict__["_fp_tensors"] = tensors
         key = [self.training]
-        for t in list(self.parameters()) + list(self.buffers()):
+        for t in tensors:
             key.append((t.data_ptr(), t._version))
         return tuple(key)
 

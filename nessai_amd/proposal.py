@@ -365,7 +365,8 @@ class FlowProposal:
         from .flows.base import populate_precision
 
         flow = self.flow.model
-        flow.eval()
+        if flow.training:
+            flow.eval()
         wanted = populate_precision(flow) if self.precision == "auto" else self.precision
         if flow.precision != wanted:
             flow.precision = wanted
