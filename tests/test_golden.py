@@ -176,3 +176,37 @@ def test_prep_data_and_one_training_step_match_reference():
     after = state_of("flowmodel/after")
     for k, v in fm.model.state_dict().items():
         assert np.array_equal(v.numpy(), after[k].numpy()), k
+
+
+def test_importance_glue_matches_reference():
+    """G6: unit-hypercube logit map with eps = 1e-8 and the meta-proposal
+    ``log Q = logsumexp(log q_i, b = w_i)`` of the importance sampler, against outputs of the
+    reference's own methods (tests/golden/make_importance_goldens.py)."""
+    import types
+
+    from nessai_amd.proposal_importance import ImportanceFlowProposal as P
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "importance_goldens.npz"))
+    me = types.SimpleNamespace(reparameterisation="logit")
+    x_prime, log_j = P.to_prime(me, g["x_unit"])
+    assert np.array_equal(x_prime, g["x_prime"]) and np.array_equal(log_j, g["log_j"])
+    x_back, log_j_inv = P.from_prime(me, g["x_prime"])
+    assert np.array_equal(x_back, g["x_back"]) and np.array_equal(log_j_inv, g["log_j_inv"])
+
+    lpa = g["log_prob_all"]
+    weights = {i - 1: float(w) for i, w in enumerate(g["weights"])}
+    flow = types.SimpleNamespace(
+        n_models=lpa.shape[1], models=[types.SimpleNamespace(training=False)] * lpa.shape[1],
+        log_prob_all=lambda x: lpa,
+    )
+    me = types.SimpleNamespace(weights=weights, weights_array=g["weights"], n_proposals=lpa.shape[1] + 1,
+                               flow=flow)
+    log_Q, log_q_all = P.compute_log_Q(me, g["x_prime"], log_j=g["log_j"])
+    assert np.array_equal(log_q_all, g["log_q_all"])
+    assert np.array_equal(log_Q, g["log_Q"])
+    assert np.array_equal(P.compute_meta_proposal_from_log_q(me, log_q_all), g["log_Q_from_q"])
+    with pytest.raises(RuntimeError, match="Must specify log_j"):
+        P.compute_log_Q(me, g["x_prime"])
+    me.weights = {**weights, 2: np.nan}
+    with pytest.raises(RuntimeError, match="weights are not set"):
+        P.compute_log_Q(me, g["x_prime"], log_j=g["log_j"])
