@@ -152,7 +152,7 @@ __device__ __forceinline__ void trf_linear(const float* __restrict__ Ain, int Kd
     const int o = ot * 32 + j;
     const bool o_ok = o < O;
     const unsigned oc = (unsigned)(o_ok ? o : O - 1);
-    f32x16 acc = {0};
+    f32x16 acc = {0}, acc2 = {0};
     const float* ax = Ain + (rt * 32 + j) * ld;
     for (int u0 = 0; u0 < pairs; u0 += 16) {
       float wv[16];
@@ -182,11 +182,16 @@ __device__ __forceinline__ void trf_linear(const float* __restrict__ Ain, int Kd
         av[q] = ok ? av[q] : 0.0f;
         wv[q] = (ok && o_ok) ? wv[q] : 0.0f;
       }
+      // two independent accumulation chains, no branches (k beyond Kd carries zero operands):
+      // guarded, single-chain MFMAs issued at 100-145 cycles each instead of 64
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        if (u0 + q < pairs) acc = nsa_mfma(av[q], wv[q], acc);  // wave-uniform guard
+      for (int q = 0; q < 16; q += 2) {
+        acc = nsa_mfma(av[q], wv[q], acc);
+        acc2 = nsa_mfma(av[q + 1], wv[q + 1], acc2);
       }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     if (o_ok) {
       const float bias = b[o];
 #pragma unroll
@@ -214,24 +219,35 @@ __device__ __forceinline__ void trf_dx(const float* __restrict__ G, int g_ld, in
     const int kcol = kt * 32 + j;
     const unsigned wc = (unsigned)(kcol < Kd ? kcol : Kd - 1);
     const bool col_ok = kcol < Kd;
-    f32x16 acc = {0};
+    f32x16 acc = {0}, acc2 = {0};
     const float* ag = G + (rt * 32 + j) * g_ld;
     for (int u0 = 0; u0 < pairs; u0 += 16) {
-      float wv[16];
+      float wv[16], av[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int o = 2 * (u0 + q) + half;
         wv[q] = W[(unsigned)(o < O ? o : O - 1) * (unsigned)Kd + wc];  // lanes along the row: coalesced
       }
 #pragma unroll
+      for (int q = 0; q < 16; ++q) {  // LDS reads issued together, not one per MFMA
+        const int o = 2 * (u0 + q) + half;
+        av[q] = ag[o < O ? o : 0];
+      }
+#pragma unroll
       for (int q = 0; q < 16; ++q) {
-        if (u0 + q < pairs) {  // wave-uniform
-          const int o = 2 * (u0 + q) + half;
-          const bool ok = o < O;
-          acc = nsa_mfma(ok ? ag[o] : 0.0f, (ok && col_ok) ? wv[q] : 0.0f, acc);
-        }
+        const int o = 2 * (u0 + q) + half;
+        const bool ok = o < O;
+        av[q] = ok ? av[q] : 0.0f;
+        wv[q] = (ok && col_ok) ? wv[q] : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {  // two independent chains; o beyond O carries zero operands
+        acc = nsa_mfma(av[q], wv[q], acc);
+        acc2 = nsa_mfma(av[q + 1], wv[q + 1], acc2);
       }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     if (col_ok) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -260,7 +276,7 @@ __device__ __forceinline__ void trf_dw(const float* __restrict__ G, int g_ld, in
     const int ot = t / KT, kt = t - ot * KT;
     const int oc = ot * 32 + j, kc = kt * 32 + j;
     const bool o_ok = oc < O, k_ok = kc < Kd;
-    f32x16 acc = {0};
+    f32x16 acc = {0}, acc2 = {0};
     const int ocl = o_ok ? oc : 0, kcl = k_ok ? kc : 0;
     for (int ub = 0; ub < TRF_ROWS / 2; ub += 16) {  // 32 LDS reads issued before each 16-MFMA chain
       float av[16], bv[16];
@@ -277,8 +293,13 @@ __device__ __forceinline__ void trf_dw(const float* __restrict__ G, int g_ld, in
         bv[q] = k_ok ? bv[q] : 0.0f;
       }
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc = nsa_mfma(av[q], bv[q], acc);  // D[i = o][jj = k]
+      for (int q = 0; q < 16; q += 2) {  // D[i = o][jj = k], two independent chains
+        acc = nsa_mfma(av[q], bv[q], acc);
+        acc2 = nsa_mfma(av[q + 1], bv[q + 1], acc2);
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     if (k_ok) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -417,12 +438,21 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
                 const int o = c0 + 2 * (u0 + q) + half;
                 wv[q] = Wf[(unsigned)(o < np ? o : np - 1) * (unsigned)H + wc];
               }
+              float av[16];
+#pragma unroll
+              for (int q = 0; q < 16; ++q) {
+                const int oc = 2 * (u0 + q) + half;
+                av[q] = ag[oc < nc ? oc : 0];
+              }
 #pragma unroll
               for (int q = 0; q < 16; ++q) {
                 const int oc = 2 * (u0 + q) + half;
                 const bool ok = oc < nc;
-                acc_dx[s_] = nsa_mfma(ok ? ag[oc] : 0.0f, (ok && col_ok) ? wv[q] : 0.0f, acc_dx[s_]);
+                av[q] = ok ? av[q] : 0.0f;
+                wv[q] = (ok && col_ok) ? wv[q] : 0.0f;
               }
+#pragma unroll
+              for (int q = 0; q < 16; ++q) acc_dx[s_] = nsa_mfma(av[q], wv[q], acc_dx[s_]);
             }
           }
         }
