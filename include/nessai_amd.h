@@ -199,6 +199,8 @@ NSA_API int nsa_populate_accept(long long n, int D, const double* log_w_dev, con
  *   x_dev       [n][D] float32 minibatch;  step = 1-based optimiser step count
  *   weights_dev [n] float32 sample weights for the weighted loss
  *               -sum(w log_prob) / sum(w) (flowmodel/base.py:404-407), or NULL
+ *   optimiser   0 AdamW, 1 Adam (L2 weight decay), 2 SGD without momentum - the three choices of
+ *               FlowModel.get_optimiser (flowmodel/base.py:105-135)
  *   loss_acc_dev  float[1], the minibatch loss is ADDED (read once per epoch)
  */
 NSA_API size_t nsa_train_workspace_floats(const long long* plan, long long n);
@@ -206,8 +208,8 @@ NSA_API int nsa_train_step(const long long* plan, const int* tables_dev, const f
                            float* params_dev, float* grads_dev, float* adam_m_dev, float* adam_v_dev,
                            const float* x_dev, const float* weights_dev, long long n,
                            float* workspace_dev, float lr, float beta1, float beta2, float eps,
-                           float weight_decay, float clip_norm, long long step, float* loss_acc_dev,
-                           void* stream);
+                           float weight_decay, float clip_norm, long long step, int optimiser,
+                           float* loss_acc_dev, void* stream);
 /* Forward only (FlowModel._validate, flowmodel/base.py:454-523):
  * loss_acc_dev[0] += -mean(log_prob(x)); log_prob_out_dev [n] may be NULL. */
 NSA_API int nsa_train_eval(const long long* plan, const int* tables_dev, const float* consts,

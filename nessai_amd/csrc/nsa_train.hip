@@ -714,10 +714,13 @@ __global__ void __launch_bounds__(256) tr_grad_sqnorm(long long n, const float* 
   if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
 }
 
-// clip_grad_norm_ (coef = min(1, max_norm / (norm + 1e-6))) fused with torch.optim.AdamW
+// clip_grad_norm_ (coef = min(1, max_norm / (norm + 1e-6))) fused with the optimiser update of
+// FlowModel.get_optimiser (src/nessai/flowmodel/base.py:105-135):
+//   mode 0 torch.optim.AdamW (decoupled decay p *= 1 - lr wd), 1 torch.optim.Adam (L2: g += wd p),
+//   2 torch.optim.SGD without momentum (g += wd p; p -= lr g)
 __global__ void tr_adamw(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                          float* __restrict__ v, const float* __restrict__ sq_partial, float max_norm, float lr,
-                         float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
+                         float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, int mode) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= n) return;
   float coef = 1.0f;
@@ -727,8 +730,14 @@ __global__ void tr_adamw(long long n, float* __restrict__ p, const float* __rest
     coef = max_norm / (sqrtf(sq) + 1e-6f);
     coef = coef < 1.0f ? coef : 1.0f;
   }
-  const float grad = g[i] * coef;
-  float pi = p[i] * (1.0f - lr * wd);
+  float grad = g[i] * coef;
+  float pi = p[i];
+  if (mode == 0) pi *= 1.0f - lr * wd;
+  else if (wd != 0.0f) grad = grad + wd * pi;
+  if (mode == 2) {
+    p[i] = pi - lr * grad;
+    return;
+  }
   const float mi = beta1 * m[i] + (1.0f - beta1) * grad;
   const float vi = beta2 * v[i] + (1.0f - beta2) * grad * grad;
   m[i] = mi;
@@ -1101,8 +1110,9 @@ extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_d
                                       long long n, float* workspace_dev, float lr, float beta1, float beta2,
                                       float eps,
                                       float weight_decay, float clip_norm, long long step,
-                                      float* loss_acc_dev, void* stream) {
-  if (!plan || !tables_dev || !params_dev || !grads_dev || !x_dev || !workspace_dev || !loss_acc_dev || n <= 1)
+                                      int optimiser, float* loss_acc_dev, void* stream) {
+  if (!plan || !tables_dev || !params_dev || !grads_dev || !x_dev || !workspace_dev || !loss_acc_dev || n <= 1 ||
+      optimiser < 0 || optimiser > 2)
     return NSA_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const long long D = plan[0], n_params = plan[8];
@@ -1122,7 +1132,7 @@ extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_d
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
   hipLaunchKernelGGL(tr_adamw, blocks_for(n_params), dim3(256), 0, s, n_params, params_dev, grads_dev, adam_m_dev,
-                     adam_v_dev, w.scal + 128, clip_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+                     adam_v_dev, w.scal + 128, clip_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, optimiser);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? NSA_OK : NSA_E_HIP;
 }

@@ -50,7 +50,7 @@ SIGNATURES = {
     "nsa_train_step": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll,
-         c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_ll, c_void_p, c_void_p],
+         c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_ll, c_int, c_void_p, c_void_p],
     ),
     "nsa_train_eval": (
         c_int,

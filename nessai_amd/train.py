@@ -31,9 +31,13 @@ from .flows import modules as M
 class Trainer:
     """Flat parameter / gradient / Adam-moment buffers + the layer plan."""
 
-    def __init__(self, flow, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+    OPTIMISERS = {"adamw": 0, "adam": 1, "sgd": 2}  # nsa_train_step's `optimiser` argument
+
+    def __init__(self, flow, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, optimiser="adamw"):
         self.flow = flow
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
+        self.base_lr = float(lr)
+        self.optimiser = self.OPTIMISERS[optimiser]
         self.step_count = 0
         device = next(flow.parameters()).device
         if device.type != "cuda":
@@ -170,7 +174,7 @@ class Trainer:
             self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(self.grads),
             lib.ptr(self.adam_m), lib.ptr(self.adam_v), lib.ptr(x), lib.ptr(weights), x.shape[0], lib.ptr(ws),
             self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-            float(clip_norm or 0.0), self.step_count, lib.ptr(self.loss_acc), lib.c_void_p(stream),
+            float(clip_norm or 0.0), self.step_count, self.optimiser, lib.ptr(self.loss_acc), lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_train_step")
 
@@ -188,28 +192,44 @@ class Trainer:
 def get_trainer(flow_model):
     tc = flow_model.training_config
     if flow_model._trainer is None or flow_model._trainer.flow is not flow_model.model:
+        # FlowModel.get_optimiser (src/nessai/flowmodel/base.py:105-135): adam adds weight_decay=1e-6
         name = (tc.get("optimiser") or "adamw").lower()
         kwargs = dict(tc.get("optimiser_kwargs") or {})
-        if name == "adamw":
-            weight_decay = kwargs.pop("weight_decay", 0.01)
-        elif name == "adam":
-            raise NotImplementedError("Adam (L2 weight decay) has no gfx950 kernel; use 'adamw'")
-        else:
-            raise NotImplementedError(f"optimiser {name!r} has no gfx950 kernel")
-        flow_model._trainer = Trainer(
-            flow_model.model, lr=tc["lr"], betas=kwargs.pop("betas", (0.9, 0.999)),
-            eps=kwargs.pop("eps", 1e-8), weight_decay=weight_decay,
-        )
+        defaults = {"adamw": 0.01, "adam": 1e-6, "sgd": 0.0}
+        if name not in defaults:
+            raise NotImplementedError(f"optimiser {name!r} has no gfx950 kernel (adamw, adam, sgd)")
+        weight_decay = kwargs.pop("weight_decay", defaults[name])
+        lr = kwargs.pop("lr", tc["lr"])
+        betas, eps = kwargs.pop("betas", (0.9, 0.999)), kwargs.pop("eps", 1e-8)
+        if name == "sgd":
+            for k in ("momentum", "dampening", "nesterov"):
+                if kwargs.pop(k, 0):
+                    raise NotImplementedError(f"SGD with {k} has no gfx950 kernel")
+        if kwargs.pop("amsgrad", False):
+            raise NotImplementedError("amsgrad has no gfx950 kernel")
+        if kwargs:
+            raise TypeError(f"Unknown optimiser arguments: {sorted(kwargs)}")
+        flow_model._trainer = Trainer(flow_model.model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      optimiser=name)
     return flow_model._trainer
 
 
 def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=None, weights=None):
     tc = flow_model.training_config
-    if tc.get("annealing"):
-        raise NotImplementedError("cosine annealing has no gfx950 kernel yet")
-    if tc.get("noise_type"):
-        raise NotImplementedError("training noise has no gfx950 kernel yet")
     trainer = get_trainer(flow_model)
+    trainer.lr = trainer.base_lr
+    # Gaussian noise added to every training minibatch (flowmodel/base.py:424-425, 596-605)
+    noise_scale = None
+    if tc.get("noise_type") == "adaptive":
+        from scipy.spatial import distance
+
+        d = distance.cdist(samples, samples, "euclidean")  # utils/distance.py:10-30
+        d[d == 0] = np.nan
+        noise_scale = float(tc["noise_scale"] * np.mean(np.nanmin(d, axis=1)))
+    elif tc.get("noise_type") == "constant":
+        noise_scale = float(tc["noise_scale"])
+    elif tc.get("noise_type"):
+        raise ValueError(f"Unknown noise type: {tc['noise_type']}")
     model = flow_model.model
     validate = val_size != 0.0
     train_data, val_data, batch_size = flow_model.prep_data(
@@ -232,7 +252,12 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
         batches = train_data[p, :].split(batch_size)
         w_batches = w_train[p].split(batch_size) if w_train is not None else [None] * len(batches)
         trainer.loss_acc.zero_()
+        if tc.get("annealing"):
+            # CosineAnnealingLR(T_max=max_epochs, eta_min=0), stepped once per epoch (base.py:449-450, 628-631)
+            trainer.lr = trainer.base_lr * 0.5 * (1.0 + math.cos(math.pi * (epoch - 1) / max_epochs))
         for x, w in zip(batches, w_batches):
+            if noise_scale:
+                x = x + noise_scale * torch.randn_like(x)
             trainer.step(x.contiguous(), clip_norm=clip, weights=None if w is None else w.contiguous())
         if validate and len(val_data):
             val_acc = torch.zeros_like(trainer.loss_acc)

@@ -282,3 +282,61 @@ def test_fused_coupling_kernels_match_the_layer_wise_kernels(name, monkeypatch):
     assert float((g0 - g1).abs().max()) <= 5e-5 * scale
     if name != "nsf_bn_lu":  # eval mode only differs for batch norm (running statistics after one step)
         assert rel_err(lp0, lp1) <= 2e-6
+
+
+@pytest.mark.parametrize("optimiser,torch_cls,kwargs", [
+    ("adam", torch.optim.Adam, dict(weight_decay=1e-6)),
+    ("adam", torch.optim.Adam, dict(weight_decay=0.05)),
+    ("sgd", torch.optim.SGD, dict()),
+    ("adamw", torch.optim.AdamW, dict()),
+])
+def test_optimiser_choices_match_torch(optimiser, torch_cls, kwargs):
+    """The three optimisers of FlowModel.get_optimiser (flowmodel/base.py:105-135): three steps on
+    the device against the same torch optimiser on the oracle."""
+    ref, flow, D = pair("nsf_d4")
+    ref.train()
+    opt = torch_cls(ref.parameters(), lr=1e-2, **kwargs)
+    tr = Trainer(flow, lr=1e-2, weight_decay=kwargs.get("weight_decay", 0.01 if optimiser == "adamw" else 0.0),
+                 optimiser=optimiser)
+    g = torch.Generator().manual_seed(4)
+    for _ in range(3):
+        x = torch.randn(200, D, generator=g)
+        opt.zero_grad()
+        (-ref.log_prob(x).mean()).backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 5.0)
+        opt.step()
+        tr.step(x.to(DEV), clip_norm=5.0)
+    torch.cuda.synchronize()
+    assert float((tr.params.cpu() - flat_of(ref)).abs().max()) <= 3e-5
+
+
+def test_annealing_and_noise_options(tmp_path):
+    """Cosine annealing of the learning rate per epoch and Gaussian training noise
+    (flowmodel/base.py:424-425, 449-450, 596-605, 628-631)."""
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    data = rng.normal(size=(600, 3)) * np.array([1.0, 0.3, 2.0])
+    fm = FlowModel(
+        flow_config=dict(n_inputs=3, n_neurons=8, n_blocks=2, n_layers=1, ftype="realnvp",
+                         batch_norm_between_layers=False, linear_transform="permutation"),
+        training_config=dict(batch_size=300, max_epochs=8, patience=100, annealing=True, noise_type="adaptive",
+                             noise_scale=0.1, optimiser="adam"),
+        output=str(tmp_path), rng=rng,
+    )
+    fm.initialise()
+    history = fm.train(data)
+    assert len(history["loss"]) == 8 and np.isfinite(history["loss"]).all()
+    tr = fm._trainer
+    assert tr.optimiser == Trainer.OPTIMISERS["adam"] and tr.weight_decay == pytest.approx(1e-6)
+    # lr of the last epoch: 7 scheduler steps of CosineAnnealingLR(T_max=8) from 1e-3
+    sched_ref = torch.optim.lr_scheduler.CosineAnnealingLR(
+        torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-3), 8)
+    for _ in range(7):
+        sched_ref.optimizer.step()
+        sched_ref.step()
+    assert tr.lr == pytest.approx(sched_ref.get_last_lr()[0], rel=1e-9)
+    with pytest.raises(NotImplementedError):
+        bad = FlowModel(flow_config=dict(n_inputs=3, n_neurons=8, n_blocks=2, n_layers=1),
+                        training_config=dict(optimiser="rmsprop"), output=str(tmp_path), rng=rng)
+        bad.initialise()
+        bad.train(data, max_epochs=1)
