@@ -1,0 +1,75 @@
+"""Sharded populate end to end: two ranks (one process each) against one rank.
+
+The draw kernel's Philox streams are indexed by the GLOBAL row, so two ranks that each take half
+of every draw batch must reproduce the single-rank run exactly: same accepted rows in the same
+order, same counts.  The GPU box has one device, so both ranks share it and the collectives run
+on the ``gloo`` backend (the product code is backend-agnostic; ``bench.py`` uses RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRAW, NS = 40_000, 300
+
+
+def _proposal(world, shard):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import load_c3_fixture
+    from nessai_amd.model import RosenbrockModel
+    from nessai_amd.proposal import FlowProposal
+
+    state, shift, scale, _ = load_c3_fixture()
+    prop = FlowProposal(
+        RosenbrockModel(32), rng=np.random.default_rng(3),
+        flow_config=dict(ftype="nsf", n_neurons=64, n_blocks=6, n_layers=2, num_bins=8),
+        poolsize=NS, drawsize=DRAW, device_seed=77, shard=shard, volume_fraction=0.5,
+    )
+    prop.initialise()
+    prop.flow.model.load_state_dict(state)
+    prop.flow.model.eval()
+    prop.set_rescaling_constants(shift, scale)
+    return prop
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    prop = _proposal(world, shard=True)
+    prop.populate(None, n_samples=NS, max_samples=10**9)
+    x = np.stack([prop.x[n] for n in prop.names], axis=1)
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), x)
+    with open(os.path.join(out_dir, f"c{rank}.txt"), "w") as f:
+        f.write(f"{prop.n_accepted} {prop.n_proposed}")
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_reproduce_one_rank(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    single = _proposal(1, shard=False)
+    single.populate(None, n_samples=NS, max_samples=10**9)
+    expected = np.stack([single.x[n] for n in single.names], axis=1)
+    xs = [np.load(tmp_path / f"x{r}.npy") for r in range(2)]
+    assert np.array_equal(xs[0], xs[1])  # both ranks end with the same pool
+    counts = [(tmp_path / f"c{r}.txt").read_text().split() for r in range(2)]
+    assert counts[0] == counts[1] == [str(single.n_accepted), str(single.n_proposed)]
+    assert np.array_equal(xs[0], expected)
