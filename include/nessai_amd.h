@@ -180,6 +180,18 @@ NSA_API int nsa_populate_accept(long long n, int D, const double* log_w_dev, con
                         double* x_acc_dev, long long* idx_acc_dev, long long* n_accept_dev,
                         void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Analytic benchmark likelihoods on device rows (the pool right after compaction).
+ *
+ * Replaces Model.batch_evaluate_log_likelihood (src/nessai/model.py:644-677) at
+ * flowproposal.py:521 for models that declare one of the built-in forms; float64 in numpy's
+ * reduction order, so the values equal the host evaluation bit for bit.
+ *   kind 0  Rosenbrock (examples/rosenbrock.py:33-45); kind 1 diagonal Gaussian
+ *           -0.5 sum ((x - mu) / sigma)^2 - constant  (mu_dev / sigma_dev [D], or both NULL)
+ *   x64_dev [n][D] float64, out_dev [n] float64; 2 <= D <= 129
+ */
+NSA_API int nsa_log_likelihood(int kind, long long n, int D, const double* x64_dev, const double* mu_dev,
+                               const double* sigma_dev, double constant, double* out_dev, void* stream);
+
 /* ---- training (nessai_amd/csrc/nsa_train.hip) ---------------------------------
  *
  * One minibatch of FlowModel._train (src/nessai/flowmodel/base.py:365-452):

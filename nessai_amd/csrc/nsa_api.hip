@@ -290,3 +290,17 @@ extern "C" int nsa_populate_accept(long long n, int D, const double* log_w_dev,
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "accept kernels: %s", hipGetErrorString(e));
   return NSA_OK;
 }
+
+extern "C" hipError_t nsa_launch_log_likelihood(int, long long, int, const double*, const double*, const double*,
+                                                double, double*, hipStream_t);
+
+extern "C" int nsa_log_likelihood(int kind, long long n, int D, const double* x64_dev, const double* mu_dev,
+                                  const double* sigma_dev, double constant, double* out_dev, void* stream) {
+  if (kind < 0 || kind > 1 || n < 0 || D < 2 || D > 129 || x64_dev == nullptr || out_dev == nullptr ||
+      ((mu_dev == nullptr) != (sigma_dev == nullptr)))
+    return nsa_fail(NSA_E_ARG, "nsa_log_likelihood: bad argument (kind 0/1, 2 <= D <= 129)");
+  hipError_t e = nsa_launch_log_likelihood(kind, n, D, x64_dev, mu_dev, sigma_dev, constant, out_dev,
+                                           (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "log-likelihood kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}

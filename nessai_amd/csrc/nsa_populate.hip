@@ -203,3 +203,61 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_accept(
 extern "C" long long nsa_max_key_init(void) { return nsa_key_encode(-__builtin_huge_val()); }
 extern "C" long long nsa_max_key_encode(double v) { return nsa_key_encode(v); }
 extern "C" double nsa_max_key_decode(long long key) { return nsa_key_decode(key); }
+
+// ---------------------------------------------------------------------------
+// analytic benchmark likelihoods on the accepted rows
+// ---------------------------------------------------------------------------
+// One thread per row, float64, no contraction, and numpy's reduction order for a row of <= 128
+// terms (eight strided partial sums combined pairwise, then the tail) so that the values equal the
+// host Model.log_likelihood bit for bit.
+//   kind 0  Rosenbrock  -sum_i 100 (x_{i+1} - x_i^2)^2 + (1 - x_i)^2      (examples/rosenbrock.py:33-45)
+//   kind 1  diagonal Gaussian  -0.5 sum_i ((x_i - mu_i) / sigma_i)^2 - cst  (mu/sigma NULL: 0 / 1)
+
+__device__ __forceinline__ double nsa_ll_term(int kind, const double* __restrict__ x, int i,
+                                              const double* __restrict__ mu, const double* __restrict__ sigma) {
+#pragma clang fp contract(off)
+  if (kind == 0) {
+    const double x0 = x[i], x1 = x[i + 1];
+    const double a = x1 - x0 * x0;
+    const double b = 1.0 - x0;
+    return 100.0 * (a * a) + b * b;
+  }
+  double t = x[i];
+  if (mu != nullptr) t = (t - mu[i]) / sigma[i];
+  return t * t;
+}
+
+__global__ void nsa_log_likelihood_kernel(int kind, long long n, int D, const double* __restrict__ x,
+                                          const double* __restrict__ mu, const double* __restrict__ sigma,
+                                          double cst, double* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long long row = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const double* xr = x + row * D;
+  const int m = (kind == 0) ? D - 1 : D;  // number of terms
+  double s;
+  if (m < 8) {
+    s = 0.0;
+    for (int i = 0; i < m; ++i) s += nsa_ll_term(kind, xr, i, mu, sigma);
+  } else {
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = nsa_ll_term(kind, xr, j, mu, sigma);
+    int i = 8;
+    for (; i + 8 <= m; i += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] += nsa_ll_term(kind, xr, i + j, mu, sigma);
+    }
+    s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < m; ++i) s += nsa_ll_term(kind, xr, i, mu, sigma);
+  }
+  out[row] = (kind == 0) ? -s : (-0.5 * s - cst);
+}
+
+extern "C" hipError_t nsa_launch_log_likelihood(int kind, long long n, int D, const double* x, const double* mu,
+                                                const double* sigma, double cst, double* out, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(nsa_log_likelihood_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, kind, n, D,
+                     x, mu, sigma, cst, out);
+  return hipGetLastError();
+}

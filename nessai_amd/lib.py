@@ -47,6 +47,7 @@ SIGNATURES = {
     "nsa_max_key_decode": (c_double, [c_ll]),
     "nsa_populate_accept_workspace": (c_size_t, [c_ll]),
     "nsa_train_workspace_floats": (c_size_t, [c_void_p, c_ll]),
+    "nsa_log_likelihood": (c_int, [c_int, c_ll, c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
     "nsa_train_step": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll,

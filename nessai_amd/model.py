@@ -175,6 +175,8 @@ class UniformBoxModel(Model):
 class RosenbrockModel(UniformBoxModel):
     """n-D Rosenbrock likelihood on [-5, 5]^n (``examples/rosenbrock.py:16-45``)."""
 
+    device_likelihood = ("rosenbrock",)  # evaluated on the accepted rows by nsa_log_likelihood
+
     def log_likelihood(self, x):
         a = self.unstructured_view(x)
         return -np.sum(
@@ -188,6 +190,7 @@ class GaussianModel(UniformBoxModel):
 
     def __init__(self, dims, lower=-10.0, upper=10.0):
         super().__init__(dims, lower, upper)
+        self.device_likelihood = ("gaussian", None, None, 0.5 * self.dims * np.log(2 * np.pi))
 
     def log_likelihood(self, x):
         a = self.unstructured_view(x)
@@ -237,6 +240,7 @@ class GWSurrogateModel(SeparablePriorModel):
         self.device_prior = {s[0]: s[2] for s in spec}
         self._mu = np.array([s[3] for s in spec])
         self._sigma = np.array([s[4] for s in spec])
+        self.device_likelihood = ("gaussian", self._mu, self._sigma, 0.0)
 
     def log_likelihood(self, x):
         a = self.unstructured_view(x)

@@ -61,6 +61,11 @@ class FlowProposal:
         analytic densities declared in ``model.device_prior``; ``'host'`` copies
         every candidate to the host and calls ``model.log_prior`` (any prior);
         ``'auto'`` picks ``'device'`` when the model declares either.
+    likelihood : {'auto', 'device', 'host'}
+        ``'device'`` evaluates the log-likelihood of the accepted rows on the GPU right after
+        compaction for models that declare ``device_likelihood`` (the analytic benchmark models);
+        ``'host'`` calls ``model.batch_evaluate_log_likelihood`` as the reference does
+        (``flowproposal.py:521``); ``'auto'`` picks ``'device'`` when declared.
     shard : bool
         When ``torch.distributed`` is initialised, split every draw batch over
         the ranks (one all-reduce(max) + one all-gather per pass).
@@ -94,6 +99,7 @@ class FlowProposal:
         check_acceptance=False,
         device_seed=None,
         prior="auto",
+        likelihood="auto",
         shard=False,
         precision="auto",
         reparameterisations=None,
@@ -138,6 +144,9 @@ class FlowProposal:
         if prior not in ("auto", "device", "host"):
             raise ValueError("prior must be 'auto', 'device' or 'host'")
         self._prior_mode = prior
+        if likelihood not in ("auto", "device", "host"):
+            raise ValueError("likelihood must be 'auto', 'device' or 'host'")
+        self._likelihood_mode = likelihood
         self.shard = shard
         if precision not in ("auto", "f32", "bf16x3"):
             raise ValueError("precision must be 'auto', 'f32' or 'bf16x3'")
@@ -240,6 +249,20 @@ class FlowProposal:
             self._prior_kind_dev = torch.from_numpy(kinds).to(self.device)
             self._prior_par_dev = torch.from_numpy(pars).to(self.device)
         self._upload_constants()
+        spec = getattr(self.model, "device_likelihood", None)
+        if self._likelihood_mode == "device" and spec is None:
+            raise ValueError("likelihood='device' needs model.device_likelihood")
+        self._ll_spec = None
+        if spec is not None and self._likelihood_mode != "host" and 2 <= self.dims <= 129:
+            f64 = dict(dtype=torch.float64, device=self.device)
+            if spec[0] == "rosenbrock":
+                self._ll_spec = (0, None, None, 0.0)
+            elif spec[0] == "gaussian":
+                mu = None if spec[1] is None else torch.tensor(np.asarray(spec[1], dtype=np.float64), **f64)
+                sg = None if spec[2] is None else torch.tensor(np.asarray(spec[2], dtype=np.float64), **f64)
+                self._ll_spec = (1, mu, sg, float(spec[3]))
+            else:
+                raise ValueError(f"Unknown device likelihood {spec[0]!r}")
         self.populated = False
         self.initialised = True
 
@@ -389,6 +412,16 @@ class FlowProposal:
         )
         lib.check(rc, "nsa_populate_draw")
 
+    def _device_log_likelihood(self, rows):
+        """log L of device rows ``(m, D)`` float64 -> ``(m,)`` float64 device tensor."""
+        kind, mu, sigma, const = self._ll_spec
+        out = torch.empty(rows.shape[0], dtype=torch.float64, device=rows.device)
+        stream = lib.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = lib.load().nsa_log_likelihood(kind, rows.shape[0], self.dims, lib.ptr(rows), lib.ptr(mu),
+                                           lib.ptr(sigma), const, lib.ptr(out), stream)
+        lib.check(rc, "nsa_log_likelihood")
+        return out
+
     def _get_buffers(self, n, capacity):
         key = (n, capacity, self.dims)
         if self._buffers is not None and self._buffers["key"] == key:
@@ -535,15 +568,21 @@ class FlowProposal:
             self._draw_counter += n_local * world
             m = min(n_samples - n_accepted, n_acc_batch)
             if m > 0:
-                rows.append(block[:m].cpu().numpy())
+                kept = block[:m].contiguous()
+                if self._ll_spec is not None:  # log L travels with the rows as one more column
+                    kept = torch.cat([kept, self._device_log_likelihood(kept)[:, None]], dim=1)
+                rows.append(kept.cpu().numpy())
             n_accepted += n_acc_batch
             if n_proposed > max_samples:
                 logger.warning("Reached max samples (%s)", max_samples)
                 break
 
-        accepted = np.concatenate(rows, axis=0) if rows else np.empty((0, self.dims))
-        self.x = array_to_live_points_fast(accepted[: min(n_accepted, n_samples)], self.names)
-        self._finish_population(st, n_accepted, n_proposed)
+        width = self.dims + (1 if self._ll_spec is not None else 0)
+        accepted = np.concatenate(rows, axis=0) if rows else np.empty((0, width))
+        accepted = accepted[: min(n_accepted, n_samples)]
+        self.x = array_to_live_points_fast(np.ascontiguousarray(accepted[:, : self.dims]), self.names)
+        log_l = accepted[:, self.dims].copy() if self._ll_spec is not None else None
+        self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
 
     def _populate_accumulate(self, st, threshold, n_samples, max_samples, injected):
         """``accumulate_weights=True`` variant (``flowproposal.py:471-490, 504-510``)."""
@@ -613,10 +652,13 @@ class FlowProposal:
         n_acc = int(buf["n_acc"].item())
         return n_acc, buf["x_acc"][: min(n_acc, n_samples)].cpu().numpy()
 
-    def _finish_population(self, st, n_accepted, n_proposed):
+    def _finish_population(self, st, n_accepted, n_proposed, log_l=None):
         self.samples = self.convert_to_samples(self.x)
         self.population_time += datetime.datetime.now() - st
-        self.samples["logL"] = self.model.batch_evaluate_log_likelihood(self.samples)
+        if log_l is not None:  # evaluated on the device with the rows (nsa_log_likelihood)
+            self.samples["logL"] = log_l
+        else:
+            self.samples["logL"] = self.model.batch_evaluate_log_likelihood(self.samples)
         self.indices = self.rng.permutation(self.samples.size).tolist()
         self.n_accepted = int(n_accepted)
         self.n_proposed = int(n_proposed)
@@ -648,7 +690,7 @@ class FlowProposal:
         state["initialised"] = False
         state["_buffers"] = None
         for k in ("_scale_dev", "_shift_dev", "_lower_dev", "_upper_dev", "_rp_kind_dev", "_rp_par_dev",
-                  "_prior_kind_dev", "_prior_par_dev"):
+                  "_prior_kind_dev", "_prior_par_dev", "_ll_spec"):
             state.pop(k, None)
         state["weights_file"] = getattr(self.flow, "weights_file", None) if self.flow else None
         state["flow"] = None

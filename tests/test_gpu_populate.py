@@ -428,3 +428,29 @@ def test_latent_temperature_validation():
         FlowProposal(RosenbrockModel(2), poolsize=10, latent_temperature=0.0)
     with pytest.raises(TypeError):
         FlowProposal(RosenbrockModel(2), poolsize=10, latent_temperature=True)
+
+
+@pytest.mark.parametrize("which", ["rosenbrock32", "gaussian16", "gw15", "rosenbrock5"])
+def test_device_likelihood_equals_host_likelihood(which):
+    """nsa_log_likelihood on the accepted rows == Model.log_likelihood on the host, bit for bit
+    (float64, numpy's reduction order) - SURVEY.md §8f rank 4, flowproposal.py:521."""
+    from nessai_amd.model import GWSurrogateModel
+
+    model = {"rosenbrock32": lambda: RosenbrockModel(32), "rosenbrock5": lambda: RosenbrockModel(5),
+             "gaussian16": lambda: GaussianModel(16), "gw15": GWSurrogateModel}[which]()
+    props = {}
+    for mode in ("device", "host"):
+        prop = FlowProposal(model, rng=np.random.default_rng(5), poolsize=400, drawsize=20000, device_seed=9,
+                            flow_config=dict(ftype="nsf", n_neurons=16, n_blocks=2), likelihood=mode)
+        torch.manual_seed(0)  # same flow weights in both modes
+        prop.initialise()
+        live = model.new_point(500, rng=np.random.default_rng(1))
+        prop.check_state(live)
+        prop.populate(None, n_samples=400, max_samples=10**8)
+        props[mode] = prop
+    dev, host = props["device"], props["host"]
+    assert dev._ll_spec is not None and host._ll_spec is None
+    for n in dev.names:
+        assert np.array_equal(dev.samples[n], host.samples[n])
+    assert np.array_equal(dev.samples["logL"], host.samples["logL"])
+    assert np.array_equal(dev.samples["logL"], model.log_likelihood(dev.samples))
