@@ -591,6 +591,106 @@ __global__ void tr_bn_eval(int n, int D, float* __restrict__ X, int ldx, const i
 }
 
 // ---------------------------------------------------------------------------
+// act norm (nflows ActNorm: y = exp(log_scale) x + shift, log|det J| = sum log_scale, with the
+// data-dependent initialisation of the first training batch)
+// ---------------------------------------------------------------------------
+
+// one workgroup per feature: std = unbiased std of the column, log_scale = -log(std),
+// shift = -mean(x / std)
+__global__ void __launch_bounds__(256) tr_actnorm_init(int n, const float* __restrict__ X, int ldx,
+                                                       const int* __restrict__ cols, float* __restrict__ log_scale,
+                                                       float* __restrict__ shift) {
+  __shared__ float sm[256];
+  const int i = blockIdx.x, col = cols[i];
+  float s = 0.0f;
+  for (int row = threadIdx.x; row < n; row += 256) s += X[(long long)row * ldx + col];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  const float mean = sm[0] / (float)n;
+  __syncthreads();
+  float q = 0.0f;
+  for (int row = threadIdx.x; row < n; row += 256) {
+    const float d = X[(long long)row * ldx + col] - mean;
+    q += d * d;
+  }
+  sm[threadIdx.x] = q;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  const float std_ = sqrtf(sm[0] / (float)(n - 1));
+  __syncthreads();
+  float m2 = 0.0f;
+  for (int row = threadIdx.x; row < n; row += 256) m2 += X[(long long)row * ldx + col] / std_;
+  sm[threadIdx.x] = m2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    log_scale[i] = -logf(std_);
+    shift[i] = -(sm[0] / (float)n);
+  }
+}
+
+// forward in place; xin (if not null) keeps the input for the backward pass
+__global__ void tr_actnorm_forward(int n, int D, float* __restrict__ X, int ldx, const int* __restrict__ cols,
+                                   const float* __restrict__ log_scale, const float* __restrict__ shift,
+                                   float* __restrict__ xin, float* __restrict__ ld_const) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    float ld = 0.0f;
+    for (int i = 0; i < D; ++i) ld += log_scale[i];
+    ld_const[0] += ld;
+  }
+  if (t >= n * D) return;
+  const int row = t / D, i = t - row * D;
+  const int col = cols[i];
+  const float x = X[(long long)row * ldx + col];
+  if (xin) xin[t] = x;
+  X[(long long)row * ldx + col] = expf(log_scale[i]) * x + shift[i];
+}
+
+// one workgroup per feature: d log_scale = sum gy x scale - 1 (the layer's log|det J| enters every
+// row's log_prob; sum_i d loss / d logdet_i = -1), d shift = sum gy; gx = gy scale; x restored
+__global__ void __launch_bounds__(256) tr_actnorm_backward(int n, float* __restrict__ X, float* __restrict__ Gx,
+                                                           int ldx, const int* __restrict__ cols,
+                                                           const float* __restrict__ xin, int D,
+                                                           const float* __restrict__ log_scale,
+                                                           float* __restrict__ g_log_scale,
+                                                           float* __restrict__ g_shift) {
+  __shared__ float sa[256], sb[256];
+  const int i = blockIdx.x, col = cols[i];
+  const float scale = expf(log_scale[i]);
+  float a = 0.0f, b = 0.0f;
+  for (int row = threadIdx.x; row < n; row += 256) {
+    const float gy = Gx[(long long)row * ldx + col];
+    const float x = xin[(long long)row * D + i];
+    a += gy * x * scale;
+    b += gy;
+    Gx[(long long)row * ldx + col] = gy * scale;
+    X[(long long)row * ldx + col] = x;
+  }
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { sa[threadIdx.x] += sa[threadIdx.x + off]; sb[threadIdx.x] += sb[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    g_log_scale[i] = sa[0] - 1.0f;
+    g_shift[i] = sb[0];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // LU-linear layer: W = L U, unit-diagonal L, diag(U) = softplus(raw) + eps
 // ---------------------------------------------------------------------------
 
@@ -770,8 +870,10 @@ __global__ void tr_copy_rows(long long n, const float* __restrict__ src, float* 
 //                off running_var, eps (float bits), momentum (float bits)}
 //   LU linear : {3, cols offset, off lower_entries, off upper_entries, off unconstrained_upper_diag,
 //                off bias, eps (float bits)}
+//   act norm  : {4, cols offset, off log_scale, off shift, 1 if the data-dependent initialisation is
+//                still due (the host clears it after the first training step)}
 #define TR_HDR 12
-enum { TR_COUPLING = 1, TR_BATCHNORM = 2, TR_LU = 3 };
+enum { TR_COUPLING = 1, TR_BATCHNORM = 2, TR_LU = 3, TR_ACTNORM = 4 };
 
 static inline float tr_bits(long long v) {
   const uint32_t u = (uint32_t)v;
@@ -969,6 +1071,14 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
         hipLaunchKernelGGL(tr_bn_eval, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, D, cols,
                            params + r[2], params + r[3], params + r[4], params + r[5], eps, w.scal + 1);
       }
+    } else if (r[0] == TR_ACTNORM) {
+      const int* cols = tabs + r[1];
+      TrLin q = tr_lin(lay, n, D);
+      if (training && r[4] != 0)
+        hipLaunchKernelGGL(tr_actnorm_init, dim3(D), dim3(256), 0, s, (int)n, w.x, D, cols, params + r[2],
+                           params + r[3]);
+      hipLaunchKernelGGL(tr_actnorm_forward, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, D, cols,
+                         params + r[2], params + r[3], training ? q.xin : (float*)nullptr, w.scal + 1);
     } else {  // TR_LU: y = (x U^T) L^T + b, outputs in logical order
       const int* cols = tabs + r[1];
       const float eps = tr_bits(r[6]);
@@ -1083,6 +1193,11 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
                          var, eps, T1, T2);
       hipLaunchKernelGGL(tr_bn_backward_apply, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, w.gx, D, cols,
                          q.xin, params + r[2], mean, var, eps, T1, T2, grads + r[2], grads + r[3]);
+    } else if (r[0] == TR_ACTNORM) {
+      const int* cols = tabs + r[1];
+      TrLin q = tr_lin(lay, n, D);
+      hipLaunchKernelGGL(tr_actnorm_backward, dim3(D), dim3(256), 0, s, (int)n, w.x, w.gx, D, cols, q.xin, D,
+                         params + r[2], grads + r[2], grads + r[3]);
     } else {  // TR_LU
       const int* cols = tabs + r[1];
       const float eps = tr_bits(r[6]);

@@ -11,11 +11,10 @@ end; training stops ``patience`` epochs after the best one.  The host reads two
 scalars per epoch.
 
 Trainable scope: permutations, LU-linear layers, coupling layers (affine,
-additive, rational-quadratic spline) with a residual conditioner, and batch
-norm between layers - i.e. the reference's RealNVP and NeuralSplineFlow
-defaults;
-act norm, the MLP conditioner and conditional inputs have no training kernels
-and raise.
+additive, rational-quadratic spline) with a residual or plain-MLP conditioner,
+batch norm between layers and act norm (with its data-dependent
+initialisation) - i.e. every RealNVP / NeuralSplineFlow configuration of the
+reference except conditional inputs, which raise.
 """
 
 import ctypes
@@ -76,6 +75,7 @@ class Trainer:
             return int(np.array([value], dtype=np.float32).view(np.uint32)[0])
 
         tmap = np.arange(total, dtype=np.int64)  # transposition map of the weight matrices
+        self._actnorms = []  # (record index, module) of every act-norm layer
 
         for t in leaves:
             if hasattr(t, "_permutation"):
@@ -114,6 +114,14 @@ class Trainer:
                        f32_bits(t.momentum)]
                 tables.extend(cur)
                 records.append(rec)
+            elif isinstance(t, M.ActNorm):
+                # the data-dependent initialisation (first training batch) is done by the kernels;
+                # word [4] says whether it is still due
+                rec = [4, len(tables), offsets[id(t.log_scale)], offsets[id(t.shift)],
+                       0 if bool(t.initialized) else 1]
+                tables.extend(cur)
+                records.append(rec)
+                self._actnorms.append((len(records) - 1, t))
             elif isinstance(t, M.LULinear):
                 if D > 64:
                     raise ValueError("LU-linear transforms support at most 64 features")
@@ -140,6 +148,7 @@ class Trainer:
         tables = list(tables) + tmap.tolist()
         plan = header + [w for rec in records for w in rec]
         self.plan = (ctypes.c_longlong * len(plan))(*plan)
+        self._rec_base, self._rec_words = len(header), rec_words
         self.tables = torch.tensor(tables, dtype=torch.int32, device=device)
         min_d = np.float32(desc.get("min_derivative", 1e-3))
         edge_raw = np.float32(math.log(math.exp(1 - float(min_d)) - 1))
@@ -177,6 +186,11 @@ class Trainer:
             float(clip_norm or 0.0), self.step_count, self.optimiser, lib.ptr(self.loss_acc), lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_train_step")
+        for index, module in self._actnorms:  # initialised by the step that just ran
+            flag = self._rec_base + index * self._rec_words + 4
+            if self.plan[flag]:
+                self.plan[flag] = 0
+                module.initialized.fill_(True)
 
     def evaluate(self, x, log_prob_out=None, weights=None):
         """``loss_acc += -mean(log_prob(x))`` without touching the weights."""

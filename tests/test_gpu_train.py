@@ -253,11 +253,41 @@ def test_batch_norm_running_statistics_follow_the_reference():
         assert torch.allclose(got[k], ref_stats[k], rtol=1e-4, atol=1e-5), k
 
 
-def test_unsupported_training_configurations_raise():
-    flow = RealNVP(4, 8, 2, 2, actnorm=True, batch_norm_between_layers=False)
+def test_act_norm_trains_with_data_dependent_initialisation():
+    """nflows ActNorm: the first training batch sets log_scale = -log(std), shift = -mean(x / std);
+    loss, gradients and the initialised parameters against the oracle (two steps)."""
+    P, Oc, args = RealNVP, O.RealNVP, (6, 16, 2, 2)
+    kw = dict(actnorm=True, batch_norm_between_layers=False, linear_transform="permutation")
+    torch.manual_seed(3)
+    ref = Oc(*args, **kw)
+    flow = P(*args, **kw)
+    flow.load_state_dict(ref.state_dict())
     flow.to(DEV)
-    with pytest.raises(NotImplementedError, match="no training kernel"):
-        Trainer(flow)
+    ref.train()
+    tr = Trainer(flow)
+    g = torch.Generator().manual_seed(8)
+    for step in range(2):
+        x = torch.randn(257, 6, generator=g) * torch.tensor([1.0, 0.2, 3.0, 0.5, 2.0, 1.5]) + 0.7
+        ref.zero_grad()
+        loss_ref = -ref.log_prob(x).mean()
+        loss_ref.backward()
+        tr.loss_acc.zero_()
+        tr.step(x.to(DEV), clip_norm=5.0, lr=0.0)
+        torch.cuda.synchronize()
+        assert abs(tr.loss_acc.item() - loss_ref.item()) <= 2e-5 * max(1.0, abs(loss_ref.item()))
+        g_ref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+        scale = max(1e-3, float(g_ref.abs().max()))
+        assert float((tr.grads.cpu() - g_ref).abs().max()) <= 3e-4 * scale
+        # lr = 0: the only parameter change is the data-dependent initialisation of step 0
+        assert float((tr.params.cpu() - flat_of(ref)).abs().max()) <= 2e-6
+    sd = flow.state_dict()
+    assert all(bool(v) for k, v in sd.items() if k.endswith("initialized"))
+    # eval mode goes through the inference kernel with the initialised parameters
+    flow.eval(); ref.eval()
+    flow._image_key = None
+    xe = torch.randn(100, 6)
+    with torch.no_grad():
+        assert rel_err(flow.log_prob(xe.to(DEV)).cpu(), ref.log_prob(xe)) <= 1e-5
 
 
 @pytest.mark.parametrize("name", ["nsf_c3", "nsf_d7_k4", "nsf_d6_tanh", "rnvp_perm", "rnvp_additive", "nsf_bn_lu"])
