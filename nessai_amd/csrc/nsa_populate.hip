@@ -53,7 +53,10 @@ __global__ void __launch_bounds__(256) nsa_weights_kernel(long long n, const dou
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
-    atomicMax(max_key, nsa_key_encode(m));
+    // thousands of same-address 64-bit atomics serialise (they were 20 of this kernel's 27 us):
+    // only workgroups that can still raise the maximum issue one
+    const long long key = nsa_key_encode(m);
+    if (key > __atomic_load_n(max_key, __ATOMIC_RELAXED)) atomicMax(max_key, key);
   }
 }
 
@@ -166,7 +169,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_weights(
     double* log_w, long long* max_key, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   long long blocks = (n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(nsa_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, log_q,
                      log_prior, log_prior_const, log_w, max_key);
   return hipGetLastError();
