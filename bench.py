@@ -118,7 +118,7 @@ def cpu_baseline():
         fm.model.load_state_dict(state)
         fm.model.eval()
         model = OP.RosenbrockModel(DIMS)
-        sample_draw = 100_000
+        sample_draw = 250_000
         prop = OP.OracleFlowProposal(model, fm, rng=np.random.default_rng(1451), poolsize=NLIVE,
                                      drawsize=sample_draw)
         for i, n in enumerate(model.names):
