@@ -143,6 +143,34 @@ NSA_API int nsa_populate_draw(const uint32_t* header, const void* image_dev, lon
                       double* log_prior_out_dev, const int* rp_kind_dev, const double* rp_par_dev,
                       int* status_dev, int waves_per_group, int max_groups, void* stream);
 
+/* A TRAIN of populate passes with the loop control on the device: for i < n_passes
+ * { nsa_populate_draw(rows row_offset + i n ...); nsa_populate_weights; nsa_populate_accept
+ *   appending to x_acc; commit }  - enqueued back to back with no host round trip.  Replaces the
+ * `while n_accepted < n_samples` loop of FlowProposal.populate (flowproposal.py:431-518) for
+ * on-device draws: a pass whose predecessors already reached the wanted count, or the
+ * `n_proposed > max_samples` exit (flowproposal.py:499-503), does nothing, so the result and the
+ * counters are those of the one-pass-at-a-time loop.
+ *   state_dev  int64[8], set by the caller before the FIRST train of a populate call:
+ *              [0] accepted so far = 0, [1] passes executed = 0, [2] accepted wanted (n_samples),
+ *              [3] rows written to x_acc = 0, [4] scratch, [5] pass limit
+ *              (floor(max_samples / n) + 1); read back after the train
+ *   max_keys_dev  int64[n_passes], each initialised to nsa_max_key_init()
+ *   x_acc_dev  [capacity][D] float64, accepted rows in draw order across the passes
+ *   log_prior_const is used when prior_kind_dev is NULL (uniform prior), otherwise the draw
+ *   kernel's per-row log_prior_dev
+ *   other arguments as nsa_populate_draw / nsa_populate_accept.
+ */
+NSA_API int nsa_populate_passes(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                        unsigned long long seed, unsigned long long row_offset, double radius,
+                        double latent_temperature, const double* scale_dev, const double* shift_dev,
+                        const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                        double* x64_dev, double* log_q_dev, const int* prior_kind_dev,
+                        const double* prior_par_dev, double* log_prior_dev, double log_prior_const,
+                        const int* rp_kind_dev, const double* rp_par_dev, double* log_w_dev,
+                        long long* max_keys_dev, long long capacity, double* x_acc_dev,
+                        long long* state_dev, void* workspace_dev, size_t workspace_bytes,
+                        int* status_dev, int waves_per_group, int max_groups, void* stream);
+
 /* log_w = log_prior - log_q and its maximum.
  *
  * Replaces BaseFlowProposal.compute_weights (proposal/flowproposal/base.py:1069-1098)

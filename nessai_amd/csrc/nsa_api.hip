@@ -198,20 +198,19 @@ extern "C" int nsa_flow_run_many(const uint32_t* header, const void* const* imag
   return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream, n_flows);
 }
 
-extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, long long n,
-                                 const float* z_in_dev, unsigned long long seed,
-                                 unsigned long long row_offset, double radius, double latent_temperature,
-                                 const double* scale_dev, const double* shift_dev,
-                                 const double* lower_dev, const double* upper_dev,
-                                 double log_j_rescale, double* x64_out_dev, double* log_q_out_dev,
-                                 float* z_out_dev, const int* prior_kind_dev,
-                                 const double* prior_par_dev, double* log_prior_out_dev,
-                                 const int* rp_kind_dev, const double* rp_par_dev,
-                                 int* status_dev, int waves_per_group, int max_groups, void* stream) {
+// fills the launch descriptor of the fused draw kernel from the C-ABI arguments
+static int nsa_draw_params(NsaLaunch& p, const uint32_t* header, const void* image_dev, long long n,
+                           const float* z_in_dev, unsigned long long seed, unsigned long long row_offset,
+                           double radius, double latent_temperature, const double* scale_dev,
+                           const double* shift_dev, const double* lower_dev, const double* upper_dev,
+                           double log_j_rescale, double* x64_out_dev, double* log_q_out_dev, float* z_out_dev,
+                           const int* prior_kind_dev, const double* prior_par_dev, double* log_prior_out_dev,
+                           const int* rp_kind_dev, const double* rp_par_dev, int* status_dev) {
   if (image_dev == nullptr || scale_dev == nullptr || shift_dev == nullptr || lower_dev == nullptr ||
       upper_dev == nullptr || x64_out_dev == nullptr || log_q_out_dev == nullptr || status_dev == nullptr)
     return nsa_fail(NSA_E_ARG, "nsa_populate_draw: NULL pointer argument");
-  NsaLaunch p;
+  if (header == nullptr) return nsa_fail(NSA_E_ARG, "header is NULL");
+  if (!(latent_temperature > 0.0)) return nsa_fail(NSA_E_ARG, "nsa_populate_draw: latent_temperature must be > 0");
   memset(&p, 0, sizeof(p));
   p.image = (const uint32_t*)image_dev;
   p.direction = NSA_DIR_INVERSE;
@@ -222,9 +221,7 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
   p.seed = seed;
   p.row_offset = row_offset;
   p.radius = radius;
-  if (!(latent_temperature > 0.0)) return nsa_fail(NSA_E_ARG, "nsa_populate_draw: latent_temperature must be > 0");
   p.latent_scale = sqrt(latent_temperature);
-  if (header == nullptr) return nsa_fail(NSA_E_ARG, "header is NULL");
   p.log_j_latent = (latent_temperature == 1.0) ? 0.0 : (double)header[NSA_H_D] * log(p.latent_scale);
   p.scale = scale_dev;
   p.shift = shift_dev;
@@ -246,16 +243,36 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
     p.rp_kind = rp_kind_dev;
     p.rp_par = rp_par_dev;
   }
+  return NSA_OK;
+}
+
+extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, long long n,
+                                 const float* z_in_dev, unsigned long long seed,
+                                 unsigned long long row_offset, double radius, double latent_temperature,
+                                 const double* scale_dev, const double* shift_dev,
+                                 const double* lower_dev, const double* upper_dev,
+                                 double log_j_rescale, double* x64_out_dev, double* log_q_out_dev,
+                                 float* z_out_dev, const int* prior_kind_dev,
+                                 const double* prior_par_dev, double* log_prior_out_dev,
+                                 const int* rp_kind_dev, const double* rp_par_dev,
+                                 int* status_dev, int waves_per_group, int max_groups, void* stream) {
+  NsaLaunch p;
+  int rc = nsa_draw_params(p, header, image_dev, n, z_in_dev, seed, row_offset, radius, latent_temperature,
+                           scale_dev, shift_dev, lower_dev, upper_dev, log_j_rescale, x64_out_dev, log_q_out_dev,
+                           z_out_dev, prior_kind_dev, prior_par_dev, log_prior_out_dev, rp_kind_dev, rp_par_dev,
+                           status_dev);
+  if (rc != NSA_OK) return rc;
   return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
 }
 
 extern "C" hipError_t nsa_launch_weights(long long, const double*, const double*, double, double*,
-                                         long long*, hipStream_t);
+                                         long long*, hipStream_t, const long long*);
+extern "C" hipError_t nsa_launch_pass_commit(long long*, long long, hipStream_t);
 extern "C" size_t nsa_accept_workspace_bytes(long long);
 extern "C" hipError_t nsa_launch_accept(long long, int, const double*, const long long*,
                                         unsigned long long, unsigned long long, const double*,
                                         const double*, long long, double*, long long*, long long*,
-                                        void*, hipStream_t);
+                                        void*, hipStream_t, const long long*);
 
 extern "C" int nsa_populate_weights(long long n, const double* log_q_dev, const double* log_prior_dev,
                                     double log_prior_const, double* log_w_dev, long long* max_key_dev,
@@ -263,7 +280,7 @@ extern "C" int nsa_populate_weights(long long n, const double* log_q_dev, const 
   if (n < 0 || log_q_dev == nullptr || log_w_dev == nullptr || max_key_dev == nullptr)
     return nsa_fail(NSA_E_ARG, "nsa_populate_weights: bad argument");
   hipError_t e = nsa_launch_weights(n, log_q_dev, log_prior_dev, log_prior_const, log_w_dev, max_key_dev,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, nullptr);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "weights kernel: %s", hipGetErrorString(e));
   return NSA_OK;
 }
@@ -286,7 +303,7 @@ extern "C" int nsa_populate_accept(long long n, int D, const double* log_w_dev,
                     nsa_accept_workspace_bytes(n));
   hipError_t e = nsa_launch_accept(n, D, log_w_dev, max_key_dev, seed, row_offset, u_in_dev, x64_dev,
                                    capacity, x_acc_dev, idx_acc_dev, n_accept_dev, workspace_dev,
-                                   (hipStream_t)stream);
+                                   (hipStream_t)stream, nullptr);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "accept kernels: %s", hipGetErrorString(e));
   return NSA_OK;
 }
@@ -302,5 +319,46 @@ extern "C" int nsa_log_likelihood(int kind, long long n, int D, const double* x6
   hipError_t e = nsa_launch_log_likelihood(kind, n, D, x64_dev, mu_dev, sigma_dev, constant, out_dev,
                                            (hipStream_t)stream);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "log-likelihood kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+// A train of populate passes without host round trips (see include/nessai_amd.h).
+extern "C" int nsa_populate_passes(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                                   unsigned long long seed, unsigned long long row_offset, double radius,
+                                   double latent_temperature, const double* scale_dev, const double* shift_dev,
+                                   const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                                   double* x64_dev, double* log_q_dev, const int* prior_kind_dev,
+                                   const double* prior_par_dev, double* log_prior_dev, double log_prior_const,
+                                   const int* rp_kind_dev, const double* rp_par_dev, double* log_w_dev,
+                                   long long* max_keys_dev, long long capacity, double* x_acc_dev,
+                                   long long* state_dev, void* workspace_dev, size_t workspace_bytes,
+                                   int* status_dev, int waves_per_group, int max_groups, void* stream) {
+  if (n <= 0 || n_passes < 1 || log_w_dev == nullptr || max_keys_dev == nullptr || x_acc_dev == nullptr ||
+      state_dev == nullptr || workspace_dev == nullptr || capacity < 0)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_passes: bad argument");
+  if (workspace_bytes < nsa_accept_workspace_bytes(n))
+    return nsa_fail(NSA_E_ARG, "nsa_populate_passes: workspace too small");
+  NsaLaunch p;
+  int rc = nsa_draw_params(p, header, image_dev, n, nullptr, seed, row_offset, radius, latent_temperature, scale_dev,
+                           shift_dev, lower_dev, upper_dev, log_j_rescale, x64_dev, log_q_dev, nullptr,
+                           prior_kind_dev, prior_par_dev, log_prior_dev, rp_kind_dev, rp_par_dev, status_dev);
+  if (rc != NSA_OK) return rc;
+  p.stop = state_dev;
+  hipStream_t s = (hipStream_t)stream;
+  const int D = (int)header[NSA_H_D];
+  const double* per_row_prior = (prior_kind_dev != nullptr) ? log_prior_dev : nullptr;
+  for (int i = 0; i < n_passes; ++i) {
+    const unsigned long long off = row_offset + (unsigned long long)i * (unsigned long long)n;
+    p.row_offset = off;
+    rc = nsa_launch_flow(header, p, waves_per_group, max_groups, s);
+    if (rc != NSA_OK) return rc;
+    hipError_t e = nsa_launch_weights(n, log_q_dev, per_row_prior, log_prior_const, log_w_dev, max_keys_dev + i, s,
+                                      state_dev);
+    if (e == hipSuccess)
+      e = nsa_launch_accept(n, D, log_w_dev, max_keys_dev + i, seed, off, nullptr, x64_dev, capacity, x_acc_dev,
+                            nullptr, state_dev + 4, workspace_dev, s, state_dev);
+    if (e == hipSuccess) e = nsa_launch_pass_commit(state_dev, capacity, s);
+    if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "populate pass %d: %s", i, hipGetErrorString(e));
+  }
   return NSA_OK;
 }

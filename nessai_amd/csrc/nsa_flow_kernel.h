@@ -64,6 +64,10 @@ struct NsaLaunch {
   // optional per-dimension reparameterisation table (NSA_RP_*); null = z-score everywhere
   const int* rp_kind;             // [D]
   const double* rp_par;           // [D][5] {lo, hi, rescale shift, rescale factor, offset}
+  // device-side loop control of nsa_populate_passes: int64 state {accepted so far, passes executed,
+  // accepted wanted, rows written, accepted in the current pass, pass limit}; a pass whose
+  // predecessors already reached a limit does nothing
+  const long long* stop;
   // grouped launch (APPLY / LOGPROB): gridDim.y flows of identical structure on the same
   // input; flow f reads image_list[f] and writes x_out + f*n*D, ld_out + f*n
   const uint32_t* const* image_list;  // device array of n_flows image pointers, or null
@@ -581,6 +585,7 @@ __device__ __forceinline__ int nsa_opaque(int v) {
 template <int HT, class TP, bool INV, int PREC>
 __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (p.stop != nullptr && (p.stop[0] >= p.stop[2] || p.stop[1] >= p.stop[5])) return;
   if (p.image_list != nullptr) {
     p.image = p.image_list[blockIdx.y];
     if (p.ld_out != nullptr) p.ld_out += (long long)blockIdx.y * p.n;

@@ -17,6 +17,10 @@
 #define NSA_ACC_ROWS (NSA_ACC_THREADS * NSA_ACC_ITEMS)
 
 // monotone (signed) integer encoding of a double, usable with atomicMax
+// loop control of nsa_populate_passes (see NsaLaunch::stop): true when an earlier pass of the
+// train already reached the wanted count or the pass limit
+#define NSA_STOPPED(stop) ((stop) != nullptr && ((stop)[0] >= (stop)[2] || (stop)[1] >= (stop)[5]))
+
 __host__ __device__ inline long long nsa_key_encode(double v) {
   long long b;
   __builtin_memcpy(&b, &v, 8);
@@ -33,7 +37,9 @@ __global__ void __launch_bounds__(256) nsa_weights_kernel(long long n, const dou
                                                           const double* __restrict__ log_prior,
                                                           double log_prior_const,
                                                           double* __restrict__ log_w,
-                                                          long long* max_key) {
+                                                          long long* max_key,
+                                                          const long long* __restrict__ stop) {
+  if (NSA_STOPPED(stop)) return;
   const double ninf = -__builtin_huge_val();
   double m = ninf;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
@@ -73,7 +79,8 @@ __device__ __forceinline__ double nsa_uniform53(unsigned long long seed, unsigne
 __global__ void __launch_bounds__(NSA_ACC_THREADS) nsa_accept_flag_kernel(
     long long n, const double* __restrict__ log_w, const long long* __restrict__ max_key,
     unsigned long long seed, unsigned long long row_offset, const double* __restrict__ u_in,
-    unsigned char* __restrict__ flags, int* __restrict__ block_counts) {
+    unsigned char* __restrict__ flags, int* __restrict__ block_counts, const long long* __restrict__ stop) {
+  if (NSA_STOPPED(stop)) return;
   const double mx = nsa_key_decode(*max_key);
   const long long base = (long long)blockIdx.x * NSA_ACC_ROWS;
   int cnt = 0;
@@ -100,7 +107,9 @@ __global__ void __launch_bounds__(NSA_ACC_THREADS) nsa_accept_flag_kernel(
 // pass 2: exclusive scan of the block counts (one workgroup)
 __global__ void __launch_bounds__(1024) nsa_accept_scan_kernel(int n_blocks, const int* __restrict__ counts,
                                                                long long* __restrict__ offsets,
-                                                               long long* __restrict__ total) {
+                                                               long long* __restrict__ total,
+                                                               const long long* __restrict__ stop) {
+  if (NSA_STOPPED(stop)) return;
   __shared__ long long sm[1024];
   __shared__ long long carry;
   if (threadIdx.x == 0) carry = 0;
@@ -128,7 +137,9 @@ __global__ void __launch_bounds__(1024) nsa_accept_scan_kernel(int n_blocks, con
 __global__ void __launch_bounds__(NSA_ACC_THREADS) nsa_accept_scatter_kernel(
     long long n, int D, const unsigned char* __restrict__ flags, const long long* __restrict__ offsets,
     const double* __restrict__ x64, long long capacity, double* __restrict__ x_acc,
-    long long* __restrict__ idx_acc) {
+    long long* __restrict__ idx_acc, const long long* __restrict__ stop) {
+  if (NSA_STOPPED(stop)) return;
+  const long long written = (stop != nullptr) ? stop[3] : 0;  // rows of earlier passes of the train
   const long long base = (long long)blockIdx.x * NSA_ACC_ROWS;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ int wave_cnt[NSA_ACC_ITEMS][4];
@@ -143,7 +154,7 @@ __global__ void __launch_bounds__(NSA_ACC_THREADS) nsa_accept_scatter_kernel(
     if (lane == 0) wave_cnt[it][wave] = __popcll(ball);
   }
   __syncthreads();
-  long long running = offsets[blockIdx.x];
+  long long running = written + offsets[blockIdx.x];
 #pragma unroll
   for (int it = 0; it < NSA_ACC_ITEMS; ++it) {
     int before = 0;
@@ -166,12 +177,29 @@ __global__ void __launch_bounds__(NSA_ACC_THREADS) nsa_accept_scatter_kernel(
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_weights(
     long long n, const double* log_q, const double* log_prior, double log_prior_const,
-    double* log_w, long long* max_key, hipStream_t stream) {
+    double* log_w, long long* max_key, hipStream_t stream, const long long* stop) {
   if (n <= 0) return hipSuccess;
   long long blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(nsa_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, log_q,
-                     log_prior, log_prior_const, log_w, max_key);
+                     log_prior, log_prior_const, log_w, max_key, stop);
+  return hipGetLastError();
+}
+
+// end of one pass of a train: publish its counts (the only writer of the loop state)
+__global__ void nsa_pass_commit_kernel(long long* state, long long capacity) {
+  if (NSA_STOPPED(state)) return;
+  const long long got = state[4];
+  state[0] += got;
+  state[1] += 1;
+  const long long w = state[3] + got;
+  state[3] = w < capacity ? w : capacity;
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_pass_commit(long long* state,
+                                                                                   long long capacity,
+                                                                                   hipStream_t stream) {
+  hipLaunchKernelGGL(nsa_pass_commit_kernel, dim3(1), dim3(1), 0, stream, state, capacity);
   return hipGetLastError();
 }
 
@@ -186,7 +214,8 @@ extern "C" __attribute__((visibility("hidden"))) size_t nsa_accept_workspace_byt
 extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_accept(
     long long n, int D, const double* log_w, const long long* max_key, unsigned long long seed,
     unsigned long long row_offset, const double* u_in, const double* x64, long long capacity,
-    double* x_acc, long long* idx_acc, long long* n_accept, void* workspace, hipStream_t stream) {
+    double* x_acc, long long* idx_acc, long long* n_accept, void* workspace, hipStream_t stream,
+    const long long* stop) {
   if (n <= 0) return hipMemsetAsync(n_accept, 0, 8, stream);
   const long long nb = (n + NSA_ACC_ROWS - 1) / NSA_ACC_ROWS;
   unsigned char* flags = (unsigned char*)workspace;
@@ -195,11 +224,11 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_accept(
   off += (((size_t)nb * 4) + 255) & ~(size_t)255;
   long long* offsets = (long long*)((char*)workspace + off);
   hipLaunchKernelGGL(nsa_accept_flag_kernel, dim3((unsigned)nb), dim3(NSA_ACC_THREADS), 0, stream, n,
-                     log_w, max_key, seed, row_offset, u_in, flags, counts);
+                     log_w, max_key, seed, row_offset, u_in, flags, counts, stop);
   hipLaunchKernelGGL(nsa_accept_scan_kernel, dim3(1), dim3(1024), 0, stream, (int)nb, counts, offsets,
-                     n_accept);
+                     n_accept, stop);
   hipLaunchKernelGGL(nsa_accept_scatter_kernel, dim3((unsigned)nb), dim3(NSA_ACC_THREADS), 0, stream, n,
-                     D, flags, offsets, x64, capacity, x_acc, idx_acc);
+                     D, flags, offsets, x64, capacity, x_acc, idx_acc, stop);
   return hipGetLastError();
 }
 

@@ -69,6 +69,10 @@ class FlowProposal:
     shard : bool
         When ``torch.distributed`` is initialised, split every draw batch over
         the ranks (one all-reduce(max) + one all-gather per pass).
+    pass_trains : bool
+        Keep the loop control of ``populate`` on the device (``nsa_populate_passes``): several
+        passes are enqueued per host synchronisation and surplus ones switch themselves off.
+        Results are identical to ``False`` (one pass per synchronisation).
     precision : {'auto', 'f32', 'bf16x3'}
         Arithmetic of the conditioner GEMMs inside the fused draw kernel.
         ``'auto'`` uses split-bf16 on the bf16 matrix cores where it is validated
@@ -102,6 +106,7 @@ class FlowProposal:
         likelihood="auto",
         shard=False,
         precision="auto",
+        pass_trains=True,
         reparameterisations=None,
         fallback_reparameterisation="z-score",
         plot=False,
@@ -151,6 +156,7 @@ class FlowProposal:
         if precision not in ("auto", "f32", "bf16x3"):
             raise ValueError("precision must be 'auto', 'f32' or 'bf16x3'")
         self.precision = precision
+        self.pass_trains = bool(pass_trains)
         self.reparameterisations = reparameterisations
         self.fallback_reparameterisation = fallback_reparameterisation
         self.device_seed = (
@@ -541,6 +547,9 @@ class FlowProposal:
         if self.accumulate_weights:
             return self._populate_accumulate(st, threshold, n_samples, max_samples, injected)
 
+        if injected is None and not sharded and self.prior_mode == "device" and self.pass_trains:
+            return self._populate_trains(st, threshold, n_samples, max_samples)
+
         prepared = self._prepare_flow()
         while n_accepted < n_samples:
             z_in = u_in = None
@@ -582,6 +591,69 @@ class FlowProposal:
         accepted = accepted[: min(n_accepted, n_samples)]
         self.x = array_to_live_points_fast(np.ascontiguousarray(accepted[:, : self.dims]), self.names)
         log_l = accepted[:, self.dims].copy() if self._ll_spec is not None else None
+        self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
+
+    def _populate_trains(self, st, threshold, n_samples, max_samples):
+        """The populate loop with its control on the device (``nsa_populate_passes``): trains of
+        passes are enqueued without host round trips; a pass whose predecessors already reached
+        ``n_samples`` (or the ``max_samples`` exit) does nothing, so rows and counters equal those
+        of the one-pass-at-a-time loop.  The train length follows the acceptance seen so far."""
+        L = lib.load()
+        n = self.drawsize
+        flow, header, image, status = self._prepare_flow()
+        buf = self._get_buffers(n, n_samples)
+        dev = self.device
+        max_train = 64
+        if buf.get("state") is None:
+            buf["state"] = torch.zeros(8, dtype=torch.int64, device=dev)
+            buf["max_keys"] = torch.empty(max_train, dtype=torch.int64, device=dev)
+            buf["state_host"] = torch.zeros(8, dtype=torch.int64).pin_memory()
+        state_h = buf["state_host"]
+        state_h.zero_()
+        state_h[2] = n_samples
+        state_h[5] = max_samples // n + 1  # first pass count with n_proposed > max_samples
+        buf["state"].copy_(state_h, non_blocking=True)
+        status.zero_()
+        key_init = int(L.nsa_max_key_init())
+        separable = self._prior_kind_dev is not None
+        log_prior_const = 0.0 if separable else self._uniform_log_prior_constant()
+        stream = lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        # expected accepted rows per pass: last populate call's acceptance, else unknown (probe 1 pass)
+        per_pass = (self.population_acceptance or 0.0) * n
+        n_accepted = passes = 0
+        while True:
+            remaining = n_samples - n_accepted
+            train = 1 if per_pass <= 0 else int(np.ceil(1.15 * remaining / per_pass))
+            train = max(1, min(train, max_train, int(state_h[5]) - passes))
+            buf["max_keys"][:train].fill_(key_init)
+            rc = L.nsa_populate_passes(
+                header, lib.ptr(image), n, train, self.device_seed, int(self._draw_counter + passes * n),
+                float(threshold), float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev),
+                lib.ptr(self._shift_dev), lib.ptr(self._lower_dev), lib.ptr(self._upper_dev),
+                float(self._log_j_rescale), lib.ptr(buf["x64"]), lib.ptr(buf["log_q"]),
+                lib.ptr(self._prior_kind_dev), lib.ptr(self._prior_par_dev),
+                lib.ptr(buf["log_p"] if separable else None), float(log_prior_const),
+                lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), lib.ptr(buf["log_w"]),
+                lib.ptr(buf["max_keys"]), n_samples, lib.ptr(buf["x_acc"]), lib.ptr(buf["state"]),
+                lib.ptr(buf["workspace"]), buf["ws_bytes"], lib.ptr(status), flow.waves_per_group,
+                flow.max_groups, stream,
+            )
+            lib.check(rc, "nsa_populate_passes")
+            state_h.copy_(buf["state"])  # the train's one synchronisation
+            n_accepted, passes = int(state_h[0]), int(state_h[1])
+            if n_accepted >= n_samples:
+                break
+            if passes >= int(state_h[5]):
+                logger.warning("Reached max samples (%s)", max_samples)
+                break
+            per_pass = n_accepted / passes if n_accepted else per_pass * 0.5
+        n_proposed = passes * n
+        self._draw_counter += n_proposed
+        kept = buf["x_acc"][: min(n_accepted, n_samples)]
+        log_l = None
+        if self._ll_spec is not None and kept.shape[0]:
+            log_l = self._device_log_likelihood(kept.contiguous()).cpu().numpy()
+        self.x = array_to_live_points_fast(kept.cpu().numpy(), self.names)
         self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
 
     def _populate_accumulate(self, st, threshold, n_samples, max_samples, injected):

@@ -454,3 +454,51 @@ def test_device_likelihood_equals_host_likelihood(which):
         assert np.array_equal(dev.samples[n], host.samples[n])
     assert np.array_equal(dev.samples["logL"], host.samples["logL"])
     assert np.array_equal(dev.samples["logL"], model.log_likelihood(dev.samples))
+
+
+@pytest.mark.parametrize("case", ["c3_fixture", "small_batches", "max_samples", "separable_prior"])
+def test_pass_trains_equal_one_pass_at_a_time(case):
+    """nsa_populate_passes (loop control on the device, several passes per host synchronisation)
+    reproduces the one-pass-per-synchronisation loop exactly: rows, order, counters, Philox use."""
+    from nessai_amd.model import GWSurrogateModel
+
+    results = {}
+    for trains in (True, False):
+        torch.manual_seed(0)
+        if case == "c3_fixture":
+            state, shift, scale, _ = load_c3_fixture()
+            prop = FlowProposal(RosenbrockModel(32), rng=np.random.default_rng(3), poolsize=150, drawsize=200_000,
+                                flow_config=dict(ftype="nsf", n_neurons=64, n_blocks=6, n_layers=2, num_bins=8),
+                                device_seed=5, pass_trains=trains)
+            prop.initialise()
+            prop.flow.model.load_state_dict(state)
+            prop.flow.model.eval()
+            prop.set_rescaling_constants(shift, scale)
+            calls = [dict(n_samples=150, max_samples=10**9)] * 2
+        elif case == "separable_prior":
+            model = GWSurrogateModel()
+            prop = FlowProposal(model, rng=np.random.default_rng(3), poolsize=300, drawsize=5000, device_seed=5,
+                                flow_config=dict(ftype="nsf", n_neurons=16, n_blocks=2), pass_trains=trains)
+            prop.initialise()
+            prop.check_state(model.new_point(500, rng=np.random.default_rng(1)))
+            calls = [dict(n_samples=300, max_samples=10**8)] * 2
+        else:
+            prop = FlowProposal(GaussianModel(4), rng=np.random.default_rng(3), poolsize=500, drawsize=700,
+                                flow_config=dict(ftype="realnvp", n_neurons=8, n_blocks=2), device_seed=5,
+                                pass_trains=trains)
+            prop.initialise()
+            prop.check_state(GaussianModel(4).new_point(300, rng=np.random.default_rng(1)))
+            calls = ([dict(n_samples=500, max_samples=10**8)] * 3 if case == "small_batches"
+                     else [dict(n_samples=5000, max_samples=3000)])
+        out = []
+        for kw in calls:
+            prop.populate(None, **kw)
+            out.append((np.stack([prop.x[n] for n in prop.names], axis=1), prop.n_accepted, prop.n_proposed,
+                        prop._draw_counter, prop.samples["logL"].copy()))
+        results[trains] = out
+    for a, b in zip(results[True], results[False]):
+        assert a[1:4] == b[1:4]
+        assert np.array_equal(a[0], b[0])
+        assert np.array_equal(a[4], b[4])
+    if case == "max_samples":
+        assert results[True][0][2] > 3000 and results[True][0][1] < 5000  # stopped by max_samples
