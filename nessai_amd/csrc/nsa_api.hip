@@ -268,6 +268,9 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
 extern "C" hipError_t nsa_launch_weights(long long, const double*, const double*, double, double*,
                                          long long*, hipStream_t, const long long*);
 extern "C" hipError_t nsa_launch_pass_commit(long long*, long long, hipStream_t);
+extern "C" hipError_t nsa_launch_small_tail(long long, int, const double*, const double*, double,
+                                            unsigned long long, unsigned long long, const double*, long long,
+                                            double*, long long*, hipStream_t);
 extern "C" size_t nsa_accept_workspace_bytes(long long);
 extern "C" hipError_t nsa_launch_accept(long long, int, const double*, const long long*,
                                         unsigned long long, unsigned long long, const double*,
@@ -352,6 +355,12 @@ extern "C" int nsa_populate_passes(const uint32_t* header, const void* image_dev
     p.row_offset = off;
     rc = nsa_launch_flow(header, p, waves_per_group, max_groups, s);
     if (rc != NSA_OK) return rc;
+    if (n <= 16384) {  // NSA_SMALL_N: the whole tail of the pass in one single-workgroup kernel
+      hipError_t es = nsa_launch_small_tail(n, D, log_q_dev, per_row_prior, log_prior_const, seed, off, x64_dev,
+                                            capacity, x_acc_dev, state_dev, s);
+      if (es != hipSuccess) return nsa_fail(NSA_E_HIP, "populate pass %d: %s", i, hipGetErrorString(es));
+      continue;
+    }
     hipError_t e = nsa_launch_weights(n, log_q_dev, per_row_prior, log_prior_const, log_w_dev, max_keys_dev + i, s,
                                       state_dev);
     if (e == hipSuccess)

@@ -186,6 +186,97 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_weights(
   return hipGetLastError();
 }
 
+// Small passes (n <= NSA_SMALL_N): weights, maximum, accept flags, scan, compaction and the commit
+// of one pass in ONE workgroup - five launches of a few microseconds each would otherwise
+// dominate a pass whose draw kernel takes ~20 us.  Thread t owns the contiguous rows
+// [t c, (t + 1) c), so thread order is draw order; the arithmetic is that of the separate kernels.
+#define NSA_SMALL_N 16384
+#define NSA_SMALL_C 16
+__global__ void __launch_bounds__(1024) nsa_small_tail_kernel(long long n, int D, const double* __restrict__ log_q,
+                                                              const double* __restrict__ log_prior,
+                                                              double log_prior_const, unsigned long long seed,
+                                                              unsigned long long row_offset,
+                                                              const double* __restrict__ x64, long long capacity,
+                                                              double* __restrict__ x_acc, long long* state) {
+  if (NSA_STOPPED(state)) return;
+  __shared__ double smax[16];
+  __shared__ int scnt[1024];
+  const double ninf = -__builtin_huge_val();
+  const int c = (int)((n + 1023) / 1024);
+  const long long lo = (long long)threadIdx.x * c;
+  double w[NSA_SMALL_C];
+  double m = ninf;
+#pragma unroll
+  for (int k = 0; k < NSA_SMALL_C; ++k) {
+    const long long i = lo + k;
+    double v = ninf;
+    if (k < c && i < n) {
+      const double lq = log_q[i];
+      const double lp = (log_prior != nullptr) ? log_prior[i] : log_prior_const;
+      v = lp - lq;
+      if (lq != lq || v != v) v = ninf;
+    }
+    w[k] = v;
+    m = fmax(m, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  double mx = smax[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) mx = fmax(mx, smax[k]);
+  unsigned flags = 0;
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < NSA_SMALL_C; ++k) {
+    const long long i = lo + k;
+    if (k < c && i < n) {
+      const double lu = log(nsa_uniform53(seed, row_offset + (unsigned long long)i));
+      const bool acc = (w[k] - mx) > lu;
+      flags |= acc ? (1u << k) : 0u;
+      cnt += acc ? 1 : 0;
+    }
+  }
+  scnt[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
+    const int t = (threadIdx.x >= off) ? scnt[threadIdx.x - off] : 0;
+    __syncthreads();
+    scnt[threadIdx.x] += t;
+    __syncthreads();
+  }
+  const long long total = scnt[1023];
+  long long dst = state[3] + scnt[threadIdx.x] - cnt;
+#pragma unroll
+  for (int k = 0; k < NSA_SMALL_C; ++k) {
+    if (flags & (1u << k)) {
+      if (dst < capacity) {
+        const long long i = lo + k;
+        for (int cc = 0; cc < D; ++cc) x_acc[dst * D + cc] = x64[i * D + cc];
+      }
+      ++dst;
+    }
+  }
+  __syncthreads();  // every thread has read state[3]
+  if (threadIdx.x == 0) {
+    state[4] = total;
+    state[0] += total;
+    state[1] += 1;
+    const long long wr = state[3] + total;
+    state[3] = wr < capacity ? wr : capacity;
+  }
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_small_tail(
+    long long n, int D, const double* log_q, const double* log_prior, double log_prior_const,
+    unsigned long long seed, unsigned long long row_offset, const double* x64, long long capacity, double* x_acc,
+    long long* state, hipStream_t stream) {
+  hipLaunchKernelGGL(nsa_small_tail_kernel, dim3(1), dim3(1024), 0, stream, n, D, log_q, log_prior,
+                     log_prior_const, seed, row_offset, x64, capacity, x_acc, state);
+  return hipGetLastError();
+}
+
 // end of one pass of a train: publish its counts (the only writer of the loop state)
 __global__ void nsa_pass_commit_kernel(long long* state, long long capacity) {
   if (NSA_STOPPED(state)) return;
