@@ -92,9 +92,11 @@ DEFAULT_PRECISION = os.environ.get("NESSAI_AMD_PRECISION", "f32")
 
 def populate_precision(flow):
     """Precision the fused populate kernel uses when the proposal asks for ``"auto"``:
-    split-bf16 inside its validated envelope (rational-quadratic flows with >= 30 hidden
-    units - configs 3, 4 and 5: <= 3.3e-6 relative), exact float32 otherwise."""
-    if flow.transform_kind == "rq" and flow.hidden_features >= 30:
+    split-bf16 inside its validated envelope - rational-quadratic flows with >= 15 features and
+    >= 30 hidden units (configs 3, 4 and 5: <= 3.3e-6 relative; a grid of randomised flows
+    with 16-32 features: <= 6.6e-6) - and exact float32 otherwise (narrower flows have a small
+    |log_prob| and reach 1.4e-5 - 2.8e-5 relative in split-bf16, outside the 1e-5 bar)."""
+    if flow.transform_kind == "rq" and flow.hidden_features >= 30 and flow.features >= 15:
         return "bf16x3"
     return "f32"
 

@@ -225,6 +225,30 @@ def test_precision_selection():
     assert populate_precision(c3) == "bf16x3"
     _, c2 = make_pair(RealNVP, O.RealNVP, (16, 32, 4, 2))
     assert populate_precision(c2) == "f32"
+    _, c5 = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (15, 30, 4, 2))
+    assert populate_precision(c5) == "bf16x3"
+    _, narrow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (8, 64, 4, 2))  # small |log_prob|: 1.4e-5 in bf16x3
+    assert populate_precision(narrow) == "f32"
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 6), (24, 48, 6), (32, 32, 6), (15, 30, 8)])
+def test_split_bf16_envelope_of_the_populate_policy(shape):
+    """Every flow shape the 'auto' populate policy sends to the split-bf16 kernel stays inside the
+    1e-5 bar on randomised weights (3 seeds x 3 input scales)."""
+    from nessai_amd.flows.base import populate_precision
+
+    D, H, B = shape
+    worst = 0.0
+    for seed in (1, 2, 3):
+        ref, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (D, H, B, 2), {}, seed=seed)
+        assert populate_precision(flow) == "bf16x3"
+        flow.precision = "bf16x3"
+        for scale in (0.5, 1.0, 3.0):
+            x = torch.randn(3000, D, generator=torch.Generator().manual_seed(seed)) * scale
+            with torch.no_grad():
+                expected = ref.log_prob(x).numpy()
+            worst = max(worst, rel_err(flow.log_prob(x.to(DEV)).cpu().numpy(), expected))
+    assert worst < LOG_PROB_RTOL
 
 
 def test_bench_configuration_meets_the_bar_in_split_bf16():
