@@ -129,7 +129,8 @@ NSA_API int nsa_flow_run_many(const uint32_t* header, const void* const* image_l
  *               (RescaleToBounds._inverse_rescale_to_bounds, rescale.py:537-547, 673-700),
  *               3 the same after u = sigmoid(x') with log|J| += log u + log1p(-u)
  *               (utils/rescaling.py:318-337: the registry's "logit" entry,
- *               reparameterisations/__init__.py:62-70); rp_par_dev [D][5] float64
+ *               reparameterisations/__init__.py:62-70), 4 the same after u = exp(x') with
+ *               log|J| += x' (the "log-rescale" entry); rp_par_dev [D][5] float64
  *               {lo, hi, rs, rf, offset}.  log_j_rescale then carries the row-independent
  *               terms only; the sigmoid terms are added per row in float64.
  */

@@ -79,7 +79,10 @@ struct NsaLaunch {
 //   TO_BOUNDS    x = (hi - lo) * (x' - rs) / rf + lo + offset (rescale.py:537-547, 673-700)
 //   TO_BOUNDS_LOGIT  the same after u = sigmoid(x'), log|J| += log u + log1p(-u)
 //                (utils/rescaling.py:318-337; the "logit" entry of reparameterisations/__init__.py:62-70)
-enum { NSA_RP_SCALE_SHIFT = 0, NSA_RP_NULL = 1, NSA_RP_TO_BOUNDS = 2, NSA_RP_TO_BOUNDS_LOGIT = 3 };
+//   TO_BOUNDS_LOG    the same after u = exp(x'), log|J| += x'
+//                (utils/rescaling.py:359-395: the "log-rescale" entry, reparameterisations/__init__.py:71-79)
+enum { NSA_RP_SCALE_SHIFT = 0, NSA_RP_NULL = 1, NSA_RP_TO_BOUNDS = 2, NSA_RP_TO_BOUNDS_LOGIT = 3,
+       NSA_RP_TO_BOUNDS_LOG = 4 };
 
 enum { NSA_PRIOR_UNIFORM = 0, NSA_PRIOR_SINE = 1, NSA_PRIOR_COSINE = 2, NSA_PRIOR_POWER_LAW = 3,
        NSA_PRIOR_GAUSSIAN = 4 };
@@ -764,6 +767,9 @@ __global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
           if (kind == NSA_RP_TO_BOUNDS_LOGIT) {
             u = 1.0 / (1.0 + exp(-xp));
             log_j_row += log(u) + log1p(-u);
+          } else if (kind == NSA_RP_TO_BOUNDS_LOG) {
+            u = exp(xp);
+            log_j_row += xp;
           }
           xv = (c[1] - c[0]) * (u - c[2]) / c[3] + c[0];
           xv = xv + c[4];

@@ -15,6 +15,7 @@ registry name                         map (x -> x')
 ``offset``                            the same with the prior mid-point subtracted first
 ``logit``                             ``RescaleToBounds`` to [0, 1] with the prior bounds, then
                                       ``logit`` (``utils/rescaling.py:290-337``)
+``log-rescale``                       the same followed by ``log`` (``utils/rescaling.py:359-395``)
 ``null`` ``none``                     ``NullReparameterisation`` (``null.py``)
 ====================================  =========================================================
 
@@ -38,7 +39,7 @@ import numpy as np
 from .livepoint import empty_structured_array
 
 # kinds of nsa_populate_draw's rp_kind table (nsa_flow_kernel.h NSA_RP_*)
-RP_SCALE_SHIFT, RP_NULL, RP_TO_BOUNDS, RP_TO_BOUNDS_LOGIT = 0, 1, 2, 3
+RP_SCALE_SHIFT, RP_NULL, RP_TO_BOUNDS, RP_TO_BOUNDS_LOGIT, RP_TO_BOUNDS_LOG = 0, 1, 2, 3, 4
 
 _KNOWN = {
     "z-score": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
@@ -52,6 +53,7 @@ _KNOWN = {
     "rescale-to-bounds": ("to_bounds", {}),
     "offset": ("to_bounds", dict(offset=True)),
     "logit": ("to_bounds", dict(rescale_bounds=[0.0, 1.0], update_bounds=False, post_rescaling="logit")),
+    "log-rescale": ("to_bounds", dict(rescale_bounds=[0.0, 1.0], update_bounds=False, post_rescaling="log")),
     "null": ("null", {}),
     "none": ("null", {}),
 }
@@ -109,9 +111,9 @@ class _Group:
                 self.rescale_bounds = {p: list(rb) for p in self.parameters}
             self.update_enabled = bool(kw.pop("update_bounds", True))
             self.post = kw.pop("post_rescaling", None)
-            if self.post not in (None, "logit"):
+            if self.post not in (None, "logit", "log"):
                 raise NotImplementedError(f"post_rescaling={self.post!r} has no device map")
-            if self.post == "logit":
+            if self.post in ("logit", "log"):
                 if self.update_enabled:
                     raise RuntimeError("Cannot use log or logit with update bounds")  # rescale.py:491-495
                 self.rescale_bounds = {p: [0, 1] for p in self.parameters}
@@ -190,6 +192,10 @@ class _Group:
                 if self.post == "logit":
                     v, lj = _logit(v)
                     log_j += lj
+                elif self.post == "log":  # utils/rescaling.py:359-375
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        v = np.log(v)
+                    log_j += -v
                 x_prime[pp] = v
         return log_j
 
@@ -213,6 +219,11 @@ class _Group:
                 v = x_prime[pp]
                 if self.post == "logit":
                     v, lj = _sigmoid(v)
+                    log_j += lj
+                elif self.post == "log":  # utils/rescaling.py:378-395
+                    with np.errstate(over="ignore"):
+                        lj = v
+                        v = np.exp(v)
                     log_j += lj
                 lo, hi = self.bounds[p]
                 v = (hi - lo) * (v - self.rshift[p]) / self.factor[p] + lo
@@ -368,7 +379,7 @@ class ReparameterisationTable:
                     shift[i] = g.shift[p] if g.shift else 0.0
                     log_j += np.log(np.abs(g.scale[p]))
                 else:
-                    kind[i] = RP_TO_BOUNDS_LOGIT if g.post == "logit" else RP_TO_BOUNDS
+                    kind[i] = {None: RP_TO_BOUNDS, "logit": RP_TO_BOUNDS_LOGIT, "log": RP_TO_BOUNDS_LOG}[g.post]
                     lo, hi = g.bounds[p]
                     par[i] = [lo, hi, g.rshift[p], g.factor[p], g.offsets[p]]
                     log_j += np.log(hi - lo) - np.log(g.factor[p])

@@ -70,7 +70,7 @@ class OracleRescaleToBounds:
         rb = [-1, 1] if rescale_bounds is None else rescale_bounds
         self.rescale_bounds = {p: list(rb) for p in parameters}
         self.post = post_rescaling
-        if post_rescaling == "logit":  # rescale.py:479-497
+        if post_rescaling in ("logit", "log"):  # rescale.py:479-497
             assert not update_bounds
             self.rescale_bounds = {p: [0, 1] for p in parameters}
         self._update = update_bounds
@@ -97,6 +97,10 @@ class OracleRescaleToBounds:
             if self.post == "logit":
                 v, lj = logit(v)
                 log_j += lj
+            elif self.post == "log":  # utils/rescaling.py:359-375
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    v = np.log(v)
+                log_j += -v
             x_prime[p + "_prime"] = v
         return log_j
 
@@ -106,6 +110,10 @@ class OracleRescaleToBounds:
             if self.post == "logit":
                 v, lj = sigmoid(v)
                 log_j += lj
+            elif self.post == "log":  # utils/rescaling.py:378-395
+                with np.errstate(over="ignore"):
+                    log_j += v
+                    v = np.exp(v)
             lo, hi = self.bounds[p]
             v = (hi - lo) * (v - self.rshift[p]) / self.factor[p] + lo
             log_j += np.log(hi - lo) - np.log(self.factor[p])

@@ -8,7 +8,7 @@ Run in the build container only (needs /root/reference):
 ``nessai.reparameterisations`` imports without glasflow (the stubs of
 ``oracle.reference_harness`` only satisfy unrelated top-level imports).  Stores inputs and the
 reference's outputs of ``CombinedReparameterisation.reparameterise`` / ``inverse_reparameterise``
-for a 6-parameter model that mixes every registry entry the device epilogue supports.
+for a 7-parameter model that mixes every registry entry the device epilogue supports.
 """
 import os
 import sys
@@ -25,15 +25,16 @@ reference_harness.install()
 from nessai.livepoint import empty_structured_array  # noqa: E402
 from nessai.reparameterisations import CombinedReparameterisation, get_reparameterisation  # noqa: E402
 
-NAMES = ["a", "b", "c", "d", "e", "f"]
+NAMES = ["a", "b", "c", "d", "e", "f", "g"]
 BOUNDS = {"a": [-3.0, 7.0], "b": [0.5, 2.5], "c": [-1.0, 1.0], "d": [10.0, 20.0], "e": [-4.0, 4.0],
-          "f": [0.0, 5.0]}
+          "f": [0.0, 5.0], "g": [1.0, 9.0]}
 # (registry name, parameters, extra kwargs), in the order they are added
 SPEC = [
     ("logit", ["b", "f"], {}),
     ("rescaletobounds", ["a"], {}),
     ("offset", ["d"], {}),
     ("null", ["c"], {}),
+    ("log-rescale", ["g"], {}),
     ("z-score", ["e"], {}),
 ]
 

@@ -127,7 +127,8 @@ def test_populate_injected_matches_oracle(cfg):
     assert prop.populated and sorted(prop.indices) == list(range(prop.samples.size))
 
 
-REPARAM_CONFIG = {"logit": ["x_0", "x_3"], "default": ["x_1"], "offset": ["x_5"], "null": ["x_2"]}  # x_4: z-score
+REPARAM_CONFIG = {"logit": ["x_0"], "log-rescale": ["x_3"], "default": ["x_1"], "offset": ["x_5"],
+                  "null": ["x_2"]}  # x_4: z-score
 
 
 def build_with_reparameterisations(seed=3, **kwargs):
@@ -137,8 +138,10 @@ def build_with_reparameterisations(seed=3, **kwargs):
     prop, oprop = build(6, "nsf", dict(n_neurons=16, n_blocks=3), reparameterisations=REPARAM_CONFIG, **kwargs)
     b = {n: [-5.0, 5.0] for n in prop.names}
     oprop.reparam = OR.OracleCombined([
-        OR.OracleRescaleToBounds(["x_0", "x_3"], b, rescale_bounds=[0.0, 1.0], update_bounds=False,
+        OR.OracleRescaleToBounds(["x_0"], b, rescale_bounds=[0.0, 1.0], update_bounds=False,
                                  post_rescaling="logit"),
+        OR.OracleRescaleToBounds(["x_3"], b, rescale_bounds=[0.0, 1.0], update_bounds=False,
+                                 post_rescaling="log"),
         OR.OracleRescaleToBounds(["x_1"], b),
         OR.OracleRescaleToBounds(["x_5"], b, offset=True),
         OR.OracleNull(["x_2"]),
@@ -161,7 +164,7 @@ def test_backward_pass_with_reparameterisation_table_matches_oracle():
     z = np.random.default_rng(0).normal(size=(6000, 6)).astype(np.float32).astype(np.float64) * 1.2
     x, log_q, z_kept = prop.backward_pass(z, return_z=True)
     x_o, log_q_o, z_o = oprop.backward_pass(z)
-    assert len(x_o) > 1000
+    assert len(x_o) > 500
     assert len(x) == len(x_o) and np.array_equal(z_kept, z_o)
     for n in prop.names:
         np.testing.assert_allclose(x[n], x_o[n], rtol=0, atol=1e-3 if n in ("x_0", "x_3") else 2e-4)
