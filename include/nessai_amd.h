@@ -172,6 +172,28 @@ NSA_API int nsa_populate_passes(const uint32_t* header, const void* image_dev, l
                         long long* state_dev, void* workspace_dev, size_t workspace_bytes,
                         int* status_dev, int waves_per_group, int max_groups, void* stream);
 
+/* The same pass in pieces, for draw batches SHARDED over ranks: the collectives of the host
+ * framework (RCCL through torch.distributed, stream ordered, no host synchronisation) go between
+ * them:  head (draw + weights + this rank's maximum)  ->  all-reduce(max) of max_key_dev  ->
+ * tail (accept + append; state[4] = this rank's count)  ->  all-reduce(sum) of a copy of state[4]
+ * ->  commit (state[0] += the global count, history[pass] = this rank's count).  Every piece
+ * honours the loop state like nsa_populate_passes.  flowproposal.py:431-518 + SURVEY.md §8e. */
+NSA_API int nsa_populate_pass_head(const uint32_t* header, const void* image_dev, long long n,
+                           unsigned long long seed, unsigned long long row_offset, double radius,
+                           double latent_temperature, const double* scale_dev, const double* shift_dev,
+                           const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                           double* x64_dev, double* log_q_dev, const int* prior_kind_dev,
+                           const double* prior_par_dev, double* log_prior_dev, double log_prior_const,
+                           const int* rp_kind_dev, const double* rp_par_dev, double* log_w_dev,
+                           long long* max_key_dev, const long long* state_dev, int* status_dev,
+                           int waves_per_group, int max_groups, void* stream);
+NSA_API int nsa_populate_pass_tail(long long n, int D, const double* log_w_dev, const long long* max_key_dev,
+                           unsigned long long seed, unsigned long long row_offset, const double* x64_dev,
+                           long long capacity, double* x_acc_dev, long long* state_dev,
+                           void* workspace_dev, size_t workspace_bytes, void* stream);
+NSA_API int nsa_populate_pass_commit(long long* state_dev, long long capacity,
+                             const long long* global_count_dev, long long* history_dev, void* stream);
+
 /* log_w = log_prior - log_q and its maximum.
  *
  * Replaces BaseFlowProposal.compute_weights (proposal/flowproposal/base.py:1069-1098)

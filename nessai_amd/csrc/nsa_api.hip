@@ -267,7 +267,7 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
 
 extern "C" hipError_t nsa_launch_weights(long long, const double*, const double*, double, double*,
                                          long long*, hipStream_t, const long long*);
-extern "C" hipError_t nsa_launch_pass_commit(long long*, long long, hipStream_t);
+extern "C" hipError_t nsa_launch_pass_commit(long long*, long long, const long long*, long long*, hipStream_t);
 extern "C" hipError_t nsa_launch_small_tail(long long, int, const double*, const double*, double,
                                             unsigned long long, unsigned long long, const double*, long long,
                                             double*, long long*, hipStream_t);
@@ -366,8 +366,58 @@ extern "C" int nsa_populate_passes(const uint32_t* header, const void* image_dev
     if (e == hipSuccess)
       e = nsa_launch_accept(n, D, log_w_dev, max_keys_dev + i, seed, off, nullptr, x64_dev, capacity, x_acc_dev,
                             nullptr, state_dev + 4, workspace_dev, s, state_dev);
-    if (e == hipSuccess) e = nsa_launch_pass_commit(state_dev, capacity, s);
+    if (e == hipSuccess) e = nsa_launch_pass_commit(state_dev, capacity, nullptr, nullptr, s);
     if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "populate pass %d: %s", i, hipGetErrorString(e));
   }
+  return NSA_OK;
+}
+
+// The pieces of one pass for SHARDED trains (the collectives of torch.distributed go in between:
+// head -> all-reduce(max) of max_key -> tail -> all-reduce(sum) of state[4] -> commit).
+extern "C" int nsa_populate_pass_head(const uint32_t* header, const void* image_dev, long long n,
+                                      unsigned long long seed, unsigned long long row_offset, double radius,
+                                      double latent_temperature, const double* scale_dev, const double* shift_dev,
+                                      const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                                      double* x64_dev, double* log_q_dev, const int* prior_kind_dev,
+                                      const double* prior_par_dev, double* log_prior_dev, double log_prior_const,
+                                      const int* rp_kind_dev, const double* rp_par_dev, double* log_w_dev,
+                                      long long* max_key_dev, const long long* state_dev, int* status_dev,
+                                      int waves_per_group, int max_groups, void* stream) {
+  if (n <= 0 || log_w_dev == nullptr || max_key_dev == nullptr || state_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_pass_head: bad argument");
+  NsaLaunch p;
+  int rc = nsa_draw_params(p, header, image_dev, n, nullptr, seed, row_offset, radius, latent_temperature, scale_dev,
+                           shift_dev, lower_dev, upper_dev, log_j_rescale, x64_dev, log_q_dev, nullptr,
+                           prior_kind_dev, prior_par_dev, log_prior_dev, rp_kind_dev, rp_par_dev, status_dev);
+  if (rc != NSA_OK) return rc;
+  p.stop = state_dev;
+  rc = nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
+  if (rc != NSA_OK) return rc;
+  hipError_t e = nsa_launch_weights(n, log_q_dev, (prior_kind_dev != nullptr) ? log_prior_dev : nullptr,
+                                    log_prior_const, log_w_dev, max_key_dev, (hipStream_t)stream, state_dev);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "weights kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+extern "C" int nsa_populate_pass_tail(long long n, int D, const double* log_w_dev, const long long* max_key_dev,
+                                      unsigned long long seed, unsigned long long row_offset,
+                                      const double* x64_dev, long long capacity, double* x_acc_dev,
+                                      long long* state_dev, void* workspace_dev, size_t workspace_bytes,
+                                      void* stream) {
+  if (n <= 0 || D < 1 || log_w_dev == nullptr || max_key_dev == nullptr || x64_dev == nullptr ||
+      x_acc_dev == nullptr || state_dev == nullptr || workspace_dev == nullptr || capacity < 0 ||
+      workspace_bytes < nsa_accept_workspace_bytes(n))
+    return nsa_fail(NSA_E_ARG, "nsa_populate_pass_tail: bad argument");
+  hipError_t e = nsa_launch_accept(n, D, log_w_dev, max_key_dev, seed, row_offset, nullptr, x64_dev, capacity,
+                                   x_acc_dev, nullptr, state_dev + 4, workspace_dev, (hipStream_t)stream, state_dev);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "accept kernels: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+extern "C" int nsa_populate_pass_commit(long long* state_dev, long long capacity, const long long* global_count_dev,
+                                        long long* history_dev, void* stream) {
+  if (state_dev == nullptr || capacity < 0) return nsa_fail(NSA_E_ARG, "nsa_populate_pass_commit: bad argument");
+  hipError_t e = nsa_launch_pass_commit(state_dev, capacity, global_count_dev, history_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "commit kernel: %s", hipGetErrorString(e));
   return NSA_OK;
 }

@@ -278,19 +278,23 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_small_tai
 }
 
 // end of one pass of a train: publish its counts (the only writer of the loop state)
-__global__ void nsa_pass_commit_kernel(long long* state, long long capacity) {
+// Sharded runs: `global_count` holds the pass's accepted count summed over the ranks (the stop test
+// is on the global count; rows are appended locally) and `history[pass]` keeps this rank's count
+// so that the host can interleave the ranks' rows pass by pass at the end.
+__global__ void nsa_pass_commit_kernel(long long* state, long long capacity, const long long* global_count,
+                                       long long* history) {
   if (NSA_STOPPED(state)) return;
   const long long got = state[4];
-  state[0] += got;
+  if (history != nullptr) history[state[1]] = got;
+  state[0] += (global_count != nullptr) ? global_count[0] : got;
   state[1] += 1;
   const long long w = state[3] + got;
   state[3] = w < capacity ? w : capacity;
 }
 
-extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_pass_commit(long long* state,
-                                                                                   long long capacity,
-                                                                                   hipStream_t stream) {
-  hipLaunchKernelGGL(nsa_pass_commit_kernel, dim3(1), dim3(1), 0, stream, state, capacity);
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_pass_commit(
+    long long* state, long long capacity, const long long* global_count, long long* history, hipStream_t stream) {
+  hipLaunchKernelGGL(nsa_pass_commit_kernel, dim3(1), dim3(1), 0, stream, state, capacity, global_count, history);
   return hipGetLastError();
 }
 

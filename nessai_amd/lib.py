@@ -47,6 +47,18 @@ SIGNATURES = {
          c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p,
          c_void_p, c_ll, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_int, c_int, c_void_p],
     ),
+    "nsa_populate_pass_head": (
+        c_int,
+        [c_void_p, c_void_p, c_ll, c_ull, c_ull, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    ),
+    "nsa_populate_pass_tail": (
+        c_int,
+        [c_ll, c_int, c_void_p, c_void_p, c_ull, c_ull, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_size_t,
+         c_void_p],
+    ),
+    "nsa_populate_pass_commit": (c_int, [c_void_p, c_ll, c_void_p, c_void_p, c_void_p]),
     "nsa_populate_weights": (c_int, [c_ll, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "nsa_max_key_init": (c_ll, []),
     "nsa_max_key_encode": (c_ll, [c_double]),

@@ -547,7 +547,9 @@ class FlowProposal:
         if self.accumulate_weights:
             return self._populate_accumulate(st, threshold, n_samples, max_samples, injected)
 
-        if injected is None and not sharded and self.prior_mode == "device" and self.pass_trains:
+        if injected is None and self.prior_mode == "device" and self.pass_trains:
+            if sharded:
+                return self._populate_trains_sharded(st, threshold, n_samples, max_samples, n_local, world, rank)
             return self._populate_trains(st, threshold, n_samples, max_samples)
 
         prepared = self._prepare_flow()
@@ -654,6 +656,107 @@ class FlowProposal:
         if self._ll_spec is not None and kept.shape[0]:
             log_l = self._device_log_likelihood(kept.contiguous()).cpu().numpy()
         self.x = array_to_live_points_fast(kept.cpu().numpy(), self.names)
+        self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
+
+    def _populate_trains_sharded(self, st, threshold, n_samples, max_samples, n, world, rank):
+        """``_populate_trains`` for a draw batch sharded over ranks: per pass
+        ``head -> all-reduce(max) -> tail -> all-reduce(sum of the pass counts) -> commit``, all
+        stream ordered; the stop test is on the GLOBAL accepted count, rows are appended locally and
+        interleaved (pass, rank, draw order) once at the end - the order of the per-pass gather."""
+        import torch.distributed as dist
+
+        L = lib.load()
+        flow, header, image, status = self._prepare_flow()
+        buf = self._get_buffers(n, n_samples)
+        dev = self.device
+        max_train = 64
+        if buf.get("state") is None:
+            buf["state"] = torch.zeros(8, dtype=torch.int64, device=dev)
+            buf["max_keys"] = torch.empty(max_train, dtype=torch.int64, device=dev)
+            buf["state_host"] = torch.zeros(8, dtype=torch.int64).pin_memory()
+        if buf.get("gcount") is None:
+            buf["gcount"] = torch.zeros(1, dtype=torch.int64, device=dev)
+            buf["history"] = torch.zeros(256, dtype=torch.int64, device=dev)
+        state, state_h, gcount = buf["state"], buf["state_host"], buf["gcount"]
+        state_h.zero_()
+        state_h[2] = n_samples
+        state_h[5] = max_samples // (n * world) + 1
+        state.copy_(state_h, non_blocking=True)
+        status.zero_()
+        key_init = int(L.nsa_max_key_init())
+        separable = self._prior_kind_dev is not None
+        log_prior_const = 0.0 if separable else self._uniform_log_prior_constant()
+        stream = lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        per_pass = (self.population_acceptance or 0.0) * n * world
+        n_accepted = passes = 0
+        while True:
+            remaining = n_samples - n_accepted
+            train = 1 if per_pass <= 0 else int(np.ceil(1.15 * remaining / per_pass))
+            train = max(1, min(train, max_train, int(state_h[5]) - passes))
+            if buf["history"].numel() < passes + train:
+                grown = torch.zeros(2 * (passes + train), dtype=torch.int64, device=dev)
+                grown[: buf["history"].numel()] = buf["history"]
+                buf["history"] = grown
+            buf["max_keys"][:train].fill_(key_init)
+            for i in range(train):
+                off = int(self._draw_counter + (passes + i) * n * world + rank * n)
+                key = buf["max_keys"][i : i + 1]
+                rc = L.nsa_populate_pass_head(
+                    header, lib.ptr(image), n, self.device_seed, off, float(threshold),
+                    float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
+                    lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
+                    lib.ptr(buf["x64"]), lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev),
+                    lib.ptr(self._prior_par_dev), lib.ptr(buf["log_p"] if separable else None),
+                    float(log_prior_const), lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev),
+                    lib.ptr(buf["log_w"]), lib.ptr(key), lib.ptr(state), lib.ptr(status), flow.waves_per_group,
+                    flow.max_groups, stream,
+                )
+                lib.check(rc, "nsa_populate_pass_head")
+                dist.all_reduce(key, op=dist.ReduceOp.MAX)
+                rc = L.nsa_populate_pass_tail(
+                    n, self.dims, lib.ptr(buf["log_w"]), lib.ptr(key), self.device_seed, off, lib.ptr(buf["x64"]),
+                    n_samples, lib.ptr(buf["x_acc"]), lib.ptr(state), lib.ptr(buf["workspace"]), buf["ws_bytes"],
+                    stream,
+                )
+                lib.check(rc, "nsa_populate_pass_tail")
+                gcount.copy_(state[4:5])
+                dist.all_reduce(gcount, op=dist.ReduceOp.SUM)
+                rc = L.nsa_populate_pass_commit(lib.ptr(state), n_samples, lib.ptr(gcount), lib.ptr(buf["history"]),
+                                                stream)
+                lib.check(rc, "nsa_populate_pass_commit")
+            state_h.copy_(state)  # the train's one synchronisation
+            n_accepted, passes = int(state_h[0]), int(state_h[1])
+            if n_accepted >= n_samples:
+                break
+            if passes >= int(state_h[5]):
+                logger.warning("Reached max samples (%s)", max_samples)
+                break
+            per_pass = n_accepted / passes if n_accepted else per_pass * 0.5
+        n_proposed = passes * n * world
+        self._draw_counter += n_proposed
+        # one exchange at the end: every rank's per-pass counts and its rows, then (pass, rank, draw) order
+        hist_all = torch.empty(world * passes, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(hist_all, buf["history"][:passes].contiguous())
+        hist = hist_all.cpu().numpy().reshape(world, passes)
+        written = np.minimum(hist.sum(axis=1), n_samples)
+        pad = max(int(written.max()), 1)
+        rows_all = torch.empty((world * pad, self.dims), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(rows_all, buf["x_acc"][:pad].contiguous())
+        rows_all = rows_all.cpu().numpy().reshape(world, pad, self.dims)
+        starts = np.concatenate([np.zeros((world, 1), dtype=np.int64), np.cumsum(hist, axis=1)], axis=1)
+        pieces, have = [], 0
+        for p in range(passes):
+            for r in range(world):
+                lo, hi = int(starts[r, p]), int(min(starts[r, p + 1], written[r]))
+                if hi > lo and have < n_samples:
+                    pieces.append(rows_all[r, lo:hi])
+                    have += hi - lo
+        accepted = np.concatenate(pieces, axis=0)[:n_samples] if pieces else np.empty((0, self.dims))
+        self.x = array_to_live_points_fast(np.ascontiguousarray(accepted), self.names)
+        log_l = None
+        if self._ll_spec is not None and accepted.shape[0]:
+            dev_rows = torch.from_numpy(np.ascontiguousarray(accepted)).to(dev)
+            log_l = self._device_log_likelihood(dev_rows).cpu().numpy()
         self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
 
     def _populate_accumulate(self, st, threshold, n_samples, max_samples, injected):
