@@ -67,6 +67,8 @@ def build_proposal(rank, world, device):
     prop.flow.model.load_state_dict(state)
     prop.flow.model.eval()
     prop.set_rescaling_constants(shift, scale)
+    if os.environ.get("NESSAI_AMD_WPG"):  # tuning knob: waves per workgroup of the flow kernel
+        prop.flow.model.waves_per_group = int(os.environ["NESSAI_AMD_WPG"])
     return prop
 
 

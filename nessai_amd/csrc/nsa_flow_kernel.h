@@ -325,85 +325,54 @@ __device__ __forceinline__ void nsa_run_phases(typename TP::State (&st)[TP::FPC]
   (nsa_run_phase<TP, INV, LO + I, NV>(st, v, cols, xrow, dummy_col, tc, logdet, n_bad), ...);
 }
 
-template <class F, int... G>
-__device__ __forceinline__ void nsa_static_for(F&& body, std::integer_sequence<int, G...>) {
-  (body(std::integral_constant<int, G>{}), ...);
-}
-
-// MFMAs of one chunk of the last conditioner layer (-> acc, cols), optionally
-// interleaved with the element-wise phases of the PREVIOUS chunk (v, vcols):
-// the MFMAs are issued in 4*HT groups of 4*TP::C, each followed by its share
-// of the phases and a scheduling fence, so that on a SIMD shared by two waves
-// one wave's VALU phase runs under the other wave's MFMA group.  The A
-// operands (LDS) of group g+1 are fetched before the MFMAs of group g.
-template <int HT, class TP, bool INV, bool WITH_PHASES, int PREC>
+// MFMAs of one chunk of the last conditioner layer (-> acc, cols).  The A operands (LDS) of
+// k-step group g+1 are fetched before the MFMAs of group g.
+template <int HT, class TP, int PREC>
 __device__ __forceinline__ void nsa_chunk_gemm(const float* stg, const float (&h)[16 * HT],
                                                const NsaSplit<HT>& hs, int lane, int half,
-                                               f32x16 (&acc)[TP::C], int (&cols)[TP::FPC],
-                                               const float (&v)[16 * TP::C],
-                                               const int (&vcols)[TP::FPC], float* xrow,
-                                               int dummy_col, const NsaTransformConsts& tc,
-                                               float& logdet, int& n_bad) {
+                                               f32x16 (&acc)[TP::C], int (&cols)[TP::FPC]) {
   constexpr int TABW = (2 * TP::FPC + 3) & ~3;
   constexpr int G = (PREC == NSA_PREC_BF16X3) ? 2 * HT : 4 * HT;  // k-step groups
-  constexpr int TOT = TP::NPH * TP::FPC;
   const int* tr_tab = (const int*)stg;
   const float* bias = stg + TABW;
   const float* w = bias + 32 * TP::C;
 #pragma unroll
   for (int q = 0; q < TP::FPC; ++q) cols[q] = tr_tab[half * TP::FPC + q];
   nsa_load_bias<TP::C>(bias, half, acc);
-  typename TP::State st[TP::FPC];
   if constexpr (PREC == NSA_PREC_BF16X3) {
-    nsa_static_for(
-        [&](auto gc) {
-          constexpr int g = decltype(gc)::value;
 #pragma unroll
-          for (int ot = 0; ot < TP::C; ++ot) {
-            const bf16x8 ah = *(const bf16x8*)(w + (((ot * G + g) * 2 + 0) * 64 + lane) * 4);
-            const bf16x8 al = *(const bf16x8*)(w + (((ot * G + g) * 2 + 1) * 64 + lane) * 4);
-            acc[ot] = nsa_mfma_x3(ah, al, hs.hi[g], hs.lo[g], acc[ot]);
-          }
-          if constexpr (WITH_PHASES) {
-            constexpr int LO = g * TOT / G, HI = (g + 1) * TOT / G;
-            nsa_run_phases<TP, INV, LO>(st, v, vcols, xrow, dummy_col, tc, logdet, n_bad,
-                                        std::make_integer_sequence<int, HI - LO>{});
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        },
-        std::make_integer_sequence<int, G>{});
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int ot = 0; ot < TP::C; ++ot) {
+        const bf16x8 ah = *(const bf16x8*)(w + (((ot * G + g) * 2 + 0) * 64 + lane) * 4);
+        const bf16x8 al = *(const bf16x8*)(w + (((ot * G + g) * 2 + 1) * 64 + lane) * 4);
+        acc[ot] = nsa_mfma_x3(ah, al, hs.hi[g], hs.lo[g], acc[ot]);
+      }
+    }
   } else {
     f32x4 a_cur[TP::C];
 #pragma unroll
     for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = *(const f32x4*)(w + ((ot * G + 0) * 64 + lane) * 4);
-    nsa_static_for(
-        [&](auto gc) {
-          constexpr int g = decltype(gc)::value;
-          f32x4 a_nxt[TP::C];
-          if constexpr (g + 1 < G) {
 #pragma unroll
-            for (int ot = 0; ot < TP::C; ++ot)
-              a_nxt[ot] = *(const f32x4*)(w + ((ot * G + g + 1) * 64 + lane) * 4);
-          }
+    for (int g = 0; g < G; ++g) {
+      f32x4 a_nxt[TP::C];
+      if (g + 1 < G) {
 #pragma unroll
-          for (int ot = 0; ot < TP::C; ++ot) {
-            acc[ot] = nsa_mfma(a_cur[ot][0], h[4 * g + 0], acc[ot]);
-            acc[ot] = nsa_mfma(a_cur[ot][1], h[4 * g + 1], acc[ot]);
-            acc[ot] = nsa_mfma(a_cur[ot][2], h[4 * g + 2], acc[ot]);
-            acc[ot] = nsa_mfma(a_cur[ot][3], h[4 * g + 3], acc[ot]);
-          }
-          if constexpr (WITH_PHASES) {
-            constexpr int LO = g * TOT / G, HI = (g + 1) * TOT / G;
-            nsa_run_phases<TP, INV, LO>(st, v, vcols, xrow, dummy_col, tc, logdet, n_bad,
-                                        std::make_integer_sequence<int, HI - LO>{});
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if constexpr (g + 1 < G) {
+        for (int ot = 0; ot < TP::C; ++ot)
+          a_nxt[ot] = *(const f32x4*)(w + ((ot * G + g + 1) * 64 + lane) * 4);
+      }
 #pragma unroll
-            for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = a_nxt[ot];
-          }
-        },
-        std::make_integer_sequence<int, G>{});
+      for (int ot = 0; ot < TP::C; ++ot) {
+        acc[ot] = nsa_mfma(a_cur[ot][0], h[4 * g + 0], acc[ot]);
+        acc[ot] = nsa_mfma(a_cur[ot][1], h[4 * g + 1], acc[ot]);
+        acc[ot] = nsa_mfma(a_cur[ot][2], h[4 * g + 2], acc[ot]);
+        acc[ot] = nsa_mfma(a_cur[ot][3], h[4 * g + 3], acc[ot]);
+      }
+      if (g + 1 < G) {
+#pragma unroll
+        for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = a_nxt[ot];
+      }
+    }
   }
 }
 
@@ -482,35 +451,19 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     }
   }
 
-  // Last layer in chunks of TP::C tiles: every lane gets TP::FPC complete
-  // parameter sets per chunk and transforms those features in place.  The loop
-  // is software-pipelined: the MFMAs of chunk c+1 are interleaved with the
-  // element-wise phases of chunk c (registers + the lane's own x-tile cells).
+  // Last layer in chunks of TP::C tiles: every lane gets TP::FPC complete parameter sets per
+  // chunk and transforms those features in place (registers + the lane's own x-tile cells) before
+  // the stage barrier, so that the next stage's copy has the whole element-wise part to land.
+  // (A software-pipelined version - the MFMAs of chunk c+1 interleaved with the element-wise
+  // phases of chunk c - needed 48 more registers and was 0.7 % slower in split-bf16, 1.7 % in f32.)
   NsaSplit<HT> hs;
   if constexpr (BF) nsa_split_regs<HT>(h, hs);
-  f32x16 acc[TP::C];
-  int cols[TP::FPC];
-  float v[16 * TP::C];
-  int vcols[TP::FPC];
-  {
+  for (int c = 0; c < n_chunks; ++c) {
+    f32x16 acc[TP::C];
+    int cols[TP::FPC];
     const float* st = pipe.begin();
-    nsa_chunk_gemm<HT, TP, INV, false, PREC>(st, h, hs, lane, half, acc, cols, v, vcols, xrow, dummy_col,
-                                             tc, logdet, n_bad);
-    pipe.end();
-  }
-  for (int c = 0; c + 1 < n_chunks; ++c) {
-#pragma unroll
-    for (int t = 0; t < TP::C; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[16 * t + r] = acc[t][r];
-#pragma unroll
-    for (int q = 0; q < TP::FPC; ++q) vcols[q] = cols[q];
-    const float* st = pipe.begin();
-    nsa_chunk_gemm<HT, TP, INV, true, PREC>(st, h, hs, lane, half, acc, cols, v, vcols, xrow, dummy_col,
-                                            tc, logdet, n_bad);
-    pipe.end();
-  }
-  {
+    nsa_chunk_gemm<HT, TP, PREC>(st, h, hs, lane, half, acc, cols);
+    float v[16 * TP::C];
 #pragma unroll
     for (int t = 0; t < TP::C; ++t)
 #pragma unroll
@@ -518,6 +471,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     typename TP::State sts[TP::FPC];
     nsa_run_phases<TP, INV, 0>(sts, v, cols, xrow, dummy_col, tc, logdet, n_bad,
                                std::make_integer_sequence<int, TP::NPH * TP::FPC>{});
+    pipe.end();
   }
 }
 
