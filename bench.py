@@ -247,9 +247,9 @@ def main():
                 "peak": PEAK_TFLOPS[precision],
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_TFLOPS[precision],
-                # HBM bytes per launch from the PMC passes of profiles/r01_bench_c3_v5.txt:
-                # WRITE_SIZE 257 997.5 KB + 2 x FETCH_SIZE 4 499.5 KB (gfx950 halves coalesced reads)
-                "traffic": 273.4e6,
+                # HBM bytes per launch from the PMC passes of profiles/r01_bench_c3_v7.txt (v5: same):
+                # WRITE_SIZE 258 127 KB + 2 x FETCH_SIZE 4 474 KB (gfx950 halves coalesced reads)
+                "traffic": 273.5e6,
                 "kernel_ms_avg": kernel_ms,
                 "kernel_ms_min": kernel_ms_min,
                 "rows_per_launch": DRAWSIZE,
