@@ -16,7 +16,11 @@ timed window is the reference's ``population_time`` window
 
 ``python bench.py --gpus N --steps K --warmup W`` (N > 1 under torchrun: one
 rank per GPU, every draw batch is sharded over the ranks - 1e6 rows per rank -
-with one all-reduce(max) + one all-gather per pass).
+with one all-reduce(max) + one all-reduce(sum) per pass and one all-gather per step).
+
+Environment knobs (tuning / diagnostics only): ``NESSAI_AMD_FORCE_SHARD=1`` runs the sharded
+code path over RCCL on a single rank; ``NESSAI_AMD_WPG=<n>`` sets the waves per workgroup of
+the flow kernel; ``NESSAI_AMD_LIBRARY=<path>`` loads another build of the library.
 """
 import argparse
 import json
