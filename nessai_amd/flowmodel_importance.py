@@ -28,8 +28,14 @@ class ImportanceFlowModel(FlowModel):
     models = None
     _resume_n_models = None
 
-    def __init__(self, flow_config=None, training_config=None, output=None, rng=None):
+    def __init__(self, flow_config=None, training_config=None, output=None, rng=None, precision="auto"):
+        """``precision``: arithmetic of the flows' conditioner GEMMs; ``"auto"`` applies the policy of
+        the populate kernel (``nessai_amd.flows.base.populate_precision``: split-bf16 inside its
+        validated envelope, e.g. the 64-D / 128-hidden flows of config 4; exact float32 otherwise)."""
         super().__init__(flow_config=flow_config, training_config=training_config, output=output, rng=rng)
+        if precision not in ("auto", "f32", "bf16x3"):
+            raise ValueError("precision must be 'auto', 'f32' or 'bf16x3'")
+        self.precision = precision
         self.weights_files = []
         self.models = torch.nn.ModuleList()
 
@@ -66,9 +72,15 @@ class ImportanceFlowModel(FlowModel):
             new_flow = copy.deepcopy(self.model)
             new_flow._image_key = None
         new_flow.to(self.device)
+        self._set_precision(new_flow)
         self.models.eval()
         self.models.append(new_flow)
         self._trainer = None  # the optimiser follows the current model (reset_optimiser)
+
+    def _set_precision(self, flow):
+        from .flows.base import populate_precision
+
+        flow.precision = populate_precision(flow) if self.precision == "auto" else self.precision
 
     def _tensor(self, x):
         return torch.from_numpy(np.ascontiguousarray(x)).type(torch.float32).to(self.device)
@@ -105,6 +117,7 @@ class ImportanceFlowModel(FlowModel):
             new_flow = configure_model(self.flow_config)
             new_flow.load_state_dict(torch.load(wf, map_location="cpu", weights_only=True))
             new_flow.to(self.device)
+            self._set_precision(new_flow)
             self.models.append(new_flow)
         self.models.eval()
 
