@@ -30,6 +30,15 @@ against the real dependency here.  What *is* pinned:
   ``tests/test_oracle_properties.py``;
 * analytic known-answer tests derived from the spline definition (knots map
   to knots, identity tails with zero log-det, zero-parameter spline);
+* the rational-quadratic spline itself, **bit for bit**, against an independent
+  third-party port of the nflows spline functions that IS installed here:
+  HuggingFace ``transformers`` 5.15.0, ``models/vits/modeling_vits.py``
+  ``_unconstrained_rational_quadratic_spline`` (forward and inverse, K = 4, 8, 10, 16,
+  inputs inside / on / beyond the tail bound): ``tests/golden/make_spline_goldens.py``
+  -> ``tests/golden/spline_hf_goldens.npz`` ->
+  ``tests/test_oracle_properties.py::test_spline_matches_the_independent_huggingface_port_of_nflows``.
+  This is not the reference's pinned dependency (there is none), so the header keeps the
+  words "parity unpinned"; it does remove the risk of a mis-restated spline;
 * the *assembly* of the flows and the whole proposal glue, against the real
   reference code: ``tests/golden/make_golden.py`` imports ``nessai`` from
   ``/root/reference`` in the build container with ``glasflow`` replaced by

@@ -186,3 +186,40 @@ def test_residual_net_init_scale():
     for name, p in flow.named_parameters():
         if "linear_layers.1" in name:
             assert p.abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("K", [4, 8, 10, 16])
+def test_spline_matches_the_independent_huggingface_port_of_nflows(K):
+    """The restated rational-quadratic spline against golden vectors produced by an independent
+    third-party port of the nflows spline functions (HuggingFace transformers' VITS model,
+    ``tests/golden/make_spline_goldens.py``): forward and inverse, inputs inside, on and beyond the
+    tail bound - bit for bit."""
+    import os
+
+    from oracle.nflows_restated import splines
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spline_hf_goldens.npz"))
+    x, uw, uh, ud = (torch.from_numpy(g[f"k{K}/{n}"]) for n in ("x", "uw", "uh", "ud"))
+    for tag, inverse in (("fwd", False), ("inv", True)):
+        y, lad = splines.unconstrained_rational_quadratic_spline(
+            x, uw, uh, ud, inverse=inverse, tails="linear", tail_bound=5.0, min_bin_width=1e-3,
+            min_bin_height=1e-3, min_derivative=1e-3)
+        assert np.array_equal(y.numpy(), g[f"k{K}/{tag}/y"])
+        assert np.array_equal(lad.numpy(), g[f"k{K}/{tag}/logabsdet"])
+
+
+def test_spline_matches_huggingface_port_live():
+    """Same comparison against the live function when transformers is importable."""
+    V = pytest.importorskip("transformers.models.vits.modeling_vits")
+    from oracle.nflows_restated import splines
+
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(3000, generator=gen) * 2.5
+    uw, uh, ud = torch.randn(3000, 8, generator=gen), torch.randn(3000, 8, generator=gen), torch.randn(3000, 7, generator=gen)
+    for inverse in (False, True):
+        a, la = V._unconstrained_rational_quadratic_spline(x, uw, uh, ud, reverse=inverse, tail_bound=5.0,
+                                                           min_bin_width=1e-3, min_bin_height=1e-3,
+                                                           min_derivative=1e-3)
+        b, lb = splines.unconstrained_rational_quadratic_spline(x, uw, uh, ud, inverse=inverse, tails="linear",
+                                                                tail_bound=5.0)
+        assert torch.equal(a, b) and torch.equal(la, lb)
