@@ -252,7 +252,9 @@ NSA_API int nsa_log_likelihood(int kind, long long n, int D, const double* x64_d
  *
  *   plan        int64 host array describing the flow: header {D, hidden, residual
  *               blocks, coupling layers, transform, bins, activation, params per
- *               feature, n trainable floats, record words} then one record per
+ *               feature, n trainable floats, record words, table offset of the weight
+ *               transposition map, conditioner kind, table offset of the final column
+ *               table} then one record per
  *               coupling layer {d_id, d_tr, id table offset, tr table offset,
  *               flat-buffer offsets of W0, b0, {W1, b1, W2, b2} x blocks, Wf, bf}
  *   tables_dev  int32 physical column tables (permutations folded in)
@@ -279,6 +281,28 @@ NSA_API int nsa_train_eval(const long long* plan, const int* tables_dev, const f
                            const float* params_dev, const float* x_dev, const float* weights_dev,
                            long long n, float* workspace_dev, float* loss_acc_dev,
                            float* log_prob_out_dev, void* stream);
+
+/* Differentiable evaluation for torch autograd (the B1 surface under the reference's own
+ * training loop, src/nessai/flowmodel/base.py:400-444: `loss = -model.log_prob(x).mean();
+ * loss.backward()`).  nsa_train_forward runs NFlow.forward / log_prob (flows/base.py:209-245) in
+ * exact float32 and keeps the activations of every layer in `workspace_dev`
+ * (nsa_train_workspace_floats(plan, n) floats, owned by the caller until the matching backward
+ * call); `training` != 0 selects batch statistics for batch norm (and updates the running ones)
+ * and runs the data-dependent act-norm initialisation when the plan says it is due.
+ *   z_out_dev [n][D] (logical column order), logdet_out_dev [n], log_prob_out_dev [n]: any may be NULL
+ * nsa_train_backward (same `training` flag as the forward call) takes the upstream gradients of
+ * those outputs (any may be NULL) and writes
+ * the gradient of EVERY trainable float to grads_dev (overwritten, same layout as params_dev)
+ * and, if gx_out_dev is not NULL, the gradient with respect to the input rows [n][D]. */
+NSA_API int nsa_train_forward(const long long* plan, const int* tables_dev, const float* consts,
+                              float* params_dev, const float* x_dev, long long n, float* workspace_dev,
+                              int training, float* z_out_dev, float* logdet_out_dev,
+                              float* log_prob_out_dev, void* stream);
+NSA_API int nsa_train_backward(const long long* plan, const int* tables_dev, const float* consts,
+                               const float* params_dev, float* grads_dev, long long n,
+                               float* workspace_dev, int training, const float* g_z_dev,
+                               const float* g_logdet_dev, const float* g_log_prob_dev, float* gx_out_dev,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,10 +26,19 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t NSA_LAUNCH_NAME(
     const NsaLaunch* p, unsigned grid, unsigned grid_y, unsigned block, size_t lds, hipStream_t stream) {
   const bool inv = p->direction == NSA_DIR_INVERSE;
   auto kern = (p->precision == NSA_PREC_BF16X3)
-                  ? (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_BF16X3>
-                         : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_BF16X3>)
-                  : (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_F32>
-                         : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_F32>);
+                  ? (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_BF16X3, 2>
+                         : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_BF16X3, 2>)
+                  : (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_F32, 2>
+                         : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_F32, 2>);
+#if NSA_HT <= 2
+  // three waves per SIMD: the hidden state of a <= 64-wide conditioner fits 168 VGPRs
+  if (p->occupancy == 3)
+    kern = (p->precision == NSA_PREC_BF16X3)
+               ? (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_BF16X3, 3>
+                      : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_BF16X3, 3>)
+               : (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_F32, 3>
+                      : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_F32, 3>);
+#endif
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -71,6 +71,9 @@ struct NsaLaunch {
   // grouped launch (APPLY / LOGPROB): gridDim.y flows of identical structure on the same
   // input; flow f reads image_list[f] and writes x_out + f*n*D, ld_out + f*n
   const uint32_t* const* image_list;  // device array of n_flows image pointers, or null
+  // waves per SIMD the kernel variant is compiled for (2: <= 256 VGPRs, 3: <= 168 VGPRs); set by
+  // the host from the launch geometry (nsa_api.hip)
+  int occupancy;
 };
 
 // x' -> x maps of the populate epilogue (inverse_reparameterise of the reference):
@@ -539,8 +542,10 @@ __device__ __forceinline__ int nsa_opaque(int v) {
   return v;
 }
 
-template <int HT, class TP, bool INV, int PREC>
-__global__ void __launch_bounds__(512, 2) nsa_flow_kernel(NsaLaunch p) {
+// OCC = waves per SIMD the instance is register-budgeted for: 2 (<= 256 VGPRs, workgroups of up to
+// 8 waves) or 3 (<= 168 VGPRs, workgroups of 6 or 12 waves; only the prologue / epilogue spill).
+template <int HT, class TP, bool INV, int PREC, int OCC>
+__global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(NsaLaunch p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (p.stop != nullptr && (p.stop[0] >= p.stop[2] || p.stop[1] >= p.stop[5])) return;
   if (p.image_list != nullptr) {

@@ -544,13 +544,16 @@ __global__ void __launch_bounds__(256) tr_bn_backward_reduce(int n, const float*
   if (threadIdx.x == 0) { T1[i] = s1[0]; T2[i] = s2[0]; }
 }
 
-// gl = d loss / d (constant log|det J|) = -1
+// gl_sum[0] = sum_i d loss / d logdet_i: the layer's constant log|det J| enters every row's
+// log_prob (-1 for the normalised losses of nsa_train_step; the sum of the upstream gradients
+// under autograd, nsa_train_backward)
 __global__ void tr_bn_backward_apply(int n, int D, float* __restrict__ X, float* __restrict__ Gx, int ldx,
                                      const int* __restrict__ cols, const float* __restrict__ xsave,
                                      const float* __restrict__ uw, const float* __restrict__ mean,
                                      const float* __restrict__ var, float eps, const float* __restrict__ T1,
                                      const float* __restrict__ T2, float* __restrict__ g_uw,
-                                     float* __restrict__ g_bias) {
+                                     float* __restrict__ g_bias, const float* __restrict__ gl_sum,
+                                     int batch_stats) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * D) return;
   const int row = t / D, i = t - row * D;
@@ -559,14 +562,16 @@ __global__ void tr_bn_backward_apply(int n, int D, float* __restrict__ X, float*
   const float ve = var[i] + eps, istd = 1.0f / sqrtf(ve);
   const float x = xsave[t], xc = x - mean[i];
   const float S1 = w * T1[i], S2 = w * T2[i];
-  const float g_var = (-0.5f * S2 + 0.5f) / ve;
-  const float g_mean = -S1 * istd;
+  const float gl = gl_sum[0];
+  // batch statistics depend on the rows (training mode); running statistics are constants
+  const float g_var = batch_stats ? (-0.5f * S2 - 0.5f * gl) / ve : 0.0f;
+  const float g_mean = batch_stats ? -S1 * istd : 0.0f;
   const float g = Gx[(long long)row * ldx + col] * w;
   Gx[(long long)row * ldx + col] = g * istd + g_var * 2.0f * xc / (float)(n - 1) + g_mean / (float)n;
   X[(long long)row * ldx + col] = x;
   if (row == 0) {
     const float sig = 1.0f / (1.0f + expf(-uw[i]));
-    g_uw[i] = (T2[i] - 1.0f / w) * sig;
+    g_uw[i] = (T2[i] + gl / w) * sig;
     g_bias[i] = T1[i];
   }
 }
@@ -575,7 +580,7 @@ __global__ void tr_bn_backward_apply(int n, int D, float* __restrict__ X, float*
 __global__ void tr_bn_eval(int n, int D, float* __restrict__ X, int ldx, const int* __restrict__ cols,
                            const float* __restrict__ uw, const float* __restrict__ bias,
                            const float* __restrict__ run_mean, const float* __restrict__ run_var, float eps,
-                           float* __restrict__ ld_const) {
+                           float* __restrict__ xsave, float* __restrict__ ld_const) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t == 0) {
     float ld = 0.0f;
@@ -587,6 +592,7 @@ __global__ void tr_bn_eval(int n, int D, float* __restrict__ X, int ldx, const i
   const int col = cols[i];
   const float w = nsa_softplus(uw[i]) + eps;
   const float x = X[(long long)row * ldx + col];
+  xsave[t] = x;
   X[(long long)row * ldx + col] = w * ((x - run_mean[i]) / sqrtf(run_var[i] + eps)) + bias[i];
 }
 
@@ -657,14 +663,15 @@ __global__ void tr_actnorm_forward(int n, int D, float* __restrict__ X, int ldx,
   X[(long long)row * ldx + col] = expf(log_scale[i]) * x + shift[i];
 }
 
-// one workgroup per feature: d log_scale = sum gy x scale - 1 (the layer's log|det J| enters every
-// row's log_prob; sum_i d loss / d logdet_i = -1), d shift = sum gy; gx = gy scale; x restored
+// one workgroup per feature: d log_scale = sum gy x scale + gl_sum (the layer's log|det J| enters
+// every row's log_prob; gl_sum = sum_i d loss / d logdet_i), d shift = sum gy; gx = gy scale; x restored
 __global__ void __launch_bounds__(256) tr_actnorm_backward(int n, float* __restrict__ X, float* __restrict__ Gx,
                                                            int ldx, const int* __restrict__ cols,
                                                            const float* __restrict__ xin, int D,
                                                            const float* __restrict__ log_scale,
                                                            float* __restrict__ g_log_scale,
-                                                           float* __restrict__ g_shift) {
+                                                           float* __restrict__ g_shift,
+                                                           const float* __restrict__ gl_sum) {
   __shared__ float sa[256], sb[256];
   const int i = blockIdx.x, col = cols[i];
   const float scale = expf(log_scale[i]);
@@ -685,7 +692,7 @@ __global__ void __launch_bounds__(256) tr_actnorm_backward(int n, float* __restr
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    g_log_scale[i] = sa[0] - 1.0f;
+    g_log_scale[i] = sa[0] + gl_sum[0];
     g_shift[i] = sb[0];
   }
 }
@@ -725,7 +732,8 @@ __global__ void tr_gather_cols(int n, int D, const float* __restrict__ src, int 
 
 __global__ void tr_lu_grads(int D, const float* __restrict__ gL, const float* __restrict__ gU,
                             const float* __restrict__ raw, float eps, float* __restrict__ g_lower,
-                            float* __restrict__ g_upper, float* __restrict__ g_raw) {
+                            float* __restrict__ g_upper, float* __restrict__ g_raw,
+                            const float* __restrict__ gl_sum) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= D * D) return;
   const int i = t / D, j = t - i * D;
@@ -733,7 +741,7 @@ __global__ void tr_lu_grads(int D, const float* __restrict__ gL, const float* __
   else if (j > i) g_upper[i * D - i * (i + 1) / 2 + (j - i - 1)] = gU[t];
   else {
     const float d = nsa_softplus(raw[i]) + eps;
-    g_raw[i] = (gU[t] - 1.0f / d) / (1.0f + expf(-raw[i]));
+    g_raw[i] = (gU[t] + gl_sum[0] / d) / (1.0f + expf(-raw[i]));
   }
 }
 
@@ -754,8 +762,10 @@ __global__ void __launch_bounds__(256) tr_loss(int n, int D, const float* __rest
                                                const float* __restrict__ weights, float inv_var, float log_z,
                                                float* __restrict__ Gx, float* __restrict__ gld_rows,
                                                float* __restrict__ loss_acc,
-                                               float* __restrict__ log_prob_out, int want_grad) {
+                                               float* __restrict__ log_prob_out, int want_grad,
+                                               float* __restrict__ gl_sum) {
   __shared__ float sm[256];
+  if (want_grad && blockIdx.x == 0 && threadIdx.x == 0) gl_sum[0] = -1.0f;  // sum_i -w_i / W
   float W = (float)n;
   if (weights != nullptr) {
     float wsum = 0.0f;
@@ -864,6 +874,8 @@ __global__ void tr_copy_rows(long long n, const float* __restrict__ src, float* 
 //   [10] offset (in the int32 device table) of the transposition map of the trainable floats
 //   [11] conditioner: 0 residual net {W0, b0, {W1, b1, W2, b2} x L, Wf, bf};
 //        1 plain MLP {W_in, b_in, {W_h, b_h} x L, W_out, b_out} (src/nessai/flows/nets.py:12-126)
+//   [12] offset (int32 device table) of the final column table: logical output i of the flow is
+//        physical column table[i] of the batch (permutations never move data)
 //   coupling  : {1, d_id, d_tr, id_cols offset, tr_cols offset (int32 device table),
 //                flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf}
 //   batch norm: {2, cols offset, off unconstrained_weight, off bias, off running_mean,
@@ -872,7 +884,7 @@ __global__ void tr_copy_rows(long long n, const float* __restrict__ src, float* 
 //                off bias, eps (float bits)}
 //   act norm  : {4, cols offset, off log_scale, off shift, 1 if the data-dependent initialisation is
 //                still due (the host clears it after the first training step)}
-#define TR_HDR 12
+#define TR_HDR 13
 enum { TR_COUPLING = 1, TR_BATCHNORM = 2, TR_LU = 3, TR_ACTNORM = 4 };
 
 static inline float tr_bits(long long v) {
@@ -883,7 +895,8 @@ static inline float tr_bits(long long v) {
 }
 
 struct TrWs {  // workspace carve (floats)
-  float *scal;      // [1] constant log|det J| of the pass, [64..127] phase timestamps, [128..191] sq-norm partials
+  float *scal;      // [1] constant log|det J| of the pass, [2] sum_i d loss / d logdet_i, [64..127] phase
+                    // timestamps, [128..191] sq-norm partials
   float *x, *gx, *logdet, *gld, *gp, *gh, *gu;
   float* wt;        // transposed copy of the weight matrices (fused kernels)
   float* layer_base;
@@ -1069,7 +1082,7 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
                            momentum, 1, w.scal + 1);
       } else {
         hipLaunchKernelGGL(tr_bn_eval, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, D, cols,
-                           params + r[2], params + r[3], params + r[4], params + r[5], eps, w.scal + 1);
+                           params + r[2], params + r[3], params + r[4], params + r[5], eps, q.xin, w.scal + 1);
       }
     } else if (r[0] == TR_ACTNORM) {
       const int* cols = tabs + r[1];
@@ -1078,7 +1091,7 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
         hipLaunchKernelGGL(tr_actnorm_init, dim3(D), dim3(256), 0, s, (int)n, w.x, D, cols, params + r[2],
                            params + r[3]);
       hipLaunchKernelGGL(tr_actnorm_forward, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, D, cols,
-                         params + r[2], params + r[3], training ? q.xin : (float*)nullptr, w.scal + 1);
+                         params + r[2], params + r[3], q.xin, w.scal + 1);
     } else {  // TR_LU: y = (x U^T) L^T + b, outputs in logical order
       const int* cols = tabs + r[1];
       const float eps = tr_bits(r[6]);
@@ -1096,8 +1109,9 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
   }
 }
 
+// training != 0: the forward pass used batch statistics (batch norm)
 static void tr_backward(const long long* plan, const int* tabs, const float* params, float* grads,
-                        const float* consts, long long n, TrWs& w, hipStream_t s) {
+                        const float* consts, long long n, TrWs& w, int training, hipStream_t s) {
   const int D = (int)plan[0], H = (int)plan[1], L = (int)plan[2], NL = (int)plan[3];
   const int transform = (int)plan[4], K = (int)plan[5], act = (int)plan[6], npf = (int)plan[7];
   const long long rec = plan[9];
@@ -1188,16 +1202,19 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       const int* cols = tabs + r[1];
       const float eps = tr_bits(r[6]);
       TrLin q = tr_lin(lay, n, D);
-      float *mean = q.vec, *var = q.vec + D, *T1 = q.vec + 2 * D, *T2 = q.vec + 3 * D;
+      float *T1 = q.vec + 2 * D, *T2 = q.vec + 3 * D;
+      const float* mean = training ? q.vec : params + r[4];  // batch / running statistics
+      const float* var = training ? q.vec + D : params + r[5];
       hipLaunchKernelGGL(tr_bn_backward_reduce, dim3(D), dim3(256), 0, s, (int)n, w.gx, D, cols, q.xin, D, mean,
                          var, eps, T1, T2);
       hipLaunchKernelGGL(tr_bn_backward_apply, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, w.gx, D, cols,
-                         q.xin, params + r[2], mean, var, eps, T1, T2, grads + r[2], grads + r[3]);
+                         q.xin, params + r[2], mean, var, eps, T1, T2, grads + r[2], grads + r[3], w.scal + 2,
+                         training ? 1 : 0);
     } else if (r[0] == TR_ACTNORM) {
       const int* cols = tabs + r[1];
       TrLin q = tr_lin(lay, n, D);
       hipLaunchKernelGGL(tr_actnorm_backward, dim3(D), dim3(256), 0, s, (int)n, w.x, w.gx, D, cols, q.xin, D,
-                         params + r[2], grads + r[2], grads + r[3]);
+                         params + r[2], grads + r[2], grads + r[3], w.scal + 2);
     } else {  // TR_LU
       const int* cols = tabs + r[1];
       const float eps = tr_bits(r[6]);
@@ -1212,7 +1229,7 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       hipLaunchKernelGGL(tr_gemm_nn, tiles(n, D), dim3(64), 0, s, (int)n, D, D, q.gt, D, q.Um,
                          (const float*)nullptr, 0, ACT_NONE, w.gx, D, cols, 3);
       hipLaunchKernelGGL(tr_lu_grads, blocks_for(D * D), dim3(256), 0, s, D, q.gL, q.gU, params + r[4], eps,
-                         grads + r[2], grads + r[3], grads + r[4]);
+                         grads + r[2], grads + r[3], grads + r[4], w.scal + 2);
       hipLaunchKernelGGL(tr_gather_cols, blocks_for(n * D), dim3(256), 0, s, (int)n, D, q.xin, D, cols, w.x, 1);
     }
   }
@@ -1241,8 +1258,8 @@ extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_d
   }
   tr_forward(plan, tables_dev, params_dev, consts, n, w, 1, s);
   hipLaunchKernelGGL(tr_loss, dim3((unsigned)((n + TR_LOSS_ROWS - 1) / TR_LOSS_ROWS)), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
-                     weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, (float*)nullptr, 1);
-  tr_backward(plan, tables_dev, params_dev, grads_dev, consts, n, w, s);
+                     weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, (float*)nullptr, 1, w.scal + 2);
+  tr_backward(plan, tables_dev, params_dev, grads_dev, consts, n, w, 1, s);
   hipLaunchKernelGGL(tr_grad_sqnorm, dim3(TR_SQ_BLOCKS), dim3(256), 0, s, n_params, grads_dev, w.scal + 128);
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
@@ -1269,7 +1286,107 @@ extern "C" NSA_API int nsa_train_eval(const long long* plan, const int* tables_d
                        tables_dev + plan[10], w.wt);
   tr_forward(plan, tables_dev, const_cast<float*>(params_dev), consts, n, w, 0, s);
   hipLaunchKernelGGL(tr_loss, dim3((unsigned)((n + TR_LOSS_ROWS - 1) / TR_LOSS_ROWS)), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
-                     weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, log_prob_out_dev, 0);
+                     weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, log_prob_out_dev, 0, w.scal + 2);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? NSA_OK : NSA_E_HIP;
+}
+
+// ---------------------------------------------------------------------------
+// differentiable evaluation for torch autograd (nessai_amd/ops.py): the forward pass keeps its
+// activations in the caller's workspace, the backward pass takes arbitrary upstream gradients
+// ---------------------------------------------------------------------------
+
+// z (logical column order), logdet and log_prob of the rows after tr_forward
+__global__ void tr_outputs(int n, int D, const float* __restrict__ X, const int* __restrict__ out_cols,
+                           const float* __restrict__ logdet, const float* __restrict__ ld_const, float inv_var,
+                           float log_z, float* __restrict__ z_out, float* __restrict__ logdet_out,
+                           float* __restrict__ log_prob_out) {
+  const int row = blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2), part = threadIdx.x & 3;
+  if (row >= n) return;
+  float e = 0.0f;
+  for (int i = part; i < D; i += 4) {
+    const float z = X[(long long)row * D + out_cols[i]];
+    e += z * z;
+    if (z_out) z_out[(long long)row * D + i] = z;
+  }
+  e += __shfl_xor(e, 1);
+  e += __shfl_xor(e, 2);
+  if (part == 0) {
+    const float ld = logdet[row] + ld_const[0];
+    if (logdet_out) logdet_out[row] = ld;
+    if (log_prob_out) log_prob_out[row] = -0.5f * inv_var * e - log_z + ld;
+  }
+}
+
+// seeds of the backward pass from the upstream gradients (any of them may be null):
+//   Gx[row][out_cols[i]] = g_z[row][i] - g_lp[row] * z / var;   gld[row] = g_ld[row] + g_lp[row]
+__global__ void tr_seed(int n, int D, const float* __restrict__ X, const int* __restrict__ out_cols,
+                        const float* __restrict__ g_z, const float* __restrict__ g_ld,
+                        const float* __restrict__ g_lp, float inv_var, float* __restrict__ Gx,
+                        float* __restrict__ gld) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * D) return;
+  const int row = t / D, i = t - row * D;
+  const int col = out_cols[i];
+  float g = g_z ? g_z[t] : 0.0f;
+  if (g_lp) g -= g_lp[row] * X[(long long)row * D + col] * inv_var;
+  Gx[(long long)row * D + col] = g;
+  if (i == 0) gld[row] = (g_ld ? g_ld[row] : 0.0f) + (g_lp ? g_lp[row] : 0.0f);
+}
+
+// gl_sum[0] = sum_i gld[i], one workgroup, fixed order (deterministic)
+__global__ void __launch_bounds__(256) tr_seed_sum(int n, const float* __restrict__ gld, float* __restrict__ gl_sum) {
+  __shared__ float sm[256];
+  float a = 0.0f;
+  for (int row = threadIdx.x; row < n; row += 256) a += gld[row];
+  sm[threadIdx.x] = a;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gl_sum[0] = sm[0];
+}
+
+extern "C" NSA_API int nsa_train_forward(const long long* plan, const int* tables_dev, const float* consts,
+                                         float* params_dev, const float* x_dev, long long n,
+                                         float* workspace_dev, int training, float* z_out_dev,
+                                         float* logdet_out_dev, float* log_prob_out_dev, void* stream) {
+  if (!plan || !tables_dev || !consts || !params_dev || !x_dev || !workspace_dev || n <= 0) return NSA_E_ARG;
+  if (training && n <= 1) return NSA_E_ARG;  // batch statistics need two rows
+  hipStream_t s = (hipStream_t)stream;
+  const long long D = plan[0];
+  TrWs w;
+  tr_carve(plan, n, workspace_dev, w);
+  hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, x_dev, w.x);
+  if (tr_use_fused(plan))
+    hipLaunchKernelGGL(tr_transpose_weights, blocks_for(plan[8]), dim3(256), 0, s, plan[8], params_dev,
+                       tables_dev + plan[10], w.wt);
+  tr_forward(plan, tables_dev, params_dev, consts, n, w, training ? 1 : 0, s);
+  hipLaunchKernelGGL(tr_outputs, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (int)n, (int)D, w.x,
+                     tables_dev + plan[12], w.logdet, w.scal + 1, consts[6], consts[7], z_out_dev,
+                     logdet_out_dev, log_prob_out_dev);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? NSA_OK : NSA_E_HIP;
+}
+
+extern "C" NSA_API int nsa_train_backward(const long long* plan, const int* tables_dev, const float* consts,
+                                          const float* params_dev, float* grads_dev, long long n,
+                                          float* workspace_dev, int training, const float* g_z_dev,
+                                          const float* g_logdet_dev, const float* g_log_prob_dev,
+                                          float* gx_out_dev, void* stream) {
+  if (!plan || !tables_dev || !consts || !params_dev || !grads_dev || !workspace_dev || n <= 0) return NSA_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long long D = plan[0], n_params = plan[8];
+  TrWs w;
+  tr_carve(plan, n, workspace_dev, w);
+  (void)hipMemsetAsync(grads_dev, 0, n_params * sizeof(float), s);
+  hipLaunchKernelGGL(tr_seed, blocks_for(n * D), dim3(256), 0, s, (int)n, (int)D, w.x, tables_dev + plan[12],
+                     g_z_dev, g_logdet_dev, g_log_prob_dev, consts[6], w.gx, w.gld);
+  hipLaunchKernelGGL(tr_seed_sum, dim3(1), dim3(256), 0, s, (int)n, w.gld, w.scal + 2);
+  tr_backward(plan, tables_dev, params_dev, grads_dev, consts, n, w, training ? 1 : 0, s);
+  if (gx_out_dev != nullptr)
+    hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, w.gx, gx_out_dev);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? NSA_OK : NSA_E_HIP;
 }

@@ -136,24 +136,28 @@ class FlowModel:
     def forward_and_log_prob(self, x):
         """x' -> (z, log_prob) (``base.py:782-811``)."""
         self.model.eval()
-        z, log_prob = self.model.forward_and_log_prob(self.numpy_array_to_tensor(x))
+        with torch.inference_mode():
+            z, log_prob = self.model.forward_and_log_prob(self.numpy_array_to_tensor(x))
         return self._to_numpy(z), self._to_numpy(log_prob)
 
     def inverse(self, z):
         """z -> (x', log|det J|) (``base.py:813-840``)."""
         self.model.eval()
-        x, log_j = self.model.inverse(self.numpy_array_to_tensor(z))
+        with torch.inference_mode():
+            x, log_j = self.model.inverse(self.numpy_array_to_tensor(z))
         return self._to_numpy(x), self._to_numpy(log_j)
 
     def log_prob(self, x):
         """(``base.py:842-864``)."""
         self.model.eval()
-        return self._to_numpy(self.model.log_prob(self.numpy_array_to_tensor(x)))
+        with torch.inference_mode():
+            return self._to_numpy(self.model.log_prob(self.numpy_array_to_tensor(x)))
 
     def sample(self, n=1):
         """(``base.py:866-887``)."""
         self.model.eval()
-        return self._to_numpy(self.model.sample(int(n)))
+        with torch.inference_mode():
+            return self._to_numpy(self.model.sample(int(n)))
 
     def sample_latent_distribution(self, n=1):
         """(``base.py:889-904``)."""
@@ -164,14 +168,15 @@ class FlowModel:
         if self.model is None:
             raise RuntimeError("Model is not initialised yet!")
         self.model.eval()
-        if z is None:
-            x, log_prob = self.model.sample_and_log_prob(int(N))
-        else:
-            if isinstance(z, np.ndarray):
-                z = self.numpy_array_to_tensor(z)
-            log_prob = self.model.base_distribution_log_prob(z)
-            x, log_J = self.model.inverse(z)
-            log_prob = log_prob - log_J
+        with torch.inference_mode():
+            if z is None:
+                x, log_prob = self.model.sample_and_log_prob(int(N))
+            else:
+                if isinstance(z, np.ndarray):
+                    z = self.numpy_array_to_tensor(z)
+                log_prob = self.model.base_distribution_log_prob(z)
+                x, log_J = self.model.inverse(z)
+                log_prob = log_prob - log_J
         return self._to_numpy(x), self._to_numpy(log_prob)
 
     # -- training --------------------------------------------------------------

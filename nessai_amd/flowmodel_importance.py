@@ -88,7 +88,8 @@ class ImportanceFlowModel(FlowModel):
     def log_prob_ith(self, x, i):
         """log-density of the i-th flow (``importance.py:100-112``)."""
         self.models[i].eval()
-        return self._to_numpy(self.models[i].log_prob(self._tensor(x)))
+        with torch.inference_mode():
+            return self._to_numpy(self.models[i].log_prob(self._tensor(x)))
 
     def log_prob_all(self, x):
         """``(N, n_flows)`` log-densities, every flow on the same batch (``importance.py:114-129``)."""
@@ -102,7 +103,8 @@ class ImportanceFlowModel(FlowModel):
         if self.models is None:
             raise RuntimeError("Models are not initialised yet!")
         self.models[i].eval()
-        return self._to_numpy(self.models[i].sample(int(N)))
+        with torch.inference_mode():
+            return self._to_numpy(self.models[i].sample(int(N)))
 
     def save_weights(self, weights_file):
         super().save_weights(weights_file)

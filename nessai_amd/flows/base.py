@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from torch.nn import Module
 
-from .. import lib, pack
+from .. import lib, ops, pack
 from . import modules as M
 
 
@@ -107,6 +107,16 @@ class HipFlow(BaseFlow):
     Inputs must be contiguous float32 tensors on a ROCm device; outputs are
     allocated on the same device.  There is no CPU path: calling a method with
     CPU tensors raises ``RuntimeError``.
+
+    Two kernel families sit behind the methods (``nessai_amd.ops``):
+
+    * inference (no gradient wanted, eval mode): the fused flow kernel ``nessai_amd::flow_run``
+      in the flow's ``precision``;
+    * ``forward`` / ``log_prob`` / ``forward_and_log_prob`` when autograd is recording and the
+      input or a parameter requires a gradient, or in training mode with batch norm / act norm
+      (batch statistics): ``nessai_amd::flow_forward`` + ``flow_backward`` in exact float32, so
+      the reference's own training loop (``flowmodel/base.py:400-444``) can drive the class.
+      ``inverse`` / ``sample`` are not differentiable (the reference never trains through them).
     """
 
     def __init__(self, transform, distribution):
@@ -124,7 +134,9 @@ class HipFlow(BaseFlow):
         self._image_host = None
         self._image_dev = None
         self._header = None
+        self._header_t = None
         self._status = None
+        self.__dict__["_trainer"] = None
         self.waves_per_group = 0
         self.max_groups = 0
         self.precision = DEFAULT_PRECISION
@@ -176,8 +188,10 @@ class HipFlow(BaseFlow):
             image = pack.pack_flow(dict(M.describe(self), precision=self.precision))
             self._image_host = image
             self._header = (lib.ctypes.c_uint32 * pack.HEADER_WORDS)(*image[: pack.HEADER_WORDS].tolist())
-            self._image_dev = torch.from_numpy(image.view(np.int32)).to(device)
-            self._status = torch.zeros(4, dtype=torch.int32, device=device)
+            with torch.inference_mode(False):  # cached across calls: must not be inference tensors
+                self._header_t = ops.header_tensor(self._header)
+                self._image_dev = torch.from_numpy(image.view(np.int32)).to(device)
+                self._status = torch.zeros(4, dtype=torch.int32, device=device)
             self._image_key = key
         return self._header, self._image_dev
 
@@ -197,30 +211,58 @@ class HipFlow(BaseFlow):
             )
         return x.detach().to(torch.float32).contiguous()
 
+    def trainer(self):
+        """The flow's ``nessai_amd.train.Trainer`` (flat parameter buffer + layer plan), built on
+        first use and rebuilt when the tensors were re-allocated or the permutations re-drawn."""
+        from ..train import Trainer
+
+        tr = self.__dict__.get("_trainer")
+        if tr is None or not tr.is_current():
+            with torch.inference_mode(False), torch.no_grad():
+                tr = Trainer(self)
+            tr.handle = ops.register_plan(tr)
+            self.__dict__["_trainer"] = tr
+            self._image_key = None
+        return tr
+
+    def _wants_grad(self, x):
+        if not torch.is_grad_enabled():
+            return False
+        return x.requires_grad or any(p.requires_grad for p in self.parameters())
+
     def _run(self, x, direction, mode, want_x=True):
-        if self.training and _has_batch_norm(self) :
+        if direction == DIR_FORWARD and (self._wants_grad(x) or (self.training and _has_norm_layers(self))):
+            return self._run_differentiable(x, mode, want_x)
+        if self.training and _has_norm_layers(self):
             raise RuntimeError(
-                "Batch-norm transforms are evaluated with running statistics; "
-                "call .eval() before using the flow for inference"
+                "The inverse of batch-norm / act-norm transforms uses running statistics; "
+                "call .eval() before inverting or sampling the flow"
             )
         x = self._check_input(x)
         header, image = self.device_image()
-        n = x.shape[0]
-        if n == 0:
-            empty = torch.empty(0, dtype=torch.float32, device=x.device)
-            self._status.zero_()
-            return (torch.empty_like(x) if want_x else None), empty, self._status
-        out = torch.empty_like(x) if want_x else None
-        ld = torch.empty(n, dtype=torch.float32, device=x.device)
-        status = self._status
-        status.zero_()
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        rc = lib.load().nsa_flow_run(
-            header, lib.ptr(image), direction, mode, n, lib.ptr(x), lib.ptr(out), lib.ptr(ld),
-            lib.ptr(status), self.waves_per_group, self.max_groups, lib.c_void_p(stream),
+        out, ld = torch.ops.nessai_amd.flow_run(
+            x, image, self._header_t, direction, mode, want_x, self._status, self.waves_per_group,
+            self.max_groups,
         )
-        lib.check(rc, "nsa_flow_run")
-        return out, ld, status
+        return (out if want_x else None), ld, self._status
+
+    def _run_differentiable(self, x, mode, want_x):
+        """Forward direction through the float32 training kernels, recorded by autograd."""
+        if not isinstance(x, torch.Tensor) or x.device.type != "cuda":
+            raise RuntimeError("nessai_amd flows take tensors on a ROCm device; there is no CPU fallback")
+        if x.dim() != 2 or x.shape[1] != self.features:
+            raise ValueError("Expected inputs of shape (N, {}), got {}".format(self.features, tuple(x.shape)))
+        if x.shape[0] == 0:
+            raise ValueError("cannot differentiate through an empty batch")
+        xin = x.to(torch.float32).contiguous()
+        log_prob = mode == MODE_LOGPROB
+        z, ld, lp = ops.differentiable_flow(self, xin, want_x, not log_prob, log_prob)
+        if self._status is None:
+            with torch.inference_mode(False):
+                self._status = torch.zeros(4, dtype=torch.int32, device=x.device)
+        else:
+            self._status.zero_()
+        return z, (lp if log_prob else ld), self._status
 
     def forward(self, x, context=None):
         """x -> (z, log|det J|)  (``NFlow.forward``, flows/base.py:209-214)."""
@@ -303,6 +345,15 @@ def _has_batch_norm(flow):
     return any(isinstance(m, M.BatchNorm) for m in flow.modules())
 
 
+def _has_norm_layers(flow):
+    """Batch norm or a not-yet-initialised act norm: layers whose training-mode pass differs."""
+    cached = flow.__dict__.get("_norm_layers")
+    if cached is None:
+        cached = [m for m in flow.modules() if isinstance(m, (M.BatchNorm, M.ActNorm))]
+        flow.__dict__["_norm_layers"] = cached
+    return any(isinstance(m, M.BatchNorm) or not bool(m.initialized) for m in cached)
+
+
 def lib_supports(ht, transform, bins):
     """Ask the library whether a kernel instance exists (no GPU needed)."""
     kind = pack.TRANSFORMS[transform]
@@ -312,8 +363,9 @@ def lib_supports(ht, transform, bins):
 _STRUCT_WORDS = (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 25, 26, 27, 29)  # nsa_format.h ints
 
 
+@torch.no_grad()
 def log_prob_many(flows, x):
-    """``(n_flows, N)`` log-densities of one batch under several flows.
+    """``(n_flows, N)`` log-densities of one batch under several flows (inference only).
 
     The loop of ``ImportanceFlowModel.log_prob_all`` (``flowmodel/importance.py:114-129``)
     as ONE grouped launch (``nsa_flow_run_many``) when the flows share their structure -

@@ -75,6 +75,16 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "nsa_train_forward": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    "nsa_train_backward": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p],
+    ),
     "nsa_populate_accept": (
         c_int,
         [c_ll, c_int, c_void_p, c_void_p, c_ull, c_ull, c_void_p, c_void_p, c_ll, c_void_p, c_void_p,

@@ -305,6 +305,7 @@ class FlowProposal:
                 g.scale[p] = float(scale[col[p]])
         self._upload_constants()
 
+    @torch.inference_mode(False)
     def _upload_constants(self):
         dev = self.device
         f64 = dict(dtype=torch.float64, device=dev)
@@ -428,6 +429,7 @@ class FlowProposal:
         lib.check(rc, "nsa_log_likelihood")
         return out
 
+    @torch.inference_mode(False)  # cached across calls: never inference tensors
     def _get_buffers(self, n, capacity):
         key = (n, capacity, self.dims)
         if self._buffers is not None and self._buffers["key"] == key:
@@ -595,6 +597,7 @@ class FlowProposal:
         log_l = accepted[:, self.dims].copy() if self._ll_spec is not None else None
         self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
 
+    @torch.inference_mode(False)
     def _populate_trains(self, st, threshold, n_samples, max_samples):
         """The populate loop with its control on the device (``nsa_populate_passes``): trains of
         passes are enqueued without host round trips; a pass whose predecessors already reached
@@ -658,6 +661,7 @@ class FlowProposal:
         self.x = array_to_live_points_fast(kept.cpu().numpy(), self.names)
         self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
 
+    @torch.inference_mode(False)
     def _populate_trains_sharded(self, st, threshold, n_samples, max_samples, n, world, rank):
         """``_populate_trains`` for a draw batch sharded over ranks: per pass
         ``head -> all-reduce(max) -> tail -> all-reduce(sum of the pass counts) -> commit``, all

@@ -28,15 +28,20 @@ from .flows import modules as M
 
 
 class Trainer:
-    """Flat parameter / gradient / Adam-moment buffers + the layer plan."""
+    """Flat parameter / gradient / Adam-moment buffers + the layer plan of ONE flow.
+
+    A flow has at most one live ``Trainer`` (``HipFlow.trainer()``): it rebinds the storage of
+    every ``Parameter`` and batch-norm statistic to views of its flat buffer, which both the
+    fused optimiser step (``nsa_train_step``) and the autograd path (``nessai_amd.ops``:
+    ``nsa_train_forward`` / ``nsa_train_backward``) work on.
+    """
 
     OPTIMISERS = {"adamw": 0, "adam": 1, "sgd": 2}  # nsa_train_step's `optimiser` argument
 
     def __init__(self, flow, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, optimiser="adamw"):
         self.flow = flow
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
-        self.base_lr = float(lr)
-        self.optimiser = self.OPTIMISERS[optimiser]
+        self.configure_optimiser(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, optimiser=optimiser,
+                                 reset=False)
         self.step_count = 0
         device = next(flow.parameters()).device
         if device.type != "cuda":
@@ -145,7 +150,8 @@ class Trainer:
                   desc.get("bins", 0) if desc["transform"] == "rq" else 0,
                   pack.ACTIVATIONS[desc["activation"]], n_tr, total, rec_words, len(tables),
                   pack.NETS[desc["net"]]]
-        tables = list(tables) + tmap.tolist()
+        header.append(len(tables) + total)  # [12] final column table: logical output i -> physical column
+        tables = list(tables) + tmap.tolist() + [int(c) for c in cur]
         plan = header + [w for rec in records for w in rec]
         self.plan = (ctypes.c_longlong * len(plan))(*plan)
         self._rec_base, self._rec_words = len(header), rec_words
@@ -163,6 +169,79 @@ class Trainer:
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)
         self._ws = None
         self._ws_rows = 0
+        self.n_params = total
+        self._params = params
+        self._stats = stats
+        self._bound = [(t, offsets[id(t)]) for t in params + stats]
+        self._perm_versions = self._permutation_versions()
+        self.has_batch_norm = any(r[0] == 2 for r in records)
+        #: (offset, numel, shape) of every Parameter, in ``flow.parameters()`` order
+        self.param_slices = [(offsets[id(p)], p.numel(), tuple(p.shape)) for p in params]
+
+    def configure_optimiser(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, optimiser="adamw",
+                            reset=True):
+        """Hyper-parameters of the fused optimiser step; ``reset`` clears the moments and the
+        step count (a fresh optimiser, as ``FlowModel.reset_model`` makes one, flowmodel/base.py:748-772)."""
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
+        self.base_lr = float(lr)
+        self.optimiser = self.OPTIMISERS[optimiser]
+        if reset:
+            self.step_count = 0
+            self.adam_m.zero_()
+            self.adam_v.zero_()
+
+    def _permutation_versions(self):
+        return tuple(b._version for name, b in self.flow.named_buffers() if name.endswith("_permutation"))
+
+    def is_current(self):
+        """False once the flow's tensors were re-allocated (``.to()`` across devices) or its
+        permutations re-drawn: the plan's tables and the flat views are then stale."""
+        if self._perm_versions != self._permutation_versions():
+            return False
+        base, item = self.flat.data_ptr(), self.flat.element_size()
+        return all(t.data_ptr() == base + off * item for t, off in self._bound)
+
+    # -- differentiable evaluation (nessai_amd.ops) ------------------------------
+
+    def forward_saved(self, x, training, want_z=True, want_logdet=True, want_log_prob=True):
+        """Forward pass that keeps every layer's activations in a fresh workspace tensor.
+
+        Returns ``(z, logdet, log_prob, workspace)``; unwanted outputs are ``None``."""
+        n = x.shape[0]
+        words = int(lib.load().nsa_train_workspace_floats(self.plan, n))
+        ws = torch.empty(words, dtype=torch.float32, device=self.device)
+        z = torch.empty((n, self.features), dtype=torch.float32, device=self.device) if want_z else None
+        ld = torch.empty(n, dtype=torch.float32, device=self.device) if want_logdet else None
+        lp = torch.empty(n, dtype=torch.float32, device=self.device) if want_log_prob else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = lib.load().nsa_train_forward(
+            self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.flat), lib.ptr(x), n, lib.ptr(ws),
+            1 if training else 0, lib.ptr(z), lib.ptr(ld), lib.ptr(lp), lib.c_void_p(stream),
+        )
+        lib.check(rc, "nsa_train_forward")
+        if training:
+            self._actnorm_initialised()
+        return z, ld, lp, ws
+
+    def backward_saved(self, ws, n, training, g_z=None, g_logdet=None, g_log_prob=None, want_gx=False):
+        """Gradients of every trainable float (a fresh flat tensor) and optionally of the input."""
+        grads = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        gx = torch.empty((n, self.features), dtype=torch.float32, device=self.device) if want_gx else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = lib.load().nsa_train_backward(
+            self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.flat), lib.ptr(grads), n, lib.ptr(ws),
+            1 if training else 0, lib.ptr(g_z), lib.ptr(g_logdet), lib.ptr(g_log_prob), lib.ptr(gx),
+            lib.c_void_p(stream),
+        )
+        lib.check(rc, "nsa_train_backward")
+        return grads, gx
+
+    def _actnorm_initialised(self):
+        for index, module in self._actnorms:  # initialised by the training-mode pass that just ran
+            flag = self._rec_base + index * self._rec_words + 4
+            if self.plan[flag]:
+                self.plan[flag] = 0
+                module.initialized.fill_(True)
 
     def _workspace(self, n):
         if self._ws is None or n > self._ws_rows:
@@ -186,11 +265,7 @@ class Trainer:
             float(clip_norm or 0.0), self.step_count, self.optimiser, lib.ptr(self.loss_acc), lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_train_step")
-        for index, module in self._actnorms:  # initialised by the step that just ran
-            flag = self._rec_base + index * self._rec_words + 4
-            if self.plan[flag]:
-                self.plan[flag] = 0
-                module.initialized.fill_(True)
+        self._actnorm_initialised()
 
     def evaluate(self, x, log_prob_out=None, weights=None):
         """``loss_acc += -mean(log_prob(x))`` without touching the weights."""
@@ -204,8 +279,11 @@ class Trainer:
 
 
 def get_trainer(flow_model):
+    """The flow's trainer with the optimiser ``FlowModel.get_optimiser`` would build; a new
+    optimiser state whenever the FlowModel dropped its handle (``reset_model``)."""
     tc = flow_model.training_config
-    if flow_model._trainer is None or flow_model._trainer.flow is not flow_model.model:
+    trainer = flow_model.model.trainer()
+    if flow_model._trainer is not trainer:
         # FlowModel.get_optimiser (src/nessai/flowmodel/base.py:105-135): adam adds weight_decay=1e-6
         name = (tc.get("optimiser") or "adamw").lower()
         kwargs = dict(tc.get("optimiser_kwargs") or {})
@@ -223,8 +301,8 @@ def get_trainer(flow_model):
             raise NotImplementedError("amsgrad has no gfx950 kernel")
         if kwargs:
             raise TypeError(f"Unknown optimiser arguments: {sorted(kwargs)}")
-        flow_model._trainer = Trainer(flow_model.model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                                      optimiser=name)
+        trainer.configure_optimiser(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, optimiser=name)
+        flow_model._trainer = trainer
     return flow_model._trainer
 
 

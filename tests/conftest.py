@@ -30,10 +30,21 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+#: GPU suites that drive the flows under autograd; every other GPU suite exercises the inference
+#: kernels and runs with autograd off, as the reference's callers do
+#: (``torch.inference_mode()`` in src/nessai/flowmodel/base.py:782-948)
+GRAD_MODULES = {"test_gpu_autograd", "test_gpu_train"}
+
+
 @pytest.fixture(autouse=True)
-def _seed():
+def _seed(request):
     import numpy as np
     import torch
 
     torch.manual_seed(170817)
     np.random.seed(170817)
+    if "gpu" in request.keywords and request.module.__name__ not in GRAD_MODULES:
+        with torch.no_grad():
+            yield
+    else:
+        yield
