@@ -53,9 +53,17 @@ __device__ __forceinline__ f32x16 nsa_mfma_x3(bf16x8 ah, bf16x8 al, bf16x8 bh, b
   return nsa_mfma16(ah, bh, c);
 }
 
+// relu on the integer ALU: negative floats are negative ints.  One instruction (fmaxf(x, 0) is two:
+// the compiler canonicalises a possibly-signalling input first); a NaN with the sign bit set
+// becomes 0, exactly as fmaxf returns the non-NaN operand.
+__device__ __forceinline__ float nsa_relu(float x) {
+  const int b = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 // activation of the conditioner (src/nessai/flows/utils.py:200-205)
 __device__ __forceinline__ float nsa_act(float x, int kind) {
-  if (kind == NSA_ACT_RELU) return fmaxf(x, 0.0f);
+  if (kind == NSA_ACT_RELU) return nsa_relu(x);
   if (kind == NSA_ACT_TANH) return tanhf(x);
   return x * (1.0f / (1.0f + expf(-x)));  // silu: x * sigmoid(x)
 }
@@ -149,11 +157,52 @@ __device__ __forceinline__ float nsa_softplus(float x) {
   return fmaxf(x, 0.0f) + nsa_log1p_unit(nsa_exp(-fabsf(x)));
 }
 
-// Element-wise transforms are written as PHASES so that the kernel can issue
-// one phase between two groups of MFMAs of the next chunk (manual MFMA/VALU
-// interleave, see nsa_coupling).  A policy provides
+// Element-wise transforms.  A policy provides
 //   C, FPC, NP, NPH (phases per feature), State, and phase<P, OFF>(...);
-// running phases 0..NPH-1 in order transforms one feature of one row.
+// running phases 0..NPH-1 in order transforms one feature of one row (all three policies have a
+// single phase now; the hook is kept so that a transform can be split again).
+
+// ln(x) for normal positive x on the bare v_log_f32 (log2, <= 1 ulp); __logf adds a denormal
+// rescue and a two-term log2 -> ln conversion (12 instructions) that the spline does not need
+__device__ __forceinline__ float nsa_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// F.softplus(x) = max(x, 0) + log1p(exp(-|x|)) with log1p(u) = ln2 * log2(1 + u): the rounding of
+// 1 + u costs <= 6e-8 absolute, i.e. <= 6e-5 relative on min_derivative + softplus = 1e-3 at the
+// far negative end and ~1e-7 where trained derivative logits live
+__device__ __forceinline__ float nsa_softplus_fast(float x) {
+  const float u = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x));
+  return fmaf(0.6931471805599453f, nsa_log2(1.0f + u), nsa_relu(x));
+}
+
+// Bin search on monotone knots by halving, carried out on THREE parallel tables (the knots that are
+// searched, the knots of the other axis, the derivative logits): a window of N bins keeps N + 1
+// entries of each; one compare against the middle knot keeps the half that holds x.
+// 3 + 30 instructions for 8 bins (7 + 42 for the linear scan).  Same index as
+// searchsorted's count of knots <= x because the knots increase strictly (min bin size > 0).
+template <int N>
+struct NsaBinSelect {
+  __device__ __forceinline__ static void run(const float (&a)[N + 1], const float (&b)[N + 1],
+                                             const float (&r)[N + 1], float x, float (&o)[6]) {
+    constexpr int S = (N + 1) / 2;  // bins kept
+    constexpr int M = N / 2;        // bin >= M  <=>  x >= a[M]; note N - S == M
+    const bool ge = x >= a[M];
+    float a2[S + 1], b2[S + 1], r2[S + 1];
+#pragma unroll
+    for (int i = 0; i <= S; ++i) {
+      a2[i] = ge ? a[M + i] : a[i];
+      b2[i] = ge ? b[M + i] : b[i];
+      r2[i] = ge ? r[M + i] : r[i];
+    }
+    NsaBinSelect<S>::run(a2, b2, r2, x, o);
+  }
+};
+template <>
+struct NsaBinSelect<1> {
+  __device__ __forceinline__ static void run(const float (&a)[2], const float (&b)[2],
+                                             const float (&r)[2], float, float (&o)[6]) {
+    o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1]; o[4] = r[0]; o[5] = r[1];
+  }
+};
 
 // Monotonic rational-quadratic spline with linear tails.  Restates the
 // arithmetic of oracle/nflows_restated/splines.py for one scalar input.
@@ -166,18 +215,14 @@ struct NsaRQ {
   static constexpr int FPC = (K == 8) ? 2 : 1;
   static constexpr int C = (FPC * NP + 15) / 16;
   static constexpr int KIND = NSA_T_RQ;
-  static constexpr int NPH = 4;
+  static constexpr int NPH = 1;
 
-  struct State {
-    float cw[K + 1], ch[K + 1];
-    float x;
-    // the bin selected by phase 2
-    float in_cw, in_cw1, in_ch, in_ch1, in_d, in_d1;
-  };
+  struct State {};
 
-  // knots of one axis: softmax -> min + scale*p -> cumulative sum mapped to [-B, B].
-  // Constant factors are folded: logits are scaled by log2(e)/sqrt(H) once so that the
-  // exponentials are bare v_exp_f32, and (right-left)*scale/sum multiplies each of them once.
+  // knots of one axis: softmax -> min + scale*p -> cumulative sum mapped to [-B, B]:
+  //   cum[i] = -B + i*(2B*min) + (2B*scale/sum) * prefix_i,   prefix_i = sum_{j<i} exp(l_j - max)
+  // The logits are scaled by log2(e)/sqrt(H) once so that the exponentials are bare v_exp_f32;
+  // the prefix sums double as the softmax denominator; the ends are exact.
   template <int OFF, int NV>
   __device__ __forceinline__ static void knots(const float (&v)[NV], float inv_div, float mn,
                                                float sc, float two_b, float B, float (&cum)[K + 1]) {
@@ -186,97 +231,74 @@ struct NsaRQ {
     float m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < K; ++i) { u[i] = v[OFF + i] * k2; m = fmaxf(m, u[i]); }
-    float s = 0.0f;
+    float pre[K + 1];
+    pre[0] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < K; ++i) { u[i] = __builtin_amdgcn_exp2f(u[i] - m); s += u[i]; }
-    const float g = (two_b * sc) * nsa_rcp(s);
+    for (int i = 0; i < K; ++i) pre[i + 1] = pre[i] + __builtin_amdgcn_exp2f(u[i] - m);
+    const float g = (two_b * sc) * nsa_rcp(pre[K]);
     const float c0 = two_b * mn;
-    float run = -B;
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-      run += fmaf(g, u[i], c0);
-      cum[i + 1] = run;
-    }
+    for (int i = 1; i < K; ++i) cum[i] = fmaf(g, pre[i], fmaf((float)i, c0, -B));
     cum[0] = -B;
     cum[K] = B;
   }
 
-  // phase 0: width knots; 1: height knots; 2: bin search + the bin's two derivatives
-  // (only the two softplus values that are used are evaluated); 3: spline evaluation
   template <int P, int OFF, bool INV, int NV>
-  __device__ __forceinline__ static void phase(State& st, const float (&v)[NV], float x_in,
+  __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
                                                const NsaTransformConsts& c, float& y, float& ld,
                                                bool& bad) {
     const float B = c.tail_bound;
-    if constexpr (P == 0) {
-      st.x = x_in;
-      knots<OFF, NV>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, st.cw);
-    } else if constexpr (P == 1) {
-      knots<OFF + K, NV>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, st.ch);
-    } else if constexpr (P == 2) {
-      const float x = st.x;
-      const bool inside = (x >= -B) && (x <= B);
-      const float xin = inside ? x : 0.0f;
-      // searchsorted (knots are increasing): keep the last knot <= x
-      float in_cw = st.cw[0], in_cw1 = st.cw[1], in_ch = st.ch[0], in_ch1 = st.ch[1];
-      float r0 = 0.0f, r1 = v[OFF + 2 * K];  // raw derivative logits of knots k and k+1
-      bool first = true, last = false;
+    float cw[K + 1], ch[K + 1], raw[K + 1];
+    knots<OFF, NV>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw);
+    knots<OFF + K, NV>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch);
+    // derivative logits per knot; the boundary knots carry the logit of derivative 1
+    raw[0] = c.edge_raw;
+    raw[K] = c.edge_raw;
 #pragma unroll
-      for (int i = 1; i < K; ++i) {
-        const bool ge = INV ? (xin >= st.ch[i]) : (xin >= st.cw[i]);
-        in_cw = ge ? st.cw[i] : in_cw;
-        in_cw1 = ge ? st.cw[i + 1] : in_cw1;
-        in_ch = ge ? st.ch[i] : in_ch;
-        in_ch1 = ge ? st.ch[i + 1] : in_ch1;
-        r0 = ge ? v[OFF + 2 * K + i - 1] : r0;
-        if (i + 1 < K) r1 = ge ? v[OFF + 2 * K + i] : r1;
-        if (i == 1) first = !ge;
-        if (i == K - 1) last = ge;
-      }
-      st.in_cw = in_cw; st.in_cw1 = in_cw1; st.in_ch = in_ch; st.in_ch1 = in_ch1;
-      // boundary knots: select the boundary LOGIT (cheap), then one unconditional softplus each
-      r0 = first ? c.edge_raw : r0;
-      r1 = last ? c.edge_raw : r1;
-      st.in_d = c.min_d + nsa_softplus(r0);
-      st.in_d1 = c.min_d + nsa_softplus(r1);
+    for (int i = 1; i < K; ++i) raw[i] = v[OFF + 2 * K + i - 1];
+    const bool inside = (x >= -B) && (x <= B);
+    const float xin = inside ? x : 0.0f;
+    float o[6];  // searched axis k, k+1; other axis k, k+1; derivative logits k, k+1
+    if constexpr (INV) NsaBinSelect<K>::run(ch, cw, raw, xin, o);
+    else NsaBinSelect<K>::run(cw, ch, raw, xin, o);
+    const float in_cw = INV ? o[2] : o[0], in_cw1 = INV ? o[3] : o[1];
+    const float in_ch = INV ? o[0] : o[2], in_ch1 = INV ? o[1] : o[3];
+    // only the two derivatives that are used are evaluated
+    const float in_d = c.min_d + nsa_softplus_fast(o[4]);
+    const float in_d1 = c.min_d + nsa_softplus_fast(o[5]);
+    const float in_w = in_cw1 - in_cw;
+    const float in_h = in_ch1 - in_ch;
+    const float inv_w = nsa_rcp(in_w);
+    const float delta = in_h * inv_w;
+    const float curv = (in_d + in_d1) - 2.0f * delta;
+    float out, dnum, den;
+    if constexpr (INV) {
+      const float sh = xin - in_ch;
+      const float a = sh * curv + in_h * (delta - in_d);
+      const float b = in_h * in_d - sh * curv;
+      const float cc = -delta * sh;
+      const float disc = b * b - 4.0f * a * cc;
+      bad = inside && !(disc >= 0.0f);
+      const float root = (2.0f * cc) * nsa_rcp(-b - __builtin_amdgcn_sqrtf(disc));
+      out = root * in_w + in_cw;
+      const float tomt = root * (1.0f - root);
+      const float omr = 1.0f - root;
+      den = delta + curv * tomt;
+      dnum = (delta * delta) * ((in_d1 * (root * root) + (2.0f * delta) * tomt) + in_d * (omr * omr));
     } else {
-      const float x = st.x;
-      const bool inside = (x >= -B) && (x <= B);
-      const float xin = inside ? x : 0.0f;
-      const float in_cw = st.in_cw, in_ch = st.in_ch, in_d = st.in_d, in_d1 = st.in_d1;
-      const float in_w = st.in_cw1 - in_cw;
-      const float in_h = st.in_ch1 - in_ch;
-      const float inv_w = nsa_rcp(in_w);
-      const float delta = in_h * inv_w;
-      const float curv = (in_d + in_d1) - 2.0f * delta;
-      float out, dnum, den;
-      if constexpr (INV) {
-        const float sh = xin - in_ch;
-        const float a = sh * curv + in_h * (delta - in_d);
-        const float b = in_h * in_d - sh * curv;
-        const float cc = -delta * sh;
-        const float disc = b * b - 4.0f * a * cc;
-        bad = inside && !(disc >= 0.0f);
-        const float root = (2.0f * cc) * nsa_rcp(-b - __builtin_amdgcn_sqrtf(disc));
-        out = root * in_w + in_cw;
-        const float tomt = root * (1.0f - root);
-        const float omr = 1.0f - root;
-        den = delta + curv * tomt;
-        dnum = (delta * delta) * ((in_d1 * (root * root) + (2.0f * delta) * tomt) + in_d * (omr * omr));
-      } else {
-        bad = false;
-        const float theta = (xin - in_cw) * inv_w;
-        const float tomt = theta * (1.0f - theta);
-        const float omt = 1.0f - theta;
-        den = delta + curv * tomt;
-        out = in_ch + (in_h * (delta * (theta * theta) + in_d * tomt)) * nsa_rcp(den);
-        dnum = (delta * delta) * ((in_d1 * (theta * theta) + (2.0f * delta) * tomt) + in_d * (omt * omt));
-      }
-      float lad = nsa_log(dnum) - 2.0f * nsa_log(den);
-      lad = INV ? -lad : lad;
-      y = inside ? out : x;
-      ld = inside ? lad : 0.0f;
+      bad = false;
+      const float theta = (xin - in_cw) * inv_w;
+      const float tomt = theta * (1.0f - theta);
+      const float omt = 1.0f - theta;
+      den = delta + curv * tomt;
+      out = in_ch + (in_h * (delta * (theta * theta) + in_d * tomt)) * nsa_rcp(den);
+      dnum = (delta * delta) * ((in_d1 * (theta * theta) + (2.0f * delta) * tomt) + in_d * (omt * omt));
     }
+    // log(dnum) - 2 log(den) on the hardware log2
+    float lad = 0.6931471805599453f * (nsa_log2(dnum) - 2.0f * nsa_log2(den));
+    lad = INV ? -lad : lad;
+    y = inside ? out : x;
+    ld = inside ? lad : 0.0f;
   }
 };
 

@@ -282,7 +282,7 @@ template <int N>
 __device__ __forceinline__ void nsa_act_regs(float (&a)[N], int act) {
   if (act == NSA_ACT_RELU) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) a[i] = fmaxf(a[i], 0.0f);
+    for (int i = 0; i < N; ++i) a[i] = nsa_relu(a[i]);
   } else if (act == NSA_ACT_TANH) {
 #pragma unroll
     for (int i = 0; i < N; ++i) a[i] = tanhf(a[i]);
