@@ -140,7 +140,11 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   const int XS = (D + 1) | 1;
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
   const size_t stage_bytes = 2 * (size_t)h[NSA_H_MAX_STAGE] * 4;
-  auto lds_of = [&](int w) { return ((((size_t)w * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + stage_bytes; };
+  // + the populate epilogue's per-column constants: 4 double tables and one int table (nsa_flow_kernel.h)
+  const size_t epi_bytes = (p.mode == NSA_MODE_POPULATE) ? (size_t)((D + 3) & ~3) * (4 * 8 + 4) : 0;
+  auto lds_of = [&](int w) {
+    return ((((size_t)w * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + stage_bytes + epi_bytes;
+  };
   auto per_cu_of = [&](int w) {
     long long c = (long long)(g_max_lds / lds_of(w));
     const long long by_waves = (4 * occ) / w;  // occ waves per SIMD

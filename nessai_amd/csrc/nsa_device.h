@@ -33,7 +33,12 @@ __device__ __forceinline__ f32x16 nsa_mfma(float a, float b, f32x16 c) {
 
 // bf16 matrix core: D[i][j] += sum_k A[i][k] B[k][j], k = 8*half + e (16 per instruction)
 __device__ __forceinline__ f32x16 nsa_mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+#if defined(NSA_ABLATE) && (NSA_ABLATE & 8)
+  asm volatile("" ::"v"(a), "v"(b));  // diagnostic build: operands stay live, no matrix work
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi)   (round to nearest even)

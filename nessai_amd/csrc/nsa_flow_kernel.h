@@ -32,6 +32,19 @@
 
 enum { NSA_MODE_APPLY = 0, NSA_MODE_LOGPROB = 1, NSA_MODE_POPULATE = 2 };
 
+// Diagnostic builds (scripts/ablate.sh; never the shipped library): -DNSA_ABLATE=<bits> removes one
+// ingredient of the kernel so that its share of the run time can be read off the clock.
+//   1 stage copies after the first   2 stage barriers   4 element-wise transform
+//   8 MFMAs of the hidden and last layers   16 latent draw (Philox / Box-Muller)   32 epilogue stores
+#ifndef NSA_ABLATE
+#define NSA_ABLATE 0
+#endif
+// LDS prefetch distance of the weight operands, in units of one k-step of one output tile
+// (3 MFMAs = 96 matrix-pipe cycles per unit against ~100+ cycles of ds_read_b128 latency)
+#ifndef NSA_PF
+#define NSA_PF 2
+#endif
+
 struct NsaLaunch {
   const uint32_t* image;  // device flow image (nsa_format.h)
   int direction;          // NSA_DIR_*
@@ -114,6 +127,7 @@ struct NsaStagePipe {
   int wave, nw, lane;
 
   __device__ __forceinline__ void issue(int s, float* dst) {
+    if ((NSA_ABLATE & 1) && s != 0) return;
     const uint32_t off = table[2 * s], words = table[2 * s + 1];
     const uint32_t* src = img + off;
     const int pieces = (int)(words >> 8);
@@ -136,7 +150,7 @@ struct NsaStagePipe {
   }
   __device__ __forceinline__ void end() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(NSA_ABLATE & 2)) __syncthreads();
     cur = (cur + 1 == n_stages) ? 0 : cur + 1;
     parity ^= 1;
   }
@@ -239,14 +253,24 @@ template <int HT, int OT>
 __device__ __forceinline__ void nsa_dense_regs16(const float* w, const NsaSplit<HT>& sp, int lane,
                                                  f32x16 (&acc)[OT]) {
   constexpr int S = 2 * HT;
+  // the A operands (LDS) of unit u + NSA_PF are fetched before the MFMAs of unit u are issued, so
+  // that the LDS latency runs under the matrix pipe instead of in front of it
+  constexpr int U = S * OT;  // unit u = s * OT + ot
+  bf16x8 ah[NSA_PF + 1], al[NSA_PF + 1];
 #pragma unroll
-  for (int s = 0; s < S; ++s) {
+  for (int u = 0; u < NSA_PF && u < U; ++u) {
+    ah[u] = *(const bf16x8*)(w + ((((u % OT) * S + u / OT) * 2 + 0) * 64 + lane) * 4);
+    al[u] = *(const bf16x8*)(w + ((((u % OT) * S + u / OT) * 2 + 1) * 64 + lane) * 4);
+  }
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
-      const bf16x8 ah = *(const bf16x8*)(w + (((ot * S + s) * 2 + 0) * 64 + lane) * 4);
-      const bf16x8 al = *(const bf16x8*)(w + (((ot * S + s) * 2 + 1) * 64 + lane) * 4);
-      acc[ot] = nsa_mfma_x3(ah, al, sp.hi[s], sp.lo[s], acc[ot]);
+  for (int u = 0; u < U; ++u) {
+    const int s = u / OT, ot = u % OT;
+    if (u + NSA_PF < U) {
+      const int s2 = (u + NSA_PF) / OT, ot2 = (u + NSA_PF) % OT;
+      ah[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * S + s2) * 2 + 0) * 64 + lane) * 4);
+      al[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * S + s2) * 2 + 1) * 64 + lane) * 4);
     }
+    acc[ot] = nsa_mfma_x3(ah[u % (NSA_PF + 1)], al[u % (NSA_PF + 1)], sp.hi[s], sp.lo[s], acc[ot]);
   }
 }
 
@@ -343,14 +367,22 @@ __device__ __forceinline__ void nsa_chunk_gemm(const float* stg, const float (&h
   for (int q = 0; q < TP::FPC; ++q) cols[q] = tr_tab[half * TP::FPC + q];
   nsa_load_bias<TP::C>(bias, half, acc);
   if constexpr (PREC == NSA_PREC_BF16X3) {
+    constexpr int U = G * TP::C;  // unit u = g * C + ot; operands fetched NSA_PF units ahead
+    bf16x8 ah[NSA_PF + 1], al[NSA_PF + 1];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
+    for (int u = 0; u < NSA_PF && u < U; ++u) {
+      ah[u] = *(const bf16x8*)(w + ((((u % TP::C) * G + u / TP::C) * 2 + 0) * 64 + lane) * 4);
+      al[u] = *(const bf16x8*)(w + ((((u % TP::C) * G + u / TP::C) * 2 + 1) * 64 + lane) * 4);
+    }
 #pragma unroll
-      for (int ot = 0; ot < TP::C; ++ot) {
-        const bf16x8 ah = *(const bf16x8*)(w + (((ot * G + g) * 2 + 0) * 64 + lane) * 4);
-        const bf16x8 al = *(const bf16x8*)(w + (((ot * G + g) * 2 + 1) * 64 + lane) * 4);
-        acc[ot] = nsa_mfma_x3(ah, al, hs.hi[g], hs.lo[g], acc[ot]);
+    for (int u = 0; u < U; ++u) {
+      const int g = u / TP::C, ot = u % TP::C;
+      if (u + NSA_PF < U) {
+        const int g2 = (u + NSA_PF) / TP::C, ot2 = (u + NSA_PF) % TP::C;
+        ah[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * G + g2) * 2 + 0) * 64 + lane) * 4);
+        al[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * G + g2) * 2 + 1) * 64 + lane) * 4);
       }
+      acc[ot] = nsa_mfma_x3(ah[u % (NSA_PF + 1)], al[u % (NSA_PF + 1)], hs.hi[g], hs.lo[g], acc[ot]);
     }
   } else {
     f32x4 a_cur[TP::C];
@@ -471,9 +503,14 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     for (int t = 0; t < TP::C; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[16 * t + r] = acc[t][r];
-    typename TP::State sts[TP::FPC];
-    nsa_run_phases<TP, INV, 0>(sts, v, cols, xrow, dummy_col, tc, logdet, n_bad,
-                               std::make_integer_sequence<int, TP::NPH * TP::FPC>{});
+    if constexpr ((NSA_ABLATE & 4) != 0) {
+#pragma unroll
+      for (int i = 0; i < 16 * TP::C; ++i) asm volatile("" ::"v"(v[i]));
+    } else {
+      typename TP::State sts[TP::FPC];
+      nsa_run_phases<TP, INV, 0>(sts, v, cols, xrow, dummy_col, tc, logdet, n_bad,
+                                 std::make_integer_sequence<int, TP::NPH * TP::FPC>{});
+    }
     pipe.end();
   }
 }
@@ -574,6 +611,23 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
   pipe.n_stages = (int)(inverse ? img[NSA_H_NSTAGES_INV] : img[NSA_H_NSTAGES_FWD]);
   pipe.buf0 = smem + tiles_words;
   pipe.buf1 = pipe.buf0 + max_stage;
+  // POPULATE: the per-column constants of the epilogue (z-score sigma / mu, prior bounds, output
+  // column table) live in LDS behind the stage buffers - the epilogue reads them per feature, and
+  // from global memory every read was a separate exposed round trip
+  const int D4e = (D + 3) & ~3;
+  double* epi = (double*)(pipe.buf1 + max_stage);  // [4][D4e] doubles + [D4e] ints = NSA_EPI_WORDS(D)
+  if (p.mode == NSA_MODE_POPULATE) {
+    int* epi_tab = (int*)(epi + 4 * D4e);
+    const int* otab = (const int*)(img + (inverse ? img[NSA_H_OUT_INV] : img[NSA_H_OUT_FWD]));
+    for (int i = (int)threadIdx.x; i < D; i += (int)blockDim.x) {
+      epi[i] = p.scale != nullptr ? p.scale[i] : 1.0;
+      epi[D4e + i] = p.shift != nullptr ? p.shift[i] : 0.0;
+      epi[2 * D4e + i] = p.lower[i];
+      epi[3 * D4e + i] = p.upper[i];
+      epi_tab[i] = otab[i];
+    }
+    __syncthreads();
+  }
   pipe.wave = wave;
   pipe.nw = nw;
   pipe.lane = lane;
@@ -626,6 +680,11 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
       const unsigned long long grow = p.row_offset + (unsigned long long)my_row;
       const int n_quads = (D + 3) >> 2;
       for (int q = half; q < n_quads; q += 2) {
+        if (NSA_ABLATE & 16) {
+          for (int e = 0; e < 4; ++e)
+            if (4 * q + e < D) xrow[4 * q + e] = 0.25f * (float)(q + e) - 1.0f;
+          continue;
+        }
         uint32_t r4[4];
         nsa_philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)q, 0u,
                           (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r4);
@@ -712,6 +771,30 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
       bool in_bounds = true;
       double log_prior = 0.0;
       double log_j_row = 0.0;  // row-dependent part of the rescaling log-Jacobian
+      if (e.rp_kind == nullptr && e.prior_kind == nullptr) {
+        // the plain case (z-score everywhere, prior evaluated elsewhere) without the per-column
+        // dispatch: one multiply, one add, two compares and one store per feature
+        double* xo = e.x64_out + my_row * D;
+        const int* epi_tab = (const int*)(epi + 4 * D4e);
+        int inb = 1;
+        if (row_ok && !(NSA_ABLATE & 32)) {
+#pragma unroll 4
+          for (int i = half; i < D; i += 2) {
+            const double xp = (double)xrow[epi_tab[i]];
+            const double xv = (xp * epi[i]) + epi[D4e + i];
+            inb &= (int)!(xv < epi[2 * D4e + i]) & (int)!(xv > epi[3 * D4e + i]);
+            xo[i] = xv;
+          }
+        } else {
+#pragma unroll 4
+          for (int i = half; i < D; i += 2) {
+            const double xp = (double)xrow[epi_tab[i]];
+            const double xv = (xp * epi[i]) + epi[D4e + i];
+            inb &= (int)!(xv < epi[2 * D4e + i]) & (int)!(xv > epi[3 * D4e + i]);
+          }
+        }
+        in_bounds = inb != 0;
+      } else
       for (int i = half; i < D; i += 2) {
         const double xp = (double)xrow[out_tab[i]];
         double xv;
@@ -734,7 +817,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
           xv = xv + c[4];
         }
         in_bounds = in_bounds && !((xv < e.lower[i]) || (xv > e.upper[i]));
-        if (row_ok) e.x64_out[my_row * D + i] = xv;
+        if (row_ok && !(NSA_ABLATE & 32)) e.x64_out[my_row * D + i] = xv;
         if (e.prior_kind != nullptr) log_prior += nsa_log_prior_term(e.prior_kind[i], xv, e.prior_par + 3 * i);
       }
       if (e.prior_kind != nullptr) {

@@ -222,9 +222,6 @@ __device__ __forceinline__ void tr_rq_forward_item(int row, int m, int d_tr, con
   float y = 0.0f, ld = 0.0f;
   bool bad = false;
   NsaRQ<K>::template phase<0, 0, false, NP>(st, v, x, tc, y, ld, bad);
-  NsaRQ<K>::template phase<1, 0, false, NP>(st, v, x, tc, y, ld, bad);
-  NsaRQ<K>::template phase<2, 0, false, NP>(st, v, x, tc, y, ld, bad);
-  NsaRQ<K>::template phase<3, 0, false, NP>(st, v, x, tc, y, ld, bad);
   X[(long long)row * ldx + col] = y;
   atomicAdd(&logdet[row], ld);
 }

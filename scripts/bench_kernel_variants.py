@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 VARIANTS = [(2, 4), (2, 8), (3, 6), (3, 12), (3, 3)]
+QUICK = "--quick" in sys.argv  # default geometry, split-bf16 only
 
 
 def main():
@@ -21,8 +22,8 @@ def main():
     prop = bench.build_proposal(0, 1, device)
     prop.populate(None, n_samples=bench.NLIVE, max_samples=10**12)
     ref = None
-    for precision in ("bf16x3", "f32"):
-        for occ, wpg in VARIANTS:
+    for precision in (("bf16x3",) if QUICK else ("bf16x3", "f32")):
+        for occ, wpg in (VARIANTS[:1] if QUICK else VARIANTS):
             os.environ["NESSAI_AMD_OCC"] = str(occ)
             prop.flow.model.waves_per_group = wpg
             ms, ms_min = bench.time_draw_kernel(prop, launches=8, precision=precision)
@@ -33,7 +34,7 @@ def main():
             checksum = float(lq[kept].sum().item())
             if precision == "bf16x3" and ref is None:
                 ref = (int(kept.sum().item()), checksum)
-            print(json.dumps(dict(precision=precision, occ=occ, waves_per_group=wpg, ms_avg=ms, ms_min=ms_min,
+            print(json.dumps(dict(library=os.path.basename(os.environ.get("NESSAI_AMD_LIBRARY", "libnessai_amd.so")), precision=precision, occ=occ, waves_per_group=wpg, ms_avg=ms, ms_min=ms_min,
                                   kept=int(kept.sum().item()), log_q_sum=checksum)), flush=True)
     os.environ.pop("NESSAI_AMD_OCC", None)
 
