@@ -15,8 +15,12 @@ timed window is the reference's ``population_time`` window
 (flowproposal.py:400-518): the likelihood evaluation of the pool is excluded.
 
 ``python bench.py --gpus N --steps K --warmup W`` (N > 1 under torchrun: one
-rank per GPU, every draw batch is sharded over the ranks - 1e6 rows per rank -
-with one all-reduce(max) + one all-reduce(sum) per pass and one all-gather per step).
+rank per GPU, every draw batch is sharded over the ranks with one all-reduce(max) + one
+all-reduce(sum) per pass and one all-gather per step).  ``--scaling strong`` (default) keeps the
+1e6-row batch of BASELINE config 3 and gives each rank 1e6 / N rows, so the acceptance - and with
+it the metric's meaning - is that of the 1-GPU run; ``--scaling weak`` gives every rank 1e6 rows
+(an N x 1e6 batch: the acceptance per row falls with the batch size because the weights are
+normalised by the batch maximum, so accepted points/s grows much more slowly than rows/s).
 
 Environment knobs (tuning / diagnostics only): ``NESSAI_AMD_FORCE_SHARD=1`` runs the sharded
 code path over RCCL on a single rank; ``NESSAI_AMD_WPG=<n>`` sets the waves per workgroup of
@@ -50,7 +54,7 @@ def load_fixture():
     return state, data["shift"], data["scale"]
 
 
-def build_proposal(rank, world, device):
+def build_proposal(rank, world, device, scaling="strong"):
     from nessai_amd.model import RosenbrockModel
     from nessai_amd.proposal import FlowProposal
 
@@ -62,7 +66,7 @@ def build_proposal(rank, world, device):
         flow_config=FLOW_CONFIG,
         training_config=dict(device_tag=str(device)),
         poolsize=NLIVE,
-        drawsize=DRAWSIZE * world,
+        drawsize=DRAWSIZE * (world if scaling == "weak" else 1),  # the TOTAL draw batch of one pass
         device_seed=1451,
         shard=world > 1,
         output=os.path.join("/tmp", f"nessai_amd_bench_{os.getpid()}"),
@@ -108,33 +112,99 @@ def _time_draw_kernel(prop, n, launches):
     return float(np.mean(ms)), float(np.min(ms))
 
 
-def cpu_baseline():
-    """The oracle (CPU restatement of the reference path) timed on this host with
-    ONE torch thread - the reference's default (src/nessai/flowsampler.py:98)."""
+def traffic_probe(device):
+    """``--traffic-probe``: a few launches of the draw kernel and nothing else (the command that
+    ``measure_traffic`` runs under rocprofv3)."""
+    prop = build_proposal(0, 1, device)
+    prop.populate(None, n_samples=NLIVE, max_samples=10**12)
+    time_draw_kernel(prop, launches=4)
+
+
+def measure_traffic():
+    """HBM bytes per launch of the draw kernel from the PMC counters, collected live: two
+    ``rocprofv3 --kernel-trace --pmc`` passes over ``bench.py --traffic-probe`` (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass), corrected as MI355X_MICROARCH.md (HBM) prescribes: both counters
+    are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes
+    (x2).  Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    per_launch = {}
+    tmp = tempfile.mkdtemp(prefix="nsa_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "pmc",
+                   "--", sys.executable, os.path.abspath(__file__), "--traffic-probe"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            values = []
+            for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                with open(path, newline="") as f:
+                    for row in csv.DictReader(f):
+                        if "nsa_flow_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                            values.append((int(row.get("Grid_Size", 0) or 0), float(row["Counter_Value"])))
+            if not values:
+                return None, f"no {counter} rows for the flow kernel in the rocprofv3 output"
+            full = max(g for g, _ in values)  # the 1e6-row launches (the populate call also makes them)
+            vals = [v for g, v in values if g == full]
+            per_launch[counter] = float(np.mean(vals)) * 1024.0
+        total = 2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]
+        return total, {"fetch_size_bytes_x2": 2.0 * per_launch["FETCH_SIZE"], "write_size_bytes": per_launch["WRITE_SIZE"],
+                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this run"}
+    except Exception as exc:  # the counters are a cross-check, never the reason a bench run fails
+        return None, f"{type(exc).__name__}: {exc}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _oracle_proposal(drawsize, chunk_rows=None):
     from oracle import proposal as OP
 
+    state, shift, scale = load_fixture()
+    fm = OP.OracleFlowModel(
+        dict(n_inputs=DIMS, n_neurons=64, n_blocks=6, n_layers=2, ftype="nsf"),
+        rng=np.random.default_rng(1451),
+    )
+    fm.model.load_state_dict(state)
+    fm.model.eval()
+    fm.chunk_rows = chunk_rows
+    model = OP.RosenbrockModel(DIMS)
+    prop = OP.OracleFlowProposal(model, fm, rng=np.random.default_rng(1451), poolsize=NLIVE, drawsize=drawsize)
+    for i, n in enumerate(model.names):
+        prop.shift[n] = float(shift[i])
+        prop.scale[n] = float(scale[i])
+    return prop
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference path) timed on this host.
+
+    Leg (i), the reported baseline: ONE torch thread - the reference's default
+    (src/nessai/flowsampler.py:98) - on a bounded sample of the workload, one populate pass of
+    2.5e5 draws.  Leg (ii) (SURVEY.md section 8d ii): every host core
+    (``torch.set_num_threads(os.cpu_count())``, the count is printed) on one FULL 1e6-row pass,
+    the flow inverse chunked at 1e5 rows to bound the eager temporaries."""
     threads = torch.get_num_threads()
-    torch.set_num_threads(1)
     try:
-        state, shift, scale = load_fixture()
-        fm = OP.OracleFlowModel(
-            dict(n_inputs=DIMS, n_neurons=64, n_blocks=6, n_layers=2, ftype="nsf"),
-            rng=np.random.default_rng(1451),
-        )
-        fm.model.load_state_dict(state)
-        fm.model.eval()
-        model = OP.RosenbrockModel(DIMS)
+        torch.set_num_threads(1)
         sample_draw = 250_000
-        prop = OP.OracleFlowProposal(model, fm, rng=np.random.default_rng(1451), poolsize=NLIVE,
-                                     drawsize=sample_draw)
-        for i, n in enumerate(model.names):
-            prop.shift[n] = float(shift[i])
-            prop.scale[n] = float(scale[i])
+        prop = _oracle_proposal(sample_draw)
         torch.manual_seed(1451)
         t = time.perf_counter()
         prop.populate(n_samples=NLIVE, max_samples=sample_draw - 1)  # exactly one pass
         dt = time.perf_counter() - t
-        return {
+        out = {
             "value": prop.n_accepted / dt,
             "unit": "accepted points/s",
             "cores": 1,
@@ -145,6 +215,24 @@ def cpu_baseline():
             "acceptance": prop.population_acceptance,
             "host_cpus": os.cpu_count(),
         }
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        prop = _oracle_proposal(DRAWSIZE, chunk_rows=100_000)
+        torch.manual_seed(1451)
+        t = time.perf_counter()
+        prop.populate(n_samples=NLIVE, max_samples=DRAWSIZE - 1)  # exactly one full-size pass
+        dt = time.perf_counter() - t
+        out["all_cores"] = {
+            "value": prop.n_accepted / dt,
+            "unit": "accepted points/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"one full populate pass of {DRAWSIZE} draws (flow inverse in chunks of 100000 rows), "
+                      f"{prop.n_accepted} accepted in {dt:.1f} s",
+            "proposed_rows_per_s": prop.n_proposed / dt,
+            "acceptance": prop.population_acceptance,
+        }
+        return out
     finally:
         torch.set_num_threads(threads)
 
@@ -155,6 +243,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: 'strong' shards the 1e6-row draw batch of BASELINE config 3 over the ranks "
+                         "(1e6 / N rows each, same acceptance as at N = 1); 'weak' gives every rank 1e6 rows "
+                         "(an N x 1e6 batch: more rows per pass but a lower acceptance per row)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that write to the C-level stdout (RCCL prints a
@@ -174,6 +268,9 @@ def main():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.traffic_probe:
+        traffic_probe(device)
+        return
     force_shard = os.environ.get("NESSAI_AMD_FORCE_SHARD") == "1"  # exercise the RCCL path on 1 rank
     if world > 1 or force_shard:
         import torch.distributed as dist
@@ -185,7 +282,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    prop = build_proposal(rank, world, device)
+    if DRAWSIZE % world:
+        raise SystemExit(f"--gpus {world} does not divide the draw batch of {DRAWSIZE} rows")
+    prop = build_proposal(rank, world, device, args.scaling)
+    batch = prop.drawsize
     if force_shard:
         prop.shard = True
 
@@ -218,6 +318,9 @@ def main():
     f32_ms, _ = time_draw_kernel(prop, precision="f32")
     f32_achieved = FLOPS_PER_ROW * DRAWSIZE / (f32_ms * 1e-3) / 1e12
 
+    traffic, traffic_detail = (None, "skipped (--no-pmc or N > 1)")
+    if rank == 0 and world == 1 and not args.no_pmc:
+        traffic, traffic_detail = measure_traffic()
     if rank == 0:
         out = {
             "metric": "accepted live points/sec in FlowProposal.populate(), 32-D Rosenbrock nlive=2000",
@@ -228,21 +331,23 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None,
             "dtype": "bf16x3 (split-bf16 operands on bf16 MFMA, f32 accumulate)" if precision == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {
                 "workload": "32-D Rosenbrock, NeuralSplineFlow (8 RQ bins, 6 coupling layers, "
-                            "2x64 residual conditioner), nlive=poolsize=2000, populate batch=1e6 per GPU",
-                "drawsize_per_gpu": DRAWSIZE,
+                            f"2x64 residual conditioner), nlive=poolsize=2000, populate batch={batch:.0e} "
+                            f"({batch // world} rows per GPU)",
+                "drawsize": batch,
+                "drawsize_per_gpu": batch // world,
                 "n_samples": NLIVE,
                 "weights": "trained on 2000 synthetic live points (tests/golden/c3_trained.npz)",
                 "parallelism": f"draw batch sharded over {world} GPU(s)",
             },
             "proposed_rows_per_s": proposed / elapsed,
             "acceptance": accepted / proposed,
-            "passes_per_step": proposed / (DRAWSIZE * world) / args.steps,
+            "passes_per_step": proposed / batch / args.steps,
             "roofline": {
                 "kernel": f"nsa_flow_kernel<2, NsaRQ<8>, inverse, {precision}> "
                           "(fused draw + inverse flow + rescale + bounds + log_q)",
@@ -251,9 +356,11 @@ def main():
                 "peak": PEAK_TFLOPS[precision],
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_TFLOPS[precision],
-                # HBM bytes per launch from the PMC passes of profiles/r01_bench_c3_v7.txt (v5: same):
-                # WRITE_SIZE 258 127 KB + 2 x FETCH_SIZE 4 474 KB (gfx950 halves coalesced reads)
-                "traffic": 273.5e6,
+                # HBM bytes per launch: PMC counters read in THIS run (measure_traffic); algorithmic
+                # bytes are 264 MB (x as float64 + log_q)
+                "traffic": traffic,
+                "traffic_detail": traffic_detail,
+                "algorithmic_bytes": 264.0e6,
                 "kernel_ms_avg": kernel_ms,
                 "kernel_ms_min": kernel_ms_min,
                 "rows_per_launch": DRAWSIZE,

@@ -206,6 +206,14 @@ NSA_API int nsa_populate_pass_commit(long long* state_dev, long long capacity,
 NSA_API int nsa_populate_weights(long long n, const double* log_q_dev, const double* log_prior_dev,
                          double log_prior_const, double* log_w_dev, long long* max_key_dev,
                          void* stream);
+/* The truncation rules that act after the flow: MinLogQTruncation.apply_after_backward
+ * (`log_q > min_log_q`, proposal/flowproposal/truncation.py:385-392) and
+ * LikelihoodThresholdTruncation.apply_after_likelihood (`logL > threshold`, :423-430).  A row that
+ * fails is marked dropped (log_q = NaN), exactly like a row outside the prior bounds.  Pass
+ * min_log_q = -inf and/or log_l_dev = NULL for an absent rule.  Call between nsa_populate_draw
+ * and nsa_populate_weights. */
+NSA_API int nsa_populate_truncate(long long n, double* log_q_dev, double min_log_q, const double* log_l_dev,
+                                  double log_l_threshold, void* stream);
 NSA_API long long nsa_max_key_init(void);
 NSA_API long long nsa_max_key_encode(double v);
 NSA_API double nsa_max_key_decode(long long key);

@@ -97,13 +97,19 @@ static int nsa_device_info(NsaDeviceInfo& out) {
   return NSA_OK;
 }
 
-// Waves per SIMD of the flow kernel: NESSAI_AMD_OCC=2|3 overrides the default (read per call: the
-// benchmark scripts flip it).  3 needs a conditioner of <= 64 hidden units (HT <= 2).
-static int nsa_occupancy(int ht) {
+// Waves per SIMD of the flow kernel.  Default: 2 (workgroups of 4 waves, two per CU); big
+// split-bf16 batches of a narrow conditioner (HT <= 2) run 3 waves per SIMD as ONE workgroup of
+// 12 waves per CU - a third of the stage copies per row and one more wave per SIMD to cover the
+// stage barriers (config 3: 1.89 -> 1.80 ms per 1e6 rows; 6- and 3-wave workgroups load the four
+// SIMDs unevenly and are slower than either).  NESSAI_AMD_OCC=2|3 overrides (read per call: the
+// benchmark scripts flip it).
+static int nsa_occupancy(int ht, int precision, long long n_tiles, int n_flows, int num_cus,
+                         int waves_per_group) {
   const char* e = getenv("NESSAI_AMD_OCC");
-  int occ = NSA_DEFAULT_OCC;
-  if (e != nullptr && (e[0] == '2' || e[0] == '3')) occ = e[0] - '0';
-  return (occ == 3 && ht <= 2) ? 3 : 2;
+  if (e != nullptr && (e[0] == '2' || e[0] == '3')) return (e[0] == '3' && ht <= 2) ? 3 : 2;
+  if (waves_per_group > 0) return (waves_per_group > 8 && ht <= 2) ? 3 : NSA_DEFAULT_OCC;
+  if (ht <= 2 && precision == NSA_PREC_BF16X3 && n_tiles * n_flows >= 24LL * num_cus) return 3;
+  return NSA_DEFAULT_OCC;
 }
 
 static int nsa_check_header(const uint32_t* h) {
@@ -134,11 +140,10 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   if (h[NSA_H_PREC] != NSA_PREC_F32 && h[NSA_H_PREC] != NSA_PREC_BF16X3)
     return nsa_fail(NSA_E_IMAGE, "unknown precision code %u", h[NSA_H_PREC]);
   p.precision = (int)h[NSA_H_PREC];
-  const int occ = nsa_occupancy((int)h[NSA_H_HT]);
-  p.occupancy = occ;
   const int D = (int)h[NSA_H_D];
   const int XS = (D + 1) | 1;
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
+  int occ = nsa_occupancy((int)h[NSA_H_HT], p.precision, n_tiles, n_flows, g_num_cus, waves_per_group);
   const size_t stage_bytes = 2 * (size_t)h[NSA_H_MAX_STAGE] * 4;
   // + the populate epilogue's per-column constants: 4 double tables and one int table (nsa_flow_kernel.h)
   const size_t epi_bytes = (p.mode == NSA_MODE_POPULATE) ? (size_t)((D + 3) & ~3) * (4 * 8 + 4) : 0;
@@ -152,8 +157,10 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     return c;
   };
   auto groups_of = [&](int w) { return (n_tiles + w - 1) / w; };
+  if (occ == 3 && waves_per_group <= 0 && lds_of(12) > g_max_lds) occ = NSA_DEFAULT_OCC;  // tiles too wide
+  p.occupancy = occ;
   const int nw_max = 4 * occ;
-  int nw = waves_per_group > 0 ? waves_per_group : 2 * occ;
+  int nw = waves_per_group > 0 ? waves_per_group : (occ == 3 ? 12 : 2 * occ);
   if (nw > nw_max) nw = nw_max;
   if (waves_per_group <= 0) {
     // small batches: fewer waves per workgroup so that more CUs take part ...
@@ -321,6 +328,16 @@ extern "C" int nsa_populate_weights(long long n, const double* log_q_dev, const 
   hipError_t e = nsa_launch_weights(n, log_q_dev, log_prior_dev, log_prior_const, log_w_dev, max_key_dev,
                                     (hipStream_t)stream, nullptr);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "weights kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+extern "C" hipError_t nsa_launch_truncate(long long, double*, double, const double*, double, hipStream_t);
+
+extern "C" int nsa_populate_truncate(long long n, double* log_q_dev, double min_log_q, const double* log_l_dev,
+                                     double log_l_threshold, void* stream) {
+  if (n < 0 || log_q_dev == nullptr) return nsa_fail(NSA_E_ARG, "nsa_populate_truncate: bad argument");
+  hipError_t e = nsa_launch_truncate(n, log_q_dev, min_log_q, log_l_dev, log_l_threshold, (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "truncate kernel: %s", hipGetErrorString(e));
   return NSA_OK;
 }
 

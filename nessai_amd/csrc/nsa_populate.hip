@@ -388,3 +388,32 @@ extern "C" hipError_t nsa_launch_log_likelihood(int kind, long long n, int D, co
                      x, mu, sigma, cst, out);
   return hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------
+// Truncation rules applied after the flow (src/nessai/proposal/flowproposal/truncation.py):
+//   min_log_q             keep log_q > min_log_q            (apply_after_backward, :385-392)
+//   likelihood_threshold  keep logL  > threshold            (apply_after_likelihood, :423-430)
+// A dropped row is marked the way the draw kernel marks rows outside the prior bounds
+// (log_q = NaN): it takes no part in the batch maximum and is never accepted.  8 (+8) bytes in,
+// at most 8 bytes out per row - HBM-bound byte work.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nsa_truncate_kernel(long long n, double* __restrict__ log_q,
+                                                           double min_log_q,
+                                                           const double* __restrict__ log_l,
+                                                           double log_l_threshold) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double lq = log_q[i];
+  bool keep = lq > min_log_q;  // false for NaN as well (already dropped)
+  if (log_l != nullptr) keep = keep && (log_l[i] > log_l_threshold);
+  if (!keep && lq == lq) log_q[i] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+extern "C" hipError_t nsa_launch_truncate(long long n, double* log_q, double min_log_q, const double* log_l,
+                                          double log_l_threshold, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  nsa_truncate_kernel<<<grid, 256, 0, stream>>>(n, log_q, min_log_q, log_l, log_l_threshold);
+  return hipGetLastError();
+}

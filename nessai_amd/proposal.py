@@ -23,6 +23,7 @@ One pass of the populate loop is three device steps and one small copy:
 """
 
 import datetime
+import math
 import logging
 import os
 
@@ -37,6 +38,7 @@ from .livepoint import (
     live_points_to_array,
 )
 from .reparam import ReparameterisationTable
+from .truncation import build_scheme, resolve_truncation
 from .utils import compute_radius
 
 logger = logging.getLogger(__name__)
@@ -92,11 +94,20 @@ class FlowProposal:
         poolsize=None,
         drawsize=None,
         latent_temperature=None,
-        volume_fraction=0.95,
-        fixed_radius=False,
-        radius_mode="constant_volume",
-        min_radius=False,
-        max_radius=50.0,
+        truncation_method=None,
+        truncation_methods=None,
+        truncation_kwargs=None,
+        truncate_log_q=False,
+        enforce_likelihood_threshold=False,
+        constant_volume_mode=None,
+        volume_fraction=None,
+        fuzz=None,
+        expansion_fraction=None,
+        fixed_radius=None,
+        radius_mode=None,
+        min_radius=None,
+        max_radius=None,
+        compute_radius_with_all=None,
         accumulate_weights=False,
         update_poolsize=True,
         max_poolsize_scale=10,
@@ -134,18 +145,17 @@ class FlowProposal:
         self.latent_temperature = None if latent_temperature is None else float(latent_temperature)
         self.accumulate_weights = accumulate_weights
         self.check_acceptance = check_acceptance
-        self.volume_fraction = float(volume_fraction)
-        if radius_mode not in {"adaptive", "fixed", "constant_volume"}:
-            raise ValueError(
-                f"Unknown radius mode: {radius_mode}. Choose from: adaptive, fixed, constant_volume"
-            )
-        if radius_mode == "fixed" and fixed_radius is False:
-            raise ValueError("Fixed radius mode requires `fixed_radius` to be specified")
-        self.radius_mode = radius_mode
-        self.fixed_radius = float(fixed_radius) if fixed_radius is not False else False
-        self.min_radius = min_radius
-        self.max_radius = max_radius
-        self.fuzz = 1.0
+        # truncation rules (flowproposal.py:246-331): the new arguments plus the deprecated
+        # latent-radius spellings, resolved exactly as the reference resolves them
+        legacy = dict(constant_volume_mode=constant_volume_mode, volume_fraction=volume_fraction, fuzz=fuzz,
+                      expansion_fraction=expansion_fraction, fixed_radius=fixed_radius, radius_mode=radius_mode,
+                      min_radius=min_radius, max_radius=max_radius, compute_radius_with_all=compute_radius_with_all)
+        names, rule_kwargs = resolve_truncation(
+            truncation_method=truncation_method, truncation_methods=truncation_methods,
+            truncation_kwargs=truncation_kwargs, truncate_log_q=truncate_log_q,
+            enforce_likelihood_threshold=enforce_likelihood_threshold, legacy=legacy,
+        )
+        self.truncation = build_scheme(names, rule_kwargs)
         if prior not in ("auto", "device", "host"):
             raise ValueError("prior must be 'auto', 'device' or 'host'")
         self._prior_mode = prior
@@ -203,6 +213,35 @@ class FlowProposal:
         return [n + "_prime" for n in self.model.names]
 
     @property
+    def prime_dims(self):
+        return self.dims
+
+    # the latent-radius rule's settings under their historical names
+    def _latent_rule(self):
+        return self.truncation.get_rule("latent_radius")
+
+    def _latent_get(self, name, default):
+        rule = self._latent_rule()
+        return default if rule is None else getattr(rule, name)
+
+    def _latent_set(self, name, value):
+        rule = self._latent_rule()
+        if rule is None:
+            raise AttributeError(f"{name}: the proposal has no latent-radius truncation rule")
+        setattr(rule, name, value)
+
+    radius_mode = property(lambda self: self._latent_get("radius_mode", None),
+                           lambda self, v: self._latent_set("radius_mode", v))
+    fixed_radius = property(lambda self: self._latent_get("fixed_radius", False),
+                            lambda self, v: self._latent_set("fixed_radius", v))
+    min_radius = property(lambda self: self._latent_get("min_radius", False),
+                          lambda self, v: self._latent_set("min_radius", v))
+    max_radius = property(lambda self: self._latent_get("max_radius", False),
+                          lambda self, v: self._latent_set("max_radius", v))
+    fuzz = property(lambda self: self._latent_get("fuzz", 1.0), lambda self, v: self._latent_set("fuzz", v))
+    volume_fraction = property(lambda self: self._latent_get("volume_fraction", None))
+
+    @property
     def x_dtype(self):
         return get_dtype(self.names)
 
@@ -217,21 +256,20 @@ class FlowProposal:
             if self._poolsize_scale < 1.0:
                 self._poolsize_scale = 1.0
 
-    def initialise(self):
-        """Set up the rescaling and the flow (``base.py:358-391``, ``:578-653``)."""
-        config = self.reparameterisations
-        if getattr(self.model, "reparameterisations", None) is not None:  # base.py:639-640
-            config = self.model.reparameterisations
-        self._reparam = ReparameterisationTable(
-            self.names, getattr(self.model, "bounds", None), config, fallback=self.fallback_reparameterisation
-        )
-        if self.radius_mode == "constant_volume":  # truncation.py:292-308
-            self.fixed_radius = compute_radius(self.dims, self.volume_fraction)
-            self.fuzz = 1.0
-            if self.max_radius and self.max_radius < self.fixed_radius:
-                self.max_radius = False
-            if self.min_radius and self.min_radius > self.fixed_radius:
-                self.min_radius = False
+    def initialise(self, resumed=False):
+        """Set up the rescaling and the flow (``base.py:358-391``, ``:578-653``).
+
+        ``resumed``: called from ``resume`` on an unpickled proposal - the reparameterisations
+        (with their fitted constants) and the truncation rules are kept as they were."""
+        os.makedirs(self.output, exist_ok=True)
+        if not resumed or getattr(self, "_reparam", None) is None:
+            config = self.reparameterisations
+            if getattr(self.model, "reparameterisations", None) is not None:  # base.py:639-640
+                config = self.model.reparameterisations
+            self._reparam = ReparameterisationTable(
+                self.names, getattr(self.model, "bounds", None), config, fallback=self.fallback_reparameterisation
+            )
+            self.truncation.configure(self)  # truncation.py:292-308 (needs the dimensions)
         config = dict(self.flow_config)
         config["n_inputs"] = self.dims
         self.flow = self._FlowModelClass(
@@ -339,14 +377,69 @@ class FlowProposal:
         self.check_state(self.training_data)
         x_prime, _ = self.rescale(x)
         x_prime_array = live_points_to_array(x_prime, self.prime_parameters)
-        self.flow.train(x_prime_array, output=self.output, plot=False)
+        rank, world = self._rank_world()
+        # every rank writes its own weights file (no race on a shared output directory)
+        output = self.output if rank == 0 else os.path.join(self.output, f"rank_{rank}")
+        self.flow.train(x_prime_array, output=output, plot=False)
+        if world > 1:
+            self._replicate_flow()
         self.populated = False
         self.training_count += 1
 
+    def _rank_world(self):
+        """(rank, world size) of a sharded run; (0, 1) otherwise."""
+        if not self.shard:
+            return 0, 1
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0, 1
+        return dist.get_rank(), dist.get_world_size()
+
+    def _replicate_flow(self):
+        """Make rank 0's flow THE flow of a sharded run (training does not
+        shard - replicas only).
+
+        Every rank runs the same fit on the same live points, so that the host generators
+        (validation split, pool shuffles) stay in lock step across the replicated samplers, but
+        the fused trainer sums weight gradients with float atomics: the fitted weights differ in
+        the last bits from rank to rank, and a populate sharded over different flows would mix
+        draws from different proposals.  Rank 0's parameters and buffers (batch-norm statistics,
+        permutations) therefore replace everyone's; the rescaling constants, which are exact
+        functions of the live points, are checked to agree."""
+        import torch.distributed as dist
+
+        model = self.flow.model
+        with torch.no_grad():
+            trainer = model.trainer()
+            dist.broadcast(trainer.flat, src=0)  # every Parameter and running statistic is a view of it
+            for name, buf in model.named_buffers():
+                if buf.numel() and buf.data_ptr() not in trainer.flat_range():
+                    dist.broadcast(buf, src=0)
+            for what, t in (("scale", self._scale_dev), ("shift", self._shift_dev)):
+                ref = t.clone()
+                dist.broadcast(ref, src=0)
+                if not torch.equal(ref, t):
+                    raise RuntimeError(
+                        f"sharded FlowProposal: the rescaling {what} differs between ranks - "
+                        "the replicated samplers were not given the same live points"
+                    )
+        # early stopping may have ended the fits at different epochs: the host generator (epoch
+        # shuffles) continues from rank 0's state everywhere
+        state = [self.rng.bit_generator.state]
+        dist.broadcast_object_list(state, src=0)
+        self.rng.bit_generator.state = state[0]
+        model._image_key = None  # repack the kernel image from the received weights
+        if self.flow.weights_file is not None:
+            self.flow.save_weights(self.flow.weights_file)
+
     # -- passes through the flow ---------------------------------------------------
 
-    def forward_pass(self, x, rescale=True):
-        """Live points -> (z, log_prob incl. rescaling Jacobian) (``base.py:961-994``)."""
+    def forward_pass(self, x, rescale=True, **kwargs):
+        """Live points -> (z, log_prob incl. rescaling Jacobian) (``base.py:961-994``).
+
+        Extra keyword arguments (``compute_radius=`` of the reference's signature) are accepted
+        and ignored: no rescaling here depends on them."""
         log_J = 0
         if rescale:
             x, log_J = self.rescale(x)
@@ -502,18 +595,37 @@ class FlowProposal:
     # -- population ----------------------------------------------------------------
 
     def compute_population_radius(self, worst_point, r=None):
-        """(``truncation.py:323-356``)."""
-        if r is not None:
-            return float(r)
-        if self.radius_mode in {"fixed", "constant_volume"}:
-            return float(self.fixed_radius)
-        worst_z = self.forward_pass(worst_point, rescale=True)[0]
-        radius = float(np.sqrt(np.sum(worst_z**2.0, axis=-1)).max())
-        if self.max_radius and radius > self.max_radius:
-            radius = self.max_radius
-        if self.min_radius and radius < self.min_radius:
-            radius = self.min_radius
-        return float(radius)
+        """Radius of the latent-radius rule for one population (``truncation.py:323-356``)."""
+        rule = self._latent_rule()
+        if rule is None:
+            return math.nan if r is None else float(r)
+        return rule._population_radius(self, worst_point, r)
+
+    def _truncate_after_flow(self, buf, n, min_log_q, log_l_threshold):
+        """The rules that act after the flow, as one device predicate on ``log_q``
+        (``nsa_populate_truncate``): ``log_q > min_log_q`` and ``logL > threshold``.  The
+        likelihood of every candidate comes from the device likelihood when the model declares
+        one, else from ``model.batch_evaluate_log_likelihood`` on the host (the rule is expensive
+        by construction: the reference evaluates every candidate too, ``flowproposal.py:455-466``)."""
+        if not (min_log_q > -math.inf or log_l_threshold is not None):
+            return
+        log_l_dev = None
+        if log_l_threshold is not None:
+            if self._ll_spec is not None:
+                log_l_dev = self._device_log_likelihood(buf["x64"][:n])
+            else:
+                alive = torch.isfinite(buf["log_q"][:n])
+                idx = torch.nonzero(alive).reshape(-1)
+                pts = array_to_live_points_fast(buf["x64"][:n][idx].cpu().numpy(), self.names)
+                values = np.asarray(self.model.batch_evaluate_log_likelihood(pts), dtype=np.float64)
+                log_l_dev = torch.full((n,), -math.inf, dtype=torch.float64, device=self.device)
+                log_l_dev[idx] = torch.from_numpy(values).to(self.device)
+        stream = lib.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = lib.load().nsa_populate_truncate(
+            n, lib.ptr(buf["log_q"]), float(min_log_q), lib.ptr(log_l_dev),
+            float(log_l_threshold) if log_l_threshold is not None else 0.0, stream,
+        )
+        lib.check(rc, "nsa_populate_truncate")
 
     def populate(self, worst_point=None, n_samples=10000, plot=False, r=None,
                  max_samples=1_000_000, injected=None):
@@ -528,9 +640,14 @@ class FlowProposal:
             raise RuntimeError(
                 "Proposal has not been initialised. Try calling `initialise()` first."
             )
-        radius = self.compute_population_radius(worst_point, r)
-        self.r = radius
-        threshold = self.fuzz * radius
+        # every rule computes its numbers for this population (truncation.py:483-486); the latent
+        # radius is compared inside the draw kernel, the other two by nsa_populate_truncate
+        self.truncation.prepare(self, worst_point, radius=r)
+        threshold, min_log_q, log_l_threshold = self.truncation.device_limits()
+        latent = self._latent_rule()
+        self.r = latent.radius if latent is not None else np.nan
+        post_rules = min_log_q > -math.inf or log_l_threshold is not None
+        self._post_limits = (min_log_q, log_l_threshold)
         self.indices = []
         n_samples = int(n_samples)
 
@@ -549,7 +666,7 @@ class FlowProposal:
         if self.accumulate_weights:
             return self._populate_accumulate(st, threshold, n_samples, max_samples, injected)
 
-        if injected is None and self.prior_mode == "device" and self.pass_trains:
+        if injected is None and self.prior_mode == "device" and self.pass_trains and not post_rules:
             if sharded:
                 return self._populate_trains_sharded(st, threshold, n_samples, max_samples, n_local, world, rank)
             return self._populate_trains(st, threshold, n_samples, max_samples)
@@ -567,6 +684,7 @@ class FlowProposal:
             self._launch_draw(n_local, z_in, row_offset, threshold, buf["x64"], buf["log_q"], None,
                               log_prior=buf["log_p"] if self._prior_kind_dev is not None else None,
                               prepared=prepared)
+            self._truncate_after_flow(buf, n_local, min_log_q, log_l_threshold)
             self._weights_and_max(buf, n_local)
             if sharded:
                 torch.distributed.all_reduce(buf["max_key"], op=torch.distributed.ReduceOp.MAX)
@@ -787,6 +905,7 @@ class FlowProposal:
             self._launch_draw(n_local, z_in, self._draw_counter, threshold, buf["x64"], buf["log_q"], None,
                               log_prior=buf["log_p"] if self._prior_kind_dev is not None else None,
                               prepared=prepared)
+            self._truncate_after_flow(buf, n_local, *self._post_limits)
             self._weights_and_max(buf, n_local, reset_max=fresh)
             n_proposed += n_local
             self._draw_counter += n_local
@@ -864,14 +983,55 @@ class FlowProposal:
     def reset_model_weights(self, **kwargs):
         self.flow.reset_model(**kwargs)
 
+    # -- checkpoint / resume (base.py:1237-1309, proposal/base.py:64-80) -------------------
+
+    def update_output(self, output):
+        """Move the proposal (and the weights files it writes from now on) to another directory."""
+        self.output = output
+        os.makedirs(self.output, exist_ok=True)
+        if self.flow is not None:
+            self.flow.output = output
+
+    def resume(self, model, flow_config, weights_file=None):
+        """Bring an unpickled proposal back to life (``base.py:1237-1271``): the model and the flow
+        configuration are not pickled and must be given again; the reparameterisations keep their
+        fitted constants; the flow is rebuilt and its last weights are loaded (``weights_file``, or
+        the file the proposal last saved).  The pool is not kept: the sampler repopulates."""
+        self.model = model
+        self.flow_config = dict(flow_config or {})
+        self.initialise(resumed=True)
+        if weights_file is None:
+            weights_file = self.weights_file
+        if weights_file is not None and os.path.exists(weights_file):
+            self.flow.reload_weights(weights_file)
+        else:
+            logger.warning("Could not reload weights for flow")
+
+    def reset(self):
+        """(``base.py:1273-1284``)"""
+        self.indices = []
+        self.samples = None
+        self.x = None
+        self.populated = False
+        self.populated_count = 0
+        self.population_acceptance = None
+        self._poolsize_scale = 1.0
+        self._checked_population = True
+        self.acceptance = []
+        self.truncation.reset()
+
     def __getstate__(self):
         state = self.__dict__.copy()
         state["initialised"] = False
         state["_buffers"] = None
         for k in ("_scale_dev", "_shift_dev", "_lower_dev", "_upper_dev", "_rp_kind_dev", "_rp_par_dev",
-                  "_prior_kind_dev", "_prior_par_dev", "_ll_spec"):
+                  "_prior_kind_dev", "_prior_par_dev", "_ll_spec", "device"):
             state.pop(k, None)
         state["weights_file"] = getattr(self.flow, "weights_file", None) if self.flow else None
+        state["resume_populated"] = bool(state.get("populated") and state.get("indices"))
+        # the user provides the model and the flow configuration again on resume
+        state["model"] = None
+        state["flow_config"] = None
         state["flow"] = None
         return state
 

@@ -190,6 +190,11 @@ class Trainer:
             self.adam_m.zero_()
             self.adam_v.zero_()
 
+    def flat_range(self):
+        """``range`` of byte addresses covered by the flat buffer (is a tensor a view of it?)."""
+        base = self.flat.data_ptr()
+        return range(base, base + self.flat.numel() * self.flat.element_size())
+
     def _permutation_versions(self):
         return tuple(b._version for name, b in self.flow.named_buffers() if name.endswith("_permutation"))
 

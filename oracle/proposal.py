@@ -170,11 +170,20 @@ class OracleFlowModel:
             log_prob.numpy().astype(np.float64),
         )
 
+    #: rows per call of ``model.inverse`` (None = the whole array at once, as the reference does);
+    #: chunking only bounds the size of the eager temporaries, the rows are independent
+    chunk_rows = None
+
     def inverse(self, z):  # base.py:813-840
         z = self.numpy_array_to_tensor(z)
         self.model.eval()
         with torch.inference_mode():
-            x, log_j = self.model.inverse(z)
+            if self.chunk_rows and len(z) > self.chunk_rows:
+                parts = [self.model.inverse(c) for c in torch.split(z, int(self.chunk_rows))]
+                x = torch.cat([p[0] for p in parts])
+                log_j = torch.cat([p[1] for p in parts])
+            else:
+                x, log_j = self.model.inverse(z)
         return x.numpy().astype(np.float64), log_j.numpy().astype(np.float64)
 
     def log_prob(self, x):  # base.py:842-864
@@ -291,7 +300,9 @@ class OracleFlowProposal:
     """
 
     def __init__(self, model, flow, rng=None, poolsize=2000, drawsize=None,
-                 volume_fraction=0.95, accumulate_weights=False):
+                 volume_fraction=0.95, accumulate_weights=False, radius_mode="constant_volume",
+                 fixed_radius=False, expansion_fraction=4.0, min_radius=False, max_radius=50.0,
+                 truncate_log_q=False, enforce_likelihood_threshold=False):
         self.model = model
         self.flow = flow
         self.rng = rng if rng is not None else np.random.default_rng()
@@ -302,8 +313,18 @@ class OracleFlowProposal:
         self.prime_names = [n + "_prime" for n in self.names]
         self.scale = {n: 1.0 for n in self.names}
         self.shift = {n: 0.0 for n in self.names}
-        self.fixed_radius = compute_radius(len(self.names), volume_fraction)
-        self.fuzz = 1.0  # truncation.py:305-308
+        # LatentRadiusTruncation.configure (truncation.py:292-308): outside constant-volume mode the
+        # ball is inflated by fuzz = (1 + expansion_fraction) ** (1 / dims)
+        self.radius_mode = radius_mode
+        self.min_radius, self.max_radius = min_radius, max_radius
+        self.fuzz = (1 + expansion_fraction) ** (1 / len(self.names)) if expansion_fraction else 1.0
+        self.fixed_radius = fixed_radius
+        if radius_mode == "constant_volume":
+            self.fixed_radius = compute_radius(len(self.names), volume_fraction)
+            self.fuzz = 1.0  # truncation.py:305-308
+        self.truncate_log_q = truncate_log_q                      # MinLogQTruncation, truncation.py:368-392
+        self.enforce_likelihood_threshold = enforce_likelihood_threshold  # :398-430
+        self.training_data = None
         self.population_time = datetime.timedelta()
         self.population_acceptance = None
         self.x = None
@@ -363,7 +384,21 @@ class OracleFlowProposal:
 
     # -- flow passes ----------------------------------------------------------
 
+    def compute_population_radius(self, worst_point, r=None):  # truncation.py:323-356
+        if r is not None:
+            return float(r)
+        if self.radius_mode != "adaptive":
+            return float(self.fixed_radius)
+        worst_z = self.forward_pass(worst_point)[0]
+        radius = float(np.sqrt(np.sum(worst_z**2.0, axis=-1)).max())
+        if self.max_radius and radius > self.max_radius:
+            radius = self.max_radius
+        if self.min_radius and radius < self.min_radius:
+            radius = self.min_radius
+        return float(radius)
+
     def train(self, live_points, **kwargs):  # base.py:870-925
+        self.training_data = live_points.copy()
         self.update_rescaling(live_points)
         x_prime, _ = self.rescale(live_points)
         arr = np.stack([x_prime[pp] for pp in self.prime_names], axis=-1)
@@ -415,13 +450,22 @@ class OracleFlowProposal:
     def compute_weights(self, x, log_q):  # base.py:1069-1098
         return self.model.log_prior(x) - log_q
 
-    def populate(self, n_samples=None, r=None, max_samples=1_000_000):
-        """flowproposal.py:391-534 (both ``accumulate_weights`` modes)."""
+    def populate(self, n_samples=None, r=None, max_samples=1_000_000, worst_point=None):
+        """flowproposal.py:391-534 (both ``accumulate_weights`` modes, the three truncation rules)."""
         st = datetime.datetime.now()
         if n_samples is None:
             n_samples = self.poolsize
-        radius = float(r) if r is not None else float(self.fixed_radius)
+        radius = self.compute_population_radius(worst_point, r)
+        self.r = radius
         threshold = self.fuzz * radius
+        min_log_q = None
+        if self.truncate_log_q:  # MinLogQTruncation.prepare
+            min_log_q = float(self.forward_pass(self.training_data)[1].min())
+        log_l_threshold = None
+        if self.enforce_likelihood_threshold:  # LikelihoodThresholdTruncation.prepare
+            log_l_threshold = float(np.asarray(worst_point["logL"], dtype=float).reshape(-1)[0])
+            if not np.isfinite(log_l_threshold):
+                log_l_threshold = -np.inf
         self.indices = []
         if self.accumulate_weights:
             samples = empty_structured_array(0, self.names)
@@ -446,10 +490,21 @@ class OracleFlowProposal:
                     break
                 continue
             x, log_q, z = self.backward_pass(z)
+            if min_log_q is not None and len(x):  # apply_after_backward
+                keep = log_q > min_log_q
+                x, log_q, z = x[keep], log_q[keep], z[keep]
             if not len(x):
                 if n_proposed > max_samples:
                     break
                 continue
+            if log_l_threshold is not None:  # apply_after_likelihood (flowproposal.py:455-466)
+                x["logL"] = self.model.log_likelihood(x)
+                keep = x["logL"] > log_l_threshold
+                x, log_q, z = x[keep], log_q[keep], z[keep]
+                if not len(x):
+                    if n_proposed > max_samples:
+                        break
+                    continue
             log_w = self.compute_weights(x, log_q)
             if self.accumulate_weights:
                 samples = np.concatenate([samples, x])

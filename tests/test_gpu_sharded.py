@@ -73,3 +73,52 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
     counts = [(tmp_path / f"c{r}.txt").read_text().split() for r in range(2)]
     assert counts[0] == counts[1] == [str(single.n_accepted), str(single.n_proposed)]
     assert np.array_equal(xs[0], expected)
+
+
+def _train_worker(rank, world, port, out_dir):
+    """Both ranks fit the same live points (the fused trainer is not bit-reproducible), then
+    populate sharded: the flow, the pool and the host generator must agree afterwards."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    sys.path.insert(0, ROOT)
+    from nessai_amd.model import GaussianModel
+    from nessai_amd.proposal import FlowProposal
+
+    torch.manual_seed(11)
+    model = GaussianModel(6)
+    prop = FlowProposal(
+        model, rng=np.random.default_rng(5),
+        flow_config=dict(ftype="nsf", n_neurons=16, n_blocks=2, n_layers=1, num_bins=4),
+        training_config=dict(max_epochs=40, patience=40, batch_size=250),
+        poolsize=200, drawsize=20_000, device_seed=9, shard=True,
+        output=os.path.join(out_dir, "run"),
+    )
+    prop.initialise()
+    live = model.new_point(500, rng=np.random.default_rng(1))
+    if rank == 1:  # desynchronise the replicas on purpose: rank 1 starts from other weights
+        with torch.no_grad():
+            for p_ in prop.flow.model.parameters():
+                p_.add_(0.01 * torch.randn_like(p_))
+    prop.train(live)
+    flat = prop.flow.model.trainer().flat.detach().cpu().numpy()
+    prop.populate(live[0], n_samples=200, max_samples=10**8)
+    x = np.stack([prop.x[n] for n in prop.names], axis=1)
+    np.savez(os.path.join(out_dir, f"t{rank}.npz"), flat=flat, x=x, indices=np.asarray(prop.indices),
+             rng=prop.rng.random(4), weights_file=prop.flow.weights_file)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_train_leaves_one_flow_on_every_rank(tmp_path):
+    mp.spawn(_train_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(tmp_path / f"t{r}.npz") for r in range(2))
+    assert np.array_equal(a["flat"], b["flat"])          # rank 0's weights everywhere
+    assert np.array_equal(a["x"], b["x"]) and len(a["x"]) == 200
+    assert np.array_equal(a["indices"], b["indices"])    # the replicated samplers stay in lock step
+    assert np.array_equal(a["rng"], b["rng"])
+    assert str(a["weights_file"]) != str(b["weights_file"])  # one weights file per rank
+    for r, d in enumerate((a, b)):
+        state = torch.load(str(d["weights_file"]), map_location="cpu", weights_only=True)
+        assert all(torch.isfinite(v).all() for v in state.values() if v.is_floating_point()), r

@@ -1,0 +1,178 @@
+"""FlowProposal on the device: the truncation rules beyond the constant-volume radius
+(``proposal/flowproposal/truncation.py:201-430``: fuzz, adaptive radius, min-log-q, likelihood
+threshold) against the oracle, and checkpoint -> resume (``proposal/flowproposal/base.py:1237-1309``)."""
+import math
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from nessai_amd.livepoint import numpy_array_to_live_points
+from nessai_amd.model import GaussianModel, RosenbrockModel
+from nessai_amd.proposal import FlowProposal
+from oracle import proposal as OP
+from test_gpu_populate import build
+
+pytestmark = pytest.mark.gpu
+
+
+def alive_rows(prop, z, threshold, min_log_q=-math.inf, log_l_threshold=None):
+    """log_q (NaN = dropped) of one pass over injected latents, rules applied on the device."""
+    n = len(z)
+    buf = prop._get_buffers(n, 10)
+    z_dev = torch.from_numpy(z).to(torch.float32).to(prop.device)
+    prop._launch_draw(n, z_dev, 0, threshold, buf["x64"], buf["log_q"], None)
+    prop._truncate_after_flow(buf, n, min_log_q, log_l_threshold)
+    torch.cuda.synchronize()
+    return buf["log_q"][:n].cpu().numpy(), buf["x64"][:n].cpu().numpy()
+
+
+def oracle_alive(oprop, z, threshold, min_log_q=None, log_l_threshold=None):
+    zt = oprop.apply_latent(z, threshold)
+    x, log_q, zk = oprop.backward_pass(zt)
+    if min_log_q is not None:
+        keep = log_q > min_log_q
+        x, log_q, zk = x[keep], log_q[keep], zk[keep]
+    if log_l_threshold is not None:
+        keep = oprop.model.log_likelihood(x) > log_l_threshold
+        x, log_q, zk = x[keep], log_q[keep], zk[keep]
+    lookup = {row.tobytes(): i for i, row in enumerate(z)}
+    return np.array([lookup[row.tobytes()] for row in zk], dtype=np.int64), log_q
+
+
+def test_fuzz_inflates_the_radius_outside_constant_volume_mode():
+    """`fixed` / `adaptive`: threshold = (1 + expansion_fraction)^(1/D) r; constant volume: r."""
+    prop, oprop = build(4, "nsf", dict(n_neurons=8, n_blocks=2), poolsize=20, drawsize=2000, radius_mode="adaptive")
+    oref = OP.OracleFlowProposal(oprop.model, oprop.flow, radius_mode="adaptive")
+    oref.shift, oref.scale = oprop.shift, oprop.scale
+    worst = numpy_array_to_live_points(np.array([[0.4, -0.3, 0.2, 0.1]]), prop.names)
+    oworst = OP.empty_structured_array(1, oprop.names)
+    for i, n in enumerate(oprop.names):
+        oworst[n] = [0.4, -0.3, 0.2, 0.1][i]
+    assert prop.fuzz == oref.fuzz == 5.0 ** 0.25
+    prop.truncation.prepare(prop, worst)
+    threshold, min_log_q, log_l = prop.truncation.device_limits()
+    r_o = oref.compute_population_radius(oworst)
+    assert abs(threshold - oref.fuzz * r_o) < 1e-4 and min_log_q == -math.inf and log_l is None
+    # the kernel's radius cut uses the inflated threshold
+    z = np.random.default_rng(2).normal(size=(4000, 4)).astype(np.float32).astype(np.float64)
+    log_q, _ = alive_rows(prop, z, threshold)
+    idx, lq_o = oracle_alive(oref, z, oref.fuzz * r_o)
+    got = np.nonzero(~np.isnan(log_q))[0]
+    assert abs(len(got) - len(idx)) <= 2 and len(np.setxor1d(got, idx)) <= 2  # f32 norm at the edge
+    for kw, fuzz in ((dict(radius_mode="fixed", fixed_radius=2.0), 5.0 ** 0.25), (dict(), 1.0),
+                     (dict(radius_mode="fixed", fixed_radius=2.0, expansion_fraction=0.0), 1.0)):
+        p2, _ = build(4, "nsf", dict(n_neurons=8, n_blocks=2), poolsize=20, drawsize=2000, **kw)
+        assert p2.fuzz == fuzz
+
+
+def test_min_log_q_and_likelihood_threshold_on_the_device():
+    prop, oprop = build(6, "nsf", dict(n_neurons=16, n_blocks=3), model_cls=GaussianModel, poolsize=100,
+                        drawsize=4000, truncate_log_q=True, enforce_likelihood_threshold=True)
+    assert prop.truncation.rule_names == ["latent_radius", "min_log_q", "likelihood_threshold"]
+    z = np.random.default_rng(5).normal(size=(5000, 6)).astype(np.float32).astype(np.float64)
+    radius = OP.compute_radius(6, 0.95)
+    base_log_q, x_all = alive_rows(prop, z, radius)
+    fin = base_log_q[np.isfinite(base_log_q)]
+    min_log_q = float(np.quantile(fin, 0.3))
+    pts = numpy_array_to_live_points(x_all[np.isfinite(base_log_q)], prop.names)
+    log_l_thr = float(np.quantile(prop.model.log_likelihood(pts), 0.4))
+    for mq, lt in ((min_log_q, None), (-math.inf, log_l_thr), (min_log_q, log_l_thr)):
+        log_q, _ = alive_rows(prop, z, radius, mq, lt)
+        idx, lq_o = oracle_alive(oprop, z, radius, None if mq == -math.inf else mq, lt)
+        got = np.nonzero(~np.isnan(log_q))[0]
+        # rows within float32 round-off of a threshold may fall on either side
+        assert len(np.setxor1d(got, idx)) <= 3
+        common = np.intersect1d(got, idx)
+        assert len(common) > 500
+        lookup = {int(i): k for k, i in enumerate(idx)}
+        np.testing.assert_allclose(log_q[common], lq_o[[lookup[int(i)] for i in common]], rtol=1e-5, atol=1e-4)
+    # host-likelihood path gives the same mask as the device likelihood
+    prop._ll_spec, keep = None, prop._ll_spec
+    log_q_host, _ = alive_rows(prop, z, radius, -math.inf, log_l_thr)
+    prop._ll_spec = keep
+    log_q_dev, _ = alive_rows(prop, z, radius, -math.inf, log_l_thr)
+    assert np.array_equal(np.isnan(log_q_host), np.isnan(log_q_dev))
+
+
+def test_populate_with_all_three_rules():
+    """End to end on the device generator: every accepted point clears both thresholds."""
+    prop, _ = build(6, "nsf", dict(n_neurons=16, n_blocks=3), model_cls=GaussianModel, poolsize=200,
+                    drawsize=20000, truncate_log_q=True, enforce_likelihood_threshold=True)
+    live = prop.model.new_point(300, rng=np.random.default_rng(4))
+    for n in prop.names:
+        live[n] *= 0.1
+    live["logL"] = prop.model.log_likelihood(live)
+    prop.training_data = live
+    worst = live[np.argmin(live["logL"])]
+    prop.populate(worst, n_samples=200, max_samples=10**8)
+    assert prop.samples.size == 200
+    _, min_log_q, log_l_thr = prop.truncation.device_limits()
+    assert np.isfinite(min_log_q) and log_l_thr == float(worst["logL"])
+    assert (prop.samples["logL"] > log_l_thr).all()
+    _, log_q = prop.forward_pass(prop.samples)
+    assert (log_q > min_log_q - 1e-3).all()
+    # without the rules the same draws accept points below the likelihood threshold
+    free, _ = build(6, "nsf", dict(n_neurons=16, n_blocks=3), model_cls=GaussianModel, poolsize=200, drawsize=20000)
+    free.populate(worst, n_samples=200, max_samples=10**8)
+    assert (free.samples["logL"] <= log_l_thr).any()
+
+
+def test_unknown_arguments_and_rule_access():
+    with pytest.raises(TypeError):
+        FlowProposal(RosenbrockModel(4), poolsize=10, not_an_argument=1)
+    with pytest.raises(ValueError):
+        FlowProposal(RosenbrockModel(4), poolsize=10, radius_mode="fixed")
+    prop = FlowProposal(RosenbrockModel(4), poolsize=10, truncation_method="min_log_q")
+    assert prop.truncation.rule_names == ["min_log_q"] and prop.radius_mode is None and prop.fuzz == 1.0
+
+
+def test_pickle_resume_populate_round_trip(tmp_path):
+    """Checkpoint between two populations: the resumed proposal keeps the fitted rescaling, reloads
+    the weights it last saved and continues the device generator where it stopped - its next pool
+    equals the pool the original would have drawn."""
+    torch.manual_seed(2)
+    model = GaussianModel(5)
+    cfg = dict(ftype="nsf", n_neurons=16, n_blocks=2, n_layers=1, num_bins=4)
+    prop = FlowProposal(model, rng=np.random.default_rng(6), flow_config=cfg, poolsize=150, drawsize=20000,
+                        device_seed=3, output=str(tmp_path / "run"), radius_mode="adaptive",
+                        training_config=dict(max_epochs=15, patience=15, batch_size=200))
+    prop.initialise()
+    live = model.new_point(400, rng=np.random.default_rng(1))
+    for n in prop.names:
+        live[n] *= 0.2
+    live["logL"] = model.log_likelihood(live)
+    prop.train(live)
+    worst = live[np.argmin(live["logL"])]
+    prop.populate(worst, n_samples=150, max_samples=10**8)
+    blob = pickle.dumps(prop)
+
+    prop.populate(worst, n_samples=150, max_samples=10**8)  # what the original draws next
+    expected = np.stack([prop.x[n] for n in prop.names], axis=1)
+
+    resumed = pickle.loads(blob)
+    assert resumed.flow is None and resumed.model is None and not resumed.initialised
+    assert resumed.resume_populated and resumed.weights_file == prop.flow.weights_file
+    with pytest.raises(Exception):
+        resumed.populate(worst, n_samples=10)
+    resumed.resume(model, cfg)
+    assert resumed.initialised and not resumed.populated and resumed.training_count == 1
+    assert resumed.scale == prop.scale and resumed.shift == prop.shift  # fitted constants survive
+    assert resumed.radius_mode == "adaptive" and resumed.fuzz == prop.fuzz
+    a, b = prop.flow.model.state_dict(), resumed.flow.model.state_dict()
+    assert all(torch.equal(a[k].cpu(), b[k].cpu()) for k in a)
+    resumed.populate(worst, n_samples=150, max_samples=10**8)
+    got = np.stack([resumed.x[n] for n in resumed.names], axis=1)
+    assert np.array_equal(got, expected) and resumed.r == prop.r
+    # update_output: the next weights file goes to the new directory
+    resumed.update_output(str(tmp_path / "moved"))
+    resumed.train(live)
+    assert resumed.flow.weights_file.startswith(str(tmp_path / "moved"))
+    # explicit weights file, and a missing one
+    again = pickle.loads(blob)
+    again.resume(model, cfg, weights_file=prop.flow.weights_file)
+    assert again.flow.weights_file == prop.flow.weights_file
+    lost = pickle.loads(blob)
+    lost.resume(model, cfg, weights_file=str(tmp_path / "nope.pt"))  # warns, keeps the fresh flow
+    assert lost.initialised
