@@ -187,14 +187,58 @@ def _oracle_proposal(drawsize, chunk_rows=None):
     return prop
 
 
+ALL_CORES_SAMPLE = 250_000
+ALL_CORES_THREADS = 32   # eager torch on ~100 us operators stops scaling long before a 256-thread host is full
+ALL_CORES_TIMEOUT = 120  # seconds
+
+
+def cpu_all_cores_leg():
+    """Leg (ii) of SURVEY.md section 8d: the same oracle pass with many torch threads.  Run in a
+    child process under a timeout: intra-op threading of the eager restatement is slower, not
+    faster, on hosts with hundreds of cores (1e6 draws took 1060 s on 256 threads of the GPU box
+    against 53 s on one), and a baseline leg must not decide how long the benchmark runs."""
+    import subprocess
+
+    cores = min(os.cpu_count() or 1, ALL_CORES_THREADS)
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", str(cores)], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=ALL_CORES_TIMEOUT)
+        return json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except subprocess.TimeoutExpired:
+        return {"value": None, "cores": cores, "kind": "port", "host_cpus": os.cpu_count(),
+                "sample": f"one populate pass of {ALL_CORES_SAMPLE} draws did not finish in {ALL_CORES_TIMEOUT} s "
+                          f"on {cores} torch threads (slower than the single-thread leg)"}
+    except Exception as exc:
+        return {"value": None, "cores": cores, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"}
+
+
+def cpu_leg_child(cores):
+    """``--cpu-leg N``: one bounded oracle pass on N torch threads, one JSON line (child of the above)."""
+    torch.set_num_threads(cores)
+    prop = _oracle_proposal(ALL_CORES_SAMPLE, chunk_rows=50_000)
+    torch.manual_seed(1451)
+    t = time.perf_counter()
+    prop.populate(n_samples=NLIVE, max_samples=ALL_CORES_SAMPLE - 1)
+    dt = time.perf_counter() - t
+    print(json.dumps({
+        "value": prop.n_accepted / dt, "unit": "accepted points/s", "cores": cores, "kind": "port",
+        "host_cpus": os.cpu_count(),
+        "sample": f"one populate pass of {ALL_CORES_SAMPLE} draws (flow inverse in chunks of 50000 rows), "
+                  f"{prop.n_accepted} accepted in {dt:.1f} s",
+        "proposed_rows_per_s": prop.n_proposed / dt, "acceptance": prop.population_acceptance,
+    }))
+
+
 def cpu_baseline():
     """The oracle (CPU restatement of the reference path) timed on this host.
 
     Leg (i), the reported baseline: ONE torch thread - the reference's default
     (src/nessai/flowsampler.py:98) - on a bounded sample of the workload, one populate pass of
-    2.5e5 draws.  Leg (ii) (SURVEY.md section 8d ii): every host core
-    (``torch.set_num_threads(os.cpu_count())``, the count is printed) on one FULL 1e6-row pass,
-    the flow inverse chunked at 1e5 rows to bound the eager temporaries."""
+    2.5e5 draws.  Leg (ii) (SURVEY.md section 8d ii): the same pass on many threads
+    (``cpu_all_cores_leg``; the count used is printed)."""
     threads = torch.get_num_threads()
     try:
         torch.set_num_threads(1)
@@ -215,23 +259,7 @@ def cpu_baseline():
             "acceptance": prop.population_acceptance,
             "host_cpus": os.cpu_count(),
         }
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
-        prop = _oracle_proposal(DRAWSIZE, chunk_rows=100_000)
-        torch.manual_seed(1451)
-        t = time.perf_counter()
-        prop.populate(n_samples=NLIVE, max_samples=DRAWSIZE - 1)  # exactly one full-size pass
-        dt = time.perf_counter() - t
-        out["all_cores"] = {
-            "value": prop.n_accepted / dt,
-            "unit": "accepted points/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": f"one full populate pass of {DRAWSIZE} draws (flow inverse in chunks of 100000 rows), "
-                      f"{prop.n_accepted} accepted in {dt:.1f} s",
-            "proposed_rows_per_s": prop.n_proposed / dt,
-            "acceptance": prop.population_acceptance,
-        }
+        out["all_cores"] = cpu_all_cores_leg()
         return out
     finally:
         torch.set_num_threads(threads)
@@ -245,11 +273,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: 'strong' shards the 1e6-row draw batch of BASELINE config 3 over the ranks "
                          "(1e6 / N rows each, same acceptance as at N = 1); 'weak' gives every rank 1e6 rows "
                          "(an N x 1e6 batch: more rows per pass but a lower acceptance per row)")
     args = ap.parse_args()
+    if args.cpu_leg:
+        cpu_leg_child(args.cpu_leg)
+        return
 
     # stdout carries exactly ONE JSON line: libraries that write to the C-level stdout (RCCL prints a
     # version banner there, flushed at exit) are sent to stderr for the whole run

@@ -194,6 +194,30 @@ NSA_API int nsa_populate_pass_tail(long long n, int D, const double* log_w_dev, 
 NSA_API int nsa_populate_pass_commit(long long* state_dev, long long capacity,
                              const long long* global_count_dev, long long* history_dev, void* stream);
 
+/* Importance nested sampler (config 4), ImportanceFlowProposal.draw
+ * (src/nessai/proposal/importance.py:443-487), first half: draw rows [row_offset, row_offset + n)
+ * from ONE flow and map them to the unit hypercube.  Same fused kernel as nsa_populate_draw
+ * (Philox latents indexed by the global row, or z_in_dev), with the importance epilogue:
+ *   x64_out_dev [n][D]  x = 1 / (1 + exp(-x'))        (inverse_rescale, utils/rescaling.py:316-336)
+ *   xp_out_dev  [n][D]  x' in float32, logical column order: the point every stored flow is then
+ *                       evaluated at (nsa_flow_run_many), as flowmodel/importance.py:114-129 does
+ *   log_j_out_dev [n]   log|J| of the logit map at x clipped to [unit_eps, 1 - unit_eps]
+ *                       (rescale, utils/rescaling.py:290-313; eps = 1e-8, config.py:159);
+ *                       NaN marks a row that fails the reference's checks (non-finite x', log|J|
+ *                       or log|J_inv|, x outside [0, 1]: importance.py:476-483) */
+NSA_API int nsa_importance_draw(const uint32_t* header, const void* image_dev, long long n,
+                                const float* z_in_dev, unsigned long long seed, unsigned long long row_offset,
+                                double unit_eps, double* x64_out_dev, float* xp_out_dev, double* log_j_out_dev,
+                                int* status_dev, int waves_per_group, int max_groups, void* stream);
+
+/* ... second half, compute_log_Q (importance.py:415-441): log_q_all[r][0] = 0 (the prior),
+ * log_q_all[r][1 + j] = log_prob_all[j][r] + log_j[r], log_Q[r] = logsumexp(log_q_all[r], b = weights)
+ * in float64 (scipy.special.logsumexp's arithmetic).  log_prob_all_dev is the (n_flows, n) float32
+ * output of nsa_flow_run_many; weights_dev has n_flows + 1 entries (prior first). */
+NSA_API int nsa_importance_mix(long long n, int n_flows, const float* log_prob_all_dev, const double* log_j_dev,
+                               const double* weights_dev, double* log_q_all_dev, double* log_Q_dev,
+                               void* stream);
+
 /* log_w = log_prior - log_q and its maximum.
  *
  * Replaces BaseFlowProposal.compute_weights (proposal/flowproposal/base.py:1069-1098)

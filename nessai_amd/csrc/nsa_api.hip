@@ -308,6 +308,48 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
   return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
 }
 
+extern "C" int nsa_importance_draw(const uint32_t* header, const void* image_dev, long long n,
+                                   const float* z_in_dev, unsigned long long seed, unsigned long long row_offset,
+                                   double unit_eps, double* x64_out_dev, float* xp_out_dev, double* log_j_out_dev,
+                                   int* status_dev, int waves_per_group, int max_groups, void* stream) {
+  if (header == nullptr || image_dev == nullptr || x64_out_dev == nullptr || xp_out_dev == nullptr ||
+      log_j_out_dev == nullptr || status_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_importance_draw: NULL pointer argument");
+  if (!(unit_eps >= 0.0 && unit_eps < 0.5)) return nsa_fail(NSA_E_ARG, "nsa_importance_draw: eps must be in [0, 0.5)");
+  NsaLaunch p;
+  memset(&p, 0, sizeof(p));
+  p.image = (const uint32_t*)image_dev;
+  p.direction = NSA_DIR_INVERSE;
+  p.mode = NSA_MODE_POPULATE;
+  p.n = n;
+  p.x_in = z_in_dev;
+  p.status = status_dev;
+  p.seed = seed;
+  p.row_offset = row_offset;
+  p.radius = INFINITY;
+  p.latent_scale = 1.0;
+  p.x64_out = x64_out_dev;
+  p.log_q_out = log_j_out_dev;
+  p.xp_out = xp_out_dev;
+  p.unit_eps = unit_eps;
+  return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
+}
+
+extern "C" hipError_t nsa_launch_importance_mix(long long, int, const float*, const double*, const double*,
+                                                double*, double*, hipStream_t);
+
+extern "C" int nsa_importance_mix(long long n, int n_flows, const float* log_prob_all_dev, const double* log_j_dev,
+                                  const double* weights_dev, double* log_q_all_dev, double* log_Q_dev,
+                                  void* stream) {
+  if (n < 0 || n_flows < 0 || log_j_dev == nullptr || weights_dev == nullptr || log_q_all_dev == nullptr ||
+      log_Q_dev == nullptr || (n_flows > 0 && log_prob_all_dev == nullptr))
+    return nsa_fail(NSA_E_ARG, "nsa_importance_mix: bad argument");
+  hipError_t e = nsa_launch_importance_mix(n, n_flows, log_prob_all_dev, log_j_dev, weights_dev, log_q_all_dev,
+                                           log_Q_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "importance mix kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
 extern "C" hipError_t nsa_launch_weights(long long, const double*, const double*, double, double*,
                                          long long*, hipStream_t, const long long*);
 extern "C" hipError_t nsa_launch_pass_commit(long long*, long long, const long long*, long long*, hipStream_t);

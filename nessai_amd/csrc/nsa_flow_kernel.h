@@ -87,6 +87,13 @@ struct NsaLaunch {
   // waves per SIMD the kernel variant is compiled for (2: <= 256 VGPRs, 3: <= 168 VGPRs); set by
   // the host from the launch geometry (nsa_api.hip)
   int occupancy;
+  // importance sampler draw (POPULATE with xp_out != null; ImportanceFlowProposal.draw,
+  // src/nessai/proposal/importance.py:443-487): x64_out = sigmoid(x') (the unit hypercube),
+  // xp_out = x' (float32, the point the OTHER flows are evaluated at), log_q_out = log|J| of the
+  // logit map at x clipped to [unit_eps, 1 - unit_eps] (utils/rescaling.py:290-313), NaN for rows
+  // that fail the reference's finiteness / unit-hypercube checks
+  float* xp_out;
+  double unit_eps;
 };
 
 // x' -> x maps of the populate epilogue (inverse_reparameterise of the reference):
@@ -622,8 +629,8 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
     for (int i = (int)threadIdx.x; i < D; i += (int)blockDim.x) {
       epi[i] = p.scale != nullptr ? p.scale[i] : 1.0;
       epi[D4e + i] = p.shift != nullptr ? p.shift[i] : 0.0;
-      epi[2 * D4e + i] = p.lower[i];
-      epi[3 * D4e + i] = p.upper[i];
+      epi[2 * D4e + i] = p.lower != nullptr ? p.lower[i] : 0.0;
+      epi[3 * D4e + i] = p.upper != nullptr ? p.upper[i] : 1.0;
       epi_tab[i] = otab[i];
     }
     __syncthreads();
@@ -762,7 +769,36 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
     const long long row0 = (g_epi * nw + wave) * NSA_ROWS;
     const long long my_row = row0 + j;
     const bool row_ok = my_row < p.n;
-    if (p.mode == NSA_MODE_POPULATE) {
+    if (p.mode == NSA_MODE_POPULATE && p.xp_out != nullptr) {
+#pragma clang fp contract(off)
+      // importance-sampler draw: x = 1 / (1 + exp(-x')), log|J_inv| = sum log x + log1p(-x)
+      // (utils/rescaling.py:316-336), log|J| = sum -log xc - log1p(-xc) on the clipped x
+      const int* epi_tab = (const int*)(epi + 4 * D4e);
+      double lj_inv = 0.0, lj = 0.0;
+      int good = 1;
+      double* xo = p.x64_out + my_row * D;
+      float* xpo = p.xp_out + my_row * D;
+      const double eps = p.unit_eps;
+      for (int i = half; i < D; i += 2) {
+        const float xpf = xrow[epi_tab[i]];
+        const double xp = (double)xpf;
+        const double u = 1.0 / (1.0 + exp(-xp));
+        lj_inv += log(u) + log1p(-u);
+        const double uc = fmin(fmax(u, eps), 1.0 - eps);
+        lj += -log(uc) - log1p(-uc);
+        good &= (int)((xp - xp) == 0.0) & (int)!(u < 0.0) & (int)!(u > 1.0);
+        if (row_ok) {
+          xo[i] = u;
+          xpo[i] = xpf;
+        }
+      }
+      lj_inv += __shfl_xor(lj_inv, 32);
+      lj += __shfl_xor(lj, 32);
+      good &= __shfl_xor(good, 32);
+      const bool ok = good != 0 && (lj - lj) == 0.0 && (lj_inv - lj_inv) == 0.0 && n_bad == 0;
+      if (row_ok && half == 0) p.log_q_out[my_row] = ok ? lj : __longlong_as_double(0x7ff8000000000000LL);
+      if (row_ok && half == 0 && n_bad != 0) atomicAdd(p.status, 1);
+    } else if (p.mode == NSA_MODE_POPULATE) {
 #pragma clang fp contract(off)
       const NsaLaunch& e = p;
       // x = x' * sigma + mu in float64 (rescale.py:276-279), prior bounds

@@ -417,3 +417,46 @@ extern "C" hipError_t nsa_launch_truncate(long long n, double* log_q, double min
   nsa_truncate_kernel<<<grid, 256, 0, stream>>>(n, log_q, min_log_q, log_l, log_l_threshold);
   return hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------
+// Meta-proposal of the importance sampler (src/nessai/proposal/importance.py:415-441):
+//   log_q_all[r][0]     = 0                                   (the prior, proposal -1)
+//   log_q_all[r][1 + j] = log_prob_j(x'_r) + log|J|_r         (flow j in the unit hypercube)
+//   log_Q[r]            = logsumexp(log_q_all[r], b = weights)
+// in float64 as the reference's numpy / scipy glue: scipy's logsumexp subtracts the row maximum
+// (0 if it is not finite), sums b * exp(a - max) and adds the maximum back.  One thread per row;
+// 4 F bytes in (the (F, n) float32 log-probabilities, coalesced across rows), 8 (F + 2) bytes out.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nsa_importance_mix_kernel(long long n, int n_flows,
+                                                                 const float* __restrict__ log_prob_all,
+                                                                 const double* __restrict__ log_j,
+                                                                 const double* __restrict__ weights,
+                                                                 double* __restrict__ log_q_all,
+                                                                 double* __restrict__ log_Q) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int P = n_flows + 1;
+  const double lj = log_j[r];
+  double* row = log_q_all + r * P;
+  double a_max = 0.0;  // column 0
+  row[0] = 0.0;
+  for (int j = 0; j < n_flows; ++j) {
+    const double a = (double)log_prob_all[(long long)j * n + r] + lj;
+    row[1 + j] = a;
+    a_max = (a > a_max || a != a) ? a : a_max;  // numpy.amax propagates NaN
+  }
+  if (!((a_max - a_max) == 0.0)) a_max = 0.0;   // scipy: a_max[~isfinite(a_max)] = 0
+  double s = 0.0;
+  for (int k = 0; k < P; ++k) s += weights[k] * exp(row[k] - a_max);
+  log_Q[r] = log(s) + a_max;
+}
+
+extern "C" hipError_t nsa_launch_importance_mix(long long n, int n_flows, const float* log_prob_all,
+                                                const double* log_j, const double* weights, double* log_q_all,
+                                                double* log_Q, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  nsa_importance_mix_kernel<<<grid, 256, 0, stream>>>(n, n_flows, log_prob_all, log_j, weights, log_q_all, log_Q);
+  return hipGetLastError();
+}

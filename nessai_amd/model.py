@@ -197,6 +197,33 @@ class GaussianModel(UniformBoxModel):
         return -0.5 * np.sum(a**2, axis=-1) - 0.5 * self.dims * np.log(2 * np.pi)
 
 
+class CorrelatedGaussianModel(UniformBoxModel):
+    """Zero-mean Gaussian likelihood with the Toeplitz covariance ``Sigma_ij = rho ** |i - j|`` on
+    ``[-bound, bound]^n`` - the 64-D, rho = 0.5 workload of BASELINE config 4 (SURVEY.md section
+    8d).  The inverse of an AR(1) covariance is tridiagonal, so the quadratic form is
+    ``(sum x_i^2 + rho^2 sum_{interior} x_i^2 - 2 rho sum x_i x_{i+1}) / (1 - rho^2)`` and
+    ``log|Sigma| = (n - 1) log(1 - rho^2)``.  The importance sampler works in the unit hypercube
+    through the affine maps of ``Model.to_unit_hypercube`` / ``from_unit_hypercube``."""
+
+    def __init__(self, dims=64, rho=0.5, bound=10.0):
+        super().__init__(dims, -float(bound), float(bound))
+        if not -1.0 < rho < 1.0:
+            raise ValueError("rho must be in (-1, 1)")
+        self.rho = float(rho)
+        self._log_norm = -0.5 * (dims * np.log(2 * np.pi) + (dims - 1) * np.log1p(-self.rho**2))
+
+    def covariance(self):
+        idx = np.arange(self.dims)
+        return self.rho ** np.abs(idx[:, None] - idx[None, :])
+
+    def log_likelihood(self, x):
+        a = self.unstructured_view(x)
+        rho = self.rho
+        quad = np.sum(a**2, axis=-1) + rho**2 * np.sum(a[..., 1:-1] ** 2, axis=-1)
+        quad = quad - 2.0 * rho * np.sum(a[..., 1:] * a[..., :-1], axis=-1)
+        return -0.5 * quad / (1.0 - rho**2) + self._log_norm
+
+
 class SeparablePriorModel(Model):
     """Model whose prior is a product of the 1-D densities declared in ``device_prior``."""
 

@@ -4,19 +4,38 @@ Counterpart of the reference's ``nessai.proposal.importance.ImportanceFlowPropos
 (``src/nessai/proposal/importance.py:35``).  Samples live in the unit hypercube; the flows are
 trained in the logit space (``to_prime`` / ``from_prime``, ``importance.py:203-257``,
 ``utils/rescaling.py:290-336``); the meta-proposal is the weighted mixture
-``log Q = logsumexp(log q_i + log w_i)`` over the prior (proposal ``-1``, ``log q = 0``) and
-every flow added so far (``compute_log_Q``, ``importance.py:382-441``).  Flow evaluation and
-training run on the GPU through ``ImportanceFlowModel``; the glue is float64 numpy as in the
-reference.
+``log Q = logsumexp(log q_i + log w_i)`` over the prior (proposal ``-1``, ``log q = 0``) and every
+flow added so far (``compute_log_Q``, ``importance.py:382-441``).
+
+Where the reference loops over host arrays, one batch of ``draw`` here is three launches on
+device tensors and one copy of the rows that survive:
+
+1. ``nsa_importance_draw`` - the fused flow kernel with the importance epilogue: Philox latents
+   indexed by the global row -> inverse flow ``i`` -> ``x = sigmoid(x')`` in float64, the
+   flow-space point ``x'`` for step 2, ``log|J|`` of the logit map on the clipped ``x`` and the
+   reference's finiteness / unit-hypercube checks (``importance.py:470-483``) as a NaN mark;
+2. ``nsa_flow_run_many`` - ``log_prob`` of EVERY stored flow on those points in one grouped launch
+   (``flowmodel/importance.py:114-129`` is a Python loop over flows);
+3. ``nsa_importance_mix`` - ``log_q_all`` and ``log Q = logsumexp(log_q_all, b = weights)`` in
+   float64.
+
+The prior terms (``logP``, ``logU``) stay with the user's model on the host, on the surviving rows
+only.  With ``shard=True`` under ``torch.distributed`` the rows of every batch - and of
+``update_log_q`` / ``compute_log_Q``, whose cost grows with every level - are split over the ranks
+and all-gathered; the Philox streams are indexed by the global row, so the
+sharded run draws exactly the points of the single-rank run.
 """
 
 import logging
 import os
 
 import numpy as np
+import torch
 from scipy.special import logsumexp
 
+from . import lib
 from .flowmodel_importance import ImportanceFlowModel
+from .flows.base import log_prob_many
 from .livepoint import NON_SAMPLING_DEFAULTS, NON_SAMPLING_DTYPES, NON_SAMPLING_PARAMETERS, live_points_to_array
 
 logger = logging.getLogger(__name__)
@@ -63,7 +82,7 @@ def empty_ins_array(n, names):
 class ImportanceFlowProposal:
     def __init__(self, model, output, rng=None, flow_config=None, training_config=None,
                  reparameterisation="logit", weighted_kl=True, reset_flow=True, clip=False,
-                 plot_training=False):
+                 plot_training=False, device_seed=None, shard=False):
         self.level_count = -1
         self.initialised = False
         self.model = model
@@ -80,6 +99,9 @@ class ImportanceFlowProposal:
         self._weights = {-1: 1.0}
         self.dtype = ins_dtype(model.names)
         self.flow = None
+        self.shard = bool(shard)
+        self.device_seed = int(device_seed) if device_seed is not None else int(self.rng.integers(0, 2**63 - 1))
+        self._draw_counter = 0  # rows drawn so far: Philox row offset
 
     # -- meta-proposal weights -------------------------------------------------
 
@@ -94,6 +116,10 @@ class ImportanceFlowProposal:
     @property
     def n_proposals(self):
         return len(self._weights)
+
+    @property
+    def dims(self):
+        return len(self.model.names)
 
     @property
     def _reset_flow(self):
@@ -178,25 +204,155 @@ class ImportanceFlowProposal:
             weights = None
         self.flow.add_new_flow(reset=self._reset_flow)
         self.flow.train(x_prime, weights=weights, output=level_output, plot=False, **kwargs)
+        rank, world = self._rank_world()
+        if world > 1:
+            self._replicate_newest_flow()
+
+    # -- device plumbing --------------------------------------------------------------------
+
+    def _rank_world(self):
+        if not self.shard:
+            return 0, 1
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0, 1
+        return dist.get_rank(), dist.get_world_size()
+
+    def _replicate_newest_flow(self):
+        """Rank 0's fit becomes the newest flow of every rank (training does not shard and the
+        fused trainer is not bit-reproducible - see ``FlowProposal._replicate_flow``)."""
+        import torch.distributed as dist
+
+        model = self.flow.model
+        with torch.no_grad():
+            trainer = model.trainer()
+            dist.broadcast(trainer.flat, src=0)
+            for _, buf in model.named_buffers():
+                if buf.numel() and buf.data_ptr() not in trainer.flat_range():
+                    dist.broadcast(buf, src=0)
+        state = [self.rng.bit_generator.state]
+        dist.broadcast_object_list(state, src=0)
+        self.rng.bit_generator.state = state[0]
+        model._image_key = None
+
+    def _check_ready(self):
+        if any(np.isnan(w) for w in self.weights.values()):
+            raise RuntimeError("Some weights are not set!")
+        if any(flow.training for flow in self.flow.models):
+            raise RuntimeError("One or more flows are in training mode!")
+
+    def _stream(self):
+        return lib.c_void_p(torch.cuda.current_stream(self.flow.device).cuda_stream)
+
+    def _mix(self, log_prob_all, log_j):
+        """(log_q_all ``(n, P)``, log_Q ``(n,)``) float64 device tensors (``nsa_importance_mix``)."""
+        dev = self.flow.device
+        n = log_j.shape[0]
+        n_flows = self.flow.n_models
+        weights = torch.tensor(self.weights_array, dtype=torch.float64, device=dev)
+        if weights.numel() != n_flows + 1:
+            raise RuntimeError(f"{weights.numel()} proposal weights for {n_flows} flows and the prior")
+        log_q_all = torch.empty((n, n_flows + 1), dtype=torch.float64, device=dev)
+        log_Q = torch.empty(n, dtype=torch.float64, device=dev)
+        rc = lib.load().nsa_importance_mix(
+            n, n_flows, lib.ptr(log_prob_all) if n_flows else None, lib.ptr(log_j), lib.ptr(weights),
+            lib.ptr(log_q_all), lib.ptr(log_Q), self._stream(),
+        )
+        lib.check(rc, "nsa_importance_mix")
+        return log_q_all, log_Q
+
+    def _log_prob_rows(self, flows, xp):
+        """``(len(flows), n)`` float32 log-densities of the rows of ``xp`` (device, float32); with
+        ``shard`` every rank evaluates a slice of the rows and the slices are all-gathered."""
+        rank, world = self._rank_world()
+        n = xp.shape[0]
+        if world == 1 or n < world:
+            return log_prob_many(flows, xp)
+        import torch.distributed as dist
+
+        per = (n + world - 1) // world
+        lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+        mine = torch.zeros((len(flows), per), dtype=torch.float32, device=xp.device)
+        if hi > lo:
+            mine[:, : hi - lo] = log_prob_many(flows, xp[lo:hi].contiguous())
+        gathered = torch.empty((world * len(flows), per), dtype=torch.float32, device=xp.device)  # rank-major
+        dist.all_gather_into_tensor(gathered, mine)
+        gathered = gathered.reshape(world, len(flows), per)
+        return gathered.permute(1, 0, 2).reshape(len(flows), world * per)[:, :n].contiguous()
+
+    def _draw_batch(self, flow_number, n_rows, z_in=None):
+        """One batch of ``draw`` on the device.  Returns host arrays ``(x (m, D), log_q_all (m, P),
+        log_Q (m,))`` of the rows that pass the reference's first filter, in draw order."""
+        if self.reparameterisation != "logit":
+            raise NotImplementedError("the gfx950 draw epilogue implements the logit reparameterisation only")
+        L = lib.load()
+        flow = self.flow.models[flow_number]
+        flow.eval()
+        dev, D = self.flow.device, self.dims
+        rank, world = self._rank_world()
+        per = (n_rows + world - 1) // world if world > 1 else n_rows
+        lo = min(rank * per, n_rows)
+        n_loc = min((rank + 1) * per, n_rows) - lo if world > 1 else n_rows
+        # same capacity on every rank: the all-gather pads to the largest count
+        packed = torch.empty((max(per, 1), D + self.n_proposals + 1), dtype=torch.float64, device=dev)
+        n_keep = torch.zeros(1, dtype=torch.int64, device=dev)
+        if n_loc > 0:
+            header, image = flow.device_image()
+            x64 = torch.empty((n_loc, D), dtype=torch.float64, device=dev)
+            xp = torch.empty((n_loc, D), dtype=torch.float32, device=dev)
+            log_j = torch.empty(n_loc, dtype=torch.float64, device=dev)
+            z_dev = None
+            if z_in is not None:
+                z_dev = torch.from_numpy(np.ascontiguousarray(z_in[lo : lo + n_loc])).to(torch.float32).to(dev)
+            rc = L.nsa_importance_draw(
+                header, lib.ptr(image), n_loc, lib.ptr(z_dev), self.device_seed, self._draw_counter + lo, EPS,
+                lib.ptr(x64), lib.ptr(xp), lib.ptr(log_j), lib.ptr(flow._status), flow.waves_per_group,
+                flow.max_groups, self._stream(),
+            )
+            lib.check(rc, "nsa_importance_draw")
+            if self.clip:
+                x64.clamp_(0.0, 1.0)
+            log_prob_all = log_prob_many(self.flow.models, xp)  # this rank's rows under every flow
+            log_q_all, log_Q = self._mix(log_prob_all, log_j)
+            keep = torch.nonzero(~torch.isnan(log_j)).reshape(-1)  # draw order
+            m = keep.numel()
+            packed[:m, :D] = x64[keep]
+            packed[:m, D:-1] = log_q_all[keep]
+            packed[:m, -1] = log_Q[keep]
+            n_keep[0] = m
+        self._draw_counter += n_rows
+        if world > 1:
+            from .proposal import _gather_accepted
+
+            _, rows = _gather_accepted(packed, n_keep, packed.shape[0], packed.shape[1])
+        else:
+            rows = packed[: int(n_keep.item())]
+        rows = rows.cpu().numpy()
+        return rows[:, :D], rows[:, D:-1], rows[:, -1]
 
     # -- meta-proposal -------------------------------------------------------------------
 
     def compute_log_Q(self, x_prime, log_j=None):
         """(log Q, log q of every proposal) (``importance.py:382-441``)."""
-        if any(np.isnan(w) for w in self.weights.values()):
-            raise RuntimeError("Some weights are not set!")
-        log_q_all = np.zeros([x_prime.shape[0], self.n_proposals])
+        self._check_ready()
         n_flows = self.flow.n_models
         if self.n_proposals > 1 and log_j is None:
             raise RuntimeError("Must specify log_j! Meta-proposal includes flows")
-        if any(flow.training for flow in self.flow.models):
-            raise RuntimeError("One or more flows are in training mode!")
+        dev = self.flow.device
+        n = x_prime.shape[0]
+        if n == 0:
+            return np.empty(0), np.zeros((0, self.n_proposals))
+        lj = torch.from_numpy(np.ascontiguousarray(log_j if log_j is not None else np.zeros(n), dtype=np.float64)).to(dev)
+        log_prob_all = None
         if n_flows >= 1:
-            log_q_all[:, 1 : (n_flows + 1)] = self.flow.log_prob_all(x_prime) + log_j[:, np.newaxis]
-        log_Q = logsumexp(log_q_all, b=self.weights_array, axis=1)
+            xp = torch.from_numpy(np.ascontiguousarray(x_prime)).to(torch.float32).to(dev)
+            log_prob_all = self._log_prob_rows(self.flow.models, xp)
+        log_q_all, log_Q = self._mix(log_prob_all, lj)
+        log_Q = log_Q.cpu().numpy()
         if np.isnan(log_Q).any():
             raise ValueError("There is a NaN in log g!")
-        return log_Q, log_q_all
+        return log_Q, log_q_all.cpu().numpy()
 
     def compute_meta_proposal_from_log_q(self, log_q):
         return logsumexp(log_q, b=self.weights_array, axis=1)
@@ -211,57 +367,59 @@ class ImportanceFlowProposal:
         if it == -1:
             return lambda x: np.zeros(x.shape[0])
         elif it < len(self.flow.models):
-            return lambda x: self.flow.log_prob_ith(x, it)
+            return lambda x: self._log_prob_ith(x, it)
         raise ValueError
 
+    def _log_prob_ith(self, x_prime, it):
+        flow = self.flow.models[it]
+        flow.eval()
+        xp = torch.from_numpy(np.ascontiguousarray(x_prime)).to(torch.float32).to(self.flow.device)
+        return self._log_prob_rows([flow], xp)[0].cpu().numpy().astype(np.float64)
+
     def update_log_q(self, samples, log_q):
-        """Append the newest proposal's column (``importance.py:528-543``)."""
+        """Append the newest proposal's column (``importance.py:528-543``); this is evaluated on
+        every stored sample at every level, so its rows are sharded as well."""
         if log_q.shape[1] == self.n_proposals:
             raise ValueError("log_q array already contains current proposal")
         x, log_j = self.rescale(samples)
-        log_q_current = self.get_proposal_log_prob(self.level_count)(x)
-        return np.concatenate([log_q, log_q_current[:, np.newaxis] + log_j[:, np.newaxis]], axis=1)
+        column = self.get_proposal_log_prob(self.level_count)(x) + log_j
+        return np.concatenate([log_q, column[:, np.newaxis]], axis=1)
 
-    def draw(self, n, flow_number=None):
-        """Draw n points from one flow with their meta-proposal weights (``importance.py:443-526``)."""
-        if flow_number is None:
-            flow_number = self.level_count
-        n_draw = int(1.01 * n)
-        samples = np.zeros(0, dtype=self.dtype)
-        log_q_samples = np.empty([0, self.n_proposals])
-        n_accepted = 0
-        while n_accepted < n and n_draw > 0:
-            x_prime = self.flow.sample_ith(i=flow_number, N=n_draw)
-            x, log_j_inv = self.inverse_rescale(x_prime)
-            with np.errstate(divide="ignore", invalid="ignore"):
-                x_check, log_j = self.rescale(x)
-            acc = (
-                self.model.in_unit_hypercube(x)
-                & np.isfinite(x_check).all(axis=1)
-                & np.isfinite(x_prime).all(axis=1)
-                & np.isfinite(log_j)
-                & np.isfinite(log_j_inv)
-            )
-            if not np.any(acc):
+    def draw(self, n, flow_number=None, injected=None):
+        """``n`` points from one flow with their meta-proposal weights (``importance.py:443-526``).
+
+        Batches of ``int(1.01 n)`` rows until ``n`` survive both filters; the first ``n`` are
+        returned.  ``injected`` (parity tests): iterator of latent arrays used instead of the
+        device generator."""
+        self._check_ready()
+        source = self.level_count if flow_number is None else flow_number
+        batch = int(1.01 * n)
+        names = self.model.names
+        kept_points, kept_log_q, have = [], [], 0
+        while have < n and batch > 0:
+            z_in = next(injected) if injected is not None else None
+            x, log_q_all, log_Q = self._draw_batch(source, batch, z_in=z_in)
+            if not len(x):
                 continue
-            x, x_prime, log_j = x[acc], x_prime[acc], log_j[acc]
-            x["logQ"], log_q_all = self.compute_log_Q(x_prime, log_j=log_j)
-            x["logP"] = self.model.batch_evaluate_log_prior(self.model.from_unit_hypercube(x))
-            x["logU"] = self.model.batch_evaluate_log_prior_unit_hypercube(x)
-            x["logW"] = x["logU"] - x["logQ"]
-            accept = (
-                np.isfinite(x["logP"])
-                & ~np.isposinf(x["logW"])
-                & ~np.isnan(log_q_all).all(axis=1)
-                & ~np.isposinf(log_q_all).all(axis=1)
-            )
-            if not np.any(accept):
+            points = empty_ins_array(len(x), names)
+            for col, name in enumerate(names):
+                points[name] = x[:, col]
+            points["logQ"] = log_Q
+            points["logP"] = self.model.batch_evaluate_log_prior(self.model.from_unit_hypercube(points))
+            points["logU"] = self.model.batch_evaluate_log_prior_unit_hypercube(points)
+            points["logW"] = points["logU"] - points["logQ"]
+            # second filter (importance.py:497-503): a usable prior, a weight that is not +inf, and
+            # not every proposal density NaN / +inf
+            usable = np.isfinite(points["logP"]) & ~np.isposinf(points["logW"])
+            usable &= ~np.isnan(log_q_all).all(axis=1) & ~np.isposinf(log_q_all).all(axis=1)
+            if not usable.any():
                 continue
-            x, log_q_all = x[accept], log_q_all[accept]
-            samples = np.concatenate([samples, x])
-            log_q_samples = np.concatenate([log_q_samples, log_q_all], axis=0)
-            n_accepted += x.size
-        return samples[:n], log_q_samples[:n]
+            kept_points.append(points[usable])
+            kept_log_q.append(log_q_all[usable])
+            have += int(usable.sum())
+        if not kept_points:
+            return np.zeros(0, dtype=self.dtype), np.empty([0, self.n_proposals])
+        return np.concatenate(kept_points)[:n], np.concatenate(kept_log_q, axis=0)[:n]
 
     def draw_from_prior(self, n):
         """(``importance.py:632-641``)."""

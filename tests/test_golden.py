@@ -193,20 +193,58 @@ def test_importance_glue_matches_reference():
     x_back, log_j_inv = P.from_prime(me, g["x_prime"])
     assert np.array_equal(x_back, g["x_back"]) and np.array_equal(log_j_inv, g["log_j_inv"])
 
-    lpa = g["log_prob_all"]
-    weights = {i - 1: float(w) for i, w in enumerate(g["weights"])}
-    flow = types.SimpleNamespace(
-        n_models=lpa.shape[1], models=[types.SimpleNamespace(training=False)] * lpa.shape[1],
-        log_prob_all=lambda x: lpa,
-    )
-    me = types.SimpleNamespace(weights=weights, weights_array=g["weights"], n_proposals=lpa.shape[1] + 1,
-                               flow=flow)
-    log_Q, log_q_all = P.compute_log_Q(me, g["x_prime"], log_j=g["log_j"])
-    assert np.array_equal(log_q_all, g["log_q_all"])
-    assert np.array_equal(log_Q, g["log_Q"])
-    assert np.array_equal(P.compute_meta_proposal_from_log_q(me, log_q_all), g["log_Q_from_q"])
-    with pytest.raises(RuntimeError, match="Must specify log_j"):
-        P.compute_log_Q(me, g["x_prime"])
-    me.weights = {**weights, 2: np.nan}
-    with pytest.raises(RuntimeError, match="weights are not set"):
-        P.compute_log_Q(me, g["x_prime"], log_j=g["log_j"])
+    me = types.SimpleNamespace(weights_array=g["weights"])
+    assert np.array_equal(P.compute_meta_proposal_from_log_q(me, g["log_q_all"]), g["log_Q_from_q"])
+    # compute_log_Q itself runs on the device (nsa_importance_mix): tests/test_gpu_importance.py
+    # replays this golden there
+
+
+def test_oracle_importance_draw_matches_reference():
+    """The oracle's restatement of ``ImportanceFlowProposal.draw`` / ``update_log_q``
+    (oracle/importance.py) replays the reference's own loop bit for bit on the stand-in flow of
+    ``make_importance_goldens.py``: both filters, the order of the accepted rows, logQ / logW / logU,
+    the truncation to n."""
+    from oracle.importance import OracleImportanceProposal
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "importance_goldens.npz"))
+    names = [str(n) for n in g["draw_names"]]
+    batches, tables = g["draw_batches"], g["draw_lp_tables"]
+    state = dict(k=0)
+
+    class Model:
+        def in_unit_hypercube(self, x):
+            return ~np.any([(x[nm] < 0) | (x[nm] > 1) for nm in names], axis=0)
+
+        def batch_evaluate_log_prior(self, x, unit_hypercube=False):
+            out = np.full(x.size, -3.25)
+            out[x[names[0]] > 0.97] = -np.inf
+            return out
+
+        def batch_evaluate_log_prior_unit_hypercube(self, x):
+            with np.errstate(divide="ignore"):
+                return np.log(self.in_unit_hypercube(x), dtype=float)
+
+    model = Model()
+    model.names = names
+
+    class Replay(OracleImportanceProposal):
+        def log_prob_all(self, x):
+            b = batches[state["k"]]
+            rows = [np.flatnonzero(np.all((b == r) | (np.isnan(b) & np.isnan(r)), axis=1))[0] for r in x]
+            table = tables[state["k"]]
+            state["k"] += 1
+            return table[rows]
+
+        def log_prob_ith(self, x, i):
+            return g["update_ith"]
+
+    orc = Replay(model, flows=[None] * tables.shape[2], weights=g["weights"])
+    with np.errstate(all="ignore"):
+        samples, log_q = orc.draw(150, flow_number=tables.shape[2] - 1, x_primes=iter(batches))
+    assert state["k"] == int(g["draw_batches_used"])
+    assert np.array_equal(np.stack([samples[n] for n in names], axis=1), g["draw_x"])
+    for field in ("logQ", "logW", "logP", "logU"):
+        assert np.array_equal(samples[field], g["draw_" + field], equal_nan=True), field
+    assert np.array_equal(log_q, g["draw_log_q"], equal_nan=True)
+    upd = orc.update_log_q(samples, log_q[:, :-1], level=tables.shape[2] - 1)
+    assert np.array_equal(upd, g["update_log_q"], equal_nan=True)

@@ -1,0 +1,225 @@
+"""Config 4 on the device: the importance nested sampler's meta-proposal at nlive = 5000 on the
+64-D correlated Gaussian (BASELINE.json configs[3]), n_flows in
+{1, 8, 32}: ``ImportanceFlowProposal.draw`` / ``compute_log_Q`` / ``update_log_q`` against the
+oracle (``oracle/importance.py``, pinned bit for bit to the reference's own loop) fed identical
+latents and weights, and the row-sharded run against the single-rank run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+D, NLIVE = 64, 5000
+FLOW = dict(ftype="nsf", n_neurons=128, n_blocks=6, n_layers=2, num_bins=8)
+
+
+class OracleModel:
+    """The reference's model interface in the unit hypercube (``model.py:520-620``) over the
+    product's model."""
+
+    def __init__(self, model):
+        self.m = model
+        self.names = model.names
+
+    def in_unit_hypercube(self, x):
+        return self.m.in_unit_hypercube(x)
+
+    def batch_evaluate_log_prior(self, x, unit_hypercube=False):
+        return self.m.batch_evaluate_log_prior(self.m.from_unit_hypercube(x) if unit_hypercube else x)
+
+    def batch_evaluate_log_prior_unit_hypercube(self, x):
+        return self.m.batch_evaluate_log_prior_unit_hypercube(x)
+
+
+def build(n_flows, tmp, dims=D, flow=FLOW, shard=False, seed=4):
+    sys.path.insert(0, ROOT)
+    from nessai_amd.model import CorrelatedGaussianModel
+    from nessai_amd.proposal_importance import ImportanceFlowProposal
+
+    torch.manual_seed(seed)
+    model = CorrelatedGaussianModel(dims, rho=0.5)
+    prop = ImportanceFlowProposal(model, output=str(tmp), rng=np.random.default_rng(seed), flow_config=dict(flow),
+                                  device_seed=99, shard=shard)
+    prop.initialise()
+    for k in range(n_flows):
+        prop.flow.add_new_flow(reset=True)
+        hip = prop.flow.models[k]  # every level a different flow
+        state = {name: v.cpu().clone() for name, v in hip.state_dict().items()}
+        g = torch.Generator().manual_seed(10 + k)
+        for name, v in state.items():
+            if v.is_floating_point() and (name.endswith(".bias") or name.endswith(".weight")):
+                v.add_(0.05 * torch.randn(v.shape, generator=g))
+        hip.load_state_dict(state)
+        hip._image_key = None
+        prop._weights[k] = np.nan
+    prop.level_count = n_flows - 1
+    w = np.random.default_rng(seed).uniform(0.5, 1.5, size=n_flows + 1)
+    w /= w.sum()
+    w[-1] = 1.0 - w[:-1].sum()
+    prop.update_proposal_weights({k - 1: float(w[k]) for k in range(n_flows + 1)})
+    prop.flow.models.eval()
+    return model, prop
+
+
+def oracle_for(model, prop):
+    from oracle import flows as OF
+    from oracle.importance import OracleImportanceProposal
+
+    cfg = prop.flow_config
+    flows = []
+    for hip in prop.flow.models:
+        ref = OF.NeuralSplineFlow(cfg["n_inputs"], cfg["n_neurons"], cfg["n_blocks"], cfg["n_layers"],
+                                  num_bins=cfg.get("num_bins", 8))
+        ref.load_state_dict({k: v.cpu() for k, v in hip.state_dict().items()})
+        ref.eval()
+        flows.append(ref)
+    return OracleImportanceProposal(OracleModel(model), flows, prop.weights_array)
+
+
+@pytest.mark.parametrize("n_flows", [1, 8, 32])
+def test_draw_compute_log_Q_update_log_q_match_the_oracle(n_flows, tmp_path):
+    model, prop = build(n_flows, tmp_path)
+    orc = oracle_for(model, prop)
+    n_draw = int(1.01 * NLIVE)
+    g = np.random.default_rng(n_flows)
+    z = [g.normal(size=(n_draw, D)).astype(np.float32).astype(np.float64) for _ in range(2)]
+    source = n_flows // 2  # not only the newest flow
+    got, got_q = prop.draw(NLIVE, flow_number=source, injected=iter(z))
+    exp, exp_q = orc.draw(NLIVE, source, latents=iter(z))
+    assert got.size == exp.size == NLIVE and got_q.shape == exp_q.shape == (NLIVE, n_flows + 1)
+    x_got = np.stack([got[n] for n in model.names], axis=1)
+    x_exp = np.stack([exp[n] for n in model.names], axis=1)
+    # x = sigmoid(x'): the flow's inverse agrees with the oracle's to a few 1e-5 (float32 spline)
+    np.testing.assert_allclose(x_got, x_exp, rtol=0, atol=3e-5)
+    assert np.all(got_q[:, 0] == 0.0)
+    # log q_j(x) = log_prob_j(x') + log|J|: |log q| ~ 1e2, the float32 flows agree to 1e-5 relative
+    np.testing.assert_allclose(got_q, exp_q, rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(got["logQ"], exp["logQ"], rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(got["logW"], exp["logW"], rtol=2e-5, atol=2e-3)
+    assert np.array_equal(got["logP"], exp["logP"]) and np.array_equal(got["logU"], exp["logU"])
+    # the meta-proposal is the weighted mixture of the columns, in float64 on both sides
+    np.testing.assert_allclose(prop.compute_meta_proposal_from_log_q(got_q), got["logQ"], rtol=1e-12)
+
+    # compute_log_Q on host arrays (the sampler's path for stored samples)
+    xp, log_j = prop.rescale(exp)
+    log_Q, log_q_all = prop.compute_log_Q(xp, log_j=log_j)
+    log_Q_o, log_q_all_o = orc.compute_log_Q(xp, log_j)
+    np.testing.assert_allclose(log_q_all, log_q_all_o, rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(log_Q, log_Q_o, rtol=2e-5, atol=2e-3)
+
+    # update_log_q: a table without the newest flow gains its column
+    upd = prop.update_log_q(exp, exp_q[:, :-1])
+    upd_o = orc.update_log_q(exp, exp_q[:, :-1], level=n_flows - 1)
+    assert upd.shape == (NLIVE, n_flows + 1) and np.array_equal(upd[:, :-1], exp_q[:, :-1])
+    np.testing.assert_allclose(upd[:, -1], upd_o[:, -1], rtol=2e-5, atol=2e-3)
+    with pytest.raises(ValueError):
+        prop.update_log_q(exp, exp_q)
+
+
+def test_first_filter_on_the_device_matches_the_oracle(tmp_path):
+    """Saturated / non-finite flow samples: rows the reference drops before ``compute_log_Q``
+    (importance.py:476-483) carry the NaN mark of the draw kernel."""
+    model, prop = build(2, tmp_path, dims=6, flow=dict(ftype="nsf", n_neurons=16, n_blocks=2, n_layers=1, num_bins=4))
+    orc = oracle_for(model, prop)
+    z = np.random.default_rng(1).normal(size=(int(1.01 * 400), 6)).astype(np.float32).astype(np.float64)
+    z[3, 2] = 60.0     # far in the linear tail: sigmoid saturates, log|J_inv| = -inf
+    z[9, 0] = -70.0
+    got, got_q = prop.draw(390, flow_number=1, injected=iter([z, z]))
+    exp, exp_q = orc.draw(390, 1, latents=iter([z, z]))
+    assert got.size == exp.size == 390
+    np.testing.assert_allclose(np.stack([got[n] for n in model.names], 1), np.stack([exp[n] for n in model.names], 1),
+                               rtol=0, atol=3e-5)
+    np.testing.assert_allclose(got_q, exp_q, rtol=2e-5, atol=2e-4)
+    # a non-finite latent (cannot come out of the generator) is dropped, not propagated
+    z[11, 4] = np.nan
+    z[15, 1] = np.inf
+    more, _ = prop.draw(390, flow_number=1, injected=iter([z, z]))
+    assert more.size == 390 and np.isfinite(np.stack([more[n] for n in model.names], 1)).all()
+
+
+def test_device_generator_is_reproducible_and_row_indexed(tmp_path):
+    """Without injected latents the rows come from the Philox stream of the global row: two
+    proposals with one seed draw the same points; the second call continues the stream."""
+    model, a = build(3, tmp_path / "a", dims=8, flow=dict(ftype="nsf", n_neurons=16, n_blocks=2, n_layers=1, num_bins=4))
+    _, b = build(3, tmp_path / "b", dims=8, flow=dict(ftype="nsf", n_neurons=16, n_blocks=2, n_layers=1, num_bins=4))
+    xa, qa = a.draw(1000)
+    xb, qb = b.draw(1000)
+    assert np.array_equal(qa, qb) and all(np.array_equal(xa[n], xb[n]) for n in model.names)
+    xa2, _ = a.draw(1000)
+    assert not np.array_equal(xa2[model.names[0]], xa[model.names[0]])
+    assert a._draw_counter == 2 * int(1.01 * 1000)
+    u = np.stack([xa[n] for n in model.names], axis=1)
+    assert ((u >= 0) & (u <= 1)).all() and np.isfinite(xa["logW"]).all()
+
+
+def test_mix_kernel_replays_the_reference_golden(tmp_path):
+    """``compute_log_Q`` of the reference on a fixed ``log_prob_all`` table
+    (tests/golden/make_importance_goldens.py): the float64 mix kernel reproduces ``log_q_all`` and
+    ``log Q`` (scipy's weighted logsumexp, incl. a -inf entry) to the last bits."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "importance_goldens.npz"))
+    model, prop = build(3, tmp_path, dims=5, flow=dict(ftype="nsf", n_neurons=8, n_blocks=2, n_layers=1, num_bins=4))
+    prop._weights = {i - 1: float(w) for i, w in enumerate(g["weights"])}
+    table = g["log_prob_all"].astype(np.float32)  # what the flows hand over
+    lp = torch.from_numpy(np.ascontiguousarray(table.T)).to(prop.flow.device)
+    lj = torch.from_numpy(g["log_j"]).to(prop.flow.device)
+    log_q_all, log_Q = prop._mix(lp, lj)
+    from scipy.special import logsumexp
+
+    expect = np.zeros((len(table), 4))
+    expect[:, 1:] = table.astype(np.float64) + g["log_j"][:, None]
+    assert np.array_equal(log_q_all.cpu().numpy(), expect)
+    np.testing.assert_allclose(log_Q.cpu().numpy(), logsumexp(expect, b=g["weights"], axis=1), rtol=1e-12, atol=0)
+    np.testing.assert_allclose(log_Q.cpu().numpy(), g["log_Q"], rtol=1e-4, atol=1e-5)  # the golden's float64 table
+    with pytest.raises(RuntimeError, match="Must specify log_j"):
+        prop.compute_log_Q(g["x_prime"])
+    prop._weights[2] = np.nan
+    with pytest.raises(RuntimeError, match="weights are not set"):
+        prop.compute_log_Q(g["x_prime"], log_j=g["log_j"])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _shard_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    model, prop = build(4, os.path.join(out_dir, f"r{rank}"), dims=16,
+                        flow=dict(ftype="nsf", n_neurons=32, n_blocks=3, n_layers=2, num_bins=8), shard=True)
+    pts, log_q = prop.draw(1500)
+    upd = prop.update_log_q(pts, log_q[:, :-1])
+    xp, log_j = prop.rescale(pts)
+    log_Q, _ = prop.compute_log_Q(xp, log_j)
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), x=np.stack([pts[n] for n in model.names], 1), log_q=log_q,
+             upd=upd, log_Q=log_Q, counter=prop._draw_counter)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rows_sharded_over_two_ranks_equal_one_rank(tmp_path):
+    mp.spawn(_shard_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    model, single = build(4, tmp_path / "single", dims=16,
+                          flow=dict(ftype="nsf", n_neurons=32, n_blocks=3, n_layers=2, num_bins=8))
+    pts, log_q = single.draw(1500)
+    upd = single.update_log_q(pts, log_q[:, :-1])
+    xp, log_j = single.rescale(pts)
+    log_Q, _ = single.compute_log_Q(xp, log_j)
+    for r in range(2):
+        s = np.load(tmp_path / f"s{r}.npz")
+        assert np.array_equal(s["x"], np.stack([pts[n] for n in model.names], 1))
+        assert np.array_equal(s["log_q"], log_q) and np.array_equal(s["upd"], upd)
+        assert np.array_equal(s["log_Q"], log_Q) and int(s["counter"]) == single._draw_counter

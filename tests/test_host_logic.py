@@ -111,29 +111,19 @@ def test_importance_proposal_glue():
     np.testing.assert_allclose(ljb[0], -lj[0])
     assert ins_dtype(["a"]).names == ("a", "logP", "logL", "it", "logQ", "logW", "logU")
 
-    class FakeFlows:
-        n_models = 2
-        models = []
-
-        def log_prob_all(self, x):
-            return np.stack([-np.sum(x**2, axis=1), -0.5 * np.sum(x**2, axis=1)], axis=1)
-
     m = RosenbrockModel(2)
     prop = ImportanceFlowProposal(m, output="/tmp")
-    prop.flow = FakeFlows()
     prop._weights = {-1: 0.2, 0: 0.3, 1: 0.5}
     xp = np.random.default_rng(0).normal(size=(7, 2))
     lj = np.random.default_rng(1).normal(size=7)
-    log_Q, log_q = prop.compute_log_Q(xp, log_j=lj)
-    assert log_q.shape == (7, 3) and np.all(log_q[:, 0] == 0)
-    expect = logsumexp(np.concatenate([np.zeros((7, 1)), FakeFlows().log_prob_all(xp) + lj[:, None]], axis=1),
-                       b=np.array([0.2, 0.3, 0.5]), axis=1)
-    np.testing.assert_allclose(log_Q, expect)
+    log_q = np.concatenate([np.zeros((7, 1)), np.stack([-np.sum(xp**2, 1), -0.5 * np.sum(xp**2, 1)], 1) + lj[:, None]], 1)
+    expect = logsumexp(log_q, b=np.array([0.2, 0.3, 0.5]), axis=1)
+    np.testing.assert_allclose(prop.compute_meta_proposal_from_log_q(log_q), expect)
     with pytest.raises(RuntimeError, match="Weights must sum to 1"):
         prop.update_proposal_weights({1: 0.9})
-    prop._weights[2] = np.nan
-    with pytest.raises(RuntimeError, match="Some weights are not set"):
-        prop.compute_log_Q(xp, log_j=lj)
+    # compute_log_Q / draw run on the device: tests/test_gpu_importance.py
+    xs, ljs = prop.rescale(np.zeros(3, dtype=ins_dtype(m.names)))
+    assert xs.shape == (3, 2) and ljs.shape == (3,)
 
 
 def test_separable_prior_terms_are_normalised():
