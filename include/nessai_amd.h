@@ -307,6 +307,17 @@ NSA_API int nsa_train_step(const long long* plan, const int* tables_dev, const f
                            float* workspace_dev, float lr, float beta1, float beta2, float eps,
                            float weight_decay, float clip_norm, long long step, int optimiser,
                            float* loss_acc_dev, void* stream);
+
+/* The same minibatch with the learning rate and the optimiser step counter read from device memory
+ * (opt_dev: float[4] = {lr, steps done so far, scratch, scratch}; the call increments [1]).  No
+ * argument changes from step to step, so the launches of a whole epoch - the reference runs two
+ * minibatches and one validation pass per epoch on 2000 live points, flowmodel/base.py:195-236,
+ * 607-640 - can be captured once into a HIP graph and replayed with one launch. */
+NSA_API int nsa_train_step_dev(const long long* plan, const int* tables_dev, const float* consts,
+                               float* params_dev, float* grads_dev, float* adam_m_dev, float* adam_v_dev,
+                               const float* x_dev, const float* weights_dev, long long n, float* workspace_dev,
+                               float* opt_dev, float beta1, float beta2, float eps, float weight_decay,
+                               float clip_norm, int optimiser, float* loss_acc_dev, void* stream);
 /* Forward only (FlowModel._validate, flowmodel/base.py:454-523):
  * loss_acc_dev[0] += -mean(log_prob(x)); log_prob_out_dev [n] may be NULL. */
 NSA_API int nsa_train_eval(const long long* plan, const int* tables_dev, const float* consts,

@@ -825,11 +825,26 @@ __global__ void __launch_bounds__(256) tr_grad_sqnorm(long long n, const float* 
 // FlowModel.get_optimiser (src/nessai/flowmodel/base.py:105-135):
 //   mode 0 torch.optim.AdamW (decoupled decay p *= 1 - lr wd), 1 torch.optim.Adam (L2: g += wd p),
 //   2 torch.optim.SGD without momentum (g += wd p; p -= lr g)
+//   opt (optional, device): {lr, steps done, 1 - beta1^step, sqrt(1 - beta2^step)} maintained by
+//   tr_opt_tick - the form a captured HIP graph replays (no per-step host scalars).
+__global__ void tr_opt_tick(float* __restrict__ opt, float beta1, float beta2) {
+  const float step = opt[1] + 1.0f;
+  opt[1] = step;
+  opt[2] = 1.0f - powf(beta1, step);
+  opt[3] = sqrtf(1.0f - powf(beta2, step));
+}
+
 __global__ void tr_adamw(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                          float* __restrict__ v, const float* __restrict__ sq_partial, float max_norm, float lr,
-                         float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, int mode) {
+                         float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, int mode,
+                         const float* __restrict__ opt) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (opt != nullptr) {
+    lr = opt[0];
+    bc1 = opt[2];
+    bc2_sqrt = opt[3];
+  }
   float coef = 1.0f;
   if (max_norm > 0.0f) {
     float sq = 0.0f;
@@ -1233,6 +1248,12 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
 }
 
 // One minibatch: forward, loss, backward, clip, AdamW.  loss_acc_dev[0] += loss.
+static int tr_step_impl(const long long* plan, const int* tables_dev, const float* consts, float* params_dev,
+                        float* grads_dev, float* adam_m_dev, float* adam_v_dev, const float* x_dev,
+                        const float* weights_dev, long long n, float* workspace_dev, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float clip_norm, long long step, int optimiser,
+                        float* loss_acc_dev, float* opt_dev, void* stream);
+
 extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_dev, const float* consts,
                                       float* params_dev, float* grads_dev, float* adam_m_dev,
                                       float* adam_v_dev, const float* x_dev, const float* weights_dev,
@@ -1240,6 +1261,31 @@ extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_d
                                       float eps,
                                       float weight_decay, float clip_norm, long long step,
                                       int optimiser, float* loss_acc_dev, void* stream) {
+  return tr_step_impl(plan, tables_dev, consts, params_dev, grads_dev, adam_m_dev, adam_v_dev, x_dev, weights_dev, n,
+                      workspace_dev, lr, beta1, beta2, eps, weight_decay, clip_norm, step, optimiser, loss_acc_dev,
+                      nullptr, stream);
+}
+
+// The same minibatch with the learning rate and the step counter on the DEVICE (opt_dev[0] = lr,
+// opt_dev[1] = optimiser steps done so far; [2], [3] scratch): nothing in the launch sequence depends
+// on a per-step host value, so a whole epoch can be captured once as a HIP graph and replayed.
+extern "C" NSA_API int nsa_train_step_dev(const long long* plan, const int* tables_dev, const float* consts,
+                                          float* params_dev, float* grads_dev, float* adam_m_dev,
+                                          float* adam_v_dev, const float* x_dev, const float* weights_dev,
+                                          long long n, float* workspace_dev, float* opt_dev, float beta1,
+                                          float beta2, float eps, float weight_decay, float clip_norm,
+                                          int optimiser, float* loss_acc_dev, void* stream) {
+  if (!opt_dev) return NSA_E_ARG;
+  return tr_step_impl(plan, tables_dev, consts, params_dev, grads_dev, adam_m_dev, adam_v_dev, x_dev, weights_dev, n,
+                      workspace_dev, 0.0f, beta1, beta2, eps, weight_decay, clip_norm, 1, optimiser, loss_acc_dev,
+                      opt_dev, stream);
+}
+
+static int tr_step_impl(const long long* plan, const int* tables_dev, const float* consts, float* params_dev,
+                        float* grads_dev, float* adam_m_dev, float* adam_v_dev, const float* x_dev,
+                        const float* weights_dev, long long n, float* workspace_dev, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float clip_norm, long long step, int optimiser,
+                        float* loss_acc_dev, float* opt_dev, void* stream) {
   if (!plan || !tables_dev || !params_dev || !grads_dev || !x_dev || !workspace_dev || !loss_acc_dev || n <= 1 ||
       optimiser < 0 || optimiser > 2)
     return NSA_E_ARG;
@@ -1260,8 +1306,10 @@ extern "C" NSA_API int nsa_train_step(const long long* plan, const int* tables_d
   hipLaunchKernelGGL(tr_grad_sqnorm, dim3(TR_SQ_BLOCKS), dim3(256), 0, s, n_params, grads_dev, w.scal + 128);
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  if (opt_dev != nullptr) hipLaunchKernelGGL(tr_opt_tick, dim3(1), dim3(1), 0, s, opt_dev, beta1, beta2);
   hipLaunchKernelGGL(tr_adamw, blocks_for(n_params), dim3(256), 0, s, n_params, params_dev, grads_dev, adam_m_dev,
-                     adam_v_dev, w.scal + 128, clip_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, optimiser);
+                     adam_v_dev, w.scal + 128, clip_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, optimiser,
+                     (const float*)opt_dev);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? NSA_OK : NSA_E_HIP;
 }

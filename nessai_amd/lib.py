@@ -73,6 +73,11 @@ SIGNATURES = {
     "nsa_populate_accept_workspace": (c_size_t, [c_ll]),
     "nsa_train_workspace_floats": (c_size_t, [c_void_p, c_ll]),
     "nsa_log_likelihood": (c_int, [c_int, c_ll, c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
+    "nsa_train_step_dev": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p,
+         c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p],
+    ),
     "nsa_train_step": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll,

@@ -19,6 +19,7 @@ reference except conditional inputs, which raise.
 
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -167,6 +168,9 @@ class Trainer:
         self.consts = (ctypes.c_float * len(consts))(*consts)
         self.features = D
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)
+        self.val_acc = torch.zeros(1, dtype=torch.float32, device=device)
+        #: {lr, optimiser steps done, 1 - beta1^t, sqrt(1 - beta2^t)} for nsa_train_step_dev
+        self.opt = torch.zeros(4, dtype=torch.float32, device=device)
         self._ws = None
         self._ws_rows = 0
         self.n_params = total
@@ -272,6 +276,20 @@ class Trainer:
         lib.check(rc, "nsa_train_step")
         self._actnorm_initialised()
 
+    def step_dev(self, x, clip_norm=5.0, weights=None):
+        """``step`` with the learning rate and the step counter in device memory (``self.opt``):
+        the form whose launches can be captured into a HIP graph (``nsa_train_step_dev``)."""
+        self.step_count += 1
+        ws = self._workspace(x.shape[0])
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = lib.load().nsa_train_step_dev(
+            self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(self.grads),
+            lib.ptr(self.adam_m), lib.ptr(self.adam_v), lib.ptr(x), lib.ptr(weights), x.shape[0], lib.ptr(ws),
+            lib.ptr(self.opt), self.betas[0], self.betas[1], self.eps, self.weight_decay, float(clip_norm or 0.0),
+            self.optimiser, lib.ptr(self.loss_acc), lib.c_void_p(stream),
+        )
+        lib.check(rc, "nsa_train_step_dev")
+
     def evaluate(self, x, log_prob_out=None, weights=None):
         """``loss_acc += -mean(log_prob(x))`` without touching the weights."""
         ws = self._workspace(x.shape[0])
@@ -344,27 +362,62 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
     trainer.best.copy_(trainer.flat)
     history = dict(loss=[], val_loss=[])
     model.train()
-    for epoch in range(1, max_epochs + 1):
-        p = torch.randperm(train_data.shape[0]).to(train_data.device)
-        batches = train_data[p, :].split(batch_size)
-        w_batches = w_train[p].split(batch_size) if w_train is not None else [None] * len(batches)
+    # One epoch = the minibatch steps + the validation pass.  Live-point sets are small (2000 rows:
+    # two minibatches), so an epoch is ~35 short launches and launch overhead dominates: after the
+    # first epoch (which also runs the data-dependent act-norm initialisation) the launches of an
+    # epoch are captured ONCE into a HIP graph and every later epoch is one graph launch.  Nothing
+    # in the captured sequence depends on a per-epoch host value: the shuffled rows are gathered
+    # into a static buffer, the learning rate and the optimiser's step counter live in device
+    # memory (Trainer.opt).  NESSAI_AMD_EPOCH_GRAPH=0 keeps the launch-by-launch loop.
+    n_train = train_data.shape[0]
+    epoch_rows = torch.empty_like(train_data)
+    epoch_w = torch.empty_like(w_train) if w_train is not None else None
+    bounds = [(a, min(a + batch_size, n_train)) for a in range(0, n_train, batch_size)]
+    has_val = bool(validate and len(val_data))
+    trainer.opt[1] = float(trainer.step_count)
+
+    def run_epoch():
         trainer.loss_acc.zero_()
+        for a, b in bounds:
+            trainer.step_dev(epoch_rows[a:b], clip_norm=clip, weights=None if epoch_w is None else epoch_w[a:b])
+        if has_val:
+            trainer.val_acc.zero_()
+            keep, trainer.loss_acc = trainer.loss_acc, trainer.val_acc
+            trainer.evaluate(val_data, weights=w_val)
+            trainer.loss_acc = keep
+
+    use_graph = os.environ.get("NESSAI_AMD_EPOCH_GRAPH", "1") != "0"
+    graph = None
+    for epoch in range(1, max_epochs + 1):
+        p = torch.randperm(n_train).to(train_data.device)
+        torch.index_select(train_data, 0, p, out=epoch_rows)
+        if epoch_w is not None:
+            torch.index_select(w_train, 0, p, out=epoch_w)
+        if noise_scale:
+            epoch_rows.add_(noise_scale * torch.randn_like(epoch_rows))
         if tc.get("annealing"):
             # CosineAnnealingLR(T_max=max_epochs, eta_min=0), stepped once per epoch (base.py:449-450, 628-631)
             trainer.lr = trainer.base_lr * 0.5 * (1.0 + math.cos(math.pi * (epoch - 1) / max_epochs))
-        for x, w in zip(batches, w_batches):
-            if noise_scale:
-                x = x + noise_scale * torch.randn_like(x)
-            trainer.step(x.contiguous(), clip_norm=clip, weights=None if w is None else w.contiguous())
-        if validate and len(val_data):
-            val_acc = torch.zeros_like(trainer.loss_acc)
-            keep, trainer.loss_acc = trainer.loss_acc, val_acc
-            trainer.evaluate(val_data, weights=w_val)
-            trainer.loss_acc = keep
-            both = torch.cat([trainer.loss_acc, val_acc]).cpu().numpy()  # the epoch's one sync
-            loss, val_loss = float(both[0]) / len(batches), float(both[1])
+        trainer.opt[0] = trainer.lr
+        if graph is not None:
+            graph.replay()
+            trainer.step_count += len(bounds)
+        elif use_graph and epoch == 2:
+            graph = torch.cuda.CUDAGraph()
+            steps_before = trainer.step_count
+            with torch.cuda.graph(graph):
+                run_epoch()
+            trainer.step_count = steps_before  # capture records, it does not run
+            graph.replay()
+            trainer.step_count += len(bounds)
         else:
-            loss, val_loss = float(trainer.loss_acc.item()) / len(batches), np.nan
+            run_epoch()
+            trainer._actnorm_initialised()
+        if has_val:
+            both = torch.cat([trainer.loss_acc, trainer.val_acc]).cpu().numpy()  # the epoch's one sync
+            loss, val_loss = float(both[0]) / len(bounds), float(both[1])
+        else:
+            loss, val_loss = float(trainer.loss_acc.item()) / len(bounds), np.nan
         history["loss"].append(loss)
         history["val_loss"].append(val_loss)
         if validate and (val_loss < best_val_loss):

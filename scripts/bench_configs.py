@@ -113,6 +113,43 @@ def run_c4(n_flows_list=(1, 8), n=5000, dims=64):
                               "speedup": cpu_one * target / gpu_s, "log_prob_rel_err_flow0": err}), flush=True)
 
 
+def run_c4_draw(n_flows_list=(1, 8, 32), nlive=5000, dims=64):
+    """Config 4 as a workload: ImportanceFlowProposal.draw(nlive) on the 64-D correlated Gaussian
+    (draw -> sigmoid -> log_prob under every stored flow -> weighted logsumexp), points per second."""
+    from nessai_amd.model import CorrelatedGaussianModel
+    from nessai_amd.proposal_importance import ImportanceFlowProposal
+
+    torch.manual_seed(1451)
+    model = CorrelatedGaussianModel(dims, rho=0.5)
+    with tempfile.TemporaryDirectory() as tmp:
+        prop = ImportanceFlowProposal(model, output=tmp, rng=np.random.default_rng(1451), device_seed=1451,
+                                      flow_config=dict(ftype="nsf", n_neurons=128, n_blocks=6, n_layers=2, num_bins=8))
+        prop.initialise()
+        for target in n_flows_list:
+            while prop.flow.n_models < target:
+                prop.flow.add_new_flow(reset=True)
+                prop._weights[prop.flow.n_models - 1] = np.nan
+            prop.level_count = target - 1
+            prop._weights = {k - 1: 1.0 / (target + 1) for k in range(target + 1)}
+            prop.flow.models.eval()
+            prop.draw(nlive)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(5):
+                pts, log_q = prop.draw(nlive)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / 5
+            stored = np.concatenate([pts] * 4)
+            t = time.perf_counter()
+            for _ in range(3):
+                prop.update_log_q(stored, np.zeros((stored.size, target)))
+            torch.cuda.synchronize()
+            du = (time.perf_counter() - t) / 3
+            print(json.dumps({"config": "C4 ImportanceFlowProposal.draw, 64-D correlated Gaussian", "n_flows": target,
+                              "nlive": nlive, "draw_ms": 1e3 * dt, "points_per_s": nlive / dt,
+                              "update_log_q_ms_20000_rows": 1e3 * du}), flush=True)
+
+
 if __name__ == "__main__":
     run("C2 16-D Gaussian RealNVP (LU+BN), drawsize=nlive", GaussianModel(16),
         dict(ftype="realnvp", n_neurons=32, n_blocks=4, n_layers=2), 2000, 2000, cpu_draw=2000)
@@ -121,3 +158,4 @@ if __name__ == "__main__":
     run("C5 15-D GW surrogate NSF", GWSurrogateModel(),
         dict(ftype="nsf", n_neurons=30, n_blocks=4, n_layers=2), 4000, 1_000_000, cpu_draw=100_000)
     run_c4()
+    run_c4_draw()

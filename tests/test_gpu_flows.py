@@ -65,7 +65,10 @@ def test_log_prob_matches_oracle(pair, scale, request):
     lp = flow.log_prob(x.to(DEV)).cpu()
     name = request.node.callspec.params["pair"][0]
     if flow.precision == "f32" or name in BF16X3_WITHIN_BAR:
-        assert rel_err(lp, lp_ref) <= LOG_PROB_RTOL
+        # TRULY relative (|a - b| / |b|; the floor only guards a log_prob within 1e-3 of zero):
+        # measured <= 7.7e-6 over every configuration incl. the 2- to 5-D flows whose |log_prob|
+        # goes down to 0.8 (scripts/rel_error_stats.py)
+        assert rel_err(lp, lp_ref, floor=1e-3) <= LOG_PROB_RTOL
     else:
         assert rel_err(lp, lp_ref) <= 2e-4  # documented split-bf16 envelope
 

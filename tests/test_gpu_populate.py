@@ -6,6 +6,8 @@ latents and uniforms.  The glue arithmetic is float64 on both sides, so apart
 from the float32 flow outputs (summation order) the results are identical;
 accept decisions can only differ for draws within ~1e-6 of the threshold.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -285,6 +287,35 @@ def test_populate_device_rng_statistics():
         u = philox.uniforms(1451, k * 20000, 20000)[idx]
         acc += int((lw > np.log(u)).sum())
     assert abs(acc - prop.n_accepted) <= max(3, int(0.02 * acc))
+
+
+@pytest.mark.timeout(900)
+def test_accepted_set_gate_c3_independent_streams():
+    """SURVEY.md section 8d parity gate on the accepted SET: config-3 flow (trained weights), 2000
+    accepted points from the device (its own Philox stream) against 2000 from the oracle on an
+    independent stream (torch generator, numpy uniforms): acceptance rates within 3 sigma
+    (binomial) and the per-dimension two-sample Kolmogorov-Smirnov test - family-wise 1 %, i.e.
+    p > 0.01 / 32 in every dimension.  Draw batches of 2e4 rows keep the CPU side to ~2e6 rows."""
+    from scipy.stats import ks_2samp
+
+    state, shift, scale, _ = load_c3_fixture()
+    prop, oprop = build(32, "nsf", dict(n_neurons=64, n_blocks=6), poolsize=2000, drawsize=20000,
+                        state=state, shift=shift, scale=scale)
+    prop.populate(None, n_samples=2000, max_samples=10**9)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    try:
+        torch.manual_seed(20260930)
+        oprop.rng = np.random.default_rng(20260930)
+        oprop.populate(n_samples=2000, max_samples=10**9)
+    finally:
+        torch.set_num_threads(threads)
+    assert prop.samples.size == oprop.x.size == 2000
+    p_dev, p_orc = prop.n_accepted / prop.n_proposed, oprop.n_accepted / oprop.n_proposed
+    sigma = np.sqrt(p_orc * (1 - p_orc) * (1 / prop.n_proposed + 1 / oprop.n_proposed))
+    assert abs(p_dev - p_orc) <= 3 * sigma, (p_dev, p_orc, sigma)
+    p_values = [ks_2samp(prop.samples[n], oprop.x[n]).pvalue for n in prop.names]
+    assert min(p_values) > 0.01 / 32, sorted(p_values)[:4]
 
 
 def test_populate_all_truncated_hits_max_samples():
