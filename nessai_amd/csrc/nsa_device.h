@@ -130,6 +130,7 @@ struct NsaTransformConsts {
   float min_d, edge_d;              // min_derivative, boundary derivative (== 1 up to f32 rounding)
   float edge_raw;                   // its logit log(exp(1 - min_d) - 1): edge_d == min_d + softplus(edge_raw)
   float inv_logit_div;              // 1/sqrt(hidden_features) or 1
+  float aff_a, aff_b;               // affine coupling: scale = sigmoid(raw + aff_a) + aff_b
 };
 
 // Fast-but-accurate scalar helpers.  The spline's arithmetic *structure* follows
@@ -307,8 +308,9 @@ struct NsaRQ {
   }
 };
 
-// Affine coupling: scale = sigmoid(raw + 2) + 1e-3 (nflows default
-// scale_activation).  v[OFF] = shift, v[OFF+1] = raw scale.
+// Affine coupling: scale = sigmoid(raw + a) + b; a = 2, b = 1e-3 is the nflows default
+// scale_activation, other (a, b) come from a user callable of that family
+// (flows/realnvp.py).  v[OFF] = shift, v[OFF+1] = raw scale.
 struct NsaAffine {
   static constexpr int NP = 2;
   static constexpr int FPC = 8;
@@ -319,11 +321,11 @@ struct NsaAffine {
 
   template <int P, int OFF, bool INV, int NV>
   __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
-                                               const NsaTransformConsts&, float& y, float& ld,
+                                               const NsaTransformConsts& c, float& y, float& ld,
                                                bool& bad) {
     const float shift = v[OFF];
-    const float raw = v[OFF + 1] + 2.0f;
-    const float scale = nsa_rcp(1.0f + nsa_exp(-raw)) + 1e-3f;
+    const float raw = v[OFF + 1] + c.aff_a;
+    const float scale = nsa_rcp(1.0f + nsa_exp(-raw)) + c.aff_b;
     const float ls = nsa_log(scale);
     bad = false;
     if constexpr (INV) { y = (x - shift) / scale; ld = -ls; }

@@ -652,6 +652,8 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
   tc.edge_raw = nsa_bits_to_float(img[NSA_H_EDGE_RAW]);
   tc.edge_d = tc.min_d + nsa_softplus(tc.edge_raw);
   tc.inv_logit_div = 1.0f / nsa_bits_to_float(img[NSA_H_LOGIT_DIV]);
+  tc.aff_a = nsa_bits_to_float(img[NSA_H_AFF_A]);
+  tc.aff_b = nsa_bits_to_float(img[NSA_H_AFF_B]);
   {
     const int K = (int)img[NSA_H_BINS];
     tc.bw_scale = (float)(1.0 - (double)tc.min_bw * K);

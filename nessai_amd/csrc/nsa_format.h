@@ -48,6 +48,8 @@ enum {
   NSA_H_NLAYERS = 27,      // residual blocks (resnet) / hidden layers (mlp)
   NSA_H_BASE_INV_VAR = 28, // float: 1/var of the base Gaussian (1.0 for StandardNormal)
   NSA_H_PREC = 29,         // NSA_PREC_*: arithmetic of the conditioner GEMMs
+  NSA_H_AFF_A = 30,        // float: affine coupling scale = sigmoid(raw + a) + b (default 2)
+  NSA_H_AFF_B = 31,        // float: ... b (default 1e-3)
   NSA_H_WORDS = 32
 };
 

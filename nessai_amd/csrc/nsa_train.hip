@@ -195,6 +195,7 @@ __global__ void __launch_bounds__(256) tr_gemm_tn(int n, int O, int I, const flo
 
 struct TrConsts {
   float tail_bound, min_bw, min_bh, min_d, edge_d, inv_div;
+  float aff_a, aff_b;  // affine coupling: scale = sigmoid(raw + aff_a) + aff_b (nflows default 2, 1e-3)
 };
 
 // one thread per (row, transformed feature).  Forward: saves x, writes y in place,
@@ -403,7 +404,8 @@ __global__ void tr_rq_backward(int n, int d_tr, const int* __restrict__ tr_cols,
 __device__ __forceinline__ void tr_affine_forward_item(int row, int m, int d_tr, int additive,
                                                        const int* __restrict__ tr_cols,
                                                        const float* __restrict__ P, float* __restrict__ X, int ldx,
-                                                       float* __restrict__ xsave, float* __restrict__ logdet) {
+                                                       float* __restrict__ xsave, float* __restrict__ logdet,
+                                                       float aff_a, float aff_b) {
   const int t = row * d_tr + m;
   const int np = additive ? d_tr : 2 * d_tr;
   const int col = tr_cols[m];
@@ -412,7 +414,7 @@ __device__ __forceinline__ void tr_affine_forward_item(int row, int m, int d_tr,
   const float shift = P[(long long)row * np + m];
   float scale = 1.0f, ls = 0.0f;
   if (!additive) {
-    scale = 1.0f / (1.0f + expf(-(P[(long long)row * np + d_tr + m] + 2.0f))) + 1e-3f;
+    scale = 1.0f / (1.0f + expf(-(P[(long long)row * np + d_tr + m] + aff_a))) + aff_b;
     ls = logf(scale);
   }
   X[(long long)row * ldx + col] = x * scale + shift;
@@ -421,11 +423,12 @@ __device__ __forceinline__ void tr_affine_forward_item(int row, int m, int d_tr,
 
 __global__ void tr_affine_forward(int n, int d_tr, int additive, const int* __restrict__ tr_cols,
                                   const float* __restrict__ P, float* __restrict__ X, int ldx,
-                                  float* __restrict__ xsave, float* __restrict__ logdet) {
+                                  float* __restrict__ xsave, float* __restrict__ logdet, float aff_a,
+                                  float aff_b) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * d_tr) return;
   const int row = t / d_tr;
-  tr_affine_forward_item(row, t - row * d_tr, d_tr, additive, tr_cols, P, X, ldx, xsave, logdet);
+  tr_affine_forward_item(row, t - row * d_tr, d_tr, additive, tr_cols, P, X, ldx, xsave, logdet, aff_a, aff_b);
 }
 
 __device__ __forceinline__ void tr_affine_backward_item(int row, int m, int d_tr, int additive,
@@ -434,7 +437,7 @@ __device__ __forceinline__ void tr_affine_backward_item(int row, int m, int d_tr
                                                         const float* __restrict__ xsave, float* __restrict__ X,
                                                         int ldx, float* __restrict__ Gx,
                                                         const float* __restrict__ gld_rows,
-                                                        float* __restrict__ GP) {
+                                                        float* __restrict__ GP, float aff_a, float aff_b) {
   const int t = row * d_tr + m;
   const float gld = gld_rows[row];
   const int np = additive ? d_tr : 2 * d_tr;
@@ -444,8 +447,8 @@ __device__ __forceinline__ void tr_affine_backward_item(int row, int m, int d_tr
   X[(long long)row * ldx + col] = x;
   GP[(long long)row * np + m] = gy;
   if (additive) return;
-  const float sig = 1.0f / (1.0f + expf(-(P[(long long)row * np + d_tr + m] + 2.0f)));
-  const float scale = sig + 1e-3f;
+  const float sig = 1.0f / (1.0f + expf(-(P[(long long)row * np + d_tr + m] + aff_a)));
+  const float scale = sig + aff_b;
   const float s_b = gy * x + gld / scale;
   GP[(long long)row * np + d_tr + m] = s_b * sig * (1.0f - sig);
   Gx[(long long)row * ldx + col] = gy * scale;
@@ -454,11 +457,13 @@ __device__ __forceinline__ void tr_affine_backward_item(int row, int m, int d_tr
 __global__ void tr_affine_backward(int n, int d_tr, int additive, const int* __restrict__ tr_cols,
                                    const float* __restrict__ P, const float* __restrict__ xsave,
                                    float* __restrict__ X, int ldx, float* __restrict__ Gx,
-                                   const float* __restrict__ gld_rows, float* __restrict__ GP) {
+                                   const float* __restrict__ gld_rows, float* __restrict__ GP, float aff_a,
+                                   float aff_b) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * d_tr) return;
   const int row = t / d_tr;
-  tr_affine_backward_item(row, t - row * d_tr, d_tr, additive, tr_cols, P, xsave, X, ldx, Gx, gld_rows, GP);
+  tr_affine_backward_item(row, t - row * d_tr, d_tr, additive, tr_cols, P, xsave, X, ldx, Gx, gld_rows, GP, aff_a,
+                          aff_b);
 }
 
 // ---------------------------------------------------------------------------
@@ -1018,7 +1023,7 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
   const int D = (int)plan[0], H = (int)plan[1], L = (int)plan[2], NL = (int)plan[3];
   const int transform = (int)plan[4], K = (int)plan[5], act = (int)plan[6], npf = (int)plan[7];
   const long long rec = plan[9];
-  TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5]};
+  TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5], consts[8], consts[9]};
   (void)hipMemsetAsync(w.logdet, 0, n * sizeof(float), s);
   (void)hipMemsetAsync(w.scal, 0, 64 * sizeof(float), s);
   for (int b = 0; b < NL; ++b) {
@@ -1079,7 +1084,7 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
                            w.x, D, xsave, w.logdet, c);
       } else {
         hipLaunchKernelGGL(tr_affine_forward, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr,
-                           transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, w.x, D, xsave, w.logdet);
+                           transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, w.x, D, xsave, w.logdet, c.aff_a, c.aff_b);
       }
     } else if (r[0] == TR_BATCHNORM) {
       const int* cols = tabs + r[1];
@@ -1127,7 +1132,7 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
   const int D = (int)plan[0], H = (int)plan[1], L = (int)plan[2], NL = (int)plan[3];
   const int transform = (int)plan[4], K = (int)plan[5], act = (int)plan[6], npf = (int)plan[7];
   const long long rec = plan[9];
-  TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5]};
+  TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5], consts[8], consts[9]};
   for (int b = NL - 1; b >= 0; --b) {
     const long long* r = plan + TR_HDR + b * rec;
     float* lay = w.layer_base + b * w.per_layer;
@@ -1160,7 +1165,8 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
                            xsave, w.x, D, w.gx, w.gld, w.gp, c);
       } else {
         hipLaunchKernelGGL(tr_affine_backward, blocks_for(n * d_tr), dim3(256), 0, s, (int)n, d_tr,
-                           transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, xsave, w.x, D, w.gx, w.gld, w.gp);
+                           transform == NSA_T_ADDITIVE ? 1 : 0, tr_cols, p, xsave, w.x, D, w.gx, w.gld, w.gp, c.aff_a,
+                           c.aff_b);
       }
       if (plan[11] == NSA_NET_MLP) {
         float* zL = h + (long long)L * n * H;

@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_forward(TrfArgs a) {
       tr_rq_forward_item<K>(row, m, a.d_tr, a.tr_cols, a.p, a.X, a.D, a.xsave, a.logdet, a.c);
     } else {
       tr_affine_forward_item(row, m, a.d_tr, a.transform == NSA_T_ADDITIVE ? 1 : 0, a.tr_cols, a.p, a.X, a.D,
-                             a.xsave, a.logdet);
+                             a.xsave, a.logdet, a.c.aff_a, a.c.aff_b);
     }
   }
   TRF_MARK(22);
@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
       tr_rq_backward_item<K>(row, m, a.d_tr, a.tr_cols, a.p, a.xsave, a.X, a.D, a.Gx, a.gld, a.gp, a.c);
     } else {
       tr_affine_backward_item(row, m, a.d_tr, a.transform == NSA_T_ADDITIVE ? 1 : 0, a.tr_cols, a.p, a.xsave, a.X,
-                              a.D, a.Gx, a.gld, a.gp);
+                              a.D, a.Gx, a.gld, a.gp, a.c.aff_a, a.c.aff_b);
     }
   }
   trf_stage(A1, ld, a.h + a.L * nH, H, r0, n, 0, H, H, nullptr, tid);  // h_L

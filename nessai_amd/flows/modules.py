@@ -284,10 +284,14 @@ class CouplingTransform(_Container):
 
 
 class AffineCouplingTransform(CouplingTransform):
+    """``scale = sigmoid(raw + scale_shift) + scale_eps`` (2 and 1e-3: nflows' DEFAULT_SCALE_ACTIVATION)."""
+
     transform = "affine"
 
-    def __init__(self, mask, transform_net_create_fn):
+    def __init__(self, mask, transform_net_create_fn, scale_shift=2.0, scale_eps=1e-3):
         super().__init__(mask, transform_net_create_fn, 2)
+        self.scale_shift = float(scale_shift)
+        self.scale_eps = float(scale_eps)
 
 
 class AdditiveCouplingTransform(CouplingTransform):
@@ -411,6 +415,9 @@ def describe(flow):
                 scale_logits=scale_logits,
                 activation=act,
             )
+            if transform == "affine":
+                this.update(affine_shift=float(getattr(t, "scale_shift", 2.0)),
+                            affine_eps=float(getattr(t, "scale_eps", 1e-3)))
             if transform == "rq":
                 this.update(
                     bins=t.num_bins,

@@ -9,12 +9,44 @@ batch norm between layers (on by default).
 """
 
 import numpy as np
+import math
+
 import torch
 
 from . import modules as M
 from .base import HipFlow
 from .nsf import _reject_unsupported
 from .utils import create_linear_transform, create_pre_transform
+
+
+def identify_scale_activation(fn):
+    """``(a, b)`` such that ``fn(x) == sigmoid(x + a) + b``.
+
+    The reference passes ``scale_activation`` (a callable on tensors) straight to nflows'
+    ``AffineCouplingTransform`` (``src/nessai/flows/realnvp.py:112, 199-203``; exercised with
+    ``lambda x: torch.sigmoid(x + 2) + 1e-3`` in ``tests/test_flows/test_specific_flows.py:32``).  A
+    kernel cannot call Python, so the callable is probed on a grid and must belong to the family the
+    gfx950 affine transform implements - shifted sigmoid plus a floor, of which nflows' default is
+    ``a = 2, b = 1e-3``; anything else raises."""
+    x = torch.linspace(-12.0, 12.0, 193, dtype=torch.float64)
+    try:
+        with torch.no_grad():
+            y = torch.as_tensor(fn(x), dtype=torch.float64)
+            floor = float(torch.as_tensor(fn(torch.tensor([-200.0], dtype=torch.float64)), dtype=torch.float64))
+    except Exception as exc:
+        raise NotImplementedError(f"scale_activation could not be evaluated on a float64 grid: {exc}") from exc
+    if y.shape != x.shape or not torch.isfinite(y).all() or not (0.0 <= floor < 1.0):
+        raise NotImplementedError("scale_activation is not of the form sigmoid(x + a) + b (no gfx950 kernel)")
+    mid = float(y[96]) - floor  # x = 0
+    if not 0.0 < mid < 1.0:
+        raise NotImplementedError("scale_activation is not of the form sigmoid(x + a) + b (no gfx950 kernel)")
+    shift = math.log(mid / (1.0 - mid))
+    if float((torch.sigmoid(x + shift) + floor - y).abs().max()) > 1e-9:
+        raise NotImplementedError(
+            "scale_activation is not of the form sigmoid(x + a) + b: only that family (nflows' default is "
+            "a = 2, b = 1e-3) has a gfx950 kernel"
+        )
+    return round(shift, 9), round(floor, 12)
 
 
 class RealNVP(HipFlow):
@@ -50,11 +82,11 @@ class RealNVP(HipFlow):
             )
         _reject_unsupported(context_features, dropout_probability and net.lower() != "mlp",
                             batch_norm_within_layers and net.lower() != "mlp")
-        if "scale_activation" in kwargs and kwargs["scale_activation"] is not None:
-            raise NotImplementedError(
-                "custom scale_activation has no gfx950 kernel (default: sigmoid(x + 2) + 1e-3)"
-            )
-        kwargs.pop("scale_activation", None)
+        scale_kwargs = {}
+        scale_activation = kwargs.pop("scale_activation", None)
+        if scale_activation is not None and not use_volume_preserving:
+            shift, eps = identify_scale_activation(scale_activation)
+            scale_kwargs = dict(scale_shift=shift, scale_eps=eps)
         if kwargs:
             raise TypeError(f"Unexpected coupling arguments: {sorted(kwargs)}")
 
@@ -105,7 +137,7 @@ class RealNVP(HipFlow):
                 layers.append(M.ActNorm(features=features))
             if linear_transform is not None and linear_transform.lower() != "none":
                 layers.append(create_linear_transform(linear_transform, features))
-            layers.append(coupling(mask=mask[i], transform_net_create_fn=conditioner))
+            layers.append(coupling(mask=mask[i], transform_net_create_fn=conditioner, **scale_kwargs))
             if batch_norm_between_layers:
                 layers.append(M.BatchNorm(features=features))
 

@@ -40,7 +40,7 @@ H_NOPS_FWD, H_OPS_FWD, H_NOPS_INV, H_OPS_INV = 6, 7, 8, 9
 H_NSTAGES_FWD, H_STAGES_FWD, H_NSTAGES_INV, H_STAGES_INV = 10, 11, 12, 13
 H_MAX_STAGE, H_TOTAL, H_OUT_FWD, H_OUT_INV = 14, 15, 16, 17
 H_LOG_Z, H_TAIL_BOUND, H_MIN_BW, H_MIN_BH, H_MIN_D, H_EDGE_RAW = 18, 19, 20, 21, 22, 23
-H_LOGIT_DIV, H_ACT, H_NET, H_NLAYERS, H_BASE_INV_VAR, H_PREC = 24, 25, 26, 27, 28, 29
+H_LOGIT_DIV, H_ACT, H_NET, H_NLAYERS, H_BASE_INV_VAR, H_PREC, H_AFF_A, H_AFF_B = 24, 25, 26, 27, 28, 29, 30, 31
 
 T_NONE, T_RQ, T_AFFINE, T_ADDITIVE = 0, 1, 2, 3
 TRANSFORMS = {"rq": T_RQ, "affine": T_AFFINE, "additive": T_ADDITIVE}
@@ -488,6 +488,8 @@ def pack_flow(desc):
     img[H_MIN_D] = _f32_bits(min_d)
     img[H_EDGE_RAW] = _f32_bits(math.log(math.exp(1 - min_d) - 1))
     img[H_LOGIT_DIV] = _f32_bits(math.sqrt(hidden) if desc.get("scale_logits", True) else 1.0)
+    img[H_AFF_A] = _f32_bits(float(desc.get("affine_shift", 2.0)))   # scale = sigmoid(raw + a) + b
+    img[H_AFF_B] = _f32_bits(float(desc.get("affine_eps", 1e-3)))
     img[H_ACT] = ACTIVATIONS[desc.get("activation", "relu")]
     img[H_NET] = NETS[desc.get("net", "resnet")]
     img[H_NLAYERS] = n_net_layers if n_net_layers is not None else 0

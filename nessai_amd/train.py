@@ -164,7 +164,8 @@ class Trainer:
         inv_div = 1.0 / math.sqrt(desc["hidden"]) if desc.get("scale_logits", True) else 1.0
         consts = [desc.get("tail_bound", 5.0), desc.get("min_bin_width", 1e-3),
                   desc.get("min_bin_height", 1e-3), float(min_d), float(edge_d), inv_div,
-                  1.0 / var, 0.5 * D * math.log(2 * math.pi * var)]
+                  1.0 / var, 0.5 * D * math.log(2 * math.pi * var),
+                  float(desc.get("affine_shift", 2.0)), float(desc.get("affine_eps", 1e-3))]
         self.consts = (ctypes.c_float * len(consts))(*consts)
         self.features = D
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)

@@ -39,6 +39,11 @@ CONFIGS = {
     "rnvp_silu_perm": (RealNVP, O.RealNVP, (7, 33, 3, 1),
                        dict(linear_transform="permutation", activation=torch.nn.functional.silu)),
     "rnvp_pre_bn": (RealNVP, O.RealNVP, (4, 8, 2, 2), dict(pre_transform="batch_norm")),
+    # a user scale_activation of the sigmoid(x + a) + b family (tests/test_flows/test_specific_flows.py:32
+    # of the reference passes the default as a lambda); a, b are recovered by probing the callable
+    "rnvp_custom_scale": (RealNVP, O.RealNVP, (6, 16, 3, 2),
+                          dict(linear_transform="permutation", batch_norm_between_layers=False,
+                               scale_activation=lambda x: torch.sigmoid(x - 0.5) + 0.05)),
 }
 
 

@@ -26,6 +26,9 @@ CASES = {
     "rnvp_additive": (RealNVP, O.RealNVP, (5, 8, 2, 1),
                       dict(linear_transform="permutation", batch_norm_between_layers=False,
                            use_volume_preserving=True)),
+    "rnvp_custom_scale": (RealNVP, O.RealNVP, (6, 16, 3, 2),
+                          dict(linear_transform="permutation", batch_norm_between_layers=False,
+                               scale_activation=lambda x: torch.sigmoid(x - 0.5) + 0.05)),
     "rnvp_c2_default": (RealNVP, O.RealNVP, (16, 32, 4, 2), {}),  # LU-linear + batch norm
     "rnvp_lu_only": (RealNVP, O.RealNVP, (5, 8, 2, 2), dict(batch_norm_between_layers=False)),
     "nsf_bn_lu": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 3, 2),

@@ -142,3 +142,27 @@ def test_separable_prior_terms_are_normalised():
     pts = m.new_point(50, rng=np.random.default_rng(0))
     assert m.in_bounds(pts).all() and np.isfinite(m.log_prior(pts)).all()
     assert np.isfinite(m.log_likelihood(pts)).all()
+
+
+def test_scale_activation_callables_are_identified():
+    """RealNVP(scale_activation=callable): the callable is probed and must be sigmoid(x + a) + b
+    (the reference's own test passes the default as a lambda, test_specific_flows.py:32)."""
+    import torch
+
+    from nessai_amd.flows import RealNVP
+    from nessai_amd.flows.realnvp import identify_scale_activation
+
+    assert identify_scale_activation(lambda x: torch.sigmoid(x + 2) + 1e-3) == (2.0, 0.001)
+    assert identify_scale_activation(lambda x: torch.sigmoid(x - 0.5) + 0.05) == (-0.5, 0.05)
+    for bad in (torch.exp, lambda x: (torch.nn.functional.softplus(x) + 1e-3).clamp(0, 3), lambda x: x[:3],
+                lambda x: torch.sigmoid(2 * x) + 0.1):
+        with pytest.raises(NotImplementedError):
+            identify_scale_activation(bad)
+    flow = RealNVP(2, 2, 2, 2, scale_activation=lambda x: torch.sigmoid(x + 2) + 1e-3)
+    from nessai_amd.flows import modules as M
+
+    desc = M.describe(flow)
+    assert desc["affine_shift"] == 2.0 and desc["affine_eps"] == 1e-3
+    flow = RealNVP(4, 8, 2, 2, scale_activation=lambda x: torch.sigmoid(x - 1.0) + 0.2)
+    assert M.describe(flow)["affine_shift"] == -1.0
+    RealNVP(4, 8, 2, 2, use_volume_preserving=True, scale_activation=torch.exp)  # unused for additive couplings
