@@ -45,6 +45,26 @@ enum { NSA_MODE_APPLY = 0, NSA_MODE_LOGPROB = 1, NSA_MODE_POPULATE = 2 };
 #define NSA_PF 2
 #endif
 
+// Sub-stages along k of a register-fed GEMM with `tiles` output tiles (same rule as pack.ksplit):
+// for the 128-wide conditioners (HT = 4) packed weights above 16 KiB are dealt to 2 or 4 consecutive
+// stages, the accumulators live across them: 2 x 17 KiB of stage buffers instead of 2 x 64 KiB.
+constexpr int nsa_ksplit(int tiles, int ht) {
+  if (ht < 4) return 1;  // <= 64 hidden units: the largest stage is 25 KiB, splitting only adds barriers
+  int ks = 1;
+  while (tiles * ht * 4096 / ks > 16384 && ks < 2 * ht) ks *= 2;
+  return ks;
+}
+
+// f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
+template <class F, int... I>
+__device__ __forceinline__ void nsa_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void nsa_static_for(F&& f) {
+  nsa_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 struct NsaLaunch {
   const uint32_t* image;  // device flow image (nsa_format.h)
   int direction;          // NSA_DIR_*
@@ -183,19 +203,19 @@ __device__ __forceinline__ void nsa_load_bias(const float* bias, int half, f32x1
 }
 
 // Input from registers (D layout of the previous layer): in[16*HT] -> OT tiles.
-// W layout: [OT][4*HT][64 lanes][4].
-template <int HT, int OT>
+// W layout of the sub-stage: [OT][NS4][64 lanes][4]; it covers the step groups [S0, S0 + NS4) of `in`.
+template <int HT, int OT, int S0 = 0, int NS4 = 4 * HT>
 __device__ __forceinline__ void nsa_dense_regs(const float* w, const float (&in)[16 * HT], int lane,
                                                f32x16 (&acc)[OT]) {
 #pragma unroll
-  for (int s4 = 0; s4 < 4 * HT; ++s4) {
+  for (int s4 = 0; s4 < NS4; ++s4) {
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
-      const f32x4 a = *(const f32x4*)(w + ((ot * (4 * HT) + s4) * 64 + lane) * 4);
-      acc[ot] = nsa_mfma(a[0], in[4 * s4 + 0], acc[ot]);
-      acc[ot] = nsa_mfma(a[1], in[4 * s4 + 1], acc[ot]);
-      acc[ot] = nsa_mfma(a[2], in[4 * s4 + 2], acc[ot]);
-      acc[ot] = nsa_mfma(a[3], in[4 * s4 + 3], acc[ot]);
+      const f32x4 a = *(const f32x4*)(w + ((ot * NS4 + s4) * 64 + lane) * 4);
+      acc[ot] = nsa_mfma(a[0], in[4 * (S0 + s4) + 0], acc[ot]);
+      acc[ot] = nsa_mfma(a[1], in[4 * (S0 + s4) + 1], acc[ot]);
+      acc[ot] = nsa_mfma(a[2], in[4 * (S0 + s4) + 2], acc[ot]);
+      acc[ot] = nsa_mfma(a[3], in[4 * (S0 + s4) + 3], acc[ot]);
     }
   }
 }
@@ -255,29 +275,29 @@ __device__ __forceinline__ void nsa_split_regs(const float (&in)[16 * HT], NsaSp
   }
 }
 
-// W layout: [OT][2*HT steps][part][64 lanes][8 bf16]  (4 words per lane and part)
-template <int HT, int OT>
+// W layout of the sub-stage: [OT][NS steps][part][64 lanes][8 bf16] (4 words per lane and part); it
+// covers the k steps [S0, S0 + NS) of the split activations.  The A operands (LDS) of unit
+// u + NSA_PF are fetched before the MFMAs of unit u are issued, so that the LDS latency runs under the
+// matrix pipe instead of in front of it.
+template <int HT, int OT, int S0 = 0, int NS = 2 * HT>
 __device__ __forceinline__ void nsa_dense_regs16(const float* w, const NsaSplit<HT>& sp, int lane,
                                                  f32x16 (&acc)[OT]) {
-  constexpr int S = 2 * HT;
-  // the A operands (LDS) of unit u + NSA_PF are fetched before the MFMAs of unit u are issued, so
-  // that the LDS latency runs under the matrix pipe instead of in front of it
-  constexpr int U = S * OT;  // unit u = s * OT + ot
+  constexpr int U = NS * OT;  // unit u = s * OT + ot
   bf16x8 ah[NSA_PF + 1], al[NSA_PF + 1];
 #pragma unroll
   for (int u = 0; u < NSA_PF && u < U; ++u) {
-    ah[u] = *(const bf16x8*)(w + ((((u % OT) * S + u / OT) * 2 + 0) * 64 + lane) * 4);
-    al[u] = *(const bf16x8*)(w + ((((u % OT) * S + u / OT) * 2 + 1) * 64 + lane) * 4);
+    ah[u] = *(const bf16x8*)(w + ((((u % OT) * NS + u / OT) * 2 + 0) * 64 + lane) * 4);
+    al[u] = *(const bf16x8*)(w + ((((u % OT) * NS + u / OT) * 2 + 1) * 64 + lane) * 4);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int s = u / OT, ot = u % OT;
     if (u + NSA_PF < U) {
       const int s2 = (u + NSA_PF) / OT, ot2 = (u + NSA_PF) % OT;
-      ah[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * S + s2) * 2 + 0) * 64 + lane) * 4);
-      al[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * S + s2) * 2 + 1) * 64 + lane) * 4);
+      ah[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * NS + s2) * 2 + 0) * 64 + lane) * 4);
+      al[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * NS + s2) * 2 + 1) * 64 + lane) * 4);
     }
-    acc[ot] = nsa_mfma_x3(ah[u % (NSA_PF + 1)], al[u % (NSA_PF + 1)], sp.hi[s], sp.lo[s], acc[ot]);
+    acc[ot] = nsa_mfma_x3(ah[u % (NSA_PF + 1)], al[u % (NSA_PF + 1)], sp.hi[S0 + s], sp.lo[S0 + s], acc[ot]);
   }
 }
 
@@ -359,63 +379,25 @@ __device__ __forceinline__ void nsa_run_phases(typename TP::State (&st)[TP::FPC]
   (nsa_run_phase<TP, INV, LO + I, NV>(st, v, cols, xrow, dummy_col, tc, logdet, n_bad), ...);
 }
 
-// MFMAs of one chunk of the last conditioner layer (-> acc, cols).  The A operands (LDS) of
-// k-step group g+1 are fetched before the MFMAs of group g.
-template <int HT, class TP, int PREC>
+// MFMAs of sub-stage J of one chunk of the last conditioner layer (-> acc; cols and the bias come
+// with sub-stage 0).
+template <int HT, class TP, int PREC, int J>
 __device__ __forceinline__ void nsa_chunk_gemm(const float* stg, const float (&h)[16 * HT],
                                                const NsaSplit<HT>& hs, int lane, int half,
                                                f32x16 (&acc)[TP::C], int (&cols)[TP::FPC]) {
   constexpr int TABW = (2 * TP::FPC + 3) & ~3;
-  constexpr int G = (PREC == NSA_PREC_BF16X3) ? 2 * HT : 4 * HT;  // k-step groups
-  const int* tr_tab = (const int*)stg;
-  const float* bias = stg + TABW;
-  const float* w = bias + 32 * TP::C;
+  constexpr int KS = nsa_ksplit(TP::C, HT);
+  const float* w = stg;
+  if constexpr (J == 0) {
+    const int* tr_tab = (const int*)stg;
+    const float* bias = stg + TABW;
+    w = bias + 32 * TP::C;
 #pragma unroll
-  for (int q = 0; q < TP::FPC; ++q) cols[q] = tr_tab[half * TP::FPC + q];
-  nsa_load_bias<TP::C>(bias, half, acc);
-  if constexpr (PREC == NSA_PREC_BF16X3) {
-    constexpr int U = G * TP::C;  // unit u = g * C + ot; operands fetched NSA_PF units ahead
-    bf16x8 ah[NSA_PF + 1], al[NSA_PF + 1];
-#pragma unroll
-    for (int u = 0; u < NSA_PF && u < U; ++u) {
-      ah[u] = *(const bf16x8*)(w + ((((u % TP::C) * G + u / TP::C) * 2 + 0) * 64 + lane) * 4);
-      al[u] = *(const bf16x8*)(w + ((((u % TP::C) * G + u / TP::C) * 2 + 1) * 64 + lane) * 4);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int g = u / TP::C, ot = u % TP::C;
-      if (u + NSA_PF < U) {
-        const int g2 = (u + NSA_PF) / TP::C, ot2 = (u + NSA_PF) % TP::C;
-        ah[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * G + g2) * 2 + 0) * 64 + lane) * 4);
-        al[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * G + g2) * 2 + 1) * 64 + lane) * 4);
-      }
-      acc[ot] = nsa_mfma_x3(ah[u % (NSA_PF + 1)], al[u % (NSA_PF + 1)], hs.hi[g], hs.lo[g], acc[ot]);
-    }
-  } else {
-    f32x4 a_cur[TP::C];
-#pragma unroll
-    for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = *(const f32x4*)(w + ((ot * G + 0) * 64 + lane) * 4);
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      f32x4 a_nxt[TP::C];
-      if (g + 1 < G) {
-#pragma unroll
-        for (int ot = 0; ot < TP::C; ++ot)
-          a_nxt[ot] = *(const f32x4*)(w + ((ot * G + g + 1) * 64 + lane) * 4);
-      }
-#pragma unroll
-      for (int ot = 0; ot < TP::C; ++ot) {
-        acc[ot] = nsa_mfma(a_cur[ot][0], h[4 * g + 0], acc[ot]);
-        acc[ot] = nsa_mfma(a_cur[ot][1], h[4 * g + 1], acc[ot]);
-        acc[ot] = nsa_mfma(a_cur[ot][2], h[4 * g + 2], acc[ot]);
-        acc[ot] = nsa_mfma(a_cur[ot][3], h[4 * g + 3], acc[ot]);
-      }
-      if (g + 1 < G) {
-#pragma unroll
-        for (int ot = 0; ot < TP::C; ++ot) a_cur[ot] = a_nxt[ot];
-      }
-    }
+    for (int q = 0; q < TP::FPC; ++q) cols[q] = tr_tab[half * TP::FPC + q];
+    nsa_load_bias<TP::C>(bias, half, acc);
   }
+  if constexpr (PREC == NSA_PREC_BF16X3) nsa_dense_regs16<HT, TP::C, J * (2 * HT / KS), 2 * HT / KS>(w, hs, lane, acc);
+  else nsa_dense_regs<HT, TP::C, J * (4 * HT / KS), 4 * HT / KS>(w, h, lane, acc);
 }
 
 // one coupling layer -----------------------------------------------------------
@@ -431,16 +413,23 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
   float h[16 * HT];
 
   // one H -> H layer from registers: out = W in + b
+  // (nsa_ksplit(HT, HT) stages along k; the caller closes the LAST one after its own epilogue)
   auto hidden_layer = [&](const float (&in)[16 * HT], f32x16 (&acc)[HT]) {
-    const float* st = pipe.begin();
-    nsa_load_bias<HT>(st, half, acc);
-    if constexpr (BF) {
-      NsaSplit<HT> sp;
-      nsa_split_regs<HT>(in, sp);
-      nsa_dense_regs16<HT, HT>(st + 32 * HT, sp, lane, acc);
-    } else {
-      nsa_dense_regs<HT, HT>(st + 32 * HT, in, lane, acc);
-    }
+    constexpr int KS = nsa_ksplit(HT, HT);
+    NsaSplit<HT> sp;
+    if constexpr (BF) nsa_split_regs<HT>(in, sp);
+    nsa_static_for<KS>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const float* st = pipe.begin();
+      const float* w = st;
+      if constexpr (J == 0) {
+        nsa_load_bias<HT>(st, half, acc);
+        w = st + 32 * HT;
+      }
+      if constexpr (BF) nsa_dense_regs16<HT, HT, J * (2 * HT / KS), 2 * HT / KS>(w, sp, lane, acc);
+      else nsa_dense_regs<HT, HT, J * (4 * HT / KS), 4 * HT / KS>(w, in, lane, acc);
+      if constexpr (J + 1 < KS) pipe.end();
+    });
   };
 
   // layer 0: identity features (x tile) -> hidden
@@ -503,8 +492,12 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
   for (int c = 0; c < n_chunks; ++c) {
     f32x16 acc[TP::C];
     int cols[TP::FPC];
-    const float* st = pipe.begin();
-    nsa_chunk_gemm<HT, TP, PREC>(st, h, hs, lane, half, acc, cols);
+    nsa_static_for<nsa_ksplit(TP::C, HT)>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const float* st = pipe.begin();
+      nsa_chunk_gemm<HT, TP, PREC, J>(st, h, hs, lane, half, acc, cols);
+      if constexpr (J + 1 < nsa_ksplit(TP::C, HT)) pipe.end();
+    });
     float v[16 * TP::C];
 #pragma unroll
     for (int t = 0; t < TP::C; ++t)

@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define NSA_MAGIC 0x3141534e /* "NSA1" */
-#define NSA_VERSION 4
+#define NSA_VERSION 5
 
 // header word indices
 enum {
@@ -72,8 +72,10 @@ enum { NSA_PREC_F32 = 0, NSA_PREC_BF16X3 = 1 };
 // Stage blob layouts (word offsets inside the blob; every section is padded
 // to a multiple of 4 words, every blob to a multiple of 256 words):
 //   coupling layer 0 : id_tab[2*n_steps0] | bias[32*HT] | W[HT][n_steps0/4][64][4]
-//   hidden layer     : bias[32*HT]        | W[HT][4*HT][64][4]
-//   final chunk      : tr_tab[pad4(2*FPC)] | bias[32*C] | W[C][4*HT][64][4]
+//   hidden layer     : bias[32*HT]        | W[HT][4*HT/KS][64][4]      (sub-stage 0 of KS; the others: W only)
+//   final chunk      : tr_tab[pad4(2*FPC)] | bias[32*C] | W[C][4*HT/KS][64][4]   (likewise)
+//   KS = nsa_ksplit(output tiles, HT): a GEMM whose packed weights exceed 16 KiB is dealt to 2 or 4
+//   consecutive stages along k (its accumulators live across them).
 //   dense            : in_tab[2*n_steps] | pre[2*n_steps] | bias[32*OT] | W[OT][n_steps/4][64][4]
 //   elementwise      : a[D4] | b[D4] | c[D4] | d[D4]  (D4 = pad4(D); y = ((x-a)/b)*c + d per physical column)
 //

@@ -31,7 +31,7 @@ import math
 import numpy as np
 
 MAGIC = 0x3141534E
-VERSION = 4
+VERSION = 5
 HEADER_WORDS = 32
 OP_WORDS = 4
 
@@ -69,6 +69,27 @@ def transform_policy(transform, bins):
     if transform == "additive":
         return 1, 16, 1
     raise ValueError(f"unknown transform {transform}")
+
+
+def ksplit(tiles, ht):
+    """Number of sub-stages along k of a register-fed GEMM with ``tiles`` output tiles.
+
+    A stage must fit an LDS buffer; the packed weights of one GEMM are ``tiles * ht * 4`` KiB
+    (32 outputs x 32 inputs x 4 bytes per tile pair, either precision).  Above 16 KiB the k steps
+    are dealt to 2 or 4 consecutive stages (the accumulators live across them).  Applied to the
+    128-wide conditioners (hidden tiles = 4, config 4), whose 64 KiB hidden-layer stages left room
+    for 2 waves per workgroup only: with 17 KiB stages two 4-wave workgroups share a CU.  Same rule
+    as ``nsa_ksplit`` in ``csrc/nsa_flow_kernel.h``."""
+    if ht < 4:
+        # a 64-wide conditioner's largest stage is 25 KiB: 12 waves per CU already run from one
+        # double buffer, and the extra stage barriers of a split cost more than a third workgroup
+        # per CU brings (1.92 against 1.76 ms per 1e6 rows of config 3)
+        return 1
+    nbytes = tiles * ht * 4096
+    ks = 1
+    while nbytes // ks > 16384 and ks < 2 * ht:
+        ks *= 2
+    return ks
 
 
 def hidden_tiles(hidden):
@@ -257,19 +278,25 @@ class _CouplingBlobs:
             pack_w(w0, _plain_out_rows(ht, hidden), in_cols0),
         )
 
-        self.hidden_layers = []
+        def pack_split(w, out_rows, tiles):
+            """Packed weights dealt to ksplit(tiles, ht) sub-stages along k."""
+            ks = ksplit(tiles, ht)
+            per = len(reg_cols) // ks
+            return [pack_w(w, out_rows, reg_cols[j * per : (j + 1) * per]) for j in range(ks)]
+
+        self.hidden_layers = []  # (bias, [W of sub-stage 0, 1, ...])
         for w, b in layers[1:-1]:
             assert w.shape == (hidden, hidden)
             self.hidden_layers.append(
                 (
                     pack_bias(b, _plain_out_rows(ht, hidden)),
-                    pack_w(w, _plain_out_rows(ht, hidden), reg_cols),
+                    pack_split(w, _plain_out_rows(ht, hidden), ht),
                 )
             )
 
         wf, bf = layers[-1]
         assert wf.shape[1] == hidden
-        self.chunks = []  # (feature slots [2*fpc] (index into transform_idx or -1), bias, W)
+        self.chunks = []  # (feature slots [2*fpc] (index into transform_idx or -1), bias, [W of sub-stage 0, 1, ...])
         for c in range(self.n_chunks):
             out_rows = []
             for t in range(n_tiles_c):
@@ -289,7 +316,7 @@ class _CouplingBlobs:
                 for q in range(fpc):
                     m = c * 2 * fpc + half * fpc + q
                     slots.append(m if m < self.d_tr else -1)
-            self.chunks.append((slots, pack_bias(bf, out_rows), pack_w(wf, out_rows, reg_cols)))
+            self.chunks.append((slots, pack_bias(bf, out_rows), pack_split(wf, out_rows, n_tiles_c)))
 
     @staticmethod
     def _decode(transform, v, n_params):
@@ -387,14 +414,18 @@ def pack_flow(desc):
                 for k, f in enumerate(identity_idx):
                     id_tab[k] = cur[int(f)]
                 stages.append(add_blob(_stage(id_tab, *packed.layer0)))
-                for bias, w in packed.hidden_layers:
-                    stages.append(add_blob(_stage(bias, w)))
-                for slots, bias, w in packed.chunks:
+                for bias, subs in packed.hidden_layers:
+                    stages.append(add_blob(_stage(bias, subs[0])))
+                    for w in subs[1:]:
+                        stages.append(add_blob(_stage(w)))
+                for slots, bias, subs in packed.chunks:
                     tr_tab = np.full(tabw, -1, dtype=np.int32)
                     for k, m in enumerate(slots):
                         if m >= 0:
                             tr_tab[k] = cur[int(transform_idx[m])]
-                    stages.append(add_blob(_stage(tr_tab, bias, w)))
+                    stages.append(add_blob(_stage(tr_tab, bias, subs[0])))
+                    for w in subs[1:]:
+                        stages.append(add_blob(_stage(w)))
                 ops.append([OP_COUPLING, packed.n_steps0, packed.n_chunks, 0])
             elif kind == "elementwise":
                 a, b, c, d, ld = tr[2] if inverse else tr[1]

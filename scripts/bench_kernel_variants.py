@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-VARIANTS = [(2, 4), (2, 8), (3, 6), (3, 12), (3, 3)]
+VARIANTS = [(2, 4), (3, 4), (3, 12), (2, 8), (3, 6)]
 QUICK = "--quick" in sys.argv  # default geometry, split-bf16 only
 
 

@@ -158,11 +158,25 @@ class Emulator:
                 h = np.concatenate([acc[ot] for ot in range(HT)], axis=1)  # [64][16*HT]
 
                 def from_regs(words, n_ot, inp, bias):
-                    if self.bf16:
-                        return self._dense16(words[: n_ot * 2 * HT * 512], n_ot, 2 * HT,
-                                             lambda s: inp[:, 8 * s : 8 * s + 8], self._bias(bias, n_ot))
-                    return self._dense(words.view(np.float32)[: n_ot * 16 * HT * 64], n_ot, 16 * HT,
-                                       lambda s: inp[:, s], self._bias(bias, n_ot))
+                    """A register-fed GEMM: ``words`` = the first sub-stage behind its tables and
+                    bias; further sub-stages along k (pack.ksplit) are whole stages of their own."""
+                    nonlocal stage
+                    ks = P.ksplit(n_ot, HT)
+                    acc = self._bias(bias, n_ot)
+                    for j in range(ks):
+                        if j:
+                            words = self._stage_words(inverse, stage)
+                            stage += 1
+                        if self.bf16:
+                            per = 2 * HT // ks
+                            acc = self._dense16(words[: n_ot * per * 512], n_ot, per,
+                                                lambda s, j=j, per=per: inp[:, 8 * (j * per + s) : 8 * (j * per + s) + 8],
+                                                acc)
+                        else:
+                            per = 16 * HT // ks
+                            acc = self._dense(words.view(np.float32)[: n_ot * per * 64], n_ot, per,
+                                              lambda s, j=j, per=per: inp[:, j * per + s], acc)
+                    return acc
 
                 def hidden(inp):
                     nonlocal stage

@@ -105,6 +105,25 @@ def test_image_header_and_alignment():
         assert off % 256 == 0 and n % 256 == 0 and off + n <= len(img)
 
 
+def test_wide_conditioner_stages_are_split_along_k():
+    """128 hidden units (config 4): the 64 KiB hidden-layer GEMMs and the 48 KiB chunk GEMMs are
+    dealt to four stages along k each (pack.ksplit), so that no stage exceeds 17 KiB; the emulator,
+    which walks the stages exactly as the kernel does, still reproduces the oracle."""
+    assert P.ksplit(3, 2) == 1 and P.ksplit(4, 4) == 4 and P.ksplit(3, 4) == 4 and P.ksplit(1, 4) == 1
+    torch.manual_seed(1)
+    flow = O.NeuralSplineFlow(12, 128, 2, 1).eval()
+    for precision in ("f32", "bf16x3"):
+        img = P.pack_flow(dict(describe(flow), precision=precision))
+        assert img[P.H_HT] == 4 and img[P.H_MAX_STAGE] * 4 <= 17 * 1024
+        # 2 couplings x (1 layer-0 + 2 x 4 hidden + 2 chunks x 4) stages
+        assert img[P.H_NSTAGES_FWD] == 2 * (1 + 8 + 8)
+        x = torch.randn(32, 12)
+        with torch.no_grad():
+            z_ref, ld_ref = flow.forward(x)
+        z, ld = Emulator(img).run(x.numpy(), inverse=False)
+        assert np.abs(z - z_ref.numpy()).max() < 2e-4 and np.abs(ld - ld_ref.numpy()).max() < 5e-4
+
+
 def test_unsupported_configurations_fail_loudly():
     with pytest.raises(ValueError, match="No gfx950 kernel instance"):
         NeuralSplineFlow(4, 8, 2, 2, num_bins=7)
