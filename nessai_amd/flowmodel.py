@@ -41,6 +41,10 @@ DEFAULT_TRAINING_CONFIG = dict(  # src/nessai/flowmodel/config.py:31-46
     use_dataloader=False,
     optimiser="adamw",
     optimiser_kwargs=None,
+    # not in the reference: bit-reproducible fits.  The fused coupling kernels add the weight gradients
+    # of a workgroup's rows with float atomics (run-to-run differences in the last bits); True selects
+    # the layer-wise kernels, whose reductions run in a fixed order (about 2x slower per step).
+    deterministic=False,
 )
 
 

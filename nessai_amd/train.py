@@ -17,6 +17,7 @@ initialisation) - i.e. every RealNVP / NeuralSplineFlow configuration of the
 reference except conditional inputs, which raise.
 """
 
+import contextlib
 import ctypes
 import math
 import os
@@ -330,6 +331,24 @@ def get_trainer(flow_model):
     return flow_model._trainer
 
 
+@contextlib.contextmanager
+def _training_kernels(deterministic):
+    """``training_config["deterministic"]``: run this fit on the layer-wise kernels, whose reductions
+    have a fixed order (the fused coupling kernels add weight gradients with float atomics).  The
+    library reads the switch per call."""
+    before = os.environ.get("NESSAI_AMD_TRAIN_FUSED")
+    if deterministic:
+        os.environ["NESSAI_AMD_TRAIN_FUSED"] = "0"
+    try:
+        yield
+    finally:
+        if deterministic:
+            if before is None:
+                os.environ.pop("NESSAI_AMD_TRAIN_FUSED", None)
+            else:
+                os.environ["NESSAI_AMD_TRAIN_FUSED"] = before
+
+
 def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=None, weights=None):
     tc = flow_model.training_config
     trainer = get_trainer(flow_model)
@@ -389,43 +408,44 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
 
     use_graph = os.environ.get("NESSAI_AMD_EPOCH_GRAPH", "1") != "0"
     graph = None
-    for epoch in range(1, max_epochs + 1):
-        p = torch.randperm(n_train).to(train_data.device)
-        torch.index_select(train_data, 0, p, out=epoch_rows)
-        if epoch_w is not None:
-            torch.index_select(w_train, 0, p, out=epoch_w)
-        if noise_scale:
-            epoch_rows.add_(noise_scale * torch.randn_like(epoch_rows))
-        if tc.get("annealing"):
-            # CosineAnnealingLR(T_max=max_epochs, eta_min=0), stepped once per epoch (base.py:449-450, 628-631)
-            trainer.lr = trainer.base_lr * 0.5 * (1.0 + math.cos(math.pi * (epoch - 1) / max_epochs))
-        trainer.opt[0] = trainer.lr
-        if graph is not None:
-            graph.replay()
-            trainer.step_count += len(bounds)
-        elif use_graph and epoch == 2:
-            graph = torch.cuda.CUDAGraph()
-            steps_before = trainer.step_count
-            with torch.cuda.graph(graph):
+    with _training_kernels(tc.get("deterministic")):
+        for epoch in range(1, max_epochs + 1):
+            p = torch.randperm(n_train).to(train_data.device)
+            torch.index_select(train_data, 0, p, out=epoch_rows)
+            if epoch_w is not None:
+                torch.index_select(w_train, 0, p, out=epoch_w)
+            if noise_scale:
+                epoch_rows.add_(noise_scale * torch.randn_like(epoch_rows))
+            if tc.get("annealing"):
+                # CosineAnnealingLR(T_max=max_epochs, eta_min=0), stepped once per epoch (base.py:449-450, 628-631)
+                trainer.lr = trainer.base_lr * 0.5 * (1.0 + math.cos(math.pi * (epoch - 1) / max_epochs))
+            trainer.opt[0] = trainer.lr
+            if graph is not None:
+                graph.replay()
+                trainer.step_count += len(bounds)
+            elif use_graph and epoch == 2:
+                graph = torch.cuda.CUDAGraph()
+                steps_before = trainer.step_count
+                with torch.cuda.graph(graph):
+                    run_epoch()
+                trainer.step_count = steps_before  # capture records, it does not run
+                graph.replay()
+                trainer.step_count += len(bounds)
+            else:
                 run_epoch()
-            trainer.step_count = steps_before  # capture records, it does not run
-            graph.replay()
-            trainer.step_count += len(bounds)
-        else:
-            run_epoch()
-            trainer._actnorm_initialised()
-        if has_val:
-            both = torch.cat([trainer.loss_acc, trainer.val_acc]).cpu().numpy()  # the epoch's one sync
-            loss, val_loss = float(both[0]) / len(bounds), float(both[1])
-        else:
-            loss, val_loss = float(trainer.loss_acc.item()) / len(bounds), np.nan
-        history["loss"].append(loss)
-        history["val_loss"].append(val_loss)
-        if validate and (val_loss < best_val_loss):
-            best_epoch, best_val_loss = epoch, val_loss
-            trainer.best.copy_(trainer.flat)
-        if validate and (epoch - best_epoch > patience):
-            break
+                trainer._actnorm_initialised()
+            if has_val:
+                both = torch.cat([trainer.loss_acc, trainer.val_acc]).cpu().numpy()  # the epoch's one sync
+                loss, val_loss = float(both[0]) / len(bounds), float(both[1])
+            else:
+                loss, val_loss = float(trainer.loss_acc.item()) / len(bounds), np.nan
+            history["loss"].append(loss)
+            history["val_loss"].append(val_loss)
+            if validate and (val_loss < best_val_loss):
+                best_epoch, best_val_loss = epoch, val_loss
+                trainer.best.copy_(trainer.flat)
+            if validate and (epoch - best_epoch > patience):
+                break
     if validate:
         trainer.flat.copy_(trainer.best)
     model._image_key = None  # weights changed behind torch's version counters

@@ -374,3 +374,29 @@ def test_annealing_and_noise_options(tmp_path):
                         training_config=dict(optimiser="rmsprop"), output=str(tmp_path), rng=rng)
         bad.initialise()
         bad.train(data, max_epochs=1)
+
+
+def test_deterministic_training_is_bit_reproducible(tmp_path):
+    """``training_config["deterministic"]``: the layer-wise kernels with fixed-order reductions - two
+    fits from the same seed end with identical weights (the fused kernels' float atomics do not
+    promise that) and agree with the default fit to float32 round-off."""
+    from nessai_amd.flowmodel import FlowModel
+
+    data = np.random.default_rng(3).normal(size=(600, 6))
+    cfg = dict(n_inputs=6, n_neurons=16, n_blocks=3, n_layers=2, ftype="nsf")
+
+    def fit(deterministic, tag):
+        torch.manual_seed(7)
+        fm = FlowModel(flow_config=cfg, training_config=dict(batch_size=250, max_epochs=8, patience=20,
+                                                            deterministic=deterministic),
+                       output=str(tmp_path / tag), rng=np.random.default_rng(7))
+        fm.initialise()
+        hist = fm.train(data)
+        return fm.model.trainer().flat.detach().cpu().clone(), hist
+
+    a, ha = fit(True, "a")
+    b, hb = fit(True, "b")
+    assert torch.equal(a, b) and ha["val_loss"] == hb["val_loss"]
+    c, hc = fit(False, "c")
+    assert float((a - c).abs().max()) < 5e-3 and abs(ha["loss"][-1] - hc["loss"][-1]) < 1e-2
+    assert "NESSAI_AMD_TRAIN_FUSED" not in os.environ
