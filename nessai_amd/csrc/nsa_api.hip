@@ -147,8 +147,12 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   const size_t stage_bytes = 2 * (size_t)h[NSA_H_MAX_STAGE] * 4;
   // + the populate epilogue's per-column constants: 4 double tables and one int table (nsa_flow_kernel.h)
   const size_t epi_bytes = (p.mode == NSA_MODE_POPULATE) ? (size_t)((D + 3) & ~3) * (4 * 8 + 4) : 0;
+  // + the direction's program (stage table + op table), read from LDS at every stage / op
+  const bool inv = p.direction == NSA_DIR_INVERSE;
+  const size_t prog_bytes = (((size_t)2 * h[inv ? NSA_H_NSTAGES_INV : NSA_H_NSTAGES_FWD] +
+                              (size_t)NSA_OP_WORDS * h[inv ? NSA_H_NOPS_INV : NSA_H_NOPS_FWD] + 3) & ~(size_t)3) * 4;
   auto lds_of = [&](int w) {
-    return ((((size_t)w * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + stage_bytes + epi_bytes;
+    return ((((size_t)w * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + stage_bytes + epi_bytes + prog_bytes;
   };
   auto per_cu_of = [&](int w) {
     long long c = (long long)(g_max_lds / lds_of(w));
@@ -182,6 +186,12 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   long long grid = (per_cu * g_num_cus + n_flows - 1) / n_flows;
   if (max_groups > 0 && grid > max_groups) grid = max_groups;
   if (grid > n_groups) grid = n_groups;
+#ifdef NSA_TIMELINE
+  {
+    const char* tl = getenv("NSA_TL_PTR");  // diagnostic build: device uint64[16] the waves add their section cycles to
+    p.dbg = tl != nullptr ? (unsigned long long*)strtoull(tl, nullptr, 0) : nullptr;
+  }
+#endif
   hipError_t e = fn(&p, (unsigned)grid, (unsigned)n_flows, (unsigned)(nw * 64), lds, stream);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "flow kernel launch: %s", hipGetErrorString(e));
   return NSA_OK;

@@ -45,11 +45,39 @@ enum { NSA_MODE_APPLY = 0, NSA_MODE_LOGPROB = 1, NSA_MODE_POPULATE = 2 };
 #define NSA_PF 2
 #endif
 
+// Diagnostic build -DNSA_TIMELINE (scripts/timeline.py; never the shipped library): every wave sums
+// the shader-clock cycles it spends in each section of the tile loop (s_memtime at the section
+// boundaries, fenced so that the compiler does not move work across them) and adds them to
+// NsaLaunch::dbg at exit.  Slots: 0 fill + prologue, 1 layer-0 GEMM issue, 2 layer-0 tail,
+// 3 hidden GEMM issue, 4 hidden tail (activation / residual), 5 chunk GEMM issue, 6 element-wise
+// transform, 7 wait for the next stage's copy, 8 stage barrier, 9 epilogue, 10 other ops, 11 loop top,
+// 12 issue of the next stage's copy, 13 bias / table reads in front of a GEMM;
+// 14 = tiles, 15 = waves.
+#ifdef NSA_TIMELINE
+struct NsaTl {
+  unsigned long long acc[14];
+  unsigned long long last;
+};
+__device__ __forceinline__ void nsa_tl_mark(NsaTl& t, int slot) {
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long now = __builtin_readcyclecounter();
+  __builtin_amdgcn_sched_barrier(0);
+  t.acc[slot] += now - t.last;
+  t.last = now;
+}
+#define NSA_TL(pipe, slot) nsa_tl_mark((pipe).tl, slot)
+#else
+#define NSA_TL(pipe, slot)
+#endif
+
 // Sub-stages along k of a register-fed GEMM with `tiles` output tiles (same rule as pack.ksplit):
 // for the 128-wide conditioners (HT = 4) packed weights above 16 KiB are dealt to 2 or 4 consecutive
 // stages, the accumulators live across them: 2 x 17 KiB of stage buffers instead of 2 x 64 KiB.
+#ifndef NSA_KSPLIT_MIN_HT
+#define NSA_KSPLIT_MIN_HT 4  // diagnostic builds lower it together with NESSAI_AMD_KSPLIT_MIN_HT (pack.py)
+#endif
 constexpr int nsa_ksplit(int tiles, int ht) {
-  if (ht < 4) return 1;  // <= 64 hidden units: the largest stage is 25 KiB, splitting only adds barriers
+  if (ht < NSA_KSPLIT_MIN_HT) return 1;  // <= 64 hidden units: the largest stage is 25 KiB, splitting only adds barriers
   int ks = 1;
   while (tiles * ht * 4096 / ks > 16384 && ks < 2 * ht) ks *= 2;
   return ks;
@@ -114,6 +142,9 @@ struct NsaLaunch {
   // that fail the reference's finiteness / unit-hypercube checks
   float* xp_out;
   double unit_eps;
+#ifdef NSA_TIMELINE
+  unsigned long long* dbg;
+#endif
 };
 
 // x' -> x maps of the populate epilogue (inverse_reparameterise of the reference):
@@ -143,41 +174,84 @@ __device__ __forceinline__ double nsa_log_prior_term(int kind, double x, const d
 
 // double-buffered weight-stage pipeline -------------------------------------
 
+// The copy of a stage is issued in NSA_COPY_PARTS instalments: the LDS-DMA path of a CU lands about
+// one 1 KiB piece per ~85 cycles, and a wave that issues a global_load_lds behind a full queue is
+// held at that instruction - 25 pieces issued by all waves at the top of a stage kept every wave
+// of the workgroup there for ~1.5 k cycles (scripts/timeline.py).  Part 0 goes out at the top of the
+// stage, the rest after the stage's MFMAs have been issued.
+#ifndef NSA_COPY_PARTS
+#define NSA_COPY_PARTS 2
+#endif
+
 struct NsaStagePipe {
   const uint32_t* img;
-  const uint32_t* table;  // {src word offset, n words} per stage
+  const uint32_t* table;  // {src word offset, n words} per stage (the workgroup's LDS copy)
   int n_stages;
   float* buf0;
   float* buf1;
   int cur;      // stage index within the program
   int parity;   // LDS buffer holding stage `cur`
   int wave, nw, lane;
+  // table entry of the stage after `cur` (read one stage ahead: the scalar load is off the path)
+  uint32_t nxt_off, nxt_words;
+  // the stage being copied: its entry, and the instalment to issue next
+  uint32_t cp_off, cp_words;
+  int cp_part;
+#ifdef NSA_TIMELINE
+  NsaTl tl;
+#endif
 
-  __device__ __forceinline__ void issue(int s, float* dst) {
-    if ((NSA_ABLATE & 1) && s != 0) return;
-    const uint32_t off = table[2 * s], words = table[2 * s + 1];
+  // pieces wave + nw * (part + parts * k)
+  __device__ __forceinline__ void issue(uint32_t off, uint32_t words, float* dst, int part, int parts) {
+    if ((NSA_ABLATE & 1) && cur >= 0) return;
     const uint32_t* src = img + off;
     const int pieces = (int)(words >> 8);
-    for (int c = wave; c < pieces; c += nw) nsa_glds16(src + c * 256 + lane * 4, dst + c * 256);
+    for (int c = wave + part * nw; c < pieces; c += parts * nw) nsa_glds16(src + c * 256 + lane * 4, dst + c * 256);
+  }
+  __device__ __forceinline__ void load_entry(int s) {
+    const uint2 e = *(const uint2*)(table + 2 * s);
+    nxt_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+    nxt_words = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
   }
   // first stage of the program for this workgroup
   __device__ __forceinline__ void prime() {
-    cur = 0;
+    cur = -1;
     parity = 0;
-    issue(0, buf0);
+    cp_part = NSA_COPY_PARTS;
+    load_entry(0);
+    issue(nxt_off, nxt_words, buf0, 0, 1);
+    cur = 0;
+    load_entry(n_stages > 1 ? 1 : 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  // current stage's data; prefetches the next stage (wrapping to stage 0 for
-  // the workgroup's next tile group)
+  // current stage's data; starts the copy of the next stage (wrapping to stage 0 for the
+  // workgroup's next tile group)
   __device__ __forceinline__ const float* begin() {
     const int nxt = (cur + 1 == n_stages) ? 0 : cur + 1;
-    issue(nxt, parity ? buf0 : buf1);
+    cp_off = nxt_off;
+    cp_words = nxt_words;
+    issue(cp_off, cp_words, parity ? buf0 : buf1, 0, NSA_COPY_PARTS);
+    cp_part = 1;
+    load_entry((nxt + 1 == n_stages) ? 0 : nxt + 1);
+    NSA_TL(*this, 12);
     return parity ? buf1 : buf0;
   }
+  // next instalment of the copy begin() started (after the stage's MFMAs; end() otherwise)
+  __device__ __forceinline__ void more() {
+#pragma unroll
+    for (int part = 1; part < NSA_COPY_PARTS; ++part)
+      if (cp_part == part) {
+        issue(cp_off, cp_words, parity ? buf0 : buf1, part, NSA_COPY_PARTS);
+        cp_part = part + 1;
+      }
+  }
   __device__ __forceinline__ void end() {
+    more();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NSA_TL(*this, 7);
     if (!(NSA_ABLATE & 2)) __syncthreads();
+    NSA_TL(*this, 8);
     cur = (cur + 1 == n_stages) ? 0 : cur + 1;
     parity ^= 1;
   }
@@ -228,14 +302,25 @@ __device__ __forceinline__ void nsa_dense_tile(const float* w, const int* tab, c
                                                f32x16 (&acc)[OT]) {
   const int n_s4 = n_steps >> 2;
   for (int s4 = 0; s4 < n_s4; ++s4) {
+    // the 8 table entries of this step group in two 16-byte reads (a lane uses those of its half),
+    // then 4 independent tile reads - no per-element branch, no read -> wait -> read chains
+    const int4 c0 = *(const int4*)(tab + 8 * s4), c1 = *(const int4*)(tab + 8 * s4 + 4);
+    const int col[4] = {half ? c0.y : c0.x, half ? c0.w : c0.z, half ? c1.y : c1.x, half ? c1.w : c1.z};
+    float sh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (PRE) {
+      const f32x4 p0 = *(const f32x4*)(pre + 8 * s4), p1 = *(const f32x4*)(pre + 8 * s4 + 4);
+      sh[0] = half ? p0[1] : p0[0];
+      sh[1] = half ? p0[3] : p0[2];
+      sh[2] = half ? p1[1] : p1[0];
+      sh[3] = half ? p1[3] : p1[2];
+    }
     float b[4];
 #pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = xrow[col[e] < 0 ? 0 : col[e]];
+#pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int idx = 2 * (4 * s4 + e) + half;
-      const int col = tab[idx];
-      float val = (col >= 0) ? xrow[col] : 0.0f;
-      if (PRE) val = (col >= 0) ? (val - pre[idx]) : 0.0f;
-      b[e] = val;
+      if (PRE) b[e] = b[e] - sh[e];
+      b[e] = (col[e] >= 0) ? b[e] : 0.0f;
     }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
@@ -307,14 +392,27 @@ __device__ __forceinline__ void nsa_dense_tile16(const float* w, const int* tab,
                                                  const float* xrow, int n_steps, int lane, int half,
                                                  f32x16 (&acc)[OT]) {
   for (int s = 0; s < n_steps; ++s) {
+    // 8 table entries (and pre-shifts) in two 16-byte reads, then 8 independent tile reads: with a
+    // branch per element the compiler issued read -> wait -> read -> wait sixteen times in a row
+    const int base = 16 * s + 8 * half;
+    const int4 c0 = *(const int4*)(tab + base), c1 = *(const int4*)(tab + base + 4);
+    const int col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    float sh[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (PRE) {
+      const f32x4 p0 = *(const f32x4*)(pre + base), p1 = *(const f32x4*)(pre + base + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sh[e] = p0[e];
+        sh[4 + e] = p1[e];
+      }
+    }
     float v[8];
 #pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = xrow[col[e] < 0 ? 0 : col[e]];
+#pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int idx = 16 * s + 8 * half + e;
-      const int col = tab[idx];
-      float val = (col >= 0) ? xrow[col] : 0.0f;
-      if (PRE) val = (col >= 0) ? (val - pre[idx]) : 0.0f;
-      v[e] = val;
+      if (PRE) v[e] = v[e] - sh[e];
+      v[e] = (col[e] >= 0) ? v[e] : 0.0f;
     }
     bf16x8 bh, bl;
     nsa_split8(v, bh, bl);
@@ -382,7 +480,7 @@ __device__ __forceinline__ void nsa_run_phases(typename TP::State (&st)[TP::FPC]
 // MFMAs of sub-stage J of one chunk of the last conditioner layer (-> acc; cols and the bias come
 // with sub-stage 0).
 template <int HT, class TP, int PREC, int J>
-__device__ __forceinline__ void nsa_chunk_gemm(const float* stg, const float (&h)[16 * HT],
+__device__ __forceinline__ void nsa_chunk_gemm([[maybe_unused]] NsaStagePipe& pipe, const float* stg, const float (&h)[16 * HT],
                                                const NsaSplit<HT>& hs, int lane, int half,
                                                f32x16 (&acc)[TP::C], int (&cols)[TP::FPC]) {
   constexpr int TABW = (2 * TP::FPC + 3) & ~3;
@@ -395,6 +493,7 @@ __device__ __forceinline__ void nsa_chunk_gemm(const float* stg, const float (&h
 #pragma unroll
     for (int q = 0; q < TP::FPC; ++q) cols[q] = tr_tab[half * TP::FPC + q];
     nsa_load_bias<TP::C>(bias, half, acc);
+    NSA_TL(pipe, 13);
   }
   if constexpr (PREC == NSA_PREC_BF16X3) nsa_dense_regs16<HT, TP::C, J * (2 * HT / KS), 2 * HT / KS>(w, hs, lane, acc);
   else nsa_dense_regs<HT, TP::C, J * (4 * HT / KS), 4 * HT / KS>(w, h, lane, acc);
@@ -408,8 +507,8 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
                                              int n_layers, const NsaTransformConsts& tc,
                                              float& logdet, int& n_bad) {
   constexpr bool BF = (PREC == NSA_PREC_BF16X3);
-  const int n_steps0 = (int)op[1];
-  const int n_chunks = (int)op[2];
+  const int n_steps0 = __builtin_amdgcn_readfirstlane((int)op[1]);
+  const int n_chunks = __builtin_amdgcn_readfirstlane((int)op[2]);
   float h[16 * HT];
 
   // one H -> H layer from registers: out = W in + b
@@ -425,9 +524,12 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
       if constexpr (J == 0) {
         nsa_load_bias<HT>(st, half, acc);
         w = st + 32 * HT;
+        NSA_TL(pipe, 13);
       }
       if constexpr (BF) nsa_dense_regs16<HT, HT, J * (2 * HT / KS), 2 * HT / KS>(w, sp, lane, acc);
       else nsa_dense_regs<HT, HT, J * (4 * HT / KS), 4 * HT / KS>(w, in, lane, acc);
+      pipe.more();
+      NSA_TL(pipe, 3);
       if constexpr (J + 1 < KS) pipe.end();
     });
   };
@@ -442,7 +544,10 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     nsa_load_bias<HT>(bias, half, acc);
     if constexpr (BF) nsa_dense_tile16<HT, false>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
     else nsa_dense_tile<HT, false>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
+    pipe.more();
+    NSA_TL(pipe, 1);
     nsa_acc_to_regs<HT>(acc, h);
+    NSA_TL(pipe, 2);
     pipe.end();
   }
 
@@ -458,6 +563,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
         hidden_layer(t, acc);
         nsa_acc_to_regs<HT>(acc, t);
         nsa_act_regs<16 * HT>(t, act);
+        NSA_TL(pipe, 4);
         pipe.end();
       }
       {
@@ -467,6 +573,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
         for (int ot = 0; ot < HT; ++ot)
 #pragma unroll
           for (int r = 0; r < 16; ++r) h[16 * ot + r] = h[16 * ot + r] + acc[ot][r];
+        NSA_TL(pipe, 4);
         pipe.end();
       }
     }
@@ -478,6 +585,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
       hidden_layer(h, acc);
       nsa_acc_to_regs<HT>(acc, h);
       nsa_act_regs<16 * HT>(h, act);
+      NSA_TL(pipe, 4);
       pipe.end();
     }
   }
@@ -495,7 +603,9 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     nsa_static_for<nsa_ksplit(TP::C, HT)>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
       const float* st = pipe.begin();
-      nsa_chunk_gemm<HT, TP, PREC, J>(st, h, hs, lane, half, acc, cols);
+      nsa_chunk_gemm<HT, TP, PREC, J>(pipe, st, h, hs, lane, half, acc, cols);
+      pipe.more();
+      NSA_TL(pipe, 5);
       if constexpr (J + 1 < nsa_ksplit(TP::C, HT)) pipe.end();
     });
     float v[16 * TP::C];
@@ -511,6 +621,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
       nsa_run_phases<TP, INV, 0>(sts, v, cols, xrow, dummy_col, tc, logdet, n_bad,
                                  std::make_integer_sequence<int, TP::NPH * TP::FPC>{});
     }
+    NSA_TL(pipe, 6);
     pipe.end();
   }
 }
@@ -521,8 +632,8 @@ template <int PREC>
 __device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t* op, float* xrow,
                                              int D, int lane, int half, float& logdet) {
   constexpr bool BF = (PREC == NSA_PREC_BF16X3);
-  const int n_steps = (int)op[1];
-  const int n_ot = (int)op[2];
+  const int n_steps = __builtin_amdgcn_readfirstlane((int)op[1]);
+  const int n_ot = __builtin_amdgcn_readfirstlane((int)op[2]);
   const int tab_len = (BF ? 16 : 2) * n_steps;
   const float* st = pipe.begin();
   const int* in_tab = (const int*)st;
@@ -553,6 +664,7 @@ __device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t*
       }
   }
   if (half == 0) logdet += nsa_bits_to_float(op[3]);
+  NSA_TL(pipe, 10);
   pipe.end();
 }
 
@@ -607,15 +719,27 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
 
   NsaStagePipe pipe;
   pipe.img = img;
-  pipe.table = img + (inverse ? img[NSA_H_STAGES_INV] : img[NSA_H_STAGES_FWD]);
   pipe.n_stages = (int)(inverse ? img[NSA_H_NSTAGES_INV] : img[NSA_H_NSTAGES_FWD]);
   pipe.buf0 = smem + tiles_words;
   pipe.buf1 = pipe.buf0 + max_stage;
+  const int n_ops = (int)(inverse ? img[NSA_H_NOPS_INV] : img[NSA_H_NOPS_FWD]);
   // POPULATE: the per-column constants of the epilogue (z-score sigma / mu, prior bounds, output
   // column table) live in LDS behind the stage buffers - the epilogue reads them per feature, and
   // from global memory every read was a separate exposed round trip
   const int D4e = (D + 3) & ~3;
-  double* epi = (double*)(pipe.buf1 + max_stage);  // [4][D4e] doubles + [D4e] ints = NSA_EPI_WORDS(D)
+  double* epi = (double*)(pipe.buf1 + max_stage);  // [4][D4e] doubles + [D4e] ints (populate only)
+  // The program of this direction - stage table {offset, words} and op table - also lives in LDS
+  // (NSA_PROG_WORDS): both are read at every stage / op, the loop's global stores make the compiler
+  // fetch them with vector loads, and each was an exposed L2 round trip in front of the stage's copy.
+  uint32_t* prog = (uint32_t*)(pipe.buf1 + max_stage) + (p.mode == NSA_MODE_POPULATE ? 9 * D4e : 0);
+  uint32_t* prog_ops = prog + 2 * pipe.n_stages;
+  {
+    const uint32_t* gtab = img + (inverse ? img[NSA_H_STAGES_INV] : img[NSA_H_STAGES_FWD]);
+    const uint32_t* gops = img + (inverse ? img[NSA_H_OPS_INV] : img[NSA_H_OPS_FWD]);
+    for (int i = (int)threadIdx.x; i < 2 * pipe.n_stages; i += (int)blockDim.x) prog[i] = gtab[i];
+    for (int i = (int)threadIdx.x; i < n_ops * NSA_OP_WORDS; i += (int)blockDim.x) prog_ops[i] = gops[i];
+  }
+  pipe.table = prog;
   if (p.mode == NSA_MODE_POPULATE) {
     int* epi_tab = (int*)(epi + 4 * D4e);
     const int* otab = (const int*)(img + (inverse ? img[NSA_H_OUT_INV] : img[NSA_H_OUT_FWD]));
@@ -626,15 +750,17 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
       epi[3 * D4e + i] = p.upper != nullptr ? p.upper[i] : 1.0;
       epi_tab[i] = otab[i];
     }
-    __syncthreads();
   }
+  __syncthreads();
   pipe.wave = wave;
   pipe.nw = nw;
   pipe.lane = lane;
 
-  const uint32_t* ops = img + (inverse ? img[NSA_H_OPS_INV] : img[NSA_H_OPS_FWD]);
-  const int n_ops = (int)(inverse ? img[NSA_H_NOPS_INV] : img[NSA_H_NOPS_FWD]);
+  const uint32_t* ops = prog_ops;
   const int* out_tab = (const int*)(img + (inverse ? img[NSA_H_OUT_INV] : img[NSA_H_OUT_FWD]));
+  // base density constants (read once: inside the tile loop they were global loads per tile)
+  const float base_half_inv_var = 0.5f * nsa_bits_to_float(img[NSA_H_BASE_INV_VAR]);
+  const float base_log_z = nsa_bits_to_float(img[NSA_H_LOG_Z]);
 
   NsaTransformConsts tc;
   tc.tail_bound = nsa_bits_to_float(img[NSA_H_TAIL_BOUND]);
@@ -659,9 +785,20 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
   const long long n_groups = (n_tiles + nw - 1) / nw;
 
+#ifdef NSA_TIMELINE
+  for (int i = 0; i < 14; ++i) pipe.tl.acc[i] = 0;
+  unsigned long long tl_tiles = 0;
+#endif
   if (pipe.n_stages > 0) pipe.prime();
+#ifdef NSA_TIMELINE
+  pipe.tl.last = __builtin_readcyclecounter();
+#endif
 
   for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    NSA_TL(pipe, 11);
+#ifdef NSA_TIMELINE
+    ++tl_tiles;
+#endif
     // ---- fill the x tile ---------------------------------------------------
     bool keep = true;
     float log_pz = 0.0f;
@@ -726,7 +863,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
       r2 += __shfl_xor(r2, 32);
       e += __shfl_xor(e, 32);
       keep = sqrt(r2) <= p.radius;
-      log_pz = -(0.5f * nsa_bits_to_float(img[NSA_H_BASE_INV_VAR])) * e - nsa_bits_to_float(img[NSA_H_LOG_Z]);
+      log_pz = -base_half_inv_var * e - base_log_z;
       if (p.z_out != nullptr) {
         const long long base = row0 * D;
         const long long limit = p.n * (long long)D;
@@ -739,12 +876,13 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
     }
 
     }
+    NSA_TL(pipe, 0);
     // ---- run the flow --------------------------------------------------------
     float logdet = 0.0f;
     int n_bad = 0;
     for (int o = 0; o < n_ops; ++o) {
       const uint32_t* op = ops + o * NSA_OP_WORDS;
-      const int kind = (int)op[0];
+      const int kind = __builtin_amdgcn_readfirstlane((int)op[0]);
       if (kind == NSA_OP_COUPLING) {
         nsa_coupling<HT, TP, INV, PREC>(pipe, op, xrow, D, lane, half, act, net, n_layers, tc, logdet, n_bad);
       } else if (kind == NSA_OP_DENSE) {
@@ -877,7 +1015,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
           e += z * z;
         }
         e += __shfl_xor(e, 32);
-        const float lp = -(0.5f * nsa_bits_to_float(img[NSA_H_BASE_INV_VAR])) * e - nsa_bits_to_float(img[NSA_H_LOG_Z]);
+        const float lp = -base_half_inv_var * e - base_log_z;
         out_ld = lp + logdet;
       }
       if (row_ok && half == 0 && p.ld_out != nullptr) p.ld_out[my_row] = out_ld;
@@ -892,7 +1030,15 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
         }
       }
     }
+    NSA_TL(pipe, 9);
   }
   // drain the wrap-around prefetch before the workgroup exits
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef NSA_TIMELINE
+  if (p.dbg != nullptr && lane == 0) {
+    for (int i = 0; i < 14; ++i) atomicAdd(p.dbg + i, pipe.tl.acc[i]);
+    atomicAdd(p.dbg + 14, tl_tiles);
+    atomicAdd(p.dbg + 15, 1ull);
+  }
+#endif
 }
