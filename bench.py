@@ -109,7 +109,23 @@ def _time_draw_kernel(prop, n, launches):
         events.append((s, e))
     torch.cuda.synchronize()
     ms = [s.elapsed_time(e) for s, e in events]
+    global LAST_GEOMETRY
+    LAST_GEOMETRY = last_geometry()
     return float(np.mean(ms)), float(np.min(ms))
+
+
+LAST_GEOMETRY = None
+
+
+def last_geometry():
+    """Launch geometry the library chose for the last flow kernel (nsa_last_geometry)."""
+    import ctypes
+
+    from nessai_amd import lib
+
+    v = [ctypes.c_int(0) for _ in range(3)]
+    lib.load().nsa_last_geometry(*[ctypes.addressof(x) for x in v])
+    return {"waves_per_simd": v[0].value, "waves_per_group": v[1].value, "workgroups": v[2].value}
 
 
 def traffic_probe(device):
@@ -345,6 +361,7 @@ def main():
         elapsed = float(t.item())
 
     kernel_ms, kernel_ms_min = time_draw_kernel(prop)
+    geometry = LAST_GEOMETRY
     precision = prop.flow.model.precision  # what populate() actually ran
     achieved = FLOPS_PER_ROW * DRAWSIZE / (kernel_ms * 1e-3) / 1e12
     f32_ms, _ = time_draw_kernel(prop, precision="f32")
@@ -395,6 +412,8 @@ def main():
                 "algorithmic_bytes": 264.0e6,
                 "kernel_ms_avg": kernel_ms,
                 "kernel_ms_min": kernel_ms_min,
+                # chosen by the library (big split-bf16 batches: timed once per process, nsa_api.hip)
+                "launch_geometry": geometry,
                 "rows_per_launch": DRAWSIZE,
                 "flops_per_row": FLOPS_PER_ROW,
                 "note": "algorithmic FLOPs (one product per weight); the split-bf16 mode issues 3 bf16 MFMAs "

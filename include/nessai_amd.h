@@ -44,6 +44,13 @@ NSA_API const char* nsa_last_error(void);
  * (src/nessai/flows/utils.py:208-246, configure_model). */
 NSA_API int nsa_flow_supported(int hidden_tiles, int transform, int bins);
 
+/* Launch geometry of the last flow kernel this thread enqueued: waves per SIMD the instance is
+ * built for (2 or 3), waves per workgroup, workgroups.  The library picks it per launch (batch
+ * size, conditioner width, precision; for big split-bf16 batches by timing the two candidates
+ * once per process) - reported so that a benchmark line can say what it measured.  No reference
+ * counterpart (torch picks its own launch shapes). */
+NSA_API void nsa_last_geometry(int* waves_per_simd, int* waves_per_group, int* groups);
+
 /* Run a whole flow over n rows.
  *
  * Replaces NFlow.forward / NFlow.inverse / NFlow.log_prob /

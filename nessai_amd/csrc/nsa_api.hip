@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 #include "../../include/nessai_amd.h"
 #include "nsa_flow_kernel.h"
@@ -30,6 +31,13 @@ static int nsa_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* nsa_last_error(void) { return g_err; }
+
+static thread_local int g_last_geometry[3] = {0, 0, 0};
+extern "C" void nsa_last_geometry(int* waves_per_simd, int* waves_per_group, int* groups) {
+  if (waves_per_simd != nullptr) *waves_per_simd = g_last_geometry[0];
+  if (waves_per_group != nullptr) *waves_per_group = g_last_geometry[1];
+  if (groups != nullptr) *groups = g_last_geometry[2];
+}
 extern "C" int nsa_version(void) { return NSA_VERSION; }
 
 // ---------------------------------------------------------------------------
@@ -123,7 +131,79 @@ static int nsa_check_header(const uint32_t* h) {
 }
 
 static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group, int max_groups,
-                           hipStream_t stream, int n_flows = 1) {
+                           hipStream_t stream, int n_flows = 1, int force_occ = 0);
+
+// Big split-bf16 batches of a narrow conditioner have two good geometries - ONE 12-wave workgroup
+// per CU at 3 waves per SIMD (a third of the stage copies per row) or TWO 4-wave workgroups at 2
+// waves per SIMD (no spills, cheap barriers) - and which one is faster differs from box to box by
+// more than they differ from each other (1.76 / 1.88 ms per 1e6 rows of config 3 on one MI355X,
+// 1.97 / 1.83 on another).  The first such launch of a (device, kernel instance, mode, program)
+// times both on the caller's stream - the same launch, whose output does not depend on the
+// geometry, with a private status buffer and without the device-side loop control - and the
+// choice is kept for the process.  NESSAI_AMD_TUNE=0 keeps the static rule (12 waves); so does a
+// stream that is being captured.
+struct NsaTuneEntry {
+  int device, ht, kind, bins, mode, n_stages, occ;
+};
+static std::mutex g_tune_mutex;
+static std::vector<NsaTuneEntry> g_tune;
+
+static int nsa_tuned_occupancy(const uint32_t* h, const NsaLaunch& p, int max_groups, hipStream_t stream,
+                               int n_flows) {
+  const char* env = getenv("NESSAI_AMD_TUNE");
+  if (env != nullptr && env[0] == '0') return 3;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return 3;
+  const bool inv = p.direction == NSA_DIR_INVERSE;
+  const NsaTuneEntry key = {device, (int)h[NSA_H_HT], (int)h[NSA_H_TRANSFORM], (int)h[NSA_H_BINS], p.mode,
+                            (int)h[inv ? NSA_H_NSTAGES_INV : NSA_H_NSTAGES_FWD], 0};
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  for (const NsaTuneEntry& e : g_tune)
+    if (e.device == key.device && e.ht == key.ht && e.kind == key.kind && e.bins == key.bins && e.mode == key.mode &&
+        e.n_stages == key.n_stages)
+      return e.occ;
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone) return 3;
+  int* status = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  if (hipMalloc((void**)&status, 4 * sizeof(int)) != hipSuccess) return 3;
+  int best = 3;
+  if (hipMemsetAsync(status, 0, 4 * sizeof(int), stream) == hipSuccess && hipEventCreate(&t0) == hipSuccess &&
+      hipEventCreate(&t1) == hipSuccess) {
+    NsaLaunch q = p;
+    q.status = status;
+    q.stop = nullptr;
+    float best_ms = 0.0f;
+    bool ok = true;
+    for (int occ = 3; occ >= 2 && ok; --occ) {
+      ok = nsa_launch_flow(h, q, 0, max_groups, stream, n_flows, occ) == NSA_OK;  // first use of the code object
+      ok = ok && hipEventRecord(t0, stream) == hipSuccess;
+      ok = ok && nsa_launch_flow(h, q, 0, max_groups, stream, n_flows, occ) == NSA_OK;
+      ok = ok && hipEventRecord(t1, stream) == hipSuccess && hipEventSynchronize(t1) == hipSuccess;
+      float ms = 0.0f;
+      ok = ok && hipEventElapsedTime(&ms, t0, t1) == hipSuccess;
+      if (ok && (occ == 3 || ms < best_ms)) {
+        best = occ;
+        best_ms = ms;
+      }
+    }
+    if (ok) {
+      NsaTuneEntry e = key;
+      e.occ = best;
+      g_tune.push_back(e);
+    } else {
+      best = 3;
+    }
+  }
+  if (t0 != nullptr) (void)hipEventDestroy(t0);
+  if (t1 != nullptr) (void)hipEventDestroy(t1);
+  (void)hipStreamSynchronize(stream);
+  (void)hipFree(status);
+  return best;
+}
+
+static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group, int max_groups,
+                           hipStream_t stream, int n_flows, int force_occ) {
   int rc = nsa_check_header(h);
   if (rc != NSA_OK) return rc;
   NsaDeviceInfo dev;
@@ -143,7 +223,10 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   const int D = (int)h[NSA_H_D];
   const int XS = (D + 1) | 1;
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
-  int occ = nsa_occupancy((int)h[NSA_H_HT], p.precision, n_tiles, n_flows, g_num_cus, waves_per_group);
+  int occ = force_occ != 0 ? force_occ
+                           : nsa_occupancy((int)h[NSA_H_HT], p.precision, n_tiles, n_flows, g_num_cus, waves_per_group);
+  if (force_occ == 0 && occ == 3 && waves_per_group <= 0 && getenv("NESSAI_AMD_OCC") == nullptr)
+    occ = nsa_tuned_occupancy(h, p, max_groups, stream, n_flows);
   const size_t stage_bytes = 2 * (size_t)h[NSA_H_MAX_STAGE] * 4;
   // + the populate epilogue's per-column constants: 4 double tables and one int table (nsa_flow_kernel.h)
   const size_t epi_bytes = (p.mode == NSA_MODE_POPULATE) ? (size_t)((D + 3) & ~3) * (4 * 8 + 4) : 0;
@@ -194,6 +277,9 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
 #endif
   hipError_t e = fn(&p, (unsigned)grid, (unsigned)n_flows, (unsigned)(nw * 64), lds, stream);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "flow kernel launch: %s", hipGetErrorString(e));
+  g_last_geometry[0] = occ;
+  g_last_geometry[1] = nw;
+  g_last_geometry[2] = (int)grid;
   return NSA_OK;
 }
 

@@ -42,13 +42,25 @@ __device__ __forceinline__ f32x16 nsa_mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi)   (round to nearest even)
+// Two values per v_cvt_pk_bf16_f32; float(hi) comes back out of the packed pair with one shift or
+// mask per value (written per element, the compiler converted every value twice - once alone for the
+// subtraction, once packed for the operand: 4 VALU per value instead of 3).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void nsa_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  u32x4 hw, lw;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 x = {v[2 * q], v[2 * q + 1]};
+    const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+    const f32x2 d = {x[0] - __builtin_bit_cast(float, hp << 16), x[1] - __builtin_bit_cast(float, hp & 0xffff0000u)};
+    hw[q] = hp;
+    lw[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2));
   }
+  hi = __builtin_bit_cast(bf16x8, hw);
+  lo = __builtin_bit_cast(bf16x8, lw);
 }
 
 // three-product split-bf16 multiply-accumulate: a*b ~ ah*bh + ah*bl + al*bh

@@ -902,6 +902,9 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
     const long long row0 = (g_epi * nw + wave) * NSA_ROWS;
     const long long my_row = row0 + j;
     const bool row_ok = my_row < p.n;
+    // (opaque too: with `half` the per-lane table addresses of every epilogue variant were hoisted out
+    // of the tile loop and lived - spilled, in the 168-register instances - across the whole flow)
+    const int half_e = nsa_opaque(half);
     if (p.mode == NSA_MODE_POPULATE && p.xp_out != nullptr) {
 #pragma clang fp contract(off)
       // importance-sampler draw: x = 1 / (1 + exp(-x')), log|J_inv| = sum log x + log1p(-x)
@@ -912,7 +915,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
       double* xo = p.x64_out + my_row * D;
       float* xpo = p.xp_out + my_row * D;
       const double eps = p.unit_eps;
-      for (int i = half; i < D; i += 2) {
+      for (int i = half_e; i < D; i += 2) {
         const float xpf = xrow[epi_tab[i]];
         const double xp = (double)xpf;
         const double u = 1.0 / (1.0 + exp(-xp));
@@ -948,7 +951,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
         int inb = 1;
         if (row_ok && !(NSA_ABLATE & 32)) {
 #pragma unroll 4
-          for (int i = half; i < D; i += 2) {
+          for (int i = half_e; i < D; i += 2) {
             const double xp = (double)xrow[epi_tab[i]];
             const double xv = (xp * epi[i]) + epi[D4e + i];
             inb &= (int)!(xv < epi[2 * D4e + i]) & (int)!(xv > epi[3 * D4e + i]);
@@ -956,7 +959,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
           }
         } else {
 #pragma unroll 4
-          for (int i = half; i < D; i += 2) {
+          for (int i = half_e; i < D; i += 2) {
             const double xp = (double)xrow[epi_tab[i]];
             const double xv = (xp * epi[i]) + epi[D4e + i];
             inb &= (int)!(xv < epi[2 * D4e + i]) & (int)!(xv > epi[3 * D4e + i]);
@@ -964,7 +967,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
         }
         in_bounds = inb != 0;
       } else
-      for (int i = half; i < D; i += 2) {
+      for (int i = half_e; i < D; i += 2) {
         const double xp = (double)xrow[out_tab[i]];
         double xv;
         const int kind = (e.rp_kind != nullptr) ? e.rp_kind[i] : NSA_RP_SCALE_SHIFT;
@@ -1010,7 +1013,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
       if (p.mode == NSA_MODE_LOGPROB) {
         // log_prob = (-0.5/var * sum z^2 - log_z) + logabsdet (base.py:243-245)
         float e = 0.0f;
-        for (int i = half; i < D; i += 2) {
+        for (int i = half_e; i < D; i += 2) {
           const float z = xrow[out_tab[i]];
           e += z * z;
         }

@@ -536,3 +536,44 @@ def test_pass_trains_equal_one_pass_at_a_time(case):
         assert np.array_equal(a[4], b[4])
     if case == "max_samples":
         assert results[True][0][2] > 3000 and results[True][0][1] < 5000  # stopped by max_samples
+
+
+def test_launch_geometry_is_tuned_once_and_never_changes_the_result(monkeypatch):
+    """Big split-bf16 batches: the library times its two launch geometries once per process
+    (csrc/nsa_api.hip, nsa_tuned_occupancy) and reports the choice through nsa_last_geometry; the
+    rows drawn do not depend on it (row-indexed Philox streams, per-row arithmetic)."""
+    import ctypes
+
+    from nessai_amd import lib
+
+    def geometry():
+        v = [ctypes.c_int(0) for _ in range(3)]
+        lib.load().nsa_last_geometry(*[ctypes.addressof(x) for x in v])
+        return tuple(x.value for x in v)
+
+    state, shift, scale, _ = load_c3_fixture()
+    n = 300_000  # >= 24 tiles per CU: the range in which both geometries are candidates
+    prop, _ = build(32, "nsf", dict(n_neurons=64, n_blocks=6), poolsize=2000, drawsize=n,
+                    state=state, shift=shift, scale=scale)
+    prop.populate(None, n_samples=50, max_samples=10**9)  # rescaling constants, radius, device tables
+    radius = prop.fixed_radius if prop.fixed_radius is not None else 1.0e9
+    buf = prop._get_buffers(n, 2000)
+    outs = {}
+    for occ in ("3", "2", None, None):
+        if occ is None:
+            monkeypatch.delenv("NESSAI_AMD_OCC", raising=False)
+        else:
+            monkeypatch.setenv("NESSAI_AMD_OCC", occ)
+        buf["x64"].zero_()
+        buf["log_q"].zero_()
+        prop._launch_draw(n, None, 0, radius, buf["x64"], buf["log_q"], None)
+        torch.cuda.synchronize()
+        outs.setdefault(occ, []).append((geometry(), buf["x64"][:n].clone(), buf["log_q"][:n].clone()))
+    g3, x3, q3 = outs["3"][0]
+    g2, x2, q2 = outs["2"][0]
+    assert g3[:2] == (3, 12) and g2[:2] == (2, 4)
+    (ga, xa, qa), (gb, xb, qb) = outs[None]
+    assert ga[:2] in ((3, 12), (2, 4)) and gb == ga  # tuned once, kept
+    for x, q in ((x2, q2), (xa, qa), (xb, qb)):
+        assert torch.equal(x, x3)
+        assert torch.equal(torch.nan_to_num(q, nan=12345.0), torch.nan_to_num(q3, nan=12345.0))
