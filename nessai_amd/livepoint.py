@@ -38,11 +38,36 @@ def empty_structured_array(n, names=None, dtype=None, non_sampling_parameters=Tr
     return out
 
 
+def parameter_block(live_points, names):
+    """Writable ``(N, D)`` float64 VIEW of the fields ``names`` of a structured array, or ``None``.
+
+    The live-point records keep their parameters as consecutive ``f8`` fields, so the block of a
+    C-contiguous array is one strided 2-D array: reading or writing it replaces a Python loop over
+    D fields (64 strided copies per call for config 4) by one copy with the same values."""
+    if not isinstance(live_points, np.ndarray) or live_points.ndim != 1 or not live_points.flags.c_contiguous:
+        return None
+    fields = live_points.dtype.fields
+    if fields is None or not names or any(n not in fields for n in names):
+        return None
+    first = fields[names[0]][1]
+    for i, n in enumerate(names):
+        dt, off = fields[n][:2]
+        if dt != np.float64 or off != first + 8 * i:
+            return None
+    if live_points.size == 0:
+        return np.empty((0, len(names)), dtype=np.float64)
+    return np.ndarray((live_points.size, len(names)), dtype=np.float64, buffer=live_points.data, offset=first,
+                      strides=(live_points.dtype.itemsize, 8))
+
+
 def live_points_to_array(live_points, names=None, copy=False):
     """Structured -> plain ``(N, D)`` float64 array (``livepoint.py:158-190``)."""
     if names is None:
         names = [n for n in live_points.dtype.names if n not in NON_SAMPLING_PARAMETERS]
     live_points = np.atleast_1d(live_points)
+    block = parameter_block(live_points, list(names))
+    if block is not None:
+        return np.array(block)  # contiguous copy
     return np.stack([np.asarray(live_points[n], dtype=np.float64) for n in names], axis=-1)
 
 

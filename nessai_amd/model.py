@@ -92,8 +92,17 @@ class Model:
     def upper_bounds(self):
         return np.array([self.bounds[n][1] for n in self.names], dtype=np.float64)
 
+    def _block(self, x):
+        """(N, D) view of the parameter fields of ``x`` (None if they are not one f8 block)."""
+        from .livepoint import parameter_block
+
+        return parameter_block(x, self.names) if isinstance(x, np.ndarray) else None
+
     def in_bounds(self, x):
         """True where every parameter is inside its prior bounds (``model.py:497-518``)."""
+        v = self._block(x)
+        if v is not None:
+            return ~((v < self.lower_bounds) | (v > self.upper_bounds)).any(axis=1)
         return ~np.any(
             [(x[n] < self.bounds[n][0]) | (x[n] > self.bounds[n][1]) for n in self.names],
             axis=0,
@@ -118,6 +127,9 @@ class Model:
 
     def in_unit_hypercube(self, x):
         """True where every parameter is in [0, 1]."""
+        v = self._block(x)
+        if v is not None:
+            return ~((v < 0.0) | (v > 1.0)).any(axis=1)
         return ~np.any([(x[n] < 0.0) | (x[n] > 1.0) for n in self.names], axis=0)
 
     def from_unit_hypercube(self, x):
@@ -125,6 +137,11 @@ class Model:
         if not self.uniform_prior:
             raise NotImplementedError("from_unit_hypercube needs a user implementation")
         out = x.copy()
+        v, w = self._block(x), self._block(out)
+        if v is not None and w is not None:
+            lo, hi = self.lower_bounds, self.upper_bounds
+            w[:] = lo + (hi - lo) * v
+            return out
         for n in self.names:
             lo, hi = self.bounds[n]
             out[n] = lo + (hi - lo) * x[n]
@@ -134,6 +151,11 @@ class Model:
         if not self.uniform_prior:
             raise NotImplementedError("to_unit_hypercube needs a user implementation")
         out = x.copy()
+        v, w = self._block(x), self._block(out)
+        if v is not None and w is not None:
+            lo, hi = self.lower_bounds, self.upper_bounds
+            w[:] = (v - lo) / (hi - lo)
+            return out
         for n in self.names:
             lo, hi = self.bounds[n]
             out[n] = (x[n] - lo) / (hi - lo)

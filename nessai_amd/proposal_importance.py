@@ -36,7 +36,8 @@ from scipy.special import logsumexp
 from . import lib
 from .flowmodel_importance import ImportanceFlowModel
 from .flows.base import log_prob_many
-from .livepoint import NON_SAMPLING_DEFAULTS, NON_SAMPLING_DTYPES, NON_SAMPLING_PARAMETERS, live_points_to_array
+from .livepoint import (NON_SAMPLING_DEFAULTS, NON_SAMPLING_DTYPES, NON_SAMPLING_PARAMETERS, live_points_to_array,
+                        parameter_block)
 
 logger = logging.getLogger(__name__)
 
@@ -48,8 +49,8 @@ def logit(x, eps=None):
     """(x', log|J|) with inputs clamped to [eps, 1 - eps] (``utils/rescaling.py:290-313``)."""
     if eps:
         x = np.clip(x, eps, 1 - eps)
-    log_j = -np.log(x) - np.log1p(-x)
-    return np.log(x) - np.log1p(-x), log_j
+    a, b = np.log(x), np.log1p(-x)  # each evaluated once; the same two roundings as the reference's lines
+    return a - b, -a - b
 
 
 def sigmoid(x):
@@ -70,8 +71,12 @@ def ins_dtype(names):
 
 def empty_ins_array(n, names):
     out = np.empty(n, dtype=ins_dtype(names))
-    for nm in names:
-        out[nm] = np.nan
+    block = parameter_block(out, list(names))
+    if block is not None:
+        block.fill(np.nan)
+    else:
+        for nm in names:
+            out[nm] = np.nan
     for nm, v in zip(NON_SAMPLING_PARAMETERS, NON_SAMPLING_DEFAULTS):
         out[nm] = v
     for nm in INS_PARAMETERS:
@@ -174,8 +179,12 @@ class ImportanceFlowProposal:
         if self.clip:
             x = np.clip(x, 0.0, 1.0)
         out = empty_ins_array(x.shape[0], self.model.names)
-        for i, n in enumerate(self.model.names):
-            out[n] = x[:, i]
+        block = parameter_block(out, list(self.model.names))
+        if block is not None:
+            block[:] = x
+        else:
+            for i, n in enumerate(self.model.names):
+                out[n] = x[:, i]
         return out, log_j
 
     # -- training ----------------------------------------------------------------------
@@ -402,8 +411,12 @@ class ImportanceFlowProposal:
             if not len(x):
                 continue
             points = empty_ins_array(len(x), names)
-            for col, name in enumerate(names):
-                points[name] = x[:, col]
+            block = parameter_block(points, list(names))
+            if block is not None:
+                block[:] = x
+            else:
+                for col, name in enumerate(names):
+                    points[name] = x[:, col]
             points["logQ"] = log_Q
             points["logP"] = self.model.batch_evaluate_log_prior(self.model.from_unit_hypercube(points))
             points["logU"] = self.model.batch_evaluate_log_prior_unit_hypercube(points)
