@@ -136,7 +136,7 @@ def traffic_probe(device):
     time_draw_kernel(prop, launches=4)
 
 
-def measure_traffic():
+def measure_traffic(waves_per_simd=None):
     """HBM bytes per launch of the draw kernel from the PMC counters, collected live: two
     ``rocprofv3 --kernel-trace --pmc`` passes over ``bench.py --traffic-probe`` (FETCH_SIZE and
     WRITE_SIZE do not fit one pass), corrected as MI355X_MICROARCH.md (HBM) prescribes: both counters
@@ -156,6 +156,10 @@ def measure_traffic():
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
+    if waves_per_simd in (2, 3):
+        # the probe is another process: pin it to the geometry THIS run's launches used (the library
+        # times its two candidates once per process; their launches would be in the probe's trace too)
+        env["NESSAI_AMD_OCC"] = str(waves_per_simd)
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out_dir = os.path.join(tmp, counter)
@@ -174,7 +178,8 @@ def measure_traffic():
                 return None, f"no {counter} rows for the flow kernel in the rocprofv3 output"
             full = max(g for g, _ in values)  # the 1e6-row launches (the populate call also makes them)
             vals = [v for g, v in values if g == full]
-            per_launch[counter] = float(np.mean(vals)) * 1024.0
+            # median: the populate call's switched-off surplus passes have the same grid and move nothing
+            per_launch[counter] = float(np.median(vals)) * 1024.0
         total = 2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]
         return total, {"fetch_size_bytes_x2": 2.0 * per_launch["FETCH_SIZE"], "write_size_bytes": per_launch["WRITE_SIZE"],
                        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this run"}
@@ -369,7 +374,7 @@ def main():
 
     traffic, traffic_detail = (None, "skipped (--no-pmc or N > 1)")
     if rank == 0 and world == 1 and not args.no_pmc:
-        traffic, traffic_detail = measure_traffic()
+        traffic, traffic_detail = measure_traffic((geometry or {}).get("waves_per_simd"))
     if rank == 0:
         out = {
             "metric": "accepted live points/sec in FlowProposal.populate(), 32-D Rosenbrock nlive=2000",
