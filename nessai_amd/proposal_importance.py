@@ -36,8 +36,8 @@ from scipy.special import logsumexp
 from . import lib
 from .flowmodel_importance import ImportanceFlowModel
 from .flows.base import log_prob_many
-from .livepoint import (NON_SAMPLING_DEFAULTS, NON_SAMPLING_DTYPES, NON_SAMPLING_PARAMETERS, live_points_to_array,
-                        parameter_block)
+from .livepoint import (NON_SAMPLING_DEFAULTS, NON_SAMPLING_DTYPES, NON_SAMPLING_PARAMETERS, concatenate_points,
+                        live_points_to_array, parameter_block, take_points)
 
 logger = logging.getLogger(__name__)
 
@@ -427,12 +427,14 @@ class ImportanceFlowProposal:
             usable &= ~np.isnan(log_q_all).all(axis=1) & ~np.isposinf(log_q_all).all(axis=1)
             if not usable.any():
                 continue
-            kept_points.append(points[usable])
-            kept_log_q.append(log_q_all[usable])
+            all_usable = bool(usable.all())
+            kept_points.append(points if all_usable else take_points(points, usable))
+            kept_log_q.append(log_q_all if all_usable else log_q_all[usable])
             have += int(usable.sum())
         if not kept_points:
             return np.zeros(0, dtype=self.dtype), np.empty([0, self.n_proposals])
-        return np.concatenate(kept_points)[:n], np.concatenate(kept_log_q, axis=0)[:n]
+        log_q_kept = kept_log_q[0] if len(kept_log_q) == 1 else np.concatenate(kept_log_q, axis=0)
+        return concatenate_points(kept_points)[:n], log_q_kept[:n]
 
     def draw_from_prior(self, n):
         """(``importance.py:632-641``)."""
