@@ -244,15 +244,16 @@ struct NsaRQ {
   template <int OFF, int NV>
   __device__ __forceinline__ static void knots(const float (&v)[NV], float inv_div, float mn,
                                                float sc, float two_b, float B, float (&cum)[K + 1]) {
-    float u[K];
+    // max over the raw logits (the scale is positive), then scale and shift in ONE fma per logit
     const float k2 = inv_div * 1.4426950408889634f;
-    float m = -INFINITY;
+    float m = v[OFF];
 #pragma unroll
-    for (int i = 0; i < K; ++i) { u[i] = v[OFF + i] * k2; m = fmaxf(m, u[i]); }
+    for (int i = 1; i < K; ++i) m = fmaxf(m, v[OFF + i]);
+    const float mk = m * k2;
     float pre[K + 1];
     pre[0] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < K; ++i) pre[i + 1] = pre[i] + __builtin_amdgcn_exp2f(u[i] - m);
+    for (int i = 0; i < K; ++i) pre[i + 1] = pre[i] + __builtin_amdgcn_exp2f(fmaf(v[OFF + i], k2, -mk));
     const float g = (two_b * sc) * nsa_rcp(pre[K]);
     const float c0 = two_b * mn;
 #pragma unroll
