@@ -217,6 +217,15 @@ NSA_API int nsa_importance_draw(const uint32_t* header, const void* image_dev, l
                                 double unit_eps, double* x64_out_dev, float* xp_out_dev, double* log_j_out_dev,
                                 int* status_dev, int waves_per_group, int max_groups, void* stream);
 
+/* Unit hypercube -> x' of the importance sampler for stored samples: x' = logit(clip(x, eps, 1 - eps))
+ * (float32, what the flows read) and log|J| = sum_i -log(xc_i) - log1p(-xc_i) (float64).
+ *
+ * Replaces ImportanceFlowProposal.to_prime / rescale (proposal/importance.py:219-245, the "logit"
+ * branch; utils/rescaling.py:290-313) on the path of update_log_q (importance.py:528-543), which the
+ * sampler runs over EVERY stored sample at every level. */
+NSA_API int nsa_importance_to_prime(long long n, int dims, const double* x_unit_dev, double eps,
+                                    float* x_prime_dev, double* log_j_dev, void* stream);
+
 /* ... second half, compute_log_Q (importance.py:415-441): log_q_all[r][0] = 0 (the prior),
  * log_q_all[r][1 + j] = log_prob_all[j][r] + log_j[r], log_Q[r] = logsumexp(log_q_all[r], b = weights)
  * in float64 (scipy.special.logsumexp's arithmetic).  log_prob_all_dev is the (n_flows, n) float32

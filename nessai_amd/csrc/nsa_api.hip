@@ -434,6 +434,19 @@ extern "C" int nsa_importance_draw(const uint32_t* header, const void* image_dev
 extern "C" hipError_t nsa_launch_importance_mix(long long, int, const float*, const double*, const double*,
                                                 double*, double*, hipStream_t);
 
+extern "C" hipError_t nsa_launch_importance_to_prime(long long, int, const double*, double, float*, double*,
+                                                     hipStream_t);
+
+extern "C" int nsa_importance_to_prime(long long n, int dims, const double* x_unit_dev, double eps,
+                                       float* x_prime_dev, double* log_j_dev, void* stream) {
+  if (n < 0 || dims < 1 || x_unit_dev == nullptr || x_prime_dev == nullptr || log_j_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_importance_to_prime: bad argument");
+  if (!(eps >= 0.0 && eps < 0.5)) return nsa_fail(NSA_E_ARG, "nsa_importance_to_prime: eps must be in [0, 0.5)");
+  hipError_t e = nsa_launch_importance_to_prime(n, dims, x_unit_dev, eps, x_prime_dev, log_j_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "importance to-prime kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
 extern "C" int nsa_importance_mix(long long n, int n_flows, const float* log_prob_all_dev, const double* log_j_dev,
                                   const double* weights_dev, double* log_q_all_dev, double* log_Q_dev,
                                   void* stream) {

@@ -452,6 +452,48 @@ __global__ void __launch_bounds__(256) nsa_importance_mix_kernel(long long n, in
   log_Q[r] = log(s) + a_max;
 }
 
+// Unit hypercube -> x' of the importance sampler, one thread per row (proposal/importance.py:219-245,
+// utils/rescaling.py:290-313): xc = clip(x, eps, 1 - eps), x' = log(xc) - log1p(-xc) (float32 out: what
+// the flows read), log|J| = sum_i (-log(xc_i) - log1p(-xc_i)) in float64, summed in numpy's order for a
+// contiguous row (8 interleaved partial sums combined as a tree, then the remainder).
+__global__ void nsa_importance_to_prime_kernel(long long n, int D, const double* __restrict__ x, double eps,
+                                               float* __restrict__ xp, double* __restrict__ log_j) {
+#pragma clang fp contract(off)
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const double* xr = x + row * D;
+  float* xo = xp + row * D;
+  auto term = [&](int i) {
+    double v = xr[i];
+    if (eps > 0.0) v = fmin(fmax(v, eps), 1.0 - eps);
+    const double a = log(v), b = log1p(-v);
+    xo[i] = (float)(a - b);
+    return -a - b;
+  };
+  double total;
+  if (D < 8) {
+    total = 0.0;
+    for (int i = 0; i < D; ++i) total += term(i);
+  } else {
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = term(k);
+    int i = 8;
+    for (; i + 8 <= D; i += 8)
+      for (int k = 0; k < 8; ++k) r[k] += term(i + k);
+    total = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < D; ++i) total += term(i);
+  }
+  log_j[row] = total;
+}
+
+extern "C" hipError_t nsa_launch_importance_to_prime(long long n, int D, const double* x, double eps, float* xp,
+                                                     double* log_j, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((n + 127) / 128);
+  nsa_importance_to_prime_kernel<<<grid, 128, 0, stream>>>(n, D, x, eps, xp, log_j);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t nsa_launch_importance_mix(long long n, int n_flows, const float* log_prob_all,
                                                 const double* log_j, const double* weights, double* log_q_all,
                                                 double* log_Q, hipStream_t stream) {

@@ -65,6 +65,7 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_ll, c_void_p, c_ull, c_ull, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
          c_int, c_void_p],
     ),
+    "nsa_importance_to_prime": (c_int, [c_ll, c_int, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "nsa_importance_mix": (c_int, [c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsa_populate_truncate": (c_int, [c_ll, c_void_p, c_double, c_void_p, c_double, c_void_p]),
     "nsa_populate_weights": (c_int, [c_ll, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),

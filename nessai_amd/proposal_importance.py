@@ -390,9 +390,30 @@ class ImportanceFlowProposal:
         every stored sample at every level, so its rows are sharded as well."""
         if log_q.shape[1] == self.n_proposals:
             raise ValueError("log_q array already contains current proposal")
-        x, log_j = self.rescale(samples)
-        column = self.get_proposal_log_prob(self.level_count)(x) + log_j
+        if self.reparameterisation == "logit" and self.level_count >= 0:
+            column = self._newest_column_device(samples)
+        else:
+            x, log_j = self.rescale(samples)
+            column = self.get_proposal_log_prob(self.level_count)(x) + log_j
         return np.concatenate([log_q, column[:, np.newaxis]], axis=1)
+
+    def _newest_column_device(self, samples):
+        """``log q_newest(x)`` of stored samples with the logit map on the device
+        (``nsa_importance_to_prime``): the host only flattens the records and uploads them.  On the
+        host the map was 60 % of ``update_log_q`` (two float64 logarithms per element in numpy)."""
+        x = live_points_to_array(samples, self.model.names)
+        dev = self.flow.device
+        n, d = x.shape
+        with torch.inference_mode(False), torch.no_grad():
+            xd = torch.from_numpy(x).to(dev)
+            xp = torch.empty((n, d), dtype=torch.float32, device=dev)
+            log_j = torch.empty(n, dtype=torch.float64, device=dev)
+            rc = lib.load().nsa_importance_to_prime(n, d, lib.ptr(xd), EPS, lib.ptr(xp), lib.ptr(log_j), self._stream())
+            lib.check(rc, "nsa_importance_to_prime")
+            flow = self.flow.models[self.level_count]
+            flow.eval()
+            log_prob = self._log_prob_rows([flow], xp)[0]
+            return (log_prob.to(torch.float64) + log_j).cpu().numpy()
 
     def draw(self, n, flow_number=None, injected=None):
         """``n`` points from one flow with their meta-proposal weights (``importance.py:443-526``).

@@ -223,3 +223,29 @@ def test_rows_sharded_over_two_ranks_equal_one_rank(tmp_path):
         assert np.array_equal(s["x"], np.stack([pts[n] for n in model.names], 1))
         assert np.array_equal(s["log_q"], log_q) and np.array_equal(s["upd"], upd)
         assert np.array_equal(s["log_Q"], log_Q) and int(s["counter"]) == single._draw_counter
+
+
+def test_device_logit_map_matches_numpy():
+    """``nsa_importance_to_prime`` (the to_prime of ``update_log_q``) against the host map
+    (``proposal_importance.logit``, itself pinned to the reference): x' agrees to float32
+    rounding, log|J| to a few float64 ulps, inputs outside [eps, 1 - eps] are clipped."""
+    from nessai_amd import lib
+    from nessai_amd.proposal_importance import EPS, logit
+
+    g = np.random.default_rng(5)
+    for n, d in ((1000, 64), (37, 5), (1, 9)):
+        x = g.random((n, d))
+        x[0, 0], x[-1, -1] = 0.0, 1.0   # clipped to eps / 1 - eps
+        if n > 2:
+            x[1, :] = 1e-12
+            x[2, :] = 1.0 - 1e-12
+        xp_ref, lj_ref = logit(x, eps=EPS)
+        lj_ref = lj_ref.sum(axis=1)
+        xd = torch.from_numpy(x).cuda()
+        xp = torch.empty((n, d), dtype=torch.float32, device="cuda")
+        lj = torch.empty(n, dtype=torch.float64, device="cuda")
+        rc = lib.load().nsa_importance_to_prime(n, d, lib.ptr(xd), EPS, lib.ptr(xp), lib.ptr(lj),
+                                                lib.c_void_p(torch.cuda.current_stream().cuda_stream))
+        lib.check(rc, "nsa_importance_to_prime")
+        np.testing.assert_allclose(xp.cpu().numpy(), xp_ref.astype(np.float32), rtol=2e-7, atol=0)
+        np.testing.assert_allclose(lj.cpu().numpy(), lj_ref, rtol=1e-14, atol=0)
