@@ -73,11 +73,8 @@ __device__ __forceinline__ void nsa_tl_mark(NsaTl& t, int slot) {
 // Sub-stages along k of a register-fed GEMM with `tiles` output tiles (same rule as pack.ksplit):
 // for the 128-wide conditioners (HT = 4) packed weights above 16 KiB are dealt to 2 or 4 consecutive
 // stages, the accumulators live across them: 2 x 17 KiB of stage buffers instead of 2 x 64 KiB.
-#ifndef NSA_KSPLIT_MIN_HT
-#define NSA_KSPLIT_MIN_HT 4  // diagnostic builds lower it together with NESSAI_AMD_KSPLIT_MIN_HT (pack.py)
-#endif
 constexpr int nsa_ksplit(int tiles, int ht) {
-  if (ht < NSA_KSPLIT_MIN_HT) return 1;  // <= 64 hidden units: the largest stage is 25 KiB, splitting only adds barriers
+  if (ht < 4) return 1;  // <= 64 hidden units: the largest stage is 25 KiB, splitting only adds barriers
   int ks = 1;
   while (tiles * ht * 4096 / ks > 16384 && ks < 2 * ht) ks *= 2;
   return ks;

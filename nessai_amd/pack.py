@@ -28,8 +28,6 @@ with transforms (mirroring the reference's ``CompositeTransform`` lists,
 
 import math
 
-import os
-
 import numpy as np
 
 MAGIC = 0x3141534E
@@ -82,7 +80,7 @@ def ksplit(tiles, ht):
     128-wide conditioners (hidden tiles = 4, config 4), whose 64 KiB hidden-layer stages left room
     for 2 waves per workgroup only: with 17 KiB stages two 4-wave workgroups share a CU.  Same rule
     as ``nsa_ksplit`` in ``csrc/nsa_flow_kernel.h``."""
-    if ht < int(os.environ.get("NESSAI_AMD_KSPLIT_MIN_HT", 4)):  # (the variable: diagnostic builds only)
+    if ht < 4:
         # a 64-wide conditioner's largest stage is 25 KiB: 12 waves per CU already run from one
         # double buffer, and the extra stage barriers of a split cost more than a third workgroup
         # per CU brings (1.92 against 1.76 ms per 1e6 rows of config 3)
