@@ -102,27 +102,28 @@ class FlowModel:
 
     @staticmethod
     def check_batch_size(x, batch_size, min_fraction=0.1):
-        """Shrink the batch size until the last batch holds >= 10 % of it
-        (``base.py:195-236``)."""
+        """Largest batch size <= ``batch_size`` whose last batch is either empty or holds at least
+        ``min_fraction`` of the REQUESTED size (same outcome as ``base.py:195-236``; pinned by
+        ``tests/test_golden.py``).  Sizes at or below that floor are accepted with a warning as soon
+        as they leave more than one sample over."""
         if batch_size == 1:
             raise ValueError("Cannot use a batch size of 1!")
-        min_batch_size = int(min_fraction * batch_size)
-        final_batch_size = len(x) % batch_size
-        if final_batch_size and (final_batch_size < min_batch_size):
-            while True:
-                batch_size -= 1
-                final_batch_size = len(x) % batch_size
-                if batch_size < 2:
-                    raise RuntimeError("Could not find a valid batch size")
-                elif (final_batch_size == 0) or (final_batch_size >= min_batch_size):
-                    break
-                elif (batch_size <= min_batch_size) and final_batch_size > 1:
-                    logger.warning(
-                        f"Batch size is less than {min_batch_size} but valid. "
-                        f"Setting batch size to: {batch_size}"
-                    )
-                    break
-        return batch_size
+        n = len(x)
+        floor = int(min_fraction * batch_size)
+
+        def tail_ok(size):
+            rest = n % size
+            return rest == 0 or rest >= floor
+
+        if tail_ok(batch_size):
+            return batch_size
+        for size in range(batch_size - 1, 1, -1):
+            if tail_ok(size):
+                return size
+            if size <= floor and n % size > 1:
+                logger.warning(f"Batch size is less than {floor} but valid. Setting batch size to: {size}")
+                return size
+        raise RuntimeError("Could not find a valid batch size")
 
     # -- numpy <-> device ------------------------------------------------------
 

@@ -246,15 +246,10 @@ class FlowProposal:
         return get_dtype(self.names)
 
     def update_poolsize_scale(self, acceptance):
-        """(``proposal/flowproposal/base.py:416-435``)."""
-        if not acceptance:
-            self._poolsize_scale = self.max_poolsize_scale
-        else:
-            self._poolsize_scale = 1.0 / acceptance
-            if self._poolsize_scale > self.max_poolsize_scale:
-                self._poolsize_scale = self.max_poolsize_scale
-            if self._poolsize_scale < 1.0:
-                self._poolsize_scale = 1.0
+        """Pool-size multiplier 1 / acceptance, kept inside [1, ``max_poolsize_scale``]; the upper
+        limit when nothing was accepted (``proposal/flowproposal/base.py:416-435``)."""
+        wanted = 1.0 / acceptance if acceptance else self.max_poolsize_scale
+        self._poolsize_scale = max(min(wanted, self.max_poolsize_scale), 1.0)
 
     def initialise(self, resumed=False):
         """Set up the rescaling and the flow (``base.py:358-391``, ``:578-653``).
@@ -965,20 +960,24 @@ class FlowProposal:
         self.populated = True
         self._checked_population = False
 
-    def draw(self, worst_point):
-        """Pop one pooled sample, repopulating when the pool is empty (``base.py:1152-1183``)."""
-        if not self.populated:
-            self.populating = True
+    def _refill(self, worst_point):
+        """Populate until the pool holds samples again (the sampler's acceptance sets its size)."""
+        self.populating = True
+        try:
             if self.update_poolsize:
                 self.update_poolsize_scale(self.ns_acceptance)
             while not self.populated:
                 self.populate(worst_point, n_samples=self.poolsize)
+        finally:
             self.populating = False
-        index = self.indices.pop()
-        new_sample = self.samples[index]
-        if not self.indices:
-            self.populated = False
-        return new_sample
+
+    def draw(self, worst_point):
+        """Next pooled sample; an empty pool is refilled first (``base.py:1152-1183``)."""
+        if not self.populated:
+            self._refill(worst_point)
+        sample = self.samples[self.indices.pop()]
+        self.populated = bool(self.indices)
+        return sample
 
     def reset_model_weights(self, **kwargs):
         self.flow.reset_model(**kwargs)
