@@ -153,6 +153,10 @@ class HipFlow(BaseFlow):
                 f"(hidden={desc['hidden']}, transform={desc['transform']}, "
                 f"bins={desc.get('bins', 0)})"
             )
+        # every other structural limit of the kernels (LU-linear beyond 64 features, mixed conditioner
+        # depths, ...) is known to the packer: pack once now so that an unsupported configuration raises
+        # at construction like the checks above, not at the first call
+        pack.pack_flow(dict(desc, precision=self.precision))
 
     # -- device image ----------------------------------------------------------
 

@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""Randomised parity sweep: random supported flow configurations x random inputs, device (exact-f32
+mode) against the CPU oracle.  Complements the fixed list of tests/test_gpu_flows.py.
+
+    python scripts/fuzz_parity.py [--iterations 200] [--seed 0]
+
+Prints one line per failing case and a summary; exit code 1 if any case misses the bars
+(log_prob 1e-5 relative with a 1e-3 floor; forward 2e-4 / 5e-4 absolute-relative for x / log-det; where
+the float32 oracle itself is further than a bar from its float64 twin - inverses that blow up, log_prob
+near zero - the device must be within 3x the float32 oracle's own error of the float64 result)."""
+import argparse
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from helpers import DEV, make_pair, rel_err  # noqa: E402
+from nessai_amd.flows import NeuralSplineFlow, RealNVP  # noqa: E402
+from oracle import flows as O  # noqa: E402
+
+ACTS = {"relu": torch.relu, "tanh": torch.tanh, "silu": torch.nn.functional.silu}
+
+
+def random_case(g):
+    nsf = g.random() < 0.6
+    D = int(g.integers(2, 41)) if g.random() < 0.85 else int(g.integers(41, 97))
+    H = int(g.choice([8, 12, 16, 30, 32, 33, 48, 64, 100, 128]))
+    blocks = int(g.integers(1, 7))
+    layers = int(g.integers(1, 4))
+    kw = {}
+    act = str(g.choice(list(ACTS)))
+    if act != "relu":
+        kw["activation"] = ACTS[act]
+    if nsf:
+        kw["num_bins"] = int(g.choice([4, 8, 10, 16]))
+        if g.random() < 0.4:
+            kw["linear_transform"] = str(g.choice(["lu", "permutation"]))
+        if g.random() < 0.3:
+            kw["batch_norm_between_layers"] = True
+        if g.random() < 0.2:
+            kw["tail_bound"] = float(g.choice([3.0, 5.0, 8.0]))
+    else:
+        if g.random() < 0.3:
+            kw["net"] = "mlp"
+        if g.random() < 0.5:
+            kw["linear_transform"] = g.choice(["lu", "permutation", None])
+            if kw["linear_transform"] is not None:
+                kw["linear_transform"] = str(kw["linear_transform"])
+        if g.random() < 0.5:
+            kw["batch_norm_between_layers"] = bool(g.random() < 0.5)
+        if g.random() < 0.2:
+            kw["use_volume_preserving"] = True
+        if g.random() < 0.2:
+            kw["actnorm"] = True
+        if g.random() < 0.15:
+            kw["pre_transform"] = "batch_norm"
+    return ("nsf" if nsf else "realnvp"), (D, H, blocks, layers), kw, act
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    g = np.random.default_rng(args.seed)
+    failures, skipped, worst = [], 0, dict(log_prob=0.0, forward=0.0, inverse=0.0)
+    for it in range(args.iterations):
+        kind, shape, kw, act = random_case(g)
+        P, Oc = (NeuralSplineFlow, O.NeuralSplineFlow) if kind == "nsf" else (RealNVP, O.RealNVP)
+        desc = dict(kind=kind, shape=shape, act=act, **{k: (v if not callable(v) else act) for k, v in kw.items()})
+        try:
+            ref, flow = make_pair(P, Oc, shape, kw, seed=int(g.integers(0, 2**31)))
+        except (ValueError, NotImplementedError, RuntimeError) as exc:  # an unsupported combination raises: fine
+            skipped += 1
+            if "--verbose" in sys.argv:
+                print("skip", json.dumps(desc), type(exc).__name__, str(exc)[:80])
+            continue
+        flow.precision = "f32"
+        n = int(g.choice([1, 31, 33, 257, 1000, 4097]))
+        scale = float(g.choice([0.3, 1.0, 2.5]))
+        x = torch.randn(n, shape[0], generator=torch.Generator().manual_seed(it)) * scale
+        ref64 = copy.deepcopy(ref).double()  # the arbiter where float32 itself is ill-conditioned
+        with torch.no_grad():
+            lp_ref = ref.log_prob(x)
+            z_ref, ld_ref = ref.forward(x)
+            xi_ref, ldi_ref = ref.inverse(x)
+            lp64 = ref64.log_prob(x.double())
+            xi64, ldi64 = ref64.inverse(x.double())
+            lp = flow.log_prob(x.to(DEV)).cpu()
+            z, ld = flow.forward(x.to(DEV))
+            xi, ldi = flow.inverse(x.to(DEV))
+        # log_prob: the north_star bar against the float32 oracle, or - where the float32 oracle itself
+        # is further than that from float64 (|log_prob| near zero, deep tails) - no worse than 3x its error
+        e_lp = rel_err(lp, lp_ref, floor=1e-3)
+        lp_slack = 3.0 * rel_err(lp_ref, lp64, floor=1e-3)
+        ok_lp = e_lp <= 1e-5 or rel_err(lp, lp64, floor=1e-3) <= lp_slack
+        e_f = max(rel_err(z.cpu(), z_ref) / 2e-4, rel_err(ld.cpu(), ld_ref) / 5e-4)
+        finite = bool(torch.isfinite(xi64).all() and torch.isfinite(ldi64).all() and torch.isfinite(xi_ref).all())
+        if finite:
+            # the inverse amplifies round-off (affine couplings divide by scales down to 1e-3; |x| reaches
+            # 1e10 for inputs at 2.5 sigma): the bar is the forward one or 3x the float32 oracle's own
+            # distance from float64, whichever is larger
+            bar_x = max(2e-4, 3.0 * rel_err(xi_ref, xi64))
+            bar_l = max(5e-4, 3.0 * rel_err(ldi_ref, ldi64))
+            e_i = max(rel_err(xi.cpu(), xi64) / bar_x, rel_err(ldi.cpu(), ldi64) / bar_l)
+        else:
+            e_i = 0.0
+        worst["log_prob"] = max(worst["log_prob"], e_lp if e_lp <= 1e-5 else 0.0)
+        worst["forward"] = max(worst["forward"], e_f)
+        worst["inverse"] = max(worst["inverse"], e_i)
+        if not (ok_lp and e_f <= 1.0 and e_i <= 1.0):
+            failures.append(dict(case=it, n=n, scale=scale, log_prob_rel=e_lp, log_prob_slack=lp_slack,
+                                 forward_over_bar=e_f, inverse_over_bar=e_i, **desc))
+            print("FAIL", json.dumps(failures[-1], default=str), flush=True)
+    print(json.dumps(dict(iterations=args.iterations, skipped=skipped, failures=len(failures), worst=worst)))
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()
