@@ -367,7 +367,7 @@ def main():
 
     kernel_ms, kernel_ms_min = time_draw_kernel(prop)
     geometry = LAST_GEOMETRY
-    precision = prop.flow.model.precision  # what populate() actually ran
+    precision = prop.flow.model.effective_precision  # what populate() actually ran ("auto" resolved by the flow)
     achieved = FLOPS_PER_ROW * DRAWSIZE / (kernel_ms * 1e-3) / 1e12
     f32_ms, _ = time_draw_kernel(prop, precision="f32")
     f32_achieved = FLOPS_PER_ROW * DRAWSIZE / (f32_ms * 1e-3) / 1e12
@@ -388,6 +388,10 @@ def main():
             "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None,
             "dtype": "bf16x3 (split-bf16 operands on bf16 MFMA, f32 accumulate)" if precision == "bf16x3" else "f32",
+            # populate() asks for "auto": split-bf16 only if a 4096-row probe of THIS flow agrees with the
+            # exact-float32 kernels to 1e-5 relative in both directions (HipFlow._pack_auto)
+            "precision_policy": {"requested": prop.precision, "effective": precision,
+                                 "probe_rel_err_vs_f32": prop.flow.model.probe_error},
             "data": "synthetic",
             "config": {
                 "workload": "32-D Rosenbrock, NeuralSplineFlow (8 RQ bins, 6 coupling layers, "

@@ -78,9 +78,7 @@ class ImportanceFlowModel(FlowModel):
         self._trainer = None  # the optimiser follows the current model (reset_optimiser)
 
     def _set_precision(self, flow):
-        from .flows.base import populate_precision
-
-        flow.precision = populate_precision(flow) if self.precision == "auto" else self.precision
+        flow.precision = self.precision  # "auto" is resolved by the flow per set of weights (HipFlow._pack_auto)
 
     def _tensor(self, x):
         return torch.from_numpy(np.ascontiguousarray(x)).type(torch.float32).to(self.device)

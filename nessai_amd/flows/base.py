@@ -8,6 +8,7 @@ the reference's ``NFlow`` (``flows/base.py:170-316``) whose transform and base
 distribution run in the gfx950 kernels of ``nessai_amd/csrc``.
 """
 
+import math
 import os
 from abc import ABC, abstractmethod
 
@@ -140,8 +141,10 @@ class HipFlow(BaseFlow):
         self.waves_per_group = 0
         self.max_groups = 0
         self.precision = DEFAULT_PRECISION
-        if self.precision not in pack.PRECISIONS:
-            raise ValueError(f"unknown precision {self.precision!r}; choose from {sorted(pack.PRECISIONS)}")
+        self.effective_precision = self.precision if self.precision != "auto" else "f32"
+        self.probe_error = None
+        if self.precision not in pack.PRECISIONS and self.precision != "auto":
+            raise ValueError(f"unknown precision {self.precision!r}; choose from {sorted(pack.PRECISIONS)} or 'auto'")
         desc = M.describe(self)
         self.features = desc["D"]
         self.transform_kind = desc["transform"]
@@ -156,7 +159,7 @@ class HipFlow(BaseFlow):
         # every other structural limit of the kernels (LU-linear beyond 64 features, mixed conditioner
         # depths, ...) is known to the packer: pack once now so that an unsupported configuration raises
         # at construction like the checks above, not at the first call
-        pack.pack_flow(dict(desc, precision=self.precision))
+        pack.pack_flow(dict(desc, precision=self.precision if self.precision != "auto" else "f32"))
 
     # -- device image ----------------------------------------------------------
 
@@ -189,7 +192,12 @@ class HipFlow(BaseFlow):
             )
         key = (device, self.precision, self._fingerprint())
         if key != self._image_key:
-            image = pack.pack_flow(dict(M.describe(self), precision=self.precision))
+            desc = M.describe(self)
+            if self.precision == "auto":
+                image = self._pack_auto(desc, device)
+            else:
+                image = pack.pack_flow(dict(desc, precision=self.precision))
+                self.effective_precision = self.precision
             self._image_host = image
             self._header = (lib.ctypes.c_uint32 * pack.HEADER_WORDS)(*image[: pack.HEADER_WORDS].tolist())
             with torch.inference_mode(False):  # cached across calls: must not be inference tensors
@@ -198,6 +206,53 @@ class HipFlow(BaseFlow):
                 self._status = torch.zeros(4, dtype=torch.int32, device=device)
             self._image_key = key
         return self._header, self._image_dev
+
+    #: ``precision = "auto"``: rows of the probe and the bar its two precision modes must agree to
+    AUTO_PROBE_ROWS = 4096
+    AUTO_PROBE_BAR = 1e-5
+
+    def _pack_auto(self, desc, device):
+        """Packed image for ``precision = "auto"``: split-bf16 where it is MEASURED to agree with the
+        exact-float32 kernels on this flow's current weights, float32 otherwise.
+
+        The static envelope (``populate_precision``) only says where split-bf16 is worth trying: its
+        error grows with the conditioning of the flow - random flows inside the envelope reach 6e-5
+        relative at initialisation scale and 1e-3 with weights three times larger
+        (``scripts/fuzz_bf16x3.py``) - so every time the weights change, a probe of
+        ``AUTO_PROBE_ROWS`` latent rows goes through both kernels in both directions (inverse:
+        ``log q`` of the populate path; forward: ``log_prob``) and split-bf16 is kept only if they
+        agree to ``AUTO_PROBE_BAR`` relative.  Costs one extra pack and four small launches per
+        change of the weights."""
+        if populate_precision(self) != "bf16x3" or self.training:
+            self.effective_precision, self.probe_error = "f32", None
+            return pack.pack_flow(dict(desc, precision="f32"))
+        images = {p: pack.pack_flow(dict(desc, precision=p)) for p in ("f32", "bf16x3")}
+        n, d = self.AUTO_PROBE_ROWS, self.features
+        with torch.inference_mode(False), torch.no_grad():
+            z = torch.randn(n, d, generator=torch.Generator().manual_seed(20260930)).to(device)
+            status = torch.zeros(4, dtype=torch.int32, device=device)
+            out = {}
+            for p, image in images.items():
+                header = (lib.ctypes.c_uint32 * pack.HEADER_WORDS)(*image[: pack.HEADER_WORDS].tolist())
+                header_t = ops.header_tensor(header)
+                image_dev = torch.from_numpy(image.view(np.int32)).to(device)
+                x, ld = torch.ops.nessai_amd.flow_run(z, image_dev, header_t, DIR_INVERSE, MODE_APPLY, True, status,
+                                                      self.waves_per_group, self.max_groups)
+                out[p] = (x, ld, image_dev, header_t)
+            x32, ld32 = out["f32"][0], out["f32"][1].double()
+            log_pz = -0.5 * (z.double() ** 2).sum(dim=1) - 0.5 * d * math.log(2.0 * math.pi)
+            log_q32 = log_pz - ld32
+            err = ((out["bf16x3"][1].double() - ld32).abs() / log_q32.abs().clamp_min(1e-3)).max()
+            lp = {}
+            for p in images:
+                _, lp[p] = torch.ops.nessai_amd.flow_run(x32, out[p][2], out[p][3], DIR_FORWARD, MODE_LOGPROB, False,
+                                                         status, self.waves_per_group, self.max_groups)
+            lp32 = lp["f32"].double()
+            err = torch.maximum(err, ((lp["bf16x3"].double() - lp32).abs() / lp32.abs().clamp_min(1e-3)).max())
+            err = float(err)
+        ok = math.isfinite(err) and err <= self.AUTO_PROBE_BAR
+        self.effective_precision, self.probe_error = ("bf16x3" if ok else "f32"), err
+        return images[self.effective_precision]
 
     # -- kernel calls ----------------------------------------------------------
 

@@ -480,14 +480,13 @@ class FlowProposal:
         """(flow, header, image, status) for the draw kernel: eval mode, precision policy and the
         packed device image.  Costs ~0.3 ms of host time (it walks the module tree), so
         ``populate`` does it once per call, not once per pass."""
-        from .flows.base import populate_precision
-
         flow = self.flow.model
         if flow.training:
             flow.eval()
-        wanted = populate_precision(flow) if self.precision == "auto" else self.precision
-        if flow.precision != wanted:
-            flow.precision = wanted
+        # "auto": the flow resolves it per set of weights - split-bf16 inside the static envelope AND
+        # measured to agree with float32 on a probe (HipFlow._pack_auto)
+        if flow.precision != self.precision:
+            flow.precision = self.precision
         header, image = flow.device_image()
         return flow, header, image, flow._status
 

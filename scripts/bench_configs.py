@@ -73,7 +73,7 @@ def run(tag, model, flow_config, nlive, drawsize, steps=5, cpu_draw=50_000):
         cpu_s = time.perf_counter() - t
     out = {
         "config": tag, "nlive": nlive, "drawsize": drawsize,
-        "precision": prop.flow.model.precision,
+        "precision": prop.flow.model.effective_precision,
         "gpu_train_seconds": train_s,
         "gpu_accepted_per_s": acc / gpu_s, "gpu_rows_per_s": prop_n / gpu_s,
         "gpu_acceptance": acc / prop_n, "gpu_ms_per_populate": 1e3 * gpu_s / steps,

@@ -5,6 +5,8 @@ reference CPU path on identical weights and inputs; the reference's own
 property tests for the flows (``tests/test_flows/test_included_flows.py``)
 are restated on the device path.
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -331,3 +333,37 @@ def test_log_prob_many_mixed_structures_falls_back_to_per_flow_launches():
     out = log_prob_many([a, b], x)
     assert torch.equal(out[0], a.log_prob(x)) and torch.equal(out[1], b.log_prob(x))
     assert log_prob_many([a], x[:0]).shape == (1, 0)
+
+
+def test_auto_precision_is_measured_per_set_of_weights():
+    """``precision = "auto"`` (what ``FlowProposal.populate`` asks for): the static envelope only
+    nominates split-bf16, a probe of the flow's CURRENT weights through both kernels decides.  The
+    benchmark flow at initialisation scale stays in split-bf16; the same flow with its conditioner
+    weights blown up - an ill-conditioned flow, where split-bf16 is off by 1e-4..1e-2
+    (``scripts/fuzz_bf16x3.py``) - falls back to exact float32, and the choice follows the weights."""
+    ref, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (32, 64, 6, 2), {})
+    flow.precision = "auto"
+    x = torch.randn(2000, 32)
+    with torch.no_grad():
+        lp_ref = ref.log_prob(x)
+    lp = flow.log_prob(x.to(DEV)).cpu()
+    assert flow.effective_precision == "bf16x3" and flow.probe_error <= flow.AUTO_PROBE_BAR
+    assert rel_err(lp, lp_ref, floor=1e-3) <= LOG_PROB_RTOL
+
+    with torch.no_grad():
+        for r, f in zip(ref.parameters(), flow.parameters()):
+            if r.ndim == 2:
+                r.mul_(3.0)
+                f.mul_(3.0)
+        lp_ref = ref.log_prob(x)
+        lp64 = copy.deepcopy(ref).double().log_prob(x.double())
+    lp = flow.log_prob(x.to(DEV)).cpu()
+    assert flow.effective_precision == "f32" and flow.probe_error > flow.AUTO_PROBE_BAR
+    # float32 itself is ~1e-4 from float64 on this flow: the device must be as good as the float32 oracle
+    assert rel_err(lp, lp64, floor=1e-3) <= 3.0 * rel_err(lp_ref, lp64, floor=1e-3)
+
+    # a flow outside the static envelope is never probed
+    _, small = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2), {})
+    small.precision = "auto"
+    small.log_prob(torch.randn(10, 4, device=DEV))
+    assert small.effective_precision == "f32" and small.probe_error is None
