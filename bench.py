@@ -389,7 +389,7 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16x3 (split-bf16 operands on bf16 MFMA, f32 accumulate)" if precision == "bf16x3" else "f32",
             # populate() asks for "auto": split-bf16 only if a 4096-row probe of THIS flow agrees with the
-            # exact-float32 kernels to 1e-5 relative in both directions (HipFlow._pack_auto)
+            # exact-float32 kernels to 5e-6 relative in both directions (HipFlow._pack_auto)
             "precision_policy": {"requested": prop.precision, "effective": precision,
                                  "probe_rel_err_vs_f32": prop.flow.model.probe_error},
             "data": "synthetic",
