@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Randomised parity sweep of the fused populate pass: FlowProposal.backward_pass (draw-kernel
+epilogue: inverse flow, z-score, prior bounds, log q) on injected latents against the CPU oracle,
+over random flow families / shapes and both precision settings of the proposal ("f32", "auto").
+
+    python scripts/fuzz_populate.py [--iterations 60] [--seed 0]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import test_gpu_populate as T  # noqa: E402  (build(): device proposal + oracle proposal on the same weights)
+from nessai_amd.model import GaussianModel, RosenbrockModel  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    g = np.random.default_rng(args.seed)
+    bad, worst, borderline, chosen = [], 0.0, 0, {"f32": 0, "bf16x3": 0}
+    for it in range(args.iterations):
+        ftype = "nsf" if g.random() < 0.65 else "realnvp"
+        dims = int(g.integers(2, 41))
+        fk = dict(n_neurons=int(g.choice([8, 16, 32, 48, 64, 128])), n_blocks=int(g.integers(1, 7)),
+                  n_layers=int(g.integers(1, 4)))
+        if ftype == "nsf" and g.random() < 0.5:
+            fk["num_bins"] = int(g.choice([4, 8, 10, 16]))
+        precision = str(g.choice(["f32", "auto"]))
+        mcls = RosenbrockModel if g.random() < 0.5 else GaussianModel
+        desc = dict(case=it, ftype=ftype, dims=dims, precision=precision, model=mcls.__name__, **fk)
+        try:
+            prop, oprop = T.build(dims, ftype, fk, model_cls=mcls, seed=int(g.integers(1, 10**6)), precision=precision)
+        except (ValueError, NotImplementedError) as exc:
+            print("skip", json.dumps(desc), str(exc)[:60])
+            continue
+        n = int(g.choice([257, 2000, 5000]))
+        z = g.normal(size=(n, dims)).astype(np.float32).astype(np.float64) * float(g.choice([0.7, 1.0, 1.3]))
+        x, log_q, z_kept = prop.backward_pass(z, return_z=True)
+        x_o, log_q_o, z_o = oprop.backward_pass(z)
+        chosen[prop.flow.model.effective_precision] += 1
+        if len(x) != len(x_o):
+            # a row within float32 round-off of a prior bound may be kept on one side only
+            if abs(len(x) - len(x_o)) <= 2:
+                borderline += 1
+                continue
+            bad.append(dict(kind="kept rows", got=len(x), oracle=len(x_o), **desc))
+            print("FAIL", json.dumps(bad[-1]), flush=True)
+            continue
+        if len(x) == 0:
+            continue
+        a = np.stack([x[nm] for nm in prop.names], axis=1)
+        b = np.stack([x_o[nm] for nm in prop.names], axis=1)
+        e_x = float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)))
+        e_q = float(np.max(np.abs(log_q - log_q_o) / np.maximum(np.abs(log_q_o), 1e-3)))
+        worst = max(worst, e_q)
+        # log q: the parity bar, with the head-room the tests give float32 vs float32 (atol 1e-4 on |log q| ~ 10..100)
+        if not (np.array_equal(z_kept, z_o) and e_x <= 6e-4 and (e_q <= 2e-5 or np.max(np.abs(log_q - log_q_o)) <= 1e-4)):
+            bad.append(dict(kind="values", x_rel=e_x, log_q_rel=e_q, abs_log_q=float(np.max(np.abs(log_q - log_q_o))),
+                            effective=prop.flow.model.effective_precision, probe=prop.flow.model.probe_error, **desc))
+            print("FAIL", json.dumps(bad[-1]), flush=True)
+    print(json.dumps(dict(iterations=args.iterations, failures=len(bad), borderline_row_cases=borderline,
+                          worst_log_q_rel=worst, effective_precisions=chosen)))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
