@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""Randomised parity sweep of the training kernels: loss and every gradient of one minibatch
+(-mean log_prob) against torch autograd of the CPU oracle, over random supported flow
+configurations and batch sizes (fused per-coupling kernels where they apply, layer-wise otherwise).
+
+    python scripts/fuzz_train.py [--iterations 60] [--seed 0]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+import fuzz_parity as F  # noqa: E402  (random_case)
+from helpers import DEV  # noqa: E402
+from nessai_amd.flows import NeuralSplineFlow, RealNVP  # noqa: E402
+from nessai_amd.train import Trainer  # noqa: E402
+from oracle import flows as O  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    g = np.random.default_rng(args.seed)
+    bad, skipped, worst = [], 0, dict(loss=0.0, grad=0.0)
+    for it in range(args.iterations):
+        kind, shape, kw, act = F.random_case(g)
+        if shape[0] > 48:
+            shape = (int(g.integers(2, 49)),) + shape[1:]
+        P, Oc = (NeuralSplineFlow, O.NeuralSplineFlow) if kind == "nsf" else (RealNVP, O.RealNVP)
+        desc = dict(case=it, kind=kind, shape=shape, act=act, **{k: (v if not callable(v) else act) for k, v in kw.items()})
+        torch.manual_seed(int(g.integers(0, 2**31)))
+        try:
+            ref = Oc(*shape, **kw)
+            flow = P(*shape, **kw)
+        except (ValueError, NotImplementedError, RuntimeError):
+            skipped += 1
+            continue
+        with torch.no_grad():
+            gen = torch.Generator().manual_seed(it)
+            for n_, p in ref.named_parameters():
+                if "linear_layers.1" in n_:
+                    p.mul_(200.0)  # residual branches start at ~1e-3: make them matter
+                if "entries" in n_ or "unconstrained" in n_:
+                    p.add_(0.1 * torch.randn(p.shape, generator=gen))
+        flow.load_state_dict(ref.state_dict())
+        flow.to(DEV)
+        n = int(g.choice([33, 200, 333, 1000]))
+        x = torch.randn(n, shape[0], generator=torch.Generator().manual_seed(1000 + it)) * float(g.choice([0.7, 1.5]))
+        ref.train()
+        loss_ref = -ref.log_prob(x).mean()
+        if not torch.isfinite(loss_ref):
+            skipped += 1
+            continue
+        loss_ref.backward()
+        g_ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ref.parameters()])
+        try:
+            tr = Trainer(flow)
+            tr.step(x.to(DEV), clip_norm=5.0, lr=0.0)
+        except (ValueError, NotImplementedError, RuntimeError) as exc:
+            skipped += 1
+            if "--verbose" in sys.argv:
+                print("skip", json.dumps(desc, default=str), str(exc)[:80])
+            continue
+        torch.cuda.synchronize()
+        e_loss = abs(tr.loss_acc.item() - loss_ref.item()) / max(1.0, abs(loss_ref.item()))
+        gd = tr.grads.cpu()
+        scale = max(1e-3, float(g_ref.abs().max()))
+        e_grad = float((gd - g_ref).abs().max()) / scale
+        worst["loss"] = max(worst["loss"], e_loss)
+        worst["grad"] = max(worst["grad"], e_grad)
+        if not (e_loss <= 1e-5 and e_grad <= 2e-4):
+            bad.append(dict(n=n, loss_rel=e_loss, grad_rel_to_max=e_grad, **desc))
+            print("FAIL", json.dumps(bad[-1], default=str), flush=True)
+    print(json.dumps(dict(iterations=args.iterations, skipped=skipped, failures=len(bad), worst=worst)))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
