@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Randomised parity sweep of the reparameterisation table in the draw kernel's epilogue: every
+parameter gets a random map (rescale-to-bounds with logit / log post-rescaling, plain, with offset,
+null, z-score), the proposal and the oracle are fitted to the same live points, and
+``backward_pass`` on injected latents is compared (kept rows, x per column, log q incl. the row-dependent
+Jacobians).
+
+    python scripts/fuzz_reparam.py [--iterations 40] [--seed 0]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import test_gpu_populate as T  # noqa: E402
+from oracle import reparam as OR  # noqa: E402
+
+KINDS = ["logit", "log-rescale", "default", "offset", "null", "zscore"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    g = np.random.default_rng(args.seed)
+    bad, worst, borderline = [], 0.0, 0
+    for it in range(args.iterations):
+        dims = int(g.integers(2, 13))
+        names = [f"x_{i}" for i in range(dims)]
+        assign = {n: str(g.choice(KINDS)) for n in names}
+        config = {k: [n for n in names if assign[n] == k] for k in KINDS[:-1]}
+        config = {k: v for k, v in config.items() if v}
+        if not config:
+            continue
+        fk = dict(n_neurons=int(g.choice([8, 16, 32])), n_blocks=int(g.integers(1, 5)))
+        desc = dict(case=it, dims=dims, assign=assign, **fk)
+        prop, oprop = T.build(dims, "nsf", fk, seed=int(g.integers(1, 10**6)), reparameterisations=config)
+        b = {n: [-5.0, 5.0] for n in names}
+        parts = []
+        for kind, members in config.items():  # the product applies the maps in the order of the configuration
+            if kind == "logit":
+                parts.append(OR.OracleRescaleToBounds(members, b, rescale_bounds=[0.0, 1.0], update_bounds=False, post_rescaling="logit"))
+            elif kind == "log-rescale":
+                parts.append(OR.OracleRescaleToBounds(members, b, rescale_bounds=[0.0, 1.0], update_bounds=False, post_rescaling="log"))
+            elif kind == "default":
+                parts.append(OR.OracleRescaleToBounds(members, b))
+            elif kind == "offset":
+                parts.append(OR.OracleRescaleToBounds(members, b, offset=True))
+            else:
+                parts.append(OR.OracleNull(members))
+        rest = [n for n in names if assign[n] == "zscore"]
+        if rest:
+            parts.append(OR.OracleScaleAndShift(rest, estimate_scale=True, estimate_shift=True))
+        oprop.reparam = OR.OracleCombined(parts)
+        live = prop.model.new_point(400, rng=np.random.default_rng(it))
+        for n in names:
+            live[n] = (0.1 if assign[n] == "null" else 0.4) * live[n]
+        prop.check_state(live)
+        oprop.update_rescaling(live)
+        z = g.normal(size=(4000, dims)).astype(np.float32).astype(np.float64) * float(g.choice([0.8, 1.2]))
+        x, log_q, z_kept = prop.backward_pass(z, return_z=True)
+        x_o, log_q_o, z_o = oprop.backward_pass(z)
+        if len(x) != len(x_o):
+            if abs(len(x) - len(x_o)) <= 2:
+                borderline += 1
+                continue
+            bad.append(dict(kind="kept rows", got=len(x), oracle=len(x_o), **desc))
+            print("FAIL", json.dumps(bad[-1]), flush=True)
+            continue
+        if not len(x):
+            continue
+        ok = np.array_equal(z_kept, z_o)
+        e_x = 0.0
+        for n in names:
+            tol = 1e-3 if assign[n] in ("logit", "log-rescale") else 2e-4
+            e = float(np.max(np.abs(x[n] - x_o[n])))
+            e_x = max(e_x, e / tol)
+        fin = np.isfinite(log_q_o)
+        ok = ok and np.array_equal(np.isfinite(log_q), fin)
+        d = np.abs(log_q[fin] - log_q_o[fin])
+        e_q = float(np.max(d / np.maximum(np.abs(log_q_o[fin]), 1e-3))) if fin.any() else 0.0
+        worst = max(worst, e_q)
+        if not (ok and e_x <= 1.0 and (e_q <= 1e-5 or float(d.max()) <= 2e-4)):
+            bad.append(dict(kind="values", x_over_tol=e_x, log_q_rel=e_q, log_q_abs=float(d.max()), rows_equal=bool(ok), **desc))
+            print("FAIL", json.dumps(bad[-1]), flush=True)
+    print(json.dumps(dict(iterations=args.iterations, failures=len(bad), borderline_row_cases=borderline, worst_log_q_rel=worst)))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
