@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("script, iterations, seed", [
-    ("fuzz_parity.py", 60, 2),     # flows: forward / inverse / log_prob, float64 arbiter
+    ("fuzz_parity.py", 30, 2),     # flows: forward / inverse / log_prob, float64 arbiter
     ("fuzz_populate.py", 30, 4),   # fused populate pass, proposal precision f32 / auto
     ("fuzz_reparam.py", 25, 6),    # reparameterisation table of the draw epilogue
     ("fuzz_train.py", 40, 5),      # loss and gradients of one minibatch
