@@ -166,3 +166,75 @@ def test_scale_activation_callables_are_identified():
     flow = RealNVP(4, 8, 2, 2, scale_activation=lambda x: torch.sigmoid(x - 1.0) + 0.2)
     assert M.describe(flow)["affine_shift"] == -1.0
     RealNVP(4, 8, 2, 2, use_volume_preserving=True, scale_activation=torch.exp)  # unused for additive couplings
+
+
+def test_parameter_block_view_and_record_copies_equal_the_field_loops():
+    """The (N, D) view of the parameter fields and the record-wise copy / mask / concatenate helpers
+    (livepoint.py) give exactly what numpy's per-field operations give, and step aside for layouts
+    they do not cover."""
+    from nessai_amd.proposal_importance import empty_ins_array
+
+    names = [f"x_{i}" for i in range(7)]
+    rng = np.random.default_rng(1)
+    a = empty_ins_array(50, names)
+    for n in names:
+        a[n] = rng.normal(size=50)
+    a["logL"] = rng.normal(size=50)
+    ref = np.stack([a[n] for n in names], axis=-1)
+    block = livepoint.parameter_block(a, names)
+    assert block is not None and np.array_equal(block, ref)
+    block[3, 2] = 42.0  # a writable view
+    assert a["x_2"][3] == 42.0
+    assert np.array_equal(livepoint.live_points_to_array(a, names), np.stack([a[n] for n in names], axis=-1))
+    # layouts the view does not cover fall back to the field loop
+    assert livepoint.parameter_block(a[::2], names) is None
+    assert livepoint.parameter_block(a, names[::-1]) is None
+    assert livepoint.parameter_block(a, ["x_0", "logL"]) is None
+    assert np.array_equal(livepoint.live_points_to_array(a[::2], names), np.stack([a[n][::2] for n in names], axis=-1))
+    assert np.array_equal(livepoint.live_points_to_array(a, names[::-1]), np.stack([a[n] for n in names[::-1]], axis=-1))
+    assert livepoint.parameter_block(a[:0], names).shape == (0, 7)
+
+    def same(u, v):
+        return u.dtype == v.dtype and all(np.array_equal(u[f], v[f], equal_nan=True) for f in u.dtype.names)
+
+    c = livepoint.copy_points(a)
+    assert same(c, a.copy()) and c is not a
+    c["x_0"][0] = -1.0
+    assert a["x_0"][0] != -1.0
+    mask = rng.random(50) > 0.4
+    assert same(livepoint.take_points(a, mask), a[mask])
+    idx = np.array([5, 1, 1, 40])
+    assert same(livepoint.take_points(a, idx), a[idx])
+    assert same(livepoint.concatenate_points([a[:10], a[20:25]]), np.concatenate([a[:10], a[20:25]]))
+    assert same(livepoint.take_points(a[::2], mask[::2]), a[::2][mask[::2]])  # non-contiguous: plain numpy
+
+
+def test_vectorised_model_maps_equal_the_per_field_forms():
+    m = RosenbrockModel(5)
+    pts = m.new_point(200, rng=np.random.default_rng(2))
+    pts["x_1"][:5] = [6.0, -6.0, 5.0, -5.0, np.nan]
+    slow_in = ~np.any([(pts[n] < m.bounds[n][0]) | (pts[n] > m.bounds[n][1]) for n in m.names], axis=0)
+    assert np.array_equal(m.in_bounds(pts), slow_in)
+    unit = m.to_unit_hypercube(pts)
+    back = m.from_unit_hypercube(unit)
+    for n in m.names:
+        lo, hi = m.bounds[n]
+        assert np.array_equal(unit[n], (pts[n] - lo) / (hi - lo), equal_nan=True)
+        assert np.array_equal(back[n], lo + (hi - lo) * unit[n], equal_nan=True)
+    slow_unit = ~np.any([(unit[n] < 0.0) | (unit[n] > 1.0) for n in m.names], axis=0)
+    assert np.array_equal(m.in_unit_hypercube(unit), slow_unit)
+
+
+def test_poolsize_scale_limits():
+    """1 / acceptance inside [1, max_poolsize_scale]; the maximum when nothing was accepted
+    (proposal/flowproposal/base.py:416-435)."""
+    from nessai_amd.proposal import FlowProposal
+
+    class Stub:
+        max_poolsize_scale = 10.0
+        _poolsize_scale = None
+
+    s = Stub()
+    for acceptance, want in ((0.0, 10.0), (None, 10.0), (0.5, 2.0), (0.01, 10.0), (2.0, 1.0), (1.0, 1.0)):
+        FlowProposal.update_poolsize_scale(s, acceptance)
+        assert s._poolsize_scale == want
