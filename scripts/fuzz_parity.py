@@ -7,7 +7,7 @@ mode) against the CPU oracle.  Complements the fixed list of tests/test_gpu_flow
 Prints one line per failing case and a summary; exit code 1 if any case misses the bars
 (log_prob 1e-5 relative with a 1e-3 floor; forward 2e-4 / 5e-4 absolute-relative for x / log-det; where
 the float32 oracle itself is further than a bar from its float64 twin - inverses that blow up, log_prob
-near zero - the device must be within 3x the float32 oracle's own error of the float64 result)."""
+near zero, LU layers at 2.5 sigma in the forward direction - the device must be within 3x the float32 oracle's own error of the float64 result)."""
 import argparse
 import copy
 import json
@@ -102,6 +102,12 @@ def main():
         lp_slack = 3.0 * rel_err(lp_ref, lp64, floor=1e-3)
         ok_lp = e_lp <= 1e-5 or rel_err(lp, lp64, floor=1e-3) <= lp_slack
         e_f = max(rel_err(z.cpu(), z_ref) / 2e-4, rel_err(ld.cpu(), ld_ref) / 5e-4)
+        if e_f > 1.0:  # same rule as the inverse: 3x the float32 oracle's own distance from float64
+            with torch.no_grad():
+                z64, ld64 = ref64.forward(x.double())
+            if bool(torch.isfinite(z64).all() and torch.isfinite(ld64).all()):
+                e_f = max(rel_err(z.cpu(), z64) / max(2e-4, 3.0 * rel_err(z_ref, z64)),
+                          rel_err(ld.cpu(), ld64) / max(5e-4, 3.0 * rel_err(ld_ref, ld64)))
         finite = bool(torch.isfinite(xi64).all() and torch.isfinite(ldi64).all() and torch.isfinite(xi_ref).all())
         if finite:
             # the inverse amplifies round-off (affine couplings divide by scales down to 1e-3; |x| reaches
