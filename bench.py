@@ -125,7 +125,8 @@ def last_geometry():
 
     v = [ctypes.c_int(0) for _ in range(3)]
     lib.load().nsa_last_geometry(*[ctypes.addressof(x) for x in v])
-    return {"waves_per_simd": v[0].value, "waves_per_group": v[1].value, "workgroups": v[2].value}
+    return {"waves_per_simd": v[0].value, "waves_per_group": v[1].value, "workgroups": v[2].value,
+            "row_tiles_per_wave": int(lib.load().nsa_last_row_tiles())}
 
 
 def traffic_probe(device):
@@ -156,9 +157,9 @@ def measure_traffic(waves_per_simd=None):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    if waves_per_simd in (2, 3):
+    if waves_per_simd in (2, 3, "2x2"):
         # the probe is another process: pin it to the geometry THIS run's launches used (the library
-        # times its two candidates once per process; their launches would be in the probe's trace too)
+        # times its candidates once per process; their launches would be in the probe's trace too)
         env["NESSAI_AMD_OCC"] = str(waves_per_simd)
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -374,7 +375,8 @@ def main():
 
     traffic, traffic_detail = (None, "skipped (--no-pmc or N > 1)")
     if rank == 0 and world == 1 and not args.no_pmc:
-        traffic, traffic_detail = measure_traffic((geometry or {}).get("waves_per_simd"))
+        traffic, traffic_detail = measure_traffic("2x2" if (geometry or {}).get("row_tiles_per_wave") == 2
+                                                  else (geometry or {}).get("waves_per_simd"))
     if rank == 0:
         out = {
             "metric": "accepted live points/sec in FlowProposal.populate(), 32-D Rosenbrock nlive=2000",

@@ -46,10 +46,15 @@ NSA_API int nsa_flow_supported(int hidden_tiles, int transform, int bins);
 
 /* Launch geometry of the last flow kernel this thread enqueued: waves per SIMD the instance is
  * built for (2 or 3), waves per workgroup, workgroups.  The library picks it per launch (batch
- * size, conditioner width, precision; for big split-bf16 batches by timing the two candidates
+ * size, conditioner width, precision; for big split-bf16 batches by timing the three candidates
  * once per process) - reported so that a benchmark line can say what it measured.  No reference
  * counterpart (torch picks its own launch shapes). */
 NSA_API void nsa_last_geometry(int* waves_per_simd, int* waves_per_group, int* groups);
+
+/* 32-row tiles each wave of that launch carried through the flow together: 1, or 2 (the third
+ * candidate geometry of big split-bf16 batches: one 8-wave workgroup per CU, every weight operand
+ * read from LDS feeding both tiles). */
+NSA_API int nsa_last_row_tiles(void);
 
 /* Run a whole flow over n rows.
  *

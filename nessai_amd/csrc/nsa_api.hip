@@ -32,12 +32,13 @@ static int nsa_fail(int code, const char* fmt, ...) {
 
 extern "C" const char* nsa_last_error(void) { return g_err; }
 
-static thread_local int g_last_geometry[3] = {0, 0, 0};
+static thread_local int g_last_geometry[4] = {0, 0, 0, 0};
 extern "C" void nsa_last_geometry(int* waves_per_simd, int* waves_per_group, int* groups) {
   if (waves_per_simd != nullptr) *waves_per_simd = g_last_geometry[0];
   if (waves_per_group != nullptr) *waves_per_group = g_last_geometry[1];
   if (groups != nullptr) *groups = g_last_geometry[2];
 }
+extern "C" int nsa_last_row_tiles(void) { return g_last_geometry[3]; }
 extern "C" int nsa_version(void) { return NSA_VERSION; }
 
 // ---------------------------------------------------------------------------
@@ -105,15 +106,42 @@ static int nsa_device_info(NsaDeviceInfo& out) {
   return NSA_OK;
 }
 
-// Waves per SIMD of the flow kernel.  Default: 2 (workgroups of 4 waves, two per CU); big
-// split-bf16 batches of a narrow conditioner (HT <= 2) run 3 waves per SIMD as ONE workgroup of
-// 12 waves per CU - a third of the stage copies per row and one more wave per SIMD to cover the
-// stage barriers (config 3: 1.89 -> 1.80 ms per 1e6 rows; 6- and 3-wave workgroups load the four
-// SIMDs unevenly and are slower than either).  NESSAI_AMD_OCC=2|3 overrides (read per call: the
-// benchmark scripts flip it).
+// Launch geometry of the flow kernel, as a code: waves per SIMD | (row tiles per wave - 1) << 5.
+//   2     workgroups of 4 waves, two per CU (the default)
+//   3     ONE workgroup of 12 waves per CU at 3 waves per SIMD (<= 168 VGPRs): a third of the stage
+//         copies per row and one more wave per SIMD to cover the stage barriers
+//   0x22  ONE workgroup of 8 waves per CU at 2 waves per SIMD, each wave taking TWO 32-row tiles through
+//         every layer together: a weight operand read from LDS feeds 6 MFMAs instead of 3, a stage is
+//         copied once per 512 rows, and every wave has two independent accumulator / spline chains
+//         (config 3: 1.70 ms per 1e6 rows where the other two take 1.93 on the same box)
+// The last two are for big split-bf16 batches of a narrow conditioner (HT <= 2): nsa_big_batch_geometry.
+// NESSAI_AMD_OCC=2|3|2x2 overrides (read per call: the benchmark scripts flip it).
+#define NSA_GEO_2X2 0x22
+
+// Big batches: the geometry with the least estimated time = whole rounds of the grid x tiles per round
+// x relative time per tile (steady-state draw kernel of config 3 on three MI355X boxes: 1.67-1.70 ms
+// per 1e6 rows with two tiles per wave, 1.75-1.93 with 12 waves, 1.75-1.94 with 2 x 4 waves).  The
+// rounds matter at the lower end: 6144 tiles are 1.5 rounds of 256 x 16 tiles but exactly 2 of 256 x 12.
+static int nsa_big_batch_geometry(long long tiles, int num_cus) {
+  const int geo[3] = {NSA_GEO_2X2, 3, 2};
+  const long long per_round[3] = {16LL * num_cus, 12LL * num_cus, 8LL * num_cus};
+  const double per_tile[3] = {1.00, 1.06, 1.09};
+  int best = NSA_GEO_2X2;
+  double best_t = 0.0;
+  for (int c = 0; c < 3; ++c) {
+    const double t = (double)((tiles + per_round[c] - 1) / per_round[c]) * (double)per_round[c] * per_tile[c];
+    if (c == 0 || t < best_t) {
+      best = geo[c];
+      best_t = t;
+    }
+  }
+  return best;
+}
 static int nsa_occupancy(int ht, int precision, long long n_tiles, int n_flows, int num_cus,
                          int waves_per_group) {
   const char* e = getenv("NESSAI_AMD_OCC");
+  if (e != nullptr && e[0] == '2' && e[1] == 'x' && e[2] == '2')
+    return (ht <= 2 && precision == NSA_PREC_BF16X3 && waves_per_group <= 0) ? NSA_GEO_2X2 : NSA_DEFAULT_OCC;
   if (e != nullptr && (e[0] == '2' || e[0] == '3')) return (e[0] == '3' && ht <= 2) ? 3 : 2;
   if (waves_per_group > 0) return (waves_per_group > 8 && ht <= 2) ? 3 : NSA_DEFAULT_OCC;
   if (ht <= 2 && precision == NSA_PREC_BF16X3 && n_tiles * n_flows >= 24LL * num_cus) return 3;
@@ -133,15 +161,14 @@ static int nsa_check_header(const uint32_t* h) {
 static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group, int max_groups,
                            hipStream_t stream, int n_flows = 1, int force_occ = 0);
 
-// Big split-bf16 batches of a narrow conditioner have two good geometries - ONE 12-wave workgroup
-// per CU at 3 waves per SIMD (a third of the stage copies per row) or TWO 4-wave workgroups at 2
-// waves per SIMD (no spills, cheap barriers) - and which one is faster differs from box to box by
-// more than they differ from each other (1.76 / 1.88 ms per 1e6 rows of config 3 on one MI355X,
-// 1.97 / 1.83 on another).  The first such launch of a (device, kernel instance, mode, program)
-// times both on the caller's stream - the same launch, whose output does not depend on the
-// geometry, with a private status buffer and without the device-side loop control - and the
-// choice is kept for the process.  NESSAI_AMD_TUNE=0 keeps the static rule (12 waves); so does a
-// stream that is being captured.
+// NESSAI_AMD_TUNE=1 (or "verbose") replaces that static rule by a measurement: the first big launch of a
+// (device, kernel instance, mode, program) times the three candidates on the caller's stream - the same
+// launch, whose output does not depend on the geometry, with a private status buffer and without the
+// device-side loop control; every candidate twice untimed, then five rounds, best time of each - and the
+// choice is kept for the process.  Off by default: a probe at the start of a process sees the candidates
+// 0.05-0.15 ms slower than they run in steady state and closer together than they are (1.81 / 1.82 / 1.80 ms
+// for kernels that then run at 1.67 / 1.76 / 1.75), so it picked the slower geometry on two boxes of three.
+// A stream that is being captured keeps the static rule.
 struct NsaTuneEntry {
   int device, ht, kind, bins, mode, n_stages, occ;
 };
@@ -149,11 +176,11 @@ static std::mutex g_tune_mutex;
 static std::vector<NsaTuneEntry> g_tune;
 
 static int nsa_tuned_occupancy(const uint32_t* h, const NsaLaunch& p, int max_groups, hipStream_t stream,
-                               int n_flows) {
+                               int n_flows, int fallback) {
   const char* env = getenv("NESSAI_AMD_TUNE");
-  if (env != nullptr && env[0] == '0') return 3;
+  if (env == nullptr || (env[0] != '1' && env[0] != 'v')) return fallback;
   int device = 0;
-  if (hipGetDevice(&device) != hipSuccess) return 3;
+  if (hipGetDevice(&device) != hipSuccess) return fallback;
   const bool inv = p.direction == NSA_DIR_INVERSE;
   const NsaTuneEntry key = {device, (int)h[NSA_H_HT], (int)h[NSA_H_TRANSFORM], (int)h[NSA_H_BINS], p.mode,
                             (int)h[inv ? NSA_H_NSTAGES_INV : NSA_H_NSTAGES_FWD], 0};
@@ -163,11 +190,11 @@ static int nsa_tuned_occupancy(const uint32_t* h, const NsaLaunch& p, int max_gr
         e.n_stages == key.n_stages)
       return e.occ;
   hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone) return 3;
+  if (hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone) return fallback;
   int* status = nullptr;
   hipEvent_t t0 = nullptr, t1 = nullptr;
-  if (hipMalloc((void**)&status, 4 * sizeof(int)) != hipSuccess) return 3;
-  int best = 3;
+  if (hipMalloc((void**)&status, 4 * sizeof(int)) != hipSuccess) return fallback;
+  int best = fallback;
   if (hipMemsetAsync(status, 0, 4 * sizeof(int), stream) == hipSuccess && hipEventCreate(&t0) == hipSuccess &&
       hipEventCreate(&t1) == hipSuccess) {
     NsaLaunch q = p;
@@ -175,24 +202,33 @@ static int nsa_tuned_occupancy(const uint32_t* h, const NsaLaunch& p, int max_gr
     q.stop = nullptr;
     float best_ms = 0.0f;
     bool ok = true;
-    for (int occ = 3; occ >= 2 && ok; --occ) {
-      ok = nsa_launch_flow(h, q, 0, max_groups, stream, n_flows, occ) == NSA_OK;  // first use of the code object
-      ok = ok && hipEventRecord(t0, stream) == hipSuccess;
-      ok = ok && nsa_launch_flow(h, q, 0, max_groups, stream, n_flows, occ) == NSA_OK;
-      ok = ok && hipEventRecord(t1, stream) == hipSuccess && hipEventSynchronize(t1) == hipSuccess;
-      float ms = 0.0f;
-      ok = ok && hipEventElapsedTime(&ms, t0, t1) == hipSuccess;
-      if (ok && (occ == 3 || ms < best_ms)) {
-        best = occ;
-        best_ms = ms;
+    const int candidates[3] = {NSA_GEO_2X2, 3, 2};
+    float best_of[3] = {0.0f, 0.0f, 0.0f};
+    for (int warm = 0; warm < 2 && ok; ++warm)
+      for (int c = 0; c < 3 && ok; ++c) ok = nsa_launch_flow(h, q, 0, max_groups, stream, n_flows, candidates[c]) == NSA_OK;
+    for (int round = 0; round < 5 && ok; ++round)
+      for (int c = 0; c < 3 && ok; ++c) {
+        ok = hipEventRecord(t0, stream) == hipSuccess;
+        ok = ok && nsa_launch_flow(h, q, 0, max_groups, stream, n_flows, candidates[c]) == NSA_OK;
+        ok = ok && hipEventRecord(t1, stream) == hipSuccess && hipEventSynchronize(t1) == hipSuccess;
+        float ms = 0.0f;
+        ok = ok && hipEventElapsedTime(&ms, t0, t1) == hipSuccess;
+        if (ok && (round == 0 || ms < best_of[c])) best_of[c] = ms;
       }
-    }
+    for (int c = 0; c < 3 && ok; ++c)
+      if (c == 0 || best_of[c] < best_ms) {
+        best = candidates[c];
+        best_ms = best_of[c];
+      }
+    if (ok && env != nullptr && env[0] == 'v')  // NESSAI_AMD_TUNE=verbose
+      fprintf(stderr, "nessai_amd: geometry timing (ms) 2x2 %.3f, 12 waves %.3f, 2 x 4 waves %.3f -> %s\n",
+              best_of[0], best_of[1], best_of[2], best == NSA_GEO_2X2 ? "2x2" : (best == 3 ? "3" : "2"));
     if (ok) {
       NsaTuneEntry e = key;
       e.occ = best;
       g_tune.push_back(e);
     } else {
-      best = 3;
+      best = fallback;
     }
   }
   if (t0 != nullptr) (void)hipEventDestroy(t0);
@@ -226,7 +262,12 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   int occ = force_occ != 0 ? force_occ
                            : nsa_occupancy((int)h[NSA_H_HT], p.precision, n_tiles, n_flows, g_num_cus, waves_per_group);
   if (force_occ == 0 && occ == 3 && waves_per_group <= 0 && getenv("NESSAI_AMD_OCC") == nullptr)
-    occ = nsa_tuned_occupancy(h, p, max_groups, stream, n_flows);
+    occ = nsa_tuned_occupancy(h, p, max_groups, stream, n_flows, nsa_big_batch_geometry(n_tiles * n_flows, g_num_cus));
+  int rt = 1;  // row tiles per wave
+  if (occ == NSA_GEO_2X2) {
+    rt = (h[NSA_H_HT] <= 2 && p.precision == NSA_PREC_BF16X3) ? 2 : 1;
+    occ = 2;
+  }
   const size_t stage_bytes = 2 * (size_t)h[NSA_H_MAX_STAGE] * 4;
   // + the populate epilogue's per-column constants: 4 double tables and one int table (nsa_flow_kernel.h)
   const size_t epi_bytes = (p.mode == NSA_MODE_POPULATE) ? (size_t)((D + 3) & ~3) * (4 * 8 + 4) : 0;
@@ -235,7 +276,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   const size_t prog_bytes = (((size_t)2 * h[inv ? NSA_H_NSTAGES_INV : NSA_H_NSTAGES_FWD] +
                               (size_t)NSA_OP_WORDS * h[inv ? NSA_H_NOPS_INV : NSA_H_NOPS_FWD] + 3) & ~(size_t)3) * 4;
   auto lds_of = [&](int w) {
-    return ((((size_t)w * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + stage_bytes + epi_bytes + prog_bytes;
+    return ((((size_t)w * rt * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + stage_bytes + epi_bytes + prog_bytes;
   };
   auto per_cu_of = [&](int w) {
     long long c = (long long)(g_max_lds / lds_of(w));
@@ -243,15 +284,20 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     if (c > by_waves) c = by_waves;
     return c;
   };
-  auto groups_of = [&](int w) { return (n_tiles + w - 1) / w; };
+  auto groups_of = [&](int w) { return (n_tiles + (long long)w * rt - 1) / ((long long)w * rt); };
   if (occ == 3 && waves_per_group <= 0 && lds_of(12) > g_max_lds) occ = NSA_DEFAULT_OCC;  // tiles too wide
+  if (rt == 2 && lds_of(4 * occ) > g_max_lds) {  // tiles too wide for two per wave
+    rt = 1;
+    occ = NSA_DEFAULT_OCC;
+  }
   p.occupancy = occ;
+  p.row_tiles = rt;
   const int nw_max = 4 * occ;
-  int nw = waves_per_group > 0 ? waves_per_group : (occ == 3 ? 12 : 2 * occ);
+  int nw = waves_per_group > 0 ? waves_per_group : (occ == 3 || rt == 2 ? 4 * occ : 2 * occ);
   if (nw > nw_max) nw = nw_max;
   if (waves_per_group <= 0) {
     // small batches: fewer waves per workgroup so that more CUs take part ...
-    while (nw > 1 && n_tiles * n_flows < (long long)nw * g_num_cus) nw >>= 1;
+    while (nw > 1 && n_tiles * n_flows < (long long)nw * rt * g_num_cus) nw >>= 1;
     // ... unless that leaves a mostly idle second round which wider workgroups avoid
     while (2 * nw <= nw_max && per_cu_of(2 * nw) >= 1 &&
            groups_of(nw) * n_flows > per_cu_of(nw) * g_num_cus &&
@@ -278,6 +324,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   hipError_t e = fn(&p, (unsigned)grid, (unsigned)n_flows, (unsigned)(nw * 64), lds, stream);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "flow kernel launch: %s", hipGetErrorString(e));
   g_last_geometry[0] = occ;
+  g_last_geometry[3] = rt;
   g_last_geometry[1] = nw;
   g_last_geometry[2] = (int)grid;
   return NSA_OK;

@@ -139,6 +139,9 @@ struct NsaLaunch {
   // that fail the reference's finiteness / unit-hypercube checks
   float* xp_out;
   double unit_eps;
+  // 32-row tiles per wave: 1, or 2 in the split-bf16 instances of <= 64-wide conditioners (`occupancy`
+  // 2, 8-wave workgroups)
+  int row_tiles;
 #ifdef NSA_TIMELINE
   unsigned long long* dbg;
 #endif
@@ -275,28 +278,29 @@ __device__ __forceinline__ void nsa_load_bias(const float* bias, int half, f32x1
 
 // Input from registers (D layout of the previous layer): in[16*HT] -> OT tiles.
 // W layout of the sub-stage: [OT][NS4][64 lanes][4]; it covers the step groups [S0, S0 + NS4) of `in`.
-template <int HT, int OT, int S0 = 0, int NS4 = 4 * HT>
-__device__ __forceinline__ void nsa_dense_regs(const float* w, const float (&in)[16 * HT], int lane,
-                                               f32x16 (&acc)[OT]) {
+// RT row tiles per wave share every weight operand read from LDS.
+template <int HT, int OT, int RT, int S0 = 0, int NS4 = 4 * HT>
+__device__ __forceinline__ void nsa_dense_regs(const float* w, const float (&in)[RT][16 * HT], int lane,
+                                               f32x16 (&acc)[RT][OT]) {
 #pragma unroll
   for (int s4 = 0; s4 < NS4; ++s4) {
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
       const f32x4 a = *(const f32x4*)(w + ((ot * NS4 + s4) * 64 + lane) * 4);
-      acc[ot] = nsa_mfma(a[0], in[4 * (S0 + s4) + 0], acc[ot]);
-      acc[ot] = nsa_mfma(a[1], in[4 * (S0 + s4) + 1], acc[ot]);
-      acc[ot] = nsa_mfma(a[2], in[4 * (S0 + s4) + 2], acc[ot]);
-      acc[ot] = nsa_mfma(a[3], in[4 * (S0 + s4) + 3], acc[ot]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma(a[e], in[t][4 * (S0 + s4) + e], acc[t][ot]);
     }
   }
 }
 
 // Input gathered from the wave's x tile through a column table
 // (tab[2*s + half] = physical column or -1), optional pre-shift.
-template <int OT, bool PRE>
+template <int OT, bool PRE, int RT>
 __device__ __forceinline__ void nsa_dense_tile(const float* w, const int* tab, const float* pre,
-                                               const float* xrow, int n_steps, int lane, int half,
-                                               f32x16 (&acc)[OT]) {
+                                               float* const (&xrow)[RT], int n_steps, int lane, int half,
+                                               f32x16 (&acc)[RT][OT]) {
   const int n_s4 = n_steps >> 2;
   for (int s4 = 0; s4 < n_s4; ++s4) {
     // the 8 table entries of this step group in two 16-byte reads (a lane uses those of its half),
@@ -311,21 +315,25 @@ __device__ __forceinline__ void nsa_dense_tile(const float* w, const int* tab, c
       sh[2] = half ? p1[1] : p1[0];
       sh[3] = half ? p1[3] : p1[2];
     }
-    float b[4];
+    float b[RT][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) b[e] = xrow[col[e] < 0 ? 0 : col[e]];
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (PRE) b[e] = b[e] - sh[e];
-      b[e] = (col[e] >= 0) ? b[e] : 0.0f;
-    }
+      for (int e = 0; e < 4; ++e) b[t][e] = xrow[t][col[e] < 0 ? 0 : col[e]];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (PRE) b[t][e] = b[t][e] - sh[e];
+        b[t][e] = (col[e] >= 0) ? b[t][e] : 0.0f;
+      }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
       const f32x4 a = *(const f32x4*)(w + ((ot * n_s4 + s4) * 64 + lane) * 4);
-      acc[ot] = nsa_mfma(a[0], b[0], acc[ot]);
-      acc[ot] = nsa_mfma(a[1], b[1], acc[ot]);
-      acc[ot] = nsa_mfma(a[2], b[2], acc[ot]);
-      acc[ot] = nsa_mfma(a[3], b[3], acc[ot]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma(a[e], b[t][e], acc[t][ot]);
     }
   }
 }
@@ -361,9 +369,9 @@ __device__ __forceinline__ void nsa_split_regs(const float (&in)[16 * HT], NsaSp
 // covers the k steps [S0, S0 + NS) of the split activations.  The A operands (LDS) of unit
 // u + NSA_PF are fetched before the MFMAs of unit u are issued, so that the LDS latency runs under the
 // matrix pipe instead of in front of it.
-template <int HT, int OT, int S0 = 0, int NS = 2 * HT>
-__device__ __forceinline__ void nsa_dense_regs16(const float* w, const NsaSplit<HT>& sp, int lane,
-                                                 f32x16 (&acc)[OT]) {
+template <int HT, int OT, int RT, int S0 = 0, int NS = 2 * HT>
+__device__ __forceinline__ void nsa_dense_regs16(const float* w, const NsaSplit<HT> (&sp)[RT], int lane,
+                                                 f32x16 (&acc)[RT][OT]) {
   constexpr int U = NS * OT;  // unit u = s * OT + ot
   bf16x8 ah[NSA_PF + 1], al[NSA_PF + 1];
 #pragma unroll
@@ -379,15 +387,22 @@ __device__ __forceinline__ void nsa_dense_regs16(const float* w, const NsaSplit<
       ah[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * NS + s2) * 2 + 0) * 64 + lane) * 4);
       al[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * NS + s2) * 2 + 1) * 64 + lane) * 4);
     }
-    acc[ot] = nsa_mfma_x3(ah[u % (NSA_PF + 1)], al[u % (NSA_PF + 1)], sp.hi[S0 + s], sp.lo[S0 + s], acc[ot]);
+    const bf16x8 a_h = ah[u % (NSA_PF + 1)], a_l = al[u % (NSA_PF + 1)];
+    // the row tiles of the wave take turns product by product: independent accumulators back to back
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma16(a_l, sp[t].hi[S0 + s], acc[t][ot]);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma16(a_h, sp[t].lo[S0 + s], acc[t][ot]);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma16(a_h, sp[t].hi[S0 + s], acc[t][ot]);
   }
 }
 
 // input gathered from the x tile: tab[16*s + 8*half + e]
-template <int OT, bool PRE>
+template <int OT, bool PRE, int RT>
 __device__ __forceinline__ void nsa_dense_tile16(const float* w, const int* tab, const float* pre,
-                                                 const float* xrow, int n_steps, int lane, int half,
-                                                 f32x16 (&acc)[OT]) {
+                                                 float* const (&xrow)[RT], int n_steps, int lane, int half,
+                                                 f32x16 (&acc)[RT][OT]) {
   for (int s = 0; s < n_steps; ++s) {
     // 8 table entries (and pre-shifts) in two 16-byte reads, then 8 independent tile reads: with a
     // branch per element the compiler issued read -> wait -> read -> wait sixteen times in a row
@@ -403,21 +418,25 @@ __device__ __forceinline__ void nsa_dense_tile16(const float* w, const int* tab,
         sh[4 + e] = p1[e];
       }
     }
-    float v[8];
+    bf16x8 bh[RT], bl[RT];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = xrow[col[e] < 0 ? 0 : col[e]];
+    for (int t = 0; t < RT; ++t) {
+      float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (PRE) v[e] = v[e] - sh[e];
-      v[e] = (col[e] >= 0) ? v[e] : 0.0f;
+      for (int e = 0; e < 8; ++e) v[e] = xrow[t][col[e] < 0 ? 0 : col[e]];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (PRE) v[e] = v[e] - sh[e];
+        v[e] = (col[e] >= 0) ? v[e] : 0.0f;
+      }
+      nsa_split8(v, bh[t], bl[t]);
     }
-    bf16x8 bh, bl;
-    nsa_split8(v, bh, bl);
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
       const bf16x8 ah = *(const bf16x8*)(w + (((ot * n_steps + s) * 2 + 0) * 64 + lane) * 4);
       const bf16x8 al = *(const bf16x8*)(w + (((ot * n_steps + s) * 2 + 1) * 64 + lane) * 4);
-      acc[ot] = nsa_mfma_x3(ah, al, bh, bl, acc[ot]);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma_x3(ah, al, bh[t], bl[t], acc[t][ot]);
     }
   }
 }
@@ -476,10 +495,11 @@ __device__ __forceinline__ void nsa_run_phases(typename TP::State (&st)[TP::FPC]
 
 // MFMAs of sub-stage J of one chunk of the last conditioner layer (-> acc; cols and the bias come
 // with sub-stage 0).
-template <int HT, class TP, int PREC, int J>
-__device__ __forceinline__ void nsa_chunk_gemm([[maybe_unused]] NsaStagePipe& pipe, const float* stg, const float (&h)[16 * HT],
-                                               const NsaSplit<HT>& hs, int lane, int half,
-                                               f32x16 (&acc)[TP::C], int (&cols)[TP::FPC]) {
+template <int HT, class TP, int PREC, int J, int RT>
+__device__ __forceinline__ void nsa_chunk_gemm([[maybe_unused]] NsaStagePipe& pipe, const float* stg,
+                                               const float (&h)[RT][16 * HT], const NsaSplit<HT> (&hs)[RT],
+                                               int lane, int half, f32x16 (&acc)[RT][TP::C],
+                                               int (&cols)[TP::FPC]) {
   constexpr int TABW = (2 * TP::FPC + 3) & ~3;
   constexpr int KS = nsa_ksplit(TP::C, HT);
   const float* w = stg;
@@ -489,42 +509,53 @@ __device__ __forceinline__ void nsa_chunk_gemm([[maybe_unused]] NsaStagePipe& pi
     w = bias + 32 * TP::C;
 #pragma unroll
     for (int q = 0; q < TP::FPC; ++q) cols[q] = tr_tab[half * TP::FPC + q];
-    nsa_load_bias<TP::C>(bias, half, acc);
+    nsa_load_bias<TP::C>(bias, half, acc[0]);
+#pragma unroll
+    for (int t = 1; t < RT; ++t)
+#pragma unroll
+      for (int ot = 0; ot < TP::C; ++ot) acc[t][ot] = acc[0][ot];
     NSA_TL(pipe, 13);
   }
-  if constexpr (PREC == NSA_PREC_BF16X3) nsa_dense_regs16<HT, TP::C, J * (2 * HT / KS), 2 * HT / KS>(w, hs, lane, acc);
-  else nsa_dense_regs<HT, TP::C, J * (4 * HT / KS), 4 * HT / KS>(w, h, lane, acc);
+  if constexpr (PREC == NSA_PREC_BF16X3) nsa_dense_regs16<HT, TP::C, RT, J * (2 * HT / KS), 2 * HT / KS>(w, hs, lane, acc);
+  else nsa_dense_regs<HT, TP::C, RT, J * (4 * HT / KS), 4 * HT / KS>(w, h, lane, acc);
 }
 
-// one coupling layer -----------------------------------------------------------
+// one coupling layer (over the RT row tiles of the wave) ---------------------------
 
-template <int HT, class TP, bool INV, int PREC>
-__device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t* op, float* xrow,
+template <int HT, class TP, bool INV, int PREC, int RT>
+__device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t* op, float* const (&xrow)[RT],
                                              int dummy_col, int lane, int half, int act, int net,
                                              int n_layers, const NsaTransformConsts& tc,
-                                             float& logdet, int& n_bad) {
+                                             float (&logdet)[RT], int (&n_bad)[RT]) {
   constexpr bool BF = (PREC == NSA_PREC_BF16X3);
   const int n_steps0 = __builtin_amdgcn_readfirstlane((int)op[1]);
   const int n_chunks = __builtin_amdgcn_readfirstlane((int)op[2]);
-  float h[16 * HT];
+  float h[RT][16 * HT];
 
   // one H -> H layer from registers: out = W in + b
   // (nsa_ksplit(HT, HT) stages along k; the caller closes the LAST one after its own epilogue)
-  auto hidden_layer = [&](const float (&in)[16 * HT], f32x16 (&acc)[HT]) {
+  auto hidden_layer = [&](const float (&in)[RT][16 * HT], f32x16 (&acc)[RT][HT]) {
     constexpr int KS = nsa_ksplit(HT, HT);
-    NsaSplit<HT> sp;
-    if constexpr (BF) nsa_split_regs<HT>(in, sp);
+    NsaSplit<HT> sp[RT];
+    if constexpr (BF) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) nsa_split_regs<HT>(in[t], sp[t]);
+    }
     nsa_static_for<KS>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
       const float* st = pipe.begin();
       const float* w = st;
       if constexpr (J == 0) {
-        nsa_load_bias<HT>(st, half, acc);
+        nsa_load_bias<HT>(st, half, acc[0]);
+#pragma unroll
+        for (int t = 1; t < RT; ++t)
+#pragma unroll
+          for (int ot = 0; ot < HT; ++ot) acc[t][ot] = acc[0][ot];
         w = st + 32 * HT;
         NSA_TL(pipe, 13);
       }
-      if constexpr (BF) nsa_dense_regs16<HT, HT, J * (2 * HT / KS), 2 * HT / KS>(w, sp, lane, acc);
-      else nsa_dense_regs<HT, HT, J * (4 * HT / KS), 4 * HT / KS>(w, in, lane, acc);
+      if constexpr (BF) nsa_dense_regs16<HT, HT, RT, J * (2 * HT / KS), 2 * HT / KS>(w, sp, lane, acc);
+      else nsa_dense_regs<HT, HT, RT, J * (4 * HT / KS), 4 * HT / KS>(w, in, lane, acc);
       pipe.more();
       NSA_TL(pipe, 3);
       if constexpr (J + 1 < KS) pipe.end();
@@ -537,13 +568,18 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     const int* id_tab = (const int*)st;
     const float* bias = st + (BF ? 16 : 2) * n_steps0;
     const float* w = bias + 32 * HT;
-    f32x16 acc[HT];
-    nsa_load_bias<HT>(bias, half, acc);
-    if constexpr (BF) nsa_dense_tile16<HT, false>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
-    else nsa_dense_tile<HT, false>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
+    f32x16 acc[RT][HT];
+    nsa_load_bias<HT>(bias, half, acc[0]);
+#pragma unroll
+    for (int t = 1; t < RT; ++t)
+#pragma unroll
+      for (int ot = 0; ot < HT; ++ot) acc[t][ot] = acc[0][ot];
+    if constexpr (BF) nsa_dense_tile16<HT, false, RT>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
+    else nsa_dense_tile<HT, false, RT>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
     pipe.more();
     NSA_TL(pipe, 1);
-    nsa_acc_to_regs<HT>(acc, h);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) nsa_acc_to_regs<HT>(acc[t], h[t]);
     NSA_TL(pipe, 2);
     pipe.end();
   }
@@ -551,37 +587,49 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
   if (net == NSA_NET_RESNET) {
     // pre-activation residual blocks: h += W2 act(W1 act(h) + b1) + b2
     for (int l = 0; l < n_layers; ++l) {
-      float t[16 * HT];
+      float tmp[RT][16 * HT];
 #pragma unroll
-      for (int i = 0; i < 16 * HT; ++i) t[i] = h[i];
-      nsa_act_regs<16 * HT>(t, act);
+      for (int t = 0; t < RT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16 * HT; ++i) tmp[t][i] = h[t][i];
+        nsa_act_regs<16 * HT>(tmp[t], act);
+      }
       {
-        f32x16 acc[HT];
-        hidden_layer(t, acc);
-        nsa_acc_to_regs<HT>(acc, t);
-        nsa_act_regs<16 * HT>(t, act);
+        f32x16 acc[RT][HT];
+        hidden_layer(tmp, acc);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          nsa_acc_to_regs<HT>(acc[t], tmp[t]);
+          nsa_act_regs<16 * HT>(tmp[t], act);
+        }
         NSA_TL(pipe, 4);
         pipe.end();
       }
       {
-        f32x16 acc[HT];
-        hidden_layer(t, acc);
+        f32x16 acc[RT][HT];
+        hidden_layer(tmp, acc);
 #pragma unroll
-        for (int ot = 0; ot < HT; ++ot)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) h[16 * ot + r] = h[16 * ot + r] + acc[ot][r];
+          for (int ot = 0; ot < HT; ++ot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[t][16 * ot + r] = h[t][16 * ot + r] + acc[t][ot][r];
         NSA_TL(pipe, 4);
         pipe.end();
       }
     }
   } else {
     // plain MLP (src/nessai/flows/nets.py:110-124): act after every layer but the last
-    nsa_act_regs<16 * HT>(h, act);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) nsa_act_regs<16 * HT>(h[t], act);
     for (int l = 1; l < n_layers; ++l) {
-      f32x16 acc[HT];
+      f32x16 acc[RT][HT];
       hidden_layer(h, acc);
-      nsa_acc_to_regs<HT>(acc, h);
-      nsa_act_regs<16 * HT>(h, act);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        nsa_acc_to_regs<HT>(acc[t], h[t]);
+        nsa_act_regs<16 * HT>(h[t], act);
+      }
       NSA_TL(pipe, 4);
       pipe.end();
     }
@@ -592,31 +640,37 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
   // the stage barrier, so that the next stage's copy has the whole element-wise part to land.
   // (A software-pipelined version - the MFMAs of chunk c+1 interleaved with the element-wise
   // phases of chunk c - needed 48 more registers and was 0.7 % slower in split-bf16, 1.7 % in f32.)
-  NsaSplit<HT> hs;
-  if constexpr (BF) nsa_split_regs<HT>(h, hs);
+  NsaSplit<HT> hs[RT];
+  if constexpr (BF) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) nsa_split_regs<HT>(h[t], hs[t]);
+  }
   for (int c = 0; c < n_chunks; ++c) {
-    f32x16 acc[TP::C];
+    f32x16 acc[RT][TP::C];
     int cols[TP::FPC];
     nsa_static_for<nsa_ksplit(TP::C, HT)>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
       const float* st = pipe.begin();
-      nsa_chunk_gemm<HT, TP, PREC, J>(pipe, st, h, hs, lane, half, acc, cols);
+      nsa_chunk_gemm<HT, TP, PREC, J, RT>(pipe, st, h, hs, lane, half, acc, cols);
       pipe.more();
       NSA_TL(pipe, 5);
       if constexpr (J + 1 < nsa_ksplit(TP::C, HT)) pipe.end();
     });
-    float v[16 * TP::C];
 #pragma unroll
-    for (int t = 0; t < TP::C; ++t)
+    for (int t = 0; t < RT; ++t) {
+      float v[16 * TP::C];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[16 * t + r] = acc[t][r];
-    if constexpr ((NSA_ABLATE & 4) != 0) {
+      for (int q = 0; q < TP::C; ++q)
 #pragma unroll
-      for (int i = 0; i < 16 * TP::C; ++i) asm volatile("" ::"v"(v[i]));
-    } else {
-      typename TP::State sts[TP::FPC];
-      nsa_run_phases<TP, INV, 0>(sts, v, cols, xrow, dummy_col, tc, logdet, n_bad,
-                                 std::make_integer_sequence<int, TP::NPH * TP::FPC>{});
+        for (int r = 0; r < 16; ++r) v[16 * q + r] = acc[t][q][r];
+      if constexpr ((NSA_ABLATE & 4) != 0) {
+#pragma unroll
+        for (int i = 0; i < 16 * TP::C; ++i) asm volatile("" ::"v"(v[i]));
+      } else {
+        typename TP::State sts[TP::FPC];
+        nsa_run_phases<TP, INV, 0>(sts, v, cols, xrow[t], dummy_col, tc, logdet[t], n_bad[t],
+                                   std::make_integer_sequence<int, TP::NPH * TP::FPC>{});
+      }
     }
     NSA_TL(pipe, 6);
     pipe.end();
@@ -625,9 +679,9 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
 
 // dense (LU-linear, eval-mode cached weight) -----------------------------------
 // y = W (x - pre) + bias over all D features; D <= 64.
-template <int PREC>
-__device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t* op, float* xrow,
-                                             int D, int lane, int half, float& logdet) {
+template <int PREC, int RT>
+__device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t* op, float* const (&xrow)[RT],
+                                             int D, int lane, int half, float (&logdet)[RT]) {
   constexpr bool BF = (PREC == NSA_PREC_BF16X3);
   const int n_steps = __builtin_amdgcn_readfirstlane((int)op[1]);
   const int n_ot = __builtin_amdgcn_readfirstlane((int)op[2]);
@@ -638,44 +692,57 @@ __device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t*
   const float* bias = pre + tab_len;
   const float* w = bias + 32 * n_ot;
   if (n_ot == 1) {
-    f32x16 acc[1];
-    nsa_load_bias<1>(bias, half, acc);
-    if constexpr (BF) nsa_dense_tile16<1, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
-    else nsa_dense_tile<1, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+    f32x16 acc[RT][1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (i < D) xrow[i] = acc[0][r];
-    }
-  } else {
-    f32x16 acc[2];
-    nsa_load_bias<2>(bias, half, acc);
-    if constexpr (BF) nsa_dense_tile16<2, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
-    else nsa_dense_tile<2, true>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+    for (int t = 0; t < RT; ++t) nsa_load_bias<1>(bias, half, acc[t]);
+    if constexpr (BF) nsa_dense_tile16<1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+    else nsa_dense_tile<1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
 #pragma unroll
-    for (int ot = 0; ot < 2; ++ot)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (i < D) xrow[i] = acc[ot][r];
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (i < D) xrow[t][i] = acc[t][0][r];
       }
+  } else {
+    f32x16 acc[RT][2];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) nsa_load_bias<2>(bias, half, acc[t]);
+    if constexpr (BF) nsa_dense_tile16<2, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+    else nsa_dense_tile<2, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (i < D) xrow[t][i] = acc[t][ot][r];
+        }
   }
-  if (half == 0) logdet += nsa_bits_to_float(op[3]);
+  if (half == 0) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) logdet[t] += nsa_bits_to_float(op[3]);
+  }
   NSA_TL(pipe, 10);
   pipe.end();
 }
 
 // per-column ((x - a) / b) * c + d (batch norm / act norm in eval mode) ----------
+template <int RT>
 __device__ __forceinline__ void nsa_elementwise_op(NsaStagePipe& pipe, const uint32_t* op,
-                                                   float* xrow, int D, int half, float& logdet) {
+                                                   float* const (&xrow)[RT], int D, int half, float (&logdet)[RT]) {
 #pragma clang fp contract(off)
   const float* st = pipe.begin();
   const int D4 = (D + 3) & ~3;
-  for (int c = half; c < D; c += 2) {
-    const float x = xrow[c];
-    xrow[c] = ((x - st[c]) / st[D4 + c]) * st[2 * D4 + c] + st[3 * D4 + c];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    for (int c = half; c < D; c += 2) {
+      const float x = xrow[t][c];
+      xrow[t][c] = ((x - st[c]) / st[D4 + c]) * st[2 * D4 + c] + st[3 * D4 + c];
+    }
+    if (half == 0) logdet[t] += nsa_bits_to_float(op[3]);
   }
-  if (half == 0) logdet += nsa_bits_to_float(op[3]);
   pipe.end();
 }
 
@@ -690,7 +757,10 @@ __device__ __forceinline__ int nsa_opaque(int v) {
 
 // OCC = waves per SIMD the instance is register-budgeted for: 2 (<= 256 VGPRs, workgroups of up to
 // 8 waves) or 3 (<= 168 VGPRs, workgroups of 6 or 12 waves; only the prologue / epilogue spill).
-template <int HT, class TP, bool INV, int PREC, int OCC>
+// RT = 32-row tiles per wave: the tiles of a wave go through every layer together, so that one read of a
+// weight operand from LDS feeds RT x 3 MFMAs, a stage is copied and a barrier crossed once per RT x NW
+// tiles, and the wave always has RT independent accumulator chains and element-wise chains to issue from.
+template <int HT, class TP, bool INV, int PREC, int OCC, int RT = 1>
 __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(NsaLaunch p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (p.stop != nullptr && (p.stop[0] >= p.stop[2] || p.stop[1] >= p.stop[5])) return;
@@ -709,10 +779,15 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
   const int j = lane & 31;
   constexpr bool inverse = INV;  // p.direction selects the instantiation on the host
 
-  const int tiles_words = (nw * NSA_ROWS * XS + 3) & ~3;
+  const int tiles_words = (nw * RT * NSA_ROWS * XS + 3) & ~3;
   const int max_stage = (int)img[NSA_H_MAX_STAGE];
-  float* xt = smem + wave * (NSA_ROWS * XS);
-  float* xrow = xt + j * XS;
+  float* xt_a[RT];
+  float* xrow_a[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    xt_a[t] = smem + (wave * RT + t) * (NSA_ROWS * XS);
+    xrow_a[t] = xt_a[t] + j * XS;
+  }
 
   NsaStagePipe pipe;
   pipe.img = img;
@@ -780,7 +855,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
   const int n_layers = (int)img[NSA_H_NLAYERS];
 
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
-  const long long n_groups = (n_tiles + nw - 1) / nw;
+  const long long n_groups = (n_tiles + nw * RT - 1) / (nw * RT);
 
 #ifdef NSA_TIMELINE
   for (int i = 0; i < 14; ++i) pipe.tl.acc[i] = 0;
@@ -796,11 +871,16 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
 #ifdef NSA_TIMELINE
     ++tl_tiles;
 #endif
-    // ---- fill the x tile ---------------------------------------------------
+    // ---- fill the x tiles --------------------------------------------------
+    bool keep_a[RT];
+    float log_pz_a[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
     bool keep = true;
     float log_pz = 0.0f;
-    {
-    const long long row0 = (g * nw + wave) * NSA_ROWS;
+    float* const xt = xt_a[t];
+    float* const xrow = xrow_a[t];
+    const long long row0 = ((g * nw + wave) * RT + t) * NSA_ROWS;
     const long long my_row = row0 + j;
     if (p.x_in != nullptr) {
       const long long base = row0 * D;
@@ -871,32 +951,44 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
         }
       }
     }
-
+    keep_a[t] = keep;
+    log_pz_a[t] = log_pz;
     }
     NSA_TL(pipe, 0);
     // ---- run the flow --------------------------------------------------------
-    float logdet = 0.0f;
-    int n_bad = 0;
+    float logdet_a[RT];
+    int n_bad_a[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      logdet_a[t] = 0.0f;
+      n_bad_a[t] = 0;
+    }
     for (int o = 0; o < n_ops; ++o) {
       const uint32_t* op = ops + o * NSA_OP_WORDS;
       const int kind = __builtin_amdgcn_readfirstlane((int)op[0]);
       if (kind == NSA_OP_COUPLING) {
-        nsa_coupling<HT, TP, INV, PREC>(pipe, op, xrow, D, lane, half, act, net, n_layers, tc, logdet, n_bad);
+        nsa_coupling<HT, TP, INV, PREC, RT>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
       } else if (kind == NSA_OP_DENSE) {
-        nsa_dense_op<PREC>(pipe, op, xrow, D, lane, half, logdet);
+        nsa_dense_op<PREC, RT>(pipe, op, xrow_a, D, lane, half, logdet_a);
       } else {
-        nsa_elementwise_op(pipe, op, xrow, D, half, logdet);
+        nsa_elementwise_op<RT>(pipe, op, xrow_a, D, half, logdet_a);
       }
     }
-    logdet += __shfl_xor(logdet, 32);
-    n_bad += __shfl_xor(n_bad, 32);
 
     // ---- epilogues -----------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+    float* const xt = xt_a[t];
+    float* const xrow = xrow_a[t];
+    const bool keep = keep_a[t];
+    const float log_pz = log_pz_a[t];
+    const float logdet = logdet_a[t] + __shfl_xor(logdet_a[t], 32);
+    const int n_bad = n_bad_a[t] + __shfl_xor(n_bad_a[t], 32);
     // row indices are recomputed from the (opaque) group counter instead of staying live in
     // VGPRs through the whole flow, where they were spilled to scratch
     long long g_epi = g;
     asm volatile("" : "+s"(g_epi));
-    const long long row0 = (g_epi * nw + wave) * NSA_ROWS;
+    const long long row0 = ((g_epi * nw + wave) * RT + t) * NSA_ROWS;
     const long long my_row = row0 + j;
     const bool row_ok = my_row < p.n;
     // (opaque too: with `half` the per-lane table addresses of every epilogue variant were hoisted out
@@ -1029,6 +1121,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
           if (gi < limit) p.x_out[gi] = xt[r * XS + out_tab[c]];
         }
       }
+    }
     }
     NSA_TL(pipe, 9);
   }

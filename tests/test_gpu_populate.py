@@ -539,9 +539,11 @@ def test_pass_trains_equal_one_pass_at_a_time(case):
 
 
 def test_launch_geometry_is_tuned_once_and_never_changes_the_result(monkeypatch):
-    """Big split-bf16 batches: the library times its two launch geometries once per process
-    (csrc/nsa_api.hip, nsa_tuned_occupancy) and reports the choice through nsa_last_geometry; the
-    rows drawn do not depend on it (row-indexed Philox streams, per-row arithmetic)."""
+    """Big split-bf16 batches have three launch geometries (csrc/nsa_api.hip): a static rule picks one
+    (nsa_big_batch_geometry), NESSAI_AMD_TUNE=1 times them once per process instead
+    (nsa_tuned_occupancy); the choice is reported through nsa_last_geometry / nsa_last_row_tiles, and
+    the rows drawn do not depend on it (row-indexed Philox streams, per-row arithmetic) - including
+    the geometry in which every wave carries two 32-row tiles."""
     import ctypes
 
     from nessai_amd import lib
@@ -549,7 +551,7 @@ def test_launch_geometry_is_tuned_once_and_never_changes_the_result(monkeypatch)
     def geometry():
         v = [ctypes.c_int(0) for _ in range(3)]
         lib.load().nsa_last_geometry(*[ctypes.addressof(x) for x in v])
-        return tuple(x.value for x in v)
+        return tuple(x.value for x in v[:2]) + (int(lib.load().nsa_last_row_tiles()),)
 
     state, shift, scale, _ = load_c3_fixture()
     n = 300_000  # >= 24 tiles per CU: the range in which both geometries are candidates
@@ -559,8 +561,12 @@ def test_launch_geometry_is_tuned_once_and_never_changes_the_result(monkeypatch)
     radius = prop.fixed_radius if prop.fixed_radius is not None else 1.0e9
     buf = prop._get_buffers(n, 2000)
     outs = {}
-    for occ in ("3", "2", None, None):
+    for occ in ("3", "2", "2x2", "static", None, None):
+        monkeypatch.delenv("NESSAI_AMD_TUNE", raising=False)
         if occ is None:
+            monkeypatch.delenv("NESSAI_AMD_OCC", raising=False)
+            monkeypatch.setenv("NESSAI_AMD_TUNE", "1")
+        elif occ == "static":
             monkeypatch.delenv("NESSAI_AMD_OCC", raising=False)
         else:
             monkeypatch.setenv("NESSAI_AMD_OCC", occ)
@@ -571,9 +577,14 @@ def test_launch_geometry_is_tuned_once_and_never_changes_the_result(monkeypatch)
         outs.setdefault(occ, []).append((geometry(), buf["x64"][:n].clone(), buf["log_q"][:n].clone()))
     g3, x3, q3 = outs["3"][0]
     g2, x2, q2 = outs["2"][0]
-    assert g3[:2] == (3, 12) and g2[:2] == (2, 4)
+    g22, x22, q22 = outs["2x2"][0]
+    assert g3 == (3, 12, 1) and g2 == (2, 4, 1) and g22 == (2, 8, 2)
+    gs, xs, qs = outs["static"][0]
+    # 9375 tiles on 256 CUs: 5 rounds of 256 x 8 tiles at 1.09 (11.2 k) are estimated below 3 rounds of
+    # 256 x 16 at 1.00 (12.3 k) and 4 rounds of 256 x 12 at 1.06 (13.0 k); at 1e6 rows it is two tiles per wave
+    assert gs == (2, 4, 1)
     (ga, xa, qa), (gb, xb, qb) = outs[None]
-    assert ga[:2] in ((3, 12), (2, 4)) and gb == ga  # tuned once, kept
-    for x, q in ((x2, q2), (xa, qa), (xb, qb)):
+    assert ga in ((3, 12, 1), (2, 4, 1), (2, 8, 2)) and gb == ga  # tuned once, kept
+    for x, q in ((x2, q2), (x22, q22), (xs, qs), (xa, qa), (xb, qb)):
         assert torch.equal(x, x3)
         assert torch.equal(torch.nan_to_num(q, nan=12345.0), torch.nan_to_num(q3, nan=12345.0))
