@@ -23,7 +23,7 @@ def main():
     prop.populate(None, n_samples=bench.NLIVE, max_samples=10**12)
     ref = None
     for precision in (("bf16x3",) if QUICK else ("bf16x3", "f32")):
-        for occ, wpg in ([(2, 4), (3, 12), ("2x2", 0)] if QUICK else VARIANTS + [("2x2", 0)]):
+        for occ, wpg in ([("2x2", 0)] if "--2x2" in sys.argv else [(2, 4), (3, 12), ("2x2", 0)] if QUICK else VARIANTS + [("2x2", 0)]):
             os.environ["NESSAI_AMD_OCC"] = str(occ)
             prop.flow.model.waves_per_group = wpg
             ms, ms_min = bench.time_draw_kernel(prop, launches=8, precision=precision)
