@@ -144,7 +144,10 @@ static int nsa_occupancy(int ht, int precision, long long n_tiles, int n_flows, 
     return (ht <= 2 && precision == NSA_PREC_BF16X3 && waves_per_group <= 0) ? NSA_GEO_2X2 : NSA_DEFAULT_OCC;
   if (e != nullptr && (e[0] == '2' || e[0] == '3')) return (e[0] == '3' && ht <= 2) ? 3 : 2;
   if (waves_per_group > 0) return (waves_per_group > 8 && ht <= 2) ? 3 : NSA_DEFAULT_OCC;
-  if (ht <= 2 && precision == NSA_PREC_BF16X3 && n_tiles * n_flows >= 24LL * num_cus) return 3;
+  // (3 = "big batch": nsa_launch_flow replaces it by nsa_big_batch_geometry's estimate; from one full round
+  // of the default geometry upwards - 2048 tiles on 256 CUs - the estimate is the measured order:
+  // scripts/bench_geometry_sizes.py, 62 500 to 1e6 rows)
+  if (ht <= 2 && precision == NSA_PREC_BF16X3 && n_tiles * n_flows >= 8LL * num_cus) return 3;
   return NSA_DEFAULT_OCC;
 }
 

@@ -554,7 +554,7 @@ def test_launch_geometry_is_tuned_once_and_never_changes_the_result(monkeypatch)
         return tuple(x.value for x in v[:2]) + (int(lib.load().nsa_last_row_tiles()),)
 
     state, shift, scale, _ = load_c3_fixture()
-    n = 300_000  # >= 24 tiles per CU: the range in which both geometries are candidates
+    n = 300_000  # >= 8 tiles per CU: the range in which the three geometries are candidates
     prop, _ = build(32, "nsf", dict(n_neurons=64, n_blocks=6), poolsize=2000, drawsize=n,
                     state=state, shift=shift, scale=scale)
     prop.populate(None, n_samples=50, max_samples=10**9)  # rescaling constants, radius, device tables
