@@ -26,7 +26,7 @@ def main():
     device = torch.device("cuda", 0)
     prop = bench.build_proposal(0, 1, device)
     prop.populate(None, n_samples=bench.NLIVE, max_samples=10**12)
-    for occ, wpg in ((3, 12), (2, 4)):
+    for occ, wpg in (("2x2", 0), (3, 12), (2, 4)):  # "2x2": a "tile" below is a wave's PAIR of tiles
         os.environ["NESSAI_AMD_OCC"] = str(occ)
         prop.flow.model.waves_per_group = wpg
         os.environ.pop("NSA_TL_PTR", None)
