@@ -423,7 +423,7 @@ def main():
                 "algorithmic_bytes": 264.0e6,
                 "kernel_ms_avg": kernel_ms,
                 "kernel_ms_min": kernel_ms_min,
-                # chosen by the library (big split-bf16 batches: timed once per process, nsa_api.hip)
+                # chosen by the library (big split-bf16 batches: round-count estimate of nsa_big_batch_geometry, nsa_api.hip)
                 "launch_geometry": geometry,
                 "rows_per_launch": DRAWSIZE,
                 "flops_per_row": FLOPS_PER_ROW,
