@@ -805,6 +805,7 @@ class FlowProposal:
         stream = lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         per_pass = (self.population_acceptance or 0.0) * n * world
         n_accepted = passes = 0
+        head_args = None
         while True:
             remaining = n_samples - n_accepted
             train = 1 if per_pass <= 0 else int(np.ceil(1.15 * remaining / per_pass))
@@ -814,32 +815,43 @@ class FlowProposal:
                 grown[: buf["history"].numel()] = buf["history"]
                 buf["history"] = grown
             buf["max_keys"][:train].fill_(key_init)
-            for i in range(train):
-                off = int(self._draw_counter + (passes + i) * n * world + rank * n)
-                key = buf["max_keys"][i : i + 1]
-                rc = L.nsa_populate_pass_head(
-                    header, lib.ptr(image), n, self.device_seed, off, float(threshold),
+            # the per-pass host work is what bounds a pass once the batch is split over many ranks: every
+            # argument that does not change from pass to pass is converted once per train
+            if head_args is None:
+                head_args = (
+                    header, lib.ptr(image), n, self.device_seed, None, float(threshold),
                     float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
                     lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
                     lib.ptr(buf["x64"]), lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev),
                     lib.ptr(self._prior_par_dev), lib.ptr(buf["log_p"] if separable else None),
                     float(log_prior_const), lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev),
-                    lib.ptr(buf["log_w"]), lib.ptr(key), lib.ptr(state), lib.ptr(status), flow.waves_per_group,
+                    lib.ptr(buf["log_w"]), None, lib.ptr(state), lib.ptr(status), flow.waves_per_group,
                     flow.max_groups, stream,
                 )
-                lib.check(rc, "nsa_populate_pass_head")
+                tail_ptrs = (lib.ptr(buf["log_w"]), lib.ptr(buf["x64"]), lib.ptr(buf["x_acc"]), lib.ptr(state),
+                             lib.ptr(buf["workspace"]), lib.ptr(gcount))
+                local_count = state[4:5]
+            keys_base = buf["max_keys"].data_ptr()
+            hist_ptr = lib.ptr(buf["history"])
+            base_off = int(self._draw_counter + rank * n)
+            for i in range(train):
+                off = base_off + (passes + i) * n * world
+                key = buf["max_keys"][i : i + 1]
+                key_ptr = lib.c_void_p(keys_base + 8 * i)
+                rc = L.nsa_populate_pass_head(*head_args[:4], off, *head_args[5:21], key_ptr, *head_args[22:])
+                if rc:
+                    lib.check(rc, "nsa_populate_pass_head")
                 dist.all_reduce(key, op=dist.ReduceOp.MAX)
-                rc = L.nsa_populate_pass_tail(
-                    n, self.dims, lib.ptr(buf["log_w"]), lib.ptr(key), self.device_seed, off, lib.ptr(buf["x64"]),
-                    n_samples, lib.ptr(buf["x_acc"]), lib.ptr(state), lib.ptr(buf["workspace"]), buf["ws_bytes"],
-                    stream,
-                )
-                lib.check(rc, "nsa_populate_pass_tail")
-                gcount.copy_(state[4:5])
+                rc = L.nsa_populate_pass_tail(n, self.dims, tail_ptrs[0], key_ptr, self.device_seed, off, tail_ptrs[1],
+                                              n_samples, tail_ptrs[2], tail_ptrs[3], tail_ptrs[4], buf["ws_bytes"],
+                                              stream)
+                if rc:
+                    lib.check(rc, "nsa_populate_pass_tail")
+                gcount.copy_(local_count)
                 dist.all_reduce(gcount, op=dist.ReduceOp.SUM)
-                rc = L.nsa_populate_pass_commit(lib.ptr(state), n_samples, lib.ptr(gcount), lib.ptr(buf["history"]),
-                                                stream)
-                lib.check(rc, "nsa_populate_pass_commit")
+                rc = L.nsa_populate_pass_commit(tail_ptrs[3], n_samples, tail_ptrs[5], hist_ptr, stream)
+                if rc:
+                    lib.check(rc, "nsa_populate_pass_commit")
             state_h.copy_(state)  # the train's one synchronisation
             n_accepted, passes = int(state_h[0]), int(state_h[1])
             if n_accepted >= n_samples:
