@@ -44,7 +44,11 @@ NLIVE = 2000
 DRAWSIZE = 1_000_000
 FLOPS_PER_ROW = 491_520          # conditioner GEMM FLOPs per proposed row
 PEAK_TFLOPS = {"f32": 157.3,     # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
-               "bf16x3": 2500.0}  # v_mfma_f32_32x32x16_bf16 dense peak
+               "bf16x3": 2500.0,  # v_mfma_f32_32x32x16_bf16 dense peak
+               "f16x3": 2500.0}   # v_mfma_f32_32x32x16_f16: the same rate
+DTYPE_NAMES = {"f32": "f32",
+               "bf16x3": "bf16x3 (split-bf16 operands on bf16 MFMA, f32 accumulate)",
+               "f16x3": "f16x3 (split-f16 operands - float32-class products - on f16 MFMA, f32 accumulate)"}
 FLOW_CONFIG = dict(ftype="nsf", n_neurons=64, n_blocks=6, n_layers=2, num_bins=8)
 
 
@@ -254,18 +258,20 @@ def cpu_leg_child(cores):
     }))
 
 
-def cpu_baseline():
+def cpu_baseline(full=False):
     """The oracle (CPU restatement of the reference path) timed on this host.
 
     Leg (i), the reported baseline: ONE torch thread - the reference's default
     (src/nessai/flowsampler.py:98) - on a bounded sample of the workload, one populate pass of
     2.5e5 draws.  Leg (ii) (SURVEY.md section 8d ii): the same pass on many threads
-    (``cpu_all_cores_leg``; the count used is printed)."""
+    (``cpu_all_cores_leg``; the count used is printed).  ``full`` (``--cpu-full``): the single-thread
+    leg over one pass of the metric's own batch, 1e6 draws with the flow inverse in chunks of 1e5 rows
+    (about a minute; the default stays bounded so that the benchmark finishes in minutes)."""
     threads = torch.get_num_threads()
     try:
         torch.set_num_threads(1)
-        sample_draw = 250_000
-        prop = _oracle_proposal(sample_draw)
+        sample_draw = DRAWSIZE if full else 250_000
+        prop = _oracle_proposal(sample_draw, chunk_rows=100_000 if full else None)
         torch.manual_seed(1451)
         t = time.perf_counter()
         prop.populate(n_samples=NLIVE, max_samples=sample_draw - 1)  # exactly one pass
@@ -275,16 +281,44 @@ def cpu_baseline():
             "unit": "accepted points/s",
             "cores": 1,
             "kind": "port",
-            "sample": f"one populate pass of {sample_draw} draws (of the 1e6-row batch), "
-                      f"{prop.n_accepted} accepted in {dt:.1f} s",
+            "sample": (f"one populate pass of the full {sample_draw}-draw batch (flow inverse in chunks of 100000 "
+                       f"rows), {prop.n_accepted} accepted in {dt:.1f} s" if full else
+                       f"one populate pass of {sample_draw} draws (of the 1e6-row batch), "
+                       f"{prop.n_accepted} accepted in {dt:.1f} s"),
             "proposed_rows_per_s": prop.n_proposed / dt,
             "acceptance": prop.population_acceptance,
             "host_cpus": os.cpu_count(),
         }
-        out["all_cores"] = cpu_all_cores_leg()
+        if not full:
+            out["all_cores"] = cpu_all_cores_leg()
         return out
     finally:
         torch.set_num_threads(threads)
+
+
+def self_launch(n_gpus, json_fd):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks."""
+    import socket
+    import subprocess
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        raise SystemExit(f"bench.py --gpus {n_gpus} needs {n_gpus} devices on this node, found {have}")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # the children's stdout carries rank 0's JSON line only (every rank sends library chatter to stderr)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(proc.stdout.decode())
+        raise SystemExit(f"bench.py: the {n_gpus}-rank run failed (exit code {proc.returncode}, {len(lines)} JSON lines)")
+    os.write(json_fd, (lines[0] + "\n").encode())
 
 
 def main():
@@ -294,6 +328,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="time the single-thread CPU baseline over one pass of the full 1e6-draw batch (about a "
+                         "minute) instead of the bounded 2.5e5-draw sample")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
@@ -314,9 +351,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1); rank 0 of the children prints the JSON line
+        self_launch(args.gpus, json_fd)
+        return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torchrun for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
@@ -389,11 +430,13 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None,
-            "dtype": "bf16x3 (split-bf16 operands on bf16 MFMA, f32 accumulate)" if precision == "bf16x3" else "f32",
-            # populate() asks for "auto": split-bf16 only if a 4096-row probe of THIS flow agrees with the
-            # exact-float32 kernels to 5e-6 relative in both directions (HipFlow._pack_auto)
+            "dtype": DTYPE_NAMES[precision],
+            # populate() asks for "auto": the first 16-bit matrix-core mode (split-f16, then split-bf16) that a
+            # 4096-row probe of THIS flow shows to agree with the exact-float32 kernels to 5e-6 relative in
+            # both directions (HipFlow._pack_auto)
             "precision_policy": {"requested": prop.precision, "effective": precision,
-                                 "probe_rel_err_vs_f32": prop.flow.model.probe_error},
+                                 "probe_rel_err_vs_f32": prop.flow.model.probe_error,
+                                 "probe_rel_errs": prop.flow.model.probe_errors},
             "data": "synthetic",
             "config": {
                 "workload": "32-D Rosenbrock, NeuralSplineFlow (8 RQ bins, 6 coupling layers, "
@@ -423,12 +466,12 @@ def main():
                 "algorithmic_bytes": 264.0e6,
                 "kernel_ms_avg": kernel_ms,
                 "kernel_ms_min": kernel_ms_min,
-                # chosen by the library (big split-bf16 batches: round-count estimate of nsa_big_batch_geometry, nsa_api.hip)
+                # chosen by the library (big batches of the 16-bit modes: round-count estimate of nsa_big_batch_geometry, nsa_api.hip)
                 "launch_geometry": geometry,
                 "rows_per_launch": DRAWSIZE,
                 "flops_per_row": FLOPS_PER_ROW,
-                "note": "algorithmic FLOPs (one product per weight); the split-bf16 mode issues 3 bf16 MFMAs "
-                        "per product and is bound by the spline's VALU/transcendental work, not by the matrix pipe",
+                "note": "algorithmic FLOPs (one product per weight); the split 16-bit modes issue 3 MFMAs "
+                        "per product and are bound by the spline's VALU/transcendental work, not by the matrix pipe",
             },
             "roofline_f32_mode": {
                 "kernel": "nsa_flow_kernel<2, NsaRQ<8>, inverse, f32> (exact float32 products)",
@@ -441,7 +484,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(full=args.cpu_full)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             # the acceptance of a pass falls with the batch size (the weights are normalised by the
             # batch maximum): the bounded sample accepts ~2.5x more per row than a 1e6-row batch, so

@@ -156,6 +156,21 @@ NSA_API int nsa_populate_draw(const uint32_t* header, const void* image_dev, lon
                       double* log_prior_out_dev, const int* rp_kind_dev, const double* rp_par_dev,
                       int* status_dev, int waves_per_group, int max_groups, void* stream);
 
+/* The truncation rules that act AFTER the flow, for the trains of passes below
+ * (src/nessai/proposal/flowproposal/truncation.py:368-446; nsa_populate_truncate is the one-pass form):
+ *   min_log_q        keep log_q > min_log_q (-inf: rule off)
+ *   ll_kind          -1: no likelihood rule; 0 / 1: keep rows whose built-in analytic log-likelihood
+ *                    (kinds and constants of nsa_log_likelihood) exceeds log_l_threshold
+ * A pointer to this struct is optional everywhere (NULL = no rule after the flow). */
+typedef struct nsa_post_rules {
+  double min_log_q;
+  int ll_kind;
+  const double* ll_mu_dev;
+  const double* ll_sigma_dev;
+  double ll_const;
+  double log_l_threshold;
+} nsa_post_rules;
+
 /* A TRAIN of populate passes with the loop control on the device: for i < n_passes
  * { nsa_populate_draw(rows row_offset + i n ...); nsa_populate_weights; nsa_populate_accept
  *   appending to x_acc; commit }  - enqueued back to back with no host round trip.  Replaces the
@@ -182,7 +197,8 @@ NSA_API int nsa_populate_passes(const uint32_t* header, const void* image_dev, l
                         const int* rp_kind_dev, const double* rp_par_dev, double* log_w_dev,
                         long long* max_keys_dev, long long capacity, double* x_acc_dev,
                         long long* state_dev, void* workspace_dev, size_t workspace_bytes,
-                        int* status_dev, int waves_per_group, int max_groups, void* stream);
+                        int* status_dev, int waves_per_group, int max_groups, void* stream,
+                        const nsa_post_rules* rules);
 
 /* The same pass in pieces, for draw batches SHARDED over ranks: the collectives of the host
  * framework (RCCL through torch.distributed, stream ordered, no host synchronisation) go between
@@ -205,6 +221,51 @@ NSA_API int nsa_populate_pass_tail(long long n, int D, const double* log_w_dev, 
                            void* workspace_dev, size_t workspace_bytes, void* stream);
 NSA_API int nsa_populate_pass_commit(long long* state_dev, long long capacity,
                              const long long* global_count_dev, long long* history_dev, void* stream);
+
+/* A TRAIN of sharded passes with two collectives per train instead of two per pass
+ * (flowproposal.py:431-518 + SURVEY.md §8e; the passes of a train are independent until the stop test):
+ *   nsa_populate_train_heads   n_passes heads back to back: pass i draws rows
+ *                              [row_offset + i * row_stride, + n) into x64_many_dev + i n D and
+ *                              log_w_many_dev + i n, its maximum into max_keys_dev[i]
+ *   -> ONE all-reduce(max) of max_keys_dev[0 .. n_passes)
+ *   nsa_populate_train_tails   n_passes accept + append steps against the global maxima, in pass order,
+ *                              on a scratch copy of the loop state that never stops;
+ *                              local_counts_dev[i] = this rank's accepted rows of pass i
+ *   -> ONE all-reduce(sum) of a copy of local_counts_dev[0 .. n_passes) (global_counts_dev)
+ *   nsa_populate_train_commit  walks the passes in order against the REAL state: pass i counts
+ *                              (state[0] += global count, state[1] += 1, history[pass] = local count,
+ *                              state[3] advances) until a stop condition holds; the rows later passes
+ *                              appended to x_acc_dev lie beyond state[3] and are never read.
+ * Rows, order, counters and Philox offsets equal those of the one-pass-at-a-time pieces above; a train
+ * that overshoots only spends the kernels of its surplus passes.  scratch_dev: int64[8]. */
+NSA_API int nsa_populate_train_heads(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                             unsigned long long seed, unsigned long long row_offset,
+                             unsigned long long row_stride, double radius, double latent_temperature,
+                             const double* scale_dev, const double* shift_dev, const double* lower_dev,
+                             const double* upper_dev, double log_j_rescale, double* x64_many_dev,
+                             double* log_q_dev, const int* prior_kind_dev, const double* prior_par_dev,
+                             double* log_prior_dev, double log_prior_const, const int* rp_kind_dev,
+                             const double* rp_par_dev, double* log_w_many_dev, long long* max_keys_dev,
+                             const long long* state_dev, int* status_dev, int waves_per_group,
+                             int max_groups, void* stream, const nsa_post_rules* rules);
+NSA_API int nsa_populate_train_tails(long long n, int D, int n_passes, const double* log_w_many_dev,
+                             const long long* max_keys_dev, unsigned long long seed,
+                             unsigned long long row_offset, unsigned long long row_stride,
+                             const double* x64_many_dev, long long capacity, double* x_acc_dev,
+                             const long long* state_dev, long long* scratch_dev,
+                             long long* local_counts_dev, void* workspace_dev, size_t workspace_bytes,
+                             void* stream);
+NSA_API int nsa_populate_train_commit(long long* state_dev, long long capacity, int n_passes,
+                              const long long* local_counts_dev, const long long* global_counts_dev,
+                              long long* history_dev, void* stream);
+
+/* accumulate_weights = True (flowproposal.py:471-476): out_dev[i] = sum over the n rows of pass i of
+ * exp(log_w - max_i), max_i = decoded max_keys_dev[i] - what pass i adds to the expected number of
+ * accepted rows `exp(logsumexp(log_weights - log_constant))`; dropped rows (-inf) add nothing.  Fixed
+ * summation order.  The host (or the ranks of a sharded proposal, after one all-reduce of the maxima and
+ * one of these sums) folds the passes into the running log_constant. */
+NSA_API int nsa_populate_sumexp(long long n, int n_passes, const double* log_w_many_dev,
+                        const long long* max_keys_dev, double* out_dev, void* stream);
 
 /* Importance nested sampler (config 4), ImportanceFlowProposal.draw
  * (src/nessai/proposal/importance.py:443-487), first half: draw rows [row_offset, row_offset + n)

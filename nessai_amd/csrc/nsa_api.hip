@@ -15,6 +15,9 @@
 #ifndef NSA_DEFAULT_OCC
 #define NSA_DEFAULT_OCC 2
 #endif
+#ifndef NSA_DEFAULT_SKEW
+#define NSA_DEFAULT_SKEW 1
+#endif
 
 // ---------------------------------------------------------------------------
 // error handling
@@ -141,13 +144,13 @@ static int nsa_occupancy(int ht, int precision, long long n_tiles, int n_flows, 
                          int waves_per_group) {
   const char* e = getenv("NESSAI_AMD_OCC");
   if (e != nullptr && e[0] == '2' && e[1] == 'x' && e[2] == '2')
-    return (ht <= 2 && precision == NSA_PREC_BF16X3 && waves_per_group <= 0) ? NSA_GEO_2X2 : NSA_DEFAULT_OCC;
+    return (ht <= 2 && precision != NSA_PREC_F32 && waves_per_group <= 0) ? NSA_GEO_2X2 : NSA_DEFAULT_OCC;
   if (e != nullptr && (e[0] == '2' || e[0] == '3')) return (e[0] == '3' && ht <= 2) ? 3 : 2;
   if (waves_per_group > 0) return (waves_per_group > 8 && ht <= 2) ? 3 : NSA_DEFAULT_OCC;
   // (3 = "big batch": nsa_launch_flow replaces it by nsa_big_batch_geometry's estimate; from one full round
   // of the default geometry upwards - 2048 tiles on 256 CUs - the estimate is the measured order:
   // scripts/bench_geometry_sizes.py, 62 500 to 1e6 rows)
-  if (ht <= 2 && precision == NSA_PREC_BF16X3 && n_tiles * n_flows >= 8LL * num_cus) return 3;
+  if (ht <= 2 && precision != NSA_PREC_F32 && n_tiles * n_flows >= 8LL * num_cus) return 3;
   return NSA_DEFAULT_OCC;
 }
 
@@ -256,7 +259,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   if (fn == nullptr)
     return nsa_fail(NSA_E_ARG, "no kernel instance for hidden_tiles=%u transform=%u bins=%u",
                     h[NSA_H_HT], h[NSA_H_TRANSFORM], h[NSA_H_BINS]);
-  if (h[NSA_H_PREC] != NSA_PREC_F32 && h[NSA_H_PREC] != NSA_PREC_BF16X3)
+  if (h[NSA_H_PREC] != NSA_PREC_F32 && h[NSA_H_PREC] != NSA_PREC_BF16X3 && h[NSA_H_PREC] != NSA_PREC_F16X3)
     return nsa_fail(NSA_E_IMAGE, "unknown precision code %u", h[NSA_H_PREC]);
   p.precision = (int)h[NSA_H_PREC];
   const int D = (int)h[NSA_H_D];
@@ -268,7 +271,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     occ = nsa_tuned_occupancy(h, p, max_groups, stream, n_flows, nsa_big_batch_geometry(n_tiles * n_flows, g_num_cus));
   int rt = 1;  // row tiles per wave
   if (occ == NSA_GEO_2X2) {
-    rt = (h[NSA_H_HT] <= 2 && p.precision == NSA_PREC_BF16X3) ? 2 : 1;
+    rt = (h[NSA_H_HT] <= 2 && p.precision != NSA_PREC_F32) ? 2 : 1;
     occ = 2;
   }
   const size_t stage_bytes = 2 * (size_t)h[NSA_H_MAX_STAGE] * 4;
@@ -295,6 +298,10 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   }
   p.occupancy = occ;
   p.row_tiles = rt;
+  {
+    const char* sk = getenv("NESSAI_AMD_SKEW");  // two-tiles geometry only (see NsaStagePipe::skew)
+    p.skew = sk != nullptr ? atoi(sk) : NSA_DEFAULT_SKEW;
+  }
   const int nw_max = 4 * occ;
   int nw = waves_per_group > 0 ? waves_per_group : (occ == 3 || rt == 2 ? 4 * occ : 2 * occ);
   if (nw > nw_max) nw = nw_max;
@@ -511,6 +518,8 @@ extern "C" int nsa_importance_mix(long long n, int n_flows, const float* log_pro
 
 extern "C" hipError_t nsa_launch_weights(long long, const double*, const double*, double, double*,
                                          long long*, hipStream_t, const long long*);
+extern "C" hipError_t nsa_launch_post_rules(long long, int, double*, const nsa_post_rules*, const double*,
+                                            const long long*, hipStream_t);
 extern "C" hipError_t nsa_launch_pass_commit(long long*, long long, const long long*, long long*, hipStream_t);
 extern "C" hipError_t nsa_launch_small_tail(long long, int, const double*, const double*, double,
                                             unsigned long long, unsigned long long, const double*, long long,
@@ -589,7 +598,8 @@ extern "C" int nsa_populate_passes(const uint32_t* header, const void* image_dev
                                    const int* rp_kind_dev, const double* rp_par_dev, double* log_w_dev,
                                    long long* max_keys_dev, long long capacity, double* x_acc_dev,
                                    long long* state_dev, void* workspace_dev, size_t workspace_bytes,
-                                   int* status_dev, int waves_per_group, int max_groups, void* stream) {
+                                   int* status_dev, int waves_per_group, int max_groups, void* stream,
+                                   const nsa_post_rules* rules) {
   if (n <= 0 || n_passes < 1 || log_w_dev == nullptr || max_keys_dev == nullptr || x_acc_dev == nullptr ||
       state_dev == nullptr || workspace_dev == nullptr || capacity < 0)
     return nsa_fail(NSA_E_ARG, "nsa_populate_passes: bad argument");
@@ -609,6 +619,10 @@ extern "C" int nsa_populate_passes(const uint32_t* header, const void* image_dev
     p.row_offset = off;
     rc = nsa_launch_flow(header, p, waves_per_group, max_groups, s);
     if (rc != NSA_OK) return rc;
+    if (rules != nullptr) {
+      hipError_t er = nsa_launch_post_rules(n, D, log_q_dev, rules, x64_dev, state_dev, s);
+      if (er != hipSuccess) return nsa_fail(NSA_E_HIP, "populate pass %d (rules after the flow): %s", i, hipGetErrorString(er));
+    }
     if (n <= 16384) {  // NSA_SMALL_N: the whole tail of the pass in one single-workgroup kernel
       hipError_t es = nsa_launch_small_tail(n, D, log_q_dev, per_row_prior, log_prior_const, seed, off, x64_dev,
                                             capacity, x_acc_dev, state_dev, s);
@@ -673,5 +687,95 @@ extern "C" int nsa_populate_pass_commit(long long* state_dev, long long capacity
   if (state_dev == nullptr || capacity < 0) return nsa_fail(NSA_E_ARG, "nsa_populate_pass_commit: bad argument");
   hipError_t e = nsa_launch_pass_commit(state_dev, capacity, global_count_dev, history_dev, (hipStream_t)stream);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "commit kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+// Trains of sharded passes: two collectives per train (see include/nessai_amd.h).
+extern "C" hipError_t nsa_launch_train_scratch(const long long*, long long*, hipStream_t);
+extern "C" hipError_t nsa_launch_train_commit(long long*, long long, int, const long long*, const long long*,
+                                              long long*, hipStream_t);
+
+extern "C" int nsa_populate_train_heads(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                                        unsigned long long seed, unsigned long long row_offset,
+                                        unsigned long long row_stride, double radius, double latent_temperature,
+                                        const double* scale_dev, const double* shift_dev, const double* lower_dev,
+                                        const double* upper_dev, double log_j_rescale, double* x64_many_dev,
+                                        double* log_q_dev, const int* prior_kind_dev, const double* prior_par_dev,
+                                        double* log_prior_dev, double log_prior_const, const int* rp_kind_dev,
+                                        const double* rp_par_dev, double* log_w_many_dev, long long* max_keys_dev,
+                                        const long long* state_dev, int* status_dev, int waves_per_group,
+                                        int max_groups, void* stream, const nsa_post_rules* rules) {
+  if (n <= 0 || n_passes < 1 || x64_many_dev == nullptr || log_w_many_dev == nullptr || max_keys_dev == nullptr ||
+      state_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_train_heads: bad argument");
+  NsaLaunch p;
+  int rc = nsa_draw_params(p, header, image_dev, n, nullptr, seed, row_offset, radius, latent_temperature, scale_dev,
+                           shift_dev, lower_dev, upper_dev, log_j_rescale, x64_many_dev, log_q_dev, nullptr,
+                           prior_kind_dev, prior_par_dev, log_prior_dev, rp_kind_dev, rp_par_dev, status_dev);
+  if (rc != NSA_OK) return rc;
+  p.stop = state_dev;
+  const long long D = (long long)header[NSA_H_D];
+  const double* per_row_prior = (prior_kind_dev != nullptr) ? log_prior_dev : nullptr;
+  for (int i = 0; i < n_passes; ++i) {
+    p.row_offset = row_offset + (unsigned long long)i * row_stride;
+    p.x64_out = x64_many_dev + (long long)i * n * D;
+    rc = nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
+    if (rc != NSA_OK) return rc;
+    if (rules != nullptr) {
+      hipError_t er = nsa_launch_post_rules(n, (int)D, log_q_dev, rules, p.x64_out, state_dev, (hipStream_t)stream);
+      if (er != hipSuccess) return nsa_fail(NSA_E_HIP, "train head %d (rules after the flow): %s", i, hipGetErrorString(er));
+    }
+    hipError_t e = nsa_launch_weights(n, log_q_dev, per_row_prior, log_prior_const, log_w_many_dev + (long long)i * n,
+                                      max_keys_dev + i, (hipStream_t)stream, state_dev);
+    if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "train head %d: %s", i, hipGetErrorString(e));
+  }
+  return NSA_OK;
+}
+
+extern "C" int nsa_populate_train_tails(long long n, int D, int n_passes, const double* log_w_many_dev,
+                                        const long long* max_keys_dev, unsigned long long seed,
+                                        unsigned long long row_offset, unsigned long long row_stride,
+                                        const double* x64_many_dev, long long capacity, double* x_acc_dev,
+                                        const long long* state_dev, long long* scratch_dev,
+                                        long long* local_counts_dev, void* workspace_dev, size_t workspace_bytes,
+                                        void* stream) {
+  if (n <= 0 || D < 1 || n_passes < 1 || log_w_many_dev == nullptr || max_keys_dev == nullptr ||
+      x64_many_dev == nullptr || x_acc_dev == nullptr || state_dev == nullptr || scratch_dev == nullptr ||
+      local_counts_dev == nullptr || workspace_dev == nullptr || capacity < 0 ||
+      workspace_bytes < nsa_accept_workspace_bytes(n))
+    return nsa_fail(NSA_E_ARG, "nsa_populate_train_tails: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = nsa_launch_train_scratch(state_dev, scratch_dev, s);
+  for (int i = 0; i < n_passes && e == hipSuccess; ++i) {
+    e = nsa_launch_accept(n, D, log_w_many_dev + (long long)i * n, max_keys_dev + i, seed,
+                          row_offset + (unsigned long long)i * row_stride, nullptr,
+                          x64_many_dev + (long long)i * n * D, capacity, x_acc_dev, nullptr, scratch_dev + 4,
+                          workspace_dev, s, scratch_dev);
+    // (scratch[1] counts the passes of this train: history index = pass within the train)
+    if (e == hipSuccess) e = nsa_launch_pass_commit(scratch_dev, capacity, nullptr, local_counts_dev, s);
+  }
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "train tails: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+extern "C" int nsa_populate_train_commit(long long* state_dev, long long capacity, int n_passes,
+                                         const long long* local_counts_dev, const long long* global_counts_dev,
+                                         long long* history_dev, void* stream) {
+  if (state_dev == nullptr || capacity < 0 || n_passes < 1 || local_counts_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_train_commit: bad argument");
+  hipError_t e = nsa_launch_train_commit(state_dev, capacity, n_passes, local_counts_dev, global_counts_dev,
+                                         history_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "train commit kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+extern "C" hipError_t nsa_launch_sumexp(long long, int, const double*, const long long*, double*, hipStream_t);
+
+extern "C" int nsa_populate_sumexp(long long n, int n_passes, const double* log_w_many_dev,
+                                   const long long* max_keys_dev, double* out_dev, void* stream) {
+  if (n <= 0 || n_passes < 1 || log_w_many_dev == nullptr || max_keys_dev == nullptr || out_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_sumexp: bad argument");
+  hipError_t e = nsa_launch_sumexp(n, n_passes, log_w_many_dev, max_keys_dev, out_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "sumexp kernel: %s", hipGetErrorString(e));
   return NSA_OK;
 }

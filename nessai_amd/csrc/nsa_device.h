@@ -31,43 +31,87 @@ __device__ __forceinline__ f32x16 nsa_mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// bf16 matrix core: D[i][j] += sum_k A[i][k] B[k][j], k = 8*half + e (16 per instruction)
-__device__ __forceinline__ f32x16 nsa_mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+// 16-bit matrix cores: D[i][j] += sum_k A[i][k] B[k][j], k = 8*half + e (16 per instruction).  The
+// operands travel as 128-bit words (eight bf16 or eight f16); PREC selects the instruction:
+//   NSA_PREC_BF16X3  v_mfma_f32_32x32x16_bf16      NSA_PREC_F16X3  v_mfma_f32_32x32x16_f16
+// (same rate, same lane layout).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef u32x4 nsa_op8;  // eight 16-bit operand values of one lane
+
+template <int PREC>
+__device__ __forceinline__ f32x16 nsa_mfma16(nsa_op8 a, nsa_op8 b, f32x16 c) {
 #if defined(NSA_ABLATE) && (NSA_ABLATE & 8)
   asm volatile("" ::"v"(a), "v"(b));  // diagnostic build: operands stay live, no matrix work
   return c;
 #else
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  if constexpr (PREC == NSA_PREC_F16X3)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 #endif
 }
 
-// x = hi + lo with hi = bf16(x), lo = bf16(x - hi)   (round to nearest even)
-// Two values per v_cvt_pk_bf16_f32; float(hi) comes back out of the packed pair with one shift or
+// x = hi + lo with hi = r16(x), lo = r16(x - hi)   (round to nearest even; r16 = bf16 or f16)
+// bf16: two values per v_cvt_pk_bf16_f32; float(hi) comes back out of the packed pair with one shift or
 // mask per value (written per element, the compiler converted every value twice - once alone for the
-// subtraction, once packed for the operand: 4 VALU per value instead of 3).
+// subtraction, once packed for the operand: 4 VALU per value instead of 3).  8 + 8 significant bits:
+// ~2^-17 relative per operand.
+// f16: v_cvt_pk_f16_f32, float(hi) by v_cvt_f32_f16 (the upper half through SDWA) - also 3 VALU per
+// value.  11 + 11 significant bits: x - hi is exact in float32 and |lo| <= 2^-11 |x|, so hi + lo carries x
+// to 2^-24 relative (float32 itself) while lo stays a normal f16 (|x| >= 2^-3), and to 2^-25 ABSOLUTE
+// below that (f16 subnormals, which the matrix cores do not flush).  The price is the range: |x| must
+// stay below 65520, where f16 rounds to infinity.  A launch that split such a value must not be used, and
+// the kernel says so in status[1] without an instruction per value: hi = +-inf makes lo = x - hi = -+inf,
+// so EVERY product of that batch row's column - a_l*b_h, a_h*b_l, a_h*b_h with a zero or non-zero weight -
+// is inf - inf or 0 * inf: all accumulators of the row come out NaN.  A NaN travels to the row's outputs
+// through every path of the flow except an activation (the default NaN of the matrix cores is negative,
+// a relu returns 0 for it: scripts/ubench/f16_facts.hip), so one accumulator per row is tested after the
+// GEMMs that feed an activation and the row's log-det / outputs in the epilogue.  (The wave's sticky IEEE
+// flags do not work for this: TRAPSTS.EXCP stays 0 on gfx950 whatever overflows.  A running maximum over the
+// split values, even as one v_pk_max_u16 per pair on the hi words, cost 25-120 more spilled VGPRs in the
+// two-tiles instances: NSA_F16_DETECT=2 keeps that form for cross-checks.)  The host repeats such a call
+// in exact float32 (HipFlow: precision "auto") or raises.  A NaN of any other origin is reported too: a
+// needless repeat, never a miss.
+#ifndef NSA_F16_DETECT
+#define NSA_F16_DETECT 1
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void nsa_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-  u32x4 hw, lw;
+#define NSA_F16_INF 0x7c00
+
+template <int PREC>
+__device__ __forceinline__ void nsa_split8(const float (&v)[8], nsa_op8& hi, nsa_op8& lo, u16x2& amax) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const f32x2 x = {v[2 * q], v[2 * q + 1]};
-    const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
-    const f32x2 d = {x[0] - __builtin_bit_cast(float, hp << 16), x[1] - __builtin_bit_cast(float, hp & 0xffff0000u)};
-    hw[q] = hp;
-    lw[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2));
+    if constexpr (PREC == NSA_PREC_F16X3) {
+      const f16x2 h = __builtin_convertvector(x, f16x2);
+      const f32x2 hf = __builtin_convertvector(h, f32x2);
+      const f32x2 d = {x[0] - hf[0], x[1] - hf[1]};
+      hi[q] = __builtin_bit_cast(uint32_t, h);
+      lo[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, f16x2));
+#if NSA_F16_DETECT == 2
+      amax = __builtin_elementwise_max(amax, __builtin_bit_cast(u16x2, hi[q] & 0x7fff7fffu));
+#endif
+    } else {
+      const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+      const f32x2 d = {x[0] - __builtin_bit_cast(float, hp << 16), x[1] - __builtin_bit_cast(float, hp & 0xffff0000u)};
+      hi[q] = hp;
+      lo[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2));
+    }
   }
-  hi = __builtin_bit_cast(bf16x8, hw);
-  lo = __builtin_bit_cast(bf16x8, lw);
 }
 
-// three-product split-bf16 multiply-accumulate: a*b ~ ah*bh + ah*bl + al*bh
-__device__ __forceinline__ f32x16 nsa_mfma_x3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
-  c = nsa_mfma16(al, bh, c);
-  c = nsa_mfma16(ah, bl, c);
-  return nsa_mfma16(ah, bh, c);
+// three-product split multiply-accumulate: a*b ~ ah*bh + ah*bl + al*bh
+template <int PREC>
+__device__ __forceinline__ f32x16 nsa_mfma_x3(nsa_op8 ah, nsa_op8 al, nsa_op8 bh, nsa_op8 bl, f32x16 c) {
+  c = nsa_mfma16<PREC>(al, bh, c);
+  c = nsa_mfma16<PREC>(ah, bl, c);
+  return nsa_mfma16<PREC>(ah, bh, c);
 }
 
 // relu on the integer ALU: negative floats are negative ints.  One instruction (fmaxf(x, 0) is two:

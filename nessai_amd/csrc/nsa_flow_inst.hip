@@ -22,27 +22,34 @@ using TP = NsaAdditive;
 #define NSA_CAT(a, b, c, d, e, f) NSA_CAT_(a, b, c, d, e, f)
 #define NSA_LAUNCH_NAME NSA_CAT(nsa_launch_h, NSA_HT, _t, NSA_TKIND, _k, NSA_BINS)
 
+// kernel of one (direction, precision, waves per SIMD, row tiles per wave)
+template <int PREC, int OCC, int RT>
+static auto nsa_pick(bool inv) {
+  return inv ? nsa_flow_kernel<NSA_HT, TP, true, PREC, OCC, RT> : nsa_flow_kernel<NSA_HT, TP, false, PREC, OCC, RT>;
+}
+
+// the split 16-bit modes share their geometries
+template <int PREC>
+static auto nsa_pick16(const NsaLaunch* p, bool inv) {
+  auto kern = nsa_pick<PREC, 2, 1>(inv);
+#if NSA_HT <= 2
+  // three waves per SIMD: the hidden state of a <= 64-wide conditioner fits 168 VGPRs
+  if (p->occupancy == 3) kern = nsa_pick<PREC, 3, 1>(inv);
+  // two row tiles per wave, 8-wave workgroups at two waves per SIMD (not in exact f32: the matrix pipe is
+  // the limit there and the variant measured 4.41 ms against 4.36)
+  if (p->row_tiles == 2) kern = nsa_pick<PREC, 2, 2>(inv);
+#endif
+  return kern;
+}
+
 extern "C" __attribute__((visibility("hidden"))) hipError_t NSA_LAUNCH_NAME(
     const NsaLaunch* p, unsigned grid, unsigned grid_y, unsigned block, size_t lds, hipStream_t stream) {
   const bool inv = p->direction == NSA_DIR_INVERSE;
-  auto kern = (p->precision == NSA_PREC_BF16X3)
-                  ? (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_BF16X3, 2>
-                         : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_BF16X3, 2>)
-                  : (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_F32, 2>
-                         : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_F32, 2>);
+  auto kern = nsa_pick<NSA_PREC_F32, 2, 1>(inv);
+  if (p->precision == NSA_PREC_BF16X3) kern = nsa_pick16<NSA_PREC_BF16X3>(p, inv);
+  else if (p->precision == NSA_PREC_F16X3) kern = nsa_pick16<NSA_PREC_F16X3>(p, inv);
 #if NSA_HT <= 2
-  // three waves per SIMD: the hidden state of a <= 64-wide conditioner fits 168 VGPRs
-  if (p->occupancy == 3)
-    kern = (p->precision == NSA_PREC_BF16X3)
-               ? (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_BF16X3, 3>
-                      : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_BF16X3, 3>)
-               : (inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_F32, 3>
-                      : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_F32, 3>);
-  // two row tiles per wave, 8-wave workgroups at two waves per SIMD: split-bf16 only (in exact f32 the
-  // matrix pipe is the limit and the variant measured 4.41 ms against 4.36)
-  if (p->row_tiles == 2 && p->precision == NSA_PREC_BF16X3)
-    kern = inv ? nsa_flow_kernel<NSA_HT, TP, true, NSA_PREC_BF16X3, 2, 2>
-               : nsa_flow_kernel<NSA_HT, TP, false, NSA_PREC_BF16X3, 2, 2>;
+  else if (p->occupancy == 3) kern = nsa_pick<NSA_PREC_F32, 3, 1>(inv);
 #endif
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -142,6 +142,9 @@ struct NsaLaunch {
   // 32-row tiles per wave: 1, or 2 in the split-bf16 instances of <= 64-wide conditioners (`occupancy`
   // 2, 8-wave workgroups)
   int row_tiles;
+  // the two-tiles instances: which waves cross the stage barriers between a stage's MFMAs and its vector
+  // part (NsaStagePipe::skew): 0 none, 1 the upper half of the workgroup's waves, 2 every other wave
+  int skew;
 #ifdef NSA_TIMELINE
   unsigned long long* dbg;
 #endif
@@ -197,6 +200,27 @@ struct NsaStagePipe {
   // the stage being copied: its entry, and the instalment to issue next
   uint32_t cp_off, cp_words;
   int cp_part;
+  // Skewed waves (the two-tiles geometry; nsa_coupling<..., SKEW = true>): a stage is {M: its MFMAs, reading the stage buffer} then {V: the vector
+  // work on their results, registers and the wave's own x tile only}.  A skewed wave crosses the stage
+  // barrier BETWEEN M and V instead of after V, so that from the second stage on it runs V(s-1) while the
+  // plain waves of its SIMD run M(s), then M(s) while they run V(s): the matrix pipe and the vector ALUs of
+  // a SIMD are busy at the same time instead of in turns.  Same barrier count, same buffers: every wave
+  // finishes M(s) - its last read of stage s - before barrier s.  The two kinds of wave run two copies of the
+  // coupling code (template parameter): with one copy and the barrier position tested at run time the M / V
+  // boundary is a scheduling boundary for every wave, which cost the plain ones 3 %.
+  bool skew;
+  bool issued;  // the copy of the next stage went out right after the barrier (skewed waves)
+  // NSA_PREC_F16X3: an accumulator that feeds an activation came out NaN in this tile group (an operand
+  // beyond the f16 range: nsa_device.h); with NSA_F16_DETECT=2 instead the largest |hi| split (nsa_split8)
+  bool nan_seen;
+  u16x2 amax;
+  template <int PREC, int RT, int OT>
+  __device__ __forceinline__ void watch(const f32x16 (&acc)[RT][OT]) {
+    if constexpr (PREC == NSA_PREC_F16X3 && NSA_F16_DETECT == 1) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) nan_seen |= acc[t][0][0] != acc[t][0][0];
+    }
+  }
 #ifdef NSA_TIMELINE
   NsaTl tl;
 #endif
@@ -227,13 +251,18 @@ struct NsaStagePipe {
   }
   // current stage's data; starts the copy of the next stage (wrapping to stage 0 for the
   // workgroup's next tile group)
-  __device__ __forceinline__ const float* begin() {
+  __device__ __forceinline__ void issue_next(int parts) {
     const int nxt = (cur + 1 == n_stages) ? 0 : cur + 1;
     cp_off = nxt_off;
     cp_words = nxt_words;
-    issue(cp_off, cp_words, parity ? buf0 : buf1, 0, NSA_COPY_PARTS);
-    cp_part = 1;
+    issue(cp_off, cp_words, parity ? buf0 : buf1, 0, parts);
+    cp_part = parts == 1 ? NSA_COPY_PARTS : 1;
     load_entry((nxt + 1 == n_stages) ? 0 : nxt + 1);
+  }
+  template <bool SKEW = false>
+  __device__ __forceinline__ const float* begin() {
+    if (SKEW && issued) issued = false;
+    else issue_next(NSA_COPY_PARTS);
     NSA_TL(*this, 12);
     return parity ? buf1 : buf0;
   }
@@ -254,6 +283,21 @@ struct NsaStagePipe {
     NSA_TL(*this, 8);
     cur = (cur + 1 == n_stages) ? 0 : cur + 1;
     parity ^= 1;
+  }
+  // end of a stage's M part / of its V part: the barrier is at the first for skewed waves (which then send
+  // the whole next copy off at once - its second instalment would otherwise go out right in front of the
+  // wait for it), at the second for the others
+  template <bool SKEW>
+  __device__ __forceinline__ void end_m() {
+    if constexpr (SKEW) {
+      end();
+      issue_next(1);
+      issued = true;
+    }
+  }
+  template <bool SKEW>
+  __device__ __forceinline__ void end_v() {
+    if constexpr (!SKEW) end();
   }
 };
 
@@ -346,22 +390,22 @@ __device__ __forceinline__ void nsa_acc_to_regs(const f32x16 (&acc)[HT], float (
     for (int r = 0; r < 16; ++r) out[16 * ot + r] = acc[ot][r];
 }
 
-// ---- split-bf16 (NSA_PREC_BF16X3) variants --------------------------------------
+// ---- split 16-bit (NSA_PREC_BF16X3 / NSA_PREC_F16X3) variants --------------------
 
 // activations of one layer, split once and reused for every output tile
 template <int HT>
 struct NsaSplit {
-  bf16x8 hi[2 * HT], lo[2 * HT];
+  nsa_op8 hi[2 * HT], lo[2 * HT];
 };
 
-template <int HT>
-__device__ __forceinline__ void nsa_split_regs(const float (&in)[16 * HT], NsaSplit<HT>& sp) {
+template <int PREC, int HT>
+__device__ __forceinline__ void nsa_split_regs(const float (&in)[16 * HT], NsaSplit<HT>& sp, u16x2& amax) {
 #pragma unroll
   for (int s = 0; s < 2 * HT; ++s) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = in[8 * s + e];
-    nsa_split8(v, sp.hi[s], sp.lo[s]);
+    nsa_split8<PREC>(v, sp.hi[s], sp.lo[s], amax);
   }
 }
 
@@ -369,40 +413,40 @@ __device__ __forceinline__ void nsa_split_regs(const float (&in)[16 * HT], NsaSp
 // covers the k steps [S0, S0 + NS) of the split activations.  The A operands (LDS) of unit
 // u + NSA_PF are fetched before the MFMAs of unit u are issued, so that the LDS latency runs under the
 // matrix pipe instead of in front of it.
-template <int HT, int OT, int RT, int S0 = 0, int NS = 2 * HT>
+template <int PREC, int HT, int OT, int RT, int S0 = 0, int NS = 2 * HT>
 __device__ __forceinline__ void nsa_dense_regs16(const float* w, const NsaSplit<HT> (&sp)[RT], int lane,
                                                  f32x16 (&acc)[RT][OT]) {
   constexpr int U = NS * OT;  // unit u = s * OT + ot
-  bf16x8 ah[NSA_PF + 1], al[NSA_PF + 1];
+  nsa_op8 ah[NSA_PF + 1], al[NSA_PF + 1];
 #pragma unroll
   for (int u = 0; u < NSA_PF && u < U; ++u) {
-    ah[u] = *(const bf16x8*)(w + ((((u % OT) * NS + u / OT) * 2 + 0) * 64 + lane) * 4);
-    al[u] = *(const bf16x8*)(w + ((((u % OT) * NS + u / OT) * 2 + 1) * 64 + lane) * 4);
+    ah[u] = *(const nsa_op8*)(w + ((((u % OT) * NS + u / OT) * 2 + 0) * 64 + lane) * 4);
+    al[u] = *(const nsa_op8*)(w + ((((u % OT) * NS + u / OT) * 2 + 1) * 64 + lane) * 4);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int s = u / OT, ot = u % OT;
     if (u + NSA_PF < U) {
       const int s2 = (u + NSA_PF) / OT, ot2 = (u + NSA_PF) % OT;
-      ah[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * NS + s2) * 2 + 0) * 64 + lane) * 4);
-      al[(u + NSA_PF) % (NSA_PF + 1)] = *(const bf16x8*)(w + (((ot2 * NS + s2) * 2 + 1) * 64 + lane) * 4);
+      ah[(u + NSA_PF) % (NSA_PF + 1)] = *(const nsa_op8*)(w + (((ot2 * NS + s2) * 2 + 0) * 64 + lane) * 4);
+      al[(u + NSA_PF) % (NSA_PF + 1)] = *(const nsa_op8*)(w + (((ot2 * NS + s2) * 2 + 1) * 64 + lane) * 4);
     }
-    const bf16x8 a_h = ah[u % (NSA_PF + 1)], a_l = al[u % (NSA_PF + 1)];
+    const nsa_op8 a_h = ah[u % (NSA_PF + 1)], a_l = al[u % (NSA_PF + 1)];
     // the row tiles of the wave take turns product by product: independent accumulators back to back
 #pragma unroll
-    for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma16(a_l, sp[t].hi[S0 + s], acc[t][ot]);
+    for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma16<PREC>(a_l, sp[t].hi[S0 + s], acc[t][ot]);
 #pragma unroll
-    for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma16(a_h, sp[t].lo[S0 + s], acc[t][ot]);
+    for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma16<PREC>(a_h, sp[t].lo[S0 + s], acc[t][ot]);
 #pragma unroll
-    for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma16(a_h, sp[t].hi[S0 + s], acc[t][ot]);
+    for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma16<PREC>(a_h, sp[t].hi[S0 + s], acc[t][ot]);
   }
 }
 
 // input gathered from the x tile: tab[16*s + 8*half + e]
-template <int OT, bool PRE, int RT>
+template <int PREC, int OT, bool PRE, int RT>
 __device__ __forceinline__ void nsa_dense_tile16(const float* w, const int* tab, const float* pre,
                                                  float* const (&xrow)[RT], int n_steps, int lane, int half,
-                                                 f32x16 (&acc)[RT][OT]) {
+                                                 f32x16 (&acc)[RT][OT], u16x2& amax) {
   for (int s = 0; s < n_steps; ++s) {
     // 8 table entries (and pre-shifts) in two 16-byte reads, then 8 independent tile reads: with a
     // branch per element the compiler issued read -> wait -> read -> wait sixteen times in a row
@@ -418,7 +462,7 @@ __device__ __forceinline__ void nsa_dense_tile16(const float* w, const int* tab,
         sh[4 + e] = p1[e];
       }
     }
-    bf16x8 bh[RT], bl[RT];
+    nsa_op8 bh[RT], bl[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
       float v[8];
@@ -429,14 +473,14 @@ __device__ __forceinline__ void nsa_dense_tile16(const float* w, const int* tab,
         if (PRE) v[e] = v[e] - sh[e];
         v[e] = (col[e] >= 0) ? v[e] : 0.0f;
       }
-      nsa_split8(v, bh[t], bl[t]);
+      nsa_split8<PREC>(v, bh[t], bl[t], amax);
     }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
-      const bf16x8 ah = *(const bf16x8*)(w + (((ot * n_steps + s) * 2 + 0) * 64 + lane) * 4);
-      const bf16x8 al = *(const bf16x8*)(w + (((ot * n_steps + s) * 2 + 1) * 64 + lane) * 4);
+      const nsa_op8 ah = *(const nsa_op8*)(w + (((ot * n_steps + s) * 2 + 0) * 64 + lane) * 4);
+      const nsa_op8 al = *(const nsa_op8*)(w + (((ot * n_steps + s) * 2 + 1) * 64 + lane) * 4);
 #pragma unroll
-      for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma_x3(ah, al, bh[t], bl[t], acc[t][ot]);
+      for (int t = 0; t < RT; ++t) acc[t][ot] = nsa_mfma_x3<PREC>(ah, al, bh[t], bl[t], acc[t][ot]);
     }
   }
 }
@@ -516,18 +560,18 @@ __device__ __forceinline__ void nsa_chunk_gemm([[maybe_unused]] NsaStagePipe& pi
       for (int ot = 0; ot < TP::C; ++ot) acc[t][ot] = acc[0][ot];
     NSA_TL(pipe, 13);
   }
-  if constexpr (PREC == NSA_PREC_BF16X3) nsa_dense_regs16<HT, TP::C, RT, J * (2 * HT / KS), 2 * HT / KS>(w, hs, lane, acc);
+  if constexpr (PREC != NSA_PREC_F32) nsa_dense_regs16<PREC, HT, TP::C, RT, J * (2 * HT / KS), 2 * HT / KS>(w, hs, lane, acc);
   else nsa_dense_regs<HT, TP::C, RT, J * (4 * HT / KS), 4 * HT / KS>(w, h, lane, acc);
 }
 
 // one coupling layer (over the RT row tiles of the wave) ---------------------------
 
-template <int HT, class TP, bool INV, int PREC, int RT>
+template <int HT, class TP, bool INV, int PREC, int RT, bool SKEW = false>
 __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t* op, float* const (&xrow)[RT],
                                              int dummy_col, int lane, int half, int act, int net,
                                              int n_layers, const NsaTransformConsts& tc,
                                              float (&logdet)[RT], int (&n_bad)[RT]) {
-  constexpr bool BF = (PREC == NSA_PREC_BF16X3);
+  constexpr bool BF = (PREC != NSA_PREC_F32);  // split 16-bit operands (bf16 or f16 pairs)
   const int n_steps0 = __builtin_amdgcn_readfirstlane((int)op[1]);
   const int n_chunks = __builtin_amdgcn_readfirstlane((int)op[2]);
   float h[RT][16 * HT];
@@ -539,11 +583,11 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     NsaSplit<HT> sp[RT];
     if constexpr (BF) {
 #pragma unroll
-      for (int t = 0; t < RT; ++t) nsa_split_regs<HT>(in[t], sp[t]);
+      for (int t = 0; t < RT; ++t) nsa_split_regs<PREC, HT>(in[t], sp[t], pipe.amax);
     }
     nsa_static_for<KS>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
-      const float* st = pipe.begin();
+      const float* st = pipe.template begin<SKEW>();
       const float* w = st;
       if constexpr (J == 0) {
         nsa_load_bias<HT>(st, half, acc[0]);
@@ -554,17 +598,19 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
         w = st + 32 * HT;
         NSA_TL(pipe, 13);
       }
-      if constexpr (BF) nsa_dense_regs16<HT, HT, RT, J * (2 * HT / KS), 2 * HT / KS>(w, sp, lane, acc);
+      if constexpr (BF) nsa_dense_regs16<PREC, HT, HT, RT, J * (2 * HT / KS), 2 * HT / KS>(w, sp, lane, acc);
       else nsa_dense_regs<HT, HT, RT, J * (4 * HT / KS), 4 * HT / KS>(w, in, lane, acc);
       pipe.more();
       NSA_TL(pipe, 3);
       if constexpr (J + 1 < KS) pipe.end();
+      else pipe.template end_m<SKEW>();
     });
+    pipe.template watch<PREC>(acc);
   };
 
   // layer 0: identity features (x tile) -> hidden
   {
-    const float* st = pipe.begin();
+    const float* st = pipe.template begin<SKEW>();
     const int* id_tab = (const int*)st;
     const float* bias = st + (BF ? 16 : 2) * n_steps0;
     const float* w = bias + 32 * HT;
@@ -574,14 +620,16 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     for (int t = 1; t < RT; ++t)
 #pragma unroll
       for (int ot = 0; ot < HT; ++ot) acc[t][ot] = acc[0][ot];
-    if constexpr (BF) nsa_dense_tile16<HT, false, RT>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
+    if constexpr (BF) nsa_dense_tile16<PREC, HT, false, RT>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc, pipe.amax);
     else nsa_dense_tile<HT, false, RT>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
     pipe.more();
     NSA_TL(pipe, 1);
+    pipe.template end_m<SKEW>();
+    pipe.template watch<PREC>(acc);
 #pragma unroll
     for (int t = 0; t < RT; ++t) nsa_acc_to_regs<HT>(acc[t], h[t]);
     NSA_TL(pipe, 2);
-    pipe.end();
+    pipe.template end_v<SKEW>();
   }
 
   if (net == NSA_NET_RESNET) {
@@ -603,7 +651,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
           nsa_act_regs<16 * HT>(tmp[t], act);
         }
         NSA_TL(pipe, 4);
-        pipe.end();
+        pipe.template end_v<SKEW>();
       }
       {
         f32x16 acc[RT][HT];
@@ -615,7 +663,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[t][16 * ot + r] = h[t][16 * ot + r] + acc[t][ot][r];
         NSA_TL(pipe, 4);
-        pipe.end();
+        pipe.template end_v<SKEW>();
       }
     }
   } else {
@@ -631,7 +679,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
         nsa_act_regs<16 * HT>(h[t], act);
       }
       NSA_TL(pipe, 4);
-      pipe.end();
+      pipe.template end_v<SKEW>();
     }
   }
 
@@ -643,18 +691,19 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
   NsaSplit<HT> hs[RT];
   if constexpr (BF) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t) nsa_split_regs<HT>(h[t], hs[t]);
+    for (int t = 0; t < RT; ++t) nsa_split_regs<PREC, HT>(h[t], hs[t], pipe.amax);
   }
   for (int c = 0; c < n_chunks; ++c) {
     f32x16 acc[RT][TP::C];
     int cols[TP::FPC];
     nsa_static_for<nsa_ksplit(TP::C, HT)>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
-      const float* st = pipe.begin();
+      const float* st = pipe.template begin<SKEW>();
       nsa_chunk_gemm<HT, TP, PREC, J, RT>(pipe, st, h, hs, lane, half, acc, cols);
       pipe.more();
       NSA_TL(pipe, 5);
       if constexpr (J + 1 < nsa_ksplit(TP::C, HT)) pipe.end();
+      else pipe.template end_m<SKEW>();
     });
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -673,7 +722,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
       }
     }
     NSA_TL(pipe, 6);
-    pipe.end();
+    pipe.template end_v<SKEW>();
   }
 }
 
@@ -682,7 +731,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
 template <int PREC, int RT>
 __device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t* op, float* const (&xrow)[RT],
                                              int D, int lane, int half, float (&logdet)[RT]) {
-  constexpr bool BF = (PREC == NSA_PREC_BF16X3);
+  constexpr bool BF = (PREC != NSA_PREC_F32);  // split 16-bit operands (bf16 or f16 pairs)
   const int n_steps = __builtin_amdgcn_readfirstlane((int)op[1]);
   const int n_ot = __builtin_amdgcn_readfirstlane((int)op[2]);
   const int tab_len = (BF ? 16 : 2) * n_steps;
@@ -695,7 +744,7 @@ __device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t*
     f32x16 acc[RT][1];
 #pragma unroll
     for (int t = 0; t < RT; ++t) nsa_load_bias<1>(bias, half, acc[t]);
-    if constexpr (BF) nsa_dense_tile16<1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+    if constexpr (BF) nsa_dense_tile16<PREC, 1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc, pipe.amax);
     else nsa_dense_tile<1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -708,7 +757,7 @@ __device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t*
     f32x16 acc[RT][2];
 #pragma unroll
     for (int t = 0; t < RT; ++t) nsa_load_bias<2>(bias, half, acc[t]);
-    if constexpr (BF) nsa_dense_tile16<2, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+    if constexpr (BF) nsa_dense_tile16<PREC, 2, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc, pipe.amax);
     else nsa_dense_tile<2, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -762,6 +811,7 @@ __device__ __forceinline__ int nsa_opaque(int v) {
 // tiles, and the wave always has RT independent accumulator chains and element-wise chains to issue from.
 template <int HT, class TP, bool INV, int PREC, int OCC, int RT = 1>
 __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(NsaLaunch p) {
+  constexpr bool SK = RT == 2;  // the two-tiles instances carry the skewed copy of the coupling code
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (p.stop != nullptr && (p.stop[0] >= p.stop[2] || p.stop[1] >= p.stop[5])) return;
   if (p.image_list != nullptr) {
@@ -827,6 +877,9 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
   pipe.wave = wave;
   pipe.nw = nw;
   pipe.lane = lane;
+  pipe.issued = false;
+  // p.skew: 1 = the upper half of the workgroup's waves, 2 = every other wave
+  pipe.skew = SK && (p.skew == 1 ? (wave >= (nw >> 1)) : (p.skew == 2 ? (wave & 1) != 0 : false));
 
   const uint32_t* ops = prog_ops;
   const int* out_tab = (const int*)(img + (inverse ? img[NSA_H_OUT_INV] : img[NSA_H_OUT_FWD]));
@@ -956,6 +1009,8 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
     }
     NSA_TL(pipe, 0);
     // ---- run the flow --------------------------------------------------------
+    pipe.amax = u16x2{0, 0};
+    pipe.nan_seen = false;
     float logdet_a[RT];
     int n_bad_a[RT];
 #pragma unroll
@@ -967,7 +1022,10 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
       const uint32_t* op = ops + o * NSA_OP_WORDS;
       const int kind = __builtin_amdgcn_readfirstlane((int)op[0]);
       if (kind == NSA_OP_COUPLING) {
-        nsa_coupling<HT, TP, INV, PREC, RT>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
+        if (SK && pipe.skew)
+          nsa_coupling<HT, TP, INV, PREC, RT, SK>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
+        else
+          nsa_coupling<HT, TP, INV, PREC, RT, false>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
       } else if (kind == NSA_OP_DENSE) {
         nsa_dense_op<PREC, RT>(pipe, op, xrow_a, D, lane, half, logdet_a);
       } else {
@@ -976,6 +1034,24 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
     }
 
     // ---- epilogues -----------------------------------------------------------
+    if constexpr (PREC == NSA_PREC_F16X3) {
+      // a value beyond the f16 range went into a matrix product somewhere in this wave's tiles: the
+      // results of the call are not to be used (status[1]; the host repeats it in float32 or raises)
+      bool over;
+      if constexpr (NSA_F16_DETECT == 1) {
+        over = pipe.nan_seen;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          float poison = logdet_a[t];  // NaN or +-inf in the log-det or in any output column -> NaN
+          for (int c = half; c < D; c += 2) poison = fmaf(xrow_a[t][c], 0.0f, poison);
+          over |= (poison - poison) != 0.0f;
+        }
+        over = __any(over);
+      } else {
+        over = __any(pipe.amax[0] >= NSA_F16_INF || pipe.amax[1] >= NSA_F16_INF);
+      }
+      if (over && lane == 0) atomicAdd(p.status + 1, 1);
+    }
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
     float* const xt = xt_a[t];

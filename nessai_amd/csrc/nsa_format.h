@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define NSA_MAGIC 0x3141534e /* "NSA1" */
-#define NSA_VERSION 5
+#define NSA_VERSION 6
 
 // header word indices
 enum {
@@ -61,7 +61,11 @@ enum { NSA_OP_COUPLING = 1, NSA_OP_DENSE = 2, NSA_OP_ELEMENTWISE = 3 };
 // NSA_PREC_BF16X3: operands split x = hi + lo (two bf16), products hi*hi + hi*lo + lo*hi on
 //                  v_mfma_f32_32x32x16_bf16 with f32 accumulation (relative error ~2^-16 per
 //                  product; log_prob stays within the 1e-5 parity bar)
-enum { NSA_PREC_F32 = 0, NSA_PREC_BF16X3 = 1 };
+// NSA_PREC_F16X3 : the same three products on f16 pairs (v_mfma_f32_32x32x16_f16): 11 + 11 significant
+//                  bits carry an operand to 2^-24 relative (2^-25 absolute below 2^-3) - float32-class
+//                  products at the bf16 rate - for operands below 65520 in magnitude; a launch that
+//                  splits a larger value says so in status[1]
+enum { NSA_PREC_F32 = 0, NSA_PREC_BF16X3 = 1, NSA_PREC_F16X3 = 2 };
 
 // op record: 4 words
 //   COUPLING    {kind, n_steps0 (multiple of 4), n_chunks, 0}
@@ -85,9 +89,9 @@ enum { NSA_PREC_F32 = 0, NSA_PREC_BF16X3 = 1 };
 //   in_col from the x tile (layer 0, dense): 2*s + half
 // bias[ot][half][r] is the bias of out feature 32*ot + (r&3) + 8*(r>>2) + 4*half.
 //
-// NSA_PREC_BF16X3 images keep the same tables and biases but count k in steps of 16
-// (v_mfma_f32_32x32x16_bf16: lane = 32*half + i holds 8 consecutive k of its half) and
-// store W as bf16 pairs: W[ot][s][part][64][8], part 0 = hi, part 1 = lo, with
+// NSA_PREC_BF16X3 / NSA_PREC_F16X3 images keep the same tables and biases but count k in steps of 16
+// (v_mfma_f32_32x32x16_bf16 / _f16: lane = 32*half + i holds 8 consecutive k of its half) and
+// store W as bf16 (f16) pairs: W[ot][s][part][64][8], part 0 = hi, part 1 = lo, with
 //   in_col from registers: 32*(s>>1) + (r&3) + 8*(r>>2) + 4*half, r = 8*(s&1) + e
 //   in_col from the x tile: 16*s + 8*half + e            (tables hold 16 entries per step)
 

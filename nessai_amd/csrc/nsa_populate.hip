@@ -298,6 +298,78 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_pass_comm
   return hipGetLastError();
 }
 
+// accumulate_weights (flowproposal.py:471-476): sum_r exp(log_w[r] - max) of each pass of a train, the
+// term a pass adds to the expected number of accepted rows.  One workgroup per pass, fixed summation
+// order (thread-strided partial sums, then a tree over the 1024 threads): the value does not depend on
+// the launch, only on how the rows are dealt to the ranks.
+__global__ void __launch_bounds__(1024) nsa_sumexp_kernel(long long n, const double* __restrict__ log_w_many,
+                                                          const long long* __restrict__ max_keys,
+                                                          double* __restrict__ out) {
+  const double* log_w = log_w_many + (long long)blockIdx.x * n;
+  const double m = nsa_key_decode(max_keys[blockIdx.x]);
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 1024) {
+    const double w = log_w[i];
+    if (w > -__builtin_huge_val()) s += exp(w - m);
+  }
+  __shared__ double sm[1024];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_sumexp(
+    long long n, int n_passes, const double* log_w_many, const long long* max_keys, double* out,
+    hipStream_t stream) {
+  hipLaunchKernelGGL(nsa_sumexp_kernel, dim3((unsigned)n_passes), dim3(1024), 0, stream, n, log_w_many, max_keys,
+                     out);
+  return hipGetLastError();
+}
+
+// Trains of sharded passes (nsa_populate_train_*, include/nessai_amd.h): the tails of a train run on a
+// scratch copy of the loop state that never stops; the commit then replays the passes against the
+// real state with the global counts.
+__global__ void nsa_train_scratch_kernel(const long long* state, long long* scratch) {
+  scratch[0] = 0;
+  scratch[1] = 0;
+  scratch[2] = 0x7fffffffffffffffLL;
+  scratch[3] = state[3];
+  scratch[4] = 0;
+  scratch[5] = 0x7fffffffffffffffLL;
+}
+
+__global__ void nsa_train_commit_kernel(long long* state, long long capacity, int n_passes,
+                                        const long long* local_counts, const long long* global_counts,
+                                        long long* history) {
+  for (int i = 0; i < n_passes; ++i) {
+    if (NSA_STOPPED(state)) return;
+    const long long got = local_counts[i];
+    if (history != nullptr) history[state[1]] = got;
+    state[0] += (global_counts != nullptr) ? global_counts[i] : got;
+    state[1] += 1;
+    const long long w = state[3] + got;
+    state[3] = w < capacity ? w : capacity;
+  }
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_train_scratch(
+    const long long* state, long long* scratch, hipStream_t stream) {
+  hipLaunchKernelGGL(nsa_train_scratch_kernel, dim3(1), dim3(1), 0, stream, state, scratch);
+  return hipGetLastError();
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_train_commit(
+    long long* state, long long capacity, int n_passes, const long long* local_counts,
+    const long long* global_counts, long long* history, hipStream_t stream) {
+  hipLaunchKernelGGL(nsa_train_commit_kernel, dim3(1), dim3(1), 0, stream, state, capacity, n_passes, local_counts,
+                     global_counts, history);
+  return hipGetLastError();
+}
+
 extern "C" __attribute__((visibility("hidden"))) size_t nsa_accept_workspace_bytes(long long n) {
   const long long nb = (n + NSA_ACC_ROWS - 1) / NSA_ACC_ROWS;
   size_t bytes = ((size_t)n + 255) & ~(size_t)255;      // flags
@@ -354,13 +426,11 @@ __device__ __forceinline__ double nsa_ll_term(int kind, const double* __restrict
   return t * t;
 }
 
-__global__ void nsa_log_likelihood_kernel(int kind, long long n, int D, const double* __restrict__ x,
-                                          const double* __restrict__ mu, const double* __restrict__ sigma,
-                                          double cst, double* __restrict__ out) {
+// log L of one row
+__device__ __forceinline__ double nsa_ll_row(int kind, int D, const double* __restrict__ xr,
+                                             const double* __restrict__ mu, const double* __restrict__ sigma,
+                                             double cst) {
 #pragma clang fp contract(off)
-  const long long row = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (row >= n) return;
-  const double* xr = x + row * D;
   const int m = (kind == 0) ? D - 1 : D;  // number of terms
   double s;
   if (m < 8) {
@@ -378,7 +448,15 @@ __global__ void nsa_log_likelihood_kernel(int kind, long long n, int D, const do
     s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
     for (; i < m; ++i) s += nsa_ll_term(kind, xr, i, mu, sigma);
   }
-  out[row] = (kind == 0) ? -s : (-0.5 * s - cst);
+  return (kind == 0) ? -s : (-0.5 * s - cst);
+}
+
+__global__ void nsa_log_likelihood_kernel(int kind, long long n, int D, const double* __restrict__ x,
+                                          const double* __restrict__ mu, const double* __restrict__ sigma,
+                                          double cst, double* __restrict__ out) {
+  const long long row = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  out[row] = nsa_ll_row(kind, D, x + row * D, mu, sigma, cst);
 }
 
 extern "C" hipError_t nsa_launch_log_likelihood(int kind, long long n, int D, const double* x, const double* mu,
@@ -410,6 +488,34 @@ __global__ void __launch_bounds__(256) nsa_truncate_kernel(long long n, double* 
   if (!keep && lq == lq) log_q[i] = __longlong_as_double(0x7ff8000000000000LL);
 }
 
+// The same two rules inside a train of passes (nsa_post_rules, include/nessai_amd.h): the likelihood of a
+// candidate that is still alive is evaluated in place (the built-in analytic likelihoods, the arithmetic of
+// nsa_log_likelihood_kernel) - no (n,) log L array, and the kernel honours the loop state of the train.
+__global__ void __launch_bounds__(256) nsa_post_rules_kernel(long long n, int D, double* __restrict__ log_q,
+                                                             double min_log_q, const double* __restrict__ x64,
+                                                             int ll_kind, const double* __restrict__ mu,
+                                                             const double* __restrict__ sigma, double cst,
+                                                             double log_l_threshold,
+                                                             const long long* __restrict__ stop) {
+  if (NSA_STOPPED(stop)) return;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double lq = log_q[i];
+  if (lq != lq) return;  // already dropped
+  bool keep = lq > min_log_q;
+  if (keep && ll_kind >= 0) keep = nsa_ll_row(ll_kind, D, x64 + i * D, mu, sigma, cst) > log_l_threshold;
+  if (!keep) log_q[i] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+extern "C" hipError_t nsa_launch_post_rules(long long n, int D, double* log_q, const nsa_post_rules* r,
+                                            const double* x64, const long long* stop, hipStream_t stream) {
+  if (n == 0 || r == nullptr) return hipSuccess;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  nsa_post_rules_kernel<<<grid, 256, 0, stream>>>(n, D, log_q, r->min_log_q, x64, r->ll_kind, r->ll_mu_dev,
+                                                  r->ll_sigma_dev, r->ll_const, r->log_l_threshold, stop);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t nsa_launch_truncate(long long n, double* log_q, double min_log_q, const double* log_l,
                                           double log_l_threshold, hipStream_t stream) {
   if (n == 0) return hipSuccess;
@@ -439,16 +545,21 @@ __global__ void __launch_bounds__(256) nsa_importance_mix_kernel(long long n, in
   const int P = n_flows + 1;
   const double lj = log_j[r];
   double* row = log_q_all + r * P;
-  double a_max = 0.0;  // column 0
+  // scipy masks the entries of a zero-weight proposal (a[b == 0] = -inf) BEFORE it takes the maximum:
+  // such a proposal takes no part in log Q, whatever its density (NaN and inf included)
+  const double ninf = -__builtin_huge_val();
+  double a_max = (weights[0] == 0.0) ? ninf : 0.0;  // column 0
   row[0] = 0.0;
   for (int j = 0; j < n_flows; ++j) {
     const double a = (double)log_prob_all[(long long)j * n + r] + lj;
     row[1 + j] = a;
-    a_max = (a > a_max || a != a) ? a : a_max;  // numpy.amax propagates NaN
+    const double am = (weights[1 + j] == 0.0) ? ninf : a;
+    a_max = (am > a_max || am != am) ? am : a_max;  // numpy.amax propagates NaN
   }
   if (!((a_max - a_max) == 0.0)) a_max = 0.0;   // scipy: a_max[~isfinite(a_max)] = 0
   double s = 0.0;
-  for (int k = 0; k < P; ++k) s += weights[k] * exp(row[k] - a_max);
+  for (int k = 0; k < P; ++k)
+    if (weights[k] != 0.0) s += weights[k] * exp(row[k] - a_max);
   log_Q[r] = log(s) + a_max;
 }
 

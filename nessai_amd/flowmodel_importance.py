@@ -30,11 +30,11 @@ class ImportanceFlowModel(FlowModel):
 
     def __init__(self, flow_config=None, training_config=None, output=None, rng=None, precision="auto"):
         """``precision``: arithmetic of the flows' conditioner GEMMs; ``"auto"`` applies the policy of
-        the populate kernel (``nessai_amd.flows.base.populate_precision``: split-bf16 inside its
+        the populate kernel (``nessai_amd.flows.base.auto_candidates``: split-f16, then split-bf16 inside its
         validated envelope, e.g. the 64-D / 128-hidden flows of config 4; exact float32 otherwise)."""
         super().__init__(flow_config=flow_config, training_config=training_config, output=output, rng=rng)
-        if precision not in ("auto", "f32", "bf16x3"):
-            raise ValueError("precision must be 'auto', 'f32' or 'bf16x3'")
+        if precision not in ("auto", "f32", "bf16x3", "f16x3"):
+            raise ValueError("precision must be 'auto', 'f32', 'bf16x3' or 'f16x3'")
         self.precision = precision
         self.weights_files = []
         self.models = torch.nn.ModuleList()

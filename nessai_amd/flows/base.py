@@ -87,19 +87,44 @@ DIR_FORWARD, DIR_INVERSE = 0, 1
 #: on the bf16 matrix cores with float32 accumulation - 2x faster; measured ``log_prob`` error
 #: 1e-6..7e-5 relative depending on the flow (within the bar for the spline flows of the
 #: benchmark configs, outside it for small or affine flows; table in DESIGN.md).
+#: ``"f16x3"``: the same three products on f16 pairs (11 + 11 significant bits: operands carried to
+#: 2^-24 relative, i.e. float32-class products at the bf16 matrix rate) for operands below 65520 in
+#: magnitude; a call that meets a larger value is detected (``status[1]``) and raises
+#: ``FloatingPointError`` - under ``"auto"`` it is repeated in exact float32 instead.
+#: ``"auto"``: the fastest mode MEASURED to agree with float32 on the current weights
+#: (``HipFlow._pack_auto``).
 #: Override per flow (``flow.precision = ...``) or with ``NESSAI_AMD_PRECISION``.
 DEFAULT_PRECISION = os.environ.get("NESSAI_AMD_PRECISION", "f32")
 
 
 def populate_precision(flow):
-    """Precision the fused populate kernel uses when the proposal asks for ``"auto"``:
-    split-bf16 inside its validated envelope - rational-quadratic flows with >= 15 features and
-    >= 30 hidden units (configs 3, 4 and 5: <= 3.3e-6 relative; a grid of randomised flows
-    with 16-32 features: <= 6.6e-6) - and exact float32 otherwise (narrower flows have a small
-    |log_prob| and reach 1.4e-5 - 2.8e-5 relative in split-bf16, outside the 1e-5 bar)."""
-    if flow.transform_kind == "rq" and flow.hidden_features >= 30 and flow.features >= 15:
-        return "bf16x3"
-    return "f32"
+    """First candidate of ``precision = "auto"`` (the probe of ``HipFlow._pack_auto`` decides):
+    split-f16 - float32-class products at the 16-bit matrix rate - for every flow."""
+    return "f16x3"
+
+
+def bf16x3_envelope(flow):
+    """Static envelope in which split-bf16 is worth probing: rational-quadratic flows with >= 15
+    features and >= 30 hidden units (configs 3, 4 and 5: <= 3.3e-6 relative; a grid of randomised
+    flows with 16-32 features: <= 6.6e-6).  Narrower flows have a small |log_prob| and reach
+    1.4e-5 - 2.8e-5 relative in split-bf16, affine flows 3.3e-5: outside the 1e-5 bar."""
+    return flow.transform_kind == "rq" and flow.hidden_features >= 30 and flow.features >= 15
+
+
+def auto_candidates(flow):
+    """Fast modes ``precision = "auto"`` probes, in the order it prefers them; exact float32 is the
+    fallback behind the last one.  Split-f16 first (as fast as split-bf16 - 1.68 against 1.74 ms per
+    1e6 rows of config 3 - and ~100x closer to float32); split-bf16, whose operands cannot leave
+    their range, behind it inside its envelope: it is what is left when a flow's activations
+    exceed the f16 range."""
+    order = os.environ.get("NESSAI_AMD_AUTO_ORDER")
+    if order:
+        return tuple(p for p in order.split(",") if p)
+    return ("f16x3", "bf16x3") if bf16x3_envelope(flow) else ("f16x3",)
+
+
+class F16RangeError(FloatingPointError):
+    """A value beyond the f16 range (65520) met a split-f16 matrix product."""
 
 
 class HipFlow(BaseFlow):
@@ -143,6 +168,8 @@ class HipFlow(BaseFlow):
         self.precision = DEFAULT_PRECISION
         self.effective_precision = self.precision if self.precision != "auto" else "f32"
         self.probe_error = None
+        self.probe_errors = {}
+        self._f16_blocked = None  # fingerprint of the weights for which a split-f16 call left the f16 range
         if self.precision not in pack.PRECISIONS and self.precision != "auto":
             raise ValueError(f"unknown precision {self.precision!r}; choose from {sorted(pack.PRECISIONS)} or 'auto'")
         desc = M.describe(self)
@@ -160,6 +187,19 @@ class HipFlow(BaseFlow):
         # depths, ...) is known to the packer: pack once now so that an unsupported configuration raises
         # at construction like the checks above, not at the first call
         pack.pack_flow(dict(desc, precision=self.precision if self.precision != "auto" else "f32"))
+
+    def apply(self, fn):
+        """``torch.nn.Module.apply``, with the reference's two reset visitors
+        (``nessai.flows.utils.reset_weights`` / ``reset_permutations``, which ``FlowModel.reset_model``
+        applies: ``flowmodel/base.py:748-772``) replaced by their counterparts here: the reference's
+        test ``isinstance(module, glasflow...BatchNorm / LULinear / RandomPermutation)``, which the module
+        tree of this class - same names, same parameters, other classes - cannot satisfy."""
+        module, name = getattr(fn, "__module__", None) or "", getattr(fn, "__name__", "")
+        if module.startswith("nessai.") and name in ("reset_weights", "reset_permutations"):
+            from . import utils as own
+
+            fn = getattr(own, name)
+        return super().apply(fn)
 
     # -- device image ----------------------------------------------------------
 
@@ -212,48 +252,100 @@ class HipFlow(BaseFlow):
     AUTO_PROBE_ROWS = 4096
     AUTO_PROBE_BAR = 5e-6
 
+    #: split-f16 is accepted up to this multiple of float32's OWN response to a 1-ulp change of the
+    #: probe inputs (see ``_pack_auto``)
+    AUTO_NOISE_FACTOR = 4.0
+
     def _pack_auto(self, desc, device):
-        """Packed image for ``precision = "auto"``: split-bf16 where it is MEASURED to agree with the
+        """Packed image for ``precision = "auto"``: the first fast mode (``auto_candidates``:
+        split-f16, then split-bf16 inside its static envelope) that is MEASURED to agree with the
         exact-float32 kernels on this flow's current weights, float32 otherwise.
 
-        The static envelope (``populate_precision``) only says where split-bf16 is worth trying: its
-        error grows with the conditioning of the flow - random flows inside the envelope reach 6e-5
-        relative at initialisation scale and 1e-3 with weights three times larger
-        (``scripts/fuzz_bf16x3.py``) - so every time the weights change, a probe of
-        ``AUTO_PROBE_ROWS`` latent rows goes through both kernels in both directions (inverse:
-        ``log q`` of the populate path; forward: ``log_prob``) and split-bf16 is kept only if they
-        agree to ``AUTO_PROBE_BAR`` relative.  Costs one extra pack and four small launches per
-        change of the weights."""
-        if populate_precision(self) != "bf16x3" or self.training:
-            self.effective_precision, self.probe_error = "f32", None
+        Every time the weights change, a probe of ``AUTO_PROBE_ROWS`` latent rows goes through the
+        kernels in both directions (inverse: ``log q`` of the populate path; forward:
+        ``log_prob``) and a fast mode is kept only if it agrees with float32 to ``AUTO_PROBE_BAR``
+        relative.  Split-bf16 needs that test because its ~2^-16 per product is amplified by the
+        flow's conditioning: random flows inside its envelope reach 6e-5 relative at initialisation
+        scale and 1e-2 with weights three times larger (``scripts/fuzz_precision.py``).  Split-f16
+        products are float32-class by construction (2^-24 relative per operand), so on an
+        ill-conditioned flow it differs from the float32 kernel as any two float32 evaluations
+        differ (the same sweep: 2e-3 against 7e-3 for the float32 kernel itself, both measured
+        against the CPU oracle); it is therefore also accepted within ``AUTO_NOISE_FACTOR`` times
+        the float32 kernel's own response to moving every probe input by one ulp - and never when
+        the probe left the f16 range.  Costs one extra pack and four small launches per candidate
+        and change of the weights."""
+        if self.training:
+            self.effective_precision, self.probe_error, self.probe_errors = "f32", None, {}
             return pack.pack_flow(dict(desc, precision="f32"))
-        images = {p: pack.pack_flow(dict(desc, precision=p)) for p in ("f32", "bf16x3")}
+        fingerprint = self._fingerprint()
+        images = {"f32": pack.pack_flow(dict(desc, precision="f32"))}
         n, d = self.AUTO_PROBE_ROWS, self.features
+        self.probe_errors = {}
+        chosen = "f32"
         with torch.inference_mode(False), torch.no_grad():
             z = torch.randn(n, d, generator=torch.Generator().manual_seed(20260930)).to(device)
             status = torch.zeros(4, dtype=torch.int32, device=device)
-            out = {}
-            for p, image in images.items():
+            log_pz = -0.5 * (z.double() ** 2).sum(dim=1) - 0.5 * d * math.log(2.0 * math.pi)
+
+            def run(image, z_in, x_fwd=None):
                 header = (lib.ctypes.c_uint32 * pack.HEADER_WORDS)(*image[: pack.HEADER_WORDS].tolist())
                 header_t = ops.header_tensor(header)
                 image_dev = torch.from_numpy(image.view(np.int32)).to(device)
-                x, ld = torch.ops.nessai_amd.flow_run(z, image_dev, header_t, DIR_INVERSE, MODE_APPLY, True, status,
+                x, ld = torch.ops.nessai_amd.flow_run(z_in, image_dev, header_t, DIR_INVERSE, MODE_APPLY, True, status,
                                                       self.waves_per_group, self.max_groups)
-                out[p] = (x, ld, image_dev, header_t)
-            x32, ld32 = out["f32"][0], out["f32"][1].double()
-            log_pz = -0.5 * (z.double() ** 2).sum(dim=1) - 0.5 * d * math.log(2.0 * math.pi)
-            log_q32 = log_pz - ld32
-            err = ((out["bf16x3"][1].double() - ld32).abs() / log_q32.abs().clamp_min(1e-3)).max()
-            lp = {}
-            for p in images:
-                _, lp[p] = torch.ops.nessai_amd.flow_run(x32, out[p][2], out[p][3], DIR_FORWARD, MODE_LOGPROB, False,
-                                                         status, self.waves_per_group, self.max_groups)
-            lp32 = lp["f32"].double()
-            err = torch.maximum(err, ((lp["bf16x3"].double() - lp32).abs() / lp32.abs().clamp_min(1e-3)).max())
-            err = float(err)
-        ok = math.isfinite(err) and err <= self.AUTO_PROBE_BAR
-        self.effective_precision, self.probe_error = ("bf16x3" if ok else "f32"), err
-        return images[self.effective_precision]
+                over = int(status[1].item())
+                _, lp = torch.ops.nessai_amd.flow_run(x if x_fwd is None else x_fwd, image_dev, header_t, DIR_FORWARD,
+                                                      MODE_LOGPROB, False, status, self.waves_per_group,
+                                                      self.max_groups)
+                over += int(status[1].item())
+                return x, ld.double(), lp.double(), over
+
+            def rel(a, b, scale):
+                return float(((a - b).abs() / scale.abs().clamp_min(1e-3)).max())
+
+            ref = noise = None
+            for p in auto_candidates(self):
+                if p == "f16x3" and self._f16_blocked == fingerprint:
+                    continue
+                try:
+                    images[p] = pack.pack_flow(dict(desc, precision=p))
+                except ValueError:  # a weight beyond the f16 range
+                    continue
+                if ref is None:
+                    ref = run(images["f32"], z)
+                x32, ld32, lp32, _ = ref
+                _, ld, lp, over = run(images[p], z, x_fwd=x32)
+                log_q32 = log_pz - ld32
+                err = max(rel(ld, ld32, log_q32), rel(lp, lp32, lp32))
+                self.probe_errors[p] = err
+                bar = self.AUTO_PROBE_BAR
+                if p == "f16x3" and over == 0 and math.isfinite(err) and err > bar:
+                    if noise is None:  # the float32 kernel against itself, inputs one ulp further out
+                        inf = torch.full_like(z, math.inf)
+                        _, ld_n, lp_n, _ = run(images["f32"], torch.nextafter(z, inf * z.sign()),
+                                               x_fwd=torch.nextafter(x32, inf * x32.sign()))
+                        noise = max(rel(ld_n, ld32, log_q32), rel(lp_n, lp32, lp32))
+                        self.probe_errors["f32_one_ulp"] = noise
+                    if math.isfinite(noise):
+                        bar = max(bar, self.AUTO_NOISE_FACTOR * noise)
+                if over == 0 and math.isfinite(err) and err <= bar:
+                    chosen = p
+                    break
+        self.effective_precision = chosen
+        errs = [v for k, v in self.probe_errors.items() if k in pack.PRECISIONS]
+        self.probe_error = self.probe_errors.get(chosen, max(errs, default=None))
+        return images[chosen]
+
+    def note_f16_overflow(self):
+        """A split-f16 call on the current weights left the f16 range: ``"auto"`` stops choosing the mode
+        until the weights change; a flow pinned to ``"f16x3"`` raises."""
+        if self.precision != "auto":
+            raise F16RangeError(
+                "a value beyond the f16 range (65520) met a matrix product of the 'f16x3' kernels; "
+                "use precision 'auto' (falls back by itself), 'bf16x3' or 'f32' for this flow"
+            )
+        self._f16_blocked = self._fingerprint()
+        self._image_key = None
 
     # -- kernel calls ----------------------------------------------------------
 
@@ -299,11 +391,17 @@ class HipFlow(BaseFlow):
                 "call .eval() before inverting or sampling the flow"
             )
         x = self._check_input(x)
-        header, image = self.device_image()
-        out, ld = torch.ops.nessai_amd.flow_run(
-            x, image, self._header_t, direction, mode, want_x, self._status, self.waves_per_group,
-            self.max_groups,
-        )
+        for _ in range(2):
+            header, image = self.device_image()
+            out, ld = torch.ops.nessai_amd.flow_run(
+                x, image, self._header_t, direction, mode, want_x, self._status, self.waves_per_group,
+                self.max_groups,
+            )
+            # split-f16 products hold for operands inside the f16 range only: the kernel says when a call
+            # left it (one 16-byte read-back; the callers of this API read the results back anyway)
+            if self.effective_precision != "f16x3" or x.shape[0] == 0 or int(self._status[1].item()) == 0:
+                break
+            self.note_f16_overflow()  # raises unless "auto": then the repeat runs in float32
         return (out if want_x else None), ld, self._status
 
     def _run_differentiable(self, x, mode, want_x):
@@ -312,8 +410,10 @@ class HipFlow(BaseFlow):
             raise RuntimeError("nessai_amd flows take tensors on a ROCm device; there is no CPU fallback")
         if x.dim() != 2 or x.shape[1] != self.features:
             raise ValueError("Expected inputs of shape (N, {}), got {}".format(self.features, tuple(x.shape)))
-        if x.shape[0] == 0:
-            raise ValueError("cannot differentiate through an empty batch")
+        if x.shape[0] == 0:  # nothing to differentiate: empty outputs, as the inference path returns
+            empty = torch.empty(0, dtype=torch.float32, device=x.device)
+            z = torch.empty((0, self.features), dtype=torch.float32, device=x.device) if want_x else None
+            return z, empty, self._status
         xin = x.to(torch.float32).contiguous()
         log_prob = mode == MODE_LOGPROB
         z, ld, lp = ops.differentiable_flow(self, xin, want_x, not log_prob, log_prob)
@@ -406,12 +506,24 @@ def _has_batch_norm(flow):
 
 
 def _has_norm_layers(flow):
-    """Batch norm or a not-yet-initialised act norm: layers whose training-mode pass differs."""
+    """Batch norm or a not-yet-initialised act norm: layers whose training-mode pass differs.  The
+    act-norm flags live on the device; they are read once per (buffer, version) - not per call, which
+    would be a device synchronisation on the inference path of every act-norm flow."""
     cached = flow.__dict__.get("_norm_layers")
     if cached is None:
         cached = [m for m in flow.modules() if isinstance(m, (M.BatchNorm, M.ActNorm))]
         flow.__dict__["_norm_layers"] = cached
-    return any(isinstance(m, M.BatchNorm) or not bool(m.initialized) for m in cached)
+    for m in cached:
+        if isinstance(m, M.BatchNorm):
+            return True
+        key = (m.initialized.data_ptr(), m.initialized._version)
+        known = m.__dict__.get("_initialized_host")
+        if known is None or known[0] != key:
+            known = (key, bool(m.initialized))
+            m.__dict__["_initialized_host"] = known
+        if not known[1]:
+            return True
+    return False
 
 
 def lib_supports(ht, transform, bins):
@@ -460,4 +572,9 @@ def log_prob_many(flows, x):
         lib.ptr(status), first.waves_per_group, first.max_groups, lib.c_void_p(stream),
     )
     lib.check(rc, "nsa_flow_run_many")
+    if first.effective_precision == "f16x3" and int(status[1].item()) != 0:
+        # the batch left the f16 range under (at least) one of the flows: all of them again, each on its own
+        # (HipFlow._run repeats a flow whose split-f16 launch reports the overflow in float32)
+        for i, f in enumerate(flows):
+            out[i] = f.log_prob(x)
     return out

@@ -224,6 +224,15 @@ class BatchNorm(_Container):
         self.register_buffer("running_mean", torch.zeros(features))
         self.register_buffer("running_var", torch.ones(features))
 
+    def reset_parameters(self):
+        """Initial values (the constants ``nessai.flows.utils.reset_weights`` writes for nflows' BatchNorm,
+        ``flows/utils.py:265-272``)."""
+        with torch.no_grad():
+            self.unconstrained_weight.fill_(math.log(math.exp(1 - self.eps) - 1))
+            self.bias.zero_()
+            self.running_mean.zero_()
+            self.running_var.fill_(1)
+
     def host_tables(self):
         """Per-feature ``((x - a) / b) * c + d`` tables for both directions."""
         with torch.no_grad():

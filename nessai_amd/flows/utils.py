@@ -121,14 +121,11 @@ def configure_model(config):
 
 
 def reset_weights(module):
-    """Re-initialise a module in place (``flows/utils.py:249-274``)."""
-    if isinstance(module, M.BatchNorm):
-        constant = math.log(math.exp(1 - module.eps) - 1)
-        module.unconstrained_weight.data.fill_(constant)
-        module.bias.data.zero_()
-        module.running_mean.zero_()
-        module.running_var.fill_(1)
-    elif hasattr(module, "reset_parameters"):
+    """Re-initialise a module in place (``flows/utils.py:249-274``): whatever has a
+    ``reset_parameters`` (the Linear layers; batch norm, whose constants the reference writes by
+    hand).  As in the reference, LU-linear layers and act norm have none - they are re-initialised by
+    ``reset_permutations`` / never."""
+    if hasattr(module, "reset_parameters"):
         module.reset_parameters()
 
 

@@ -22,6 +22,15 @@ c_double = ctypes.c_double
 c_size_t = ctypes.c_size_t
 c_float = ctypes.c_float
 
+
+
+class PostRules(ctypes.Structure):
+    """``nsa_post_rules`` (include/nessai_amd.h): the truncation rules that act after the flow."""
+
+    _fields_ = [("min_log_q", c_double), ("ll_kind", c_int), ("ll_mu_dev", c_void_p), ("ll_sigma_dev", c_void_p),
+                ("ll_const", c_double), ("log_l_threshold", c_double)]
+
+
 SIGNATURES = {
     "nsa_version": (c_int, []),
     "nsa_last_error": (ctypes.c_char_p, []),
@@ -47,7 +56,8 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_ll, c_int, c_ull, c_ull, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
          c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p,
-         c_void_p, c_ll, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_int, c_int, c_void_p],
+         c_void_p, c_ll, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_int, c_int, c_void_p,
+         ctypes.POINTER(PostRules)],
     ),
     "nsa_populate_pass_head": (
         c_int,
@@ -61,6 +71,19 @@ SIGNATURES = {
          c_void_p],
     ),
     "nsa_populate_pass_commit": (c_int, [c_void_p, c_ll, c_void_p, c_void_p, c_void_p]),
+    "nsa_populate_train_heads": (
+        c_int,
+        [c_void_p, c_void_p, c_ll, c_int, c_ull, c_ull, c_ull, c_double, c_double, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(PostRules)],
+    ),
+    "nsa_populate_train_tails": (
+        c_int,
+        [c_ll, c_int, c_int, c_void_p, c_void_p, c_ull, c_ull, c_ull, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "nsa_populate_train_commit": (c_int, [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsa_populate_sumexp": (c_int, [c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsa_importance_draw": (
         c_int,
         [c_void_p, c_void_p, c_ll, c_void_p, c_ull, c_ull, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

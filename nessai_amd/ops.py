@@ -22,6 +22,8 @@ only, plus ``Meta`` shape functions.
 
 import weakref
 
+import os
+
 import numpy as np
 import torch
 
@@ -90,6 +92,9 @@ def _flow_forward(x, flat, plan, training, want_z, want_logdet, want_log_prob):
     if flat.data_ptr() != trainer.flat.data_ptr():
         raise RuntimeError("nessai_amd::flow_forward: `flat` is not the plan's parameter buffer")
     z, ld, lp, ws = trainer.forward_saved(x, training, want_z, want_logdet, want_log_prob)
+    if training and (trainer._stats or trainer._actnorms):
+        # batch norm / act norm: the kernels just rewrote running statistics (or initialised act norm)
+        trainer.stats_version = getattr(trainer, "stats_version", 0) + 1
     none = _empty(x, 0)
     return (z if z is not None else none, ld if ld is not None else none, lp if lp is not None else none, ws)
 
@@ -152,6 +157,12 @@ class FlowFunction(torch.autograd.Function):
         )
         ctx.trainer = trainer
         ctx.workspace = ws
+        # what the backward kernels will read besides the workspace: the live flat parameter buffer (the
+        # Parameters are views of it) and the kernel family.  Nothing goes through save_for_backward, so
+        # torch's own version check does not see an optimiser step or a second training-mode forward between
+        # this call and its backward: the node checks by itself.
+        ctx.flat_version = _state_version(trainer)  # AFTER the forward (it may rewrite statistics itself)
+        ctx.fused = os.environ.get("NESSAI_AMD_TRAIN_FUSED")
         ctx.n = x.shape[0]
         ctx.training = bool(training)
         ctx.want = (want_z, want_logdet, want_log_prob)
@@ -162,7 +173,18 @@ class FlowFunction(torch.autograd.Function):
     def backward(ctx, g_z, g_ld, g_lp):
         trainer = ctx.trainer
         if ctx.workspace is None:
-            raise RuntimeError("nessai_amd: backward through a flow evaluation whose workspace was released")
+            raise RuntimeError(
+                "nessai_amd: backward through a flow evaluation whose activations were already consumed "
+                "(retain_graph=True / a second backward is not supported: run the forward pass again)"
+            )
+        if _state_version(trainer) != ctx.flat_version:
+            raise RuntimeError(
+                "nessai_amd: a parameter or running statistic of the flow was modified in place between the "
+                "forward pass and its backward (an optimiser step or another training-mode forward); the "
+                "gradients would be computed against the new values"
+            )
+        if os.environ.get("NESSAI_AMD_TRAIN_FUSED") != ctx.fused:
+            raise RuntimeError("nessai_amd: NESSAI_AMD_TRAIN_FUSED changed between the forward pass and its backward")
         want_z, want_ld, want_lp = ctx.want
 
         def grad(g, wanted):
@@ -179,6 +201,17 @@ class FlowFunction(torch.autograd.Function):
             for (off, numel, shape), need in zip(trainer.param_slices, ctx.needs_input_grad[6:])
         ]
         return (gx if want_gx else None, None, None, None, None, None, *per_param)
+
+
+def _state_version(trainer):
+    """Changes when a parameter / buffer of the flow is written in place through torch (the Parameters are
+    views of ``trainer.flat`` with version counters of their own) or when a training-mode forward of a flow
+    with batch norm / act norm rewrote its statistics inside the kernels (``stats_version``)."""
+    flow = trainer.flow
+    tensors = flow.__dict__.get("_fp_tensors")
+    if tensors is None:
+        tensors = list(flow.parameters()) + list(flow.buffers())
+    return (getattr(trainer, "stats_version", 0), tuple(t._version for t in tensors))
 
 
 def differentiable_flow(flow, x, want_z, want_logdet, want_log_prob):

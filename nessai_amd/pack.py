@@ -31,7 +31,7 @@ import math
 import numpy as np
 
 MAGIC = 0x3141534E
-VERSION = 5
+VERSION = 6
 HEADER_WORDS = 32
 OP_WORDS = 4
 
@@ -47,7 +47,11 @@ TRANSFORMS = {"rq": T_RQ, "affine": T_AFFINE, "additive": T_ADDITIVE}
 ACTIVATIONS = {"relu": 0, "tanh": 1, "silu": 2, "swish": 2}
 NETS = {"resnet": 0, "mlp": 1}
 OP_COUPLING, OP_DENSE, OP_ELEMENTWISE = 1, 2, 3
-PRECISIONS = {"f32": 0, "bf16x3": 1}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x3": 2}
+#: precisions whose operands are pairs of 16-bit values (k in steps of 16, W stored as hi / lo parts)
+SPLIT16 = ("bf16x3", "f16x3")
+#: |values| from here on round to infinity in f16 (``NSA_F16_LIMIT``)
+F16_LIMIT = 65520.0
 
 
 def _f32_bits(value):
@@ -164,11 +168,27 @@ def split_bf16(x):
     return hi, lo
 
 
-def pack_matrix_bf16(weight, out_rows, in_cols):
-    """A operand of v_mfma_f32_32x32x16_bf16, split in hi/lo parts.
+def split_f16(x):
+    """x ~= hi + lo with hi = f16(x), lo = f16(x - hi) (round to nearest even, subnormals kept);
+    returns the two bit arrays.  ``x - hi`` is exact in float32, so the pair carries x to 2^-24
+    relative down to |x| = 2^-3 and to 2^-25 absolute below."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if x.size and not np.all(np.abs(x) < F16_LIMIT):
+        raise ValueError("precision 'f16x3' needs every weight below 65520 in magnitude")
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    return hi.view(np.uint16), lo.view(np.uint16)
+
+
+def f16_to_f32(bits):
+    return bits.view(np.float16).astype(np.float32)
+
+
+def pack_matrix_bf16(weight, out_rows, in_cols, split=split_bf16):
+    """A operand of v_mfma_f32_32x32x16_bf16 (or _f16: ``split=split_f16``), split in hi/lo parts.
 
     ``in_cols[s][half][e]`` original input column of k-step ``s`` (or -1).
-    Returns uint32 words of the layout ``[OT][S][part][64 lanes][8 bf16]``.
+    Returns uint32 words of the layout ``[OT][S][part][64 lanes][8 x 16 bit]``.
     """
     n_ot, n_steps = len(out_rows), len(in_cols)
     w = np.zeros((n_ot, n_steps, 64, 8), dtype=np.float32)
@@ -181,9 +201,16 @@ def pack_matrix_bf16(weight, out_rows, in_cols):
             valid = (r[:, None, None] >= 0) & (c[None, :, :] >= 0)
             block = np.where(valid, weight[np.maximum(r, 0)[:, None, None], np.maximum(c, 0)[None, :, :]], 0.0)
             w[ot, :, 32 * half : 32 * half + 32, :] = block.transpose(1, 0, 2)  # [S][32][8]
-    hi, lo = split_bf16(w)
+    hi, lo = split(w)
     parts = np.stack([hi, lo], axis=2)  # [OT][S][2][64][8] uint16
     return np.ascontiguousarray(parts).reshape(-1).view(np.uint32)
+
+
+def _pack_matrix16(precision):
+    """Packer of the 16-bit A operands of ``precision``."""
+    if precision == "f16x3":
+        return lambda w, out_rows, in_cols: pack_matrix_bf16(w, out_rows, in_cols, split=split_f16)
+    return pack_matrix_bf16
 
 
 def _reg_in_cols16(n_tiles, limit):
@@ -255,13 +282,13 @@ class _CouplingBlobs:
         hidden = desc["hidden"]
         ht = hidden_tiles(hidden)
         n_tiles_c, fpc, n_params = transform_policy(desc["transform"], desc.get("bins", 0))
-        bf16 = desc.get("precision", "f32") == "bf16x3"
+        bf16 = desc.get("precision", "f32") in SPLIT16  # k in steps of 16, weights as 16-bit pairs
         self.bf16 = bf16
         self.n_steps0 = (self.d_id + 15) // 16 if bf16 else pad4((self.d_id + 1) // 2)
         self.n_chunks = (self.d_tr + 2 * fpc - 1) // (2 * fpc)
         self.fpc = fpc
         if bf16:
-            pack_w = pack_matrix_bf16
+            pack_w = _pack_matrix16(desc["precision"])
             reg_cols = _reg_in_cols16(ht, hidden)
         else:
             pack_w = pack_matrix
@@ -351,7 +378,7 @@ def pack_flow(desc):
     precision = desc.get("precision", "f32")
     if precision not in PRECISIONS:
         raise ValueError(f"unknown precision {precision!r}; choose from {sorted(PRECISIONS)}")
-    bf16 = precision == "bf16x3"
+    bf16 = precision in SPLIT16
 
     blobs = []  # list of uint32 arrays
     blob_offsets = []
@@ -403,7 +430,7 @@ def pack_flow(desc):
                     post = np.asarray(bias, dtype=np.float32)
                     ld = np.float32(logabsdet)
                 out_rows = _plain_out_rows(n_ot, D)
-                pack_w = pack_matrix_bf16 if bf16 else pack_matrix
+                pack_w = _pack_matrix16(precision) if bf16 else pack_matrix
                 blob = _stage(in_tab, pre, pack_bias(post, out_rows), pack_w(mat, out_rows, in_cols))
                 stages.append(add_blob(blob))
                 ops.append([OP_DENSE, n_steps, n_ot, _f32_bits(ld)])

@@ -75,11 +75,13 @@ class FlowProposal:
         Keep the loop control of ``populate`` on the device (``nsa_populate_passes``): several
         passes are enqueued per host synchronisation and surplus ones switch themselves off.
         Results are identical to ``False`` (one pass per synchronisation).
-    precision : {'auto', 'f32', 'bf16x3'}
+    precision : {'auto', 'f32', 'bf16x3', 'f16x3'}
         Arithmetic of the conditioner GEMMs inside the fused draw kernel.
-        ``'auto'`` uses split-bf16 on the bf16 matrix cores where it is validated
-        to stay within the 1e-5 relative parity bar (see
-        ``nessai_amd.flows.base.populate_precision``) and exact float32 elsewhere.
+        ``'auto'`` uses the fastest 16-bit matrix-core mode (split-bf16, then split-f16) that is
+        MEASURED to agree with exact float32 on the flow's current weights to half the 1e-5
+        relative parity bar (``nessai_amd.flows.base.HipFlow._pack_auto``) and exact float32
+        otherwise; a split-f16 population that meets a value beyond the f16 range is detected and
+        drawn again in float32.
     """
 
     _FlowModelClass = FlowModel
@@ -163,8 +165,12 @@ class FlowProposal:
             raise ValueError("likelihood must be 'auto', 'device' or 'host'")
         self._likelihood_mode = likelihood
         self.shard = shard
-        if precision not in ("auto", "f32", "bf16x3"):
-            raise ValueError("precision must be 'auto', 'f32' or 'bf16x3'")
+        self._status_hold = False
+        #: which loop the last ``populate`` ran: "trains" (device-side loop control), "trains_sharded",
+        #: "accumulate" (device arena), "accumulate_host" or "passes" (one synchronisation per pass)
+        self.last_populate_path = None
+        if precision not in ("auto", "f32", "bf16x3", "f16x3"):
+            raise ValueError("precision must be 'auto', 'f32', 'bf16x3' or 'f16x3'")
         self.precision = precision
         self.pass_trains = bool(pass_trains)
         self.reparameterisations = reparameterisations
@@ -454,6 +460,9 @@ class FlowProposal:
         x64 = torch.empty((n, self.dims), dtype=torch.float64, device=dev)
         log_q = torch.empty(n, dtype=torch.float64, device=dev)
         self._launch_draw(n, z_dev, 0, np.inf, x64, log_q, None)
+        if n and self._f16_range_left():  # split-f16 met a value beyond its range: again in float32
+            self.flow.model.note_f16_overflow()
+            self._launch_draw(n, z_dev, 0, np.inf, x64, log_q, None)
         log_q_h = log_q.cpu().numpy()
         keep = ~np.isnan(log_q_h)  # NaN marks a dropped row; +inf (saturated logit) is kept as in the reference
         x = array_to_live_points_fast(x64.cpu().numpy()[keep], self.names)
@@ -492,7 +501,8 @@ class FlowProposal:
 
     def _launch_draw(self, n, z_in, row_offset, radius, x64, log_q, z_out, log_prior=None, prepared=None):
         flow, header, image, status = prepared if prepared is not None else self._prepare_flow()
-        status.zero_()
+        if not self._status_hold:  # inside populate() the flags accumulate over the passes
+            status.zero_()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = lib.load().nsa_populate_draw(
             header, lib.ptr(image), n, lib.ptr(z_in), self.device_seed, int(row_offset),
@@ -621,6 +631,34 @@ class FlowProposal:
         )
         lib.check(rc, "nsa_populate_truncate")
 
+    def _device_rules(self):
+        """``nsa_post_rules`` of the current population (``None``: no rule acts after the flow): the
+        ``min_log_q`` / likelihood-threshold numbers ``truncation.prepare`` computed, with the model's
+        built-in device likelihood."""
+        min_log_q, log_l_threshold = self._post_limits
+        if not (min_log_q > -math.inf or log_l_threshold is not None):
+            return None
+        rules = lib.PostRules(float(min_log_q), -1, None, None, 0.0, 0.0)
+        if log_l_threshold is not None:
+            kind, mu, sigma, const = self._ll_spec
+            rules.ll_kind = int(kind)
+            rules.ll_mu_dev = mu.data_ptr() if mu is not None else None
+            rules.ll_sigma_dev = sigma.data_ptr() if sigma is not None else None
+            rules.ll_const = float(const)
+            rules.log_l_threshold = float(log_l_threshold)
+        return rules
+
+    def _f16_range_left(self):
+        """True when the draw kernel ran in split-f16 and reported a value beyond the f16 range
+        (``status[1]``; agreed over the ranks of a sharded proposal).  One 16-byte read-back."""
+        flow = self.flow.model
+        if flow.effective_precision != "f16x3" or flow._status is None:
+            return False
+        flag = flow._status[1:2].clone()
+        if self.shard and torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        return int(flag.item()) != 0
+
     def populate(self, worst_point=None, n_samples=10000, plot=False, r=None,
                  max_samples=1_000_000, injected=None):
         """Fill the pool with ``n_samples`` accepted draws (``flowproposal.py:391-534``).
@@ -628,7 +666,27 @@ class FlowProposal:
         ``injected`` (parity tests) is an iterator of ``(z, u)`` host arrays used
         in place of the on-device draws, the analogue of the reference test's
         mocked ``rng.random`` / latent draws.
-        """
+
+        The draw kernel's split-f16 mode is exact-float32 class only while every operand of its
+        matrix products stays inside the f16 range; a population that left it (reported by the
+        kernel, checked once per call) is discarded and drawn again with the mode switched off for
+        the current weights (``precision="auto"``) or raises (``precision="f16x3"``)."""
+        if self.initialised and self.flow.model._status is not None:
+            self.flow.model._status.zero_()
+        self._status_hold = True
+        try:
+            self._populate(worst_point, n_samples, plot, r, max_samples, injected)
+            if self._f16_range_left():
+                self.flow.model.note_f16_overflow()  # raises F16RangeError unless "auto"
+                if injected is not None:
+                    raise RuntimeError("injected latents left the f16 range of the split-f16 kernels")
+                logger.warning("split-f16 draw kernel left the f16 range: population redrawn in float32")
+                self.flow.model._status.zero_()
+                self._populate(worst_point, n_samples, plot, r, max_samples, injected)
+        finally:
+            self._status_hold = False
+
+    def _populate(self, worst_point, n_samples, plot, r, max_samples, injected):
         st = datetime.datetime.now()
         if not self.initialised:
             raise RuntimeError(
@@ -640,7 +698,6 @@ class FlowProposal:
         threshold, min_log_q, log_l_threshold = self.truncation.device_limits()
         latent = self._latent_rule()
         self.r = latent.radius if latent is not None else np.nan
-        post_rules = min_log_q > -math.inf or log_l_threshold is not None
         self._post_limits = (min_log_q, log_l_threshold)
         self.indices = []
         n_samples = int(n_samples)
@@ -657,14 +714,23 @@ class FlowProposal:
         n_proposed = 0
         n_accepted = 0
         rows = []  # accepted blocks (host, float64)
+        # the rules that act after the flow stay on the device-side loop unless the likelihood rule needs
+        # the user's host likelihood (no built-in device likelihood declared by the model)
+        host_rule = log_l_threshold is not None and self._ll_spec is None
         if self.accumulate_weights:
-            return self._populate_accumulate(st, threshold, n_samples, max_samples, injected)
+            if injected is None and self.prior_mode == "device" and not host_rule:
+                return self._populate_accumulate(st, threshold, n_samples, max_samples, n_local, world, rank)
+            if sharded:
+                raise RuntimeError("a sharded accumulate_weights population needs the device prior "
+                                   "(and, for a likelihood rule, the model's device likelihood)")
+            return self._populate_accumulate_host(st, threshold, n_samples, max_samples, injected)
 
-        if injected is None and self.prior_mode == "device" and self.pass_trains and not post_rules:
+        if injected is None and self.prior_mode == "device" and self.pass_trains and not host_rule:
             if sharded:
                 return self._populate_trains_sharded(st, threshold, n_samples, max_samples, n_local, world, rank)
             return self._populate_trains(st, threshold, n_samples, max_samples)
 
+        self.last_populate_path = "passes"
         prepared = self._prepare_flow()
         while n_accepted < n_samples:
             z_in = u_in = None
@@ -717,6 +783,7 @@ class FlowProposal:
         of the one-pass-at-a-time loop.  The train length follows the acceptance seen so far."""
         L = lib.load()
         n = self.drawsize
+        self.last_populate_path = "trains"
         flow, header, image, status = self._prepare_flow()
         buf = self._get_buffers(n, n_samples)
         dev = self.device
@@ -730,7 +797,6 @@ class FlowProposal:
         state_h[2] = n_samples
         state_h[5] = max_samples // n + 1  # first pass count with n_proposed > max_samples
         buf["state"].copy_(state_h, non_blocking=True)
-        status.zero_()
         key_init = int(L.nsa_max_key_init())
         separable = self._prior_kind_dev is not None
         log_prior_const = 0.0 if separable else self._uniform_log_prior_constant()
@@ -738,6 +804,7 @@ class FlowProposal:
         # expected accepted rows per pass: last populate call's acceptance, else unknown (probe 1 pass)
         per_pass = (self.population_acceptance or 0.0) * n
         n_accepted = passes = 0
+        rules = self._device_rules()
         while True:
             remaining = n_samples - n_accepted
             train = 1 if per_pass <= 0 else int(np.ceil(1.15 * remaining / per_pass))
@@ -753,7 +820,7 @@ class FlowProposal:
                 lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), lib.ptr(buf["log_w"]),
                 lib.ptr(buf["max_keys"]), n_samples, lib.ptr(buf["x_acc"]), lib.ptr(buf["state"]),
                 lib.ptr(buf["workspace"]), buf["ws_bytes"], lib.ptr(status), flow.waves_per_group,
-                flow.max_groups, stream,
+                flow.max_groups, stream, rules,
             )
             lib.check(rc, "nsa_populate_passes")
             state_h.copy_(buf["state"])  # the train's one synchronisation
@@ -773,85 +840,91 @@ class FlowProposal:
         self.x = array_to_live_points_fast(kept.cpu().numpy(), self.names)
         self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
 
+    #: bytes of candidate rows a sharded train may keep on the device (its passes are independent until
+    #: the stop test, so their rows wait for ONE exchange of the maxima and ONE of the counts)
+    TRAIN_ARENA_BYTES = 4 << 30
+
     @torch.inference_mode(False)
     def _populate_trains_sharded(self, st, threshold, n_samples, max_samples, n, world, rank):
-        """``_populate_trains`` for a draw batch sharded over ranks: per pass
-        ``head -> all-reduce(max) -> tail -> all-reduce(sum of the pass counts) -> commit``, all
-        stream ordered; the stop test is on the GLOBAL accepted count, rows are appended locally and
-        interleaved (pass, rank, draw order) once at the end - the order of the per-pass gather."""
+        """``_populate_trains`` for a draw batch sharded over ranks.  A pass needs two exchanges - the
+        batch-global maximum of the weights before the accept step (``flowproposal.py:492``) and the
+        global accepted count for the stop test - and at n = drawsize / world rows a pass is shorter
+        than two collectives.  The passes of a train are independent until the stop test, so a train is
+        ``K heads -> ONE all-reduce(max) of K maxima -> K tails -> ONE all-reduce(sum) of K counts ->
+        commit`` (``nsa_populate_train_*``), all stream ordered: the commit replays the passes in order
+        against the loop state, rows that surplus passes appended are never read.  Rows are appended
+        locally and interleaved (pass, rank, draw order) once at the end - the order of a per-pass
+        gather.  The train length is the number of passes the acceptance seen so far predicts,
+        rounded down: a short train costs one more round of collectives, a long one whole draw
+        kernels."""
         import torch.distributed as dist
 
         L = lib.load()
+        self.last_populate_path = "trains_sharded"
         flow, header, image, status = self._prepare_flow()
         buf = self._get_buffers(n, n_samples)
         dev = self.device
-        max_train = 64
+        max_train = int(max(1, min(64, self.TRAIN_ARENA_BYTES // (8 * n * (self.dims + 1)))))
         if buf.get("state") is None:
             buf["state"] = torch.zeros(8, dtype=torch.int64, device=dev)
-            buf["max_keys"] = torch.empty(max_train, dtype=torch.int64, device=dev)
+            buf["max_keys"] = torch.empty(64, dtype=torch.int64, device=dev)
             buf["state_host"] = torch.zeros(8, dtype=torch.int64).pin_memory()
         if buf.get("gcount") is None:
-            buf["gcount"] = torch.zeros(1, dtype=torch.int64, device=dev)
+            buf["gcount"] = torch.zeros(64, dtype=torch.int64, device=dev)
+            buf["lcount"] = torch.zeros(64, dtype=torch.int64, device=dev)
+            buf["scratch"] = torch.zeros(8, dtype=torch.int64, device=dev)
             buf["history"] = torch.zeros(256, dtype=torch.int64, device=dev)
-        state, state_h, gcount = buf["state"], buf["state_host"], buf["gcount"]
+        state, state_h = buf["state"], buf["state_host"]
         state_h.zero_()
         state_h[2] = n_samples
         state_h[5] = max_samples // (n * world) + 1
         state.copy_(state_h, non_blocking=True)
-        status.zero_()
         key_init = int(L.nsa_max_key_init())
         separable = self._prior_kind_dev is not None
         log_prior_const = 0.0 if separable else self._uniform_log_prior_constant()
         stream = lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         per_pass = (self.population_acceptance or 0.0) * n * world
         n_accepted = passes = 0
-        head_args = None
+        stride = n * world
+        rules = self._device_rules()
         while True:
             remaining = n_samples - n_accepted
-            train = 1 if per_pass <= 0 else int(np.ceil(1.15 * remaining / per_pass))
+            train = 1 if per_pass <= 0 else int(remaining / per_pass)
             train = max(1, min(train, max_train, int(state_h[5]) - passes))
+            if buf.get("arena_passes", 0) < train:
+                buf["x64_many"] = torch.empty((train, n, self.dims), dtype=torch.float64, device=dev)
+                buf["log_w_many"] = torch.empty((train, n), dtype=torch.float64, device=dev)
+                buf["arena_passes"] = train
             if buf["history"].numel() < passes + train:
                 grown = torch.zeros(2 * (passes + train), dtype=torch.int64, device=dev)
                 grown[: buf["history"].numel()] = buf["history"]
                 buf["history"] = grown
-            buf["max_keys"][:train].fill_(key_init)
-            # the per-pass host work is what bounds a pass once the batch is split over many ranks: every
-            # argument that does not change from pass to pass is converted once per train
-            if head_args is None:
-                head_args = (
-                    header, lib.ptr(image), n, self.device_seed, None, float(threshold),
-                    float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
-                    lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
-                    lib.ptr(buf["x64"]), lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev),
-                    lib.ptr(self._prior_par_dev), lib.ptr(buf["log_p"] if separable else None),
-                    float(log_prior_const), lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev),
-                    lib.ptr(buf["log_w"]), None, lib.ptr(state), lib.ptr(status), flow.waves_per_group,
-                    flow.max_groups, stream,
-                )
-                tail_ptrs = (lib.ptr(buf["log_w"]), lib.ptr(buf["x64"]), lib.ptr(buf["x_acc"]), lib.ptr(state),
-                             lib.ptr(buf["workspace"]), lib.ptr(gcount))
-                local_count = state[4:5]
-            keys_base = buf["max_keys"].data_ptr()
-            hist_ptr = lib.ptr(buf["history"])
-            base_off = int(self._draw_counter + rank * n)
-            for i in range(train):
-                off = base_off + (passes + i) * n * world
-                key = buf["max_keys"][i : i + 1]
-                key_ptr = lib.c_void_p(keys_base + 8 * i)
-                rc = L.nsa_populate_pass_head(*head_args[:4], off, *head_args[5:21], key_ptr, *head_args[22:])
-                if rc:
-                    lib.check(rc, "nsa_populate_pass_head")
-                dist.all_reduce(key, op=dist.ReduceOp.MAX)
-                rc = L.nsa_populate_pass_tail(n, self.dims, tail_ptrs[0], key_ptr, self.device_seed, off, tail_ptrs[1],
-                                              n_samples, tail_ptrs[2], tail_ptrs[3], tail_ptrs[4], buf["ws_bytes"],
-                                              stream)
-                if rc:
-                    lib.check(rc, "nsa_populate_pass_tail")
-                gcount.copy_(local_count)
-                dist.all_reduce(gcount, op=dist.ReduceOp.SUM)
-                rc = L.nsa_populate_pass_commit(tail_ptrs[3], n_samples, tail_ptrs[5], hist_ptr, stream)
-                if rc:
-                    lib.check(rc, "nsa_populate_pass_commit")
+            keys, lcount, gcount = buf["max_keys"][:train], buf["lcount"][:train], buf["gcount"][:train]
+            keys.fill_(key_init)
+            off = int(self._draw_counter + rank * n + passes * stride)
+            rc = L.nsa_populate_train_heads(
+                header, lib.ptr(image), n, train, self.device_seed, off, stride, float(threshold),
+                float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
+                lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
+                lib.ptr(buf["x64_many"]), lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev),
+                lib.ptr(self._prior_par_dev), lib.ptr(buf["log_p"] if separable else None),
+                float(log_prior_const), lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev),
+                lib.ptr(buf["log_w_many"]), lib.ptr(keys), lib.ptr(state), lib.ptr(status), flow.waves_per_group,
+                flow.max_groups, stream, rules,
+            )
+            lib.check(rc, "nsa_populate_train_heads")
+            dist.all_reduce(keys, op=dist.ReduceOp.MAX)
+            rc = L.nsa_populate_train_tails(
+                n, self.dims, train, lib.ptr(buf["log_w_many"]), lib.ptr(keys), self.device_seed, off, stride,
+                lib.ptr(buf["x64_many"]), n_samples, lib.ptr(buf["x_acc"]), lib.ptr(state), lib.ptr(buf["scratch"]),
+                lib.ptr(lcount), lib.ptr(buf["workspace"]), buf["ws_bytes"], stream,
+            )
+            lib.check(rc, "nsa_populate_train_tails")
+            gcount.copy_(lcount)
+            dist.all_reduce(gcount, op=dist.ReduceOp.SUM)
+            rc = L.nsa_populate_train_commit(lib.ptr(state), n_samples, train, lib.ptr(lcount), lib.ptr(gcount),
+                                             lib.ptr(buf["history"]), stream)
+            lib.check(rc, "nsa_populate_train_commit")
             state_h.copy_(state)  # the train's one synchronisation
             n_accepted, passes = int(state_h[0]), int(state_h[1])
             if n_accepted >= n_samples:
@@ -862,15 +935,36 @@ class FlowProposal:
             per_pass = n_accepted / passes if n_accepted else per_pass * 0.5
         n_proposed = passes * n * world
         self._draw_counter += n_proposed
-        # one exchange at the end: every rank's per-pass counts and its rows, then (pass, rank, draw) order
-        hist_all = torch.empty(world * passes, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(hist_all, buf["history"][:passes].contiguous())
-        hist = hist_all.cpu().numpy().reshape(world, passes)
+        accepted = self._assemble_sharded_pool(buf["history"][:passes], buf["x_acc"], n_samples, world)
+        self.x = array_to_live_points_fast(np.ascontiguousarray(accepted), self.names)
+        log_l = None
+        if self._ll_spec is not None and accepted.shape[0]:
+            dev_rows = torch.from_numpy(np.ascontiguousarray(accepted)).to(dev)
+            log_l = self._device_log_likelihood(dev_rows).cpu().numpy()
+        self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
+
+    def _assemble_sharded_pool(self, counts_dev, x_acc, n_samples, world):
+        """First ``n_samples`` accepted rows in (pass, rank, draw) order - the order of a per-pass
+        gather - from every rank's per-pass counts and its locally appended rows: one exchange of
+        the counts, one of the rows."""
+        import torch.distributed as dist
+
+        dev = self.device
+        passes = int(counts_dev.numel())
+        if world > 1:
+            hist_all = torch.empty(world * passes, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(hist_all, counts_dev.contiguous())
+            hist = hist_all.cpu().numpy().reshape(world, passes)
+        else:
+            hist = counts_dev.cpu().numpy().reshape(1, passes)
         written = np.minimum(hist.sum(axis=1), n_samples)
         pad = max(int(written.max()), 1)
-        rows_all = torch.empty((world * pad, self.dims), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(rows_all, buf["x_acc"][:pad].contiguous())
-        rows_all = rows_all.cpu().numpy().reshape(world, pad, self.dims)
+        if world > 1:
+            rows_all = torch.empty((world * pad, self.dims), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(rows_all, x_acc[:pad].contiguous())
+            rows_all = rows_all.cpu().numpy().reshape(world, pad, self.dims)
+        else:
+            rows_all = x_acc[:pad].cpu().numpy().reshape(1, pad, self.dims)
         starts = np.concatenate([np.zeros((world, 1), dtype=np.int64), np.cumsum(hist, axis=1)], axis=1)
         pieces, have = [], 0
         for p in range(passes):
@@ -879,7 +973,149 @@ class FlowProposal:
                 if hi > lo and have < n_samples:
                     pieces.append(rows_all[r, lo:hi])
                     have += hi - lo
-        accepted = np.concatenate(pieces, axis=0)[:n_samples] if pieces else np.empty((0, self.dims))
+        return np.concatenate(pieces, axis=0)[:n_samples] if pieces else np.empty((0, self.dims))
+
+    @torch.inference_mode(False)
+    def _populate_accumulate(self, st, threshold, n_samples, max_samples, n, world, rank):
+        """``accumulate_weights=True`` (``flowproposal.py:471-490, 504-510``) on the device, for one rank or
+        a draw batch sharded over ranks.
+
+        Every draw of the population is kept: pass ``p`` lives in slot ``p`` of an arena on the device
+        (``x`` as float64 and ``log_w``; a dropped row keeps weight -inf).  The reference's test after
+        each batch - ``logsumexp(log_weights - log_constant) >= log(n_samples)`` with the running
+        ``log_constant = max(log_w)`` - needs, per pass, the maximum of the pass and
+        ``sum exp(log_w - max)`` (``nsa_populate_sumexp``); sharded, the ranks exchange them with ONE
+        all-reduce(max) and ONE all-reduce(sum) per train of passes ("the running
+        log_constant all-reduced each pass") and every rank folds the passes into the same running
+        constant.  The accept step over all rows so far (``log_w - log_constant > log u``, ``u`` from
+        the Philox stream of the GLOBAL row, so the rows do not depend on the sharding) appends to the
+        rank's pool; the counts are summed over the ranks and the loop goes on while fewer than
+        ``n_samples`` rows were accepted, exactly as the reference redraws its uniforms over the
+        grown set.  Passes a train drew beyond the one that met the test are kept for the next round
+        of the loop (never counted unless used)."""
+        import torch.distributed as dist
+
+        L = lib.load()
+        self.last_populate_path = "accumulate"
+        flow, header, image, status = self._prepare_flow()
+        buf = self._get_buffers(n, n_samples)
+        dev = self.device
+        D = self.dims
+        if buf.get("state") is None:
+            buf["state"] = torch.zeros(8, dtype=torch.int64, device=dev)
+            buf["max_keys"] = torch.empty(64, dtype=torch.int64, device=dev)
+            buf["state_host"] = torch.zeros(8, dtype=torch.int64).pin_memory()
+        if buf.get("scratch") is None:
+            buf["scratch"] = torch.zeros(8, dtype=torch.int64, device=dev)
+        state, state_h = buf["state"], buf["state_host"]
+        state_h.zero_()
+        state_h[2] = 2**62  # the loop is steered from the host here: heads never stop by themselves
+        state_h[5] = 2**62
+        state.copy_(state_h, non_blocking=True)
+        key_init = int(L.nsa_max_key_init())
+        separable = self._prior_kind_dev is not None
+        log_prior_const = 0.0 if separable else self._uniform_log_prior_constant()
+        stream = lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rules = self._device_rules()
+        stride = n * world
+        first = int(self._draw_counter + rank * n)
+        log_n = np.log(n_samples)
+
+        cap = 0  # arena slots
+        x_many = lw_many = keys = sums = lcount = gcount = None
+        pass_max, pass_sum = [], []  # per pass, global: max log_w and sum exp(log_w - max)
+        have = used = 0
+        log_constant, total = -np.inf, 0.0  # running max and sum exp(log_w - log_constant) over the used passes
+        n_accepted = 0
+        accepted_at = -1  # number of passes the last accept step covered
+        hint = int(getattr(self, "_accumulate_passes_hint", 0))
+
+        def grow(slots):
+            nonlocal cap, x_many, lw_many, keys, sums, lcount, gcount
+            if slots <= cap:
+                return
+            slots = max(slots, 2 * cap)
+            nx = torch.empty((slots, n, D), dtype=torch.float64, device=dev)
+            nw = torch.empty((slots, n), dtype=torch.float64, device=dev)
+            if have:
+                nx[:have] = x_many[:have]
+                nw[:have] = lw_many[:have]
+            x_many, lw_many, cap = nx, nw, slots
+            keys = torch.empty(slots, dtype=torch.int64, device=dev)
+            sums = torch.empty(slots, dtype=torch.float64, device=dev)
+            lcount = torch.zeros(slots, dtype=torch.int64, device=dev)
+            gcount = torch.zeros(slots, dtype=torch.int64, device=dev)
+
+        def draw(k):
+            """k more passes into the arena; their global maxima and sums onto the host lists."""
+            nonlocal have
+            grow(have + k)
+            kk, ss = keys[have : have + k], sums[have : have + k]
+            kk.fill_(key_init)
+            rc = L.nsa_populate_train_heads(
+                header, lib.ptr(image), n, k, self.device_seed, first + have * stride, stride, float(threshold),
+                float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
+                lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
+                lib.ptr(x_many[have:]), lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev),
+                lib.ptr(self._prior_par_dev), lib.ptr(buf["log_p"] if separable else None),
+                float(log_prior_const), lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev),
+                lib.ptr(lw_many[have:]), lib.ptr(kk), lib.ptr(state), lib.ptr(status), flow.waves_per_group,
+                flow.max_groups, stream, rules,
+            )
+            lib.check(rc, "nsa_populate_train_heads")
+            if world > 1:
+                dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+            rc = L.nsa_populate_sumexp(n, k, lib.ptr(lw_many[have:]), lib.ptr(kk), lib.ptr(ss), stream)
+            lib.check(rc, "nsa_populate_sumexp")
+            if world > 1:
+                dist.all_reduce(ss, op=dist.ReduceOp.SUM)
+            kk_h, ss_h = kk.cpu().numpy(), ss.cpu().numpy()  # the train's synchronisation
+            for i in range(k):
+                pass_max.append(float(L.nsa_max_key_decode(int(kk_h[i]))))
+                pass_sum.append(float(ss_h[i]))
+            have += k
+
+        def accept(m):
+            """Accept step over the first m passes with the current constant; global accepted count."""
+            ckeys = torch.full((m,), int(L.nsa_max_key_encode(float(log_constant))), dtype=torch.int64, device=dev)
+            rc = L.nsa_populate_train_tails(
+                n, D, m, lib.ptr(lw_many), lib.ptr(ckeys), self.device_seed, first, stride, lib.ptr(x_many),
+                n_samples, lib.ptr(buf["x_acc"]), lib.ptr(state), lib.ptr(buf["scratch"]), lib.ptr(lcount),
+                lib.ptr(buf["workspace"]), buf["ws_bytes"], stream,
+            )
+            lib.check(rc, "nsa_populate_train_tails")
+            g = gcount[:m]
+            g.copy_(lcount[:m])
+            if world > 1:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            return int(g.sum().item())
+
+        n_proposed = 0
+        while n_accepted < n_samples:
+            if used == have:
+                draw(max(1, hint - used - 1) if hint > used else 1)
+            m, s = pass_max[used], pass_sum[used]
+            used += 1
+            n_proposed = used * stride
+            if m > log_constant:  # a new constant rescales what was summed so far
+                total = total * np.exp(log_constant - m) if total > 0.0 else 0.0
+                log_constant = m
+            if s > 0.0:
+                total += s * np.exp(m - log_constant)
+            if total > 0.0 and np.log(total) >= log_n:
+                n_accepted = accept(used)
+                accepted_at = used
+            if n_proposed > max_samples:
+                logger.warning("Reached max samples (%s)", max_samples)
+                break
+        if accepted_at != used:
+            n_accepted = accept(used) if np.isfinite(log_constant) else 0
+        self._accumulate_passes_hint = used
+        self._draw_counter += n_proposed
+        if n_accepted:
+            accepted = self._assemble_sharded_pool(lcount[:used], buf["x_acc"], n_samples, world)
+        else:
+            accepted = np.empty((0, D))
         self.x = array_to_live_points_fast(np.ascontiguousarray(accepted), self.names)
         log_l = None
         if self._ll_spec is not None and accepted.shape[0]:
@@ -887,9 +1123,13 @@ class FlowProposal:
             log_l = self._device_log_likelihood(dev_rows).cpu().numpy()
         self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
 
-    def _populate_accumulate(self, st, threshold, n_samples, max_samples, injected):
-        """``accumulate_weights=True`` variant (``flowproposal.py:471-490, 504-510``)."""
+    def _populate_accumulate_host(self, st, threshold, n_samples, max_samples, injected):
+        """``accumulate_weights=True`` (``flowproposal.py:471-490, 504-510``) one pass per synchronisation:
+        injected latents / uniforms (parity tests: the uniforms belong to the KEPT rows, as the
+        reference's ``rng.random(len(log_weights))``), a prior evaluated on the host, or a likelihood rule
+        on the user's host likelihood.  One rank only."""
         L = lib.load()
+        self.last_populate_path = "accumulate_host"
         log_n = np.log(n_samples)
         xs, lws = [], []
         first_row = self._draw_counter

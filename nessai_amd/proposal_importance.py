@@ -314,18 +314,27 @@ class ImportanceFlowProposal:
             z_dev = None
             if z_in is not None:
                 z_dev = torch.from_numpy(np.ascontiguousarray(z_in[lo : lo + n_loc])).to(torch.float32).to(dev)
-            rc = L.nsa_importance_draw(
-                header, lib.ptr(image), n_loc, lib.ptr(z_dev), self.device_seed, self._draw_counter + lo, EPS,
-                lib.ptr(x64), lib.ptr(xp), lib.ptr(log_j), lib.ptr(flow._status), flow.waves_per_group,
-                flow.max_groups, self._stream(),
-            )
-            lib.check(rc, "nsa_importance_draw")
+            for _ in range(2):
+                flow._status.zero_()
+                rc = L.nsa_importance_draw(
+                    header, lib.ptr(image), n_loc, lib.ptr(z_dev), self.device_seed, self._draw_counter + lo, EPS,
+                    lib.ptr(x64), lib.ptr(xp), lib.ptr(log_j), lib.ptr(flow._status), flow.waves_per_group,
+                    flow.max_groups, self._stream(),
+                )
+                lib.check(rc, "nsa_importance_draw")
+                # split-f16 draw kernel outside the f16 range: repeat this rank's rows in float32
+                if flow.effective_precision != "f16x3" or int(flow._status[1].item()) == 0:
+                    break
+                flow.note_f16_overflow()
+                header, image = flow.device_image()
             if self.clip:
                 x64.clamp_(0.0, 1.0)
             log_prob_all = log_prob_many(self.flow.models, xp)  # this rank's rows under every flow
             log_q_all, log_Q = self._mix(log_prob_all, log_j)
             keep = torch.nonzero(~torch.isnan(log_j)).reshape(-1)  # draw order
             m = keep.numel()
+            if m and bool(torch.isnan(log_Q[keep]).any()):  # compute_log_Q's check (importance.py:436-441)
+                raise ValueError("There is a NaN in log g!")
             packed[:m, :D] = x64[keep]
             packed[:m, D:-1] = log_q_all[keep]
             packed[:m, -1] = log_Q[keep]

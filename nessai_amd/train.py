@@ -291,6 +291,11 @@ class Trainer:
             self.optimiser, lib.ptr(self.loss_acc), lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_train_step_dev")
+        # the data-dependent act-norm initialisation belongs to the FIRST training batch only (nflows ActNorm):
+        # clear the plan's flag now, not at the end of the epoch - every further minibatch would re-initialise
+        # log_scale / shift from its own statistics on top of the optimiser's updates.  (No-op, hence safe
+        # under graph capture, once the flag is clear: the first epoch always runs launch by launch.)
+        self._actnorm_initialised()
 
     def evaluate(self, x, log_prob_out=None, weights=None):
         """``loss_acc += -mean(log_prob(x))`` without touching the weights."""

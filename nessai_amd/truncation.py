@@ -118,9 +118,11 @@ class LatentRadiusTruncation(BaseTruncationRule):
 
     @staticmethod
     def _radius_argument(value, name):
-        if value is None or value is False:
+        # the reference's coercion to the letter (truncation.py:244-249): `value in (False, None)` is also
+        # true for 0 and 0.0 (-> the rule is off), and True passes the isinstance test (-> 1.0)
+        if value in (False, None):
             return False
-        if isinstance(value, bool) or not isinstance(value, (int, float)):
+        if not isinstance(value, (int, float)):
             raise RuntimeError(f"{name} must be an int or float")
         return float(value)
 

@@ -13,7 +13,11 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 VARIANTS = [(2, 4), (3, 4), (3, 12), (2, 8), (3, 6)]
-QUICK = "--quick" in sys.argv  # default geometry, split-bf16 only
+QUICK = "--quick" in sys.argv  # the three big-batch geometries, 16-bit modes only
+# --precisions a,b,c overrides the list of modes
+PRECISIONS = None
+if "--precisions" in sys.argv:
+    PRECISIONS = tuple(sys.argv[sys.argv.index("--precisions") + 1].split(","))
 
 
 def main():
@@ -22,7 +26,7 @@ def main():
     prop = bench.build_proposal(0, 1, device)
     prop.populate(None, n_samples=bench.NLIVE, max_samples=10**12)
     ref = None
-    for precision in (("bf16x3",) if QUICK else ("bf16x3", "f32")):
+    for precision in (PRECISIONS or (("bf16x3", "f16x3") if QUICK else ("bf16x3", "f16x3", "f32"))):
         for occ, wpg in ([("2x2", 0)] if "--2x2" in sys.argv else [(2, 4), (3, 12), ("2x2", 0)] if QUICK else VARIANTS + [("2x2", 0)]):
             os.environ["NESSAI_AMD_OCC"] = str(occ)
             prop.flow.model.waves_per_group = wpg
@@ -34,7 +38,8 @@ def main():
             checksum = float(lq[kept].sum().item())
             if precision == "bf16x3" and ref is None:
                 ref = (int(kept.sum().item()), checksum)
-            print(json.dumps(dict(library=os.path.basename(os.environ.get("NESSAI_AMD_LIBRARY", "libnessai_amd.so")), precision=precision, occ=occ, waves_per_group=wpg, ms_avg=ms, ms_min=ms_min,
+            status = prop.flow.model._status.tolist()
+            print(json.dumps(dict(skew=os.environ.get("NESSAI_AMD_SKEW", ""), status=status, library=os.path.basename(os.environ.get("NESSAI_AMD_LIBRARY", "libnessai_amd.so")), precision=precision, occ=occ, waves_per_group=wpg, ms_avg=ms, ms_min=ms_min,
                                   kept=int(kept.sum().item()), log_q_sum=checksum)), flush=True)
     os.environ.pop("NESSAI_AMD_OCC", None)
 

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
+torch.set_grad_enabled(False)
 from helpers import DEV, make_pair, rel_err, load_c3_fixture
 from test_gpu_flows import CONFIGS
 from nessai_amd.flows import NeuralSplineFlow
@@ -16,7 +17,7 @@ for name in sorted(CONFIGS):
         x = torch.randn(4000, args[0]) * scale
         with torch.no_grad():
             lp_ref = ref.log_prob(x); xi_ref, ldi_ref = ref.inverse(x)
-        for prec in ("f32", "bf16x3"):
+        for prec in ("f32", "bf16x3", "f16x3"):
             flow.precision = prec
             lp = flow.log_prob(x.to(DEV)).cpu()
             xi, ldi = flow.inverse(x.to(DEV))
@@ -29,7 +30,7 @@ x = torch.from_numpy(((live - shift) / scale).astype(np.float32))
 z = torch.randn(20000, 32)
 with torch.no_grad():
     lp_ref = ref.log_prob(x); xi_ref, ld_ref = ref.inverse(z)
-for prec in ("f32", "bf16x3"):
+for prec in ("f32", "bf16x3", "f16x3"):
     flow.precision = prec
     lp = flow.log_prob(x.to(DEV)).cpu(); xi, ld = flow.inverse(z.to(DEV))
     print("trained C3", prec, f"log_prob rel {rel_err(lp, lp_ref):.2e}  inverse x {rel_err(xi.cpu(), xi_ref):.2e} logdet {rel_err(ld.cpu(), ld_ref):.2e}")

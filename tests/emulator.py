@@ -52,7 +52,10 @@ def mfma_32x32x16_x3(a_hi, a_lo, b_hi, b_lo, c):
     return out
 
 
-def split_f32(x):
+def split_f32(x, f16=False):
+    if f16:
+        hi, lo = P.split_f16(x)
+        return P.f16_to_f32(hi), P.f16_to_f32(lo)
     hi, lo = P.split_bf16(x)
     return P.bf16_to_f32(hi), P.bf16_to_f32(lo)
 
@@ -69,7 +72,8 @@ class Emulator:
         self.act = int(h[P.H_ACT])
         self.net = int(h[P.H_NET])
         self.n_layers = int(h[P.H_NLAYERS])
-        self.bf16 = int(h[P.H_PREC]) == 1
+        self.bf16 = int(h[P.H_PREC]) in (1, 2)  # split 16-bit operands
+        self.f16 = int(h[P.H_PREC]) == 2
         name = {1: "rq", 2: "affine", 3: "additive"}[self.transform]
         self.C, self.FPC, self.NP = P.transform_policy(name, self.bins)
 
@@ -100,9 +104,9 @@ class Emulator:
     def _dense16(self, w_words, n_ot, n_steps, b_of_step, acc):
         """w_words: uint32 [n_ot][n_steps][2][64][4]; b_of_step(s) -> [64][8] float32."""
         w16 = np.ascontiguousarray(w_words).view(np.uint16).reshape(n_ot, n_steps, 2, 64, 8)
-        wf = P.bf16_to_f32(w16)
+        wf = P.f16_to_f32(w16) if self.f16 else P.bf16_to_f32(w16)
         for s in range(n_steps):
-            b_hi, b_lo = split_f32(b_of_step(s))
+            b_hi, b_lo = split_f32(b_of_step(s), self.f16)
             for ot in range(n_ot):
                 acc[ot] = mfma_32x32x16_x3(wf[ot, s, 0], wf[ot, s, 1], b_hi, b_lo, acc[ot])
         return acc

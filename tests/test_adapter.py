@@ -69,3 +69,72 @@ def test_reference_accepts_the_subclass():
         check_proposal_kwargs(cls, dict(no_such_option=1))
     prop = cls(RosenbrockModel(3), **kwargs)
     assert prop.drawsize == 1000 and prop.volume_fraction == 0.9 and isinstance(prop, ReferenceFlowProposal)
+    # the module-level export the `nessai.proposals` entry point names
+    from nessai_amd.plugin import MI355XFlowProposal
+
+    assert MI355XFlowProposal is cls and get_flow_proposal_class(MI355XFlowProposal) is cls
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/nessai"), reason="reference tree not present")
+def test_reference_reset_visitors_reach_the_hip_flow():
+    """``FlowModel.reset_model`` of the reference applies ITS ``reset_weights`` / ``reset_permutations``
+    to the flow (``flowmodel/base.py:748-772``, ``flows/utils.py:249-292``); they select modules with
+    ``isinstance(..., glasflow class)``.  Given to ``HipFlow.apply`` they are swapped for the counterparts of
+    this package, so batch norm returns to its constants, Linear layers are re-drawn, LU-linear layers go
+    back to the identity and permutations are re-drawn - through the reference's own entry points."""
+    import sys
+
+    import torch
+
+    from oracle import reference_harness
+
+    reference_harness.install()
+    sys.path.insert(0, reference_harness.REFERENCE_SRC)
+    from nessai.flows.utils import reset_permutations, reset_weights
+
+    from nessai_amd.flows import RealNVP
+    from nessai_amd.flows import modules as M
+
+    torch.manual_seed(4)
+    flow = RealNVP(6, 16, 2, 2)  # the reference's defaults: LU-linear + batch norm between the couplings
+    bn = [m for m in flow.modules() if isinstance(m, M.BatchNorm)]
+    lu = [m for m in flow.modules() if isinstance(m, M.LULinear)]
+    perms = [m for m in flow.modules() if isinstance(m, M.RandomPermutation)]
+    linear = [m for m in flow.modules() if isinstance(m, torch.nn.Linear)]
+    assert bn and lu and perms and linear
+    with torch.no_grad():
+        for m in bn:
+            m.unconstrained_weight.add_(0.3)
+            m.bias.add_(1.0)
+            m.running_mean.add_(2.0)
+            m.running_var.mul_(3.0)
+        for m in lu:
+            for p in m.parameters():
+                p.add_(0.2)
+    before = [m.weight.detach().clone() for m in linear]
+    lu_before = [torch.cat([p.detach().reshape(-1) for p in m.parameters()]) for m in lu]
+    flow.apply(reset_weights)
+    for m in bn:
+        constant = np.log(np.exp(1 - m.eps) - 1)
+        assert torch.allclose(m.unconstrained_weight, torch.full_like(m.unconstrained_weight, constant))
+        assert float(m.bias.abs().max()) == 0.0 and float(m.running_mean.abs().max()) == 0.0
+        assert torch.equal(m.running_var, torch.ones_like(m.running_var))
+    assert all(not torch.equal(a, m.weight) for a, m in zip(before, linear))
+    # LU-linear layers have no reset_parameters in nflows either: untouched by reset_weights ...
+    assert all(torch.equal(a, torch.cat([p.detach().reshape(-1) for p in m.parameters()])) for a, m in zip(lu_before, lu))
+    old_perms = [m._permutation.clone() for m in perms]
+    torch.manual_seed(9)
+    expected = [torch.randperm(len(m._permutation)) for m in perms]
+    torch.manual_seed(9)
+    flow.apply(reset_permutations)
+    # ... and re-initialised to the identity by reset_permutations, which also re-draws the permutations
+    for m in lu:
+        w = m.weight() if callable(getattr(m, "weight", None)) else None
+        if w is not None:
+            assert torch.allclose(w, torch.eye(w.shape[0]), atol=1e-6)
+    assert all(torch.equal(m._permutation.cpu(), e) for m, e in zip(perms, expected))
+    assert any(not torch.equal(a, m._permutation) for a, m in zip(old_perms, perms))
+    # any other visitor goes through untouched
+    seen = []
+    flow.apply(lambda m: seen.append(type(m).__name__))
+    assert "BatchNorm" in seen and "LULinear" in seen

@@ -187,6 +187,27 @@ def test_two_graphs_alive_at_once_and_gradient_accumulation():
         l1.backward()  # the graph (and its workspace) was consumed
 
 
+def test_backward_refuses_stale_parameters():
+    """The backward kernels re-read the live parameter buffer: a parameter changed in place between a
+    forward pass and its backward (an optimiser step; a second training-mode forward of a batch-norm flow)
+    raises instead of giving gradients against the new values (torch's own version check for saved tensors)."""
+    ref, flow, D = pair("nsf_d4")
+    flow.train()
+    x = torch.randn(40, D, device=DEV)
+    loss = -flow.log_prob(x).mean()
+    with torch.no_grad():
+        next(flow.parameters()).mul_(1.001)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        loss.backward()
+    ref, flow, D = pair("rnvp_c2_default")  # batch norm: a training-mode forward rewrites the running statistics
+    flow.train()
+    x = torch.randn(64, D, device=DEV)
+    loss = -flow.log_prob(x).mean()
+    flow.log_prob(x)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        loss.backward()
+
+
 def test_frozen_transform_and_no_grad_use_the_inference_kernel():
     ref, flow, D = pair("nsf_d4")
     x = torch.randn(50, D, device=DEV)

@@ -52,3 +52,52 @@ def test_proposal_drives_a_small_nested_sampling_loop(tmp_path):
     state = pickle.loads(pickle.dumps(proposal))
     assert state.flow is None and state.populated == proposal.populated
     assert state.weights_file is not None
+
+
+@pytest.mark.timeout(900)
+def test_config_1_two_dimensional_gaussian_with_the_reference_defaults(tmp_path):
+    """BASELINE config 1 at its own size (``examples/2d_gaussian.py``): 2-D unit Gaussian on [-10, 10]^2,
+    nlive = 1000, the reference's DEFAULT flow (RealNVP, 4 coupling layers, 2-block ResNet conditioners of
+    2 x n_dims neurons, LU-linear + batch norm: ``flowmodel/config.py:17-21``, ``flows/realnvp.py:84-90``) and
+    default proposal settings, driven by a plain nested-sampling loop to termination.  The evidence is known:
+    Z = 1 / 400 (the likelihood integrates to one inside the box), log Z = -5.9915."""
+    rng = np.random.default_rng(1234)
+    torch.manual_seed(1234)
+    model = GaussianModel(2)
+    nlive = 1000
+    proposal = FlowProposal(model, rng=rng, poolsize=nlive, output=str(tmp_path),
+                            training_config=dict(max_epochs=100, patience=20))
+    proposal.initialise()
+    fc = proposal.flow.flow_config
+    assert fc["n_blocks"] == 4 and fc["n_layers"] == 2 and fc["n_neurons"] == 4 and fc["ftype"].lower() == "realnvp"
+    live = model.new_point(nlive, rng=rng)
+    live["logL"] = model.log_likelihood(live)
+    live = np.sort(live, order="logL")
+    dead_log_l = []
+    n_iter = 8000
+    for it in range(n_iter):
+        if it % 1000 == 0:
+            proposal.train(live)
+        worst = live[0]
+        dead_log_l.append(float(worst["logL"]))
+        for _ in range(2000):
+            new = proposal.draw(worst)
+            if new["logL"] > worst["logL"]:
+                break
+        else:
+            pytest.fail("no point above the worst likelihood in 2000 draws")
+        idx = np.searchsorted(live["logL"], new["logL"])
+        live[: idx - 1] = live[1:idx]
+        live[idx - 1] = new
+    # log Z = log sum_i L_i (X_{i-1} - X_i) with X_i = exp(-i / nlive), plus the live points' share of X_final
+    i = np.arange(1, n_iter + 1)
+    log_w = -(i - 1) / nlive + np.log1p(-np.exp(-1.0 / nlive))
+    terms = np.concatenate([np.asarray(dead_log_l) + log_w,
+                            live["logL"] - n_iter / nlive - np.log(nlive)])
+    log_z = float(np.logaddexp.reduce(terms))
+    # statistical error of nested sampling: sqrt(H / nlive) ~ sqrt(4.2 / 1000) = 0.065
+    assert abs(log_z - (-np.log(400.0))) < 0.3, log_z
+    assert proposal.training_count == 8 and proposal.populated_count >= 8
+    assert model.in_bounds(live).all()
+    # the default flow runs the float32-class split-f16 kernels by the measured policy
+    assert proposal.flow.model.effective_precision in ("f16x3", "f32")

@@ -49,7 +49,7 @@ CONFIGS = {
 }
 
 
-@pytest.fixture(params=[(name, prec) for name in sorted(CONFIGS) for prec in ("bf16x3", "f32")],
+@pytest.fixture(params=[(name, prec) for name in sorted(CONFIGS) for prec in ("bf16x3", "f16x3", "f32")],
                 ids=lambda p: f"{p[0]}-{p[1]}")
 def pair(request):
     name, precision = request.param
@@ -71,7 +71,7 @@ def test_log_prob_matches_oracle(pair, scale, request):
         lp_ref = ref.log_prob(x)
     lp = flow.log_prob(x.to(DEV)).cpu()
     name = request.node.callspec.params["pair"][0]
-    if flow.precision == "f32" or name in BF16X3_WITHIN_BAR:
+    if flow.precision in ("f32", "f16x3") or name in BF16X3_WITHIN_BAR:  # split-f16: float32-class, every flow
         # TRULY relative (|a - b| / |b|; the floor only guards a log_prob within 1e-3 of zero):
         # measured <= 7.7e-6 over every configuration incl. the 2- to 5-D flows whose |log_prob|
         # goes down to 0.8 (scripts/rel_error_stats.py)
@@ -88,7 +88,7 @@ def test_forward_inverse_match_oracle(pair):
         xi_ref, ldi_ref = ref.inverse(x)
     z, ld = flow.forward(x.to(DEV))
     xi, ldi = flow.inverse(x.to(DEV))
-    k = 1.0 if flow.precision == "f32" else 10.0
+    k = 10.0 if flow.precision == "bf16x3" else 1.0
     assert rel_err(z.cpu(), z_ref) <= X_ATOL * k
     assert rel_err(ld.cpu(), ld_ref) <= LOGDET_ATOL * k
     assert rel_err(xi.cpu(), xi_ref) <= X_ATOL * k
@@ -114,7 +114,7 @@ def test_invertibility(pair):
     x = torch.randn(1000, D, device=DEV)
     z, log_J = flow.forward(x)
     x_out, log_J_out = flow.inverse(z)
-    decimal = 4 if flow.precision == "f32" else 3
+    decimal = 3 if flow.precision == "bf16x3" else 4
     np.testing.assert_array_almost_equal(x.cpu().numpy(), x_out.cpu().numpy(), decimal=decimal)
     np.testing.assert_array_almost_equal(log_J.cpu().numpy(), -log_J_out.cpu().numpy(), decimal=decimal)
 
@@ -219,9 +219,10 @@ def test_configure_model_factory():
 
 
 def test_precision_selection():
-    """Flow API default: exact f32.  Populate 'auto': split-bf16 inside its validated envelope."""
+    """Flow API default: exact f32.  Populate 'auto': split-f16 first, split-bf16 behind it inside its
+    validated envelope."""
     from nessai_amd import pack
-    from nessai_amd.flows.base import populate_precision
+    from nessai_amd.flows.base import auto_candidates, bf16x3_envelope, populate_precision
 
     _, small = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2))
     assert small.precision == "f32"
@@ -230,28 +231,31 @@ def test_precision_selection():
     small.precision = "bf16x3"
     header, _ = small.device_image()
     assert header[pack.H_PREC] == pack.PRECISIONS["bf16x3"]
-    assert populate_precision(small) == "f32"
+    small.precision = "f16x3"
+    header, _ = small.device_image()
+    assert header[pack.H_PREC] == pack.PRECISIONS["f16x3"]
+    assert populate_precision(small) == "f16x3" and auto_candidates(small) == ("f16x3",)
     _, c3 = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (32, 64, 6, 2))
-    assert populate_precision(c3) == "bf16x3"
+    assert populate_precision(c3) == "f16x3" and auto_candidates(c3) == ("f16x3", "bf16x3")
     _, c2 = make_pair(RealNVP, O.RealNVP, (16, 32, 4, 2))
-    assert populate_precision(c2) == "f32"
+    assert auto_candidates(c2) == ("f16x3",) and not bf16x3_envelope(c2)
     _, c5 = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (15, 30, 4, 2))
-    assert populate_precision(c5) == "bf16x3"
+    assert bf16x3_envelope(c5)
     _, narrow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (8, 64, 4, 2))  # small |log_prob|: 1.4e-5 in bf16x3
-    assert populate_precision(narrow) == "f32"
+    assert not bf16x3_envelope(narrow)
 
 
 @pytest.mark.parametrize("shape", [(16, 32, 6), (24, 48, 6), (32, 32, 6), (15, 30, 8)])
 def test_split_bf16_envelope_of_the_populate_policy(shape):
-    """Every flow shape the 'auto' populate policy sends to the split-bf16 kernel stays inside the
+    """Every flow shape inside the static split-bf16 envelope of the 'auto' policy stays inside the
     1e-5 bar on randomised weights (3 seeds x 3 input scales)."""
-    from nessai_amd.flows.base import populate_precision
+    from nessai_amd.flows.base import bf16x3_envelope
 
     D, H, B = shape
     worst = 0.0
     for seed in (1, 2, 3):
         ref, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (D, H, B, 2), {}, seed=seed)
-        assert populate_precision(flow) == "bf16x3"
+        assert bf16x3_envelope(flow)
         flow.precision = "bf16x3"
         for scale in (0.5, 1.0, 3.0):
             x = torch.randn(3000, D, generator=torch.Generator().manual_seed(seed)) * scale
@@ -335,18 +339,27 @@ def test_log_prob_many_mixed_structures_falls_back_to_per_flow_launches():
     assert log_prob_many([a], x[:0]).shape == (1, 0)
 
 
-def test_auto_precision_is_measured_per_set_of_weights():
-    """``precision = "auto"`` (what ``FlowProposal.populate`` asks for): the static envelope only
-    nominates split-bf16, a probe of the flow's CURRENT weights through both kernels decides.  The
-    benchmark flow at initialisation scale stays in split-bf16; the same flow with its conditioner
-    weights blown up - an ill-conditioned flow, where split-bf16 is off by 1e-4..1e-2
-    (``scripts/fuzz_bf16x3.py``) - falls back to exact float32, and the choice follows the weights."""
+def test_auto_precision_is_measured_per_set_of_weights(monkeypatch):
+    """``precision = "auto"`` (what ``FlowProposal.populate`` asks for): a probe of the flow's CURRENT
+    weights through the float32 kernel and each fast mode decides.  Split-f16 - float32-class products -
+    is taken at initialisation scale, and also for the same flow with its conditioner weights blown up
+    (an ill-conditioned flow, where the float32 kernel itself is ~1e-4 from float64): there it is
+    accepted by the float32 kernel's own one-ulp response, and it must be as close to the float64 twin
+    as the float32 oracle is.  Split-bf16 (probed first here) is off by 1e-4..1e-2 on such a flow
+    (``scripts/fuzz_precision.py``) and falls through; the choice follows the weights."""
     ref, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (32, 64, 6, 2), {})
     flow.precision = "auto"
     x = torch.randn(2000, 32)
     with torch.no_grad():
         lp_ref = ref.log_prob(x)
-    lp = flow.log_prob(x.to(DEV)).cpu()
+        lp = flow.log_prob(x.to(DEV)).cpu()
+    assert flow.effective_precision == "f16x3" and flow.probe_error <= flow.AUTO_PROBE_BAR
+    assert rel_err(lp, lp_ref, floor=1e-3) <= LOG_PROB_RTOL
+
+    monkeypatch.setenv("NESSAI_AMD_AUTO_ORDER", "bf16x3,f16x3")
+    flow._image_key = None
+    with torch.no_grad():
+        lp = flow.log_prob(x.to(DEV)).cpu()
     assert flow.effective_precision == "bf16x3" and flow.probe_error <= flow.AUTO_PROBE_BAR
     assert rel_err(lp, lp_ref, floor=1e-3) <= LOG_PROB_RTOL
 
@@ -357,13 +370,60 @@ def test_auto_precision_is_measured_per_set_of_weights():
                 f.mul_(3.0)
         lp_ref = ref.log_prob(x)
         lp64 = copy.deepcopy(ref).double().log_prob(x.double())
-    lp = flow.log_prob(x.to(DEV)).cpu()
-    assert flow.effective_precision == "f32" and flow.probe_error > flow.AUTO_PROBE_BAR
+        lp = flow.log_prob(x.to(DEV)).cpu()
+    assert flow.probe_errors["bf16x3"] > flow.AUTO_PROBE_BAR  # split-bf16 fails the probe ...
+    assert flow.effective_precision == "f16x3"  # ... split-f16 takes over
+    noise = flow.probe_errors.get("f32_one_ulp", 0.0)
+    assert flow.probe_errors["f16x3"] <= max(flow.AUTO_PROBE_BAR, flow.AUTO_NOISE_FACTOR * noise)
     # float32 itself is ~1e-4 from float64 on this flow: the device must be as good as the float32 oracle
     assert rel_err(lp, lp64, floor=1e-3) <= 3.0 * rel_err(lp_ref, lp64, floor=1e-3)
+    flow.precision = "f32"
+    with torch.no_grad():
+        lp32 = flow.log_prob(x.to(DEV)).cpu()
+    assert rel_err(lp, lp64, floor=1e-3) <= 3.0 * rel_err(lp32, lp64, floor=1e-3)
 
-    # a flow outside the static envelope is never probed
+    # a flow outside the split-bf16 envelope never probes that mode
+    monkeypatch.delenv("NESSAI_AMD_AUTO_ORDER")
     _, small = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2), {})
     small.precision = "auto"
     small.log_prob(torch.randn(10, 4, device=DEV))
-    assert small.effective_precision == "f32" and small.probe_error is None
+    assert small.effective_precision == "f16x3" and "bf16x3" not in small.probe_errors
+
+
+def test_split_f16_reports_operands_beyond_the_f16_range():
+    """The split-f16 products hold for operands below 65520 only.  A call that meets a larger one is
+    detected by the kernel (status[1], the wave's sticky IEEE overflow flag): a flow pinned to the mode
+    raises, ``precision = "auto"`` repeats the call in exact float32 and stops choosing the mode until the
+    weights change.  Ordinary batches never trip the flag."""
+    from nessai_amd.flows.base import F16RangeError
+
+    for cls, ocls, args, kw in [(NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 3, 2), {}),
+                                (RealNVP, O.RealNVP, (16, 32, 4, 2), {})]:
+        ref, flow = make_pair(cls, ocls, args, kw)
+        D = args[0]
+        x = torch.randn(3000, D, generator=torch.Generator().manual_seed(2)) * 2.0
+        flow.precision = "f16x3"
+        flow.log_prob(x.to(DEV))
+        assert flow._status.tolist()[1] == 0
+        flow.inverse(x.to(DEV))
+        assert flow._status.tolist()[1] == 0
+        big = x.clone()
+        big[1234, D - 1] = 7.0e4  # an identity feature of some coupling layer: goes into a matrix product
+        big[77, 0] = -7.0e4
+        with pytest.raises(F16RangeError, match="f16 range"):
+            flow.log_prob(big.to(DEV))
+        flow.precision = "f32"
+        expected = flow.log_prob(big.to(DEV))
+        flow.precision = "auto"
+        got = flow.log_prob(x.to(DEV))
+        assert flow.effective_precision == "f16x3"
+        got = flow.log_prob(big.to(DEV))
+        assert flow.effective_precision == "f32"  # blocked for these weights
+        assert np.array_equal(got.cpu().numpy(), expected.cpu().numpy(), equal_nan=True)
+        flow.log_prob(x.to(DEV))
+        assert flow.effective_precision == "f32"
+        with torch.no_grad():
+            for p in flow.parameters():
+                p.mul_(1.0001)  # new weights: probed again
+        flow.log_prob(x.to(DEV))
+        assert flow.effective_precision == "f16x3"

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRAW, NS = 40_000, 300
 
 
-def _proposal(world, shard):
+def _proposal(world, shard, **extra):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import load_c3_fixture
@@ -31,7 +31,7 @@ def _proposal(world, shard):
     prop = FlowProposal(
         RosenbrockModel(32), rng=np.random.default_rng(3),
         flow_config=dict(ftype="nsf", n_neurons=64, n_blocks=6, n_layers=2, num_bins=8),
-        poolsize=NS, drawsize=DRAW, device_seed=77, shard=shard, volume_fraction=0.5,
+        poolsize=NS, drawsize=DRAW, device_seed=77, shard=shard, volume_fraction=0.5, **extra,
     )
     prop.initialise()
     prop.flow.model.load_state_dict(state)
@@ -40,13 +40,14 @@ def _proposal(world, shard):
     return prop
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, extra=None, calls=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    prop = _proposal(world, shard=True)
-    prop.populate(None, n_samples=NS, max_samples=10**9)
+    prop = _proposal(world, shard=True, **(extra or {}))
+    for _ in range(calls):  # the second call runs its trains from the acceptance the first one saw
+        prop.populate(None, n_samples=NS, max_samples=10**9)
     x = np.stack([prop.x[n] for n in prop.names], axis=1)
     np.save(os.path.join(out_dir, f"x{rank}.npy"), x)
     with open(os.path.join(out_dir, f"c{rank}.txt"), "w") as f:
@@ -73,6 +74,53 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
     counts = [(tmp_path / f"c{r}.txt").read_text().split() for r in range(2)]
     assert counts[0] == counts[1] == [str(single.n_accepted), str(single.n_proposed)]
     assert np.array_equal(xs[0], expected)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("extra", [dict(accumulate_weights=True),
+                                   dict(enforce_likelihood_threshold=True)],
+                         ids=["accumulate_weights", "rules_after_the_flow"])
+def test_two_ranks_reproduce_one_rank_in_the_other_modes(tmp_path, extra):
+    """``accumulate_weights=True`` sharded (the running log_constant and the expected count exchanged per
+    train of passes; flowproposal.py:471-490) and the truncation rules that act
+    after the flow on the device-side loop (truncation.py:385-392, 423-430): two ranks end with the pool
+    of one rank, bit for bit, over two consecutive populations."""
+    worst = None
+    if "enforce_likelihood_threshold" in extra:
+        probe = _proposal(1, shard=False)
+        probe.populate(None, n_samples=NS, max_samples=10**9)
+        worst = probe.samples[np.argsort(probe.samples["logL"])[NS // 4]]  # a quarter of the pool lies below it
+
+    def run(prop):
+        for _ in range(2):
+            prop.populate(worst, n_samples=NS, max_samples=10**9)
+
+    mp.spawn(_mode_worker, args=(2, _free_port(), str(tmp_path), extra, worst), nprocs=2, join=True)
+    single = _proposal(1, shard=False, **extra)
+    run(single)
+    expected = np.stack([single.x[n] for n in single.names], axis=1)
+    xs = [np.load(tmp_path / f"x{r}.npy") for r in range(2)]
+    assert np.array_equal(xs[0], xs[1])
+    counts = [(tmp_path / f"c{r}.txt").read_text().split() for r in range(2)]
+    assert counts[0] == counts[1] == [str(single.n_accepted), str(single.n_proposed)]
+    assert len(expected) == NS and np.array_equal(xs[0], expected)
+    if worst is not None:  # every row of the pool passed the likelihood rule
+        assert (single.samples["logL"] > worst["logL"]).all()
+
+
+def _mode_worker(rank, world, port, out_dir, extra, worst):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    prop = _proposal(world, shard=True, **extra)
+    for _ in range(2):
+        prop.populate(worst, n_samples=NS, max_samples=10**9)
+    x = np.stack([prop.x[n] for n in prop.names], axis=1)
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), x)
+    with open(os.path.join(out_dir, f"c{rank}.txt"), "w") as f:
+        f.write(f"{prop.n_accepted} {prop.n_proposed}")
+    dist.destroy_process_group()
 
 
 def _train_worker(rank, world, port, out_dir):

@@ -318,6 +318,38 @@ def test_fused_coupling_kernels_match_the_layer_wise_kernels(name, monkeypatch):
         assert rel_err(lp0, lp1) <= 2e-6
 
 
+def test_act_norm_is_initialised_by_the_first_minibatch_only():
+    """Several minibatches through the graph-capturable step (``Trainer.step_dev``, what ``train_flow`` runs
+    from the first epoch on): act norm takes its data-dependent initialisation from the FIRST batch and is
+    then trained by the optimiser like every other parameter, as nflows' ActNorm does - three AdamW steps
+    against torch on the oracle."""
+    P, Oc, args = RealNVP, O.RealNVP, (6, 16, 2, 2)
+    kw = dict(actnorm=True, batch_norm_between_layers=False, linear_transform="permutation")
+    torch.manual_seed(3)
+    ref = Oc(*args, **kw)
+    flow = P(*args, **kw)
+    flow.load_state_dict(ref.state_dict())
+    flow.to(DEV)
+    ref.train()
+    tr = Trainer(flow, lr=1e-2, weight_decay=0.01, optimiser="adamw")
+    tr.opt[0] = 1e-2
+    tr.opt[1] = 0.0
+    g = torch.Generator().manual_seed(8)
+    opt = None
+    for step in range(3):
+        x = torch.randn(300, 6, generator=g) * torch.tensor([1.0, 0.2, 3.0, 0.5, 2.0, 1.5]) + 0.7 * (step + 1)
+        loss = -ref.log_prob(x).mean()  # the first pass initialises the oracle's act norm in place
+        if opt is None:
+            opt = torch.optim.AdamW(ref.parameters(), lr=1e-2)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 5.0)
+        opt.step()
+        tr.step_dev(x.to(DEV), clip_norm=5.0)
+    torch.cuda.synchronize()
+    assert float((tr.params.cpu() - flat_of(ref)).abs().max()) <= 5e-5
+
+
 @pytest.mark.parametrize("optimiser,torch_cls,kwargs", [
     ("adam", torch.optim.Adam, dict(weight_decay=1e-6)),
     ("adam", torch.optim.Adam, dict(weight_decay=0.05)),

@@ -113,6 +113,17 @@ def test_populate_with_all_three_rules():
     assert (prop.samples["logL"] > log_l_thr).all()
     _, log_q = prop.forward_pass(prop.samples)
     assert (log_q > min_log_q - 1e-3).all()
+    # the rules ran inside the device-side loop (nsa_populate_passes with nsa_post_rules); the loop with one
+    # synchronisation per pass (nsa_populate_truncate between draw and weights) gives the same pool bit for bit
+    assert prop.last_populate_path == "trains"
+    slow, _ = build(6, "nsf", dict(n_neurons=16, n_blocks=3), model_cls=GaussianModel, poolsize=200,
+                    drawsize=20000, truncate_log_q=True, enforce_likelihood_threshold=True, pass_trains=False)
+    slow.training_data = live
+    slow.populate(worst, n_samples=200, max_samples=10**8)
+    assert slow.last_populate_path == "passes"
+    assert (slow.n_accepted, slow.n_proposed) == (prop.n_accepted, prop.n_proposed)
+    for n in prop.names:
+        np.testing.assert_array_equal(slow.x[n], prop.x[n])
     # without the rules the same draws accept points below the likelihood threshold
     free, _ = build(6, "nsf", dict(n_neurons=16, n_blocks=3), model_cls=GaussianModel, poolsize=200, drawsize=20000)
     free.populate(worst, n_samples=200, max_samples=10**8)

@@ -42,7 +42,7 @@ def test_mfma_emulation_matches_matmul():
             assert abs(d[lane, r] - ref[i, lane & 31]) < 1e-6
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("name", sorted(CONFIGS))
 def test_emulated_kernel_matches_oracle(name, precision):
     cls, args, kw = CONFIGS[name]
@@ -60,7 +60,8 @@ def test_emulated_kernel_matches_oracle(name, precision):
     ze, lde = em.run(x.numpy(), False)
     xe, ldie = em.run(x.numpy(), True)
     scale = max(1.0, float(xi.abs().max()))
-    tol = 1.0 if precision == "f32" else 10.0  # split-bf16 products carry ~2^-16 relative error
+    # split-bf16 products carry ~2^-16 relative error; split-f16 ones are float32-class (2^-24)
+    tol = 10.0 if precision == "bf16x3" else 1.0
     assert np.abs(ze - z.numpy()).max() < 5e-5 * tol
     assert np.abs(lde - ld.numpy()).max() < 1e-4 * tol
     assert np.abs(xe - xi.numpy()).max() < 5e-5 * scale * tol
@@ -94,6 +95,8 @@ def test_image_header_and_alignment():
     assert img[P.H_PREC] == 0
     img16 = P.pack_flow(dict(describe(flow), precision="bf16x3"))
     assert img16[P.H_PREC] == 1 and img16[P.H_MAX_STAGE] == img[P.H_MAX_STAGE]
+    imgf = P.pack_flow(dict(describe(flow), precision="f16x3"))
+    assert imgf[P.H_PREC] == 2 and len(imgf) == len(img16)
     assert img[P.H_D] == 32 and img[P.H_HT] == 2 and img[P.H_BINS] == 8
     assert img[P.H_TOTAL] == len(img)
     assert img[P.H_MAX_STAGE] % 256 == 0
@@ -112,7 +115,7 @@ def test_wide_conditioner_stages_are_split_along_k():
     assert P.ksplit(3, 2) == 1 and P.ksplit(4, 4) == 4 and P.ksplit(3, 4) == 4 and P.ksplit(1, 4) == 1
     torch.manual_seed(1)
     flow = O.NeuralSplineFlow(12, 128, 2, 1).eval()
-    for precision in ("f32", "bf16x3"):
+    for precision in ("f32", "bf16x3", "f16x3"):
         img = P.pack_flow(dict(describe(flow), precision=precision))
         assert img[P.H_HT] == 4 and img[P.H_MAX_STAGE] * 4 <= 17 * 1024
         # 2 couplings x (1 layer-0 + 2 x 4 hidden + 2 chunks x 4) stages

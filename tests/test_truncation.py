@@ -126,3 +126,9 @@ def test_scheme_limits_and_errors():
         T.LatentRadiusTruncation(radius_mode="fixed")
     with pytest.raises(RuntimeError):
         T.LatentRadiusTruncation(fixed_radius="2")
+    # the reference's `value in (False, None)` coercion (truncation.py:244-249): 0 switches the rule off
+    # (-> adaptive mode), True counts as 1.0
+    assert T.LatentRadiusTruncation(fixed_radius=0).radius_mode == "adaptive"
+    assert T.LatentRadiusTruncation(fixed_radius=0.0).fixed_radius is False
+    one = T.LatentRadiusTruncation(fixed_radius=True)
+    assert one.fixed_radius == 1.0 and one.radius_mode == "fixed"
