@@ -156,6 +156,20 @@ NSA_API int nsa_populate_draw(const uint32_t* header, const void* image_dev, lon
                       double* log_prior_out_dev, const int* rp_kind_dev, const double* rp_par_dev,
                       int* status_dev, int waves_per_group, int max_groups, void* stream);
 
+/* Rebuild the parameter words of a flow image on the device after the weights changed (FlowModel.train ->
+ * the next FlowProposal.populate; the reference re-reads its torch Parameters directly, here the kernels
+ * read a packed image: src/nessai/flowmodel/base.py:681-685 is the matching "flush the cache" point).
+ * For a flow of couplings and permutations every image word is constant, one float32 parameter, or the hi /
+ * lo 16-bit halves of two parameters; the host computes that map once per structure
+ * (nessai_amd/pack.py repack_map) and this one launch replaces the host-side pack (16-33 ms + two copies).
+ *   pos_dev[k]   image word to write            kind_dev[k]  1 float32, 2 pair hi halves, 3 pair lo halves
+ *   e0_dev[k], e1_dev[k]  indices into params_dev (flat float32 parameter vector), -1 = zero padding
+ *   precision    image precision code (0 f32, 1 bf16x3, 2 f16x3; selects bf16 / f16 rounding for kinds 2, 3)
+ * The result equals pack.pack_flow of the same weights bit for bit. */
+NSA_API int nsa_repack_image(long long n_words, const int* pos_dev, const int* e0_dev, const int* e1_dev,
+                     const unsigned char* kind_dev, const float* params_dev, int precision,
+                     void* image_dev, void* stream);
+
 /* The truncation rules that act AFTER the flow, for the trains of passes below
  * (src/nessai/proposal/flowproposal/truncation.py:368-446; nsa_populate_truncate is the one-pass form):
  *   min_log_q        keep log_q > min_log_q (-inf: rule off)
@@ -199,6 +213,26 @@ NSA_API int nsa_populate_passes(const uint32_t* header, const void* image_dev, l
                         long long* state_dev, void* workspace_dev, size_t workspace_bytes,
                         int* status_dev, int waves_per_group, int max_groups, void* stream,
                         const nsa_post_rules* rules);
+
+/* nsa_populate_passes for SMALL passes (n <= 16384 rows - the reference's default drawsize = nlive): a pass
+ * of a few thousand rows is one dependent chain through the flow (~40 us) however few rows it has, and the
+ * passes of a train are independent until the stop test, so the train is ONE draw launch over its
+ * n_passes * n rows (pass i = rows [row_offset + i n, + n)), one tail launch (workgroup i: weights, the pass's
+ * own maximum, accept, compaction into stage_dev + i * stage_rows * D; counts_dev[i]) and one commit launch
+ * that walks the passes in order against the loop state.  Rows, order, counters and Philox offsets are those
+ * of nsa_populate_passes; passes beyond the one that reaches the wanted count are computed and ignored.
+ *   x64_many_dev [n_passes n][D], log_q_many_dev / log_prior_many_dev [n_passes n],
+ *   stage_dev [n_passes][stage_rows][D] with stage_rows >= min(n, capacity), counts_dev [n_passes]. */
+NSA_API int nsa_populate_passes_small(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                              unsigned long long seed, unsigned long long row_offset, double radius,
+                              double latent_temperature, const double* scale_dev, const double* shift_dev,
+                              const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                              double* x64_many_dev, double* log_q_many_dev, const int* prior_kind_dev,
+                              const double* prior_par_dev, double* log_prior_many_dev, double log_prior_const,
+                              const int* rp_kind_dev, const double* rp_par_dev, long long stage_rows,
+                              double* stage_dev, long long* counts_dev, long long capacity, double* x_acc_dev,
+                              long long* state_dev, int* status_dev, int waves_per_group, int max_groups,
+                              void* stream, const nsa_post_rules* rules);
 
 /* The same pass in pieces, for draw batches SHARDED over ranks: the collectives of the host
  * framework (RCCL through torch.distributed, stream ordered, no host synchronisation) go between

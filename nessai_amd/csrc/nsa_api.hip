@@ -779,3 +779,63 @@ extern "C" int nsa_populate_sumexp(long long n, int n_passes, const double* log_
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "sumexp kernel: %s", hipGetErrorString(e));
   return NSA_OK;
 }
+
+extern "C" hipError_t nsa_launch_repack(long long, const int*, const int*, const int*, const unsigned char*,
+                                        const float*, int, uint32_t*, hipStream_t);
+
+extern "C" int nsa_repack_image(long long n_words, const int* pos_dev, const int* e0_dev, const int* e1_dev,
+                                const unsigned char* kind_dev, const float* params_dev, int precision,
+                                void* image_dev, void* stream) {
+  if (n_words < 0 || (n_words > 0 && (pos_dev == nullptr || e0_dev == nullptr || e1_dev == nullptr ||
+                                      kind_dev == nullptr || params_dev == nullptr || image_dev == nullptr)))
+    return nsa_fail(NSA_E_ARG, "nsa_repack_image: bad argument");
+  if (precision != NSA_PREC_F32 && precision != NSA_PREC_BF16X3 && precision != NSA_PREC_F16X3)
+    return nsa_fail(NSA_E_ARG, "nsa_repack_image: unknown precision code %d", precision);
+  hipError_t e = nsa_launch_repack(n_words, pos_dev, e0_dev, e1_dev, kind_dev, params_dev, precision,
+                                   (uint32_t*)image_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "repack kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+// A train of SMALL passes as one draw launch + two tail launches (see include/nessai_amd.h).
+extern "C" hipError_t nsa_launch_small_train(long long, int, int, const double*, const double*, double,
+                                             unsigned long long, unsigned long long, const double*, long long, double*,
+                                             long long*, long long, double*, long long*, hipStream_t);
+
+extern "C" int nsa_populate_passes_small(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                                         unsigned long long seed, unsigned long long row_offset, double radius,
+                                         double latent_temperature, const double* scale_dev, const double* shift_dev,
+                                         const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                                         double* x64_many_dev, double* log_q_many_dev, const int* prior_kind_dev,
+                                         const double* prior_par_dev, double* log_prior_many_dev,
+                                         double log_prior_const, const int* rp_kind_dev, const double* rp_par_dev,
+                                         long long stage_rows, double* stage_dev, long long* counts_dev,
+                                         long long capacity, double* x_acc_dev, long long* state_dev, int* status_dev,
+                                         int waves_per_group, int max_groups, void* stream,
+                                         const nsa_post_rules* rules) {
+  if (n <= 0 || n > 16384 || n_passes < 1 || x64_many_dev == nullptr || log_q_many_dev == nullptr ||
+      stage_dev == nullptr || counts_dev == nullptr || x_acc_dev == nullptr || state_dev == nullptr || capacity < 0 ||
+      stage_rows < 1)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_passes_small: bad argument (1 <= n <= 16384)");
+  NsaLaunch p;
+  const long long rows = n * (long long)n_passes;
+  int rc = nsa_draw_params(p, header, image_dev, rows, nullptr, seed, row_offset, radius, latent_temperature, scale_dev,
+                           shift_dev, lower_dev, upper_dev, log_j_rescale, x64_many_dev, log_q_many_dev, nullptr,
+                           prior_kind_dev, prior_par_dev, log_prior_many_dev, rp_kind_dev, rp_par_dev, status_dev);
+  if (rc != NSA_OK) return rc;
+  p.stop = state_dev;
+  hipStream_t s = (hipStream_t)stream;
+  rc = nsa_launch_flow(header, p, waves_per_group, max_groups, s);
+  if (rc != NSA_OK) return rc;
+  const int D = (int)header[NSA_H_D];
+  if (rules != nullptr) {
+    hipError_t er = nsa_launch_post_rules(rows, D, log_q_many_dev, rules, x64_many_dev, state_dev, s);
+    if (er != hipSuccess) return nsa_fail(NSA_E_HIP, "small train (rules after the flow): %s", hipGetErrorString(er));
+  }
+  hipError_t e = nsa_launch_small_train(n, D, n_passes, log_q_many_dev,
+                                        (prior_kind_dev != nullptr) ? log_prior_many_dev : nullptr, log_prior_const,
+                                        seed, row_offset, x64_many_dev, stage_rows, stage_dev, counts_dev, capacity,
+                                        x_acc_dev, state_dev, s);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "small train: %s", hipGetErrorString(e));
+  return NSA_OK;
+}

@@ -259,9 +259,12 @@ struct NsaStagePipe {
     cp_part = parts == 1 ? NSA_COPY_PARTS : 1;
     load_entry((nxt + 1 == n_stages) ? 0 : nxt + 1);
   }
+  // (SKEW: compiled for skewed waves.  The flag is honoured either way: the ops that are not split into M | V -
+  // LU-linear, batch norm - share one copy of their code, and a skewed wave reaches them with the copy of
+  // their stage already sent off at the end of the coupling before.)
   template <bool SKEW = false>
   __device__ __forceinline__ const float* begin() {
-    if (SKEW && issued) issued = false;
+    if (issued) issued = false;
     else issue_next(NSA_COPY_PARTS);
     NSA_TL(*this, 12);
     return parity ? buf1 : buf0;

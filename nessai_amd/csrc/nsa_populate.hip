@@ -277,6 +277,129 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_small_tai
   return hipGetLastError();
 }
 
+// A whole TRAIN of small passes at once (nsa_populate_passes_small, include/nessai_amd.h): the draw kernel
+// has already run over the n_passes * n rows of the train in one launch; workgroup i does the tail of pass i
+// - weights, the pass's own maximum, accept flags with the uniforms of the global rows, compaction into the
+// pass's staging block - and nsa_small_commit_kernel then walks the passes in order against the loop state,
+// appending the staged rows of every pass that counts.  Same arithmetic and row order as the pass-at-a-time
+// kernel above; surplus passes only cost their share of two launches.
+__global__ void __launch_bounds__(1024) nsa_small_tails_kernel(long long n, int D, const double* __restrict__ log_q_many,
+                                                               const double* __restrict__ log_prior_many,
+                                                               double log_prior_const, unsigned long long seed,
+                                                               unsigned long long row_offset,
+                                                               const double* __restrict__ x64_many, long long cap,
+                                                               double* __restrict__ stage, long long* __restrict__ counts,
+                                                               const long long* __restrict__ state) {
+  if (NSA_STOPPED(state)) return;
+  const long long pass = blockIdx.x;
+  const double* log_q = log_q_many + pass * n;
+  const double* log_prior = (log_prior_many != nullptr) ? log_prior_many + pass * n : nullptr;
+  const double* x64 = x64_many + pass * n * D;
+  double* out = stage + pass * cap * D;
+  const unsigned long long off = row_offset + (unsigned long long)(pass * n);
+  __shared__ double smax[16];
+  __shared__ int scnt[1024];
+  const double ninf = -__builtin_huge_val();
+  const int c = (int)((n + 1023) / 1024);
+  const long long lo = (long long)threadIdx.x * c;
+  double w[NSA_SMALL_C];
+  double m = ninf;
+#pragma unroll
+  for (int k = 0; k < NSA_SMALL_C; ++k) {
+    const long long i = lo + k;
+    double v = ninf;
+    if (k < c && i < n) {
+      const double lq = log_q[i];
+      const double lp = (log_prior != nullptr) ? log_prior[i] : log_prior_const;
+      v = lp - lq;
+      if (lq != lq || v != v) v = ninf;
+    }
+    w[k] = v;
+    m = fmax(m, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  double mx = smax[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) mx = fmax(mx, smax[k]);
+  unsigned flags = 0;
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < NSA_SMALL_C; ++k) {
+    const long long i = lo + k;
+    if (k < c && i < n) {
+      const double lu = log(nsa_uniform53(seed, off + (unsigned long long)i));
+      const bool acc = (w[k] - mx) > lu;
+      flags |= acc ? (1u << k) : 0u;
+      cnt += acc ? 1 : 0;
+    }
+  }
+  scnt[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan
+    const int t = (threadIdx.x >= o) ? scnt[threadIdx.x - o] : 0;
+    __syncthreads();
+    scnt[threadIdx.x] += t;
+    __syncthreads();
+  }
+  long long dst = scnt[threadIdx.x] - cnt;
+#pragma unroll
+  for (int k = 0; k < NSA_SMALL_C; ++k) {
+    if (flags & (1u << k)) {
+      if (dst < cap) {
+        const long long i = lo + k;
+        for (int cc = 0; cc < D; ++cc) out[dst * D + cc] = x64[i * D + cc];
+      }
+      ++dst;
+    }
+  }
+  if (threadIdx.x == 1023) counts[pass] = scnt[1023];
+}
+
+__global__ void __launch_bounds__(256) nsa_small_commit_kernel(int n_passes, int D, long long cap,
+                                                               const double* __restrict__ stage,
+                                                               const long long* __restrict__ counts,
+                                                               long long capacity, double* __restrict__ x_acc,
+                                                               long long* state) {
+  __shared__ long long sh[2];  // {rows written so far, stop flag}
+  for (int i = 0; i < n_passes; ++i) {
+    if (threadIdx.x == 0) {
+      sh[0] = state[3];
+      sh[1] = NSA_STOPPED(state) ? 1 : 0;
+    }
+    __syncthreads();
+    if (sh[1] != 0) return;
+    const long long got = counts[i], written = sh[0];
+    long long take = got < cap ? got : cap;
+    if (take > capacity - written) take = capacity - written;
+    const double* src = stage + (long long)i * cap * D;
+    double* dst = x_acc + written * D;
+    for (long long k = threadIdx.x; k < take * D; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      state[4] = got;
+      state[0] += got;
+      state[1] += 1;
+      const long long wr = written + got;
+      state[3] = wr < capacity ? wr : capacity;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_small_train(
+    long long n, int D, int n_passes, const double* log_q_many, const double* log_prior_many, double log_prior_const,
+    unsigned long long seed, unsigned long long row_offset, const double* x64_many, long long cap, double* stage,
+    long long* counts, long long capacity, double* x_acc, long long* state, hipStream_t stream) {
+  hipLaunchKernelGGL(nsa_small_tails_kernel, dim3((unsigned)n_passes), dim3(1024), 0, stream, n, D, log_q_many,
+                     log_prior_many, log_prior_const, seed, row_offset, x64_many, cap, stage, counts, state);
+  hipLaunchKernelGGL(nsa_small_commit_kernel, dim3(1), dim3(256), 0, stream, n_passes, D, cap, stage, counts, capacity,
+                     x_acc, state);
+  return hipGetLastError();
+}
+
 // end of one pass of a train: publish its counts (the only writer of the loop state)
 // Sharded runs: `global_count` holds the pass's accepted count summed over the ranks (the stop test
 // is on the global count; rows are appended locally) and `history[pass]` keeps this rank's count
@@ -295,6 +418,58 @@ __global__ void nsa_pass_commit_kernel(long long* state, long long capacity, con
 extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_pass_commit(
     long long* state, long long capacity, const long long* global_count, long long* history, hipStream_t stream) {
   hipLaunchKernelGGL(nsa_pass_commit_kernel, dim3(1), dim3(1), 0, stream, state, capacity, global_count, history);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Flow image rebuilt on the device (nsa_repack_image, include/nessai_amd.h; maps from nessai_amd/pack.py
+// repack_map): parameter word k of the image is one float32 parameter, or the hi / lo 16-bit halves of two
+// parameters - the conversions of pack.split_bf16 / pack.split_f16 (round to nearest even), bit for bit.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t nsa_bf16_rne(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;  // pack.bf16_bits
+}
+__device__ __forceinline__ void nsa_split16_host_exact(float x, int precision, uint32_t& hi, uint32_t& lo) {
+  if (precision == NSA_PREC_F16X3) {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    hi = (uint32_t)__builtin_bit_cast(unsigned short, h);
+    lo = (uint32_t)__builtin_bit_cast(unsigned short, l);
+  } else {
+    hi = nsa_bf16_rne(x);
+    lo = nsa_bf16_rne(x - __uint_as_float(hi << 16));
+  }
+}
+
+__global__ void __launch_bounds__(256) nsa_repack_kernel(long long n, const int* __restrict__ pos,
+                                                         const int* __restrict__ e0, const int* __restrict__ e1,
+                                                         const unsigned char* __restrict__ kind,
+                                                         const float* __restrict__ params, int precision,
+                                                         uint32_t* __restrict__ image) {
+#pragma clang fp contract(off)
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int i0 = e0[k], i1 = e1[k];
+  const float a = i0 >= 0 ? params[i0] : 0.0f;
+  const int kd = kind[k];
+  if (kd == 1) {
+    image[pos[k]] = __float_as_uint(a);
+    return;
+  }
+  const float b = i1 >= 0 ? params[i1] : 0.0f;
+  uint32_t ah, al, bh, bl;
+  nsa_split16_host_exact(a, precision, ah, al);
+  nsa_split16_host_exact(b, precision, bh, bl);
+  image[pos[k]] = (kd == 2) ? (ah | (bh << 16)) : (al | (bl << 16));
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_repack(
+    long long n, const int* pos, const int* e0, const int* e1, const unsigned char* kind, const float* params,
+    int precision, uint32_t* image, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(nsa_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, pos, e0, e1, kind,
+                     params, precision, image);
   return hipGetLastError();
 }
 

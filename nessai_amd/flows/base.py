@@ -157,7 +157,6 @@ class HipFlow(BaseFlow):
         self._transform = transform
         self._distribution = distribution
         self._image_key = None
-        self._image_host = None
         self._image_dev = None
         self._header = None
         self._header_t = None
@@ -232,18 +231,20 @@ class HipFlow(BaseFlow):
             )
         key = (device, self.precision, self._fingerprint())
         if key != self._image_key:
-            desc = M.describe(self)
-            if self.precision == "auto":
-                image = self._pack_auto(desc, device)
-            else:
-                image = pack.pack_flow(dict(desc, precision=self.precision))
-                self.effective_precision = self.precision
-            self._image_host = image
-            self._header = (lib.ctypes.c_uint32 * pack.HEADER_WORDS)(*image[: pack.HEADER_WORDS].tolist())
-            with torch.inference_mode(False):  # cached across calls: must not be inference tensors
-                self._header_t = ops.header_tensor(self._header)
-                self._image_dev = torch.from_numpy(image.view(np.int32)).to(device)
-                self._status = torch.zeros(4, dtype=torch.int32, device=device)
+            # `_image_key = None` is how the trainer, load paths and note_f16_overflow say "the weights changed
+            # behind torch's version counters": every cached image is then stale, whatever the fingerprint says
+            old = self._image_key
+            if old is None or old[0] != key[0] or old[2] != key[2]:
+                self.__dict__["_image_epoch"] = self.__dict__.get("_image_epoch", 0) + 1
+            with torch.inference_mode(False), torch.no_grad():  # cached across calls: never inference tensors
+                images = _ImageSource(self, device, self.__dict__["_image_epoch"])
+                if self.precision == "auto":
+                    chosen = self._pack_auto(images, device)
+                else:
+                    chosen = self.effective_precision = self.precision
+                self._header, self._header_t, self._image_dev = images.get(chosen)
+                if self._status is None or self._status.device != device:
+                    self._status = torch.zeros(4, dtype=torch.int32, device=device)
             self._image_key = key
         return self._header, self._image_dev
 
@@ -256,8 +257,8 @@ class HipFlow(BaseFlow):
     #: probe inputs (see ``_pack_auto``)
     AUTO_NOISE_FACTOR = 4.0
 
-    def _pack_auto(self, desc, device):
-        """Packed image for ``precision = "auto"``: the first fast mode (``auto_candidates``:
+    def _pack_auto(self, images, device):
+        """Precision for ``precision = "auto"``: the first fast mode (``auto_candidates``:
         split-f16, then split-bf16 inside its static envelope) that is MEASURED to agree with the
         exact-float32 kernels on this flow's current weights, float32 otherwise.
 
@@ -272,69 +273,66 @@ class HipFlow(BaseFlow):
         differ (the same sweep: 2e-3 against 7e-3 for the float32 kernel itself, both measured
         against the CPU oracle); it is therefore also accepted within ``AUTO_NOISE_FACTOR`` times
         the float32 kernel's own response to moving every probe input by one ulp - and never when
-        the probe left the f16 range.  Costs one extra pack and four small launches per candidate
-        and change of the weights."""
+        the probe left the f16 range.  Costs the images of the probed modes (``_ImageSource``: one
+        gather launch each once the flow's structure is known) and four small launches per
+        candidate and change of the weights."""
         if self.training:
             self.effective_precision, self.probe_error, self.probe_errors = "f32", None, {}
-            return pack.pack_flow(dict(desc, precision="f32"))
+            return "f32"
         fingerprint = self._fingerprint()
-        images = {"f32": pack.pack_flow(dict(desc, precision="f32"))}
         n, d = self.AUTO_PROBE_ROWS, self.features
         self.probe_errors = {}
         chosen = "f32"
-        with torch.inference_mode(False), torch.no_grad():
-            z = torch.randn(n, d, generator=torch.Generator().manual_seed(20260930)).to(device)
-            status = torch.zeros(4, dtype=torch.int32, device=device)
-            log_pz = -0.5 * (z.double() ** 2).sum(dim=1) - 0.5 * d * math.log(2.0 * math.pi)
+        z = torch.randn(n, d, generator=torch.Generator().manual_seed(20260930)).to(device)
+        status = torch.zeros(4, dtype=torch.int32, device=device)
+        log_pz = -0.5 * (z.double() ** 2).sum(dim=1) - 0.5 * d * math.log(2.0 * math.pi)
 
-            def run(image, z_in, x_fwd=None):
-                header = (lib.ctypes.c_uint32 * pack.HEADER_WORDS)(*image[: pack.HEADER_WORDS].tolist())
-                header_t = ops.header_tensor(header)
-                image_dev = torch.from_numpy(image.view(np.int32)).to(device)
-                x, ld = torch.ops.nessai_amd.flow_run(z_in, image_dev, header_t, DIR_INVERSE, MODE_APPLY, True, status,
-                                                      self.waves_per_group, self.max_groups)
-                over = int(status[1].item())
-                _, lp = torch.ops.nessai_amd.flow_run(x if x_fwd is None else x_fwd, image_dev, header_t, DIR_FORWARD,
-                                                      MODE_LOGPROB, False, status, self.waves_per_group,
-                                                      self.max_groups)
-                over += int(status[1].item())
-                return x, ld.double(), lp.double(), over
+        def run(precision, z_in, x_fwd=None):
+            _, header_t, image_dev = images.get(precision)
+            x, ld = torch.ops.nessai_amd.flow_run(z_in, image_dev, header_t, DIR_INVERSE, MODE_APPLY, True, status,
+                                                  self.waves_per_group, self.max_groups)
+            over = status[1:2].clone()
+            _, lp = torch.ops.nessai_amd.flow_run(x if x_fwd is None else x_fwd, image_dev, header_t, DIR_FORWARD,
+                                                  MODE_LOGPROB, False, status, self.waves_per_group,
+                                                  self.max_groups)
+            return x, ld.double(), lp.double(), over + status[1:2]
 
-            def rel(a, b, scale):
-                return float(((a - b).abs() / scale.abs().clamp_min(1e-3)).max())
+        def rel(a, b, scale):
+            return ((a - b).abs() / scale.abs().clamp_min(1e-3)).max()
 
-            ref = noise = None
-            for p in auto_candidates(self):
-                if p == "f16x3" and self._f16_blocked == fingerprint:
-                    continue
-                try:
-                    images[p] = pack.pack_flow(dict(desc, precision=p))
-                except ValueError:  # a weight beyond the f16 range
-                    continue
-                if ref is None:
-                    ref = run(images["f32"], z)
-                x32, ld32, lp32, _ = ref
-                _, ld, lp, over = run(images[p], z, x_fwd=x32)
-                log_q32 = log_pz - ld32
-                err = max(rel(ld, ld32, log_q32), rel(lp, lp32, lp32))
-                self.probe_errors[p] = err
-                bar = self.AUTO_PROBE_BAR
-                if p == "f16x3" and over == 0 and math.isfinite(err) and err > bar:
-                    if noise is None:  # the float32 kernel against itself, inputs one ulp further out
-                        inf = torch.full_like(z, math.inf)
-                        _, ld_n, lp_n, _ = run(images["f32"], torch.nextafter(z, inf * z.sign()),
-                                               x_fwd=torch.nextafter(x32, inf * x32.sign()))
-                        noise = max(rel(ld_n, ld32, log_q32), rel(lp_n, lp32, lp32))
-                        self.probe_errors["f32_one_ulp"] = noise
-                    if math.isfinite(noise):
-                        bar = max(bar, self.AUTO_NOISE_FACTOR * noise)
-                if over == 0 and math.isfinite(err) and err <= bar:
-                    chosen = p
-                    break
+        ref = noise = None
+        for p in auto_candidates(self):
+            if p == "f16x3" and self._f16_blocked == fingerprint:
+                continue
+            try:
+                images.get(p)
+            except ValueError:  # a weight beyond the f16 range
+                continue
+            if ref is None:
+                ref = run("f32", z)
+            x32, ld32, lp32, _ = ref
+            _, ld, lp, over = run(p, z, x_fwd=x32)
+            log_q32 = log_pz - ld32
+            err, over = [float(v) for v in torch.stack([torch.maximum(rel(ld, ld32, log_q32), rel(lp, lp32, lp32)),
+                                                       over[0].double()]).tolist()]  # one read-back
+            self.probe_errors[p] = err
+            bar = self.AUTO_PROBE_BAR
+            if p == "f16x3" and over == 0 and math.isfinite(err) and err > bar:
+                if noise is None:  # the float32 kernel against itself, inputs one ulp further out
+                    inf = torch.full_like(z, math.inf)
+                    _, ld_n, lp_n, _ = run("f32", torch.nextafter(z, inf * z.sign()),
+                                           x_fwd=torch.nextafter(x32, inf * x32.sign()))
+                    noise = float(torch.maximum(rel(ld_n, ld32, log_q32), rel(lp_n, lp32, lp32)))
+                    self.probe_errors["f32_one_ulp"] = noise
+                if math.isfinite(noise):
+                    bar = max(bar, self.AUTO_NOISE_FACTOR * noise)
+            if over == 0 and math.isfinite(err) and err <= bar:
+                chosen = p
+                break
         self.effective_precision = chosen
         errs = [v for k, v in self.probe_errors.items() if k in pack.PRECISIONS]
         self.probe_error = self.probe_errors.get(chosen, max(errs, default=None))
-        return images[chosen]
+        return chosen
 
     def note_f16_overflow(self):
         """A split-f16 call on the current weights left the f16 range: ``"auto"`` stops choosing the mode
@@ -494,6 +492,82 @@ class HipFlow(BaseFlow):
 
     def unfreeze_transform(self):
         self._transform.requires_grad_(True)
+
+
+class _ImageSource:
+    """Device images of one flow at its CURRENT weights, per precision: ``get(precision)`` returns
+    ``(header, header tensor, image tensor)``.
+
+    The first image of a (structure, precision) is packed on the host (``pack.pack_flow``); for a flow of
+    couplings and permutations - whose image words are constants or plain (split) copies of parameters -
+    every later one is rebuilt ON THE DEVICE from the flat parameter vector by one gather launch
+    (``nsa_repack_image`` with the map of ``pack.repack_map``, built the second time the structure is
+    seen).  The images and maps live on the flow (``flow._repack``) across changes of the weights; the
+    structure key holds what the constants depend on: the permutations and train / eval mode."""
+
+    def __init__(self, flow, device, epoch):
+        self.flow, self.device, self.epoch = flow, device, epoch
+        self._desc = None
+        self._params = None
+        store = flow.__dict__.setdefault("_repack", {})
+        perms = tuple((b.data_ptr(), b._version) for name, b in flow.named_buffers() if name.endswith("_permutation"))
+        self.structure = (str(device), flow.training, perms)
+        for key in [k for k in store if k[0] != self.structure]:
+            del store[key]  # another structure: its images are of no use any more
+        self.store = store
+
+    def desc(self):
+        if self._desc is None:
+            self._desc = M.describe(self.flow)
+        return self._desc
+
+    def params(self):
+        """The flat float32 parameter vector on the device (the trainer's own buffer when the Parameters are
+        views of it in order - no copy)."""
+        if self._params is None:
+            ps = list(self.flow.parameters())
+            base, at, flat = ps[0].data_ptr(), 0, True
+            for p in ps:
+                flat = flat and p.dtype == torch.float32 and p.is_contiguous() and p.data_ptr() == base + 4 * at
+                at += p.numel()
+            trainer = self.flow.__dict__.get("_trainer")
+            if flat and trainer is not None and trainer.params.data_ptr() == base and trainer.params.numel() == at:
+                self._params = trainer.params
+            else:
+                self._params = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in ps])
+        return self._params
+
+    def get(self, precision):
+        key = (self.structure, precision)
+        entry = self.store.get(key)
+        flow = self.flow
+        if entry is not None and entry["epoch"] == self.epoch:  # built for these weights (e.g. by the probe)
+            return entry["header"], entry["header_t"], entry["image"]
+        pure = flow.__dict__.get("_repack_pure")
+        if entry is not None and pure is not False and os.environ.get("NESSAI_AMD_DEVICE_REPACK", "1") != "0":
+            if "map" not in entry:
+                try:
+                    pos, e0, e1, kind = pack.repack_map(lambda off: M.describe(flow, index_offset=off), precision)
+                    entry["map"] = tuple(torch.from_numpy(a).to(self.device) for a in (pos, e0, e1, kind))
+                    flow.__dict__["_repack_pure"] = True
+                except ValueError:  # LU-linear / batch norm / act norm: derived image words
+                    flow.__dict__["_repack_pure"] = pure = False
+            if pure is not False:
+                pos, e0, e1, kind = entry["map"]
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                rc = lib.load().nsa_repack_image(
+                    pos.numel(), lib.ptr(pos), lib.ptr(e0), lib.ptr(e1), lib.ptr(kind), lib.ptr(self.params()),
+                    pack.PRECISIONS[precision], lib.ptr(entry["image"]), lib.c_void_p(stream),
+                )
+                lib.check(rc, "nsa_repack_image")
+                entry["epoch"] = self.epoch
+                return entry["header"], entry["header_t"], entry["image"]
+        image = pack.pack_flow(dict(self.desc(), precision=precision))
+        header = (lib.ctypes.c_uint32 * pack.HEADER_WORDS)(*image[: pack.HEADER_WORDS].tolist())
+        entry = dict(header=header, header_t=ops.header_tensor(header),
+                     image=torch.from_numpy(image.view(np.int32)).to(self.device), epoch=self.epoch)
+        self.store[key] = entry
+        return entry["header"], entry["header_t"], entry["image"]
 
 
 def _no_context(context):

@@ -360,12 +360,29 @@ def _np(t):
     return t.detach().to(torch.float32).cpu().numpy()
 
 
-def describe(flow):
+def describe(flow, index_offset=None):
     """Module tree -> flow description for ``nessai_amd.pack.pack_flow``.
 
     Duck-typed on attribute names, so any module tree with the reference's
     structure can be described.
+
+    ``index_offset``: describe the flow's STRUCTURE instead - every conditioner weight / bias array holds
+    ``index_offset +`` the positions of its elements in the flat vector of ``flow.parameters()`` (float32),
+    for ``nessai_amd.pack.repack_map``; a flow with LU-linear / batch-norm / act-norm transforms, whose image
+    words are not plain copies of parameters, raises ``ValueError``.
     """
+    offsets = None
+    if index_offset is not None:
+        offsets, at = {}, 0
+        for p in flow.parameters():
+            offsets[id(p)] = at
+            at += p.numel()
+
+    def values(p):
+        if offsets is None:
+            return _np(p)
+        return (np.arange(p.numel(), dtype=np.float64).reshape(tuple(p.shape)) + (offsets[id(p)] + index_offset)).astype(np.float32)
+
     leaves = flatten_transforms(flow._transform)
     desc = dict(transforms=[])
     coupling = None
@@ -374,6 +391,8 @@ def describe(flow):
         if hasattr(t, "_permutation"):
             desc["transforms"].append(("permutation", t._permutation.detach().cpu().numpy()))
         elif hasattr(t, "lower_entries"):
+            if offsets is not None:
+                raise ValueError("the image words of an LU-linear transform are not copies of parameters")
             if hasattr(t, "host_matrices"):
                 W, W_inv, bias, ld = t.host_matrices()
             else:  # structurally identical foreign module (tests)
@@ -444,10 +463,12 @@ def describe(flow):
                     "coupling",
                     t.identity_features.detach().cpu().numpy().tolist(),
                     t.transform_features.detach().cpu().numpy().tolist(),
-                    [(_np(l.weight), _np(l.bias)) for l in layers],
+                    [(values(l.weight), values(l.bias)) for l in layers],
                 )
             )
         elif hasattr(t, "running_var") or hasattr(t, "log_scale"):
+            if offsets is not None:
+                raise ValueError("the image words of a batch-norm / act-norm transform are not copies of parameters")
             if hasattr(t, "host_tables"):
                 fwd, inv = t.host_tables()
             elif hasattr(t, "running_var"):

@@ -59,6 +59,12 @@ SIGNATURES = {
          c_void_p, c_ll, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_int, c_int, c_void_p,
          ctypes.POINTER(PostRules)],
     ),
+    "nsa_populate_passes_small": (
+        c_int,
+        [c_void_p, c_void_p, c_ll, c_int, c_ull, c_ull, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_ll, c_void_p,
+         c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(PostRules)],
+    ),
     "nsa_populate_pass_head": (
         c_int,
         [c_void_p, c_void_p, c_ll, c_ull, c_ull, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -84,6 +90,7 @@ SIGNATURES = {
     ),
     "nsa_populate_train_commit": (c_int, [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsa_populate_sumexp": (c_int, [c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsa_repack_image": (c_int, [c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "nsa_importance_draw": (
         c_int,
         [c_void_p, c_void_p, c_ll, c_void_p, c_ull, c_ull, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

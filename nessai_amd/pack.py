@@ -206,10 +206,13 @@ def pack_matrix_bf16(weight, out_rows, in_cols, split=split_bf16):
     return np.ascontiguousarray(parts).reshape(-1).view(np.uint32)
 
 
-def _pack_matrix16(precision):
-    """Packer of the 16-bit A operands of ``precision``."""
-    if precision == "f16x3":
-        return lambda w, out_rows, in_cols: pack_matrix_bf16(w, out_rows, in_cols, split=split_f16)
+def _pack_matrix16(precision, split=None):
+    """Packer of the 16-bit A operands of ``precision`` (``split``: another splitter, see
+    ``repack_map``)."""
+    if split is None and precision == "f16x3":
+        split = split_f16
+    if split is not None:
+        return lambda w, out_rows, in_cols: pack_matrix_bf16(w, out_rows, in_cols, split=split)
     return pack_matrix_bf16
 
 
@@ -288,7 +291,7 @@ class _CouplingBlobs:
         self.n_chunks = (self.d_tr + 2 * fpc - 1) // (2 * fpc)
         self.fpc = fpc
         if bf16:
-            pack_w = _pack_matrix16(desc["precision"])
+            pack_w = _pack_matrix16(desc["precision"], desc.get("_split16"))
             reg_cols = _reg_in_cols16(ht, hidden)
         else:
             pack_w = pack_matrix
@@ -430,7 +433,7 @@ def pack_flow(desc):
                     post = np.asarray(bias, dtype=np.float32)
                     ld = np.float32(logabsdet)
                 out_rows = _plain_out_rows(n_ot, D)
-                pack_w = _pack_matrix16(precision) if bf16 else pack_matrix
+                pack_w = _pack_matrix16(precision, desc.get("_split16")) if bf16 else pack_matrix
                 blob = _stage(in_tab, pre, pack_bias(post, out_rows), pack_w(mat, out_rows, in_cols))
                 stages.append(add_blob(blob))
                 ops.append([OP_DENSE, n_steps, n_ot, _f32_bits(ld)])
@@ -566,3 +569,94 @@ def pack_flow(desc):
     for i, blob in enumerate(blobs):
         img[blob_offsets[i] : blob_offsets[i] + len(blob)] = blob
     return img
+
+
+# ---------------------------------------------------------------------------
+# Re-packing on the device
+# ---------------------------------------------------------------------------
+# The image of a flow whose transforms are couplings and permutations only is, apart from its weights
+# and biases, a function of the flow's STRUCTURE: every parameter word is either one float32 parameter or
+# the hi / lo halves of two parameters, everything else (header, tables, padding) is constant.  After a
+# training run the image is therefore rebuilt on the device by a gather (``nsa_repack_image``: ~0.5 M
+# words, one launch) instead of on the host (16 ms for the float32 image of config 3, 33 ms for the
+# split-f16 one, plus the copy of the weights to the host and of the image back - per precision the
+# ``auto`` policy probes, inside the first ``populate`` after every ``train``).
+
+REPACK_F32, REPACK_PAIR_HI, REPACK_PAIR_LO = 1, 2, 3
+_INDEX_A, _INDEX_B = 1, 1 + 32768 + 1  # two index offsets whose low AND high 15 bits differ for every index
+
+
+def _split_index(x):
+    """Stand-in for ``split_f16`` / ``split_bf16`` when the "weights" are parameter indices: the low 15 bits
+    travel in the hi part (bit 15 clear), the next 15 bits in the lo part with bit 15 set as a tag."""
+    idx = np.ascontiguousarray(x, dtype=np.float32).astype(np.int64)
+    if idx.size and (idx.min() < 0 or idx.max() >= 1 << 30):
+        raise ValueError("parameter index out of range")
+    return (idx & 0x7FFF).astype(np.uint16), (((idx >> 15) & 0x7FFF) | 0x8000).astype(np.uint16)
+
+
+def repack_map(index_desc, precision):
+    """Where the parameters sit in the image of ``precision``.
+
+    ``index_desc(offset)`` must return the flow description with every weight / bias array replaced by
+    ``offset + (index of the parameter in the flow's flat parameter vector)`` as float32 (exact below
+    2^24).  Packing it twice with different offsets marks the parameter words (they differ) and spells
+    their indices out.  Returns ``(pos, e0, e1, kind)`` int32 / uint8 arrays, one entry per parameter
+    word: image word ``pos`` is float32 parameter ``e0`` (``REPACK_F32``), or the hi (``REPACK_PAIR_HI``)
+    / lo (``REPACK_PAIR_LO``) halves of parameters ``e0`` (low halfword) and ``e1`` (high halfword);
+    an index of -1 is a padding element (zero)."""
+    if precision not in PRECISIONS:
+        raise ValueError(f"unknown precision {precision!r}")
+    extra = {"_split16": _split_index} if precision in SPLIT16 else {}
+    img_a = pack_flow(dict(index_desc(_INDEX_A), precision=precision, **extra))
+    img_b = pack_flow(dict(index_desc(_INDEX_B), precision=precision, **extra))
+    if img_a.shape != img_b.shape:
+        raise RuntimeError("index images of different sizes")
+    changed = img_a != img_b
+
+    def f32_index(words):
+        return np.rint(words.view(np.float32).astype(np.float64)).astype(np.int64) - _INDEX_A
+
+    if precision not in SPLIT16:
+        pos = np.nonzero(changed)[0]
+        e0 = f32_index(img_a[pos])
+        return (pos.astype(np.int32), e0.astype(np.int32), np.full(len(pos), -1, np.int32),
+                np.full(len(pos), REPACK_F32, np.uint8))
+    lo_pos = np.nonzero(changed & ((img_a & 0x80008000) == 0x80008000))[0]  # tagged: the lo-part words
+    hi_pos = lo_pos - 256  # [part][64 lanes][4 words]: the hi part of the same elements
+    if len(lo_pos) and (hi_pos.min() < 0 or not changed[hi_pos].all()):
+        raise RuntimeError("split-16 weight blocks are not laid out as [hi | lo] pairs of 256 words")
+    low, high = img_a[hi_pos].astype(np.int64), img_a[lo_pos].astype(np.int64)
+    e0 = (((high & 0x7FFF) << 15) | (low & 0x7FFF)) - _INDEX_A
+    e1 = ((((high >> 16) & 0x7FFF) << 15) | ((low >> 16) & 0x7FFF)) - _INDEX_A
+    e0[e0 < 0] = -1
+    e1[e1 < 0] = -1
+    pair = np.zeros(len(img_a), dtype=bool)
+    pair[hi_pos] = True
+    pair[lo_pos] = True
+    f_pos = np.nonzero(changed & ~pair)[0]
+    pos = np.concatenate([hi_pos, lo_pos, f_pos])
+    return (pos.astype(np.int32),
+            np.concatenate([e0, e0, f32_index(img_a[f_pos])]).astype(np.int32),
+            np.concatenate([e1, e1, np.full(len(f_pos), -1, np.int64)]).astype(np.int32),
+            np.concatenate([np.full(len(hi_pos), REPACK_PAIR_HI, np.uint8), np.full(len(lo_pos), REPACK_PAIR_LO, np.uint8),
+                            np.full(len(f_pos), REPACK_F32, np.uint8)]))
+
+
+def apply_repack_map(image, repack, params, precision):
+    """Host emulation of ``nsa_repack_image`` (tests): ``image`` with its parameter words rebuilt from the
+    flat float32 vector ``params``."""
+    pos, e0, e1, kind = repack
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    a = np.where(e0 >= 0, params[np.maximum(e0, 0)], np.float32(0.0)).astype(np.float32)
+    b = np.where(e1 >= 0, params[np.maximum(e1, 0)], np.float32(0.0)).astype(np.float32)
+    out = np.array(image, dtype=np.uint32, copy=True)
+    f = kind == REPACK_F32
+    out[pos[f]] = a[f].view(np.uint32)
+    if precision in SPLIT16:
+        split = split_f16 if precision == "f16x3" else split_bf16
+        (ah, al), (bh, bl) = split(a), split(b)
+        for code, (x, y) in ((REPACK_PAIR_HI, (ah, bh)), (REPACK_PAIR_LO, (al, bl))):
+            m = kind == code
+            out[pos[m]] = x[m].astype(np.uint32) | (y[m].astype(np.uint32) << 16)
+    return out

@@ -75,6 +75,10 @@ class FlowProposal:
         Keep the loop control of ``populate`` on the device (``nsa_populate_passes``): several
         passes are enqueued per host synchronisation and surplus ones switch themselves off.
         Results are identical to ``False`` (one pass per synchronisation).
+    small_trains : bool
+        Passes of at most 16384 rows (the reference's default ``drawsize = nlive``): run a whole train
+        of them as one draw launch plus two tail launches (``nsa_populate_passes_small``) instead of
+        three launches per pass.  Results are identical to ``False``.
     precision : {'auto', 'f32', 'bf16x3', 'f16x3'}
         Arithmetic of the conditioner GEMMs inside the fused draw kernel.
         ``'auto'`` uses the fastest 16-bit matrix-core mode (split-bf16, then split-f16) that is
@@ -120,6 +124,7 @@ class FlowProposal:
         shard=False,
         precision="auto",
         pass_trains=True,
+        small_trains=True,
         reparameterisations=None,
         fallback_reparameterisation="z-score",
         plot=False,
@@ -165,6 +170,7 @@ class FlowProposal:
             raise ValueError("likelihood must be 'auto', 'device' or 'host'")
         self._likelihood_mode = likelihood
         self.shard = shard
+        self.small_trains = bool(small_trains)
         self._status_hold = False
         #: which loop the last ``populate`` ran: "trains" (device-side loop control), "trains_sharded",
         #: "accumulate" (device arena), "accumulate_host" or "passes" (one synchronisation per pass)
@@ -279,6 +285,10 @@ class FlowProposal:
         )
         self.flow.initialise()
         self.device = self.flow.device
+        # the proposal's precision policy applies to every call it makes through the flow - the forward pass of
+        # the adaptive radius, forward_pass / backward_pass - from the start, not from the first populate on
+        # (a resumed proposal must reproduce the numbers of the one that was pickled)
+        self.flow.model.precision = self.precision
         mode = self._prior_mode
         has_device_prior = getattr(self.model, "uniform_prior", False) or (
             getattr(self.model, "device_prior", None) is not None
@@ -671,8 +681,11 @@ class FlowProposal:
         matrix products stays inside the f16 range; a population that left it (reported by the
         kernel, checked once per call) is discarded and drawn again with the mode switched off for
         the current weights (``precision="auto"``) or raises (``precision="f16x3"``)."""
-        if self.initialised and self.flow.model._status is not None:
-            self.flow.model._status.zero_()
+        if self.initialised:
+            if self.flow.model.precision != self.precision:  # (a flow rebuilt by reset_model)
+                self.flow.model.precision = self.precision
+            if self.flow.model._status is not None:
+                self.flow.model._status.zero_()
         self._status_hold = True
         try:
             self._populate(worst_point, n_samples, plot, r, max_samples, injected)
@@ -805,24 +818,50 @@ class FlowProposal:
         per_pass = (self.population_acceptance or 0.0) * n
         n_accepted = passes = 0
         rules = self._device_rules()
+        small = n <= 16384 and self.small_trains
         while True:
             remaining = n_samples - n_accepted
             train = 1 if per_pass <= 0 else int(np.ceil(1.15 * remaining / per_pass))
             train = max(1, min(train, max_train, int(state_h[5]) - passes))
-            buf["max_keys"][:train].fill_(key_init)
-            rc = L.nsa_populate_passes(
-                header, lib.ptr(image), n, train, self.device_seed, int(self._draw_counter + passes * n),
-                float(threshold), float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev),
-                lib.ptr(self._shift_dev), lib.ptr(self._lower_dev), lib.ptr(self._upper_dev),
-                float(self._log_j_rescale), lib.ptr(buf["x64"]), lib.ptr(buf["log_q"]),
-                lib.ptr(self._prior_kind_dev), lib.ptr(self._prior_par_dev),
-                lib.ptr(buf["log_p"] if separable else None), float(log_prior_const),
-                lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), lib.ptr(buf["log_w"]),
-                lib.ptr(buf["max_keys"]), n_samples, lib.ptr(buf["x_acc"]), lib.ptr(buf["state"]),
-                lib.ptr(buf["workspace"]), buf["ws_bytes"], lib.ptr(status), flow.waves_per_group,
-                flow.max_groups, stream, rules,
-            )
-            lib.check(rc, "nsa_populate_passes")
+            if small:
+                # small passes (the reference's default drawsize = nlive): the whole train as ONE draw launch over
+                # train * n rows + two tail launches - a pass of 2000 rows is a ~40 us dependent chain through the
+                # flow however few rows it has, and sixty of them in a row were the whole populate call
+                if buf.get("small_passes", 0) < train:
+                    stage_rows = min(n, n_samples)
+                    buf["x64_small"] = torch.empty((train * n, self.dims), dtype=torch.float64, device=dev)
+                    buf["log_q_small"] = torch.empty(train * n, dtype=torch.float64, device=dev)
+                    buf["log_p_small"] = torch.empty(train * n if separable else 1, dtype=torch.float64, device=dev)
+                    buf["stage_small"] = torch.empty((train, stage_rows, self.dims), dtype=torch.float64, device=dev)
+                    buf["counts_small"] = torch.zeros(train, dtype=torch.int64, device=dev)
+                    buf["small_passes"] = train
+                rc = L.nsa_populate_passes_small(
+                    header, lib.ptr(image), n, train, self.device_seed, int(self._draw_counter + passes * n),
+                    float(threshold), float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev),
+                    lib.ptr(self._shift_dev), lib.ptr(self._lower_dev), lib.ptr(self._upper_dev),
+                    float(self._log_j_rescale), lib.ptr(buf["x64_small"]), lib.ptr(buf["log_q_small"]),
+                    lib.ptr(self._prior_kind_dev), lib.ptr(self._prior_par_dev),
+                    lib.ptr(buf["log_p_small"] if separable else None), float(log_prior_const),
+                    lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), buf["stage_small"].shape[1],
+                    lib.ptr(buf["stage_small"]), lib.ptr(buf["counts_small"]), n_samples, lib.ptr(buf["x_acc"]),
+                    lib.ptr(buf["state"]), lib.ptr(status), flow.waves_per_group, flow.max_groups, stream, rules,
+                )
+                lib.check(rc, "nsa_populate_passes_small")
+            else:
+                buf["max_keys"][:train].fill_(key_init)
+                rc = L.nsa_populate_passes(
+                    header, lib.ptr(image), n, train, self.device_seed, int(self._draw_counter + passes * n),
+                    float(threshold), float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev),
+                    lib.ptr(self._shift_dev), lib.ptr(self._lower_dev), lib.ptr(self._upper_dev),
+                    float(self._log_j_rescale), lib.ptr(buf["x64"]), lib.ptr(buf["log_q"]),
+                    lib.ptr(self._prior_kind_dev), lib.ptr(self._prior_par_dev),
+                    lib.ptr(buf["log_p"] if separable else None), float(log_prior_const),
+                    lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), lib.ptr(buf["log_w"]),
+                    lib.ptr(buf["max_keys"]), n_samples, lib.ptr(buf["x_acc"]), lib.ptr(buf["state"]),
+                    lib.ptr(buf["workspace"]), buf["ws_bytes"], lib.ptr(status), flow.waves_per_group,
+                    flow.max_groups, stream, rules,
+                )
+                lib.check(rc, "nsa_populate_passes")
             state_h.copy_(buf["state"])  # the train's one synchronisation
             n_accepted, passes = int(state_h[0]), int(state_h[1])
             if n_accepted >= n_samples:

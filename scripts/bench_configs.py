@@ -27,6 +27,61 @@ from nessai_amd.proposal import FlowProposal  # noqa: E402
 from oracle import proposal as OP  # noqa: E402
 
 
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0}  # dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_HBM_TBS = 8.0
+
+
+def flops_per_row(flow):
+    """Algorithmic conditioner FLOPs per row of one pass through ``flow`` (GEMMs only,
+    one product per weight): every Linear layer of every conditioner plus the LU-linear products."""
+    from nessai_amd.flows import modules as M
+
+    total = 0
+    for m in flow.modules():
+        if isinstance(m, torch.nn.Linear):
+            total += 2 * m.in_features * m.out_features
+        elif isinstance(m, M.LULinear):
+            total += 2 * flow.features * flow.features
+    return total
+
+
+def kernel_roofline(flow, precision, rows, kernel_ms, bytes_per_row, bound):
+    """SURVEY.md section 8d for one launch: achieved TFLOP/s against the mode's dense MFMA peak AND achieved
+    algorithmic GB/s against HBM; ``bound`` names the one the contract assigns to this config."""
+    flops = flops_per_row(flow)
+    tf = flops * rows / (kernel_ms * 1e-3) / 1e12
+    tbs = bytes_per_row * rows / (kernel_ms * 1e-3) / 1e12
+    frac_mfma, frac_hbm = tf / PEAK_TFLOPS[precision], tbs / PEAK_HBM_TBS
+    return {
+        "bound": bound, "kernel_ms_avg": kernel_ms, "rows_per_launch": rows, "precision": precision,
+        "flops_per_row": flops, "bytes_per_row": bytes_per_row,
+        "achieved_tflops": tf, "peak_tflops": PEAK_TFLOPS[precision], "frac_mfma": frac_mfma,
+        "achieved_tb_per_s": tbs, "peak_tb_per_s": PEAK_HBM_TBS, "frac_hbm": frac_hbm,
+        "achieved": tbs * 1e3 if bound == "hbm" else tf, "peak": PEAK_HBM_TBS * 1e3 if bound == "hbm" else PEAK_TFLOPS[precision],
+        "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": frac_hbm if bound == "hbm" else frac_mfma,
+        "traffic": None,
+    }
+
+
+def time_draw(prop, n, launches=8):
+    """Average duration of the fused draw kernel on ``n`` rows (HIP events on the launch stream)."""
+    buf = prop._get_buffers(n, prop.poolsize)
+    prepared = prop._prepare_flow()
+    log_p = buf["log_p"] if prop._prior_kind_dev is not None else None
+    for _ in range(2):
+        prop._launch_draw(n, None, 0, prop.r, buf["x64"], buf["log_q"], None, log_prior=log_p, prepared=prepared)
+    torch.cuda.synchronize()
+    events = []
+    for i in range(launches):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        prop._launch_draw(n, None, (i + 1) * n, prop.r, buf["x64"], buf["log_q"], None, log_prior=log_p, prepared=prepared)
+        b.record()
+        events.append((a, b))
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+
 def live_points(model, nlive, n_prior, rng):
     pts = model.new_point(n_prior, rng=rng)
     logl = model.log_likelihood(pts)
@@ -34,7 +89,7 @@ def live_points(model, nlive, n_prior, rng):
     return pts[np.argsort(logl)[-nlive:]]
 
 
-def run(tag, model, flow_config, nlive, drawsize, steps=5, cpu_draw=50_000):
+def run(tag, model, flow_config, nlive, drawsize, steps=5, cpu_draw=50_000, bound="mfma"):
     rng = np.random.default_rng(1451)
     torch.manual_seed(1451)
     live = live_points(model, nlive, 40 * nlive, rng)
@@ -57,6 +112,14 @@ def run(tag, model, flow_config, nlive, drawsize, steps=5, cpu_draw=50_000):
             prop_n += prop.n_proposed
         torch.cuda.synchronize()
         gpu_s = time.perf_counter() - t
+        # the dominant kernel by itself: x as float64 + log_q (+ the per-row log prior of a separable prior) out,
+        # nothing in (the latents are generated on-chip)
+        precision = prop.flow.model.effective_precision
+        kernel_ms = time_draw(prop, drawsize)
+        bytes_per_row = 8 * model.dims + 8 + (8 if prop._prior_kind_dev is not None else 0)
+        roofline = kernel_roofline(prop.flow.model, precision, drawsize, kernel_ms, bytes_per_row, bound)
+        roofline["kernel"] = "nsa_flow_kernel (fused draw + inverse flow + rescale + bounds + log_q)"
+        roofline["passes_per_populate"] = prop_n / drawsize / steps
         state = {k: v.detach().cpu() for k, v in prop.flow.model.state_dict().items()}
         # CPU oracle, one thread, one bounded pass
         torch.set_num_threads(1)
@@ -73,7 +136,8 @@ def run(tag, model, flow_config, nlive, drawsize, steps=5, cpu_draw=50_000):
         cpu_s = time.perf_counter() - t
     out = {
         "config": tag, "nlive": nlive, "drawsize": drawsize,
-        "precision": prop.flow.model.effective_precision,
+        "precision": precision, "probe_rel_errs": prop.flow.model.probe_errors,
+        "roofline": roofline,
         "gpu_train_seconds": train_s,
         "gpu_accepted_per_s": acc / gpu_s, "gpu_rows_per_s": prop_n / gpu_s,
         "gpu_acceptance": acc / prop_n, "gpu_ms_per_populate": 1e3 * gpu_s / steps,
@@ -101,6 +165,24 @@ def run_c4(n_flows_list=(1, 8), n=5000, dims=64):
                 lp = ifm.log_prob_all(x)
             torch.cuda.synchronize()
             gpu_s = (time.perf_counter() - t) / 5
+            # the grouped launch by itself on device tensors (HIP events), against both roofs
+            from nessai_amd.flows.base import log_prob_many
+
+            xd = torch.from_numpy(x).to(torch.float32).to(ifm.models[0]._device())
+            log_prob_many(ifm.models, xd)
+            torch.cuda.synchronize()
+            ev = []
+            for _ in range(8):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                log_prob_many(ifm.models, xd)
+                b.record()
+                ev.append((a, b))
+            torch.cuda.synchronize()
+            k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            roof = kernel_roofline(ifm.models[0], ifm.models[0].effective_precision, n * target, k_ms,
+                                   4 * dims / target + 4, "mfma")
+            roof["kernel"] = f"nsa_flow_kernel, forward + log_prob, grouped over {target} flows (nsa_flow_run_many)"
             torch.set_num_threads(1)
             ofm = OP.OracleFlowModel(dict(n_inputs=dims, n_neurons=128, n_blocks=6, n_layers=2, ftype="nsf"))
             ofm.model.load_state_dict({k: v.cpu() for k, v in ifm.models[0].state_dict().items()})
@@ -109,6 +191,7 @@ def run_c4(n_flows_list=(1, 8), n=5000, dims=64):
             cpu_one = time.perf_counter() - t
             err = float(np.max(np.abs(lp[:, 0] - ref) / np.maximum(np.abs(ref), 1.0)))
             print(json.dumps({"config": "C4 log_prob_all 64-D NSF", "n_flows": target, "rows": n,
+                              "precision": ifm.models[0].effective_precision, "roofline": roof,
                               "gpu_ms": 1e3 * gpu_s, "cpu_ms_estimate": 1e3 * cpu_one * target,
                               "speedup": cpu_one * target / gpu_s, "log_prob_rel_err_flow0": err}), flush=True)
 
@@ -151,10 +234,15 @@ def run_c4_draw(n_flows_list=(1, 8, 32), nlive=5000, dims=64):
 
 
 if __name__ == "__main__":
+    # the fused affine flow of config 2 is HBM-bound by contract (132-136 B per row against
+    # 41 kFLOP); the spline flows are MFMA-bound
     run("C2 16-D Gaussian RealNVP (LU+BN), drawsize=nlive", GaussianModel(16),
-        dict(ftype="realnvp", n_neurons=32, n_blocks=4, n_layers=2), 2000, 2000, cpu_draw=2000)
+        dict(ftype="realnvp", n_neurons=32, n_blocks=4, n_layers=2), 2000, 2000, cpu_draw=2000, bound="hbm")
     run("C2 16-D Gaussian RealNVP (LU+BN), drawsize=1e6", GaussianModel(16),
-        dict(ftype="realnvp", n_neurons=32, n_blocks=4, n_layers=2), 2000, 1_000_000, cpu_draw=100_000)
+        dict(ftype="realnvp", n_neurons=32, n_blocks=4, n_layers=2), 2000, 1_000_000, cpu_draw=100_000, bound="hbm")
+    run("C2 16-D Gaussian RealNVP (MLP conditioner), drawsize=1e6", GaussianModel(16),
+        dict(ftype="realnvp", n_neurons=32, n_blocks=4, n_layers=2, net="mlp"), 2000, 1_000_000, cpu_draw=100_000,
+        bound="hbm")
     run("C5 15-D GW surrogate NSF", GWSurrogateModel(),
         dict(ftype="nsf", n_neurons=30, n_blocks=4, n_layers=2), 4000, 1_000_000, cpu_draw=100_000)
     run_c4()

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     g = np.random.default_rng(args.seed)
-    bad, worst, borderline, chosen = [], 0.0, 0, {"f32": 0, "bf16x3": 0}
+    bad, worst, borderline, chosen = [], 0.0, 0, {"f32": 0, "bf16x3": 0, "f16x3": 0}
     for it in range(args.iterations):
         ftype = "nsf" if g.random() < 0.65 else "realnvp"
         dims = int(g.integers(2, 41))

@@ -490,12 +490,17 @@ def test_device_likelihood_equals_host_likelihood(which):
     assert np.array_equal(dev.samples["logL"], model.log_likelihood(dev.samples))
 
 
-@pytest.mark.parametrize("case", ["c3_fixture", "small_batches", "max_samples", "separable_prior"])
+@pytest.mark.parametrize("case", ["c3_fixture", "small_batches", "max_samples", "separable_prior",
+                                  "small_batches_pass_by_pass", "separable_prior_pass_by_pass"])
 def test_pass_trains_equal_one_pass_at_a_time(case):
-    """nsa_populate_passes (loop control on the device, several passes per host synchronisation)
-    reproduces the one-pass-per-synchronisation loop exactly: rows, order, counters, Philox use."""
+    """nsa_populate_passes (loop control on the device, several passes per host synchronisation) and, for
+    passes of <= 16384 rows, nsa_populate_passes_small (a whole train as one draw launch + two tail launches;
+    the ..._pass_by_pass cases switch it off) reproduce the one-pass-per-synchronisation loop exactly: rows,
+    order, counters, Philox use."""
     from nessai_amd.model import GWSurrogateModel
 
+    small = not case.endswith("_pass_by_pass")
+    case = case.replace("_pass_by_pass", "")
     results = {}
     for trains in (True, False):
         torch.manual_seed(0)
@@ -512,14 +517,15 @@ def test_pass_trains_equal_one_pass_at_a_time(case):
         elif case == "separable_prior":
             model = GWSurrogateModel()
             prop = FlowProposal(model, rng=np.random.default_rng(3), poolsize=300, drawsize=5000, device_seed=5,
-                                flow_config=dict(ftype="nsf", n_neurons=16, n_blocks=2), pass_trains=trains)
+                                flow_config=dict(ftype="nsf", n_neurons=16, n_blocks=2), pass_trains=trains,
+                                small_trains=small)
             prop.initialise()
             prop.check_state(model.new_point(500, rng=np.random.default_rng(1)))
             calls = [dict(n_samples=300, max_samples=10**8)] * 2
         else:
             prop = FlowProposal(GaussianModel(4), rng=np.random.default_rng(3), poolsize=500, drawsize=700,
                                 flow_config=dict(ftype="realnvp", n_neurons=8, n_blocks=2), device_seed=5,
-                                pass_trains=trains)
+                                pass_trains=trains, small_trains=small)
             prop.initialise()
             prop.check_state(GaussianModel(4).new_point(300, rng=np.random.default_rng(1)))
             calls = ([dict(n_samples=500, max_samples=10**8)] * 3 if case == "small_batches"

@@ -144,3 +144,32 @@ def test_unsupported_configurations_fail_loudly():
         RealNVP(4, 8, 2, 2, net="cnn")
     with pytest.raises(ValueError, match="Mask does not match number of features"):
         RealNVP(4, 8, 2, 2, mask=[1, -1, 1])
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
+def test_repack_map_rebuilds_the_image_from_the_flat_parameter_vector(precision):
+    """``pack.repack_map``: for a flow of couplings and permutations every image word is constant, one float32
+    parameter, or the hi / lo halves of two parameters.  The map (what ``nsa_repack_image`` executes on the
+    device) applied to NEW weights reproduces ``pack_flow`` of those weights bit for bit; LU-linear / batch-norm
+    flows have derived words and are refused."""
+    for cls, args, kw in [
+        (O.NeuralSplineFlow, (32, 64, 6, 2), {}),
+        (O.NeuralSplineFlow, (12, 128, 2, 1), dict(num_bins=4)),  # k-split stages of the 128-wide conditioner
+        (O.NeuralSplineFlow, (5, 20, 2, 3), dict(num_bins=10)),
+        (O.RealNVP, (6, 16, 3, 2), dict(linear_transform="permutation", batch_norm_between_layers=False)),
+        (O.RealNVP, (5, 12, 2, 3), dict(net="mlp", linear_transform="permutation", batch_norm_between_layers=False,
+                                        use_volume_preserving=True)),
+    ]:
+        torch.manual_seed(1)
+        flow = cls(*args, **kw).eval()
+        repack = P.repack_map(lambda off: describe(flow, index_offset=off), precision)
+        template = P.pack_flow(dict(describe(flow), precision=precision))
+        with torch.no_grad():
+            for p in flow.parameters():
+                p.mul_(1.7).add_(0.013)
+        flat = torch.cat([p.detach().reshape(-1) for p in flow.parameters()]).numpy()
+        expected = P.pack_flow(dict(describe(flow), precision=precision))
+        assert not np.array_equal(template, expected)
+        assert np.array_equal(P.apply_repack_map(template, repack, flat, precision), expected)
+    with pytest.raises(ValueError, match="not copies of parameters"):
+        describe(O.RealNVP(6, 16, 2, 2).eval(), index_offset=1)
