@@ -297,24 +297,15 @@ class Trainer:
         # under graph capture, once the flag is clear: the first epoch always runs launch by launch.)
         self._actnorm_initialised()
 
-    def evaluate(self, x, log_prob_out=None, weights=None, params=None, workspace=None, loss_acc=None):
-        """``loss_acc += -mean(log_prob(x))`` without touching the weights.
-
-        ``params`` (a copy of the flat buffer), ``workspace`` (``eval_workspace``) and ``loss_acc`` let a
-        validation pass run on weights of an earlier epoch, on another stream, beside the training steps."""
-        ws = self._workspace(x.shape[0]) if workspace is None else workspace
+    def evaluate(self, x, log_prob_out=None, weights=None):
+        """``loss_acc += -mean(log_prob(x))`` without touching the weights."""
+        ws = self._workspace(x.shape[0])
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = lib.load().nsa_train_eval(
-            self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params if params is None else params),
-            lib.ptr(x), lib.ptr(weights), x.shape[0], lib.ptr(ws),
-            lib.ptr(self.loss_acc if loss_acc is None else loss_acc), lib.ptr(log_prob_out), lib.c_void_p(stream),
+            self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(x), lib.ptr(weights),
+            x.shape[0], lib.ptr(ws), lib.ptr(self.loss_acc), lib.ptr(log_prob_out), lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_train_eval")
-
-    def eval_workspace(self, n):
-        """A workspace of its own for ``evaluate`` on ``n`` rows (not the one the training steps use)."""
-        words = int(lib.load().nsa_train_workspace_floats(self.plan, n))
-        return torch.empty(words, dtype=torch.float32, device=self.device)
 
 
 def get_trainer(flow_model):
@@ -397,70 +388,35 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
     history = dict(loss=[], val_loss=[])
     model.train()
     # One epoch = the minibatch steps + the validation pass.  Live-point sets are small (2000 rows:
-    # two minibatches), so an epoch is ~35 short launches, each a chain of dependent memory round trips on 32
-    # workgroups:
-    #  * after the first epoch (which also runs the data-dependent act-norm initialisation) the launches of an
-    #    epoch are captured into a HIP graph and every later epoch is one graph launch.  Nothing in the
-    #    captured sequence depends on a per-epoch host value: the shuffled rows are gathered into a static
-    #    buffer, the learning rate and the optimiser's step counter live in device memory (Trainer.opt);
-    #  * the validation pass of epoch e runs BESIDE the training steps of epoch e + 1, on a second stream
-    #    and on a snapshot of the weights as epoch e left them (two snapshots, alternating: the graph of an
-    #    even epoch reads the one the odd epochs write).  Its 6 forward launches use 7 of the 256 CUs; in
-    #    line they were a sixth of the epoch.  The host therefore learns the validation loss of epoch e one
-    #    epoch late: the best weights are taken from the snapshot, and when the patience runs out the fit
-    #    has trained one epoch too many - discarded with the restore of the best weights, its loss dropped
-    #    from the history - so losses, best weights and the stopping epoch are the reference's.
-    # NESSAI_AMD_EPOCH_GRAPH=0 keeps the launch-by-launch loop, NESSAI_AMD_VAL_OVERLAP=0 the in-line validation.
+    # two minibatches), so an epoch is ~35 short launches and launch overhead dominates: after the
+    # first epoch (which also runs the data-dependent act-norm initialisation) the launches of an
+    # epoch are captured ONCE into a HIP graph and every later epoch is one graph launch.  Nothing
+    # in the captured sequence depends on a per-epoch host value: the shuffled rows are gathered
+    # into a static buffer, the learning rate and the optimiser's step counter live in device
+    # memory (Trainer.opt).  NESSAI_AMD_EPOCH_GRAPH=0 keeps the launch-by-launch loop.
+    # (Round 3 also ran the validation pass of epoch e beside the training steps of epoch e + 1 - second
+    # stream, snapshot of the weights, lagged early-stopping bookkeeping; same losses, weights and stopping
+    # epoch - and measured 0.805 against 0.827 ms per step with the graph, 0.829 against 0.805 without: nothing.
+    # The epoch is a chain of latency-bound launches either way; not kept.  DESIGN.md section 4.3.)
     n_train = train_data.shape[0]
     epoch_rows = torch.empty_like(train_data)
     epoch_w = torch.empty_like(w_train) if w_train is not None else None
     bounds = [(a, min(a + batch_size, n_train)) for a in range(0, n_train, batch_size)]
     has_val = bool(validate and len(val_data))
     trainer.opt[1] = float(trainer.step_count)
-    overlap = has_val and os.environ.get("NESSAI_AMD_VAL_OVERLAP", "1") != "0"
-    snaps = side = val_ws = None
-    if overlap:
-        snaps = [torch.empty_like(trainer.flat), torch.empty_like(trainer.flat)]
-        side = torch.cuda.Stream(device=train_data.device)
-        val_ws = trainer.eval_workspace(val_data.shape[0])
 
-    def run_epoch(epoch):
-        main = torch.cuda.current_stream(train_data.device)
-        lagged = overlap and epoch > 1
-        if lagged:  # validation of the weights epoch - 1 left, beside this epoch's steps
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                trainer.val_acc.zero_()
-                trainer.evaluate(val_data, weights=w_val, params=snaps[(epoch - 1) % 2], workspace=val_ws,
-                                 loss_acc=trainer.val_acc)
+    def run_epoch():
         trainer.loss_acc.zero_()
         for a, b in bounds:
             trainer.step_dev(epoch_rows[a:b], clip_norm=clip, weights=None if epoch_w is None else epoch_w[a:b])
-        if overlap:
-            snaps[epoch % 2].copy_(trainer.flat)
-            if lagged:
-                main.wait_stream(side)
-        elif has_val:
+        if has_val:
             trainer.val_acc.zero_()
             keep, trainer.loss_acc = trainer.loss_acc, trainer.val_acc
             trainer.evaluate(val_data, weights=w_val)
             trainer.loss_acc = keep
 
-    stop = False
-
-    def validated(epoch, val_loss, weights):
-        """The reference's bookkeeping of one epoch's validation loss (flowmodel/base.py:652-675)."""
-        nonlocal best_epoch, best_val_loss, stop
-        history["val_loss"].append(val_loss)
-        if validate and (val_loss < best_val_loss):
-            best_epoch, best_val_loss = epoch, val_loss
-            trainer.best.copy_(weights)
-        if validate and (epoch - best_epoch > patience):
-            stop = True
-
     use_graph = os.environ.get("NESSAI_AMD_EPOCH_GRAPH", "1") != "0"
-    graphs = {}
-    last_epoch = 0
+    graph = None
     with _training_kernels(tc.get("deterministic")):
         for epoch in range(1, max_epochs + 1):
             p = torch.randperm(n_train).to(train_data.device)
@@ -473,41 +429,32 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
                 # CosineAnnealingLR(T_max=max_epochs, eta_min=0), stepped once per epoch (base.py:449-450, 628-631)
                 trainer.lr = trainer.base_lr * 0.5 * (1.0 + math.cos(math.pi * (epoch - 1) / max_epochs))
             trainer.opt[0] = trainer.lr
-            key = epoch % 2 if overlap else 0  # the overlapped form alternates between two snapshot buffers
-            if key in graphs:
-                graphs[key].replay()
+            if graph is not None:
+                graph.replay()
                 trainer.step_count += len(bounds)
-            elif use_graph and epoch >= 2:
-                graphs[key] = torch.cuda.CUDAGraph()
+            elif use_graph and epoch == 2:
+                graph = torch.cuda.CUDAGraph()
                 steps_before = trainer.step_count
-                with torch.cuda.graph(graphs[key]):
-                    run_epoch(epoch)
+                with torch.cuda.graph(graph):
+                    run_epoch()
                 trainer.step_count = steps_before  # capture records, it does not run
-                graphs[key].replay()
+                graph.replay()
                 trainer.step_count += len(bounds)
             else:
-                run_epoch(epoch)
+                run_epoch()
                 trainer._actnorm_initialised()
-            last_epoch = epoch
             if has_val:
                 both = torch.cat([trainer.loss_acc, trainer.val_acc]).cpu().numpy()  # the epoch's one sync
                 loss, val_loss = float(both[0]) / len(bounds), float(both[1])
             else:
                 loss, val_loss = float(trainer.loss_acc.item()) / len(bounds), np.nan
             history["loss"].append(loss)
-            if not overlap:
-                validated(epoch, val_loss, trainer.flat)
-            elif epoch > 1:
-                validated(epoch - 1, val_loss, snaps[(epoch - 1) % 2])
-                if stop:  # epoch - 1 was the last one of the reference's loop: this one is not part of the fit
-                    history["loss"].pop()
-            if stop:
+            history["val_loss"].append(val_loss)
+            if validate and (val_loss < best_val_loss):
+                best_epoch, best_val_loss = epoch, val_loss
+                trainer.best.copy_(trainer.flat)
+            if validate and (epoch - best_epoch > patience):
                 break
-        if overlap and not stop and last_epoch:  # the last epoch's validation loss, in line
-            trainer.val_acc.zero_()
-            trainer.evaluate(val_data, weights=w_val, params=snaps[last_epoch % 2], workspace=val_ws,
-                             loss_acc=trainer.val_acc)
-            validated(last_epoch, float(trainer.val_acc.item()), snaps[last_epoch % 2])
     if validate:
         trainer.flat.copy_(trainer.best)
     model._image_key = None  # weights changed behind torch's version counters

@@ -432,32 +432,3 @@ def test_deterministic_training_is_bit_reproducible(tmp_path):
     c, hc = fit(False, "c")
     assert float((a - c).abs().max()) < 5e-3 and abs(ha["loss"][-1] - hc["loss"][-1]) < 1e-2
     assert "NESSAI_AMD_TRAIN_FUSED" not in os.environ
-
-
-def test_validation_beside_the_next_epoch_keeps_the_reference_schedule(tmp_path, monkeypatch):
-    """The validation pass of an epoch runs on a second stream beside the training steps of the next one
-    (on a snapshot of the weights), so the host sees its loss one epoch late (``train_flow``).  Losses, the
-    epoch the patience runs out at and the restored best weights must be those of the in-line loop: a
-    deterministic fit both ways, with a patience short enough to stop early and with max_epochs reached."""
-    from nessai_amd.flowmodel import FlowModel
-
-    data = np.random.default_rng(5).normal(size=(700, 5)) * np.array([1.0, 0.4, 2.0, 0.7, 1.3])
-    cfg = dict(n_inputs=5, n_neurons=16, n_blocks=3, n_layers=2, ftype="nsf")
-
-    def fit(overlap, tag, **tc):
-        monkeypatch.setenv("NESSAI_AMD_VAL_OVERLAP", "1" if overlap else "0")
-        torch.manual_seed(7)
-        fm = FlowModel(flow_config=cfg, training_config=dict(batch_size=200, deterministic=True, lr=2e-2, **tc),
-                       output=str(tmp_path / tag), rng=np.random.default_rng(7))
-        fm.initialise()
-        history = fm.train(data)
-        return history, fm._trainer.flat.detach().cpu().clone()
-
-    for k, tc in enumerate([dict(max_epochs=60, patience=3), dict(max_epochs=7, patience=50)]):
-        h_in, w_in = fit(False, f"inline{k}", **tc)
-        h_ov, w_ov = fit(True, f"beside{k}", **tc)
-        assert len(h_in["loss"]) == len(h_in["val_loss"]) == len(h_ov["loss"]) == len(h_ov["val_loss"])
-        assert h_in["loss"] == h_ov["loss"] and h_in["val_loss"] == h_ov["val_loss"]
-        assert torch.equal(w_in, w_ov)
-        if k == 0:
-            assert len(h_in["loss"]) < 60  # the patience did run out
