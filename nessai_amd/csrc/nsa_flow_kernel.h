@@ -185,6 +185,10 @@ __device__ __forceinline__ double nsa_log_prior_term(int kind, double x, const d
 #ifndef NSA_COPY_PARTS
 #define NSA_COPY_PARTS 2
 #endif
+// which stages of a coupling the skewed waves split at the M | V boundary: 1 layer 0, 2 hidden layers, 4 chunks
+#ifndef NSA_SKEW_MASK
+#define NSA_SKEW_MASK 7
+#endif
 
 struct NsaStagePipe {
   const uint32_t* img;
@@ -606,7 +610,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
       pipe.more();
       NSA_TL(pipe, 3);
       if constexpr (J + 1 < KS) pipe.end();
-      else pipe.template end_m<SKEW>();
+      else pipe.template end_m<SKEW && (NSA_SKEW_MASK & 2) != 0>();
     });
     pipe.template watch<PREC>(acc);
   };
@@ -627,12 +631,12 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
     else nsa_dense_tile<HT, false, RT>(w, id_tab, nullptr, xrow, n_steps0, lane, half, acc);
     pipe.more();
     NSA_TL(pipe, 1);
-    pipe.template end_m<SKEW>();
+    pipe.template end_m<SKEW && (NSA_SKEW_MASK & 1) != 0>();
     pipe.template watch<PREC>(acc);
 #pragma unroll
     for (int t = 0; t < RT; ++t) nsa_acc_to_regs<HT>(acc[t], h[t]);
     NSA_TL(pipe, 2);
-    pipe.template end_v<SKEW>();
+    pipe.template end_v<SKEW && (NSA_SKEW_MASK & 1) != 0>();
   }
 
   if (net == NSA_NET_RESNET) {
@@ -654,7 +658,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
           nsa_act_regs<16 * HT>(tmp[t], act);
         }
         NSA_TL(pipe, 4);
-        pipe.template end_v<SKEW>();
+        pipe.template end_v<SKEW && (NSA_SKEW_MASK & 2) != 0>();
       }
       {
         f32x16 acc[RT][HT];
@@ -666,7 +670,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[t][16 * ot + r] = h[t][16 * ot + r] + acc[t][ot][r];
         NSA_TL(pipe, 4);
-        pipe.template end_v<SKEW>();
+        pipe.template end_v<SKEW && (NSA_SKEW_MASK & 2) != 0>();
       }
     }
   } else {
@@ -682,7 +686,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
         nsa_act_regs<16 * HT>(h[t], act);
       }
       NSA_TL(pipe, 4);
-      pipe.template end_v<SKEW>();
+      pipe.template end_v<SKEW && (NSA_SKEW_MASK & 2) != 0>();
     }
   }
 
@@ -706,7 +710,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
       pipe.more();
       NSA_TL(pipe, 5);
       if constexpr (J + 1 < nsa_ksplit(TP::C, HT)) pipe.end();
-      else pipe.template end_m<SKEW>();
+      else pipe.template end_m<SKEW && (NSA_SKEW_MASK & 4) != 0>();
     });
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -725,7 +729,7 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
       }
     }
     NSA_TL(pipe, 6);
-    pipe.template end_v<SKEW>();
+    pipe.template end_v<SKEW && (NSA_SKEW_MASK & 4) != 0>();
   }
 }
 

@@ -77,10 +77,11 @@ def _flow_run(x, image, header, direction, mode, want_x, status, waves_per_group
     status.zero_()
     if n == 0:
         return out, ld
-    head = (lib.ctypes.c_uint32 * header.numel())(*header.tolist())
+    if header.dtype != torch.int32 or header.device.type != "cpu" or not header.is_contiguous():
+        raise RuntimeError("nessai_amd::flow_run: `header` must be the host int32 tensor of ops.header_tensor")
     stream = torch.cuda.current_stream(x.device).cuda_stream
     rc = lib.load().nsa_flow_run(
-        head, lib.ptr(image), int(direction), int(mode), n, lib.ptr(x), lib.ptr(out) if want_x else None,
+        lib.c_void_p(header.data_ptr()), lib.ptr(image), int(direction), int(mode), n, lib.ptr(x), lib.ptr(out) if want_x else None,
         lib.ptr(ld), lib.ptr(status), int(waves_per_group), int(max_groups), lib.c_void_p(stream),
     )
     lib.check(rc, "nsa_flow_run")
@@ -226,5 +227,6 @@ def differentiable_flow(flow, x, want_z, want_logdet, want_log_prob):
 
 
 def header_tensor(header):
-    """Host int32 tensor holding the header words (operator argument of ``flow_run``)."""
-    return torch.from_numpy(np.frombuffer(bytes(header), dtype=np.uint32).astype(np.int64))
+    """Host int32 tensor holding the 32-bit header words bit for bit (operator argument of ``flow_run``, which
+    hands its address to the library: no per-call conversion)."""
+    return torch.from_numpy(np.frombuffer(bytes(header), dtype=np.uint32).view(np.int32).copy())
