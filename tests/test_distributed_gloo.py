@@ -95,3 +95,66 @@ def test_row_indexed_streams_do_not_depend_on_the_sharding():
     assert np.array_equal(whole, parts)
     assert np.array_equal(philox.uniforms(11, 0, 8000),
                           np.concatenate([philox.uniforms(11, 0, 4000), philox.uniforms(11, 4000, 4000)]))
+
+
+def _pool_worker(rank, world, port, out_dir):
+    """The end-of-populate exchange of the sharded trains (``FlowProposal._assemble_sharded_pool``): every rank
+    holds its accepted rows appended pass after pass and its per-pass counts."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nessai_amd.proposal import FlowProposal
+
+    counts, rows = _pool_case(rank)
+    from types import SimpleNamespace
+
+    prop = SimpleNamespace(device=torch.device("cpu"), dims=rows.shape[1])  # all the method reads of `self`
+    x_acc = torch.zeros((POOL_N, rows.shape[1]), dtype=torch.float64)  # capacity = n_samples rows per rank
+    kept = rows[:POOL_N]
+    x_acc[: len(kept)] = torch.from_numpy(kept)
+    pool = FlowProposal._assemble_sharded_pool(prop, torch.from_numpy(counts), x_acc, POOL_N, world)
+    np.save(os.path.join(out_dir, f"pool{rank}.npy"), pool)
+    dist.destroy_process_group()
+
+
+POOL_N = 40  # n_samples
+
+
+def _pool_case(rank):
+    """Per-pass accepted counts and the rows (tagged pass, rank, index) of one rank; rank 1 accepts more than the
+    capacity in total, pass 2 of rank 0 is empty."""
+    counts = np.array([[7, 12, 0, 9, 30], [5, 20, 11, 25, 2]], dtype=np.int64)[rank]
+    rows = np.array([[p, rank, k, p * 1000 + rank * 100 + k] for p, c in enumerate(counts) for k in range(c)],
+                    dtype=np.float64)
+    return counts, rows
+
+
+@pytest.mark.timeout(120)
+def test_sharded_pool_is_assembled_in_pass_rank_draw_order(tmp_path):
+    world = 2
+    mp.spawn(_pool_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    per_rank = [_pool_case(r) for r in range(world)]
+    expected = []
+    for p in range(5):
+        for r in range(world):
+            counts, rows = per_rank[r]
+            start = int(counts[:p].sum())
+            block = rows[start : start + int(counts[p])]
+            expected.append(block[: max(0, POOL_N - start)])  # a rank keeps its first n_samples rows only
+    expected = np.concatenate(expected)[:POOL_N]
+    pools = [np.load(tmp_path / f"pool{r}.npy") for r in range(world)]
+    assert np.array_equal(pools[0], pools[1]) and np.array_equal(pools[0], expected)
+    assert len(expected) == POOL_N and expected[0].tolist() == [0.0, 0.0, 0.0, 0.0]
+    # one rank: the same code without collectives
+    sys.path.insert(0, ROOT)
+    from nessai_amd.proposal import FlowProposal
+
+    counts, rows = per_rank[0]
+    from types import SimpleNamespace
+
+    prop = SimpleNamespace(device=torch.device("cpu"), dims=4)
+    x_acc = torch.zeros((POOL_N, 4), dtype=torch.float64)
+    x_acc[: min(len(rows), POOL_N)] = torch.from_numpy(rows[:POOL_N])
+    single = FlowProposal._assemble_sharded_pool(prop, torch.from_numpy(counts), x_acc, POOL_N, 1)
+    assert np.array_equal(single, rows[:POOL_N])
