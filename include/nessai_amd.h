@@ -143,8 +143,13 @@ NSA_API int nsa_flow_run_many(const uint32_t* header, const void* const* image_l
  *               (utils/rescaling.py:318-337: the registry's "logit" entry,
  *               reparameterisations/__init__.py:62-70), 4 the same after u = exp(x') with
  *               log|J| += x' (the "log-rescale" entry); rp_par_dev [D][5] float64
- *               {lo, hi, rs, rf, offset}.  log_j_rescale then carries the row-independent
- *               terms only; the sigmoid terms are added per row in float64.
+ *               {lo, hi, rs, rf, offset}.  Boundary inversion, inverse direction
+ *               (RescaleToBounds._reverse_inversion, rescale.py:585-612; the registry's
+ *               "inversion" / "inversion-duplicate" entries): 5 fold and measure from the
+ *               detected edge, u = |x'|, u = 1 - u at the upper edge, x = (hi - lo) u + lo + offset,
+ *               rp_par {lo, hi, upper ? 1 : 0, -, offset}; 6 no edge detected,
+ *               x = (hi - lo) ((x' + 1) / 2) + lo + offset.  log_j_rescale then carries the
+ *               row-independent terms only; the sigmoid terms are added per row in float64.
  */
 NSA_API int nsa_populate_draw(const uint32_t* header, const void* image_dev, long long n,
                       const float* z_in_dev, unsigned long long seed,

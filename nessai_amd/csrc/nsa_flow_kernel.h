@@ -158,8 +158,13 @@ struct NsaLaunch {
 //                (utils/rescaling.py:318-337; the "logit" entry of reparameterisations/__init__.py:62-70)
 //   TO_BOUNDS_LOG    the same after u = exp(x'), log|J| += x'
 //                (utils/rescaling.py:359-395: the "log-rescale" entry, reparameterisations/__init__.py:71-79)
+//   INVERT       boundary inversion, inverse direction (rescale.py:585-612): u = |x'| (only negative
+//                values are negated), u = 1 - u at the upper edge, x = (hi - lo) * u + lo + offset;
+//                par = {lo, hi, upper ? 1 : 0, -, offset}
+//   MINUS_ONE_ONE  the same parameter while no edge is detected: x = (hi - lo) * ((x' + 1) / 2) + lo + offset
+//                (utils/rescaling.py:84-105)
 enum { NSA_RP_SCALE_SHIFT = 0, NSA_RP_NULL = 1, NSA_RP_TO_BOUNDS = 2, NSA_RP_TO_BOUNDS_LOGIT = 3,
-       NSA_RP_TO_BOUNDS_LOG = 4 };
+       NSA_RP_TO_BOUNDS_LOG = 4, NSA_RP_INVERT = 5, NSA_RP_MINUS_ONE_ONE = 6 };
 
 enum { NSA_PRIOR_UNIFORM = 0, NSA_PRIOR_SINE = 1, NSA_PRIOR_COSINE = 2, NSA_PRIOR_POWER_LAW = 3,
        NSA_PRIOR_GAUSSIAN = 4 };
@@ -1147,6 +1152,16 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
           xv = (xp * e.scale[i]) + e.shift[i];
         } else if (kind == NSA_RP_NULL) {
           xv = xp;
+        } else if (kind == NSA_RP_INVERT) {
+          const double* c = e.rp_par + 5 * i;
+          double u = (xp < 0.0) ? -xp : xp;
+          if (c[2] != 0.0) u = 1.0 - u;
+          xv = (c[1] - c[0]) * u + c[0];
+          xv = xv + c[4];
+        } else if (kind == NSA_RP_MINUS_ONE_ONE) {
+          const double* c = e.rp_par + 5 * i;
+          xv = (c[1] - c[0]) * ((xp + 1.0) / 2.0) + c[0];
+          xv = xv + c[4];
         } else {
           const double* c = e.rp_par + 5 * i;
           double u = xp;

@@ -274,7 +274,8 @@ class FlowProposal:
             if getattr(self.model, "reparameterisations", None) is not None:  # base.py:639-640
                 config = self.model.reparameterisations
             self._reparam = ReparameterisationTable(
-                self.names, getattr(self.model, "bounds", None), config, fallback=self.fallback_reparameterisation
+                self.names, getattr(self.model, "bounds", None), config, fallback=self.fallback_reparameterisation,
+                rng=self.rng,
             )
             self.truncation.configure(self)  # truncation.py:292-308 (needs the dimensions)
         config = dict(self.flow_config)
@@ -370,9 +371,16 @@ class FlowProposal:
             self._rp_kind_dev = torch.from_numpy(kind).to(dev)
             self._rp_par_dev = torch.from_numpy(par).to(dev)
 
-    def rescale(self, x):
-        """x -> (x', log|J|)  (``base.py:996-1030``)."""
-        return self._reparam.rescale(x)
+    def rescale(self, x, compute_radius=False, test=None, **kwargs):
+        """x -> (x', log|J|)  (``base.py:716-753``).  ``compute_radius`` (the reference's flag for the radius
+        of the latent contour) makes every boundary inversion duplicate its rows; a boundary inversion that
+        has just detected its edges changes the draw kernel's per-column table."""
+        known = self._reparam.has_inversion and any(
+            e is None for g in self._reparam.groups if g.kind == "to_bounds" and g.inversion for e in g.edges.values())
+        out = self._reparam.rescale(x, compute_radius=compute_radius, test=test)
+        if known:  # edges were open before this call: they are decided now
+            self._upload_constants()
+        return out
 
     def inverse_rescale(self, x_prime):
         """x' -> (x, log|J|)  (``base.py:755-784``)."""
@@ -449,11 +457,11 @@ class FlowProposal:
     def forward_pass(self, x, rescale=True, **kwargs):
         """Live points -> (z, log_prob incl. rescaling Jacobian) (``base.py:961-994``).
 
-        Extra keyword arguments (``compute_radius=`` of the reference's signature) are accepted
-        and ignored: no rescaling here depends on them."""
+        Extra keyword arguments go to ``rescale`` as in the reference (``compute_radius=True``: boundary
+        inversions duplicate their rows, so there are more latents than points)."""
         log_J = 0
         if rescale:
-            x, log_J = self.rescale(x)
+            x, log_J = self.rescale(x, **kwargs)
         arr = live_points_to_array(x, self.prime_parameters)
         z, log_prob = self.flow.forward_and_log_prob(arr)
         return z, log_prob + log_J

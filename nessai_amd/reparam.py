@@ -16,11 +16,18 @@ registry name                         map (x -> x')
 ``logit``                             ``RescaleToBounds`` to [0, 1] with the prior bounds, then
                                       ``logit`` (``utils/rescaling.py:290-337``)
 ``log-rescale``                       the same followed by ``log`` (``utils/rescaling.py:359-395``)
+``inversion`` ``inversion-duplicate``   ``RescaleToBounds`` with boundary inversion (``rescale.py:541-612``):
+                                      the edge the live points pile up at is detected
+                                      (``utils/rescaling.py:106-193``), the parameter is mapped to [0, 1]
+                                      measured from that edge and mirrored about it - half of the points
+                                      flipped (``split``) or every point doubled (``duplicate``)
 ``null`` ``none``                     ``NullReparameterisation`` (``null.py``)
 ====================================  =========================================================
 
-Boundary inversion, angles, dequantisation and user-defined classes change the number of rows
-or couple parameters; they are not per-column maps and raise ``NotImplementedError`` here.
+The mirrored FORWARD map changes the number of rows (training data, host side, numpy as in the
+reference); its INVERSE - fold ``|x'|`` back, undo the [0, 1] map - is one-to-one per column and
+runs in the draw kernel's epilogue like the others.  Angles, dequantisation and user-defined
+classes couple parameters or need their own kernels and raise ``NotImplementedError`` here.
 
 The configuration forms are the reference's (``reparameterisations/utils.py:120-268``):
 ``None`` | ``"name"`` | ``{parameter: "name"}`` | ``{parameter: {"reparameterisation": "name",
@@ -40,6 +47,7 @@ from .livepoint import empty_structured_array
 
 # kinds of nsa_populate_draw's rp_kind table (nsa_flow_kernel.h NSA_RP_*)
 RP_SCALE_SHIFT, RP_NULL, RP_TO_BOUNDS, RP_TO_BOUNDS_LOGIT, RP_TO_BOUNDS_LOG = 0, 1, 2, 3, 4
+RP_INVERT, RP_MINUS_ONE_ONE = 5, 6  # boundary inversion: folded [0, 1] map about an edge / plain [-1, 1] map
 
 _KNOWN = {
     "z-score": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
@@ -52,6 +60,8 @@ _KNOWN = {
     "rescaletobounds": ("to_bounds", {}),
     "rescale-to-bounds": ("to_bounds", {}),
     "offset": ("to_bounds", dict(offset=True)),
+    "inversion": ("to_bounds", dict(detect_edges=True, boundary_inversion=True, inversion_type="split")),
+    "inversion-duplicate": ("to_bounds", dict(detect_edges=True, boundary_inversion=True, inversion_type="duplicate")),
     "logit": ("to_bounds", dict(rescale_bounds=[0.0, 1.0], update_bounds=False, post_rescaling="logit")),
     "log-rescale": ("to_bounds", dict(rescale_bounds=[0.0, 1.0], update_bounds=False, post_rescaling="log")),
     "null": ("null", {}),
@@ -75,10 +85,60 @@ def _sigmoid(x):
     return x, log_j
 
 
+def _auto_bins(x, max_bins=50):
+    """Histogram bin count: the narrower of the Freedman-Diaconis and Sturges widths, at most
+    ``max_bins`` (``utils/hist.py:9-76``)."""
+    x = np.asarray(x)
+    if not x.size:
+        raise RuntimeError("Input array is empty!")
+    q75, q25 = np.percentile(x, [75, 25])
+    fd = 2.0 * (q75 - q25) * x.size ** (-1.0 / 3.0)
+    sturges = np.ptp(x) / (np.log2(x.size) + 1.0)
+    width = min(fd, sturges) if fd else sturges
+    return min(int(np.ceil(np.ptp(x)) / width) if width else 1, max_bins)
+
+
+def detect_edge(x, x_range=None, percent=0.1, cutoff=0.5, nbins="auto", allow_both=False, allow_none=False,
+                allowed_bounds=("lower", "upper"), test=None):
+    """Which bound of a parameter the samples pile up at: ``"lower"``, ``"upper"``, ``"both"`` or
+    ``False`` (``utils/rescaling.py:106-193``).  The density histogram's mass in the outer ``percent``
+    of the bins on each side is compared with ``cutoff`` times the mass of the fullest bin; the mode
+    inside an outer band decides first, otherwise the heavier side."""
+    sides = ["lower", "upper"]
+    if test is not None:  # the reference's hook for exercising every branch
+        return False if (test in sides and test not in allowed_bounds) else test
+    if not all(b in sides for b in allowed_bounds):
+        raise RuntimeError(f"Unknown allowed bounds: {allowed_bounds}")
+    if nbins == "auto":
+        nbins = _auto_bins(x)
+    hist, edges = np.histogram(x, bins=nbins, density=True, range=x_range)
+    width = edges[1] - edges[0]
+    n = max(int(len(edges) * percent), 1)
+    mass = np.array([np.sum(hist[:n]), np.sum(hist[-n:])]) * width
+    top = int(np.argmax(hist))
+    top_mass = hist[top] * width
+    keep = [i for i, b in enumerate(sides) if b in allowed_bounds]
+    sides, mass = [sides[i] for i in keep], mass[keep]
+    if np.all(mass > cutoff * top_mass) and allow_both and len(sides) > 1:
+        return "both"
+    if top < n and "lower" in sides:
+        return sides[0]
+    if top >= (len(edges) - n) and "upper" in sides:
+        return sides[-1]
+    if not np.any(mass > cutoff * top_mass) and allow_none:
+        return False
+    return sides[int(np.argmax(mass))]
+
+
+def _concat_structured(a, b):
+    return np.concatenate([a, b])
+
+
 class _Group:
     """One reparameterisation instance of the reference: a kind and its parameters."""
 
-    def __init__(self, name, kind, parameters, prior_bounds, kwargs):
+    def __init__(self, name, kind, parameters, prior_bounds, kwargs, rng=None):
+        self.rng = rng
         self.name = name
         self.kind = kind
         self.parameters = list(parameters)
@@ -117,8 +177,41 @@ class _Group:
                 if self.update_enabled:
                     raise RuntimeError("Cannot use log or logit with update bounds")  # rescale.py:491-495
                 self.rescale_bounds = {p: [0, 1] for p in self.parameters}
-            if kw.pop("boundary_inversion", None) or kw.pop("detect_edges", False):
-                raise NotImplementedError("boundary inversion changes the row count; not a per-column map")
+            # boundary inversion (rescale.py:425-463): {parameter: "split" | "duplicate"} or False
+            inversion, itype = kw.pop("boundary_inversion", None), kw.pop("inversion_type", "split")
+            detect_edges, edge_kwargs = bool(kw.pop("detect_edges", False)), kw.pop("detect_edges_kwargs", None)
+            if inversion is None or inversion is False:
+                self.inversion = False
+            elif inversion is True:
+                self.inversion = {p: itype for p in self.parameters}
+            elif isinstance(inversion, list):
+                self.inversion = {p: itype for p in inversion}
+            elif isinstance(inversion, dict):
+                self.inversion = dict(inversion)
+            else:
+                raise TypeError(f"boundary_inversion must be a list, dict or bool. Got type: {type(inversion).__name__}")
+            if detect_edges and not self.inversion:
+                raise RuntimeError("Must enable boundary inversion to use detect edges")
+            self.edges = None
+            if self.inversion:
+                if self.post is not None:
+                    raise NotImplementedError("boundary inversion with a post-rescaling has no device map")
+                bad = [t for t in self.inversion.values() if t not in ("split", "duplicate")]
+                if bad or any(p not in self.parameters for p in self.inversion):
+                    raise ValueError(f"unknown boundary inversion configuration: {self.inversion}")
+                for p in self.inversion:
+                    self.rescale_bounds[p] = [0, 1]
+                self.edges = {p: None for p in self.parameters}
+                # utils/rescaling.py:196-222: with edge detection "no edge" is allowed, without it the
+                # heavier side is always taken
+                self.edge_kwargs = dict(cutoff=0.5)
+                given = dict(edge_kwargs or {})
+                given["allow_none"] = detect_edges
+                if not detect_edges:
+                    given["cutoff"] = 0.0
+                self.edge_kwargs.update(given)
+                if detect_edges:
+                    self.update_enabled = True  # rescale.py:451
             if kw.pop("offset", False):  # rescale.py:467-475
                 self.offsets = {p: b[0] + np.ptp(b) / 2 for p, b in self.prior_bounds.items()}
             else:
@@ -150,6 +243,8 @@ class _Group:
         self.bounds = {p: self.prior_bounds[p] - self.offsets[p] for p in self.parameters}
 
     def update(self, x):
+        if self.kind == "to_bounds":
+            self.reset_inversion()  # RescaleToBounds.update always forgets the edges (rescale.py:718-725)
         if not self.update_enabled:
             return
         if self.kind == "scale_shift":  # rescale.py:293-304
@@ -163,6 +258,11 @@ class _Group:
                 p: [np.min(x[p]) - self.offsets[p], np.max(x[p]) - self.offsets[p]] for p in self.parameters
             }
 
+    def reset_inversion(self):
+        """Forget the detected edges (``rescale.py:673-676``): the next forward pass detects them again."""
+        if getattr(self, "edges", None):
+            self.edges = {p: None for p in self.parameters}
+
     def reset(self):
         if self.kind == "scale_shift":  # rescale.py:306-312
             for p in self.parameters:
@@ -171,12 +271,47 @@ class _Group:
                 if self.estimate_shift:
                     self.shift[p] = 0.0
         elif self.kind == "to_bounds":
+            self.reset_inversion()
             self.set_bounds()
 
+    def _mirror(self, x, x_prime, log_j, p, compute_radius, test):
+        """Forward map of a parameter with boundary inversion (``rescale.py:541-583``): [0, 1] from the
+        detected edge, then mirrored about it - half of the rows flipped, or every row doubled (also
+        whenever the radius of the latent contour is being computed)."""
+        pp = p + "_prime"
+        if self.edges[p] is None:
+            self.edges[p] = detect_edge(x_prime[pp], test=test, **self.edge_kwargs)
+        lo, hi = self.bounds[p]
+        if self.edges[p]:
+            x_prime[pp] = (x_prime[pp] - self.offsets[p] - lo) / (hi - lo)
+            log_j += -np.log(hi - lo)
+            if self.edges[p] == "upper":
+                x_prime[pp] = 1 - x_prime[pp]
+            if self.inversion[p] == "duplicate" or compute_radius:
+                mirrored = x_prime.copy()
+                mirrored[pp] *= -1
+                x_prime = _concat_structured(x_prime, mirrored)
+                x = _concat_structured(x, x)
+                log_j = np.concatenate([log_j, log_j])
+            else:
+                if self.rng is None:
+                    raise RuntimeError("split boundary inversion needs the proposal's random generator")
+                flip = self.rng.choice(x_prime.size, x_prime.size // 2, replace=False)
+                x_prime[pp][flip] *= -1
+        else:
+            x_prime[pp] = (2.0 * (x_prime[pp] - self.offsets[p] - lo) / (hi - lo)) - 1
+            log_j += np.log(2) - np.log(hi - lo)
+        return x, x_prime, log_j
+
     # x -> x'
-    def forward(self, x, x_prime, log_j):
+    def forward(self, x, x_prime, log_j, compute_radius=False, test=None):
+        """Returns ``(x, x_prime, log_j)``: a duplicating boundary inversion replaces all three."""
         for p in self.parameters:
             pp = p + "_prime"
+            if self.kind == "to_bounds" and self.inversion and p in self.inversion:
+                x_prime[pp] = x[p]
+                x, x_prime, log_j = self._mirror(x, x_prime, log_j, p, compute_radius, test)
+                continue
             if self.kind == "null":
                 x_prime[pp] = x[p]
             elif self.kind == "scale_shift":  # rescale.py:233-261
@@ -197,7 +332,7 @@ class _Group:
                         v = np.log(v)
                     log_j += -v
                 x_prime[pp] = v
-        return log_j
+        return x, x_prime, log_j
 
     # x' -> x
     def inverse(self, x_prime, x, log_j):
@@ -215,6 +350,19 @@ class _Group:
                 else:
                     x[p] = x_prime[pp] * self.scale[p]
                 log_j += np.log(np.abs(self.scale[p]))
+            elif self.inversion and p in self.inversion:  # rescale.py:585-612
+                v = x_prime[pp]
+                lo, hi = self.bounds[p]
+                if self.edges[p]:
+                    v = np.where(v < 0.0, -v, v)
+                    if self.edges[p] == "upper":
+                        v = 1 - v
+                    v = (hi - lo) * v + lo
+                    log_j += np.log(hi - lo)
+                else:
+                    v = (hi - lo) * ((v + 1) / 2.0) + lo
+                    log_j += np.log(hi - lo) - np.log(2)
+                x[p] = v + self.offsets[p]
             else:  # rescale.py:537-547, 673-700
                 v = x_prime[pp]
                 if self.post == "logit":
@@ -257,7 +405,8 @@ def _lookup(name):
 class ReparameterisationTable:
     """The proposal's x <-> x' map: ordered groups + the tables the draw kernel reads."""
 
-    def __init__(self, names, bounds, reparameterisations=None, fallback="z-score"):
+    def __init__(self, names, bounds, reparameterisations=None, fallback="z-score", rng=None):
+        self.rng = rng  # split boundary inversion draws the rows it flips from the proposal's generator
         self.names = list(names)
         self.prime_names = [n + "_prime" for n in self.names]
         bounds = {n: np.asarray(bounds[n], dtype=np.float64) for n in self.names} if bounds else {}
@@ -315,26 +464,44 @@ class ReparameterisationTable:
         if not params:
             return
         defaults.update(kwargs)
-        self.groups.append(_Group(name, kind, params, bounds, defaults))
+        self.groups.append(_Group(name, kind, params, bounds, defaults, rng=self.rng))
 
     @property
     def should_update(self):
-        return any(g.update_enabled for g in self.groups)
+        return any(g.update_enabled for g in self.groups) or self.has_inversion
 
     def update(self, x):
+        """Update the data-dependent constants from a set of points (``combined.py:219-230``): every group
+        is updated and then APPLIED to the points before the next one is updated.  For the one-to-one maps
+        that chain changes nothing; a boundary inversion detects its edges here (on the live points), draws
+        the rows a split inversion flips from the generator - once here, once more in the ``rescale`` of the
+        training data, as the reference does - and hands doubled arrays to the groups behind it."""
+        if not self.has_inversion:
+            for g in self.groups:
+                g.update(x)
+            return
+        current = x.copy()
+        x_prime = empty_structured_array(current.size, names=self.prime_names)
+        log_j = np.zeros(current.size)
         for g in self.groups:
-            g.update(x)
+            g.update(current)
+            current, x_prime, log_j = g.forward(current, x_prime, log_j)
 
     def reset(self):
         for g in self.groups:
             g.reset()
 
-    def rescale(self, x):
-        """x -> (x', log|J|)  (``proposal/flowproposal/base.py:996-1030``)."""
+    @property
+    def has_inversion(self):
+        return any(g.kind == "to_bounds" and g.inversion for g in self.groups)
+
+    def rescale(self, x, compute_radius=False, test=None):
+        """x -> (x', log|J|)  (``proposal/flowproposal/base.py:996-1030``).  With a duplicating boundary
+        inversion (or ``compute_radius``) x' has twice the rows of x per mirrored parameter."""
         x_prime = empty_structured_array(x.size, names=self.prime_names)
         log_j = np.zeros(x_prime.size)
         for g in self.groups:
-            log_j = g.forward(x, x_prime, log_j)
+            x, x_prime, log_j = g.forward(x, x_prime, log_j, compute_radius=compute_radius, test=test)
         for f in _NON_SAMPLING:
             x_prime[f] = x[f]
         return x_prime, log_j
@@ -378,6 +545,16 @@ class ReparameterisationTable:
                     scale[i] = g.scale[p]
                     shift[i] = g.shift[p] if g.shift else 0.0
                     log_j += np.log(np.abs(g.scale[p]))
+                elif g.inversion and p in g.inversion:
+                    lo, hi = g.bounds[p]
+                    if g.edges[p]:  # fold |x'|, measure from the edge: par = {lo, hi, upper?, -, offset}
+                        kind[i] = RP_INVERT
+                        par[i] = [lo, hi, 1.0 if g.edges[p] == "upper" else 0.0, 0.0, g.offsets[p]]
+                        log_j += np.log(hi - lo)
+                    else:  # no edge detected (yet): the plain [-1, 1] map
+                        kind[i] = RP_MINUS_ONE_ONE
+                        par[i] = [lo, hi, 0.0, 0.0, g.offsets[p]]
+                        log_j += np.log(hi - lo) - np.log(2)
                 else:
                     kind[i] = {None: RP_TO_BOUNDS, "logit": RP_TO_BOUNDS_LOGIT, "log": RP_TO_BOUNDS_LOG}[g.post]
                     lo, hi = g.bounds[p]

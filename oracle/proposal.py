@@ -346,15 +346,16 @@ class OracleFlowProposal:
             self.scale[n] = np.std(live_points[n])
             self.shift[n] = np.mean(live_points[n])
 
-    def rescale(self, x):  # rescale.py:233-261
-        x_prime = empty_structured_array(x.size, self.prime_names)
+    def rescale(self, x, compute_radius=False):  # rescale.py:233-261, base.py:716-753
         if self.reparam is not None:
-            cols, log_J = self.reparam.rescale(x, x.size)
+            cols, log_J = self.reparam.rescale({n: x[n] for n in self.names}, x.size, compute_radius=compute_radius)
+            x_prime = empty_structured_array(len(log_J), self.prime_names)  # boundary inversion may double the rows
             for pp in self.prime_names:
                 x_prime[pp] = cols[pp]
             for p in NON_SAMPLING:
-                x_prime[p] = x[p]
+                x_prime[p] = np.tile(x[p], len(log_J) // max(x.size, 1))
             return x_prime, log_J
+        x_prime = empty_structured_array(x.size, self.prime_names)
         log_J = np.zeros(x_prime.size)
         for p, pp in zip(self.names, self.prime_names):
             x_prime[pp] = (x[p] - self.shift[p]) / self.scale[p]
@@ -404,8 +405,8 @@ class OracleFlowProposal:
         arr = np.stack([x_prime[pp] for pp in self.prime_names], axis=-1)
         return self.flow.train(arr, **kwargs)
 
-    def forward_pass(self, x):  # base.py:961-994
-        x_prime, log_J = self.rescale(x)
+    def forward_pass(self, x, compute_radius=False):  # base.py:961-994
+        x_prime, log_J = self.rescale(x, compute_radius=compute_radius)
         arr = np.stack([x_prime[pp] for pp in self.prime_names], axis=-1)
         z, log_prob = self.flow.forward_and_log_prob(arr)
         return z, log_prob + log_J

@@ -178,6 +178,56 @@ def test_backward_pass_with_reparameterisation_table_matches_oracle():
     np.testing.assert_allclose(lp, lp_o, rtol=1e-5, atol=2e-4)
 
 
+def test_backward_pass_with_boundary_inversion_matches_oracle():
+    """Boundary inversion (registry entries ``inversion`` / ``inversion-duplicate``, rescale.py:541-612): the
+    mirrored forward map runs on the host as in the reference (edges detected on the live points, half of
+    the rows flipped or every row doubled), its inverse - fold |x'|, measure from the detected edge - in the draw
+    kernel's epilogue (NSA_RP_INVERT / NSA_RP_MINUS_ONE_ONE), against the CPU restatement (itself bit-exact
+    against the reference's classes, tests/test_reparam.py)."""
+    from oracle import reparam as OR
+    from nessai_amd.reparam import RP_INVERT, RP_MINUS_ONE_ONE
+
+    config = {"x_0": "inversion", "x_3": "inversion-duplicate", "x_4": "inversion"}
+    prop, oprop = build(6, "nsf", dict(n_neurons=16, n_blocks=3), reparameterisations=config)
+    b = {n: [-5.0, 5.0] for n in prop.names}
+    oprop.reparam = OR.OracleCombined([
+        OR.OracleBoundaryInversion(["x_0"], b, "split", rng=np.random.default_rng(3)),
+        OR.OracleBoundaryInversion(["x_3"], b, "duplicate"),
+        OR.OracleBoundaryInversion(["x_4"], b, "split", rng=np.random.default_rng(3)),
+        OR.OracleScaleAndShift(["x_1", "x_2", "x_5"], estimate_scale=True, estimate_shift=True),
+    ])
+    g = np.random.default_rng(4)
+    live = prop.model.new_point(600, rng=g)
+    live["x_0"] = -5.0 + np.abs(g.normal(0.0, 0.4, 600))   # piled up at the lower bound
+    live["x_3"] = 5.0 - np.abs(g.normal(0.0, 0.5, 600))    # at the upper bound
+    live["x_4"] = g.normal(0.5, 0.2, 600)                   # in the middle: no edge
+    for n in ("x_1", "x_2", "x_5"):
+        live[n] = 0.3 * live[n]
+    prop.check_state(live)
+    oprop.update_rescaling(live)
+    edges = {p: e for grp in prop._reparam.groups if grp.kind == "to_bounds" for p, e in grp.edges.items()}
+    assert edges == {"x_0": "lower", "x_3": "upper", "x_4": False}
+    assert prop._rp_kind_dev.tolist() == [RP_INVERT, 0, 0, RP_INVERT, RP_MINUS_ONE_ONE, 0]
+    z = g.normal(size=(6000, 6)).astype(np.float32).astype(np.float64) * 0.9
+    x, log_q, z_kept = prop.backward_pass(z, return_z=True)
+    x_o, log_q_o, z_o = oprop.backward_pass(z)
+    assert len(x_o) > 1000
+    assert len(x) == len(x_o) and np.array_equal(z_kept, z_o)
+    for n in prop.names:
+        np.testing.assert_allclose(x[n], x_o[n], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(log_q, log_q_o, rtol=1e-5, atol=2e-4)
+    assert (x["x_0"] >= -5.0).all() and (x["x_3"] <= 5.0).all()  # folded back inside the bounds
+    # the radius of the latent contour uses every mirror image: 4 latents per point here (two edges found)
+    zr, _ = prop.forward_pass(live[:50], compute_radius=True)
+    zr_o, _ = oprop.forward_pass(live[:50], compute_radius=True)
+    assert zr.shape == (200, 6)
+    np.testing.assert_allclose(zr, zr_o, rtol=0, atol=3e-4)
+    # training data: the duplicating parameter doubles the rows the flow is fitted to
+    x_prime, _ = prop.rescale(live)
+    assert x_prime.size == 1200 and (x_prime["x_3_prime"][600:] == -x_prime["x_3_prime"][:600]).all()
+    assert (x_prime["x_0_prime"] < 0).sum() == 600  # split: half of the (doubled) rows flipped
+
+
 def test_saturated_sigmoid_rows_are_kept_with_infinite_log_q():
     """sigmoid(x') == 1.0 in float64: log|J| = -inf, log_q = +inf; the reference keeps the row
     (in bounds, never accepted) - flowproposal.py:366-389.  Every parameter uses the logit map so
