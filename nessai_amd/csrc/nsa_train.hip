@@ -198,21 +198,15 @@ struct TrConsts {
   float aff_a, aff_b;  // affine coupling: scale = sigmoid(raw + aff_a) + aff_b (nflows default 2, 1e-3)
 };
 
-// one thread per (row, transformed feature).  Forward: saves x, writes y in place,
-// atomically accumulates log|det J| per row.
+// the spline of one (row, transformed feature) item: y and log|dy/dx| from x and the item's 3K - 1 parameters
+// (global row-major, or an LDS tile)
 template <int K>
-__device__ __forceinline__ void tr_rq_forward_item(int row, int m, int d_tr, const int* __restrict__ tr_cols,
-                                                   const float* __restrict__ P, float* __restrict__ X, int ldx,
-                                                   float* __restrict__ xsave, float* __restrict__ logdet,
-                                                   const TrConsts& c) {
-  const int t = row * d_tr + m;
+__device__ __forceinline__ void tr_rq_forward_core(const float* __restrict__ Pit, float x, const TrConsts& c, float& y,
+                                                   float& ld) {
   constexpr int NP = 3 * K - 1;
   float v[NP];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) v[i] = P[(long long)t * NP + i];
-  const int col = tr_cols[m];
-  const float x = X[(long long)row * ldx + col];
-  xsave[t] = x;
+  for (int i = 0; i < NP; ++i) v[i] = Pit[i];
   NsaTransformConsts tc;
   tc.tail_bound = c.tail_bound; tc.two_b = 2.0f * c.tail_bound;
   tc.min_bw = c.min_bw; tc.bw_scale = (float)(1.0 - (double)c.min_bw * K);
@@ -220,9 +214,24 @@ __device__ __forceinline__ void tr_rq_forward_item(int row, int m, int d_tr, con
   tc.min_d = c.min_d; tc.edge_d = c.edge_d; tc.inv_logit_div = c.inv_div;
   tc.edge_raw = logf(expf(1.0f - c.min_d) - 1.0f);
   typename NsaRQ<K>::State st;
-  float y = 0.0f, ld = 0.0f;
+  y = 0.0f;
+  ld = 0.0f;
   bool bad = false;
   NsaRQ<K>::template phase<0, 0, false, NP>(st, v, x, tc, y, ld, bad);
+}
+
+// one thread per (row, transformed feature).  Forward: saves x, writes y in place,
+// atomically accumulates log|det J| per row.
+template <int K>
+__device__ __forceinline__ void tr_rq_forward_item(int row, int m, int d_tr, const int* __restrict__ tr_cols,
+                                                   const float* __restrict__ Pit, float* __restrict__ X, int ldx,
+                                                   float* __restrict__ xsave, float* __restrict__ logdet,
+                                                   const TrConsts& c) {
+  const int col = tr_cols[m];
+  const float x = X[(long long)row * ldx + col];
+  xsave[row * d_tr + m] = x;
+  float y, ld;
+  tr_rq_forward_core<K>(Pit, x, c, y, ld);
   X[(long long)row * ldx + col] = y;
   atomicAdd(&logdet[row], ld);
 }
@@ -234,26 +243,19 @@ __global__ void tr_rq_forward(int n, int d_tr, const int* __restrict__ tr_cols, 
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * d_tr) return;
   const int row = t / d_tr;
-  tr_rq_forward_item<K>(row, t - row * d_tr, d_tr, tr_cols, P, X, ldx, xsave, logdet, c);
+  tr_rq_forward_item<K>(row, t - row * d_tr, d_tr, tr_cols, P + (long long)t * (3 * K - 1), X, ldx, xsave, logdet, c);
 }
 
 // Backward of the spline (hand-derived reverse mode of NsaRQ::phase, forward
 // direction).  Inputs: saved x, parameters, upstream gy = dL/dy (read from
 // Gx[row][col]) and gld = dL/dlogdet (same for every row).  Outputs: dL/dx
 // (overwrites Gx[row][col]), dL/dparams (GP), and X[row][col] restored to x.
+// the item's arithmetic: dL/dx (returned) and dL/dparameters (GPit, which may be Pit itself: every
+// parameter is read before the first gradient is written) from x, gy = dL/dy and gld = dL/dlogdet
 template <int K>
-__device__ __forceinline__ void tr_rq_backward_item(int row, int m, int d_tr, const int* __restrict__ tr_cols,
-                                                    const float* __restrict__ P, const float* __restrict__ xsave,
-                                                    float* __restrict__ X, int ldx, float* __restrict__ Gx,
-                                                    const float* __restrict__ gld_rows, float* __restrict__ GP,
-                                                    const TrConsts& c) {
-  const int t = row * d_tr + m;
+__device__ __forceinline__ float tr_rq_backward_core(const float* Pit, float x, float gy, float gld,
+                                                     const TrConsts& c, float* GPit) {
   constexpr int NP = 3 * K - 1;
-  const float gld = gld_rows[row];
-  const int col = tr_cols[m];
-  const float x = xsave[t];
-  const float gy = Gx[(long long)row * ldx + col];
-  X[(long long)row * ldx + col] = x;  // undo the layer
   const float B = c.tail_bound;
   float gp[NP];
 #pragma unroll
@@ -262,7 +264,7 @@ __device__ __forceinline__ void tr_rq_backward_item(int row, int m, int d_tr, co
   if ((x >= -B) && (x <= B)) {
     float v[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) v[i] = P[(long long)t * NP + i];
+    for (int i = 0; i < NP; ++i) v[i] = Pit[i];
     const float two_b = 2.0f * B;
     const float sc_w = (float)(1.0 - (double)c.min_bw * K), sc_h = (float)(1.0 - (double)c.min_bh * K);
     // forward recompute: softmax probabilities and knots
@@ -384,9 +386,22 @@ __device__ __forceinline__ void tr_rq_backward_item(int row, int m, int d_tr, co
       gp[2 * K + i - 1] = gd * sg[i];
     }
   }
-  Gx[(long long)row * ldx + col] = gx;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) GP[(long long)t * NP + i] = gp[i];
+  for (int i = 0; i < NP; ++i) GPit[i] = gp[i];
+  return gx;
+}
+
+template <int K>
+__device__ __forceinline__ void tr_rq_backward_item(int row, int m, int d_tr, const int* __restrict__ tr_cols,
+                                                    const float* __restrict__ Pit, const float* __restrict__ xsave,
+                                                    float* __restrict__ X, int ldx, float* __restrict__ Gx,
+                                                    const float* __restrict__ gld_rows, float* __restrict__ GPit,
+                                                    const TrConsts& c) {
+  const int col = tr_cols[m];
+  const float x = xsave[row * d_tr + m];
+  const float gy = Gx[(long long)row * ldx + col];
+  X[(long long)row * ldx + col] = x;  // undo the layer
+  Gx[(long long)row * ldx + col] = tr_rq_backward_core<K>(Pit, x, gy, gld_rows[row], c, GPit);
 }
 
 template <int K>
@@ -397,24 +412,24 @@ __global__ void tr_rq_backward(int n, int d_tr, const int* __restrict__ tr_cols,
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * d_tr) return;
   const int row = t / d_tr;
-  tr_rq_backward_item<K>(row, t - row * d_tr, d_tr, tr_cols, P, xsave, X, ldx, Gx, gld_rows, GP, c);
+  tr_rq_backward_item<K>(row, t - row * d_tr, d_tr, tr_cols, P + (long long)t * (3 * K - 1), xsave, X, ldx, Gx, gld_rows,
+                         GP + (long long)t * (3 * K - 1), c);
 }
 
 // affine coupling: P row-major [n][2*d_tr] = [shift block | raw-scale block]
 __device__ __forceinline__ void tr_affine_forward_item(int row, int m, int d_tr, int additive,
                                                        const int* __restrict__ tr_cols,
-                                                       const float* __restrict__ P, float* __restrict__ X, int ldx,
+                                                       const float* __restrict__ Prow, float* __restrict__ X, int ldx,
                                                        float* __restrict__ xsave, float* __restrict__ logdet,
                                                        float aff_a, float aff_b) {
   const int t = row * d_tr + m;
-  const int np = additive ? d_tr : 2 * d_tr;
   const int col = tr_cols[m];
   const float x = X[(long long)row * ldx + col];
   xsave[t] = x;
-  const float shift = P[(long long)row * np + m];
+  const float shift = Prow[m];  // the row's parameters (global row-major, or an LDS tile)
   float scale = 1.0f, ls = 0.0f;
   if (!additive) {
-    scale = 1.0f / (1.0f + expf(-(P[(long long)row * np + d_tr + m] + aff_a))) + aff_b;
+    scale = 1.0f / (1.0f + expf(-(Prow[d_tr + m] + aff_a))) + aff_b;
     ls = logf(scale);
   }
   X[(long long)row * ldx + col] = x * scale + shift;
@@ -428,29 +443,29 @@ __global__ void tr_affine_forward(int n, int d_tr, int additive, const int* __re
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * d_tr) return;
   const int row = t / d_tr;
-  tr_affine_forward_item(row, t - row * d_tr, d_tr, additive, tr_cols, P, X, ldx, xsave, logdet, aff_a, aff_b);
+  tr_affine_forward_item(row, t - row * d_tr, d_tr, additive, tr_cols, P + (long long)row * (additive ? d_tr : 2 * d_tr), X,
+                         ldx, xsave, logdet, aff_a, aff_b);
 }
 
 __device__ __forceinline__ void tr_affine_backward_item(int row, int m, int d_tr, int additive,
                                                         const int* __restrict__ tr_cols,
-                                                        const float* __restrict__ P,
+                                                        const float* __restrict__ Prow,
                                                         const float* __restrict__ xsave, float* __restrict__ X,
                                                         int ldx, float* __restrict__ Gx,
                                                         const float* __restrict__ gld_rows,
-                                                        float* __restrict__ GP, float aff_a, float aff_b) {
+                                                        float* __restrict__ GProw, float aff_a, float aff_b) {
   const int t = row * d_tr + m;
   const float gld = gld_rows[row];
-  const int np = additive ? d_tr : 2 * d_tr;
   const int col = tr_cols[m];
   const float x = xsave[t];
   const float gy = Gx[(long long)row * ldx + col];
   X[(long long)row * ldx + col] = x;
-  GP[(long long)row * np + m] = gy;
+  GProw[m] = gy;
   if (additive) return;
-  const float sig = 1.0f / (1.0f + expf(-(P[(long long)row * np + d_tr + m] + aff_a)));
+  const float sig = 1.0f / (1.0f + expf(-(Prow[d_tr + m] + aff_a)));
   const float scale = sig + aff_b;
   const float s_b = gy * x + gld / scale;
-  GP[(long long)row * np + d_tr + m] = s_b * sig * (1.0f - sig);
+  GProw[d_tr + m] = s_b * sig * (1.0f - sig);
   Gx[(long long)row * ldx + col] = gy * scale;
 }
 
@@ -462,8 +477,9 @@ __global__ void tr_affine_backward(int n, int d_tr, int additive, const int* __r
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * d_tr) return;
   const int row = t / d_tr;
-  tr_affine_backward_item(row, t - row * d_tr, d_tr, additive, tr_cols, P, xsave, X, ldx, Gx, gld_rows, GP, aff_a,
-                          aff_b);
+  const long long np = additive ? d_tr : 2 * d_tr;
+  tr_affine_backward_item(row, t - row * d_tr, d_tr, additive, tr_cols, P + row * np, xsave, X, ldx, Gx, gld_rows,
+                          GP + row * np, aff_a, aff_b);
 }
 
 // ---------------------------------------------------------------------------
@@ -880,6 +896,7 @@ __global__ void tr_copy_rows(long long n, const float* __restrict__ src, float* 
 }
 
 #include "nsa_train_fused.h"
+#include "nsa_train_fused2.h"
 
 // ---------------------------------------------------------------------------
 // host orchestration
@@ -916,10 +933,14 @@ struct TrWs {  // workspace carve (floats)
                     // timestamps, [128..191] sq-norm partials
   float *x, *gx, *logdet, *gld, *gp, *gh, *gu;
   float* wt;        // transposed copy of the weight matrices (fused kernels)
+  float* slab;      // [ceil(n / 32)][npar] per-workgroup weight gradients of the fused backward kernels (or null)
   float* layer_base;
   long long per_layer;
   long long xsave_words;  // n * max(d_tr): size of a coupling layer's saved-input block
 };
+
+// every block of the workspace starts on a 16-byte boundary (the fused kernels copy tiles with 16-byte pieces)
+static inline long long al4(long long words) { return (words + 3) & ~3LL; }
 
 static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, long long& np_max,
                      long long& per_layer) {
@@ -930,16 +951,26 @@ static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, lo
     if (r[0] == TR_COUPLING && r[2] > d_tr_max) d_tr_max = r[2];
   }
   np_max = d_tr_max * plan[7];
-  const long long coupling = n * d_tr_max + (2 * L + 1) * n * H + n * np_max;
+  const long long coupling = al4(n * d_tr_max) + (2 * L + 1) * al4(n * H) + n * np_max;
   const long long linear = 3 * n * D + 4 * D * D + 8 * D;  // x, t, gt | L, U, gL, gU | small vectors
-  per_layer = coupling > linear ? coupling : linear;
+  per_layer = al4(coupling > linear ? coupling : linear);
+}
+
+// The fused backward kernels of the second generation leave each workgroup's share of the weight gradients
+// in its own copy of the flat gradient vector and one kernel sums the copies in a fixed order (below a cap
+// on the copies' size; above it the kernels add to the flat gradient with float atomics as the first generation does)
+static long long tr_slab_floats(const long long* plan, long long n) {
+  const long long grid = (n + TRF_ROWS - 1) / TRF_ROWS;
+  const long long words = grid * al4(plan[8]);
+  return (plan[11] == NSA_NET_RESNET && plan[1] <= 64 && words <= (64LL << 20)) ? words : 0;
 }
 
 extern "C" NSA_API size_t nsa_train_workspace_floats(const long long* plan, long long n) {
   long long d_tr_max, np_max, per_layer;
   tr_sizes(plan, n, d_tr_max, np_max, per_layer);
   const long long D = plan[0], H = plan[1], NL = plan[3];
-  return (size_t)(192 + 2 * n * D + 2 * n + n * np_max + 2 * n * H + NL * per_layer + plan[8]);
+  return (size_t)(192 + 2 * al4(n * D) + 2 * al4(n) + al4(n * np_max) + 2 * al4(n * H) + NL * per_layer + al4(plan[8]) +
+                  tr_slab_floats(plan, n));
 }
 
 static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
@@ -948,17 +979,18 @@ static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
   const long long D = plan[0], H = plan[1];
   float* p = ws;
   w.scal = p; p += 192;  // [0..63] scalars, [64..191] optional phase timestamps
-  w.x = p; p += n * D;
-  w.gx = p; p += n * D;
-  w.logdet = p; p += n;
-  w.gld = p; p += n;
-  w.gp = p; p += n * np_max;
-  w.gh = p; p += n * H;
-  w.gu = p; p += n * H;
+  w.x = p; p += al4(n * D);
+  w.gx = p; p += al4(n * D);
+  w.logdet = p; p += al4(n);
+  w.gld = p; p += al4(n);
+  w.gp = p; p += al4(n * np_max);
+  w.gh = p; p += al4(n * H);
+  w.gu = p; p += al4(n * H);
   w.layer_base = p; p += plan[3] * per_layer;
-  w.wt = p;
+  w.wt = p; p += al4(plan[8]);
+  w.slab = tr_slab_floats(plan, n) > 0 ? p : nullptr;
   w.per_layer = per_layer;
-  w.xsave_words = n * d_tr_max;
+  w.xsave_words = al4(n * d_tr_max);
 }
 
 static inline dim3 tiles(long long rows, long long cols) {
@@ -982,8 +1014,59 @@ static bool tr_use_fused(const long long* plan) {
   return enabled && plan[11] == NSA_NET_RESNET && plan[1] <= 128 && plan[2] <= TRF_MAX_L;  // H <= 128: <= 8 gh tiles
 }
 
+// grads[start + i] += sum over the workgroups' copies, in workgroup order (deterministic)
+struct TrRanges {
+  int count;
+  long long start[32];
+  int len[32];
+};
+__global__ void tr_reduce_slab(const float* __restrict__ slab, long long npar, int copies, float* __restrict__ grads,
+                               TrRanges rg) {
+  const int r = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rg.len[r]) return;
+  const float* src = slab + rg.start[r] + i;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int b = 0;
+  for (; b + 4 <= copies; b += 4) {
+    s0 += src[(long long)b * npar];
+    s1 += src[(long long)(b + 1) * npar];
+    s2 += src[(long long)(b + 2) * npar];
+    s3 += src[(long long)(b + 3) * npar];
+  }
+  for (; b < copies; ++b) s0 += src[(long long)b * npar];
+  grads[rg.start[r] + i] += (s0 + s1) + (s2 + s3);
+}
+
+// second-generation kernels (nsa_train_fused2.h): conditioner at most 64 wide, tiles within the LDS;
+// NESSAI_AMD_TRAIN_V2=0 keeps the first generation (the cross-check of the tests)
+static bool tr_v2_fits(bool backward, const TrfArgs& a) {
+  const char* e = getenv("NESSAI_AMD_TRAIN_V2");
+  if (e != nullptr && e[0] == '0') return false;
+  if (a.H > 64 || a.D > 128 || a.np > 512) return false;
+  if (!backward) return a.d_id <= 64 && trf2_forward_floats(a) * sizeof(float) <= 160 * 1024;
+  // backward: identity columns within the hidden width's tiles, <= 2 items per thread, float4-aligned tiles
+  const int ht = a.H <= 32 ? 1 : 2;
+  return a.d_id <= 32 * ht && a.d_tr <= 32 && a.H % 4 == 0 && ((uintptr_t)a.h % 16 == 0) && ((uintptr_t)a.u % 16 == 0) &&
+         (((long long)a.n * a.H) % 4 == 0) && trf2_backward_floats(a) * sizeof(float) <= 160 * 1024;
+}
+
+template <int K, int HT>
+static hipError_t tr_launch_fused2(bool backward, const TrfArgs& a, hipStream_t s) {
+  const size_t lds = (backward ? trf2_backward_floats(a) : trf2_forward_floats(a)) * sizeof(float);
+  auto kern = !backward ? trf2_forward<K, HT> : (a.gslab != nullptr ? trf2_backward<K, HT, true> : trf2_backward<K, HT, false>);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)((a.n + TRF_ROWS - 1) / TRF_ROWS);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(TRF_THREADS), lds, s, a);
+  return hipGetLastError();
+}
+
 template <int K>
 static hipError_t tr_launch_fused(bool backward, const TrfArgs& a, hipStream_t s) {
+  if (tr_v2_fits(backward, a))
+    return a.H <= 32 ? tr_launch_fused2<K, 1>(backward, a, s) : tr_launch_fused2<K, 2>(backward, a, s);
   const size_t floats = backward ? (size_t)(4 * TRF_ROWS * a.ld + TRF_ROWS * (a.ch + 1))
                                  : (size_t)(2 * TRF_ROWS * a.ld);
   const size_t lds = floats * sizeof(float);
@@ -1133,6 +1216,8 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
   const int transform = (int)plan[4], K = (int)plan[5], act = (int)plan[6], npf = (int)plan[7];
   const long long rec = plan[9];
   TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5], consts[8], consts[9]};
+  TrRanges ranges;
+  ranges.count = 0;
   for (int b = NL - 1; b >= 0; --b) {
     const long long* r = plan + TR_HDR + b * rec;
     float* lay = w.layer_base + b * w.per_layer;
@@ -1157,6 +1242,26 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
         a.id_cols = id_cols; a.tr_cols = tr_cols; a.params = params; a.grads = grads; a.X = w.x; a.Gx = w.gx;
         a.xsave = xsave; a.h = h; a.u = u; a.p = p; a.gp = w.gp; a.gld = w.gld; a.c = c;
         for (int i = 0; i < 4 + 4 * L; ++i) a.off[i] = off[i];
+        // per-workgroup gradient copies when this coupling's parameters are one contiguous block of the flat
+        // vector (they are: the module registers them in order) and there is room for one more range
+        if (w.slab != nullptr && tr_v2_fits(true, a) && ranges.count < 32) {
+          long long expect = off[0];
+          bool contiguous = true;
+          for (int i = 0; i < 4 + 4 * L; ++i) {
+            contiguous = contiguous && off[i] == expect;
+            const bool bias = (i & 1) != 0;
+            const long long rows = (i < 2) ? H : (i >= 2 + 4 * L ? np : H);
+            const long long cols = (i < 2) ? d_id : H;
+            expect += bias ? rows : rows * cols;
+          }
+          if (contiguous && expect - off[0] < (1LL << 31)) {
+            a.gslab = w.slab;
+            a.npar = al4(plan[8]);
+            ranges.start[ranges.count] = off[0];
+            ranges.len[ranges.count] = (int)(expect - off[0]);
+            ++ranges.count;
+          }
+        }
         (void)tr_fused_coupling(true, transform, K, a, s);
         continue;
       }
@@ -1250,6 +1355,12 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
                          grads + r[2], grads + r[3], grads + r[4], w.scal + 2);
       hipLaunchKernelGGL(tr_gather_cols, blocks_for(n * D), dim3(256), 0, s, (int)n, D, q.xin, D, cols, w.x, 1);
     }
+  }
+  if (ranges.count > 0) {
+    int longest = 0;
+    for (int i = 0; i < ranges.count; ++i) longest = ranges.len[i] > longest ? ranges.len[i] : longest;
+    hipLaunchKernelGGL(tr_reduce_slab, dim3((unsigned)((longest + 255) / 256), (unsigned)ranges.count), dim3(256), 0, s,
+                       (const float*)w.slab, al4(plan[8]), (int)((n + TRF_ROWS - 1) / TRF_ROWS), grads, ranges);
   }
 }
 

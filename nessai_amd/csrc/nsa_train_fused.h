@@ -50,6 +50,8 @@ struct TrfArgs {
   float* logdet;  // [n]
   const float* gld;  // [n] dL/dlogdet
   float* dbg;        // optional: 32 phase timestamps (cycles since kernel start) of workgroup 0
+  float* gslab;      // second generation: [grid][npar] per-workgroup weight gradients (null: float atomics on grads)
+  long long npar;
   TrConsts c;
   long long off[2 + 4 * TRF_MAX_L + 2];  // flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf
 };
@@ -363,10 +365,11 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_forward(TrfArgs a) {
     const int row = r0 + r;
     if (row >= n) continue;
     if constexpr (K > 0) {
-      tr_rq_forward_item<K>(row, m, a.d_tr, a.tr_cols, a.p, a.X, a.D, a.xsave, a.logdet, a.c);
+      tr_rq_forward_item<K>(row, m, a.d_tr, a.tr_cols, a.p + (long long)row * a.np + m * (3 * K - 1), a.X, a.D, a.xsave,
+                            a.logdet, a.c);
     } else {
-      tr_affine_forward_item(row, m, a.d_tr, a.transform == NSA_T_ADDITIVE ? 1 : 0, a.tr_cols, a.p, a.X, a.D,
-                             a.xsave, a.logdet, a.c.aff_a, a.c.aff_b);
+      tr_affine_forward_item(row, m, a.d_tr, a.transform == NSA_T_ADDITIVE ? 1 : 0, a.tr_cols,
+                             a.p + (long long)row * a.np, a.X, a.D, a.xsave, a.logdet, a.c.aff_a, a.c.aff_b);
     }
   }
   TRF_MARK(22);
@@ -399,10 +402,12 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
     const int row = r0 + r;
     if (row >= n) continue;
     if constexpr (K > 0) {
-      tr_rq_backward_item<K>(row, m, a.d_tr, a.tr_cols, a.p, a.xsave, a.X, a.D, a.Gx, a.gld, a.gp, a.c);
+      const long long it = (long long)row * a.np + m * (3 * K - 1);
+      tr_rq_backward_item<K>(row, m, a.d_tr, a.tr_cols, a.p + it, a.xsave, a.X, a.D, a.Gx, a.gld, a.gp + it, a.c);
     } else {
-      tr_affine_backward_item(row, m, a.d_tr, a.transform == NSA_T_ADDITIVE ? 1 : 0, a.tr_cols, a.p, a.xsave, a.X,
-                              a.D, a.Gx, a.gld, a.gp, a.c.aff_a, a.c.aff_b);
+      tr_affine_backward_item(row, m, a.d_tr, a.transform == NSA_T_ADDITIVE ? 1 : 0, a.tr_cols,
+                              a.p + (long long)row * a.np, a.xsave, a.X, a.D, a.Gx, a.gld, a.gp + (long long)row * a.np,
+                              a.c.aff_a, a.c.aff_b);
     }
   }
   trf_stage(A1, ld, a.h + a.L * nH, H, r0, n, 0, H, H, nullptr, tid);  // h_L

@@ -1,0 +1,675 @@
+// Second generation of the fused training kernels of one coupling layer (included by nsa_train.hip
+// after nsa_train_fused.h; same TrfArgs, same workspace layout, same results up to the order of the
+// float32 sums).  Used when the conditioner is at most 64 wide (tr_v2_fits); the first generation stays
+// for wider nets and as the cross-check.
+//
+// What the first generation spends its time on (scripts/ubench/layer_latency.hip measures the floor:
+// a 32 x 64 -> 64 layer costs a workgroup 1.07 us with its operands at hand, the first generation
+// ~4 us) is a chain of exposed round trips: per layer the second half of the weights and the bias
+// are requested where they are used, and only 2 of the 8 waves own an output tile.  Here
+//   * every layer's B operands and bias are requested ONE LAYER AHEAD into registers (plain loads:
+//     the compiler's own wait counting stays valid next to the activation saves), the operands of the
+//     final layer - 60 % of the weight bytes - at kernel start, two output tiles per wave;
+//   * a hidden layer is split over all 8 waves, output tile x slice of k, and the partial sums meet
+//     in LDS where bias, residual and the activation save are applied by all 512 threads;
+//   * the parameters of the transform stay in an LDS tile for the spline / affine items (and are saved
+//     for the backward pass with stores nobody waits for).
+// Reference semantics: glasflow.nflows ResidualNet (call sites src/nessai/flows/nsf.py:85-95,
+// realnvp.py:136-146) under FlowModel._train (src/nessai/flowmodel/base.py:365-452).
+#pragma once
+
+#ifndef TRF2_ABL
+#define TRF2_ABL 0  // diagnostic builds only (scripts/gpu_r03_h.sh): 1 drops the weight-gradient atomics
+#endif
+#define TRF2_PP 8  // k pairs per split-k item: 32 pairs / 4 slices (H <= 64), 32 / 8 (H <= 32)
+
+// split of a [rows x Kd] . [Kd x O] product, O <= 32 HT, over the 8 waves: tile ot = wave % HT, slice ks = wave / HT
+template <int HT>
+struct Trf2Item {
+  static constexpr int KS = TRF_WAVES / HT;
+  int ot, ks, pp;  // pp: k pairs per slice (wave-uniform, <= TRF2_PP)
+  __device__ __forceinline__ Trf2Item(int wave, int Kd) {
+    ot = wave % HT;
+    ks = wave / HT;
+    const int pairs = (Kd + 1) >> 1;
+    pp = (pairs + KS - 1) / KS;
+  }
+};
+
+// B operands of this wave's item (W^T[k][o], lanes along o: coalesced) and the bias of the column this
+// THREAD finishes in the reduction (column tid % (32 HT)).  Every load is unconditional from a clamped
+// address and its value is first touched by the MFMA: a select on the loaded value makes the compiler
+// branch round the load and wait for it on the spot - 64 serialised round trips in the first version of
+// this kernel.  Out-of-range k carry a zero A operand instead; out-of-range columns are never written.
+template <int HT>
+__device__ __forceinline__ void trf2_load_w(float (&w)[TRF2_PP], float& bias, const float* __restrict__ Wt,
+                                            const float* __restrict__ b, int Kd, int O, int wave, int lane,
+                                            int tid) {
+  const Trf2Item<HT> it(wave, Kd);
+  const int half = lane >> 5, j = lane & 31;
+  const int o = it.ot * 32 + j;
+  const unsigned oc = (unsigned)(o < O ? o : O - 1);
+#pragma unroll
+  for (int q = 0; q < TRF2_PP; ++q) {
+    const int k = 2 * (it.ks * it.pp + q) + half;
+    w[q] = Wt[(unsigned)(k < Kd ? k : Kd - 1) * (unsigned)O + oc];
+  }
+  const int oc2 = tid & (32 * HT - 1);
+  bias = b[oc2 < O ? oc2 : O - 1];
+}
+
+// out[row][o] = sum_k act(Ain[row][k]) W[o][k] + b[o] (+ R[row][o]) for the workgroup's 32 rows.
+// Ends with the output tile WRITTEN but not yet published (the caller's barrier does that).
+// GATHER: the A operand's column of slot q is cidx[q] (layer 0 reads the identity columns out of the x tile).
+template <int HT, bool GATHER = false>
+__device__ __forceinline__ void trf2_layer(const float* __restrict__ Ain, int act_in, const float (&w)[TRF2_PP],
+                                           const int (&cidx)[TRF2_PP],
+                                           float bias, int Kd, int O, const float* R, float* out_tile,
+                                           float* __restrict__ out_glb, int ld, int r0, int n,
+                                           float* __restrict__ part, int wave, int lane, int tid) {
+  constexpr int KS = Trf2Item<HT>::KS;
+  const Trf2Item<HT> it(wave, Kd);
+  const int half = lane >> 5, j = lane & 31;
+  float av[TRF2_PP];
+#pragma unroll
+  for (int q = 0; q < TRF2_PP; ++q) {
+    const int k = 2 * (it.ks * it.pp + q) + half;
+    av[q] = GATHER ? Ain[cidx[q]] : Ain[j * ld + (k < Kd ? k : 0)];
+  }
+  trf_act_batch(av, act_in);
+#pragma unroll
+  for (int q = 0; q < TRF2_PP; ++q) {  // a factor, not a select: see trf2_load_w
+    const int k = 2 * (it.ks * it.pp + q) + half;
+    av[q] *= (q < it.pp && k < Kd) ? 1.0f : 0.0f;
+  }
+  f32x16 acc = {0}, acc2 = {0};
+#pragma unroll
+  for (int q = 0; q < TRF2_PP; q += 2) {
+    if (q < it.pp) {  // wave-uniform
+      acc = nsa_mfma(av[q], w[q], acc);
+      acc2 = nsa_mfma(av[q + 1], w[q + 1], acc2);
+    }
+  }
+  float* pp_ = part + wave * 1024;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pp_[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + j] = acc[r] + acc2[r];
+  trf_barrier_lds();
+  // 32 x 32 HT outputs over 512 threads: column tid % (32 HT), rows tid / (32 HT) + (16 / HT) i
+  constexpr int NC = 32 * HT, STEP = TRF_THREADS / NC;
+  const int o = tid & (NC - 1), rb = tid / NC;
+  const float* pc = part + (o >> 5) * 1024 + (o & 31);
+  if (o < O) {
+#pragma unroll
+    for (int i = 0; i < 32 / STEP; ++i) {
+      const int row = rb + STEP * i;
+      float v = bias;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) v += pc[(s * HT) * 1024 + row * 32];
+      if (R) v += R[row * ld + o];
+      out_tile[row * ld + o] = v;
+      if (r0 + row < n) out_glb[(unsigned)(r0 + row) * (unsigned)O + (unsigned)o] = v;
+    }
+  }
+}
+
+// Async copy (global_load_lds, 4 bytes per lane) of the workgroup's 32 rows of a row-major [n][W] global matrix
+// into an LDS tile with row stride `lds_ld`: rows wave, wave + 8, ..., 64 floats per instruction, no registers
+// and no index arithmetic per element.  Rows beyond n read row n - 1.  The caller waits (vmcnt) before its barrier.
+__device__ __forceinline__ void trf2_rows_async(float* tile, int lds_ld, const float* __restrict__ src, int W,
+                                                int r0, int n, int wave, int lane) {
+  for (int r = wave; r < TRF_ROWS; r += TRF_WAVES) {
+    const int row = r0 + r < n ? r0 + r : n - 1;
+    const float* g = src + (long long)row * W;
+    for (int c0 = 0; c0 < W; c0 += 64) {
+      if (c0 + lane < W)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c0 + lane),
+                                         (__attribute__((address_space(3))) void*)(tile + r * lds_ld + c0), 4, 0, 0);
+    }
+  }
+}
+
+// LDS floats of trf2_forward: the x tile, two activation tiles, the partial sums, the parameter tile
+static inline int trf2_ldx(const TrfArgs& a) { return (a.D + 1) | 1; }
+static inline size_t trf2_forward_floats(const TrfArgs& a) {
+  return (size_t)TRF_ROWS * trf2_ldx(a) + (size_t)2 * TRF_ROWS * a.ld + (size_t)TRF_WAVES * 1024 +
+         (size_t)TRF_ROWS * a.np;
+}
+
+template <int K, int HT>  // spline bins (0: affine / additive); hidden width <= 32 HT
+__global__ void __launch_bounds__(TRF_THREADS) trf2_forward(TrfArgs a) {
+  extern __shared__ float trf_sm[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: the item tests below are scalar branches
+  const int r0 = blockIdx.x * TRF_ROWS;
+  const int ld = a.ld, n = a.n, H = a.H, np = a.np, D = a.D;
+  const int ldx = (D + 1) | 1;
+  float* XT = trf_sm;                  // [32][ldx] the workgroup's rows of x, all columns
+  float* HC = XT + TRF_ROWS * ldx;     // h_l
+  float* U = HC + TRF_ROWS * ld;       // u_l
+  float* part = U + TRF_ROWS * ld;     // [8 items][32][32] partial sums
+  float* PT = part + TRF_WAVES * 1024;  // [32][np] transform parameters
+  const float* P = a.params;
+  const float* WT = a.wt;
+  const long long nH = (long long)n * H;
+  const long long t_start = clock64();
+
+  // the x rows (async, straight into the padded tile), the identity column table and layer 0 first; the
+  // first hidden layer and - used only after the hidden layers - the final layer's operands for output
+  // tiles wave and wave + 8 are requested behind the first barrier, so that it waits for the former only
+  trf2_rows_async(XT, ldx, a.X, D, r0, n, wave, lane);
+  const Trf2Item<HT> it0(wave, a.d_id);
+  int cidx[TRF2_PP], none[TRF2_PP];
+#pragma unroll
+  for (int q = 0; q < TRF2_PP; ++q) {
+    const int k = 2 * (it0.ks * it0.pp + q) + half;
+    cidx[q] = a.id_cols[k < a.d_id ? k : 0] + j * ldx;
+    none[q] = 0;
+  }
+  float wc[TRF2_PP], wn[TRF2_PP], bc, bn = 0.0f;
+  trf2_load_w<HT>(wc, bc, WT + a.off[0], P + a.off[1], a.d_id, H, wave, lane, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the async rows (and layer 0)
+  trf_barrier_lds();
+  if (a.L > 0) trf2_load_w<HT>(wn, bn, WT + a.off[2], P + a.off[3], H, H, wave, lane, tid);
+  constexpr int FP = 16 * HT;  // k pairs of the final layer
+  const int OTf = (np + 31) >> 5;
+  const float* Wf = WT + a.off[2 + 4 * a.L];
+  const float* bf = P + a.off[3 + 4 * a.L];
+  float wf[2][FP], bfv[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int o = (wave + TRF_WAVES * s) * 32 + j;
+    const unsigned oc = (unsigned)(o < np ? o : np - 1);
+    bfv[s] = bf[oc];
+#pragma unroll
+    for (int q = 0; q < FP; ++q) {
+      const int k = 2 * q + half;
+      wf[s][q] = Wf[(unsigned)(k < H ? k : H - 1) * (unsigned)np + oc];
+    }
+  }
+  TRF_MARK(0);
+  // h_0 = W0 x_id + b0
+  trf2_layer<HT, true>(XT, ACT_NONE, wc, cidx, bc, a.d_id, H, nullptr, HC, a.h, ld, r0, n, part, wave, lane, tid);
+  TRF_MARK(1);
+  for (int l = 0; l < a.L; ++l) {
+    // u_l = W1 act(h_l) + b1;  h_{l+1} = h_l + W2 act(u_l) + b2
+#pragma unroll
+    for (int q = 0; q < TRF2_PP; ++q) wc[q] = wn[q];
+    bc = bn;
+    trf2_load_w<HT>(wn, bn, WT + a.off[4 + 4 * l], P + a.off[5 + 4 * l], H, H, wave, lane, tid);
+    trf_barrier_lds();
+    trf2_layer<HT>(HC, a.act, wc, none, bc, H, H, nullptr, U, a.u + l * nH, ld, r0, n, part, wave, lane, tid);
+    TRF_MARK(2 + 2 * l);
+#pragma unroll
+    for (int q = 0; q < TRF2_PP; ++q) wc[q] = wn[q];
+    bc = bn;
+    if (l + 1 < a.L) trf2_load_w<HT>(wn, bn, WT + a.off[6 + 4 * l], P + a.off[7 + 4 * l], H, H, wave, lane, tid);
+    trf_barrier_lds();
+    trf2_layer<HT>(U, a.act, wc, none, bc, H, H, HC, HC, a.h + (l + 1) * nH, ld, r0, n, part, wave, lane, tid);
+    TRF_MARK(3 + 2 * l);
+  }
+  trf_barrier_lds();
+  // parameters = Wf h_L + bf: whole output tiles, no split (waves w and w + 4 share a SIMD: 3 tiles each of 12)
+  {
+    float av[FP];
+    const float* ax = HC + j * ld;
+#pragma unroll
+    for (int q = 0; q < FP; ++q) {
+      const int k = 2 * q + half;
+      av[q] = ax[k < H ? k : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < FP; ++q) av[q] *= (2 * q + half < H) ? 1.0f : 0.0f;
+    const int pairs = (H + 1) >> 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int t = wave + TRF_WAVES * s;
+      if (t < OTf) {  // wave-uniform
+        f32x16 acc = {0}, acc2 = {0};
+#pragma unroll
+        for (int q = 0; q < FP; q += 2) {
+          if (q < pairs) {
+            acc = nsa_mfma(av[q], wf[s][q], acc);
+            acc2 = nsa_mfma(av[q + 1], wf[s][q + 1], acc2);
+          }
+        }
+        const int o = t * 32 + j;
+        if (o < np) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float v = acc[r] + acc2[r] + bfv[s];
+            PT[rl * np + o] = v;
+            if (r0 + rl < n) a.p[(unsigned)(r0 + rl) * (unsigned)np + (unsigned)o] = v;
+          }
+        }
+      }
+    }
+  }
+  TRF_MARK(20);
+  trf_barrier_lds();
+  TRF_MARK(21);
+  // the transform on the x tile's own copy of x: no load behind the stores above
+  const int items = TRF_ROWS * a.d_tr;
+  for (int e = tid; e < items; e += TRF_THREADS) {
+    const int r = e / a.d_tr, m = e - r * a.d_tr;
+    const int row = r0 + r;
+    if (row >= n) continue;
+    const int col = a.tr_cols[m];
+    const float x = XT[r * ldx + col];
+    float y, ldj;
+    if constexpr (K > 0) {
+      tr_rq_forward_core<K>(PT + r * np + m * (3 * K - 1), x, a.c, y, ldj);
+    } else {
+      const float* pr = PT + r * np;
+      float scale = 1.0f;
+      ldj = 0.0f;
+      if (a.transform != NSA_T_ADDITIVE) {
+        scale = 1.0f / (1.0f + expf(-(pr[a.d_tr + m] + a.c.aff_a))) + a.c.aff_b;
+        ldj = logf(scale);
+      }
+      y = x * scale + pr[m];
+    }
+    a.xsave[row * a.d_tr + m] = x;
+    a.X[(long long)row * D + col] = y;
+    if (K > 0 || a.transform != NSA_T_ADDITIVE) atomicAdd(&a.logdet[row], ldj);
+  }
+  TRF_MARK(22);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward pass of the coupling layer
+//
+// The workgroup's slice of everything the forward pass saved - transform parameters, h_0..h_L, u_0..u_{L-1},
+// its rows of x and of dL/dx - is requested at kernel start and lives in LDS; the parameter tile is
+// overwritten in place by its own gradient (the spline / affine items), so the gradient of the final
+// layer's 3K - 1 parameters per feature never travels through global memory.  Every linear layer is then
+// one step for all 8 waves:
+//   dX  partial products  G[row][out] . W[out][in], in-tile x slice of `out`   (B from registers, requested
+//       one step ahead; the final layer's, 60 % of the bytes, at kernel start)
+//   dW  G^T[out][row] . act(A)[row][in], output tile x slice of the rows, both operands from LDS, added to
+//       the flat gradient with float atomics (which also merge the row slices)
+//   barrier, then all 512 threads sum the dX slices, apply act'(z) and the residual path, write the next
+//   gradient tile and add its column sums to the bias gradient of the layer that produced it.
+// ---------------------------------------------------------------------------------------------------
+
+#define TRF2_FQ 64   // k pairs per slice of the final layer's dX: 256 pairs (np <= 512) / 4 slices
+
+static inline size_t trf2_backward_floats(const TrfArgs& a) {
+  const size_t ldx = (size_t)trf2_ldx(a);
+  return (size_t)TRF_ROWS * (a.np | 1) + (size_t)(2 * a.L + 1) * TRF_ROWS * a.H + 2 * TRF_ROWS * ldx +
+         (size_t)2 * TRF_ROWS * a.ld + (size_t)TRF_WAVES * 1024;
+}
+
+// a workgroup's contribution to a weight gradient: its own copy of the flat vector (plain store, summed by
+// tr_reduce_slab) or a float atomic on the shared one
+template <bool SLAB>
+__device__ __forceinline__ void trf2_grad_out(float* dst, float v) {
+  if (TRF2_ABL & 1) return;
+  if constexpr (SLAB) *dst = v;
+  else atomicAdd(dst, v);
+}
+
+// B operands of a dX item: W[out = k][in = it * 32 + j] (natural layout, lanes along `in`: coalesced)
+template <int HT>
+__device__ __forceinline__ void trf2_load_wx(float (&w)[TRF2_PP], const float* __restrict__ W, int O, int Kin,
+                                             int wave, int lane) {
+  const Trf2Item<HT> it(wave, O);
+  const int half = lane >> 5, j = lane & 31;
+  const int c = it.ot * 32 + j;
+  const unsigned cc = (unsigned)(c < Kin ? c : Kin - 1);
+#pragma unroll
+  for (int q = 0; q < TRF2_PP; ++q) {
+    const int k = 2 * (it.ks * it.pp + q) + half;
+    w[q] = W[(unsigned)(k < O ? k : O - 1) * (unsigned)Kin + cc];
+  }
+}
+
+// One linear layer of the backward pass (see the header of this section).
+//   G [32][ld]: gradient w.r.t. the layer's output (O = H columns);  w: this wave's dX operands
+//   Ain: the layer's input tile (A = act_in(Ain)), row stride a_ld, column of slot c = acol(c);  Kin inputs
+//   Z: pre-activation whose act' multiplies dX (null: none), row stride H;  Rs: tile added to the result (null: none)
+//   out [32][ld] <- result;  gW / gb: flat gradients of this layer's weights and bias
+template <int HT, bool GATHER, bool SLAB>
+__device__ __forceinline__ void trf2_back_linear(const float* __restrict__ G, const float (&w)[TRF2_PP], int O,
+                                                 const float* __restrict__ Ain, int a_ld, const int* __restrict__ cols,
+                                                 int act_in, int Kin, const float* __restrict__ Z, int act_z,
+                                                 const float* Rs, float* out, float* __restrict__ gW,
+                                                 float* __restrict__ gb, int ld, float* __restrict__ part,
+                                                 int wave, int lane, int tid) {
+  constexpr int KS = Trf2Item<HT>::KS;
+  const int half = lane >> 5, j = lane & 31;
+  const int IT = (Kin + 31) >> 5;  // <= HT
+  // dX partial product of item (in-tile, slice of `out`)
+  {
+    const Trf2Item<HT> it(wave, O);
+    float av[TRF2_PP];
+#pragma unroll
+    for (int q = 0; q < TRF2_PP; ++q) {
+      const int k = 2 * (it.ks * it.pp + q) + half;
+      av[q] = G[j * ld + (k < O ? k : 0)];
+    }
+#pragma unroll
+    for (int q = 0; q < TRF2_PP; ++q) {
+      const int k = 2 * (it.ks * it.pp + q) + half;
+      av[q] *= (q < it.pp && k < O) ? 1.0f : 0.0f;
+    }
+    f32x16 acc = {0}, acc2 = {0};
+    if (it.ot < IT) {
+#pragma unroll
+      for (int q = 0; q < TRF2_PP; q += 2) {
+        if (q < it.pp) {
+          acc = nsa_mfma(av[q], w[q], acc);
+          acc2 = nsa_mfma(av[q + 1], w[q + 1], acc2);
+        }
+      }
+    }
+    float* pp_ = part + wave * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pp_[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + j] = acc[r] + acc2[r];
+  }
+  // dW: one (out-tile, in-tile) per wave, all 32 rows (every element of the gradient is written once per
+  // workgroup); the last wave sums the columns of G for the bias instead
+  {
+    const int NT = HT * IT;  // 1, 2 or 4
+    if (wave < NT) {
+      const int ot = wave % HT, itl = wave / HT;
+      const int oc = ot * 32 + j, kc = itl * 32 + j;
+      const int ocl = oc < O ? oc : 0, kcl = kc < Kin ? kc : 0;
+      const int acol = GATHER ? cols[kcl] : kcl;
+      float av[16], bv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 2 * q + half;
+        av[q] = G[row * ld + ocl];
+        bv[q] = Ain[row * a_ld + acol];
+      }
+      trf_act_batch(bv, act_in);
+      f32x16 acc = {0}, acc2 = {0};
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {
+        acc = nsa_mfma(av[q], bv[q], acc);
+        acc2 = nsa_mfma(av[q + 1], bv[q + 1], acc2);
+      }
+      if (kc < Kin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (o < O) trf2_grad_out<SLAB>(&gW[(unsigned)o * (unsigned)Kin + (unsigned)kc], acc[r] + acc2[r]);
+        }
+      }
+    } else if (wave == TRF_WAVES - 1 && lane < O) {
+      float s = 0.0f;
+#pragma unroll 8
+      for (int row = 0; row < TRF_ROWS; ++row) s += G[row * ld + lane];
+      trf2_grad_out<SLAB>(&gb[lane], s);
+    }
+  }
+  trf_barrier_lds();
+  // sum the slices; act'(z), residual path, bias gradient of the producing layer
+  constexpr int NC = 32 * HT, STEP = TRF_THREADS / NC;
+  const int c = tid & (NC - 1), rb = tid / NC;
+  const float* pc = part + (c >> 5) * 1024 + (c & 31);
+  if (c < Kin) {
+#pragma unroll
+    for (int i = 0; i < 32 / STEP; ++i) {
+      const int row = rb + STEP * i;
+      float v = 0.0f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) v += pc[(s * HT) * 1024 + row * 32];
+      if (Z) {
+        const float z = Z[row * O + c];  // the tiles of h / u are [32][H] and Kin == H here
+        if (act_z == NSA_ACT_RELU) v = z > 0.0f ? v : 0.0f;
+        else v *= tr_act_grad(z, act_z);
+      }
+      if (Rs) v += Rs[row * ld + c];
+      out[row * ld + c] = v;
+    }
+  }
+}
+
+template <int K, int HT, bool SLAB>
+__global__ void __launch_bounds__(TRF_THREADS) trf2_backward(TrfArgs a) {
+  extern __shared__ float trf_sm[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: the item tests below are scalar branches
+  const int r0 = blockIdx.x * TRF_ROWS;
+  const int ld = a.ld, n = a.n, H = a.H, np = a.np, D = a.D, L = a.L;
+  const int ldx = (D + 1) | 1, pld = np | 1;
+  float* PT = trf_sm;                          // [32][pld] parameters, then their gradient
+  float* ACT = PT + TRF_ROWS * pld;            // h_0 .. h_L, u_0 .. u_{L-1}: [32][H] each
+  float* XT = ACT + (2 * L + 1) * TRF_ROWS * H;  // [32][ldx] rows of x (as the forward pass left them)
+  float* GXT = XT + TRF_ROWS * ldx;            // [32][ldx] rows of dL/dx
+  float* G0 = GXT + TRF_ROWS * ldx;
+  float* G1 = G0 + TRF_ROWS * ld;
+  float* part = G1 + TRF_ROWS * ld;
+  const float* P = a.params;
+  float* GR = SLAB ? a.gslab + (long long)blockIdx.x * a.npar : a.grads;
+  const long long nH = (long long)n * H;
+  const long long t_start = clock64();
+  const int rows_here = (n - r0 < TRF_ROWS) ? (n - r0) : TRF_ROWS;
+
+  // ---- what the transform items need: parameter tile, dL/dx rows, saved x (async copies + 3 loads) ----
+  trf2_rows_async(PT, pld, a.p, np, r0, n, wave, lane);
+  trf2_rows_async(GXT, ldx, a.Gx, D, r0, n, wave, lane);
+  // items of the transform: (row, feature) = (e / d_tr, e % d_tr), e = tid + 512 i
+  constexpr int IQ = 2;  // d_tr <= 32
+  float xs[IQ], gldv[IQ];
+  int colv[IQ];
+#pragma unroll
+  for (int i = 0; i < IQ; ++i) {
+    const int e = tid + TRF_THREADS * i;
+    const int r = e / a.d_tr, m = e - r * a.d_tr;
+    const int row = (r < rows_here) ? r0 + r : n - 1;
+    xs[i] = a.xsave[row * a.d_tr + m];
+    gldv[i] = a.gld[row];
+    colv[i] = a.tr_cols[m];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  trf_barrier_lds();
+  TRF_MARK(30);
+  // ---- requested now, used after the items: x rows (identity columns), activation tiles ([32][H] contiguous in
+  // global memory and in LDS: 1 KiB pieces; H % 4 == 0 and 16-byte aligned blocks, tr_v2_fits), the final
+  // layer's dX operands Wf[o][in] of item (in-tile wave % HT, slice wave / HT of the np parameters), and
+  // the first backward step of the hidden layers: W2 of the last block (or W0 when there is none)
+  trf2_rows_async(XT, ldx, a.X, D, r0, n, wave, lane);
+  {
+    const int words = TRF_ROWS * H;
+    for (int t = 0; t < 2 * L + 1; ++t) {
+      const float* src = (t <= L) ? a.h + t * nH : a.u + (t - L - 1) * nH;
+      for (int piece = wave; piece * 256 < words; piece += TRF_WAVES) {
+        const int word = piece * 256 + lane * 4;
+        if (word < words) {
+          long long g = (long long)r0 * H + word;
+          g = g < nH - 4 ? g : nH - 4;
+          nsa_glds16((const uint32_t*)(src + g), ACT + t * words + piece * 256);
+        }
+      }
+    }
+  }
+  constexpr int KSF = TRF_WAVES / HT;
+  const float* Wf = P + a.off[2 + 4 * L];
+  const int pairs_f = (np + 1) >> 1;
+  const int ppf = (pairs_f + KSF - 1) / KSF;  // <= TRF2_FQ
+  const int itf = wave % HT, ksf = wave / HT;
+  float wfd[TRF2_FQ];
+  {
+    const int cI = itf * 32 + j;
+    const unsigned cc = (unsigned)(cI < H ? cI : H - 1);
+#pragma unroll
+    for (int q = 0; q < TRF2_FQ; ++q) {
+      const int k = 2 * (ksf * ppf + q) + half;
+      wfd[q] = Wf[(unsigned)(k < np ? k : np - 1) * (unsigned)H + cc];
+    }
+  }
+  float wc[TRF2_PP], wn[TRF2_PP];
+  if (L > 0) trf2_load_wx<HT>(wn, P + a.off[4 + 4 * (L - 1)], H, H, wave, lane);
+  else trf2_load_wx<HT>(wn, P + a.off[0], H, a.d_id, wave, lane);
+
+  TRF_MARK(40);
+  // ---- transform backward: parameters -> their gradient in place, dL/dx_tr, x restored ----
+#pragma unroll
+  for (int i = 0; i < IQ; ++i) {
+    const int e = tid + TRF_THREADS * i;
+    if (e < TRF_ROWS * a.d_tr) {
+      const int r = e / a.d_tr, m = e - r * a.d_tr;
+      const int col = colv[i];
+      float* pit = PT + r * pld;
+      if (r < rows_here) {
+        const float gy = GXT[r * ldx + col];
+        float gx;
+        if constexpr (K > 0) {
+          gx = tr_rq_backward_core<K>(pit + m * (3 * K - 1), xs[i], gy, gldv[i], a.c, pit + m * (3 * K - 1));
+        } else {
+          gx = gy;
+          if (a.transform != NSA_T_ADDITIVE) {
+            const float sig = 1.0f / (1.0f + expf(-(pit[a.d_tr + m] + a.c.aff_a)));
+            const float scale = sig + a.c.aff_b;
+            pit[a.d_tr + m] = (gy * xs[i] + gldv[i] / scale) * sig * (1.0f - sig);
+            gx = gy * scale;
+          }
+          pit[m] = gy;
+        }
+        const long long g = (long long)(r0 + r) * D + col;
+        a.X[g] = xs[i];
+        a.Gx[g] = gx;
+      } else {  // rows beyond the batch contribute nothing to the weight gradients
+        if constexpr (K > 0) {
+#pragma unroll
+          for (int q = 0; q < 3 * K - 1; ++q) pit[m * (3 * K - 1) + q] = 0.0f;
+        } else {
+          pit[m] = 0.0f;
+          if (a.transform != NSA_T_ADDITIVE) pit[a.d_tr + m] = 0.0f;
+        }
+      }
+    }
+  }
+  TRF_MARK(41);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the async x rows and activation tiles
+  trf_barrier_lds();
+  TRF_MARK(31);
+
+  // ---- final layer: gh = gp . Wf (slices of the np parameters), dWf = gp^T . h_L, dbf ----
+  const float* hL = ACT + L * TRF_ROWS * H;
+  {
+    f32x16 acc = {0}, acc2 = {0};
+    const float* ax = PT + j * pld;
+#pragma unroll
+    for (int q0 = 0; q0 < TRF2_FQ; q0 += 16) {
+      if (q0 < ppf) {  // uniform
+        float av[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int k = 2 * (ksf * ppf + q0 + q) + half;
+          av[q] = ax[k < np ? k : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int k = 2 * (ksf * ppf + q0 + q) + half;
+          av[q] *= (q0 + q < ppf && k < np) ? 1.0f : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+          if (q0 + q < ppf) {
+            acc = nsa_mfma(av[q], wfd[q0 + q], acc);
+            acc2 = nsa_mfma(av[q + 1], wfd[q0 + q + 1], acc2);
+          }
+        }
+      }
+    }
+    float* pp_ = part + wave * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pp_[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + j] = acc[r] + acc2[r];
+  }
+  {
+    const int OTf = (np + 31) >> 5;
+    float* gWf = GR + a.off[2 + 4 * L];
+    for (int t = wave; t < OTf * HT; t += TRF_WAVES) {
+      const int ot = t / HT, itl = t - ot * HT;
+      const int oc = ot * 32 + j, kc = itl * 32 + j;
+      const int ocl = oc < np ? oc : 0, kcl = kc < H ? kc : 0;
+      float av[16], bv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 2 * q + half;
+        av[q] = PT[row * pld + ocl];
+        bv[q] = hL[row * H + kcl];
+      }
+      f32x16 acc = {0}, acc2 = {0};
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {
+        acc = nsa_mfma(av[q], bv[q], acc);
+        acc2 = nsa_mfma(av[q + 1], bv[q + 1], acc2);
+      }
+      if (kc < H) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (o < np) trf2_grad_out<SLAB>(&gWf[(unsigned)o * (unsigned)H + (unsigned)kc], acc[r] + acc2[r]);
+        }
+      }
+    }
+    float* gbf = GR + a.off[3 + 4 * L];
+    for (int o = tid; o < np; o += TRF_THREADS) {
+      float s = 0.0f;
+#pragma unroll 8
+      for (int row = 0; row < TRF_ROWS; ++row) s += PT[row * pld + o];
+      trf2_grad_out<SLAB>(&gbf[o], s);
+    }
+  }
+  trf_barrier_lds();
+  {
+    // gh -> G0
+    constexpr int NC = 32 * HT, STEP = TRF_THREADS / NC;
+    const int c = tid & (NC - 1), rb = tid / NC;
+    const float* pc = part + (c >> 5) * 1024 + (c & 31);
+    if (c < H) {
+#pragma unroll
+      for (int i = 0; i < 32 / STEP; ++i) {
+        const int row = rb + STEP * i;
+        float v = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KSF; ++s) v += pc[(s * HT) * 1024 + row * 32];
+        G0[row * ld + c] = v;
+      }
+    }
+  }
+  TRF_MARK(32);
+
+  // ---- residual blocks, last to first ----
+  for (int l = L - 1; l >= 0; --l) {
+    const float* hl = ACT + l * TRF_ROWS * H;
+    const float* ul = ACT + (L + 1 + l) * TRF_ROWS * H;
+    // h_{l+1} = h_l + W2 act(u_l) + b2:  g_u = (G0 . W2) act'(u_l) -> G1
+#pragma unroll
+    for (int q = 0; q < TRF2_PP; ++q) wc[q] = wn[q];
+    trf2_load_wx<HT>(wn, P + a.off[2 + 4 * l], H, H, wave, lane);
+    trf_barrier_lds();
+    trf2_back_linear<HT, false, SLAB>(G0, wc, H, ul, H, nullptr, a.act, H, ul, a.act, nullptr, G1, GR + a.off[4 + 4 * l],
+                                      GR + a.off[5 + 4 * l], ld, part, wave, lane, tid);
+    // u_l = W1 act(h_l) + b1:  g_h_l = G0 + (G1 . W1) act'(h_l) -> G0
+#pragma unroll
+    for (int q = 0; q < TRF2_PP; ++q) wc[q] = wn[q];
+    if (l > 0) trf2_load_wx<HT>(wn, P + a.off[4 + 4 * (l - 1)], H, H, wave, lane);
+    else trf2_load_wx<HT>(wn, P + a.off[0], H, a.d_id, wave, lane);
+    trf_barrier_lds();
+    trf2_back_linear<HT, false, SLAB>(G1, wc, H, hl, H, nullptr, a.act, H, hl, a.act, G0, G0, GR + a.off[2 + 4 * l],
+                                      GR + a.off[3 + 4 * l], ld, part, wave, lane, tid);
+    TRF_MARK(33 + (L - 1 - l));
+  }
+
+  // ---- initial layer: dW0 = G0^T . x_id, g_x[:, id_cols] += G0 . W0 ----
+#pragma unroll
+  for (int q = 0; q < TRF2_PP; ++q) wc[q] = wn[q];
+  trf_barrier_lds();
+  trf2_back_linear<HT, true, SLAB>(G0, wc, H, XT, ldx, a.id_cols, ACT_NONE, a.d_id, nullptr, ACT_NONE, nullptr, G1,
+                                   GR + a.off[0], GR + a.off[1], ld, part, wave, lane, tid);
+  trf_barrier_lds();
+  for (int idx = tid; idx < TRF_ROWS * a.d_id; idx += TRF_THREADS) {
+    const int r = idx / a.d_id, k = idx - r * a.d_id;
+    if (r < rows_here) {
+      const int col = a.id_cols[k];
+      a.Gx[(long long)(r0 + r) * D + col] = GXT[r * ldx + col] + G1[r * ld + k];
+    }
+  }
+  TRF_MARK(60);
+}

@@ -27,13 +27,12 @@ for _ in range(3):
 torch.cuda.synchronize()
 marks = tr._ws[64:128].cpu().numpy()
 names = {0: "x staged", 1: "layer 0", 2: "u_0", 3: "h_1", 4: "u_1", 5: "h_2", 20: "params", 21: "barrier",
-         22: "transform fwd", 32: "transform bwd", 33: "h_L staged", 34: "final layer", 38: "blk1 staged",
-         39: "blk1 second", 40: "blk1 first", 35: "blk0 staged", 36: "blk0 second", 37: "blk0 first",
-         60: "initial layer + end"}
+         22: "transform fwd", 30: "bwd: tiles in LDS", 31: "bwd: transform", 32: "bwd: final layer",
+         33: "bwd: last block", 34: "bwd: block before", 40: "bwd: later loads issued", 41: "bwd: items done", 60: "bwd: initial layer + end"}
 prev = 0.0
-for group in (range(0, 23), [60]):
+for group in (range(0, 23), range(30, 61)):
     prev = 0.0
-    for i in group:
+    for i in sorted(group, key=lambda k: marks[k]):
         if marks[i] > 0:
             print(f"mark {i:2d} {names.get(i, ''):22s} t = {marks[i]:9.0f}  (+{marks[i] - prev:7.0f})")
             prev = marks[i]
