@@ -828,6 +828,7 @@ __global__ void __launch_bounds__(256) tr_loss(int n, int D, const float* __rest
 // sum of squares of the flat gradient: TR_SQ_BLOCKS partial sums, added up in a fixed order by
 // the consumer (tr_adamw) => deterministic
 #define TR_SQ_BLOCKS 64
+#define TR_SQ_MAX 1024  // partial sums of tr_finish_grads (one per block), reduced in a fixed order by every block of tr_adamw
 __global__ void __launch_bounds__(256) tr_grad_sqnorm(long long n, const float* __restrict__ g,
                                                       float* __restrict__ partial) {
   __shared__ float sm[256];
@@ -855,23 +856,31 @@ __global__ void tr_opt_tick(float* __restrict__ opt, float beta1, float beta2) {
   opt[3] = sqrtf(1.0f - powf(beta2, step));
 }
 
-__global__ void tr_adamw(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                         float* __restrict__ v, const float* __restrict__ sq_partial, float max_norm, float lr,
-                         float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, int mode,
-                         const float* __restrict__ opt) {
+__global__ void __launch_bounds__(256) tr_adamw(long long n, float* __restrict__ p, const float* __restrict__ g,
+                                                float* __restrict__ m, float* __restrict__ v,
+                                                const float* __restrict__ sq_partial, int n_partial, float max_norm,
+                                                float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                float bc2_sqrt, int mode, const float* __restrict__ opt) {
+  __shared__ float sm[256];
+  float coef = 1.0f;
+  if (max_norm > 0.0f) {  // block-uniform; every block sums the partials in the same order
+    float sq = 0.0f;
+    for (int b = threadIdx.x; b < n_partial; b += 256) sq += sq_partial[b];
+    sm[threadIdx.x] = sq;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+      __syncthreads();
+    }
+    coef = max_norm / (sqrtf(sm[0]) + 1e-6f);
+    coef = coef < 1.0f ? coef : 1.0f;
+  }
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (opt != nullptr) {
     lr = opt[0];
     bc1 = opt[2];
     bc2_sqrt = opt[3];
-  }
-  float coef = 1.0f;
-  if (max_norm > 0.0f) {
-    float sq = 0.0f;
-    for (int b = 0; b < TR_SQ_BLOCKS; ++b) sq += sq_partial[b];
-    coef = max_norm / (sqrtf(sq) + 1e-6f);
-    coef = coef < 1.0f ? coef : 1.0f;
   }
   float grad = g[i] * coef;
   float pi = p[i];
@@ -897,6 +906,23 @@ __global__ void tr_copy_rows(long long n, const float* __restrict__ src, float* 
 
 #include "nsa_train_fused.h"
 #include "nsa_train_fused2.h"
+
+// Everything a pass needs before its first coupling layer, in one launch instead of five: the batch copied into
+// the workspace, the transposed weight copies of the fused kernels, the flat gradient, log|det J| and the scalar
+// block zeroed.  wt / grads may be null.
+__global__ void tr_prepare(long long n_x, const float* __restrict__ x, float* __restrict__ wx, long long n_params,
+                           const float* __restrict__ p, const int* __restrict__ tmap, float* __restrict__ wt,
+                           float* __restrict__ grads, long long n, float* __restrict__ logdet,
+                           float* __restrict__ scal) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n_x) wx[i] = x[i];
+  if (i < n_params) {
+    if (wt != nullptr) wt[tmap[i]] = p[i];
+    if (grads != nullptr) grads[i] = 0.0f;
+  }
+  if (i < n) logdet[i] = 0.0f;
+  if (i < 64) scal[i] = 0.0f;
+}
 
 // ---------------------------------------------------------------------------
 // host orchestration
@@ -928,6 +954,7 @@ static inline float tr_bits(long long v) {
   return f;
 }
 
+#define TR_SCAL_WORDS (128 + 1024)  // 128 + TR_SQ_MAX
 struct TrWs {  // workspace carve (floats)
   float *scal;      // [1] constant log|det J| of the pass, [2] sum_i d loss / d logdet_i, [64..127] phase
                     // timestamps, [128..191] sq-norm partials
@@ -969,7 +996,7 @@ extern "C" NSA_API size_t nsa_train_workspace_floats(const long long* plan, long
   long long d_tr_max, np_max, per_layer;
   tr_sizes(plan, n, d_tr_max, np_max, per_layer);
   const long long D = plan[0], H = plan[1], NL = plan[3];
-  return (size_t)(192 + 2 * al4(n * D) + 2 * al4(n) + al4(n * np_max) + 2 * al4(n * H) + NL * per_layer + al4(plan[8]) +
+  return (size_t)(TR_SCAL_WORDS + 2 * al4(n * D) + 2 * al4(n) + al4(n * np_max) + 2 * al4(n * H) + NL * per_layer + al4(plan[8]) +
                   tr_slab_floats(plan, n));
 }
 
@@ -978,7 +1005,7 @@ static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
   tr_sizes(plan, n, d_tr_max, np_max, per_layer);
   const long long D = plan[0], H = plan[1];
   float* p = ws;
-  w.scal = p; p += 192;  // [0..63] scalars, [64..191] optional phase timestamps
+  w.scal = p; p += TR_SCAL_WORDS;  // [0..63] scalars, [64..127] optional phase timestamps, [128..] sq-norm partials
   w.x = p; p += al4(n * D);
   w.gx = p; p += al4(n * D);
   w.logdet = p; p += al4(n);
@@ -1014,6 +1041,16 @@ static bool tr_use_fused(const long long* plan) {
   return enabled && plan[11] == NSA_NET_RESNET && plan[1] <= 128 && plan[2] <= TRF_MAX_L;  // H <= 128: <= 8 gh tiles
 }
 
+static void tr_prepare_pass(const long long* plan, const int* tables_dev, const float* params_dev, float* grads_dev,
+                            const float* x_dev, long long n, TrWs& w, hipStream_t s) {
+  const long long D = plan[0], n_params = plan[8];
+  const bool fused = tr_use_fused(plan);
+  const long long work = (fused || grads_dev) && n_params > n * D ? n_params : n * D;
+  hipLaunchKernelGGL(tr_prepare, blocks_for(work > 64 ? work : 64), dim3(256), 0, s, n * D, x_dev, w.x,
+                     (fused || grads_dev) ? n_params : 0LL, params_dev, tables_dev + plan[10],
+                     fused ? w.wt : (float*)nullptr, grads_dev, n, w.logdet, w.scal);
+}
+
 // grads[start + i] += sum over the workgroups' copies, in workgroup order (deterministic)
 struct TrRanges {
   int count;
@@ -1036,6 +1073,50 @@ __global__ void tr_reduce_slab(const float* __restrict__ slab, long long npar, i
   }
   for (; b < copies; ++b) s0 += src[(long long)b * npar];
   grads[rg.start[r] + i] += (s0 + s1) + (s2 + s3);
+}
+
+// The optimiser step's version of the above, fused with what follows it: the copies are summed into the flat
+// gradient, the sum of squares of the WHOLE flat gradient is left as one partial sum per block for tr_adamw
+// (fixed order: deterministic) and the device-side optimiser state ticks - one launch instead of three.
+__global__ void __launch_bounds__(256) tr_finish_grads(long long n, float* __restrict__ g, const float* __restrict__ slab,
+                                                       long long npar, int copies, TrRanges rg,
+                                                       float* __restrict__ partial, float* __restrict__ opt,
+                                                       float beta1, float beta2) {
+  __shared__ float sm[256];
+  float s = 0.0f;
+  for (long long i = blockIdx.x * 256 + threadIdx.x; i < n; i += 256LL * gridDim.x) {
+    float v = g[i];
+    bool mine = false;
+    for (int r = 0; r < rg.count; ++r) mine = mine || (i >= rg.start[r] && i < rg.start[r] + rg.len[r]);
+    if (mine) {
+      const float* src = slab + i;
+      float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+      int b = 0;
+      for (; b + 4 <= copies; b += 4) {
+        s0 += src[(long long)b * npar];
+        s1 += src[(long long)(b + 1) * npar];
+        s2 += src[(long long)(b + 2) * npar];
+        s3 += src[(long long)(b + 3) * npar];
+      }
+      for (; b < copies; ++b) s0 += src[(long long)b * npar];
+      v += (s0 + s1) + (s2 + s3);
+      g[i] = v;
+    }
+    s += v * v;
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+  if (opt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {  // tr_opt_tick
+    const float step = opt[1] + 1.0f;
+    opt[1] = step;
+    opt[2] = 1.0f - powf(beta1, step);
+    opt[3] = sqrtf(1.0f - powf(beta2, step));
+  }
 }
 
 // second-generation kernels (nsa_train_fused2.h): conditioner at most 64 wide, tiles within the LDS;
@@ -1107,8 +1188,7 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
   const int transform = (int)plan[4], K = (int)plan[5], act = (int)plan[6], npf = (int)plan[7];
   const long long rec = plan[9];
   TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5], consts[8], consts[9]};
-  (void)hipMemsetAsync(w.logdet, 0, n * sizeof(float), s);
-  (void)hipMemsetAsync(w.scal, 0, 64 * sizeof(float), s);
+  // (w.logdet and the scalar block were zeroed by tr_prepare)
   for (int b = 0; b < NL; ++b) {
     const long long* r = plan + TR_HDR + b * rec;
     float* lay = w.layer_base + b * w.per_layer;
@@ -1210,8 +1290,10 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
 }
 
 // training != 0: the forward pass used batch statistics (batch norm)
+// ranges_out: the caller sums the per-workgroup gradient copies itself (tr_finish_grads); null: done here
 static void tr_backward(const long long* plan, const int* tabs, const float* params, float* grads,
-                        const float* consts, long long n, TrWs& w, int training, hipStream_t s) {
+                        const float* consts, long long n, TrWs& w, int training, hipStream_t s,
+                        TrRanges* ranges_out = nullptr) {
   const int D = (int)plan[0], H = (int)plan[1], L = (int)plan[2], NL = (int)plan[3];
   const int transform = (int)plan[4], K = (int)plan[5], act = (int)plan[6], npf = (int)plan[7];
   const long long rec = plan[9];
@@ -1356,7 +1438,9 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       hipLaunchKernelGGL(tr_gather_cols, blocks_for(n * D), dim3(256), 0, s, (int)n, D, q.xin, D, cols, w.x, 1);
     }
   }
-  if (ranges.count > 0) {
+  if (ranges_out != nullptr) {
+    *ranges_out = ranges;
+  } else if (ranges.count > 0) {
     int longest = 0;
     for (int i = 0; i < ranges.count; ++i) longest = ranges.len[i] > longest ? ranges.len[i] : longest;
     hipLaunchKernelGGL(tr_reduce_slab, dim3((unsigned)((longest + 255) / 256), (unsigned)ranges.count), dim3(256), 0, s,
@@ -1410,22 +1494,21 @@ static int tr_step_impl(const long long* plan, const int* tables_dev, const floa
   const long long D = plan[0], n_params = plan[8];
   TrWs w;
   tr_carve(plan, n, workspace_dev, w);
-  hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, x_dev, w.x);
-  if (tr_use_fused(plan)) {
-    (void)hipMemsetAsync(grads_dev, 0, n_params * sizeof(float), s);  // atomics accumulate
-    hipLaunchKernelGGL(tr_transpose_weights, blocks_for(n_params), dim3(256), 0, s, n_params, params_dev,
-                       tables_dev + plan[10], w.wt);
-  }
+  // (the fused kernels accumulate into the flat gradient; the layer-wise ones overwrite it)
+  tr_prepare_pass(plan, tables_dev, params_dev, tr_use_fused(plan) ? grads_dev : nullptr, x_dev, n, w, s);
   tr_forward(plan, tables_dev, params_dev, consts, n, w, 1, s);
   hipLaunchKernelGGL(tr_loss, dim3((unsigned)((n + TR_LOSS_ROWS - 1) / TR_LOSS_ROWS)), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
                      weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, (float*)nullptr, 1, w.scal + 2);
-  tr_backward(plan, tables_dev, params_dev, grads_dev, consts, n, w, 1, s);
-  hipLaunchKernelGGL(tr_grad_sqnorm, dim3(TR_SQ_BLOCKS), dim3(256), 0, s, n_params, grads_dev, w.scal + 128);
+  TrRanges ranges;
+  tr_backward(plan, tables_dev, params_dev, grads_dev, consts, n, w, 1, s, &ranges);
+  const long long want_blocks = (n_params + 255) / 256;
+  const int sq_blocks = (int)(want_blocks < TR_SQ_MAX ? want_blocks : TR_SQ_MAX);
+  hipLaunchKernelGGL(tr_finish_grads, dim3(sq_blocks), dim3(256), 0, s, n_params, grads_dev, (const float*)w.slab,
+                     al4(n_params), (int)((n + TRF_ROWS - 1) / TRF_ROWS), ranges, w.scal + 128, opt_dev, beta1, beta2);
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-  if (opt_dev != nullptr) hipLaunchKernelGGL(tr_opt_tick, dim3(1), dim3(1), 0, s, opt_dev, beta1, beta2);
   hipLaunchKernelGGL(tr_adamw, blocks_for(n_params), dim3(256), 0, s, n_params, params_dev, grads_dev, adam_m_dev,
-                     adam_v_dev, w.scal + 128, clip_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, optimiser,
+                     adam_v_dev, w.scal + 128, sq_blocks, clip_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, optimiser,
                      (const float*)opt_dev);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? NSA_OK : NSA_E_HIP;
@@ -1442,10 +1525,7 @@ extern "C" NSA_API int nsa_train_eval(const long long* plan, const int* tables_d
   const long long D = plan[0];
   TrWs w;
   tr_carve(plan, n, workspace_dev, w);
-  hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, x_dev, w.x);
-  if (tr_use_fused(plan))
-    hipLaunchKernelGGL(tr_transpose_weights, blocks_for(plan[8]), dim3(256), 0, s, plan[8], params_dev,
-                       tables_dev + plan[10], w.wt);
+  tr_prepare_pass(plan, tables_dev, params_dev, nullptr, x_dev, n, w, s);
   tr_forward(plan, tables_dev, const_cast<float*>(params_dev), consts, n, w, 0, s);
   hipLaunchKernelGGL(tr_loss, dim3((unsigned)((n + TR_LOSS_ROWS - 1) / TR_LOSS_ROWS)), dim3(256), 0, s, (int)n, (int)D, w.x, (int)D, w.logdet, w.scal + 1,
                      weights_dev, consts[6], consts[7], w.gx, w.gld, loss_acc_dev, log_prob_out_dev, 0, w.scal + 2);
@@ -1520,10 +1600,7 @@ extern "C" NSA_API int nsa_train_forward(const long long* plan, const int* table
   const long long D = plan[0];
   TrWs w;
   tr_carve(plan, n, workspace_dev, w);
-  hipLaunchKernelGGL(tr_copy_rows, blocks_for(n * D), dim3(256), 0, s, n * D, x_dev, w.x);
-  if (tr_use_fused(plan))
-    hipLaunchKernelGGL(tr_transpose_weights, blocks_for(plan[8]), dim3(256), 0, s, plan[8], params_dev,
-                       tables_dev + plan[10], w.wt);
+  tr_prepare_pass(plan, tables_dev, params_dev, nullptr, x_dev, n, w, s);
   tr_forward(plan, tables_dev, params_dev, consts, n, w, training ? 1 : 0, s);
   hipLaunchKernelGGL(tr_outputs, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (int)n, (int)D, w.x,
                      tables_dev + plan[12], w.logdet, w.scal + 1, consts[6], consts[7], z_out_dev,

@@ -169,8 +169,9 @@ class Trainer:
                   float(desc.get("affine_shift", 2.0)), float(desc.get("affine_eps", 1e-3))]
         self.consts = (ctypes.c_float * len(consts))(*consts)
         self.features = D
-        self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)
-        self.val_acc = torch.zeros(1, dtype=torch.float32, device=device)
+        self.losses = torch.zeros(2, dtype=torch.float32, device=device)  # one device-to-host copy per epoch
+        self.loss_acc = self.losses[0:1]
+        self.val_acc = self.losses[1:2]
         #: {lr, optimiser steps done, 1 - beta1^t, sqrt(1 - beta2^t)} for nsa_train_step_dev
         self.opt = torch.zeros(4, dtype=torch.float32, device=device)
         self._ws = None
@@ -406,29 +407,54 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
     trainer.opt[1] = float(trainer.step_count)
 
     def run_epoch():
-        trainer.loss_acc.zero_()
+        trainer.losses.zero_()
         for a, b in bounds:
             trainer.step_dev(epoch_rows[a:b], clip_norm=clip, weights=None if epoch_w is None else epoch_w[a:b])
         if has_val:
-            trainer.val_acc.zero_()
             keep, trainer.loss_acc = trainer.loss_acc, trainer.val_acc
             trainer.evaluate(val_data, weights=w_val)
             trainer.loss_acc = keep
 
+    # The host's share of an epoch - the permutation, its upload, the gather of the shuffled rows - is queued
+    # for epoch e + 1 BEHIND the launches of epoch e and before the host waits for epoch e's losses, so the device
+    # goes from one epoch to the next without waiting for it (the gather writes the buffer the running epoch
+    # reads: stream order keeps it behind).  If epoch e turns out to be the last one, the generators are put
+    # back: the look-ahead leaves no trace in torch's random streams.
+    # (the permutation goes up from pinned memory: an upload from pageable memory holds the host until the stream
+    # has drained - the whole running epoch)
+    perm_host = torch.empty(n_train, dtype=torch.int64, pin_memory=True)
+    perm_dev = torch.empty(n_train, dtype=torch.int64, device=train_data.device)
+
+    def prepare_rows():
+        torch.randperm(n_train, out=perm_host)
+        perm_dev.copy_(perm_host, non_blocking=True)
+        p = perm_dev
+        torch.index_select(train_data, 0, p, out=epoch_rows)
+        if epoch_w is not None:
+            torch.index_select(w_train, 0, p, out=epoch_w)
+        if noise_scale:
+            epoch_rows.add_(noise_scale * torch.randn_like(epoch_rows))
+
+    def generator_states():
+        return torch.get_rng_state(), (torch.cuda.get_rng_state(train_data.device) if noise_scale else None)
+
+    def restore_generators(states):
+        torch.set_rng_state(states[0])
+        if states[1] is not None:
+            torch.cuda.set_rng_state(states[1], train_data.device)
+
     use_graph = os.environ.get("NESSAI_AMD_EPOCH_GRAPH", "1") != "0"
     graph = None
+    losses_host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+    losses_ready = torch.cuda.Event()
     with _training_kernels(tc.get("deterministic")):
+        prepare_rows()
+        trainer.opt[0] = trainer.lr
         for epoch in range(1, max_epochs + 1):
-            p = torch.randperm(n_train).to(train_data.device)
-            torch.index_select(train_data, 0, p, out=epoch_rows)
-            if epoch_w is not None:
-                torch.index_select(w_train, 0, p, out=epoch_w)
-            if noise_scale:
-                epoch_rows.add_(noise_scale * torch.randn_like(epoch_rows))
             if tc.get("annealing"):
                 # CosineAnnealingLR(T_max=max_epochs, eta_min=0), stepped once per epoch (base.py:449-450, 628-631)
                 trainer.lr = trainer.base_lr * 0.5 * (1.0 + math.cos(math.pi * (epoch - 1) / max_epochs))
-            trainer.opt[0] = trainer.lr
+                trainer.opt[0] = trainer.lr
             if graph is not None:
                 graph.replay()
                 trainer.step_count += len(bounds)
@@ -443,17 +469,23 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
             else:
                 run_epoch()
                 trainer._actnorm_initialised()
-            if has_val:
-                both = torch.cat([trainer.loss_acc, trainer.val_acc]).cpu().numpy()  # the epoch's one sync
-                loss, val_loss = float(both[0]) / len(bounds), float(both[1])
-            else:
-                loss, val_loss = float(trainer.loss_acc.item()) / len(bounds), np.nan
+            # the copy of the two losses is queued first, so the wait below is for this epoch's launches only
+            losses_host.copy_(trainer.losses, non_blocking=True)
+            losses_ready.record()
+            if epoch < max_epochs:
+                states = generator_states()
+                prepare_rows()
+            losses_ready.synchronize()  # the epoch's one sync
+            both = losses_host.numpy()
+            loss, val_loss = float(both[0]) / len(bounds), (float(both[1]) if has_val else np.nan)
             history["loss"].append(loss)
             history["val_loss"].append(val_loss)
             if validate and (val_loss < best_val_loss):
                 best_epoch, best_val_loss = epoch, val_loss
                 trainer.best.copy_(trainer.flat)
             if validate and (epoch - best_epoch > patience):
+                if epoch < max_epochs:
+                    restore_generators(states)
                 break
     if validate:
         trainer.flat.copy_(trainer.best)

@@ -16,6 +16,7 @@ import sys, glob; sys.path.insert(0, 'scripts')
 import summarise_prof as S
 for db in glob.glob('gpurun_out/i/prof/**/*.db', recursive=True):
     print(S.kernel_stats(db))
+    print(S.gap_stats(db))
 PY
 rm -rf gpurun_out/i/prof
-tail -3 gpurun_out/i/tests.txt; tail -2 gpurun_out/i/bench_v2.txt; cat gpurun_out/i/phases.txt; echo NOATOMICS; grep bwd gpurun_out/i/phases_noatomics.txt; head -4 gpurun_out/i/prof_summary.txt
+tail -3 gpurun_out/i/tests.txt; tail -2 gpurun_out/i/bench_v2.txt; cat gpurun_out/i/phases.txt; head -4 gpurun_out/i/prof_summary.txt; tail -3 gpurun_out/i/prof_summary.txt

@@ -56,3 +56,21 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def gap_stats(db_path, big_us=20.0):
+    """Idle time between consecutive kernels of a trace: how much of the wall time is not kernels, and how it
+    splits into short gaps (launch-to-launch inside a graph or a stream) and long ones (host round trips)."""
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select start, end, name from kernels order by start").fetchall()
+    if len(rows) < 2:
+        return "no kernels"
+    busy = sum(r[1] - r[0] for r in rows)
+    gaps = [max(0, rows[i + 1][0] - rows[i][1]) for i in range(len(rows) - 1)]
+    short = [g for g in gaps if g < big_us * 1e3]
+    long_ = [g for g in gaps if g >= big_us * 1e3]
+    span = rows[-1][1] - rows[0][0]
+    out = [f"kernels {len(rows)}  span {span / 1e6:.3f} ms  busy {busy / 1e6:.3f} ms ({100 * busy / span:.1f} %)",
+           f"gaps < {big_us:.0f} us: {len(short)}  total {sum(short) / 1e6:.3f} ms  mean {sum(short) / max(len(short), 1) / 1e3:.2f} us",
+           f"gaps >= {big_us:.0f} us: {len(long_)}  total {sum(long_) / 1e6:.3f} ms  mean {sum(long_) / max(len(long_), 1) / 1e3:.2f} us"]
+    return "\n".join(out)
