@@ -1135,7 +1135,12 @@ static bool tr_v2_fits(bool backward, const TrfArgs& a) {
 template <int K, int HT>
 static hipError_t tr_launch_fused2(bool backward, const TrfArgs& a, hipStream_t s) {
   const size_t lds = (backward ? trf2_backward_floats(a) : trf2_forward_floats(a)) * sizeof(float);
-  auto kern = !backward ? trf2_forward<K, HT> : (a.gslab != nullptr ? trf2_backward<K, HT, true> : trf2_backward<K, HT, false>);
+  // 16-byte accesses to the parameter tile and to the transposed final-layer weights
+  const bool vec = a.np % 4 == 0 && a.L <= 3 && a.off[2 + 4 * a.L] % 4 == 0 && ((uintptr_t)a.p % 16 == 0) &&
+                   ((uintptr_t)a.wt % 16 == 0);
+  auto kern = !backward ? trf2_forward<K, HT>
+              : a.gslab != nullptr ? (vec ? trf2_backward<K, HT, true, true> : trf2_backward<K, HT, true, false>)
+                                   : (vec ? trf2_backward<K, HT, false, true> : trf2_backward<K, HT, false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1323,6 +1328,7 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
         a.dbg = getenv("NESSAI_AMD_TRAIN_TIMING") ? w.scal + 64 : nullptr;
         a.id_cols = id_cols; a.tr_cols = tr_cols; a.params = params; a.grads = grads; a.X = w.x; a.Gx = w.gx;
         a.xsave = xsave; a.h = h; a.u = u; a.p = p; a.gp = w.gp; a.gld = w.gld; a.c = c;
+        a.wt = w.wt;
         for (int i = 0; i < 4 + 4 * L; ++i) a.off[i] = off[i];
         // per-workgroup gradient copies when this coupling's parameters are one contiguous block of the flat
         // vector (they are: the module registers them in order) and there is room for one more range

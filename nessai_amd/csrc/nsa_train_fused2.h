@@ -17,6 +17,22 @@
 // Reference semantics: glasflow.nflows ResidualNet (call sites src/nessai/flows/nsf.py:85-95,
 // realnvp.py:136-146) under FlowModel._train (src/nessai/flowmodel/base.py:365-452).
 #pragma once
+#include <type_traits>
+#include <utility>
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): indices that are constants from the start (an
+// array indexed inside a "#pragma unroll" loop can end up on the stack when the loop is unrolled after the pass that
+// would have turned it into registers - and a loaded value stored to the stack waits for its load)
+typedef float f32x4v __attribute__((ext_vector_type(4)));  // a plain vector register quad (float4 is a struct)
+
+template <typename F, int... I>
+__device__ __forceinline__ void trf2_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void trf2_static_for(F&& f) {
+  trf2_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 #ifndef TRF2_ABL
 #define TRF2_ABL 0  // diagnostic builds only (scripts/gpu_r03_h.sh): 1 drops the weight-gradient atomics
@@ -294,9 +310,13 @@ __global__ void __launch_bounds__(TRF_THREADS) trf2_forward(TrfArgs a) {
 
 #define TRF2_FQ 64   // k pairs per slice of the final layer's dX: 256 pairs (np <= 512) / 4 slices
 
+// row stride of the backward kernel's parameter tile
+__host__ __device__ static inline int trf2_pld(int np, bool vec) {
+  return vec ? ((np >> 2) & 1 ? np : np + 4) : (np | 1);
+}
 static inline size_t trf2_backward_floats(const TrfArgs& a) {
   const size_t ldx = (size_t)trf2_ldx(a);
-  return (size_t)TRF_ROWS * (a.np | 1) + (size_t)(2 * a.L + 1) * TRF_ROWS * a.H + 2 * TRF_ROWS * ldx +
+  return (size_t)TRF_ROWS * (a.np + 4) + (size_t)(2 * a.L + 1) * TRF_ROWS * a.H + 2 * TRF_ROWS * ldx +
          (size_t)2 * TRF_ROWS * a.ld + (size_t)TRF_WAVES * 1024;
 }
 
@@ -427,14 +447,18 @@ __device__ __forceinline__ void trf2_back_linear(const float* __restrict__ G, co
   }
 }
 
-template <int K, int HT, bool SLAB>
+// VEC (np % 4 == 0, 16-byte aligned parameter blocks: tr_v2_vec): the parameter tile has rows of pld floats with
+// pld / 4 odd - 16-byte aligned rows whose 16-byte reads are conflict-free - and is filled by 1 KiB async pieces;
+// the final layer's contraction index is dealt out so that every lane owns runs of 4 consecutive parameters:
+// one 16-byte LDS read (A) and one 16-byte load from the transposed weights (B) feed four MFMA steps.
+template <int K, int HT, bool SLAB, bool VEC>
 __global__ void __launch_bounds__(TRF_THREADS) trf2_backward(TrfArgs a) {
   extern __shared__ float trf_sm[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: the item tests below are scalar branches
   const int r0 = blockIdx.x * TRF_ROWS;
   const int ld = a.ld, n = a.n, H = a.H, np = a.np, D = a.D, L = a.L;
-  const int ldx = (D + 1) | 1, pld = np | 1;
+  const int ldx = (D + 1) | 1, pld = trf2_pld(np, VEC);
   float* PT = trf_sm;                          // [32][pld] parameters, then their gradient
   float* ACT = PT + TRF_ROWS * pld;            // h_0 .. h_L, u_0 .. u_{L-1}: [32][H] each
   float* XT = ACT + (2 * L + 1) * TRF_ROWS * H;  // [32][ldx] rows of x (as the forward pass left them)
@@ -448,9 +472,37 @@ __global__ void __launch_bounds__(TRF_THREADS) trf2_backward(TrfArgs a) {
   const long long t_start = clock64();
   const int rows_here = (n - r0 < TRF_ROWS) ? (n - r0) : TRF_ROWS;
 
-  // ---- what the transform items need: parameter tile, dL/dx rows, saved x (async copies + 3 loads) ----
-  trf2_rows_async(PT, pld, a.p, np, r0, n, wave, lane);
-  trf2_rows_async(GXT, ldx, a.Gx, D, r0, n, wave, lane);
+  // ---- what the transform items need: parameter tile, dL/dx rows, saved x ----
+  // (VEC: plain 16-byte loads through registers - the LDS-DMA path of a CU retires about one instruction per 85
+  // cycles whatever its size, and the ~80 of them this tile took were 6 k cycles of the prologue)
+  constexpr int PQ4 = 9;  // 16-byte units of the parameter tile per thread: 32 (np + 4) / 4 <= 9 * 512
+  constexpr int XQ = 8;   // x / dL/dx elements per thread: 32 D <= 8 * 512
+  f32x4v pq[PQ4];
+  float gq[XQ];
+  const int rq = pld >> 2, nq = np >> 2;  // 16-byte units per tile row / per row of parameters
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < PQ4; ++i) {
+      if (TRF_THREADS * i >= TRF_ROWS * rq) break;  // uniform
+      int Q = tid + TRF_THREADS * i;
+      Q = Q < TRF_ROWS * rq ? Q : TRF_ROWS * rq - 1;
+      const int r = Q / rq, cq = Q - r * rq;
+      const int row = r0 + r < n ? r0 + r : n - 1;
+      pq[i] = *(const f32x4v*)(a.p + (long long)row * np + 4 * (cq < nq ? cq : nq - 1));
+    }
+#pragma unroll
+    for (int i = 0; i < XQ; ++i) {
+      if (TRF_THREADS * i >= TRF_ROWS * D) break;  // uniform
+      int idx = tid + TRF_THREADS * i;
+      idx = idx < TRF_ROWS * D ? idx : TRF_ROWS * D - 1;
+      const int r = idx / D;
+      const int row = r0 + r < n ? r0 + r : n - 1;
+      gq[i] = a.Gx[(long long)row * D + (idx - r * D)];
+    }
+  } else {
+    trf2_rows_async(PT, pld, a.p, np, r0, n, wave, lane);
+    trf2_rows_async(GXT, ldx, a.Gx, D, r0, n, wave, lane);
+  }
   // items of the transform: (row, feature) = (e / d_tr, e % d_tr), e = tid + 512 i
   constexpr int IQ = 2;  // d_tr <= 32
   float xs[IQ], gldv[IQ];
@@ -464,15 +516,54 @@ __global__ void __launch_bounds__(TRF_THREADS) trf2_backward(TrfArgs a) {
     gldv[i] = a.gld[row];
     colv[i] = a.tr_cols[m];
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < PQ4; ++i) {
+      if (TRF_THREADS * i >= TRF_ROWS * rq) break;  // uniform
+      const int Q = tid + TRF_THREADS * i;
+      const int r = Q / rq, cq = Q - r * rq;
+      if (Q < TRF_ROWS * rq && cq < nq) *(f32x4v*)(PT + 4 * Q) = pq[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XQ; ++i) {
+      if (TRF_THREADS * i >= TRF_ROWS * D) break;  // uniform
+      const int idx = tid + TRF_THREADS * i;
+      const int r = idx / D;
+      if (idx < TRF_ROWS * D) GXT[r * ldx + (idx - r * D)] = gq[i];
+    }
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   trf_barrier_lds();
   TRF_MARK(30);
   // ---- requested now, used after the items: x rows (identity columns), activation tiles ([32][H] contiguous in
   // global memory and in LDS: 1 KiB pieces; H % 4 == 0 and 16-byte aligned blocks, tr_v2_fits), the final
   // layer's dX operands Wf[o][in] of item (in-tile wave % HT, slice wave / HT of the np parameters), and
   // the first backward step of the hidden layers: W2 of the last block (or W0 when there is none)
-  trf2_rows_async(XT, ldx, a.X, D, r0, n, wave, lane);
-  {
+  constexpr int MAXT = 7;  // activation tiles through registers: 2 L + 1 <= 7 (one 16-byte unit per thread each)
+  f32x4v aq[MAXT];  // (VEC implies 2 L + 1 <= MAXT: tr_launch_fused2)
+  float xq2[XQ];
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < XQ; ++i) {
+      if (TRF_THREADS * i >= TRF_ROWS * D) break;  // uniform
+      int idx = tid + TRF_THREADS * i;
+      idx = idx < TRF_ROWS * D ? idx : TRF_ROWS * D - 1;
+      const int r = idx / D;
+      const int row = r0 + r < n ? r0 + r : n - 1;
+      xq2[i] = a.X[(long long)row * D + (idx - r * D)];
+    }
+    const int quads = TRF_ROWS * H / 4;
+    long long g = (long long)r0 * H + 4 * (tid < quads ? tid : quads - 1);
+    g = g < nH - 4 ? g : nH - 4;
+    trf2_static_for<MAXT>([&](auto ti) {
+      constexpr int t = decltype(ti)::value;
+      const int tc = t < 2 * L + 1 ? t : 2 * L;
+      const float* src = (tc <= L) ? a.h + tc * nH : a.u + (tc - L - 1) * nH;
+      aq[t] = *(const f32x4v*)(src + g);
+    });
+  } else {
+    trf2_rows_async(XT, ldx, a.X, D, r0, n, wave, lane);
     const int words = TRF_ROWS * H;
     for (int t = 0; t < 2 * L + 1; ++t) {
       const float* src = (t <= L) ? a.h + t * nH : a.u + (t - L - 1) * nH;
@@ -491,14 +582,28 @@ __global__ void __launch_bounds__(TRF_THREADS) trf2_backward(TrfArgs a) {
   const int pairs_f = (np + 1) >> 1;
   const int ppf = (pairs_f + KSF - 1) / KSF;  // <= TRF2_FQ
   const int itf = wave % HT, ksf = wave / HT;
+  // VEC: group g = 2 ksf + half of the 2 KSF groups owns the 16-byte units [g QG, (g + 1) QG) of the np parameters
+  const int nq_f = np >> 2;
+  const int QG = (nq_f + 2 * KSF - 1) / (2 * KSF);  // <= TRF2_FQ / 4
+  const int qd0 = (2 * ksf + half) * QG;
   float wfd[TRF2_FQ];
   {
     const int cI = itf * 32 + j;
     const unsigned cc = (unsigned)(cI < H ? cI : H - 1);
+    if constexpr (VEC) {
+      const float* WfT = a.wt + a.off[2 + 4 * L] + (long long)cc * np;  // W^T[in][o]: a lane's run is contiguous
 #pragma unroll
-    for (int q = 0; q < TRF2_FQ; ++q) {
-      const int k = 2 * (ksf * ppf + q) + half;
-      wfd[q] = Wf[(unsigned)(k < np ? k : np - 1) * (unsigned)H + cc];
+      for (int t = 0; t < TRF2_FQ / 4; ++t) {
+        const int qd = qd0 + t;
+        const float4 v = *(const float4*)(WfT + 4 * (qd < nq_f ? qd : nq_f - 1));
+        wfd[4 * t] = v.x; wfd[4 * t + 1] = v.y; wfd[4 * t + 2] = v.z; wfd[4 * t + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < TRF2_FQ; ++q) {
+        const int k = 2 * (ksf * ppf + q) + half;
+        wfd[q] = Wf[(unsigned)(k < np ? k : np - 1) * (unsigned)H + cc];
+      }
     }
   }
   float wc[TRF2_PP], wn[TRF2_PP];
@@ -544,13 +649,59 @@ __global__ void __launch_bounds__(TRF_THREADS) trf2_backward(TrfArgs a) {
     }
   }
   TRF_MARK(41);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the async x rows and activation tiles
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < XQ; ++i) {
+      if (TRF_THREADS * i >= TRF_ROWS * D) break;  // uniform
+      const int idx = tid + TRF_THREADS * i;
+      const int r = idx / D;
+      if (idx < TRF_ROWS * D) XT[r * ldx + (idx - r * D)] = xq2[i];
+    }
+    const int quads = TRF_ROWS * H / 4;
+    trf2_static_for<MAXT>([&](auto ti) {
+      constexpr int t = decltype(ti)::value;
+      if (t < 2 * L + 1 && tid < quads) *(f32x4v*)(ACT + t * TRF_ROWS * H + 4 * tid) = aq[t];
+    });
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the async x rows and activation tiles
+  }
   trf_barrier_lds();
   TRF_MARK(31);
 
   // ---- final layer: gh = gp . Wf (slices of the np parameters), dWf = gp^T . h_L, dbf ----
   const float* hL = ACT + L * TRF_ROWS * H;
-  {
+  if constexpr (VEC) {
+    f32x16 acc = {0}, acc2 = {0};
+    const float* ax = PT + j * pld;
+#pragma unroll
+    for (int t0 = 0; t0 < TRF2_FQ / 4; t0 += 4) {
+      if (t0 < QG) {  // uniform
+        float4 av[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int qd = qd0 + t0 + t;
+          av[t] = *(const float4*)(ax + 4 * (qd < nq_f ? qd : 0));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float keep = (t0 + t < QG && qd0 + t0 + t < nq_f) ? 1.0f : 0.0f;
+          av[t].x *= keep; av[t].y *= keep; av[t].z *= keep; av[t].w *= keep;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (t0 + t < QG) {
+            acc = nsa_mfma(av[t].x, wfd[4 * (t0 + t)], acc);
+            acc2 = nsa_mfma(av[t].y, wfd[4 * (t0 + t) + 1], acc2);
+            acc = nsa_mfma(av[t].z, wfd[4 * (t0 + t) + 2], acc);
+            acc2 = nsa_mfma(av[t].w, wfd[4 * (t0 + t) + 3], acc2);
+          }
+        }
+      }
+    }
+    float* pp_ = part + wave * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pp_[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + j] = acc[r] + acc2[r];
+  } else {
     f32x16 acc = {0}, acc2 = {0};
     const float* ax = PT + j * pld;
 #pragma unroll
