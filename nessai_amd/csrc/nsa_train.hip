@@ -1132,15 +1132,45 @@ static bool tr_v2_fits(bool backward, const TrfArgs& a) {
          (((long long)a.n * a.H) % 4 == 0) && trf2_backward_floats(a) * sizeof(float) <= 160 * 1024;
 }
 
+// forward pass of a run of `count` coupling layers in one launch (m.a.np = the largest np of the run)
+template <int K, int HT, int COUNT>
+static hipError_t tr_launch_forward2(const Trf2Multi& m, hipStream_t s) {
+  const size_t lds = trf2_forward_floats(m.a) * sizeof(float);
+  auto kern = trf2_forward<K, HT, COUNT>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)((m.a.n + TRF_ROWS - 1) / TRF_ROWS);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(TRF_THREADS), lds, s, m);
+  return hipGetLastError();
+}
+template <int K, int HT>
+static hipError_t tr_forward_run_c(const Trf2Multi& m, int count, hipStream_t s) {
+  if (count == 1) return tr_launch_forward2<K, HT, 1>(m, s);
+  if (count == 2) return tr_launch_forward2<K, HT, 2>(m, s);
+  if (count == 3) return tr_launch_forward2<K, HT, 3>(m, s);
+  return tr_launch_forward2<K, HT, 6>(m, s);
+}
+template <int K>
+static hipError_t tr_forward_run_k(const Trf2Multi& m, int count, hipStream_t s) {
+  return m.a.H <= 32 ? tr_forward_run_c<K, 1>(m, count, s) : tr_forward_run_c<K, 2>(m, count, s);
+}
+static hipError_t tr_forward_run(int transform, int K, const Trf2Multi& m, int count, hipStream_t s) {
+  if (transform != NSA_T_RQ) return tr_forward_run_k<0>(m, count, s);
+  if (K == 4) return tr_forward_run_k<4>(m, count, s);
+  if (K == 8) return tr_forward_run_k<8>(m, count, s);
+  if (K == 10) return tr_forward_run_k<10>(m, count, s);
+  return tr_forward_run_k<16>(m, count, s);
+}
+
 template <int K, int HT>
 static hipError_t tr_launch_fused2(bool backward, const TrfArgs& a, hipStream_t s) {
-  const size_t lds = (backward ? trf2_backward_floats(a) : trf2_forward_floats(a)) * sizeof(float);
+  const size_t lds = trf2_backward_floats(a) * sizeof(float);
   // 16-byte accesses to the parameter tile and to the transposed final-layer weights
   const bool vec = a.np % 4 == 0 && a.L <= 3 && a.off[2 + 4 * a.L] % 4 == 0 && ((uintptr_t)a.p % 16 == 0) &&
                    ((uintptr_t)a.wt % 16 == 0);
-  auto kern = !backward ? trf2_forward<K, HT>
-              : a.gslab != nullptr ? (vec ? trf2_backward<K, HT, true, true> : trf2_backward<K, HT, true, false>)
-                                   : (vec ? trf2_backward<K, HT, false, true> : trf2_backward<K, HT, false, false>);
+  auto kern = a.gslab != nullptr ? (vec ? trf2_backward<K, HT, true, true> : trf2_backward<K, HT, true, false>)
+                                 : (vec ? trf2_backward<K, HT, false, true> : trf2_backward<K, HT, false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1151,7 +1181,7 @@ static hipError_t tr_launch_fused2(bool backward, const TrfArgs& a, hipStream_t 
 
 template <int K>
 static hipError_t tr_launch_fused(bool backward, const TrfArgs& a, hipStream_t s) {
-  if (tr_v2_fits(backward, a))
+  if (backward && tr_v2_fits(true, a))
     return a.H <= 32 ? tr_launch_fused2<K, 1>(backward, a, s) : tr_launch_fused2<K, 2>(backward, a, s);
   const size_t floats = backward ? (size_t)(4 * TRF_ROWS * a.ld + TRF_ROWS * (a.ch + 1))
                                  : (size_t)(2 * TRF_ROWS * a.ld);
@@ -1219,6 +1249,45 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
         a.id_cols = id_cols; a.tr_cols = tr_cols; a.params = params; a.X = w.x; a.xsave = xsave;
         a.h = h; a.u = u; a.p = p; a.logdet = w.logdet; a.c = c;
         for (int i = 0; i < 4 + 4 * L; ++i) a.off[i] = off[i];
+        if (tr_v2_fits(false, a) && plan[8] < (1LL << 31)) {
+          // second generation: this coupling and up to TRF2_MAXC - 1 couplings that follow it directly, in one
+          // launch; how many (NESSAI_AMD_TRAIN_RUN, default all three) balances the launches saved against the length
+          // of the tail a 32-workgroup grid leaves idle
+          const char* e = getenv("NESSAI_AMD_TRAIN_RUN");
+          int want = e != nullptr ? atoi(e) : TRF2_MAXC;
+          want = want < 1 ? 1 : (want > TRF2_MAXC ? TRF2_MAXC : want);
+          {  // instantiated run lengths: 1, 2, 3, 6
+            int ahead = 0;
+            for (int bb = b; bb < NL && ahead < want && plan[TR_HDR + bb * rec] == TR_COUPLING; ++bb) ++ahead;
+            want = ahead >= 6 && want >= 6 ? 6 : (ahead < 3 ? ahead : (want < 3 ? want : 3));
+          }
+          Trf2Multi m;
+          memset(&m, 0, sizeof(m));
+          m.a = a;
+          int np_max = 0, count = 0, bb = b;
+          for (; bb < NL && count < want; ++bb) {
+            const long long* rr = plan + TR_HDR + bb * rec;
+            if (rr[0] != TR_COUPLING) break;
+            TrfArgs t = a;
+            t.d_id = (int)rr[1]; t.d_tr = (int)rr[2]; t.np = t.d_tr * npf;
+            t.np = t.np > np_max ? t.np : np_max;  // the parameter tile holds the largest np of the run
+            if (!tr_v2_fits(false, t) || (((H > t.d_id ? H : t.d_id) + 1) | 1) > a.ld) break;
+            float* layb = w.layer_base + bb * w.per_layer;
+            Trf2One& o = m.one[count++];
+            o.d_id = (int)rr[1]; o.d_tr = (int)rr[2]; o.np = o.d_tr * npf;
+            if (o.np > np_max) np_max = o.np;
+            o.id_cols = tabs + rr[3]; o.tr_cols = tabs + rr[4];
+            o.xsave = layb;
+            o.h = o.xsave + w.xsave_words;
+            o.u = o.h + (long long)(L + 1) * n * H;
+            o.p = o.u + (long long)L * n * H;
+            for (int i = 0; i < 4 + 4 * L; ++i) o.off[i] = (int)rr[5 + i];
+          }
+          m.a.np = np_max;
+          (void)tr_forward_run(transform, K, m, count, s);
+          b = bb - 1;
+          continue;
+        }
         (void)tr_fused_coupling(false, transform, K, a, s);
         continue;
       }

@@ -57,6 +57,13 @@ struct Trf2Item {
 // address and its value is first touched by the MFMA: a select on the loaded value makes the compiler
 // branch round the load and wait for it on the spot - 64 serialised round trips in the first version of
 // this kernel.  Out-of-range k carry a zero A operand instead; out-of-range columns are never written.
+// a zero the compiler cannot see through (see its use in trf2_forward)
+__device__ __forceinline__ int trf2_opaque_zero() {
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
+}
+
 template <int HT>
 __device__ __forceinline__ void trf2_load_w(float (&w)[TRF2_PP], float& bias, const float* __restrict__ Wt,
                                             const float* __restrict__ b, int Kd, int O, int wave, int lane,
@@ -144,152 +151,235 @@ __device__ __forceinline__ void trf2_rows_async(float* tile, int lds_ld, const f
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// forward pass: ONE launch for COUNT consecutive coupling layers (permutations are folded into the column
+// tables, so the reference's default flows are runs of couplings).  The workgroup's 32 rows of x stay in LDS
+// from one coupling to the next - a launch, its argument fetch, the first round trip to the batch and the
+// wait for the last stores are paid once per run - and the next coupling's first operands are requested while
+// the current one's transform runs.  COUNT is a template parameter and the couplings are laid out one after
+// the other in the code: written as a run-time loop, the lane-dependent halves of every address were hoisted
+// out of it and held in registers across it (157 spilled registers, and a spilled operand waits for its
+// load on the spot - slower than a launch per coupling).
+// ---------------------------------------------------------------------------------------------------
+#define TRF2_MAXC 6
+struct Trf2One {  // what differs from one coupling layer of the run to the next
+  int d_id, d_tr, np, pad_;
+  const int* id_cols;
+  const int* tr_cols;
+  float* xsave;  // [n][d_tr]
+  float* h;      // [L + 1][n][H]
+  float* u;      // [L][n][H]
+  float* p;      // [n][np]
+  int off[2 + 4 * TRF_MAX_L + 2];  // flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf
+};
+struct Trf2Multi {
+  TrfArgs a;  // the fields common to the run; np = the largest np of the run (LDS tile)
+  Trf2One one[TRF2_MAXC];
+};
+static_assert(sizeof(Trf2Multi) <= 4096, "kernel arguments are limited to 4 KiB");
+
+#define TRF2_MARK(i)                                                      \
+  do {                                                                    \
+    if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0)            \
+      dbg[i] = (float)(long long)(clock64() - t_start);                   \
+  } while (0)
+
 // LDS floats of trf2_forward: the x tile, two activation tiles, the partial sums, the parameter tile
 static inline int trf2_ldx(const TrfArgs& a) { return (a.D + 1) | 1; }
 static inline size_t trf2_forward_floats(const TrfArgs& a) {
   return (size_t)TRF_ROWS * trf2_ldx(a) + (size_t)2 * TRF_ROWS * a.ld + (size_t)TRF_WAVES * 1024 +
-         (size_t)TRF_ROWS * a.np;
+         (size_t)TRF_ROWS * a.np + TRF_ROWS;
 }
 
-template <int K, int HT>  // spline bins (0: affine / additive); hidden width <= 32 HT
-__global__ void __launch_bounds__(TRF_THREADS) trf2_forward(TrfArgs a) {
+template <int K, int HT, int COUNT>  // spline bins (0: affine / additive); hidden width <= 32 HT; couplings
+__global__ void __launch_bounds__(TRF_THREADS) trf2_forward(Trf2Multi m) {
   extern __shared__ float trf_sm[];
+  const TrfArgs& a = m.a;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: the item tests below are scalar branches
   const int r0 = blockIdx.x * TRF_ROWS;
-  const int ld = a.ld, n = a.n, H = a.H, np = a.np, D = a.D;
+  const int ld = a.ld, n = a.n, H = a.H, D = a.D, L = a.L;
   const int ldx = (D + 1) | 1;
   float* XT = trf_sm;                  // [32][ldx] the workgroup's rows of x, all columns
   float* HC = XT + TRF_ROWS * ldx;     // h_l
   float* U = HC + TRF_ROWS * ld;       // u_l
   float* part = U + TRF_ROWS * ld;     // [8 items][32][32] partial sums
   float* PT = part + TRF_WAVES * 1024;  // [32][np] transform parameters
+  float* ldsum = PT + TRF_ROWS * a.np;  // [32] log|det J| of the run, per row (one global update per row at the end)
   const float* P = a.params;
   const float* WT = a.wt;
   const long long nH = (long long)n * H;
-  const long long t_start = clock64();
+  long long t_start = clock64();
+  float* dbg = COUNT == 1 ? a.dbg : nullptr;
+  if (tid < TRF_ROWS) ldsum[tid] = 0.0f;
 
-  // the x rows (async, straight into the padded tile), the identity column table and layer 0 first; the
-  // first hidden layer and - used only after the hidden layers - the final layer's operands for output
-  // tiles wave and wave + 8 are requested behind the first barrier, so that it waits for the former only
+  // the x rows (async, straight into the padded tile), the identity column table and layer 0 of the first
+  // coupling; everything else is requested behind the first barrier, so that it waits for these only
   trf2_rows_async(XT, ldx, a.X, D, r0, n, wave, lane);
-  const Trf2Item<HT> it0(wave, a.d_id);
   int cidx[TRF2_PP], none[TRF2_PP];
-#pragma unroll
-  for (int q = 0; q < TRF2_PP; ++q) {
-    const int k = 2 * (it0.ks * it0.pp + q) + half;
-    cidx[q] = a.id_cols[k < a.d_id ? k : 0] + j * ldx;
-    none[q] = 0;
-  }
   float wc[TRF2_PP], wn[TRF2_PP], bc, bn = 0.0f;
-  trf2_load_w<HT>(wc, bc, WT + a.off[0], P + a.off[1], a.d_id, H, wave, lane, tid);
+  {
+    const Trf2One& c0 = m.one[0];
+    const Trf2Item<HT> it0(wave, c0.d_id);
+#pragma unroll
+    for (int q = 0; q < TRF2_PP; ++q) {
+      const int k = 2 * (it0.ks * it0.pp + q) + half;
+      cidx[q] = c0.id_cols[k < c0.d_id ? k : 0] + j * ldx;
+      none[q] = 0;
+    }
+    trf2_load_w<HT>(wc, bc, WT + c0.off[0], P + c0.off[1], c0.d_id, H, wave, lane, tid);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the async rows (and layer 0)
   trf_barrier_lds();
-  if (a.L > 0) trf2_load_w<HT>(wn, bn, WT + a.off[2], P + a.off[3], H, H, wave, lane, tid);
-  constexpr int FP = 16 * HT;  // k pairs of the final layer
-  const int OTf = (np + 31) >> 5;
-  const float* Wf = WT + a.off[2 + 4 * a.L];
-  const float* bf = P + a.off[3 + 4 * a.L];
-  float wf[2][FP], bfv[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int o = (wave + TRF_WAVES * s) * 32 + j;
-    const unsigned oc = (unsigned)(o < np ? o : np - 1);
-    bfv[s] = bf[oc];
-#pragma unroll
-    for (int q = 0; q < FP; ++q) {
-      const int k = 2 * q + half;
-      wf[s][q] = Wf[(unsigned)(k < H ? k : H - 1) * (unsigned)np + oc];
+
+  const int tid_launch = tid;
+  trf2_static_for<COUNT>([&](auto bi) {
+    constexpr int b = decltype(bi)::value;
+    // lane indices the compiler cannot prove equal from one coupling to the next: what is derived from them is
+    // recomputed per coupling, as in a launch per coupling, instead of being shared between the copies of the
+    // code and held in registers across them (94 spilled registers for three couplings otherwise)
+    const int tid = tid_launch + trf2_opaque_zero(), lane = tid & 63, half = lane >> 5, j = lane & 31;
+    const Trf2One& c = m.one[b];
+    const int np = c.np, d_id = c.d_id, d_tr = c.d_tr;
+    // the parameter tile is saved for the backward pass with 16-byte stores out of LDS where its rows allow it
+    // (6 store instructions per thread instead of 32)
+    const bool p_vec = (np & 3) == 0 && (((unsigned long long)c.p) & 15) == 0;
+    if (b == COUNT - 1 && COUNT > 1) {  // phase stamps of the last coupling of the run
+      t_start = clock64();
+      dbg = a.dbg;
     }
-  }
-  TRF_MARK(0);
-  // h_0 = W0 x_id + b0
-  trf2_layer<HT, true>(XT, ACT_NONE, wc, cidx, bc, a.d_id, H, nullptr, HC, a.h, ld, r0, n, part, wave, lane, tid);
-  TRF_MARK(1);
-  for (int l = 0; l < a.L; ++l) {
-    // u_l = W1 act(h_l) + b1;  h_{l+1} = h_l + W2 act(u_l) + b2
-#pragma unroll
-    for (int q = 0; q < TRF2_PP; ++q) wc[q] = wn[q];
-    bc = bn;
-    trf2_load_w<HT>(wn, bn, WT + a.off[4 + 4 * l], P + a.off[5 + 4 * l], H, H, wave, lane, tid);
-    trf_barrier_lds();
-    trf2_layer<HT>(HC, a.act, wc, none, bc, H, H, nullptr, U, a.u + l * nH, ld, r0, n, part, wave, lane, tid);
-    TRF_MARK(2 + 2 * l);
-#pragma unroll
-    for (int q = 0; q < TRF2_PP; ++q) wc[q] = wn[q];
-    bc = bn;
-    if (l + 1 < a.L) trf2_load_w<HT>(wn, bn, WT + a.off[6 + 4 * l], P + a.off[7 + 4 * l], H, H, wave, lane, tid);
-    trf_barrier_lds();
-    trf2_layer<HT>(U, a.act, wc, none, bc, H, H, HC, HC, a.h + (l + 1) * nH, ld, r0, n, part, wave, lane, tid);
-    TRF_MARK(3 + 2 * l);
-  }
-  trf_barrier_lds();
-  // parameters = Wf h_L + bf: whole output tiles, no split (waves w and w + 4 share a SIMD: 3 tiles each of 12)
-  {
-    float av[FP];
-    const float* ax = HC + j * ld;
-#pragma unroll
-    for (int q = 0; q < FP; ++q) {
-      const int k = 2 * q + half;
-      av[q] = ax[k < H ? k : 0];
-    }
-#pragma unroll
-    for (int q = 0; q < FP; ++q) av[q] *= (2 * q + half < H) ? 1.0f : 0.0f;
-    const int pairs = (H + 1) >> 1;
+    // the first hidden layer and - used only after the hidden layers - the final layer's operands for
+    // output tiles wave and wave + 8
+    if (L > 0) trf2_load_w<HT>(wn, bn, WT + c.off[2], P + c.off[3], H, H, wave, lane, tid);
+    constexpr int FP = 16 * HT;  // k pairs of the final layer
+    const int OTf = (np + 31) >> 5;
+    const float* Wf = WT + c.off[2 + 4 * L];
+    const float* bf = P + c.off[3 + 4 * L];
+    TRF2_MARK(0);
+    // h_0 = W0 x_id + b0
+    trf2_layer<HT, true>(XT, ACT_NONE, wc, cidx, bc, d_id, H, nullptr, HC, c.h, ld, r0, n, part, wave, lane, tid);
+    // (requested here rather than at the top of the coupling: a wave has 63 memory operations in flight at most,
+    // and behind a previous coupling the queue still holds its stores - 64 loads at the top waited for them)
+    float wf[2][FP], bfv[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int t = wave + TRF_WAVES * s;
-      if (t < OTf) {  // wave-uniform
-        f32x16 acc = {0}, acc2 = {0};
+      const int o = (wave + TRF_WAVES * s) * 32 + j;
+      const unsigned oc = (unsigned)(o < np ? o : np - 1);
+      bfv[s] = bf[oc];
 #pragma unroll
-        for (int q = 0; q < FP; q += 2) {
-          if (q < pairs) {
-            acc = nsa_mfma(av[q], wf[s][q], acc);
-            acc2 = nsa_mfma(av[q + 1], wf[s][q + 1], acc2);
+      for (int q = 0; q < FP; ++q) {
+        const int k = 2 * q + half;
+        wf[s][q] = Wf[(unsigned)(k < H ? k : H - 1) * (unsigned)np + oc];
+      }
+    }
+    TRF2_MARK(1);
+    for (int l = 0; l < L; ++l) {
+      // u_l = W1 act(h_l) + b1;  h_{l+1} = h_l + W2 act(u_l) + b2
+#pragma unroll
+      for (int q = 0; q < TRF2_PP; ++q) wc[q] = wn[q];
+      bc = bn;
+      trf2_load_w<HT>(wn, bn, WT + c.off[4 + 4 * l], P + c.off[5 + 4 * l], H, H, wave, lane, tid);
+      trf_barrier_lds();
+      trf2_layer<HT>(HC, a.act, wc, none, bc, H, H, nullptr, U, c.u + l * nH, ld, r0, n, part, wave, lane, tid);
+      TRF2_MARK(2 + 2 * l);
+#pragma unroll
+      for (int q = 0; q < TRF2_PP; ++q) wc[q] = wn[q];
+      bc = bn;
+      if (l + 1 < L) trf2_load_w<HT>(wn, bn, WT + c.off[6 + 4 * l], P + c.off[7 + 4 * l], H, H, wave, lane, tid);
+      trf_barrier_lds();
+      trf2_layer<HT>(U, a.act, wc, none, bc, H, H, HC, HC, c.h + (l + 1) * nH, ld, r0, n, part, wave, lane, tid);
+      TRF2_MARK(3 + 2 * l);
+    }
+    trf_barrier_lds();
+    // parameters = Wf h_L + bf: whole output tiles, no split (waves w and w + 4 share a SIMD: 3 tiles each of 12)
+    {
+      float av[FP];
+      const float* ax = HC + j * ld;
+#pragma unroll
+      for (int q = 0; q < FP; ++q) {
+        const int k = 2 * q + half;
+        av[q] = ax[k < H ? k : 0];
+      }
+#pragma unroll
+      for (int q = 0; q < FP; ++q) av[q] *= (2 * q + half < H) ? 1.0f : 0.0f;
+      const int pairs = (H + 1) >> 1;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int t = wave + TRF_WAVES * s;
+        if (t < OTf) {  // wave-uniform
+          f32x16 acc = {0}, acc2 = {0};
+#pragma unroll
+          for (int q = 0; q < FP; q += 2) {
+            if (q < pairs) {
+              acc = nsa_mfma(av[q], wf[s][q], acc);
+              acc2 = nsa_mfma(av[q + 1], wf[s][q + 1], acc2);
+            }
           }
-        }
-        const int o = t * 32 + j;
-        if (o < np) {
+          const int o = t * 32 + j;
+          if (o < np) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float v = acc[r] + acc2[r] + bfv[s];
-            PT[rl * np + o] = v;
-            if (r0 + rl < n) a.p[(unsigned)(r0 + rl) * (unsigned)np + (unsigned)o] = v;
+            for (int r = 0; r < 16; ++r) {
+              const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+              const float v = acc[r] + acc2[r] + bfv[s];
+              PT[rl * np + o] = v;
+              if (!p_vec && r0 + rl < n) c.p[(unsigned)(r0 + rl) * (unsigned)np + (unsigned)o] = v;
+            }
           }
         }
       }
     }
-  }
-  TRF_MARK(20);
+    TRF2_MARK(20);
+    // the next coupling's identity columns and layer 0, requested before this one's transform
+    if constexpr (b + 1 < COUNT) {
+      const Trf2One& cn = m.one[b + 1];
+      const Trf2Item<HT> itn(wave, cn.d_id);
+#pragma unroll
+      for (int q = 0; q < TRF2_PP; ++q) {
+        const int k = 2 * (itn.ks * itn.pp + q) + half;
+        cidx[q] = cn.id_cols[k < cn.d_id ? k : 0] + j * ldx;
+      }
+      trf2_load_w<HT>(wc, bc, WT + cn.off[0], P + cn.off[1], cn.d_id, H, wave, lane, tid);
+    }
+    trf_barrier_lds();
+    TRF2_MARK(21);
+    if (p_vec) {
+      const int rows_here = n - r0 < TRF_ROWS ? n - r0 : TRF_ROWS;
+      const int quads = rows_here * (np >> 2);
+      float* dst = c.p + (long long)r0 * np;
+      for (int i = tid; i < quads; i += TRF_THREADS) *(f32x4v*)(dst + 4 * i) = *(const f32x4v*)(PT + 4 * i);
+    }
+    // the transform on the x tile's own copy of x (no load behind the stores above); y goes back into the
+    // tile for the next coupling and to global memory for the loss / the backward pass
+    const int items = TRF_ROWS * d_tr;
+    for (int e = tid; e < items; e += TRF_THREADS) {
+      const int r = e / d_tr, mi = e - r * d_tr;
+      const int row = r0 + r;
+      if (row >= n) continue;
+      const int col = c.tr_cols[mi];
+      const float x = XT[r * ldx + col];
+      float y, ldj;
+      if constexpr (K > 0) {
+        tr_rq_forward_core<K>(PT + r * np + mi * (3 * K - 1), x, a.c, y, ldj);
+      } else {
+        const float* pr = PT + r * np;
+        float scale = 1.0f;
+        ldj = 0.0f;
+        if (a.transform != NSA_T_ADDITIVE) {
+          scale = 1.0f / (1.0f + expf(-(pr[d_tr + mi] + a.c.aff_a))) + a.c.aff_b;
+          ldj = logf(scale);
+        }
+        y = x * scale + pr[mi];
+      }
+      if (b + 1 < COUNT) XT[r * ldx + col] = y;
+      c.xsave[row * d_tr + mi] = x;
+      a.X[(long long)row * D + col] = y;
+      if (K > 0 || a.transform != NSA_T_ADDITIVE) atomicAdd(&ldsum[r], ldj);
+    }
+    TRF2_MARK(22);
+    if (b + 1 < COUNT) trf_barrier_lds();  // the x tile of the next coupling
+  });
   trf_barrier_lds();
-  TRF_MARK(21);
-  // the transform on the x tile's own copy of x: no load behind the stores above
-  const int items = TRF_ROWS * a.d_tr;
-  for (int e = tid; e < items; e += TRF_THREADS) {
-    const int r = e / a.d_tr, m = e - r * a.d_tr;
-    const int row = r0 + r;
-    if (row >= n) continue;
-    const int col = a.tr_cols[m];
-    const float x = XT[r * ldx + col];
-    float y, ldj;
-    if constexpr (K > 0) {
-      tr_rq_forward_core<K>(PT + r * np + m * (3 * K - 1), x, a.c, y, ldj);
-    } else {
-      const float* pr = PT + r * np;
-      float scale = 1.0f;
-      ldj = 0.0f;
-      if (a.transform != NSA_T_ADDITIVE) {
-        scale = 1.0f / (1.0f + expf(-(pr[a.d_tr + m] + a.c.aff_a))) + a.c.aff_b;
-        ldj = logf(scale);
-      }
-      y = x * scale + pr[m];
-    }
-    a.xsave[row * a.d_tr + m] = x;
-    a.X[(long long)row * D + col] = y;
-    if (K > 0 || a.transform != NSA_T_ADDITIVE) atomicAdd(&a.logdet[row], ldj);
-  }
-  TRF_MARK(22);
+  if (tid < TRF_ROWS && r0 + tid < n) a.logdet[r0 + tid] += ldsum[tid];  // (this workgroup's rows only)
 }
 
 // ---------------------------------------------------------------------------------------------------
