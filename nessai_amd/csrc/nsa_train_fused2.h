@@ -419,6 +419,32 @@ __device__ __forceinline__ void trf2_grad_out(float* dst, float v) {
   else atomicAdd(dst, v);
 }
 
+// One 32 x 32 tile of a weight gradient out of the accumulators of D[i = in][jj = out] (the `in` index runs down
+// the registers of a lane, so that a lane owns runs of 4 consecutive inputs of ITS output row: four 16-byte stores
+// per tile instead of sixteen 4-byte ones when the rows allow it).  gW: [O][Kin] row-major.
+template <bool SLAB>
+__device__ __forceinline__ void trf2_dw_store(float* __restrict__ gW, int O, int Kin, int o, int in0, int half,
+                                              const f32x16& acc, const f32x16& acc2) {
+  if (o >= O) return;
+  float* row = gW + (unsigned)o * (unsigned)Kin;
+  const bool vec = SLAB && (Kin & 3) == 0 && (((unsigned long long)gW) & 15) == 0 && !(TRF2_ABL & 1);  // uniform
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = in0 + 8 * g + 4 * half;
+    if (vec) {
+      if (c < Kin) {
+        f32x4v v = {acc[4 * g] + acc2[4 * g], acc[4 * g + 1] + acc2[4 * g + 1], acc[4 * g + 2] + acc2[4 * g + 2],
+                    acc[4 * g + 3] + acc2[4 * g + 3]};
+        *(f32x4v*)(row + c) = v;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < Kin) trf2_grad_out<SLAB>(row + c + e, acc[4 * g + e] + acc2[4 * g + e]);
+    }
+  }
+}
+
 // B operands of a dX item: W[out = k][in = it * 32 + j] (natural layout, lanes along `in`: coalesced)
 template <int HT>
 __device__ __forceinline__ void trf2_load_wx(float (&w)[TRF2_PP], const float* __restrict__ W, int O, int Kin,
@@ -496,17 +522,11 @@ __device__ __forceinline__ void trf2_back_linear(const float* __restrict__ G, co
       trf_act_batch(bv, act_in);
       f32x16 acc = {0}, acc2 = {0};
 #pragma unroll
-      for (int q = 0; q < 16; q += 2) {
-        acc = nsa_mfma(av[q], bv[q], acc);
-        acc2 = nsa_mfma(av[q + 1], bv[q + 1], acc2);
+      for (int q = 0; q < 16; q += 2) {  // D[i = in][jj = out]
+        acc = nsa_mfma(bv[q], av[q], acc);
+        acc2 = nsa_mfma(bv[q + 1], av[q + 1], acc2);
       }
-      if (kc < Kin) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (o < O) trf2_grad_out<SLAB>(&gW[(unsigned)o * (unsigned)Kin + (unsigned)kc], acc[r] + acc2[r]);
-        }
-      }
+      trf2_dw_store<SLAB>(gW, O, Kin, oc, itl * 32, half, acc, acc2);
     } else if (wave == TRF_WAVES - 1 && lane < O) {
       float s = 0.0f;
 #pragma unroll 8
@@ -837,17 +857,11 @@ __global__ void __launch_bounds__(TRF_THREADS) trf2_backward(TrfArgs a) {
       }
       f32x16 acc = {0}, acc2 = {0};
 #pragma unroll
-      for (int q = 0; q < 16; q += 2) {
-        acc = nsa_mfma(av[q], bv[q], acc);
-        acc2 = nsa_mfma(av[q + 1], bv[q + 1], acc2);
+      for (int q = 0; q < 16; q += 2) {  // D[i = in][jj = out]
+        acc = nsa_mfma(bv[q], av[q], acc);
+        acc2 = nsa_mfma(bv[q + 1], av[q + 1], acc2);
       }
-      if (kc < H) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (o < np) trf2_grad_out<SLAB>(&gWf[(unsigned)o * (unsigned)H + (unsigned)kc], acc[r] + acc2[r]);
-        }
-      }
+      trf2_dw_store<SLAB>(gWf, np, H, oc, itl * 32, half, acc, acc2);
     }
     float* gbf = GR + a.off[3 + 4 * L];
     for (int o = tid; o < np; o += TRF_THREADS) {
