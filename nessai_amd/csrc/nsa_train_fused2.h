@@ -1,7 +1,8 @@
-// Second generation of the fused training kernels of one coupling layer (included by nsa_train.hip
-// after nsa_train_fused.h; same TrfArgs, same workspace layout, same results up to the order of the
-// float32 sums).  Used when the conditioner is at most 64 wide (tr_v2_fits); the first generation stays
-// for wider nets and as the cross-check.
+// Second generation of the fused training kernels (included by nsa_train.hip after nsa_train_fused.h; same
+// TrfArgs, same workspace layout, same results up to the order of the float32 sums): the forward pass of a
+// RUN of coupling layers in one launch, the backward pass of one coupling layer per launch.  Used when the
+// conditioner is at most 64 wide (tr_v2_fits); the first generation stays for wider nets and as the
+// cross-check (NESSAI_AMD_TRAIN_V2=0).  DESIGN.md section 4.3 has the measurements behind every choice below.
 //
 // What the first generation spends its time on (scripts/ubench/layer_latency.hip measures the floor:
 // a 32 x 64 -> 64 layer costs a workgroup 1.07 us with its operands at hand, the first generation
@@ -9,7 +10,7 @@
 // are requested where they are used, and only 2 of the 8 waves own an output tile.  Here
 //   * every layer's B operands and bias are requested ONE LAYER AHEAD into registers (plain loads:
 //     the compiler's own wait counting stays valid next to the activation saves), the operands of the
-//     final layer - 60 % of the weight bytes - at kernel start, two output tiles per wave;
+//     final layer - 60 % of the weight bytes - right after layer 0, two output tiles per wave;
 //   * a hidden layer is split over all 8 waves, output tile x slice of k, and the partial sums meet
 //     in LDS where bias, residual and the activation save are applied by all 512 threads;
 //   * the parameters of the transform stay in an LDS tile for the spline / affine items (and are saved
@@ -35,7 +36,7 @@ __device__ __forceinline__ void trf2_static_for(F&& f) {
 }
 
 #ifndef TRF2_ABL
-#define TRF2_ABL 0  // diagnostic builds only (scripts/gpu_r03_h.sh): 1 drops the weight-gradient atomics
+#define TRF2_ABL 0  // diagnostic builds only: 1 drops the weight-gradient writes (and, the results being unused, the MFMAs behind them)
 #endif
 #define TRF2_PP 8  // k pairs per split-k item: 32 pairs / 4 slices (H <= 64), 32 / 8 (H <= 32)
 
