@@ -29,6 +29,10 @@ CASES = {
     "rnvp_custom_scale": (RealNVP, O.RealNVP, (6, 16, 3, 2),
                           dict(linear_transform="permutation", batch_norm_between_layers=False,
                                scale_activation=lambda x: torch.sigmoid(x - 0.5) + 0.05)),
+    # wider than the second-generation kernels take (hidden width > 64): the first-generation fused kernels
+    "nsf_wide": (NeuralSplineFlow, O.NeuralSplineFlow, (10, 96, 2, 2), {}),
+    # parameter rows that are not a multiple of 16 bytes (np = 3 x 23): the scalar paths of the backward kernel
+    "nsf_d5": (NeuralSplineFlow, O.NeuralSplineFlow, (5, 24, 2, 2), {}),
     "rnvp_c2_default": (RealNVP, O.RealNVP, (16, 32, 4, 2), {}),  # LU-linear + batch norm
     "rnvp_lu_only": (RealNVP, O.RealNVP, (5, 8, 2, 2), dict(batch_norm_between_layers=False)),
     "nsf_bn_lu": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 3, 2),
@@ -83,6 +87,45 @@ def test_loss_and_gradients_match_autograd(name):
     assert rel_err(torch.linalg.norm(g), torch.linalg.norm(g_ref), floor=1e-6) <= 1e-4
     # lr = 0 and decoupled weight decay lr*wd = 0: weights untouched
     assert torch.equal(tr.params, before)
+
+
+@pytest.mark.parametrize("name", ["nsf_c3", "nsf_d7_k4", "nsf_d6_tanh", "rnvp_perm", "rnvp_additive", "nsf_bn_lu"])
+def test_first_generation_fused_kernels_match_autograd(name, monkeypatch):
+    """The first-generation per-coupling kernels (nsa_train_fused.h) remain the path of conditioners wider than
+    64 and the cross-check of the second generation: same bar, on the shapes the second generation now takes."""
+    monkeypatch.setenv("NESSAI_AMD_TRAIN_V2", "0")
+    test_loss_and_gradients_match_autograd(name)
+
+
+def test_couplings_per_forward_launch_do_not_change_the_step(monkeypatch):
+    """One, two, three or six coupling layers per forward launch (nsa_train_fused2.h, NESSAI_AMD_TRAIN_RUN) are the
+    same arithmetic up to the compiler's choice of fused multiply-adds per instantiation and the order log|det J| is
+    summed in.  On a smooth (tanh) conditioner that is rounding noise; with relu a pre-activation within an ulp of
+    zero can fall on the other side of the kink in one row (scripts/fuzz_train.py: "kink_cases"), which is why this
+    is not asserted on config 3."""
+    results = {}
+    for run in ("1", "2", "3", "6"):
+        monkeypatch.setenv("NESSAI_AMD_TRAIN_RUN", run)
+        torch.manual_seed(5)
+        ref = O.NeuralSplineFlow(8, 16, 6, 2, activation=torch.tanh)
+        with torch.no_grad():
+            for n_, p_ in ref.named_parameters():
+                if "linear_layers.1" in n_:
+                    p_.mul_(200.0)
+        flow = NeuralSplineFlow(8, 16, 6, 2, activation=torch.tanh)
+        flow.load_state_dict(ref.state_dict())
+        flow.to(DEV)
+        x = (torch.randn(1000, 8, generator=torch.Generator().manual_seed(11)) * 1.2).to(DEV)
+        tr = Trainer(flow)
+        tr.step(x, clip_norm=5.0, lr=0.0)
+        torch.cuda.synchronize()
+        results[run] = (tr.loss_acc.item(), tr.grads.cpu().clone())
+    l1, g1 = results["1"]
+    scale = max(1e-3, float(g1.abs().max()))
+    for run in ("2", "3", "6"):
+        l, g = results[run]
+        assert abs(l - l1) <= 2e-6 * max(1.0, abs(l1)), run
+        assert float((g - g1).abs().max()) <= 1e-5 * scale, run
 
 
 def test_eval_matches_inference_kernel():
