@@ -255,6 +255,18 @@ class Trainer:
                 self.plan[flag] = 0
                 module.initialized.fill_(True)
 
+    def pinned_buffers(self, n_train):
+        """Host-pinned staging of the epoch loop (permutation up, the two losses down), kept across fits: pinning
+        memory is a driver call of the order of a short fit's epoch."""
+        cached = getattr(self, "_pinned", None)
+        if cached is None or cached[0].numel() < n_train:
+            size = max(n_train, 4096)
+            cached = (torch.empty(size, dtype=torch.int64, pin_memory=True),
+                      torch.empty(size, dtype=torch.int64, device=self.device),
+                      torch.empty(2, dtype=torch.float32, pin_memory=True))
+            self._pinned = cached
+        return cached[0][:n_train], cached[1][:n_train], cached[2]
+
     def _workspace(self, n):
         if self._ws is None or n > self._ws_rows:
             words = int(lib.load().nsa_train_workspace_floats(self.plan, n))
@@ -422,8 +434,7 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
     # back: the look-ahead leaves no trace in torch's random streams.
     # (the permutation goes up from pinned memory: an upload from pageable memory holds the host until the stream
     # has drained - the whole running epoch)
-    perm_host = torch.empty(n_train, dtype=torch.int64, pin_memory=True)
-    perm_dev = torch.empty(n_train, dtype=torch.int64, device=train_data.device)
+    perm_host, perm_dev, losses_host = trainer.pinned_buffers(n_train)
 
     def prepare_rows():
         torch.randperm(n_train, out=perm_host)
@@ -445,7 +456,6 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
 
     use_graph = os.environ.get("NESSAI_AMD_EPOCH_GRAPH", "1") != "0"
     graph = None
-    losses_host = torch.empty(2, dtype=torch.float32, pin_memory=True)
     losses_ready = torch.cuda.Event()
     with _training_kernels(tc.get("deterministic")):
         prepare_rows()
