@@ -1148,7 +1148,7 @@ template <int K, int HT>
 static hipError_t tr_forward_run_c(const Trf2Multi& m, int count, hipStream_t s) {
   if (count == 1) return tr_launch_forward2<K, HT, 1>(m, s);
   if (count == 2) return tr_launch_forward2<K, HT, 2>(m, s);
-  if (count == 3) return tr_launch_forward2<K, HT, 3>(m, s);
+  if (count == 4) return tr_launch_forward2<K, HT, 4>(m, s);
   return tr_launch_forward2<K, HT, 6>(m, s);
 }
 template <int K>
@@ -1256,10 +1256,10 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
           const char* e = getenv("NESSAI_AMD_TRAIN_RUN");
           int want = e != nullptr ? atoi(e) : TRF2_MAXC;
           want = want < 1 ? 1 : (want > TRF2_MAXC ? TRF2_MAXC : want);
-          {  // instantiated run lengths: 1, 2, 3, 6
+          {  // instantiated run lengths: 6 (config 3), 4 (the reference's default n_blocks), 2, 1
             int ahead = 0;
             for (int bb = b; bb < NL && ahead < want && plan[TR_HDR + bb * rec] == TR_COUPLING; ++bb) ++ahead;
-            want = ahead >= 6 && want >= 6 ? 6 : (ahead < 3 ? ahead : (want < 3 ? want : 3));
+            want = ahead >= 6 ? 6 : (ahead >= 4 ? 4 : (ahead >= 2 ? 2 : 1));
           }
           Trf2Multi m;
           memset(&m, 0, sizeof(m));

@@ -4,7 +4,7 @@
 #   r03_layer_latency_ubench.txt   scripts/ubench/layer_latency (the floor of one hidden layer)
 #   r03_train_c3_v2.json / .txt    scripts/bench_train.py, plain and under rocprofv3 --kernel-trace --stats (+ gaps)
 #   r03_train_phases_v2.txt        in-kernel phase stamps
-#   r03_train_run_lengths.txt      step time with 1 / 3 / 6 couplings per forward launch, and with the first generation
+#   r03_train_run_lengths.txt      step time with 1 / 2 / 6 couplings per forward launch, and with the first generation
 set -u
 cd /root/repo
 O=gpurun_out/train_r03
@@ -12,7 +12,7 @@ mkdir -p $O
 [ -x scripts/ubench/layer_latency ] && timeout 120 scripts/ubench/layer_latency > $O/r03_layer_latency_ubench.txt 2>&1
 python scripts/bench_train.py --epochs 40 --cpu-epochs 3 2>/dev/null | tail -1 > $O/r03_train_c3_v2.json
 : > $O/r03_train_run_lengths.txt
-for run in 1 3 6; do
+for run in 1 2 6; do
   echo "NESSAI_AMD_TRAIN_RUN=$run" >> $O/r03_train_run_lengths.txt
   for rep in 1 2; do
     NESSAI_AMD_TRAIN_RUN=$run python scripts/bench_train.py --epochs 40 --cpu-epochs 1 2>/dev/null | tail -1 | cut -c1-150 >> $O/r03_train_run_lengths.txt

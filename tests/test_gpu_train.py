@@ -98,13 +98,13 @@ def test_first_generation_fused_kernels_match_autograd(name, monkeypatch):
 
 
 def test_couplings_per_forward_launch_do_not_change_the_step(monkeypatch):
-    """One, two, three or six coupling layers per forward launch (nsa_train_fused2.h, NESSAI_AMD_TRAIN_RUN) are the
+    """One, two, four or six coupling layers per forward launch (nsa_train_fused2.h, NESSAI_AMD_TRAIN_RUN) are the
     same arithmetic up to the compiler's choice of fused multiply-adds per instantiation and the order log|det J| is
     summed in.  On a smooth (tanh) conditioner that is rounding noise; with relu a pre-activation within an ulp of
     zero can fall on the other side of the kink in one row (scripts/fuzz_train.py: "kink_cases"), which is why this
     is not asserted on config 3."""
     results = {}
-    for run in ("1", "2", "3", "6"):
+    for run in ("1", "2", "4", "6"):
         monkeypatch.setenv("NESSAI_AMD_TRAIN_RUN", run)
         torch.manual_seed(5)
         ref = O.NeuralSplineFlow(8, 16, 6, 2, activation=torch.tanh)
@@ -122,7 +122,7 @@ def test_couplings_per_forward_launch_do_not_change_the_step(monkeypatch):
         results[run] = (tr.loss_acc.item(), tr.grads.cpu().clone())
     l1, g1 = results["1"]
     scale = max(1e-3, float(g1.abs().max()))
-    for run in ("2", "3", "6"):
+    for run in ("2", "4", "6"):
         l, g = results[run]
         assert abs(l - l1) <= 2e-6 * max(1.0, abs(l1)), run
         assert float((g - g1).abs().max()) <= 1e-5 * scale, run
