@@ -146,20 +146,23 @@ __global__ void __launch_bounds__(256) tr_gemm_tn(int n, int O, int I, const flo
   const int k_lo = wave * per, k_hi = (k_lo + per < n) ? (k_lo + per) : n;
   f32x16 acc = {0};
   float bsum = 0.0f;
-  for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
-    float gv[8], xv[8];
+  // 64 rows of operands are requested before the first of their MFMAs (this product is a chain of round trips to
+  // the batch: 16 rows per trip made it 16 us for a 1000-row batch), from clamped addresses and with the range
+  // tests as factors - a select on a loaded value makes the compiler wait for the load where it is issued
+  for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
+    float gv[32], xv[32];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 32; ++u) {
       const int row = k0 + 2 * u + half;
       const int rc = row < n ? row : n - 1;
       gv[u] = Gout[(long long)rc * ldg + oc];
       xv[u] = X[(long long)rc * ldx + xcol];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 32; ++u) {
       const int row = k0 + 2 * u + half;
-      const float a = (o_ok && row < k_hi) ? gv[u] : 0.0f;
-      const float bb = (i_ok && row < k_hi) ? tr_act(xv[u], act_in) : 0.0f;
+      const float a = gv[u] * ((o_ok && row < k_hi) ? 1.0f : 0.0f);
+      const float bb = tr_act(xv[u], act_in) * ((i_ok && row < k_hi) ? 1.0f : 0.0f);
       bsum += a;
       acc = nsa_mfma(a, bb, acc);  // D[ii = o][jj = i]
     }
@@ -739,6 +742,150 @@ __global__ void tr_lu_build(int D, const float* __restrict__ lower, const float*
 }
 
 // dst[row][k] = src[row][cols[k]]  (gather)  /  dst[row][cols[k]] = src[row][k]  (scatter)
+// ---- the LU-linear layer in one launch per direction (D <= 64; the layer-wise sequence above is 5 + 6 launches of
+// 4-16 us each, and the reference's default RealNVP has one such layer per coupling) ----
+// A workgroup takes groups of R = 256 / D rows: thread (r, i) owns one output element, the factors sit in LDS
+// (transposed for the forward products so that lanes run along the contiguous index).
+//   forward:  xin = x[:, cols];  t = xin U^T;  y = t L^T + b   (xin, t saved; block 0 adds log|det| = sum log diag U
+//             and clears the accumulators of the backward pass)
+__global__ void __launch_bounds__(256) tr_lu_forward_fused(int n, int D, float* __restrict__ X, const int* __restrict__ cols,
+                                                           const float* __restrict__ lower, const float* __restrict__ upper,
+                                                           const float* __restrict__ raw, float eps,
+                                                           const float* __restrict__ bias, float* __restrict__ xin,
+                                                           float* __restrict__ tsave, float* __restrict__ gL,
+                                                           float* __restrict__ gU, float* __restrict__ ld_const) {
+  extern __shared__ float lu_sm[];
+  float* UT = lu_sm;            // UT[j * D + i] = U[i][j]
+  float* LT = UT + D * D;       // LT[j * D + i] = L[i][j]
+  float* xs = LT + D * D;       // [R][D]
+  float* ts = xs + 256;
+  const int tid = threadIdx.x;
+  const int R = 256 / D;
+  for (int e = tid; e < D * D; e += 256) {
+    const int i = e / D, j = e - i * D;
+    float l = 0.0f, u = 0.0f;
+    if (j < i) l = lower[i * (i - 1) / 2 + j];
+    else if (j == i) { l = 1.0f; u = nsa_softplus(raw[i]) + eps; }
+    else u = upper[i * D - i * (i + 1) / 2 + (j - i - 1)];
+    LT[j * D + i] = l;
+    UT[j * D + i] = u;
+    if (blockIdx.x == 0) { gL[e] = 0.0f; gU[e] = 0.0f; }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    float ld = 0.0f;
+    for (int i = 0; i < D; ++i) ld += logf(nsa_softplus(raw[i]) + eps);
+    ld_const[0] += ld;
+  }
+  const int r = tid / D, i = tid - r * D;
+  const bool mine = r < R;
+  const int col = mine ? cols[i] : 0;
+  const float b = mine ? bias[i] : 0.0f;
+  __syncthreads();
+  for (int g = blockIdx.x; g * R < n; g += gridDim.x) {
+    const int row = g * R + r;
+    const bool ok = mine && row < n;
+    const float xv = ok ? X[(long long)row * D + col] : 0.0f;
+    if (mine) xs[r * D + i] = xv;
+    if (ok) xin[(long long)row * D + i] = xv;
+    __syncthreads();
+    float t = 0.0f;
+    if (mine)
+      for (int j = 0; j < D; ++j) t += UT[j * D + i] * xs[r * D + j];
+    if (mine) ts[r * D + i] = t;
+    if (ok) tsave[(long long)row * D + i] = t;
+    __syncthreads();
+    if (ok) {
+      float y = b;
+      for (int j = 0; j < D; ++j) y += LT[j * D + i] * ts[r * D + j];
+      X[(long long)row * D + i] = y;
+    }
+    __syncthreads();
+  }
+}
+
+//   backward: gt = gy L;  g_x[:, cols] = gt U;  dL += gy^T t;  dU += gt^T xin;  db += colsum gy;  x[:, cols] restored
+//   (per-workgroup sums in registers, one float atomic per element and workgroup at the end; tr_lu_grads follows)
+__global__ void __launch_bounds__(256) tr_lu_backward_fused(int n, int D, float* __restrict__ X, float* __restrict__ Gx,
+                                                            const int* __restrict__ cols, const float* __restrict__ lower,
+                                                            const float* __restrict__ upper, const float* __restrict__ raw,
+                                                            float eps, const float* __restrict__ xin,
+                                                            const float* __restrict__ tsave, float* __restrict__ gL,
+                                                            float* __restrict__ gU, float* __restrict__ gb) {
+  extern __shared__ float lu_sm[];
+  float* Lm = lu_sm;          // Lm[i * D + j]
+  float* Um = Lm + D * D;
+  float* gys = Um + D * D;    // [R][D] each
+  float* gts = gys + 256;
+  float* xs = gts + 256;
+  float* ts = xs + 256;
+  const int tid = threadIdx.x;
+  const int R = 256 / D;
+  for (int e = tid; e < D * D; e += 256) {
+    const int i = e / D, j = e - i * D;
+    float l = 0.0f, u = 0.0f;
+    if (j < i) l = lower[i * (i - 1) / 2 + j];
+    else if (j == i) { l = 1.0f; u = nsa_softplus(raw[i]) + eps; }
+    else u = upper[i * D - i * (i + 1) / 2 + (j - i - 1)];
+    Lm[e] = l;
+    Um[e] = u;
+  }
+  const int r = tid / D, j = tid - r * D;
+  const bool mine = r < R;
+  const int col = mine ? cols[j] : 0;
+  constexpr int PER = 16;  // (i, j) pairs of the D x D gradients per thread: 64 * 64 / 256
+  float accL[PER], accU[PER], accb = 0.0f;
+#pragma unroll
+  for (int p = 0; p < PER; ++p) { accL[p] = 0.0f; accU[p] = 0.0f; }
+  __syncthreads();
+  for (int g = blockIdx.x; g * R < n; g += gridDim.x) {
+    const int row = g * R + r;
+    const bool ok = mine && row < n;
+    if (mine) {
+      gys[r * D + j] = ok ? Gx[(long long)row * D + j] : 0.0f;
+      xs[r * D + j] = ok ? xin[(long long)row * D + j] : 0.0f;
+      ts[r * D + j] = ok ? tsave[(long long)row * D + j] : 0.0f;
+    }
+    __syncthreads();
+    float gt = 0.0f;
+    if (mine)
+      for (int i = 0; i < D; ++i) gt += gys[r * D + i] * Lm[i * D + j];
+    if (mine) gts[r * D + j] = gt;
+    __syncthreads();
+    if (ok) {
+      float gx = 0.0f;
+      for (int i = 0; i < D; ++i) gx += gts[r * D + i] * Um[i * D + j];
+      Gx[(long long)row * D + col] = gx;
+      X[(long long)row * D + col] = xs[r * D + j];
+    }
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+      const int e = tid + 256 * p;
+      if (e < D * D) {
+        const int i = e / D, jj = e - i * D;
+        float a = 0.0f, u = 0.0f;
+        for (int rr = 0; rr < R; ++rr) {
+          a += gys[rr * D + i] * ts[rr * D + jj];
+          u += gts[rr * D + i] * xs[rr * D + jj];
+        }
+        accL[p] += a;
+        accU[p] += u;
+      }
+    }
+    if (tid < D)
+      for (int rr = 0; rr < R; ++rr) accb += gys[rr * D + tid];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int p = 0; p < PER; ++p) {
+    const int e = tid + 256 * p;
+    if (e < D * D) {
+      atomicAdd(&gL[e], accL[p]);
+      atomicAdd(&gU[e], accU[p]);
+    }
+  }
+  if (tid < D) atomicAdd(&gb[tid], accb);
+}
+
 __global__ void tr_gather_cols(int n, int D, const float* __restrict__ src, int lds_, const int* __restrict__ cols,
                                float* __restrict__ dst, int scatter) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1350,6 +1497,14 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
       const int* cols = tabs + r[1];
       const float eps = tr_bits(r[6]);
       TrLin q = tr_lin(lay, n, D);
+      if (tr_use_fused(plan) && D <= 64) {
+        const int R = 256 / D;
+        const long long groups = (n + R - 1) / R;
+        hipLaunchKernelGGL(tr_lu_forward_fused, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(256),
+                           (size_t)(2 * D * D + 512) * sizeof(float), s, (int)n, D, w.x, cols, params + r[2],
+                           params + r[3], params + r[4], eps, params + r[5], q.xin, q.t, q.gL, q.gU, w.scal + 1);
+        continue;
+      }
       float* zero = q.vec;  // zero bias for the first product
       (void)hipMemsetAsync(zero, 0, D * sizeof(float), s);
       hipLaunchKernelGGL(tr_lu_build, blocks_for(D * D), dim3(256), 0, s, D, params + r[2], params + r[3],
@@ -1499,6 +1654,16 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       const int* cols = tabs + r[1];
       const float eps = tr_bits(r[6]);
       TrLin q = tr_lin(lay, n, D);
+      if (tr_use_fused(plan) && D <= 64) {  // (grads were zeroed by tr_prepare / nsa_train_backward: db accumulates)
+        const int R = 256 / D;
+        const long long groups = (n + R - 1) / R;
+        hipLaunchKernelGGL(tr_lu_backward_fused, dim3((unsigned)(groups < 32 ? groups : 32)), dim3(256),
+                           (size_t)(2 * D * D + 1024) * sizeof(float), s, (int)n, D, w.x, w.gx, cols, params + r[2],
+                           params + r[3], params + r[4], eps, q.xin, q.t, q.gL, q.gU, grads + r[5]);
+        hipLaunchKernelGGL(tr_lu_grads, blocks_for(D * D), dim3(256), 0, s, D, q.gL, q.gU, params + r[4], eps,
+                           grads + r[2], grads + r[3], grads + r[4], w.scal + 2);
+        continue;
+      }
       // gy = w.gx (logical order).  dL = gy^T t, db = colsum gy;  gt = gy L;  dU = gt^T x;  gx = gt U
       hipLaunchKernelGGL(tr_gemm_tn, tiles(D, D), dim3(256), 0, s, (int)n, D, D, w.gx, D, q.t, D,
                          (const int*)nullptr, ACT_NONE, q.gL, grads + r[5]);
