@@ -33,6 +33,9 @@ CASES = {
     "nsf_wide": (NeuralSplineFlow, O.NeuralSplineFlow, (10, 96, 2, 2), {}),
     # parameter rows that are not a multiple of 16 bytes (np = 3 x 23): the scalar paths of the backward kernel
     "nsf_d5": (NeuralSplineFlow, O.NeuralSplineFlow, (5, 24, 2, 2), {}),
+    # four residual blocks per conditioner: nine activation tiles, beyond what the backward kernel copies through
+    # registers (its async-copy path)
+    "nsf_deep": (NeuralSplineFlow, O.NeuralSplineFlow, (8, 16, 2, 4), {}),
     "rnvp_c2_default": (RealNVP, O.RealNVP, (16, 32, 4, 2), {}),  # LU-linear + batch norm
     "rnvp_lu_only": (RealNVP, O.RealNVP, (5, 8, 2, 2), dict(batch_norm_between_layers=False)),
     "nsf_bn_lu": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 3, 2),
