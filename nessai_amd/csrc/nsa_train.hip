@@ -1273,10 +1273,9 @@ static bool tr_v2_fits(bool backward, const TrfArgs& a) {
   if (e != nullptr && e[0] == '0') return false;
   if (a.H > 64 || a.D > 128 || a.np > 512) return false;
   if (!backward) return a.d_id <= 64 && trf2_forward_floats(a) * sizeof(float) <= 160 * 1024;
-  // backward: identity columns within the hidden width's tiles, <= 2 items per thread, float4-aligned tiles
+  // backward: identity columns within the hidden width's tiles, <= 2 items per thread
   const int ht = a.H <= 32 ? 1 : 2;
-  return a.d_id <= 32 * ht && a.d_tr <= 32 && a.H % 4 == 0 && ((uintptr_t)a.h % 16 == 0) && ((uintptr_t)a.u % 16 == 0) &&
-         (((long long)a.n * a.H) % 4 == 0) && trf2_backward_floats(a) * sizeof(float) <= 160 * 1024;
+  return a.d_id <= 32 * ht && a.d_tr <= 32 && trf2_backward_floats(a) * sizeof(float) <= 160 * 1024;
 }
 
 // forward pass of a run of `count` coupling layers in one launch (m.a.np = the largest np of the run)
@@ -1314,8 +1313,9 @@ template <int K, int HT>
 static hipError_t tr_launch_fused2(bool backward, const TrfArgs& a, hipStream_t s) {
   const size_t lds = trf2_backward_floats(a) * sizeof(float);
   // 16-byte accesses to the parameter tile and to the transposed final-layer weights
-  const bool vec = a.np % 4 == 0 && a.L <= 3 && a.off[2 + 4 * a.L] % 4 == 0 && ((uintptr_t)a.p % 16 == 0) &&
-                   ((uintptr_t)a.wt % 16 == 0);
+  const bool vec = a.np % 4 == 0 && a.H % 4 == 0 && a.L <= 3 && a.off[2 + 4 * a.L] % 4 == 0 && ((uintptr_t)a.p % 16 == 0) &&
+                   ((uintptr_t)a.wt % 16 == 0) && ((uintptr_t)a.h % 16 == 0) && ((uintptr_t)a.u % 16 == 0) &&
+                   (((long long)a.n * a.H) % 4 == 0);
   auto kern = a.gslab != nullptr ? (vec ? trf2_backward<K, HT, true, true> : trf2_backward<K, HT, true, false>)
                                  : (vec ? trf2_backward<K, HT, false, true> : trf2_backward<K, HT, false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -676,15 +676,22 @@ __global__ void __launch_bounds__(TRF_THREADS) trf2_backward(TrfArgs a) {
   } else {
     trf2_rows_async(XT, ldx, a.X, D, r0, n, wave, lane);
     const int words = TRF_ROWS * H;
+    // 16-byte pieces where the tiles allow it (H % 4 == 0, 16-byte aligned blocks); row by row otherwise (a hidden
+    // width of 2 x an odd number of dimensions, the reference's default for such models)
+    const bool quads = (H & 3) == 0 && (nH & 3) == 0 && ((((unsigned long long)a.h) | ((unsigned long long)a.u)) & 15) == 0;
     for (int t = 0; t < 2 * L + 1; ++t) {
       const float* src = (t <= L) ? a.h + t * nH : a.u + (t - L - 1) * nH;
-      for (int piece = wave; piece * 256 < words; piece += TRF_WAVES) {
-        const int word = piece * 256 + lane * 4;
-        if (word < words) {
-          long long g = (long long)r0 * H + word;
-          g = g < nH - 4 ? g : nH - 4;
-          nsa_glds16((const uint32_t*)(src + g), ACT + t * words + piece * 256);
+      if (quads) {
+        for (int piece = wave; piece * 256 < words; piece += TRF_WAVES) {
+          const int word = piece * 256 + lane * 4;
+          if (word < words) {
+            long long g = (long long)r0 * H + word;
+            g = g < nH - 4 ? g : nH - 4;
+            nsa_glds16((const uint32_t*)(src + g), ACT + t * words + piece * 256);
+          }
         }
+      } else {
+        trf2_rows_async(ACT + t * words, H, src, H, r0, n, wave, lane);
       }
     }
   }

@@ -5,8 +5,10 @@ configurations and batch sizes (fused per-coupling kernels where they apply, lay
 A case beyond the bars is re-judged against the oracle in float64 before it counts as a failure:
   * ill-conditioned flow - the float32 oracle is itself further than the bar from its float64 twin:
     the device has to be within 3x the float32 oracle's error of the float64 gradients;
-  * relu kink - some pre-activation of some row is within float32 round-off of zero (|pre| < 1e-6 of the
-    layer's median): which side of the kink a row falls on, and with it that row's whole contribution
+  * relu kink - some pre-activation of some row is within float32 round-off of zero (|pre| < 4e-6 of the
+    layer's median: a 100-term float32 sum carries up to ~6e-6; seed 11, case 6 sits at 1.15e-6 and moves one
+    gradient by 1.5 % of the largest in the fused kernels of either generation while the layer-wise kernels
+    land on the oracle's side): which side of the kink a row falls on, and with it that row's whole contribution
     to the upstream gradients, is decided by the rounding of the last product.  Reported as
     "kink_cases", not as failures (seed 9, case 38: one pre-activation of 3.7e-8 among 0.26-sized ones).
 
@@ -36,6 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iterations", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", type=int, default=None, help="evaluate this case of the sequence only")
     args = ap.parse_args()
     g = np.random.default_rng(args.seed)
     bad, skipped, worst = [], 0, dict(loss=0.0, grad=0.0)
@@ -64,6 +67,8 @@ def main():
         flow.to(DEV)
         n = int(g.choice([33, 200, 333, 1000]))
         x = torch.randn(n, shape[0], generator=torch.Generator().manual_seed(1000 + it)) * float(g.choice([0.7, 1.5]))
+        if args.only is not None and it != args.only:
+            continue
         ref.train()
         ref64 = copy.deepcopy(ref).double()
         pre = []  # smallest |pre-activation| of every linear layer, relative to the layer's median
@@ -97,13 +102,13 @@ def main():
             if float((gd.double() - g64).abs().max()) / scale <= 3.0 * own:
                 rejudged["ill_conditioned"] += 1
                 continue
-            if act == "relu" and min(pre) < 1e-6:
+            if act == "relu" and min(pre) < 4e-6:
                 rejudged["kink_cases"] += 1
                 continue
         worst["loss"] = max(worst["loss"], e_loss)
         worst["grad"] = max(worst["grad"], e_grad)
         if not (e_loss <= 1e-5 and e_grad <= 2e-4):
-            bad.append(dict(n=n, loss_rel=e_loss, grad_rel_to_max=e_grad, **desc))
+            bad.append(dict(n=n, loss_rel=e_loss, grad_rel_to_max=e_grad, smallest_pre_activation=min(pre), **desc))
             print("FAIL", json.dumps(bad[-1], default=str), flush=True)
     print(json.dumps(dict(iterations=args.iterations, skipped=skipped, failures=len(bad), worst=worst, **rejudged)))
     sys.exit(1 if bad else 0)

@@ -36,6 +36,8 @@ CASES = {
     # four residual blocks per conditioner: nine activation tiles, beyond what the backward kernel copies through
     # registers (its async-copy path)
     "nsf_deep": (NeuralSplineFlow, O.NeuralSplineFlow, (8, 16, 2, 4), {}),
+    # config 5's shape: 15 dimensions, 30 neurons (a hidden width that is not a multiple of 4: row-by-row tile copies)
+    "nsf_c5": (NeuralSplineFlow, O.NeuralSplineFlow, (15, 30, 4, 2), {}),
     "rnvp_c2_default": (RealNVP, O.RealNVP, (16, 32, 4, 2), {}),  # LU-linear + batch norm
     "rnvp_lu_only": (RealNVP, O.RealNVP, (5, 8, 2, 2), dict(batch_norm_between_layers=False)),
     "nsf_bn_lu": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 3, 2),
