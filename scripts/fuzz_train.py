@@ -10,7 +10,8 @@ A case beyond the bars is re-judged against the oracle in float64 before it coun
     gradient by 1.5 % of the largest in the fused kernels of either generation while the layer-wise kernels
     land on the oracle's side): which side of the kink a row falls on, and with it that row's whole contribution
     to the upstream gradients, is decided by the rounding of the last product.  Reported as
-    "kink_cases", not as failures (seed 9, case 38: one pre-activation of 3.7e-8 among 0.26-sized ones).
+    "kink_cases", not as failures (seed 9, case 38: one pre-activation of 3.7e-8 among 0.26-sized ones);
+  * spline bin edge - an input within round-off of a knot (see the comment at the re-judgement): "bin_edge_cases".
 
     python scripts/fuzz_train.py [--iterations 60] [--seed 0]"""
 import argparse
@@ -42,7 +43,7 @@ def main():
     args = ap.parse_args()
     g = np.random.default_rng(args.seed)
     bad, skipped, worst = [], 0, dict(loss=0.0, grad=0.0)
-    rejudged = dict(ill_conditioned=0, kink_cases=0)
+    rejudged = dict(ill_conditioned=0, kink_cases=0, bin_edge_cases=0)
     for it in range(args.iterations):
         kind, shape, kw, act = F.random_case(g)
         if shape[0] > 48:
@@ -69,6 +70,8 @@ def main():
         x = torch.randn(n, shape[0], generator=torch.Generator().manual_seed(1000 + it)) * float(g.choice([0.7, 1.5]))
         if args.only is not None and it != args.only:
             continue
+        if os.environ.get("FUZZ_NUDGE"):  # the same case with every input moved by a relative FUZZ_NUDGE
+            x = x * (1.0 + float(os.environ["FUZZ_NUDGE"]))
         ref.train()
         ref64 = copy.deepcopy(ref).double()
         pre = []  # smallest |pre-activation| of every linear layer, relative to the layer's median
@@ -105,10 +108,42 @@ def main():
             if act == "relu" and min(pre) < 4e-6:
                 rejudged["kink_cases"] += 1
                 continue
+        if e_loss <= 1e-5 and e_grad > 2e-4:
+            # spline bin edge: an input within round-off of a knot is searched into one bin by the device and into its
+            # neighbour by torch - same value, same dL/dx (the spline is C1), but the parameter gradients of THAT row
+            # go to different bins.  Such a case passes with every input moved by +-1e-5 relative (seed 24, case 34).
+            moved = []
+            for nudge in (1e-5, -1e-5):
+                xm = x * (1.0 + nudge)
+                ref.zero_grad()
+                (-ref.log_prob(xm).mean()).backward()
+                gm = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ref.parameters()])
+                flow2 = P(*shape, **kw)
+                flow2.load_state_dict(ref.state_dict())
+                flow2.to(DEV)
+                tr2 = Trainer(flow2)
+                tr2.step(xm.to(DEV), clip_norm=5.0, lr=0.0)
+                moved.append(float((tr2.grads.cpu() - gm).abs().max()) / max(1e-3, float(gm.abs().max())))
+            if max(moved) <= 2e-4:
+                rejudged["bin_edge_cases"] += 1
+                continue
         worst["loss"] = max(worst["loss"], e_loss)
         worst["grad"] = max(worst["grad"], e_grad)
         if not (e_loss <= 1e-5 and e_grad <= 2e-4):
-            bad.append(dict(n=n, loss_rel=e_loss, grad_rel_to_max=e_grad, smallest_pre_activation=min(pre), **desc))
+            at, pos, where = int((gd - g_ref).abs().argmax()), 0, "?"
+            for n_, p_ in ref.named_parameters():  # which parameter holds the worst element
+                if pos <= at < pos + p_.numel():
+                    where = f"{n_}[{at - pos}] device {float(gd[at]):.6g} oracle {float(g_ref[at]):.6g}"
+                pos += p_.numel()
+            if args.only is not None:  # per-parameter errors of the case under the lens
+                pos = 0
+                for n_, p_ in ref.named_parameters():
+                    e_ = float((gd[pos:pos + p_.numel()] - g_ref[pos:pos + p_.numel()]).abs().max()) / scale
+                    if e_ > 1e-5:
+                        print(f"  {n_:60s} {tuple(p_.shape)} {e_:.3e}")
+                    pos += p_.numel()
+            bad.append(dict(n=n, loss_rel=e_loss, grad_rel_to_max=e_grad, smallest_pre_activation=min(pre), worst_at=where,
+                            **desc))
             print("FAIL", json.dumps(bad[-1], default=str), flush=True)
     print(json.dumps(dict(iterations=args.iterations, skipped=skipped, failures=len(bad), worst=worst, **rejudged)))
     sys.exit(1 if bad else 0)
