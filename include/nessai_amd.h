@@ -420,6 +420,11 @@ NSA_API int nsa_log_likelihood(int kind, long long n, int D, const double* x64_d
  *   optimiser   0 AdamW, 1 Adam (L2 weight decay), 2 SGD without momentum - the three choices of
  *               FlowModel.get_optimiser (flowmodel/base.py:105-135)
  *   loss_acc_dev  float[1], the minibatch loss is ADDED (read once per epoch)
+ *
+ * The workspace (nsa_train_workspace_floats floats, 16-byte aligned blocks) holds the batch, the saved
+ * activations of every layer and, for conditioners up to 64 wide, one copy of the flat gradient per
+ * 32-row workgroup of the fused backward kernels (summed in a fixed order at the end of the pass; left
+ * out, in favour of float atomics, above 2^26 floats).
  */
 NSA_API size_t nsa_train_workspace_floats(const long long* plan, long long n);
 NSA_API int nsa_train_step(const long long* plan, const int* tables_dev, const float* consts,
