@@ -21,10 +21,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=40)
     ap.add_argument("--plain", action="store_true")
+    ap.add_argument("--config", choices=("c2", "c4", "c5"), default="c2",
+                    help="c4: 64-D NSF, 128 neurons, 6 layers, 5000 points; c5: 15-D NSF, 30 neurons, 4 layers, 4000 points")
     args = ap.parse_args()
     rng = np.random.default_rng(7)
-    x = rng.normal(size=(2000, 16)).astype(np.float64)
-    cfg = dict(n_inputs=16, n_neurons=32, n_blocks=4, n_layers=2, ftype="realnvp")
+    if args.config == "c4":
+        x = rng.normal(size=(5000, 64)).astype(np.float64)
+        cfg = dict(n_inputs=64, n_neurons=128, n_blocks=6, n_layers=2, ftype="nsf")
+    elif args.config == "c5":
+        x = rng.normal(size=(4000, 15)).astype(np.float64)
+        cfg = dict(n_inputs=15, n_neurons=30, n_blocks=4, n_layers=2, ftype="nsf")
+    else:
+        x = rng.normal(size=(2000, 16)).astype(np.float64)
+        cfg = dict(n_inputs=16, n_neurons=32, n_blocks=4, n_layers=2, ftype="realnvp")
     if args.plain:
         cfg.update(linear_transform="permutation", batch_norm_between_layers=False)
     from nessai_amd.flowmodel import FlowModel
@@ -41,8 +50,10 @@ def main():
         hist = fm.train(x, max_epochs=args.epochs)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
-    steps = 2 * len(hist["loss"])
-    print(json.dumps({"metric": "FlowModel.train optimiser step time, config 2 flow" + (" (permutations, no batch norm)" if args.plain else ""),
+    n_train = int(round(0.9 * len(x)))
+    steps = -(-n_train // 1000) * len(hist["loss"])
+    print(json.dumps({"metric": f"FlowModel.train optimiser step time, config {args.config[1]} flow" + (" (permutations, no batch norm)" if args.plain else ""),
+                      "rows": len(x), "steps_per_epoch": -(-n_train // 1000),
                       "gpu_ms_per_step": 1e3 * dt / steps, "epochs": len(hist["loss"]), "final_loss": hist["loss"][-1]}))
 
 
