@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Randomised parity sweep of the reparameterisation table in the draw kernel's epilogue: every
 parameter gets a random map (rescale-to-bounds with logit / log post-rescaling, plain, with offset,
-null, z-score), the proposal and the oracle are fitted to the same live points, and
+null, boundary inversion - split or duplicate, its live points piled up at the lower bound, at the upper
+bound or in the middle -, z-score), the proposal and the oracle are fitted to the same live points, and
 ``backward_pass`` on injected latents is compared (kept rows, x per column, log q incl. the row-dependent
 Jacobians).
 
@@ -20,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_populate as T  # noqa: E402
 from oracle import reparam as OR  # noqa: E402
 
-KINDS = ["logit", "log-rescale", "default", "offset", "null", "zscore"]
+KINDS = ["logit", "log-rescale", "default", "offset", "null", "inversion", "inversion-duplicate", "zscore"]
 
 
 def main():
@@ -52,6 +53,10 @@ def main():
                 parts.append(OR.OracleRescaleToBounds(members, b))
             elif kind == "offset":
                 parts.append(OR.OracleRescaleToBounds(members, b, offset=True))
+            elif kind == "inversion":
+                parts.append(OR.OracleBoundaryInversion(members, b, "split", rng=np.random.default_rng(it)))
+            elif kind == "inversion-duplicate":
+                parts.append(OR.OracleBoundaryInversion(members, b, "duplicate"))
             else:
                 parts.append(OR.OracleNull(members))
         rest = [n for n in names if assign[n] == "zscore"]
@@ -61,6 +66,14 @@ def main():
         live = prop.model.new_point(400, rng=np.random.default_rng(it))
         for n in names:
             live[n] = (0.1 if assign[n] == "null" else 0.4) * live[n]
+            if assign[n].startswith("inversion"):
+                where = str(g.choice(["lower", "upper", "middle"]))
+                if where == "lower":
+                    live[n] = -5.0 + np.abs(g.normal(0.0, 0.4, live.size))
+                elif where == "upper":
+                    live[n] = 5.0 - np.abs(g.normal(0.0, 0.5, live.size))
+                else:
+                    live[n] = g.normal(0.5, 0.2, live.size)
         prop.check_state(live)
         oprop.update_rescaling(live)
         z = g.normal(size=(4000, dims)).astype(np.float32).astype(np.float64) * float(g.choice([0.8, 1.2]))
