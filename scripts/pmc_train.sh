@@ -20,7 +20,7 @@ acc = collections.defaultdict(list)
 for path in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(path, newline="")):
         k = r["Kernel_Name"]
-        if "trf_forward" in k or "trf_backward" in k:
+        if "trf_forward" in k or "trf_backward" in k or "trf2_forward" in k or "trf2_backward" in k:
             acc[("fwd" if "forward" in k else "bwd", r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as f:
     for k in sorted(acc):
