@@ -28,7 +28,7 @@ extern "C" {
 #define NSA_E_HIP (-2)       /* HIP runtime error */
 #define NSA_E_IMAGE (-3)     /* malformed flow image */
 
-#define NSA_HEADER_WORDS 32
+#define NSA_HEADER_WORDS 40
 
 #define NSA_API __attribute__((visibility("default")))
 
@@ -55,6 +55,14 @@ NSA_API void nsa_last_geometry(int* waves_per_simd, int* waves_per_group, int* g
  * candidate geometry of big split-bf16 batches: one 8-wave workgroup per CU, every weight operand
  * read from LDS feeding both tiles). */
 NSA_API int nsa_last_row_tiles(void);
+
+/* 1 if that launch ran in the weights-resident geometry: the whole program of the direction (every
+ * stage blob of the flow image) copied to LDS once per workgroup, one workgroup of up to 16 waves per
+ * CU, no stage copy, wait or barrier in the tile loop.  Chosen by the library whenever the program fits
+ * in LDS beside the x tiles (the reference's default RealNVP, flows/realnvp.py:76-214: ~98 KB); the rows
+ * are those of the staged geometries bit for bit.  NESSAI_AMD_RESIDENT=0 switches it off.  No reference
+ * counterpart. */
+NSA_API int nsa_last_resident(void);
 
 /* Run a whole flow over n rows.
  *

@@ -35,13 +35,14 @@ static int nsa_fail(int code, const char* fmt, ...) {
 
 extern "C" const char* nsa_last_error(void) { return g_err; }
 
-static thread_local int g_last_geometry[4] = {0, 0, 0, 0};
+static thread_local int g_last_geometry[5] = {0, 0, 0, 0, 0};
 extern "C" void nsa_last_geometry(int* waves_per_simd, int* waves_per_group, int* groups) {
   if (waves_per_simd != nullptr) *waves_per_simd = g_last_geometry[0];
   if (waves_per_group != nullptr) *waves_per_group = g_last_geometry[1];
   if (groups != nullptr) *groups = g_last_geometry[2];
 }
 extern "C" int nsa_last_row_tiles(void) { return g_last_geometry[3]; }
+extern "C" int nsa_last_resident(void) { return g_last_geometry[4]; }
 extern "C" int nsa_version(void) { return NSA_VERSION; }
 
 // ---------------------------------------------------------------------------
@@ -265,6 +266,63 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   const int D = (int)h[NSA_H_D];
   const int XS = (D + 1) | 1;
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
+  // Weights-resident geometry (NsaResidentPipe, nsa_flow_kernel.h): the direction's whole program in LDS, ONE
+  // workgroup per CU, no barrier in the tile loop.  Taken whenever the program fits beside the x tiles of a
+  // useful number of waves; NESSAI_AMD_RESIDENT=0 switches it off (the staged geometries, which give the same
+  // rows bit for bit: tests/test_gpu_row_tiles.py), NESSAI_AMD_RESIDENT="<waves per SIMD>x<tiles per wave>"
+  // pins one of the built candidates.
+  const bool inv = p.direction == NSA_DIR_INVERSE;
+  const size_t res_bytes = (((size_t)h[inv ? NSA_H_RES_INV : NSA_H_RES_FWD] + 255) & ~(size_t)255) * 4;  // whole 1 KiB pieces
+  // + the populate epilogue's per-column constants: 4 double tables and one int table (nsa_flow_kernel.h)
+  const size_t epi_bytes = (p.mode == NSA_MODE_POPULATE) ? (size_t)((D + 3) & ~3) * (4 * 8 + 4) : 0;
+  // + the direction's program (stage table + op table), read from LDS at every stage / op
+  const size_t prog_bytes = (((size_t)2 * h[inv ? NSA_H_NSTAGES_INV : NSA_H_NSTAGES_FWD] +
+                              (size_t)NSA_OP_WORDS * h[inv ? NSA_H_NOPS_INV : NSA_H_NOPS_FWD] + 3) & ~(size_t)3) * 4;
+  // (NESSAI_AMD_OCC pins a STAGED geometry)
+  if (force_occ == 0 && h[NSA_H_HT] <= 2 && res_bytes > 0 && getenv("NESSAI_AMD_OCC") == nullptr) {
+    const char* env = getenv("NESSAI_AMD_RESIDENT");
+    int pin_occ = 0, pin_rt = 0;
+    bool on = true;
+    if (env != nullptr && env[0] == '0') on = false;
+    else if (env != nullptr && env[0] >= '2' && env[0] <= '4' && env[1] == 'x' && (env[2] == '1' || env[2] == '2')) {
+      pin_occ = env[0] - '0';
+      pin_rt = env[2] - '0';
+    }
+    const size_t fixed = res_bytes + epi_bytes + prog_bytes;
+    auto res_lds = [&](int w, int r) { return ((((size_t)w * r * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + fixed; };
+    // candidates in the order of their measured time per row on big batches (profiles/r04_resident_geometries.jsonl)
+    static const int cand[5][2] = {{3, 2}, {4, 1}, {2, 2}, {3, 1}, {2, 1}};
+    for (int c = 0; c < 5 && on; ++c) {
+      int o = cand[c][0], r = cand[c][1];
+      if (pin_occ != 0 && (o != pin_occ || r != pin_rt)) continue;
+      int w = waves_per_group > 0 ? waves_per_group : 4 * o;
+      if (w > 4 * o) w = 4 * o;
+      if (waves_per_group <= 0 && pin_occ == 0) {
+        // batches that do not fill the chip: one tile per wave, fewer waves per workgroup, more CUs
+        if (r == 2 && n_tiles * n_flows < (long long)w * r * g_num_cus) continue;
+        while (w > 1 && n_tiles * n_flows < (long long)w * r * g_num_cus) w >>= 1;
+      }
+      if (res_lds(w, r) > g_max_lds) continue;
+      p.resident = 1;
+      p.occupancy = o;
+      p.row_tiles = r;
+      p.skew = 0;
+      const long long n_groups = (n_tiles + (long long)w * r - 1) / ((long long)w * r);
+      long long grid = (g_num_cus + n_flows - 1) / n_flows;
+      if (max_groups > 0 && grid > max_groups) grid = max_groups;
+      if (grid > n_groups) grid = n_groups;
+      hipError_t e = fn(&p, (unsigned)grid, (unsigned)n_flows, (unsigned)(w * 64), res_lds(w, r), stream);
+      if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "flow kernel launch (resident): %s", hipGetErrorString(e));
+      g_last_geometry[0] = o;
+      g_last_geometry[3] = r;
+      g_last_geometry[1] = w;
+      g_last_geometry[2] = (int)grid;
+      g_last_geometry[4] = 1;
+      return NSA_OK;
+    }
+  }
+  p.resident = 0;
+  g_last_geometry[4] = 0;
   int occ = force_occ != 0 ? force_occ
                            : nsa_occupancy((int)h[NSA_H_HT], p.precision, n_tiles, n_flows, g_num_cus, waves_per_group);
   if (force_occ == 0 && occ == 3 && waves_per_group <= 0 && getenv("NESSAI_AMD_OCC") == nullptr)
@@ -275,12 +333,6 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     occ = 2;
   }
   const size_t stage_bytes = 2 * (size_t)h[NSA_H_MAX_STAGE] * 4;
-  // + the populate epilogue's per-column constants: 4 double tables and one int table (nsa_flow_kernel.h)
-  const size_t epi_bytes = (p.mode == NSA_MODE_POPULATE) ? (size_t)((D + 3) & ~3) * (4 * 8 + 4) : 0;
-  // + the direction's program (stage table + op table), read from LDS at every stage / op
-  const bool inv = p.direction == NSA_DIR_INVERSE;
-  const size_t prog_bytes = (((size_t)2 * h[inv ? NSA_H_NSTAGES_INV : NSA_H_NSTAGES_FWD] +
-                              (size_t)NSA_OP_WORDS * h[inv ? NSA_H_NOPS_INV : NSA_H_NOPS_FWD] + 3) & ~(size_t)3) * 4;
   auto lds_of = [&](int w) {
     return ((((size_t)w * rt * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + stage_bytes + epi_bytes + prog_bytes;
   };

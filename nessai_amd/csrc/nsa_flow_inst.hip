@@ -7,6 +7,9 @@
 #if !defined(NSA_HT) || !defined(NSA_TKIND) || !defined(NSA_BINS)
 #error "NSA_HT, NSA_TKIND and NSA_BINS must be defined"
 #endif
+#ifndef NSA_RES_GEOMETRIES
+#define NSA_RES_GEOMETRIES NSA_RES_GEO(3, 1) NSA_RES_GEO(4, 1) NSA_RES_GEO(2, 2) NSA_RES_GEO(3, 2)
+#endif
 
 #if NSA_TKIND == 1
 using TP = NsaRQ<NSA_BINS>;
@@ -28,6 +31,21 @@ static auto nsa_pick(bool inv) {
   return inv ? nsa_flow_kernel<NSA_HT, TP, true, PREC, OCC, RT> : nsa_flow_kernel<NSA_HT, TP, false, PREC, OCC, RT>;
 }
 
+// weights-resident instances (<= 64-wide conditioners): no barrier in the tile loop, so the geometries go up
+// to 4 waves per SIMD; NSA_RES_GEOMETRIES (Makefile) lists the (waves per SIMD, row tiles) pairs that are built
+#if NSA_HT <= 2
+template <int PREC>
+static auto nsa_pick_res(const NsaLaunch* p, bool inv) {
+  auto kern = inv ? nsa_flow_kernel<NSA_HT, TP, true, PREC, 2, 1, true> : nsa_flow_kernel<NSA_HT, TP, false, PREC, 2, 1, true>;
+#define NSA_RES_GEO(occ, rt)                          \
+  if (p->occupancy == occ && p->row_tiles == rt)      \
+    kern = inv ? nsa_flow_kernel<NSA_HT, TP, true, PREC, occ, rt, true> : nsa_flow_kernel<NSA_HT, TP, false, PREC, occ, rt, true>;
+  NSA_RES_GEOMETRIES
+#undef NSA_RES_GEO
+  return kern;
+}
+#endif
+
 // the split 16-bit modes share their geometries
 template <int PREC>
 static auto nsa_pick16(const NsaLaunch* p, bool inv) {
@@ -46,6 +64,13 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t NSA_LAUNCH_NAME(
     const NsaLaunch* p, unsigned grid, unsigned grid_y, unsigned block, size_t lds, hipStream_t stream) {
   const bool inv = p->direction == NSA_DIR_INVERSE;
   auto kern = nsa_pick<NSA_PREC_F32, 2, 1>(inv);
+#if NSA_HT <= 2
+  if (p->resident) {
+    kern = nsa_pick_res<NSA_PREC_F32>(p, inv);
+    if (p->precision == NSA_PREC_BF16X3) kern = nsa_pick_res<NSA_PREC_BF16X3>(p, inv);
+    else if (p->precision == NSA_PREC_F16X3) kern = nsa_pick_res<NSA_PREC_F16X3>(p, inv);
+  } else
+#endif
   if (p->precision == NSA_PREC_BF16X3) kern = nsa_pick16<NSA_PREC_BF16X3>(p, inv);
   else if (p->precision == NSA_PREC_F16X3) kern = nsa_pick16<NSA_PREC_F16X3>(p, inv);
 #if NSA_HT <= 2

@@ -26,6 +26,7 @@
 // straight from the MFMA accumulators (the host permutes the rows of the last
 // layer so that every lane receives complete parameter sets).
 #pragma once
+#include <type_traits>
 #include <utility>
 
 #include "nsa_device.h"
@@ -145,6 +146,9 @@ struct NsaLaunch {
   // the two-tiles instances: which waves cross the stage barriers between a stage's MFMAs and its vector
   // part (NsaStagePipe::skew): 0 none, 1 the upper half of the workgroup's waves, 2 every other wave
   int skew;
+  // weights-resident geometry (NsaResidentPipe; host-side selector of the RES instances): the whole program
+  // of the direction in LDS, `occupancy` 2 / 3 / 4 waves per SIMD in ONE workgroup per CU
+  int resident;
 #ifdef NSA_TIMELINE
   unsigned long long* dbg;
 #endif
@@ -238,7 +242,7 @@ struct NsaStagePipe {
   __device__ __forceinline__ void issue(uint32_t off, uint32_t words, float* dst, int part, int parts) {
     if ((NSA_ABLATE & 1) && cur >= 0) return;
     const uint32_t* src = img + off;
-    const int pieces = (int)(words >> 8);
+    const int pieces = (int)((words + 255) >> 8);  // the last piece may run over the stage's end (nsa_format.h)
     for (int c = wave + part * nw; c < pieces; c += parts * nw) nsa_glds16(src + c * 256 + lane * 4, dst + c * 256);
   }
   __device__ __forceinline__ void load_entry(int s) {
@@ -310,6 +314,59 @@ struct NsaStagePipe {
   template <bool SKEW>
   __device__ __forceinline__ void end_v() {
     if constexpr (!SKEW) end();
+  }
+};
+
+// Weights-resident pipe (template parameter RES of the kernel): every stage blob of the direction's
+// program was copied to LDS once, in the kernel's prologue, and stays there for the life of the
+// workgroup.  begin() is an address, end() a counter: no copy, no wait and no barrier in the tile loop,
+// so the waves of a workgroup drift apart and one wave's matrix phase runs under another wave's vector
+// phase by itself.  For flows whose packed program fits beside the x tiles (the reference's default
+// RealNVP: ~98 KB of split-f16 stages; small spline flows) - nsa_launch_flow decides.
+struct NsaResidentPipe {
+  const uint32_t* table;  // {src word offset, n words} per stage (the workgroup's LDS copy)
+  const float* base;      // LDS address of stage 0
+  uint32_t off0;          // image word offset of stage 0
+  int n_stages;
+  int cur;
+  uint32_t cur_rel, nxt_rel;  // word offsets of stage `cur` / the stage after it, relative to stage 0
+  bool nan_seen;
+  u16x2 amax;
+  bool skew;  // never set: there is no barrier to cross early
+  template <int PREC, int RT, int OT>
+  __device__ __forceinline__ void watch(const f32x16 (&acc)[RT][OT]) {
+    if constexpr (PREC == NSA_PREC_F16X3 && NSA_F16_DETECT == 1) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) nan_seen |= acc[t][0][0] != acc[t][0][0];
+    }
+  }
+#ifdef NSA_TIMELINE
+  NsaTl tl;
+#endif
+  __device__ __forceinline__ uint32_t rel_of(int s) const {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(table[2 * s] - off0));
+  }
+  __device__ __forceinline__ void prime() {
+    cur = 0;
+    cur_rel = 0;
+    nxt_rel = rel_of(n_stages > 1 ? 1 : 0);
+  }
+  template <bool SKEW = false>
+  __device__ __forceinline__ const float* begin() {
+    return base + cur_rel;
+  }
+  __device__ __forceinline__ void more() {}
+  // the offset of the stage after next is read a whole stage before it is needed
+  __device__ __forceinline__ void end() {
+    cur = (cur + 1 == n_stages) ? 0 : cur + 1;
+    cur_rel = nxt_rel;
+    nxt_rel = rel_of((cur + 1 == n_stages) ? 0 : cur + 1);
+  }
+  template <bool SKEW>
+  __device__ __forceinline__ void end_m() {}
+  template <bool SKEW>
+  __device__ __forceinline__ void end_v() {
+    end();
   }
 };
 
@@ -551,8 +608,8 @@ __device__ __forceinline__ void nsa_run_phases(typename TP::State (&st)[TP::FPC]
 
 // MFMAs of sub-stage J of one chunk of the last conditioner layer (-> acc; cols and the bias come
 // with sub-stage 0).
-template <int HT, class TP, int PREC, int J, int RT>
-__device__ __forceinline__ void nsa_chunk_gemm([[maybe_unused]] NsaStagePipe& pipe, const float* stg,
+template <int HT, class TP, int PREC, int J, int RT, class PIPE>
+__device__ __forceinline__ void nsa_chunk_gemm([[maybe_unused]] PIPE& pipe, const float* stg,
                                                const float (&h)[RT][16 * HT], const NsaSplit<HT> (&hs)[RT],
                                                int lane, int half, f32x16 (&acc)[RT][TP::C],
                                                int (&cols)[TP::FPC]) {
@@ -578,8 +635,8 @@ __device__ __forceinline__ void nsa_chunk_gemm([[maybe_unused]] NsaStagePipe& pi
 
 // one coupling layer (over the RT row tiles of the wave) ---------------------------
 
-template <int HT, class TP, bool INV, int PREC, int RT, bool SKEW = false>
-__device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t* op, float* const (&xrow)[RT],
+template <int HT, class TP, bool INV, int PREC, int RT, bool SKEW = false, class PIPE>
+__device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, float* const (&xrow)[RT],
                                              int dummy_col, int lane, int half, int act, int net,
                                              int n_layers, const NsaTransformConsts& tc,
                                              float (&logdet)[RT], int (&n_bad)[RT]) {
@@ -740,14 +797,14 @@ __device__ __forceinline__ void nsa_coupling(NsaStagePipe& pipe, const uint32_t*
 
 // dense (LU-linear, eval-mode cached weight) -----------------------------------
 // y = W (x - pre) + bias over all D features; D <= 64.
-template <int PREC, int RT>
-__device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t* op, float* const (&xrow)[RT],
+template <int PREC, int RT, class PIPE>
+__device__ __forceinline__ void nsa_dense_op(PIPE& pipe, const uint32_t* op, float* const (&xrow)[RT],
                                              int D, int lane, int half, float (&logdet)[RT]) {
   constexpr bool BF = (PREC != NSA_PREC_F32);  // split 16-bit operands (bf16 or f16 pairs)
   const int n_steps = __builtin_amdgcn_readfirstlane((int)op[1]);
   const int n_ot = __builtin_amdgcn_readfirstlane((int)op[2]);
   const int tab_len = (BF ? 16 : 2) * n_steps;
-  const float* st = pipe.begin();
+  const float* st = pipe.template begin<false>();
   const int* in_tab = (const int*)st;
   const float* pre = st + tab_len;
   const float* bias = pre + tab_len;
@@ -790,11 +847,11 @@ __device__ __forceinline__ void nsa_dense_op(NsaStagePipe& pipe, const uint32_t*
 }
 
 // per-column ((x - a) / b) * c + d (batch norm / act norm in eval mode) ----------
-template <int RT>
-__device__ __forceinline__ void nsa_elementwise_op(NsaStagePipe& pipe, const uint32_t* op,
+template <int RT, class PIPE>
+__device__ __forceinline__ void nsa_elementwise_op(PIPE& pipe, const uint32_t* op,
                                                    float* const (&xrow)[RT], int D, int half, float (&logdet)[RT]) {
 #pragma clang fp contract(off)
-  const float* st = pipe.begin();
+  const float* st = pipe.template begin<false>();
   const int D4 = (D + 3) & ~3;
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
@@ -821,9 +878,13 @@ __device__ __forceinline__ int nsa_opaque(int v) {
 // RT = 32-row tiles per wave: the tiles of a wave go through every layer together, so that one read of a
 // weight operand from LDS feeds RT x 3 MFMAs, a stage is copied and a barrier crossed once per RT x NW
 // tiles, and the wave always has RT independent accumulator chains and element-wise chains to issue from.
-template <int HT, class TP, bool INV, int PREC, int OCC, int RT = 1>
-__global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(NsaLaunch p) {
-  constexpr bool SK = RT == 2;  // the two-tiles instances carry the skewed copy of the coupling code
+// RES = weights resident in LDS (NsaResidentPipe): one workgroup per CU of up to 16 waves (OCC 4: <= 128
+// VGPRs), no barrier after the prologue.
+template <int HT, class TP, bool INV, int PREC, int OCC, int RT = 1, bool RES = false>
+__global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC) nsa_flow_kernel(NsaLaunch p) {
+  // the staged two-tiles instances carry the skewed copy of the coupling code
+  constexpr bool SK = RT == 2 && !RES;
+  using PIPE = std::conditional_t<RES, NsaResidentPipe, NsaStagePipe>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (p.stop != nullptr && (p.stop[0] >= p.stop[2] || p.stop[1] >= p.stop[5])) return;
   if (p.image_list != nullptr) {
@@ -851,21 +912,26 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
     xrow_a[t] = xt_a[t] + j * XS;
   }
 
-  NsaStagePipe pipe;
-  pipe.img = img;
+  PIPE pipe;
   pipe.n_stages = (int)(inverse ? img[NSA_H_NSTAGES_INV] : img[NSA_H_NSTAGES_FWD]);
-  pipe.buf0 = smem + tiles_words;
-  pipe.buf1 = pipe.buf0 + max_stage;
+  // stage area: two buffers of the largest stage, or (RES) every stage of the direction's program
+  float* const stage_area = smem + tiles_words;
+  const int stage_words = RES ? (((int)(inverse ? img[NSA_H_RES_INV] : img[NSA_H_RES_FWD]) + 255) & ~255) : 2 * max_stage;
+  if constexpr (!RES) {
+    pipe.img = img;
+    pipe.buf0 = stage_area;
+    pipe.buf1 = stage_area + max_stage;
+  }
   const int n_ops = (int)(inverse ? img[NSA_H_NOPS_INV] : img[NSA_H_NOPS_FWD]);
   // POPULATE: the per-column constants of the epilogue (z-score sigma / mu, prior bounds, output
   // column table) live in LDS behind the stage buffers - the epilogue reads them per feature, and
   // from global memory every read was a separate exposed round trip
   const int D4e = (D + 3) & ~3;
-  double* epi = (double*)(pipe.buf1 + max_stage);  // [4][D4e] doubles + [D4e] ints (populate only)
+  double* epi = (double*)(stage_area + stage_words);  // [4][D4e] doubles + [D4e] ints (populate only)
   // The program of this direction - stage table {offset, words} and op table - also lives in LDS
   // (NSA_PROG_WORDS): both are read at every stage / op, the loop's global stores make the compiler
   // fetch them with vector loads, and each was an exposed L2 round trip in front of the stage's copy.
-  uint32_t* prog = (uint32_t*)(pipe.buf1 + max_stage) + (p.mode == NSA_MODE_POPULATE ? 9 * D4e : 0);
+  uint32_t* prog = (uint32_t*)(stage_area + stage_words) + (p.mode == NSA_MODE_POPULATE ? 9 * D4e : 0);
   uint32_t* prog_ops = prog + 2 * pipe.n_stages;
   {
     const uint32_t* gtab = img + (inverse ? img[NSA_H_STAGES_INV] : img[NSA_H_STAGES_FWD]);
@@ -885,13 +951,27 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
       epi_tab[i] = otab[i];
     }
   }
+  if constexpr (RES) {
+    // the whole program -> LDS, 1 KiB pieces dealt round the waves; the barrier below is the LAST one
+    if (pipe.n_stages > 0) {
+      const uint32_t off0 = (inverse ? img + img[NSA_H_STAGES_INV] : img + img[NSA_H_STAGES_FWD])[0];
+      pipe.off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)off0);
+      pipe.base = stage_area;
+      const int pieces = (stage_words + 255) >> 8;
+      for (int c = wave; c < pieces; c += nw) nsa_glds16(img + pipe.off0 + c * 256 + lane * 4, stage_area + c * 256);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    pipe.skew = false;
+  }
   __syncthreads();
-  pipe.wave = wave;
-  pipe.nw = nw;
-  pipe.lane = lane;
-  pipe.issued = false;
-  // p.skew: 1 = the upper half of the workgroup's waves, 2 = every other wave
-  pipe.skew = SK && (p.skew == 1 ? (wave >= (nw >> 1)) : (p.skew == 2 ? (wave & 1) != 0 : false));
+  if constexpr (!RES) {
+    pipe.wave = wave;
+    pipe.nw = nw;
+    pipe.lane = lane;
+    pipe.issued = false;
+    // p.skew: 1 = the upper half of the workgroup's waves, 2 = every other wave
+    pipe.skew = SK && (p.skew == 1 ? (wave >= (nw >> 1)) : (p.skew == 2 ? (wave & 1) != 0 : false));
+  }
 
   const uint32_t* ops = prog_ops;
   const int* out_tab = (const int*)(img + (inverse ? img[NSA_H_OUT_INV] : img[NSA_H_OUT_FWD]));
@@ -1034,10 +1114,14 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
       const uint32_t* op = ops + o * NSA_OP_WORDS;
       const int kind = __builtin_amdgcn_readfirstlane((int)op[0]);
       if (kind == NSA_OP_COUPLING) {
-        if (SK && pipe.skew)
-          nsa_coupling<HT, TP, INV, PREC, RT, SK>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
-        else
+        if constexpr (SK) {
+          if (pipe.skew)
+            nsa_coupling<HT, TP, INV, PREC, RT, true>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
+          else
+            nsa_coupling<HT, TP, INV, PREC, RT, false>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
+        } else {
           nsa_coupling<HT, TP, INV, PREC, RT, false>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
+        }
       } else if (kind == NSA_OP_DENSE) {
         nsa_dense_op<PREC, RT>(pipe, op, xrow_a, D, lane, half, logdet_a);
       } else {
@@ -1224,7 +1308,7 @@ __global__ void __launch_bounds__(OCC == 3 ? 768 : 512, OCC) nsa_flow_kernel(Nsa
     NSA_TL(pipe, 9);
   }
   // drain the wrap-around prefetch before the workgroup exits
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (!RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef NSA_TIMELINE
   if (p.dbg != nullptr && lane == 0) {
     for (int i = 0; i < 14; ++i) atomicAdd(p.dbg + i, pipe.tl.acc[i]);

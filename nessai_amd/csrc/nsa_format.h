@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define NSA_MAGIC 0x3141534e /* "NSA1" */
-#define NSA_VERSION 6
+#define NSA_VERSION 7
 
 // header word indices
 enum {
@@ -32,7 +32,7 @@ enum {
   NSA_H_STAGES_FWD = 11,   // word offset, 2 words per stage: {src word offset, n words}
   NSA_H_NSTAGES_INV = 12,
   NSA_H_STAGES_INV = 13,
-  NSA_H_MAX_STAGE = 14,    // words, multiple of 256
+  NSA_H_MAX_STAGE = 14,    // words of the largest stage, rounded up to a multiple of 256
   NSA_H_TOTAL = 15,        // total words
   NSA_H_OUT_FWD = 16,      // word offset: D ints, physical column of logical output i
   NSA_H_OUT_INV = 17,
@@ -50,7 +50,11 @@ enum {
   NSA_H_PREC = 29,         // NSA_PREC_*: arithmetic of the conditioner GEMMs
   NSA_H_AFF_A = 30,        // float: affine coupling scale = sigmoid(raw + a) + b (default 2)
   NSA_H_AFF_B = 31,        // float: ... b (default 1e-3)
-  NSA_H_WORDS = 32
+  NSA_H_RES_FWD = 32,      // words of ALL stage blobs of the forward program, which lie back to back in stage
+                           // order from stage 0's offset on (the weights-resident geometry copies that range
+                           // to LDS once per workgroup); 0 = not contiguous, staged geometries only
+  NSA_H_RES_INV = 33,      // the same for the inverse program
+  NSA_H_WORDS = 40
 };
 
 enum { NSA_T_NONE = 0, NSA_T_RQ = 1, NSA_T_AFFINE = 2, NSA_T_ADDITIVE = 3 };
@@ -74,7 +78,9 @@ enum { NSA_PREC_F32 = 0, NSA_PREC_BF16X3 = 1, NSA_PREC_F16X3 = 2 };
 #define NSA_OP_WORDS 4
 
 // Stage blob layouts (word offsets inside the blob; every section is padded
-// to a multiple of 4 words, every blob to a multiple of 256 words):
+// to a multiple of 4 words, every blob to a multiple of 32 words = one 128-byte line; the copies move
+// 1 KiB pieces, so the last piece of a stage runs over into the next blob - or into the 1 KiB of slack
+// behind the last one - and over the stage's end in an LDS buffer that is sized in whole pieces):
 //   coupling layer 0 : id_tab[2*n_steps0] | bias[32*HT] | W[HT][n_steps0/4][64][4]
 //   hidden layer     : bias[32*HT]        | W[HT][4*HT/KS][64][4]      (sub-stage 0 of KS; the others: W only)
 //   final chunk      : tr_tab[pad4(2*FPC)] | bias[32*C] | W[C][4*HT/KS][64][4]   (likewise)

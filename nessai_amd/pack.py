@@ -31,8 +31,10 @@ import math
 import numpy as np
 
 MAGIC = 0x3141534E
-VERSION = 6
-HEADER_WORDS = 32
+VERSION = 7
+HEADER_WORDS = 40
+STAGE_ALIGN = 32   # words: stage blobs are padded to whole 128-byte lines
+PIECE_WORDS = 256  # words moved by one global_load_lds of a wave (64 lanes x 16 bytes)
 OP_WORDS = 4
 
 H_MAGIC, H_VERSION, H_D, H_HT, H_TRANSFORM, H_BINS = 0, 1, 2, 3, 4, 5
@@ -41,6 +43,7 @@ H_NSTAGES_FWD, H_STAGES_FWD, H_NSTAGES_INV, H_STAGES_INV = 10, 11, 12, 13
 H_MAX_STAGE, H_TOTAL, H_OUT_FWD, H_OUT_INV = 14, 15, 16, 17
 H_LOG_Z, H_TAIL_BOUND, H_MIN_BW, H_MIN_BH, H_MIN_D, H_EDGE_RAW = 18, 19, 20, 21, 22, 23
 H_LOGIT_DIV, H_ACT, H_NET, H_NLAYERS, H_BASE_INV_VAR, H_PREC, H_AFF_A, H_AFF_B = 24, 25, 26, 27, 28, 29, 30, 31
+H_RES_FWD, H_RES_INV = 32, 33
 
 T_NONE, T_RQ, T_AFFINE, T_ADDITIVE = 0, 1, 2, 3
 TRANSFORMS = {"rq": T_RQ, "affine": T_AFFINE, "additive": T_ADDITIVE}
@@ -253,7 +256,12 @@ def _plain_out_rows(n_tiles, limit):
 
 
 def _stage(*sections):
-    """Concatenate sections (each padded to 4 words) and pad to 256 words."""
+    """Concatenate sections (each padded to 4 words) and pad to STAGE_ALIGN words.
+
+    (Format 7: 32 words = one 128-byte line.  The copies still move 1 KiB pieces - the last piece of a
+    stage runs over into the next blob / the image's tail slack and over the end of the stage in LDS,
+    inside a buffer that is sized in whole pieces - but a blob no longer carries up to 1 KiB of padding,
+    which is a quarter of the reference's default RealNVP when its whole program is kept in LDS.)"""
     parts = []
     for sec in sections:
         sec = np.ascontiguousarray(sec)
@@ -270,7 +278,7 @@ def _stage(*sections):
         if pad:
             parts.append(np.zeros(pad, dtype=np.uint32))
     blob = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32)
-    pad = (-len(blob)) % 256
+    pad = (-len(blob)) % STAGE_ALIGN
     if pad:
         blob = np.concatenate([blob, np.zeros(pad, dtype=np.uint32)])
     return blob
@@ -517,8 +525,10 @@ def pack_flow(desc):
     for i, blob in enumerate(blobs):
         blob_offsets[i] = pos
         pos += len(blob)
+    pos += PIECE_WORDS  # slack: the last 1 KiB piece of the last stage reads past its end
     total = pos
-    max_stage = max(len(b) for b in blobs) if blobs else 256
+    max_stage = max(len(b) for b in blobs) if blobs else PIECE_WORDS
+    max_stage = (max_stage + PIECE_WORDS - 1) // PIECE_WORDS * PIECE_WORDS  # LDS stage buffers: whole pieces
 
     img = np.zeros(total, dtype=np.uint32)
     img[H_MAGIC] = MAGIC
@@ -564,6 +574,17 @@ def pack_flow(desc):
     for k, bid in enumerate(stages_inv):
         img[off_st_inv + 2 * k] = blob_offsets[bid]
         img[off_st_inv + 2 * k + 1] = len(blobs[bid])
+    # the stage blobs of a direction lie back to back in stage order: the weights-resident geometry of the
+    # kernel copies that whole range into LDS once per workgroup (0 = not contiguous, never resident)
+    for word, stage_ids in ((H_RES_FWD, stages_fwd), (H_RES_INV, stages_inv)):
+        span, expect = 0, blob_offsets[stage_ids[0]] if stage_ids else 0
+        for bid in stage_ids:
+            if blob_offsets[bid] != expect:
+                span = 0
+                break
+            span += len(blobs[bid])
+            expect += len(blobs[bid])
+        img[word] = span
     img[off_out_fwd : off_out_fwd + D] = out_fwd.view(np.uint32)
     img[off_out_inv : off_out_inv + D] = out_inv.view(np.uint32)
     for i, blob in enumerate(blobs):

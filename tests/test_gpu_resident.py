@@ -1,0 +1,128 @@
+"""The weights-resident launch geometry (csrc/nsa_flow_kernel.h: NsaResidentPipe, template parameter RES;
+csrc/nsa_api.hip: chosen whenever the direction's whole program fits in LDS beside the x tiles) copies
+every stage blob of the flow image to LDS once per workgroup and runs the tile loop without a stage copy,
+a wait or a barrier.  It must give the rows of the staged geometries BIT FOR BIT - same per-row
+arithmetic, same order, only the waves are no longer in lock step - in every candidate shape
+(waves per SIMD x row tiles per wave), at ragged sizes, in all three precisions, through the bare flow
+calls and through the fused populate pass with its on-chip latent draw; and it is compared with the ORACLE
+directly (the reference semantics: src/nessai/flows/realnvp.py:76-214, flows/nsf.py:60-130 via
+oracle/nflows_restated).  Runs on a real MI355X."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import DEV, make_pair, rel_err
+from nessai_amd import lib
+from test_gpu_flows import BF16X3_WITHIN_BAR, CONFIGS, LOG_PROB_RTOL
+
+pytestmark = pytest.mark.gpu
+
+# flows whose packed program fits in the 160 KB of LDS of a CU (everything else stays staged)
+RESIDENT = [n for n in CONFIGS if n not in ("nsf_c3", "nsf_c5_d15", "nsf_c4_d64")]
+SHAPES = ["3x2", "4x1", "2x2", "3x1", "2x1"]
+
+
+def geometry():
+    v = [ctypes.c_int(0) for _ in range(3)]
+    L = lib.load()
+    L.nsa_last_geometry(*[ctypes.addressof(x) for x in v])
+    return v[0].value, v[1].value, int(L.nsa_last_row_tiles()), int(L.nsa_last_resident())
+
+
+def run_all(flow, x):
+    with torch.no_grad():
+        lp = flow.log_prob(x)
+        geo = geometry()
+        z, ld = flow.forward(x)
+        xi, ldi = flow.inverse(x)
+    torch.cuda.synchronize()
+    return geo, [t.clone() for t in (lp, z, ld, xi, ldi)]
+
+
+def same(a, b):
+    return torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0))
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("name", RESIDENT)
+def test_resident_is_the_default_for_flows_that_fit_and_matches_the_oracle(name, precision, monkeypatch):
+    monkeypatch.delenv("NESSAI_AMD_RESIDENT", raising=False)
+    monkeypatch.delenv("NESSAI_AMD_OCC", raising=False)
+    P, Oc, args, kw = CONFIGS[name]
+    ref, flow = make_pair(P, Oc, args, kw)
+    flow.precision = precision
+    x = torch.randn(4000, args[0], generator=torch.Generator().manual_seed(11)) * 1.5
+    with torch.no_grad():
+        lp_ref = ref.log_prob(x)
+        xi_ref, ldi_ref = ref.inverse(x)
+    geo, (lp, z, ld, xi, ldi) = run_all(flow, x.to(DEV))
+    assert geo[3] == 1, geo
+    if precision != "bf16x3" or name in BF16X3_WITHIN_BAR:
+        assert rel_err(lp.cpu(), lp_ref, floor=1e-3) <= LOG_PROB_RTOL
+        assert rel_err(xi.cpu(), xi_ref) <= 2e-4 and rel_err(ldi.cpu(), ldi_ref) <= 5e-4
+    else:
+        assert rel_err(lp.cpu(), lp_ref) <= 2e-4
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("name", RESIDENT)
+@pytest.mark.parametrize("n", [1, 33, 65, 1000, 40001])
+def test_resident_rows_equal_staged_rows(name, n, shape, precision, monkeypatch):
+    if precision != "f16x3" and (n not in (33, 40001) or shape not in ("3x2", "4x1")):
+        pytest.skip("the other precisions share the code path: two sizes and two shapes pin their instances")
+    P, Oc, args, kw = CONFIGS[name]
+    _, flow = make_pair(P, Oc, args, kw)
+    flow.precision = precision
+    x = (torch.randn(n, args[0], generator=torch.Generator().manual_seed(n)) * 1.2).to(DEV)
+    monkeypatch.delenv("NESSAI_AMD_OCC", raising=False)
+    monkeypatch.setenv("NESSAI_AMD_RESIDENT", "0")
+    geo_s, staged = run_all(flow, x)
+    monkeypatch.setenv("NESSAI_AMD_RESIDENT", shape)
+    geo_r, resident = run_all(flow, x)
+    assert geo_s[3] == 0 and geo_r[3] == 1, (geo_s, geo_r)
+    assert (geo_r[0], geo_r[2]) == (int(shape[0]), int(shape[2]))
+    for a, b in zip(staged, resident):
+        assert same(a, b)
+
+
+def test_flows_that_do_not_fit_stay_staged(monkeypatch):
+    monkeypatch.delenv("NESSAI_AMD_RESIDENT", raising=False)
+    monkeypatch.delenv("NESSAI_AMD_OCC", raising=False)
+    for name in ("nsf_c3", "nsf_c4_d64"):
+        P, Oc, args, kw = CONFIGS[name]
+        _, flow = make_pair(P, Oc, args, kw)
+        with torch.no_grad():
+            flow.log_prob(torch.randn(500, args[0]).to(DEV))
+        torch.cuda.synchronize()
+        assert geometry()[3] == 0
+
+
+@pytest.mark.parametrize("net", ["resnet", "mlp"])
+@pytest.mark.parametrize("drawsize", [2000, 300_000])
+def test_populate_on_the_resident_geometry_equals_the_staged_one(net, drawsize, monkeypatch, tmp_path):
+    """The fused populate pass (on-chip Philox latents, float64 epilogue) of the reference's default flow
+    (config 2: RealNVP, LU + batch norm) - both loops, the small-passes-in-one-launch one and the big-batch
+    one: pool, order and counters are those of the staged geometry."""
+    from nessai_amd.model import GaussianModel
+    from nessai_amd.proposal import FlowProposal
+
+    pools = {}
+    for mode in ("0", "auto"):
+        if mode == "0":
+            monkeypatch.setenv("NESSAI_AMD_RESIDENT", "0")
+        else:
+            monkeypatch.delenv("NESSAI_AMD_RESIDENT", raising=False)
+        torch.manual_seed(5)
+        prop = FlowProposal(GaussianModel(16), rng=np.random.default_rng(5), poolsize=500, drawsize=drawsize,
+                            flow_config=dict(ftype="realnvp", n_neurons=32, n_blocks=4, n_layers=2, net=net),
+                            output=str(tmp_path), device_seed=5)
+        prop.initialise()
+        prop.populate(None, n_samples=500, max_samples=10**9)
+        pools[mode] = (prop.samples.copy(), prop.n_proposed, prop.n_accepted, geometry()[3])
+    assert pools["0"][3] == 0 and pools["auto"][3] == 1
+    assert pools["0"][1:3] == pools["auto"][1:3]
+    for f in pools["0"][0].dtype.names:
+        assert np.array_equal(pools["0"][0][f], pools["auto"][0][f], equal_nan=True), f

@@ -102,10 +102,17 @@ def test_image_header_and_alignment():
     assert img[P.H_MAX_STAGE] % 256 == 0
     # 6 couplings x (1 + 4 + 4) stages per direction
     assert img[P.H_NSTAGES_FWD] == 54 and img[P.H_NSTAGES_INV] == 54
+    # blobs are padded to whole 128-byte lines and lie back to back; the copies move 1 KiB pieces, so the
+    # last piece of every stage must still lie inside the image (the tail slack) and inside a stage buffer
     tab = int(img[P.H_STAGES_FWD])
+    expect, span = int(img[tab]), 0
     for s in range(54):
         off, n = int(img[tab + 2 * s]), int(img[tab + 2 * s + 1])
-        assert off % 256 == 0 and n % 256 == 0 and off + n <= len(img)
+        assert off % P.STAGE_ALIGN == 0 and n % P.STAGE_ALIGN == 0 and off == expect
+        assert off + (n + 255) // 256 * 256 <= len(img) and (n + 255) // 256 * 256 <= img[P.H_MAX_STAGE]
+        expect, span = off + n, span + n
+    # ... which is what lets the weights-resident geometry copy a direction's whole program in one go
+    assert img[P.H_RES_FWD] == span and img[P.H_RES_INV] == span
 
 
 def test_wide_conditioner_stages_are_split_along_k():
