@@ -302,6 +302,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
         if (r == 2 && n_tiles * n_flows < (long long)w * r * g_num_cus) continue;
         while (w > 1 && n_tiles * n_flows < (long long)w * r * g_num_cus) w >>= 1;
       }
+      while (w > 1 && res_lds(w, r) > g_max_lds) --w;  // fewer waves beside a bigger program
       if (res_lds(w, r) > g_max_lds) continue;
       p.resident = 1;
       p.occupancy = o;

@@ -89,9 +89,13 @@ __device__ __forceinline__ void nsa_split8(const float (&v)[8], nsa_op8& hi, nsa
   for (int q = 0; q < 4; ++q) {
     const f32x2 x = {v[2 * q], v[2 * q + 1]};
     if constexpr (PREC == NSA_PREC_F16X3) {
+      // x - float(hi) as fma(float(hi), -1, x): with the -1 opaque to the optimiser (it would turn the fma
+      // back into cvt + sub: 3 VALU per value) this selects v_fma_mix_f32, which reads the f16 half
+      // directly - cvt_pk, 2 x fma_mix, cvt_pk: 2 VALU per value; the result is the same exact difference
+      float m1 = -1.0f;
+      asm("" : "+s"(m1));
       const f16x2 h = __builtin_convertvector(x, f16x2);
-      const f32x2 hf = __builtin_convertvector(h, f32x2);
-      const f32x2 d = {x[0] - hf[0], x[1] - hf[1]};
+      const f32x2 d = {__builtin_fmaf((float)h[0], m1, x[0]), __builtin_fmaf((float)h[1], m1, x[1])};
       hi[q] = __builtin_bit_cast(uint32_t, h);
       lo[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, f16x2));
 #if NSA_F16_DETECT == 2
@@ -163,14 +167,16 @@ __device__ __forceinline__ float nsa_u01(uint32_t x) {
   return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
 }
 
-// two u32 -> two standard normals
+// two u32 -> two standard normals: r = sqrt(-2 ln u1), angle = u2 revolutions.  On the hardware's
+// transcendental unit - v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in revolutions) - 12
+// instructions where logf + sqrtf + sincospif took ~80 per pair; u1 >= 2^-33 is a normal number, u2 in (0, 1]
+// needs no range reduction.  (A random stream is defined by what the kernel does: oracle/philox.py restates
+// this map in float64 and the tests hold the device to it within the units' error, a few 1e-6 absolute.)
 __device__ __forceinline__ void nsa_box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
   const float u1 = nsa_u01(a), u2 = nsa_u01(b);
-  const float r = sqrtf(-2.0f * logf(u1));
-  float s, c;
-  sincospif(2.0f * u2, &s, &c);
-  n0 = r * c;
-  n1 = r * s;
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
+  n0 = r * __builtin_amdgcn_cosf(u2);
+  n1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 // ---------------------------------------------------------------------------
@@ -380,12 +386,14 @@ struct NsaAffine {
   __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
                                                const NsaTransformConsts& c, float& y, float& ld,
                                                bool& bad) {
+    // bare v_exp_f32 / v_log_f32 / v_rcp_f32 (<= 1 ulp each; scale lies in (aff_b, 1 + aff_b), a normal
+    // number): 12 instructions per feature where expf / logf / an IEEE division took 28
     const float shift = v[OFF];
     const float raw = v[OFF + 1] + c.aff_a;
-    const float scale = nsa_rcp(1.0f + nsa_exp(-raw)) + c.aff_b;
-    const float ls = nsa_log(scale);
+    const float scale = nsa_rcp(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * raw)) + c.aff_b;
+    const float ls = 0.6931471805599453f * nsa_log2(scale);
     bad = false;
-    if constexpr (INV) { y = (x - shift) / scale; ld = -ls; }
+    if constexpr (INV) { y = (x - shift) * nsa_rcp(scale); ld = -ls; }
     else { y = fmaf(x, scale, shift); ld = ls; }
   }
 };

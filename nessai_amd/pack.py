@@ -372,6 +372,86 @@ class _CouplingBlobs:
         return m
 
 
+def _fold_elementwise(transforms, inverse, D, fold=True):
+    """The transforms of one direction in execution order, as ``("permutation", p)`` (new logical feature i =
+    old logical feature ``p[i]``), ``("dense", M, pre, post, log|det|)`` - ``y = M (x - pre) + post`` on the
+    logical features - ``("elementwise", (a, b, c, d, log|det|))`` and couplings.
+
+    In eval mode a batch norm / act norm (``((x - a) / b) c + d`` per feature) next to an LU-linear layer -
+    only permutations between them, as in every block of the reference's default RealNVP
+    (src/nessai/flows/realnvp.py:186-206: permutation, LU, coupling, batch norm) - is one affine map with it:
+    the per-feature scale and shift are folded into the matrix and the bias on the host (in float64, rounded
+    once), and the kernel runs ONE dense op where it ran a dense op and an element-wise op (the latter: eight
+    IEEE divisions per lane and a stage of its own)."""
+    seq = []
+    for tr in (transforms[::-1] if inverse else transforms):
+        if tr[0] == "permutation":
+            perm = np.asarray(tr[1], dtype=np.int64)
+            seq.append(("permutation", np.argsort(perm) if inverse else perm))
+        elif tr[0] == "lu":
+            _, W, W_inv, bias, logabsdet = tr
+            bias = np.asarray(bias, dtype=np.float32)
+            zero = np.zeros(D, dtype=np.float32)
+            if inverse:
+                seq.append(("dense", np.asarray(W_inv, dtype=np.float32), bias, zero, -np.float32(logabsdet)))
+            else:
+                seq.append(("dense", np.asarray(W, dtype=np.float32), zero, bias, np.float32(logabsdet)))
+        elif tr[0] == "elementwise":
+            seq.append(("elementwise", tr[2] if inverse else tr[1]))
+        else:
+            seq.append(tr)
+    if not fold:
+        return seq
+
+    def neighbour(i, step):
+        """Index of the dense op reached from position i through permutations only, and the composed map
+        ``q`` of those permutations: the feature that is k AFTER them is feature ``q[k]`` BEFORE them."""
+        q = np.arange(D)
+        j = i + step
+        while 0 <= j < len(seq) and seq[j][0] == "permutation":
+            p = seq[j][1]
+            q = q[p] if step > 0 else p[q]
+            j += step
+        if 0 <= j < len(seq) and seq[j][0] == "dense":
+            return j, q
+        return None, None
+
+    i = 0
+    while i < len(seq):
+        if seq[i][0] != "elementwise":
+            i += 1
+            continue
+        a, b, c, d, ld_e = seq[i][1]
+        sc = np.asarray(c, dtype=np.float64) / np.asarray(b, dtype=np.float64)
+        sh = np.asarray(d, dtype=np.float64) - np.asarray(a, dtype=np.float64) * sc
+        j, q = neighbour(i, -1)
+        if j is not None:
+            # dense op first, then (through permutations) the element-wise map: feature k here is output row
+            # q[k] of the dense op   (q composed backwards: logical k now = row q[k] then)
+            _, M, pre, post, ld = seq[j]
+            row_s, row_t = np.empty(D), np.empty(D)
+            row_s[q], row_t[q] = sc, sh
+            M2 = row_s[:, None] * M.astype(np.float64)
+            post2 = row_s * post.astype(np.float64) + row_t
+            seq[j] = ("dense", M2.astype(np.float32), pre, post2.astype(np.float32), np.float32(np.float32(ld) + np.float32(ld_e)))
+            del seq[i]
+            continue
+        j, q = neighbour(i, +1)
+        if j is not None:
+            # element-wise map first: input k of the dense op is feature q[k] here
+            _, M, pre, post, ld = seq[j]
+            col_s, col_t = sc[q], sh[q]
+            M64 = M.astype(np.float64)
+            M2 = M64 * col_s[None, :]
+            post2 = M64 @ (col_t - pre.astype(np.float64)) + post.astype(np.float64)
+            seq[j] = ("dense", M2.astype(np.float32), np.zeros(D, dtype=np.float32), post2.astype(np.float32),
+                      np.float32(np.float32(ld) + np.float32(ld_e)))
+            del seq[i]
+            continue
+        i += 1
+    return seq
+
+
 def pack_flow(desc):
     """Return the flow image as a ``numpy.uint32`` array."""
     D = int(desc["D"])
@@ -404,18 +484,14 @@ def pack_flow(desc):
         cur = list(range(D))  # physical column of logical feature i
         ops = []
         stages = []
-        seq = list(desc["transforms"])
-        if inverse:
-            seq = seq[::-1]
+        seq = _fold_elementwise(list(desc["transforms"]), inverse, D, desc.get("fold_elementwise", True))
         for tr in seq:
             kind = tr[0]
             if kind == "permutation":
                 perm = np.asarray(tr[1], dtype=np.int64)
-                if inverse:
-                    perm = np.argsort(perm)
                 cur = [cur[int(perm[i])] for i in range(D)]
-            elif kind == "lu":
-                _, W, W_inv, bias, logabsdet = tr
+            elif kind == "dense":
+                _, mat, pre_v, post_v, ld = tr
                 if D > 64:
                     raise ValueError("LU-linear transforms support at most 64 features")
                 n_ot = (D + 31) // 32
@@ -431,15 +507,10 @@ def pack_flow(desc):
                 pre = np.zeros(tab_len, dtype=np.float32)
                 for k in range(D):
                     in_tab[k] = cur[k]
-                if inverse:
-                    mat = np.asarray(W_inv, dtype=np.float32)
-                    pre[:D] = np.asarray(bias, dtype=np.float32)
-                    post = np.zeros(D, dtype=np.float32)
-                    ld = -np.float32(logabsdet)
-                else:
-                    mat = np.asarray(W, dtype=np.float32)
-                    post = np.asarray(bias, dtype=np.float32)
-                    ld = np.float32(logabsdet)
+                mat = np.asarray(mat, dtype=np.float32)
+                pre[:D] = np.asarray(pre_v, dtype=np.float32)
+                post = np.asarray(post_v, dtype=np.float32)
+                ld = np.float32(ld)
                 out_rows = _plain_out_rows(n_ot, D)
                 pack_w = _pack_matrix16(precision, desc.get("_split16")) if bf16 else pack_matrix
                 blob = _stage(in_tab, pre, pack_bias(post, out_rows), pack_w(mat, out_rows, in_cols))
@@ -466,7 +537,7 @@ def pack_flow(desc):
                         stages.append(add_blob(_stage(w)))
                 ops.append([OP_COUPLING, packed.n_steps0, packed.n_chunks, 0])
             elif kind == "elementwise":
-                a, b, c, d, ld = tr[2] if inverse else tr[1]
+                a, b, c, d, ld = tr[1]
                 tabs = np.zeros((4, D4), dtype=np.float32)
                 tabs[1, :] = 1.0
                 tabs[2, :] = 1.0

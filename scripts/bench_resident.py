@@ -33,9 +33,18 @@ def geometry():
 
 
 def main():
-    sizes = [int(a) for a in sys.argv[1:]] or [1_000_000]
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("sizes", nargs="*", type=int, default=[1_000_000])
+    ap.add_argument("--geometry", action="append", help="NESSAI_AMD_RESIDENT value(s) to time; default: all + library choice")
+    ap.add_argument("--net", action="append", help="resnet / mlp; default both")
+    args = ap.parse_args()
+    sizes = args.sizes
+    geos = args.geometry or ["0", "3x2", "4x1", "2x2", "3x1", "2x1", None]
+    geos = [None if g in (None, "auto") else g for g in geos]
     model = GaussianModel(16)
-    for net in ("resnet", "mlp"):
+    for net in args.net or ("resnet", "mlp"):
         rng = np.random.default_rng(1451)
         torch.manual_seed(1451)
         live = live_points(model, 2000, 80_000, rng)
@@ -47,7 +56,7 @@ def main():
             prop.populate(None, n_samples=2000, max_samples=10**12)
             precision = prop.flow.model.effective_precision
             for n in sizes:
-                for geo in ("0", "3x2", "4x1", "2x2", "3x1", "2x1", None):
+                for geo in geos:
                     if geo is None:
                         os.environ.pop("NESSAI_AMD_RESIDENT", None)
                     else:

@@ -24,6 +24,10 @@ CONFIGS = {
     "rnvp_additive_actnorm": (O.RealNVP, (4, 8, 2, 2), dict(use_volume_preserving=True, linear_transform=None,
                                                             actnorm=True, batch_norm_between_layers=False)),
     "nsf_d32": (O.NeuralSplineFlow, (32, 64, 2, 2), {}),
+    # act norm -> permutation -> LU per block (the element-wise map is folded into the dense op BEHIND it in
+    # the forward direction and into the one in FRONT of it in the inverse direction)
+    "rnvp_actnorm_lu": (O.RealNVP, (5, 16, 3, 1), dict(actnorm=True, batch_norm_between_layers=False)),
+    "rnvp_pre_bn_lu": (O.RealNVP, (4, 8, 2, 2), dict(pre_transform="batch_norm")),
 }
 
 
@@ -85,6 +89,33 @@ def test_product_and_oracle_trees_pack_identically():
         a.eval()
         b.eval()
         assert np.array_equal(P.pack_flow(describe(a)), P.pack_flow(describe(b)))
+
+
+def test_batch_norm_next_to_an_lu_layer_is_folded_into_it():
+    """The reference's default RealNVP (permutation, LU, coupling, batch norm per block): in the image every
+    batch norm but the one with no LU-linear neighbour has become part of a dense op, in both directions;
+    ``fold_elementwise=False`` keeps the one-op-per-transform program (same results: the emulator test above
+    runs the folded form against the oracle)."""
+    torch.manual_seed(2)
+    flow = O.RealNVP(16, 32, 4, 2)
+    randomise(flow, 2)
+    flow.eval()
+
+    def kinds(img, inverse):
+        n = int(img[P.H_NOPS_INV if inverse else P.H_NOPS_FWD])
+        at = int(img[P.H_OPS_INV if inverse else P.H_OPS_FWD])
+        return [int(img[at + P.OP_WORDS * i]) for i in range(n)]
+
+    img = P.pack_flow(describe(flow))
+    plain = P.pack_flow(dict(describe(flow), fold_elementwise=False))
+    for inverse in (False, True):
+        assert kinds(plain, inverse).count(P.OP_ELEMENTWISE) == 4 and len(kinds(plain, inverse)) == 12
+        assert kinds(img, inverse).count(P.OP_ELEMENTWISE) == 1 and len(kinds(img, inverse)) == 9
+    x = torch.randn(50, 16) * 2
+    for inverse in (False, True):
+        a, la = Emulator(img).run(x.numpy(), inverse)
+        b, lb = Emulator(plain).run(x.numpy(), inverse)
+        assert np.abs(a - b).max() < 2e-5 * max(1.0, np.abs(b).max()) and np.abs(la - lb).max() < 2e-5
 
 
 def test_image_header_and_alignment():
