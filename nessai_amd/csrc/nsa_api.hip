@@ -266,6 +266,12 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   const int D = (int)h[NSA_H_D];
   const int XS = (D + 1) | 1;
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
+#ifdef NSA_TIMELINE
+  {
+    const char* tl = getenv("NSA_TL_PTR");  // diagnostic build: device uint64[16] the waves add their section cycles to
+    p.dbg = tl != nullptr ? (unsigned long long*)strtoull(tl, nullptr, 0) : nullptr;
+  }
+#endif
   // Weights-resident geometry (NsaResidentPipe, nsa_flow_kernel.h): the direction's whole program in LDS, ONE
   // workgroup per CU, no barrier in the tile loop.  Taken whenever the program fits beside the x tiles of a
   // useful number of waves; NESSAI_AMD_RESIDENT=0 switches it off (the staged geometries, which give the same
@@ -295,6 +301,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     for (int c = 0; c < 5 && on; ++c) {
       int o = cand[c][0], r = cand[c][1];
       if (pin_occ != 0 && (o != pin_occ || r != pin_rt)) continue;
+      if (r == 2 && p.precision == NSA_PREC_F32) continue;  // exact f32 keeps one tile per wave, as in the staged geometries
       int w = waves_per_group > 0 ? waves_per_group : 4 * o;
       if (w > 4 * o) w = 4 * o;
       if (waves_per_group <= 0 && pin_occ == 0) {
@@ -378,12 +385,6 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   long long grid = (per_cu * g_num_cus + n_flows - 1) / n_flows;
   if (max_groups > 0 && grid > max_groups) grid = max_groups;
   if (grid > n_groups) grid = n_groups;
-#ifdef NSA_TIMELINE
-  {
-    const char* tl = getenv("NSA_TL_PTR");  // diagnostic build: device uint64[16] the waves add their section cycles to
-    p.dbg = tl != nullptr ? (unsigned long long*)strtoull(tl, nullptr, 0) : nullptr;
-  }
-#endif
   hipError_t e = fn(&p, (unsigned)grid, (unsigned)n_flows, (unsigned)(nw * 64), lds, stream);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "flow kernel launch: %s", hipGetErrorString(e));
   g_last_geometry[0] = occ;

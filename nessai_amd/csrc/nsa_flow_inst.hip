@@ -37,9 +37,12 @@ static auto nsa_pick(bool inv) {
 template <int PREC>
 static auto nsa_pick_res(const NsaLaunch* p, bool inv) {
   auto kern = inv ? nsa_flow_kernel<NSA_HT, TP, true, PREC, 2, 1, true> : nsa_flow_kernel<NSA_HT, TP, false, PREC, 2, 1, true>;
-#define NSA_RES_GEO(occ, rt)                          \
-  if (p->occupancy == occ && p->row_tiles == rt)      \
-    kern = inv ? nsa_flow_kernel<NSA_HT, TP, true, PREC, occ, rt, true> : nsa_flow_kernel<NSA_HT, TP, false, PREC, occ, rt, true>;
+  if (p->occupancy != 2 || p->row_tiles != 1) kern = nullptr;  // a shape that is not built must not run another one's code
+  // (exact f32: one row tile per wave only, as in the staged geometries)
+#define NSA_RES_GEO(occ, rt)                                                      \
+  if constexpr (rt == 1 || PREC != NSA_PREC_F32)                                  \
+    if (p->occupancy == occ && p->row_tiles == rt)                                \
+      kern = inv ? nsa_flow_kernel<NSA_HT, TP, true, PREC, occ, rt, true> : nsa_flow_kernel<NSA_HT, TP, false, PREC, occ, rt, true>;
   NSA_RES_GEOMETRIES
 #undef NSA_RES_GEO
   return kern;
@@ -76,6 +79,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t NSA_LAUNCH_NAME(
 #if NSA_HT <= 2
   else if (p->occupancy == 3) kern = nsa_pick<NSA_PREC_F32, 3, 1>(inv);
 #endif
+  if (kern == nullptr) return hipErrorInvalidConfiguration;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

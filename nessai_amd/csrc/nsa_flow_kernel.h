@@ -37,6 +37,8 @@ enum { NSA_MODE_APPLY = 0, NSA_MODE_LOGPROB = 1, NSA_MODE_POPULATE = 2 };
 // ingredient of the kernel so that its share of the run time can be read off the clock.
 //   1 stage copies after the first   2 stage barriers   4 element-wise transform
 //   8 MFMAs of the hidden and last layers   16 latent draw (Philox / Box-Muller)   32 epilogue stores
+//   64 the populate epilogue's per-feature loop (log q only)   128 the populate prologue (latent norm / density)
+//   256 the f16 range check of the outputs   512 LU-linear / batch-norm ops (stage skipped)
 #ifndef NSA_ABLATE
 #define NSA_ABLATE 0
 #endif
@@ -795,6 +797,27 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
   }
 }
 
+// One output tile of a dense op back into the wave's x tile: accumulator register r = 4 q + e of a lane holds
+// output feature first + 8 q + 4 half + e.  The features end at D anywhere inside the tile; a test per element
+// is a per-LANE predicate (`half`) - sixteen exec-mask round trips, each with its mask kept in (spilled)
+// scalar registers.  Groups of eight features that lie wholly below D (a wave-uniform test) are written with
+// plain stores at immediate offsets; only the one group that straddles D is predicated per lane.
+__device__ __forceinline__ void nsa_dense_store(float* xrow, const f32x16& acc, int first, int D, int half) {
+  float* const xh = xrow + 4 * half;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int lo = first + 8 * q;  // wave-uniform
+    if (lo + 8 <= D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xh[lo + e] = acc[4 * q + e];
+    } else if (lo < D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (lo + 4 * half + e < D) xh[lo + e] = acc[4 * q + e];
+    }
+  }
+}
+
 // dense (LU-linear, eval-mode cached weight) -----------------------------------
 // y = W (x - pre) + bias over all D features; D <= 64.
 template <int PREC, int RT, class PIPE>
@@ -816,12 +839,7 @@ __device__ __forceinline__ void nsa_dense_op(PIPE& pipe, const uint32_t* op, flo
     if constexpr (BF) nsa_dense_tile16<PREC, 1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc, pipe.amax);
     else nsa_dense_tile<1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (i < D) xrow[t][i] = acc[t][0][r];
-      }
+    for (int t = 0; t < RT; ++t) nsa_dense_store(xrow[t], acc[t][0], 0, D, half);
   } else {
     f32x16 acc[RT][2];
 #pragma unroll
@@ -831,12 +849,7 @@ __device__ __forceinline__ void nsa_dense_op(PIPE& pipe, const uint32_t* op, flo
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (i < D) xrow[t][i] = acc[t][ot][r];
-        }
+      for (int ot = 0; ot < 2; ++ot) nsa_dense_store(xrow[t], acc[t][ot], 32 * ot, D, half);
   }
   if (half == 0) {
 #pragma unroll
@@ -873,6 +886,14 @@ __device__ __forceinline__ int nsa_opaque(int v) {
   return v;
 }
 
+// The kernel's argument block as it lies in the kernarg segment, through a pointer the optimiser cannot see
+// through: the loads of the fields stay where they are written (see the tile loop).
+__device__ __forceinline__ const NsaLaunch* nsa_args() {
+  const void* k = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));
+  return (const NsaLaunch*)k;
+}
+
 // OCC = waves per SIMD the instance is register-budgeted for: 2 (<= 256 VGPRs, workgroups of up to
 // 8 waves) or 3 (<= 168 VGPRs, workgroups of 6 or 12 waves; only the prologue / epilogue spill).
 // RT = 32-row tiles per wave: the tiles of a wave go through every layer together, so that one read of a
@@ -887,13 +908,9 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   using PIPE = std::conditional_t<RES, NsaResidentPipe, NsaStagePipe>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (p.stop != nullptr && (p.stop[0] >= p.stop[2] || p.stop[1] >= p.stop[5])) return;
-  if (p.image_list != nullptr) {
-    p.image = p.image_list[blockIdx.y];
-    if (p.ld_out != nullptr) p.ld_out += (long long)blockIdx.y * p.n;
-  }
+  if (p.image_list != nullptr) p.image = p.image_list[blockIdx.y];
   const uint32_t* img = p.image;
   const int D = (int)img[NSA_H_D];
-  if (p.image_list != nullptr && p.x_out != nullptr) p.x_out += (long long)blockIdx.y * p.n * D;
   const int XS = (D + 1) | 1;  // odd row stride (conflict-free column reads) with >= 1 spare column
   const int nw = (int)(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1017,6 +1034,10 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     ++tl_tiles;
 #endif
     // ---- fill the x tiles --------------------------------------------------
+    // Kernel arguments are re-read from the kernarg segment (scalar loads) by the section that uses them:
+    // held in scalar registers across the flow - ~80 of them for this argument block - they were spilled to
+    // VGPR lanes and came back through v_readlane, vector instructions, on every tile.
+    const NsaLaunch& a = *nsa_args();
     bool keep_a[RT];
     float log_pz_a[RT];
 #pragma unroll
@@ -1027,72 +1048,98 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     float* const xrow = xrow_a[t];
     const long long row0 = ((g * nw + wave) * RT + t) * NSA_ROWS;
     const long long my_row = row0 + j;
-    if (p.x_in != nullptr) {
+    if (a.x_in != nullptr) {
       const long long base = row0 * D;
-      const long long limit = p.n * (long long)D;
+      const long long limit = a.n * (long long)D;
       for (int idx = nsa_opaque(lane); idx < NSA_ROWS * D; idx += 64) {
         const int r = idx / D, c = idx - r * D;
         const long long gi = base + idx;
-        xt[r * XS + c] = (gi < limit) ? p.x_in[gi] : 0.0f;
+        xt[r * XS + c] = (gi < limit) ? a.x_in[gi] : 0.0f;
       }
     } else {
       // latent draw: 4 normals per Philox call; the two lanes of a row split
       // the quads (row-indexed counter => independent of launch geometry)
-      const unsigned long long grow = p.row_offset + (unsigned long long)my_row;
+      // (pairs of quads, one per lane of the row: while both lie wholly below D - a wave-uniform test - the
+      // four normals are stored without a per-lane predicate; only the pair that straddles D pays for one)
+      const unsigned long long grow = a.row_offset + (unsigned long long)my_row;
       const int n_quads = (D + 3) >> 2;
-      for (int q = half; q < n_quads; q += 2) {
-        if (NSA_ABLATE & 16) {
-          for (int e = 0; e < 4; ++e)
-            if (4 * q + e < D) xrow[4 * q + e] = 0.25f * (float)(q + e) - 1.0f;
-          continue;
-        }
-        uint32_t r4[4];
-        nsa_philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)q, 0u,
-                          (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r4);
+      for (int q0 = 0; q0 < n_quads; q0 += 2) {
+        const int q = q0 + half;
         float z0, z1, z2, z3;
-        nsa_box_muller(r4[0], r4[1], z0, z1);
-        nsa_box_muller(r4[2], r4[3], z2, z3);
-        const int c = 4 * q;
-        xrow[c] = z0;
-        if (c + 1 < D) xrow[c + 1] = z1;
-        if (c + 2 < D) xrow[c + 2] = z2;
-        if (c + 3 < D) xrow[c + 3] = z3;
+        if (NSA_ABLATE & 16) {
+          z0 = 0.25f * (float)q - 1.0f, z1 = z0 + 0.25f, z2 = z0 + 0.5f, z3 = z0 + 0.75f;
+        } else {
+          uint32_t r4[4];
+          nsa_philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)q, 0u,
+                            (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r4);
+          nsa_box_muller(r4[0], r4[1], z0, z1);
+          nsa_box_muller(r4[2], r4[3], z2, z3);
+        }
+        float* const xq = xrow + 4 * q;
+        if (4 * q0 + 8 <= D) {
+          xq[0] = z0;
+          xq[1] = z1;
+          xq[2] = z2;
+          xq[3] = z3;
+        } else {
+          const int c = 4 * q;
+          if (c < D) xq[0] = z0;
+          if (c + 1 < D) xq[1] = z1;
+          if (c + 2 < D) xq[2] = z2;
+          if (c + 3 < D) xq[3] = z3;
+        }
       }
     }
 
     // ---- POPULATE prologue: latent norm, latent log-density, optional z out --
-    if (p.mode == NSA_MODE_POPULATE) {
+    if constexpr (RES) NSA_TL(pipe, 12);  // (timeline of the resident geometry: slot 12 = fill / latent draw)
+    if (a.mode == NSA_MODE_POPULATE && !(NSA_ABLATE & 128)) {
       // latent temperature (proposal/flowproposal/base.py:393-414): the flow sees sqrt(T) z0,
       // the latent density is evaluated at z / sqrt(T) (= z0 exactly for drawn latents)
-      const double ls = p.latent_scale;
+      const double ls = a.latent_scale;
       const bool tempered = ls != 1.0;
       double r2 = 0.0;
       float e = 0.0f;
+      if (!tempered) {
+        // the usual case as straight-line code: D / 2 columns per lane at immediate offsets from the lane's
+        // own start (same columns in the same order as the general loop below)
+        const float* const xh = xrow + half;
+        const int nk = D >> 1;
+#pragma unroll 8
+        for (int k = 0; k < nk; ++k) {
+          const float z = xh[2 * k];
+          r2 += (double)z * (double)z;
+          e += z * z;
+        }
+        if ((D & 1) && half == 0) {
+          const float z = xrow[D - 1];
+          r2 += (double)z * (double)z;
+          e += z * z;
+        }
+      } else
       for (int c = half; c < D; c += 2) {
         float z = xrow[c];
         float zin = z;
-        if (tempered) {
-          if (p.x_in == nullptr) {
-            z = (float)((double)z * ls);
-            xrow[c] = z;
-          } else {
-            zin = (float)((double)z / ls);
-          }
+        if (a.x_in == nullptr) {
+          z = (float)((double)z * ls);
+          xrow[c] = z;
+        } else {
+          zin = (float)((double)z / ls);
         }
         r2 += (double)z * (double)z;
         e += zin * zin;
       }
       r2 += __shfl_xor(r2, 32);
       e += __shfl_xor(e, 32);
-      keep = sqrt(r2) <= p.radius;
+      keep = sqrt(r2) <= a.radius;
       log_pz = -base_half_inv_var * e - base_log_z;
-      if (p.z_out != nullptr) {
+      if (a.z_out != nullptr) {
         const long long base = row0 * D;
-        const long long limit = p.n * (long long)D;
+        const long long limit = a.n * (long long)D;
         for (int idx = nsa_opaque(lane); idx < NSA_ROWS * D; idx += 64) {
           const int r = idx / D, c = idx - r * D;
           const long long gi = base + idx;
-          if (gi < limit) p.z_out[gi] = xt[r * XS + c];
+          if (gi < limit) a.z_out[gi] = xt[r * XS + c];
         }
       }
     }
@@ -1122,6 +1169,9 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
         } else {
           nsa_coupling<HT, TP, INV, PREC, RT, false>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
         }
+      } else if (NSA_ABLATE & 512) {
+        (void)pipe.template begin<false>();
+        pipe.end();
       } else if (kind == NSA_OP_DENSE) {
         nsa_dense_op<PREC, RT>(pipe, op, xrow_a, D, lane, half, logdet_a);
       } else {
@@ -1130,24 +1180,25 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     }
 
     // ---- epilogues -----------------------------------------------------------
+    // (the arguments the epilogues use are re-read from the kernarg segment here - nsa_args)
+    const NsaLaunch& e = *nsa_args();
+    float* e_ld_out = e.ld_out;
+    float* e_x_out = e.x_out;
+    if (e.image_list != nullptr) {  // grouped launch: flow blockIdx.y writes its own block of the outputs
+      if (e_ld_out != nullptr) e_ld_out += (long long)blockIdx.y * e.n;
+      if (e_x_out != nullptr) e_x_out += (long long)blockIdx.y * e.n * D;
+    }
     if constexpr (PREC == NSA_PREC_F16X3) {
       // a value beyond the f16 range went into a matrix product somewhere in this wave's tiles: the
       // results of the call are not to be used (status[1]; the host repeats it in float32 or raises)
-      bool over;
-      if constexpr (NSA_F16_DETECT == 1) {
-        over = pipe.nan_seen;
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-          float poison = logdet_a[t];  // NaN or +-inf in the log-det or in any output column -> NaN
-          for (int c = half; c < D; c += 2) poison = fmaf(xrow_a[t][c], 0.0f, poison);
-          over |= (poison - poison) != 0.0f;
-        }
-        over = __any(over);
-      } else {
-        over = __any(pipe.amax[0] >= NSA_F16_INF || pipe.amax[1] >= NSA_F16_INF);
+      // (NSA_F16_DETECT == 1: the outputs are tested by the epilogue that reads them anyway - `poison` below)
+      if constexpr (NSA_F16_DETECT != 1) {
+        if (__any(pipe.amax[0] >= NSA_F16_INF || pipe.amax[1] >= NSA_F16_INF) && lane == 0) atomicAdd(e.status + 1, 1);
       }
-      if (over && lane == 0) atomicAdd(p.status + 1, 1);
     }
+    // NaN or +-inf in the log-det or in any output column of the wave's tiles -> NaN here (split-f16 only)
+    float poison = 0.0f;
+    constexpr bool POISON = PREC == NSA_PREC_F16X3 && NSA_F16_DETECT == 1 && !(NSA_ABLATE & 256);
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
     float* const xt = xt_a[t];
@@ -1162,22 +1213,23 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     asm volatile("" : "+s"(g_epi));
     const long long row0 = ((g_epi * nw + wave) * RT + t) * NSA_ROWS;
     const long long my_row = row0 + j;
-    const bool row_ok = my_row < p.n;
+    const bool row_ok = my_row < e.n;
     // (opaque too: with `half` the per-lane table addresses of every epilogue variant were hoisted out
     // of the tile loop and lived - spilled, in the 168-register instances - across the whole flow)
     const int half_e = nsa_opaque(half);
-    if (p.mode == NSA_MODE_POPULATE && p.xp_out != nullptr) {
+    if (e.mode == NSA_MODE_POPULATE && e.xp_out != nullptr) {
 #pragma clang fp contract(off)
       // importance-sampler draw: x = 1 / (1 + exp(-x')), log|J_inv| = sum log x + log1p(-x)
       // (utils/rescaling.py:316-336), log|J| = sum -log xc - log1p(-xc) on the clipped x
       const int* epi_tab = (const int*)(epi + 4 * D4e);
       double lj_inv = 0.0, lj = 0.0;
       int good = 1;
-      double* xo = p.x64_out + my_row * D;
-      float* xpo = p.xp_out + my_row * D;
-      const double eps = p.unit_eps;
+      double* xo = e.x64_out + my_row * D;
+      float* xpo = e.xp_out + my_row * D;
+      const double eps = e.unit_eps;
       for (int i = half_e; i < D; i += 2) {
         const float xpf = xrow[epi_tab[i]];
+        if constexpr (POISON) poison = fmaf(xpf, 0.0f, poison);
         const double xp = (double)xpf;
         const double u = 1.0 / (1.0 + exp(-xp));
         lj_inv += log(u) + log1p(-u);
@@ -1193,43 +1245,51 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
       lj += __shfl_xor(lj, 32);
       good &= __shfl_xor(good, 32);
       const bool ok = good != 0 && (lj - lj) == 0.0 && (lj_inv - lj_inv) == 0.0 && n_bad == 0;
-      if (row_ok && half == 0) p.log_q_out[my_row] = ok ? lj : __longlong_as_double(0x7ff8000000000000LL);
-      if (row_ok && half == 0 && n_bad != 0) atomicAdd(p.status, 1);
-    } else if (p.mode == NSA_MODE_POPULATE) {
+      if (row_ok && half == 0) e.log_q_out[my_row] = ok ? lj : __longlong_as_double(0x7ff8000000000000LL);
+      if (row_ok && half == 0 && n_bad != 0) atomicAdd(e.status, 1);
+    } else if (e.mode == NSA_MODE_POPULATE) {
 #pragma clang fp contract(off)
-      const NsaLaunch& e = p;
+
       // x = x' * sigma + mu in float64 (rescale.py:276-279), prior bounds
       // (model.py:512-518), log_q = (log N(z) - log_j) - log_J
       // (flowproposal.py:356, 383)
       bool in_bounds = true;
       double log_prior = 0.0;
       double log_j_row = 0.0;  // row-dependent part of the rescaling log-Jacobian
-      if (e.rp_kind == nullptr && e.prior_kind == nullptr) {
+      if (NSA_ABLATE & 64) {
+      } else if (e.rp_kind == nullptr && e.prior_kind == nullptr) {
         // the plain case (z-score everywhere, prior evaluated elsewhere) without the per-column
         // dispatch: one multiply, one add, two compares and one store per feature
-        double* xo = e.x64_out + my_row * D;
-        const int* epi_tab = (const int*)(epi + 4 * D4e);
+        // D / 2 features per lane - the lane's `half`, then every other one - as straight-line code at
+        // immediate offsets from per-lane bases (tables, output row), eight per round of the loop
+        const int* const tab_h = (const int*)(epi + 4 * D4e) + half_e;
+        const double* const epi_h = epi + half_e;
+        double* const xo_h = e.x64_out + my_row * D + half_e;
         int inb = 1;
+        auto feature = [&](const int* tab, const double* c, double* xo, bool store) {
+          const float xpf = xrow[tab[0]];
+          if constexpr (POISON) poison = fmaf(xpf, 0.0f, poison);
+          const double xv = ((double)xpf * c[0]) + c[D4e];
+          inb &= (int)!(xv < c[2 * D4e]) & (int)!(xv > c[3 * D4e]);
+          if (store) xo[0] = xv;
+        };
+        const int nk = D >> 1;
+        const bool tail = (D & 1) && half_e == 0;
         if (row_ok && !(NSA_ABLATE & 32)) {
-#pragma unroll 4
-          for (int i = half_e; i < D; i += 2) {
-            const double xp = (double)xrow[epi_tab[i]];
-            const double xv = (xp * epi[i]) + epi[D4e + i];
-            inb &= (int)!(xv < epi[2 * D4e + i]) & (int)!(xv > epi[3 * D4e + i]);
-            xo[i] = xv;
-          }
+#pragma unroll 8
+          for (int k = 0; k < nk; ++k) feature(tab_h + 2 * k, epi_h + 2 * k, xo_h + 2 * k, true);
+          if (tail) feature(tab_h + D - 1, epi_h + D - 1, xo_h + D - 1, true);
         } else {
-#pragma unroll 4
-          for (int i = half_e; i < D; i += 2) {
-            const double xp = (double)xrow[epi_tab[i]];
-            const double xv = (xp * epi[i]) + epi[D4e + i];
-            inb &= (int)!(xv < epi[2 * D4e + i]) & (int)!(xv > epi[3 * D4e + i]);
-          }
+#pragma unroll 8
+          for (int k = 0; k < nk; ++k) feature(tab_h + 2 * k, epi_h + 2 * k, xo_h + 2 * k, false);
+          if (tail) feature(tab_h + D - 1, epi_h + D - 1, xo_h + D - 1, false);
         }
         in_bounds = inb != 0;
       } else
       for (int i = half_e; i < D; i += 2) {
-        const double xp = (double)xrow[out_tab[i]];
+        const float xpf = xrow[out_tab[i]];
+        if constexpr (POISON) poison = fmaf(xpf, 0.0f, poison);
+        const double xp = (double)xpf;
         double xv;
         const int kind = (e.rp_kind != nullptr) ? e.rp_kind[i] : NSA_RP_SCALE_SHIFT;
         if (kind == NSA_RP_SCALE_SHIFT) {
@@ -1273,37 +1333,48 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
       // finite check on the flow's log_q (flowproposal.py:366-372), THEN the rescaling
       // Jacobian (flowproposal.py:383): a saturated sigmoid gives log_q = +inf, kept as the
       // reference keeps it (never accepted, still counted as proposed)
-      double lq = ((double)log_pz - p.log_j_latent) - (double)logdet;
+      double lq = ((double)log_pz - e.log_j_latent) - (double)logdet;
       const bool finite = (lq - lq) == 0.0;
       lq -= (e.log_j_rescale + log_j_row);
       if (!(keep && ok && finite && n_bad == 0)) lq = __longlong_as_double(0x7ff8000000000000LL);
       if (row_ok && half == 0) e.log_q_out[my_row] = lq;
-      if (row_ok && half == 0 && n_bad != 0) atomicAdd(p.status, 1);
+      if (row_ok && half == 0 && n_bad != 0) atomicAdd(e.status, 1);
     } else {
       float out_ld = logdet;
-      if (p.mode == NSA_MODE_LOGPROB) {
+      if (e.mode == NSA_MODE_LOGPROB) {
         // log_prob = (-0.5/var * sum z^2 - log_z) + logabsdet (base.py:243-245)
         float e = 0.0f;
         for (int i = half_e; i < D; i += 2) {
           const float z = xrow[out_tab[i]];
+          if constexpr (POISON) poison = fmaf(z, 0.0f, poison);
           e += z * z;
         }
         e += __shfl_xor(e, 32);
         const float lp = -base_half_inv_var * e - base_log_z;
         out_ld = lp + logdet;
       }
-      if (row_ok && half == 0 && p.ld_out != nullptr) p.ld_out[my_row] = out_ld;
-      if (row_ok && half == 0 && n_bad != 0) atomicAdd(p.status, 1);
-      if (p.x_out != nullptr) {
+      if (row_ok && half == 0 && e_ld_out != nullptr) e_ld_out[my_row] = out_ld;
+      if (row_ok && half == 0 && n_bad != 0) atomicAdd(e.status, 1);
+      if (e_x_out != nullptr) {
         const long long base = row0 * D;
-        const long long limit = p.n * (long long)D;
+        const long long limit = e.n * (long long)D;
         for (int idx = nsa_opaque(lane); idx < NSA_ROWS * D; idx += 64) {
           const int r = idx / D, c = idx - r * D;
           const long long gi = base + idx;
-          if (gi < limit) p.x_out[gi] = xt[r * XS + out_tab[c]];
+          const float v = xt[r * XS + out_tab[c]];
+          if constexpr (POISON) poison = fmaf(v, 0.0f, poison);
+          if (gi < limit) e_x_out[gi] = v;
         }
+      } else if (e.mode != NSA_MODE_LOGPROB) {
+        if constexpr (POISON)
+          for (int c = half_e; c < D; c += 2) poison = fmaf(xrow[c], 0.0f, poison);
       }
     }
+    if constexpr (POISON) poison = fmaf(logdet_a[t], 0.0f, poison);
+    }
+    if constexpr (PREC == NSA_PREC_F16X3 && NSA_F16_DETECT == 1) {
+      // a value beyond the f16 range went into a matrix product somewhere in this wave's tiles
+      if (__any(pipe.nan_seen || (poison - poison) != 0.0f) && lane == 0) atomicAdd(e.status + 1, 1);
     }
     NSA_TL(pipe, 9);
   }

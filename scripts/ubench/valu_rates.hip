@@ -9,7 +9,7 @@
 #define CHAINS 8
 #define UNROLL 32
 
-#define KERNEL(name, asm_text, constraint_extra)                                               \
+#define KERNEL(name, asm_text, ...)                                                            \
   __global__ void __launch_bounds__(1024) name(float* out, int reps) {                          \
     float v[CHAINS];                                                                            \
     for (int i = 0; i < CHAINS; ++i) v[i] = 1.0f + 0.001f * (float)(threadIdx.x + i);           \
@@ -17,7 +17,7 @@
     asm volatile("" : "+v"(k), "+v"(c));                                                        \
     for (int rep = 0; rep < reps; ++rep) {                                                      \
       _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                      \
-        _Pragma("unroll") for (int i = 0; i < CHAINS; ++i) asm volatile(asm_text : "+v"(v[i]) : "v"(k), "v"(c) constraint_extra); \
+        _Pragma("unroll") for (int i = 0; i < CHAINS; ++i) asm volatile(asm_text : "+v"(v[i]) : "v"(k), "v"(c) __VA_ARGS__); \
       }                                                                                         \
     }                                                                                           \
     float s = 0.0f;                                                                             \
@@ -32,8 +32,16 @@ KERNEL(k_mul, "v_mul_f32 %0, %0, %1", )
 KERNEL(k_max_i32, "v_max_i32 %0, %0, %2", )
 KERNEL(k_and, "v_and_b32 %0, %0, %1", )
 KERNEL(k_mov, "v_mov_b32 %0, %1", )
-KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc", : "vcc")
+KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %1, s[10:11]", : "s10", "s11")
 KERNEL(k_cmp, "v_cmp_lt_f32 vcc, %0, %1", : "vcc")
+KERNEL(k_cmp_cnd, "v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc", : "vcc")
+KERNEL(k_max_f32, "v_max_f32 %0, %0, %2", )
+KERNEL(k_med3_f32, "v_med3_f32 %0, %0, %1, %2", )
+KERNEL(k_add_u32, "v_add_u32 %0, %0, %1", )
+KERNEL(k_lshlrev, "v_lshlrev_b32 %0, 1, %0", )
+KERNEL(k_bfi, "v_bfi_b32 %0, %1, %0, %2", )
+KERNEL(k_perm, "v_perm_b32 %0, %0, %1, %2", )
+KERNEL(k_ashr, "v_ashrrev_i32 %0, 31, %0", )
 KERNEL(k_cvt_pk_f16, "v_cvt_pk_f16_f32 %0, %0, %1", )
 KERNEL(k_cvt_f32_f16, "v_cvt_f32_f16 %0, %0", )
 KERNEL(k_cvt_f32_f16_sdwa, "v_cvt_f32_f16_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", )
@@ -97,7 +105,9 @@ int main() {
   hipMalloc(&out, sizeof(float) * 256 * 1024);
   struct { const char* name; kern_t k; } ks[] = {
       {"v_fma_f32", k_fma}, {"v_add_f32", k_add}, {"v_sub_f32", k_sub}, {"v_mul_f32", k_mul}, {"v_max_i32", k_max_i32},
-      {"v_and_b32", k_and}, {"v_mov_b32", k_mov}, {"v_cndmask_b32", k_cndmask}, {"v_cmp_lt_f32", k_cmp},
+      {"v_and_b32", k_and}, {"v_mov_b32", k_mov}, {"v_cndmask_b32 (sgpr mask)", k_cndmask}, {"v_cmp_lt_f32", k_cmp}, {"v_cmp + v_cndmask (2 insts)", k_cmp_cnd},
+      {"v_max_f32", k_max_f32}, {"v_med3_f32", k_med3_f32}, {"v_add_u32", k_add_u32}, {"v_lshlrev_b32", k_lshlrev},
+      {"v_bfi_b32", k_bfi}, {"v_perm_b32", k_perm}, {"v_ashrrev_i32", k_ashr},
       {"v_cvt_pk_f16_f32", k_cvt_pk_f16}, {"v_cvt_f32_f16", k_cvt_f32_f16}, {"v_cvt_f32_f16_sdwa", k_cvt_f32_f16_sdwa},
       {"v_fma_mix_f32", k_fma_mix}, {"v_pk_add_f32 (2 values)", k_pk_add_f32}, {"v_pk_fma_f32 (2 values)", k_pk_fma_f32},
       {"v_pk_mul_f32 (2 values)", k_pk_mul_f32}, {"v_fma_f64", k_fma_f64}, {"v_add_f64", k_add_f64}, {"v_pk_max_f16", k_pk_max_f16}, {"v_exp_f32", k_exp}, {"v_log_f32", k_log},

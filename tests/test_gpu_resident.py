@@ -71,7 +71,9 @@ def test_resident_is_the_default_for_flows_that_fit_and_matches_the_oracle(name,
 @pytest.mark.parametrize("name", RESIDENT)
 @pytest.mark.parametrize("n", [1, 33, 65, 1000, 40001])
 def test_resident_rows_equal_staged_rows(name, n, shape, precision, monkeypatch):
-    if precision != "f16x3" and (n not in (33, 40001) or shape not in ("3x2", "4x1")):
+    if precision == "f32" and shape[2] == "2":
+        pytest.skip("exact f32 keeps one row tile per wave, as in the staged geometries")
+    if precision != "f16x3" and (n not in (33, 40001) or shape not in ("3x2", "4x1", "3x1")):
         pytest.skip("the other precisions share the code path: two sizes and two shapes pin their instances")
     P, Oc, args, kw = CONFIGS[name]
     _, flow = make_pair(P, Oc, args, kw)
