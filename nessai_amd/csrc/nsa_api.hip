@@ -264,7 +264,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     return nsa_fail(NSA_E_IMAGE, "unknown precision code %u", h[NSA_H_PREC]);
   p.precision = (int)h[NSA_H_PREC];
   const int D = (int)h[NSA_H_D];
-  const int XS = (D + 1) | 1;
+  const int XS = (D + 2) | 1;  // row stride of the x tiles (nsa_flow_kernel.h)
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
 #ifdef NSA_TIMELINE
   {
@@ -295,9 +295,10 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
       pin_rt = env[2] - '0';
     }
     const size_t fixed = res_bytes + epi_bytes + prog_bytes;
-    auto res_lds = [&](int w, int r) { return ((((size_t)w * r * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + fixed; };
+    // (x tiles + one parked float per lane and tile, nsa_flow_kernel.h)
+    auto res_lds = [&](int w, int r) { return ((((size_t)w * r * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + (size_t)w * r * 256 + fixed; };
     // candidates in the order of their measured time per row on big batches (profiles/r04_resident_geometries.jsonl)
-    static const int cand[5][2] = {{3, 2}, {4, 1}, {2, 2}, {3, 1}, {2, 1}};
+    static const int cand[5][2] = {{4, 1}, {3, 1}, {2, 2}, {3, 2}, {2, 1}};
     for (int c = 0; c < 5 && on; ++c) {
       int o = cand[c][0], r = cand[c][1];
       if (pin_occ != 0 && (o != pin_occ || r != pin_rt)) continue;
@@ -342,7 +343,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   }
   const size_t stage_bytes = 2 * (size_t)h[NSA_H_MAX_STAGE] * 4;
   auto lds_of = [&](int w) {
-    return ((((size_t)w * rt * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + stage_bytes + epi_bytes + prog_bytes;
+    return ((((size_t)w * rt * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + (size_t)w * rt * 256 + stage_bytes + epi_bytes + prog_bytes;
   };
   auto per_cu_of = [&](int w) {
     long long c = (long long)(g_max_lds / lds_of(w));

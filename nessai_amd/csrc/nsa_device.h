@@ -193,6 +193,7 @@ struct NsaTransformConsts {
   float edge_raw;                   // its logit log(exp(1 - min_d) - 1): edge_d == min_d + softplus(edge_raw)
   float inv_logit_div;              // 1/sqrt(hidden_features) or 1
   float aff_a, aff_b;               // affine coupling: scale = sigmoid(raw + aff_a) + aff_b
+  float aff_arg0, aff_1pb;          // -aff_a log2(e), 1 + aff_b
 };
 
 // Fast-but-accurate scalar helpers.  The spline's arithmetic *structure* follows
@@ -284,6 +285,7 @@ struct NsaRQ {
   static constexpr int C = (FPC * NP + 15) / 16;
   static constexpr int KIND = NSA_T_RQ;
   static constexpr int NPH = 1;
+  static constexpr bool LD_FACTOR = false;
 
   struct State {};
 
@@ -374,27 +376,42 @@ struct NsaRQ {
 // Affine coupling: scale = sigmoid(raw + a) + b; a = 2, b = 1e-3 is the nflows default
 // scale_activation, other (a, b) come from a user callable of that family
 // (flows/realnvp.py).  v[OFF] = shift, v[OFF+1] = raw scale.
+//
+// With e = exp(-(raw + a)):  scale = (1 + b + b e) / (1 + e),  1 / scale = (1 + e) / (1 + b + b e)  - ONE
+// reciprocal for the direction at hand (the plain form needs two in the inverse direction: of 1 + e and of
+// the scale), on the bare v_exp_f32 / v_rcp_f32; and log|det J| = sum log(scale) is taken as the log of a
+// PRODUCT of the factors a lane holds (LD_FACTOR: the caller multiplies the `ld` of up to four features -
+// >= b^4, no underflow for any sensible b - and takes one v_log_f32), since a transcendental costs 2.7 plain
+// vector instructions here (scripts/ubench/valu_rates).  e is capped at 2^64, where sigmoid is 0 to
+// float32 beside b; the cap is a compare + select, not a min: a NaN stays a NaN.
 struct NsaAffine {
   static constexpr int NP = 2;
   static constexpr int FPC = 8;
   static constexpr int C = 1;
   static constexpr int KIND = NSA_T_AFFINE;
   static constexpr int NPH = 1;
+  static constexpr bool LD_FACTOR = true;  // `ld` is the Jacobian FACTOR of the feature, not its logarithm
   struct State {};
 
   template <int P, int OFF, bool INV, int NV>
   __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
                                                const NsaTransformConsts& c, float& y, float& ld,
                                                bool& bad) {
-    // bare v_exp_f32 / v_log_f32 / v_rcp_f32 (<= 1 ulp each; scale lies in (aff_b, 1 + aff_b), a normal
-    // number): 12 instructions per feature where expf / logf / an IEEE division took 28
     const float shift = v[OFF];
-    const float raw = v[OFF + 1] + c.aff_a;
-    const float scale = nsa_rcp(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * raw)) + c.aff_b;
-    const float ls = 0.6931471805599453f * nsa_log2(scale);
+    float arg = fmaf(v[OFF + 1], -1.4426950408889634f, c.aff_arg0);  // -(raw + a) log2(e)
+    arg = arg > 64.0f ? 64.0f : arg;
+    const float e = __builtin_amdgcn_exp2f(arg);
+    const float num = 1.0f + e, den = fmaf(c.aff_b, e, c.aff_1pb);
     bad = false;
-    if constexpr (INV) { y = (x - shift) * nsa_rcp(scale); ld = -ls; }
-    else { y = fmaf(x, scale, shift); ld = ls; }
+    if constexpr (INV) {
+      const float inv_scale = num * nsa_rcp(den);
+      y = (x - shift) * inv_scale;
+      ld = inv_scale;
+    } else {
+      const float scale = den * nsa_rcp(num);
+      y = fmaf(x, scale, shift);
+      ld = scale;
+    }
   }
 };
 
@@ -405,6 +422,7 @@ struct NsaAdditive {
   static constexpr int C = 1;
   static constexpr int KIND = NSA_T_ADDITIVE;
   static constexpr int NPH = 1;
+  static constexpr bool LD_FACTOR = false;
   struct State {};
 
   template <int P, int OFF, bool INV, int NV>

@@ -411,7 +411,8 @@ __device__ __forceinline__ void nsa_dense_regs(const float* w, const float (&in)
 }
 
 // Input gathered from the wave's x tile through a column table
-// (tab[2*s + half] = physical column or -1), optional pre-shift.
+// (tab[2*s + half] = byte offset of the physical column in the row; unused entries: the row's zero cell),
+// optional pre-shift.
 template <int OT, bool PRE, int RT>
 __device__ __forceinline__ void nsa_dense_tile(const float* w, const int* tab, const float* pre,
                                                float* const (&xrow)[RT], int n_steps, int lane, int half,
@@ -421,7 +422,7 @@ __device__ __forceinline__ void nsa_dense_tile(const float* w, const int* tab, c
     // the 8 table entries of this step group in two 16-byte reads (a lane uses those of its half),
     // then 4 independent tile reads - no per-element branch, no read -> wait -> read chains
     const int4 c0 = *(const int4*)(tab + 8 * s4), c1 = *(const int4*)(tab + 8 * s4 + 4);
-    const int col[4] = {half ? c0.y : c0.x, half ? c0.w : c0.z, half ? c1.y : c1.x, half ? c1.w : c1.z};
+    const int col[4] = {half ? c0.y : c0.x, half ? c0.w : c0.z, half ? c1.y : c1.x, half ? c1.w : c1.z};  // byte offsets
     float sh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (PRE) {
       const f32x4 p0 = *(const f32x4*)(pre + 8 * s4), p1 = *(const f32x4*)(pre + 8 * s4 + 4);
@@ -434,14 +435,13 @@ __device__ __forceinline__ void nsa_dense_tile(const float* w, const int* tab, c
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) b[t][e] = xrow[t][col[e] < 0 ? 0 : col[e]];
+      for (int e = 0; e < 4; ++e) b[t][e] = *(const float*)((const char*)xrow[t] + col[e]);
+    if (PRE) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+      for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (PRE) b[t][e] = b[t][e] - sh[e];
-        b[t][e] = (col[e] >= 0) ? b[t][e] : 0.0f;
-      }
+        for (int e = 0; e < 4; ++e) b[t][e] = b[t][e] - sh[e];
+    }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
       const f32x4 a = *(const f32x4*)(w + ((ot * n_s4 + s4) * 64 + lane) * 4);
@@ -538,11 +538,10 @@ __device__ __forceinline__ void nsa_dense_tile16(const float* w, const int* tab,
     for (int t = 0; t < RT; ++t) {
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = xrow[t][col[e] < 0 ? 0 : col[e]];
+      for (int e = 0; e < 8; ++e) v[e] = *(const float*)((const char*)xrow[t] + col[e]);  // byte offsets
+      if (PRE) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (PRE) v[e] = v[e] - sh[e];
-        v[e] = (col[e] >= 0) ? v[e] : 0.0f;
+        for (int e = 0; e < 8; ++e) v[e] = v[e] - sh[e];
       }
       nsa_split8<PREC>(v, bh[t], bl[t], amax);
     }
@@ -581,7 +580,7 @@ template <class TP, bool INV, int PH, int NV>
 __device__ __forceinline__ void nsa_run_phase(typename TP::State (&st)[TP::FPC], const float (&v)[NV],
                                               const int (&cols)[TP::FPC], float* xrow,
                                               int dummy_col, const NsaTransformConsts& tc,
-                                              float& logdet, int& n_bad) {
+                                              float& logdet, int& n_bad, float (&prod)[(TP::FPC + 3) / 4]) {
   constexpr int Q = PH / TP::NPH, P = PH % TP::NPH;
   // unused feature slots (col < 0) run on the tile's spare column and add nothing
   const int col = cols[Q];
@@ -594,7 +593,8 @@ __device__ __forceinline__ void nsa_run_phase(typename TP::State (&st)[TP::FPC],
   TP::template phase<P, Q * TP::NP, INV, NV>(st[Q], v, x_in, tc, y, ld, bad);
   if constexpr (P == TP::NPH - 1) {
     xrow[c] = y;
-    logdet += live ? ld : 0.0f;
+    if constexpr (TP::LD_FACTOR) prod[Q / 4] *= live ? ld : 1.0f;
+    else logdet += live ? ld : 0.0f;
     n_bad += (live && bad) ? 1 : 0;
   }
 }
@@ -605,7 +605,17 @@ __device__ __forceinline__ void nsa_run_phases(typename TP::State (&st)[TP::FPC]
                                                int dummy_col, const NsaTransformConsts& tc,
                                                float& logdet, int& n_bad,
                                                std::integer_sequence<int, I...>) {
-  (nsa_run_phase<TP, INV, LO + I, NV>(st, v, cols, xrow, dummy_col, tc, logdet, n_bad), ...);
+  // LD_FACTOR transforms hand back Jacobian factors: multiplied in groups of four, one logarithm per group
+  float prod[(TP::FPC + 3) / 4];
+#pragma unroll
+  for (int g = 0; g < (TP::FPC + 3) / 4; ++g) prod[g] = 1.0f;
+  (nsa_run_phase<TP, INV, LO + I, NV>(st, v, cols, xrow, dummy_col, tc, logdet, n_bad, prod), ...);
+  if constexpr (TP::LD_FACTOR) {
+    float l2 = 0.0f;
+#pragma unroll
+    for (int g = 0; g < (TP::FPC + 3) / 4; ++g) l2 += nsa_log2(prod[g]);
+    logdet = fmaf(0.6931471805599453f, l2, logdet);
+  }
 }
 
 // MFMAs of sub-stage J of one chunk of the last conditioner layer (-> acc; cols and the bias come
@@ -894,6 +904,13 @@ __device__ __forceinline__ const NsaLaunch* nsa_args() {
   return (const NsaLaunch*)k;
 }
 
+// A float of the flow image's header, read where it is used by a scalar load (the image is read-only for
+// the kernel: constant address space) through a pointer the optimiser cannot hoist the load with.
+__device__ __forceinline__ float nsa_header_float(const uint32_t* img, int word) {
+  asm volatile("" : "+s"(img));
+  return __uint_as_float(((const __attribute__((address_space(4))) uint32_t*)img)[word]);
+}
+
 // OCC = waves per SIMD the instance is register-budgeted for: 2 (<= 256 VGPRs, workgroups of up to
 // 8 waves) or 3 (<= 168 VGPRs, workgroups of 6 or 12 waves; only the prologue / epilogue spill).
 // RT = 32-row tiles per wave: the tiles of a wave go through every layer together, so that one read of a
@@ -910,24 +927,19 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   if (p.stop != nullptr && (p.stop[0] >= p.stop[2] || p.stop[1] >= p.stop[5])) return;
   if (p.image_list != nullptr) p.image = p.image_list[blockIdx.y];
   const uint32_t* img = p.image;
-  const int D = (int)img[NSA_H_D];
-  const int XS = (D + 1) | 1;  // odd row stride (conflict-free column reads) with >= 1 spare column
+  const int D0 = (int)img[NSA_H_D];
+  // odd row stride (conflict-free column reads) with two spare columns behind the features: D0 takes the
+  // writes of unused feature slots, D0 + 1 always holds 0.0 - the gather tables of layer 0 / the LU-linear op
+  // point their unused entries at it (byte offsets: nsa_format.h), so a gathered operand is one add and
+  // one read, without the clamp, the shift and the two selects a "-1 = nothing" entry cost per element
+  const int XS0 = (D0 + 2) | 1;
   const int nw = (int)(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = (int)(threadIdx.x & 63);
-  const int half = lane >> 5;
-  const int j = lane & 31;
+  const int lane0 = (int)(threadIdx.x & 63);
   constexpr bool inverse = INV;  // p.direction selects the instantiation on the host
 
-  const int tiles_words = (nw * RT * NSA_ROWS * XS + 3) & ~3;
+  const int tiles_words = (nw * RT * NSA_ROWS * XS0 + 3) & ~3;
   const int max_stage = (int)img[NSA_H_MAX_STAGE];
-  float* xt_a[RT];
-  float* xrow_a[RT];
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    xt_a[t] = smem + (wave * RT + t) * (NSA_ROWS * XS);
-    xrow_a[t] = xt_a[t] + j * XS;
-  }
 
   PIPE pipe;
   pipe.n_stages = (int)(inverse ? img[NSA_H_NSTAGES_INV] : img[NSA_H_NSTAGES_FWD]);
@@ -943,13 +955,16 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   // POPULATE: the per-column constants of the epilogue (z-score sigma / mu, prior bounds, output
   // column table) live in LDS behind the stage buffers - the epilogue reads them per feature, and
   // from global memory every read was a separate exposed round trip
-  const int D4e = (D + 3) & ~3;
+  const int D4e = (D0 + 3) & ~3;
   double* epi = (double*)(stage_area + stage_words);  // [4][D4e] doubles + [D4e] ints (populate only)
   // The program of this direction - stage table {offset, words} and op table - also lives in LDS
   // (NSA_PROG_WORDS): both are read at every stage / op, the loop's global stores make the compiler
   // fetch them with vector loads, and each was an exposed L2 round trip in front of the stage's copy.
   uint32_t* prog = (uint32_t*)(stage_area + stage_words) + (p.mode == NSA_MODE_POPULATE ? 9 * D4e : 0);
   uint32_t* prog_ops = prog + 2 * pipe.n_stages;
+  // one float per lane and tile behind the program: the latent log-density of the row (NaN = row outside
+  // the latent radius), written by the tile's prologue and read by its epilogue
+  float* const park = (float*)(prog + ((2 * pipe.n_stages + NSA_OP_WORDS * n_ops + 3) & ~3));
   {
     const uint32_t* gtab = img + (inverse ? img[NSA_H_STAGES_INV] : img[NSA_H_STAGES_FWD]);
     const uint32_t* gops = img + (inverse ? img[NSA_H_OPS_INV] : img[NSA_H_OPS_FWD]);
@@ -960,7 +975,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   if (p.mode == NSA_MODE_POPULATE) {
     int* epi_tab = (int*)(epi + 4 * D4e);
     const int* otab = (const int*)(img + (inverse ? img[NSA_H_OUT_INV] : img[NSA_H_OUT_FWD]));
-    for (int i = (int)threadIdx.x; i < D; i += (int)blockDim.x) {
+    for (int i = (int)threadIdx.x; i < D0; i += (int)blockDim.x) {
       epi[i] = p.scale != nullptr ? p.scale[i] : 1.0;
       epi[D4e + i] = p.shift != nullptr ? p.shift[i] : 0.0;
       epi[2 * D4e + i] = p.lower != nullptr ? p.lower[i] : 0.0;
@@ -975,7 +990,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
       pipe.off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)off0);
       pipe.base = stage_area;
       const int pieces = (stage_words + 255) >> 8;
-      for (int c = wave; c < pieces; c += nw) nsa_glds16(img + pipe.off0 + c * 256 + lane * 4, stage_area + c * 256);
+      for (int c = wave; c < pieces; c += nw) nsa_glds16(img + pipe.off0 + c * 256 + lane0 * 4, stage_area + c * 256);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     pipe.skew = false;
@@ -984,7 +999,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   if constexpr (!RES) {
     pipe.wave = wave;
     pipe.nw = nw;
-    pipe.lane = lane;
+    pipe.lane = lane0;
     pipe.issued = false;
     // p.skew: 1 = the upper half of the workgroup's waves, 2 = every other wave
     pipe.skew = SK && (p.skew == 1 ? (wave >= (nw >> 1)) : (p.skew == 2 ? (wave & 1) != 0 : false));
@@ -992,9 +1007,8 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
 
   const uint32_t* ops = prog_ops;
   const int* out_tab = (const int*)(img + (inverse ? img[NSA_H_OUT_INV] : img[NSA_H_OUT_FWD]));
-  // base density constants (read once: inside the tile loop they were global loads per tile)
-  const float base_half_inv_var = 0.5f * nsa_bits_to_float(img[NSA_H_BASE_INV_VAR]);
-  const float base_log_z = nsa_bits_to_float(img[NSA_H_LOG_Z]);
+  // base density constants: header words, kept in the workgroup's LDS copy of the program (two more words
+  // behind the op table) and read there by the tile's prologue / epilogue
 
   NsaTransformConsts tc;
   tc.tail_bound = nsa_bits_to_float(img[NSA_H_TAIL_BOUND]);
@@ -1007,6 +1021,8 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   tc.inv_logit_div = 1.0f / nsa_bits_to_float(img[NSA_H_LOGIT_DIV]);
   tc.aff_a = nsa_bits_to_float(img[NSA_H_AFF_A]);
   tc.aff_b = nsa_bits_to_float(img[NSA_H_AFF_B]);
+  tc.aff_arg0 = -1.4426950408889634f * tc.aff_a;
+  tc.aff_1pb = 1.0f + tc.aff_b;
   {
     const int K = (int)img[NSA_H_BINS];
     tc.bw_scale = (float)(1.0 - (double)tc.min_bw * K);
@@ -1038,8 +1054,27 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     // held in scalar registers across the flow - ~80 of them for this argument block - they were spilled to
     // VGPR lanes and came back through v_readlane, vector instructions, on every tile.
     const NsaLaunch& a = *nsa_args();
-    bool keep_a[RT];
-    float log_pz_a[RT];
+    // The lane index is opaque to the optimiser from here on: every per-lane quantity that depends on the lane
+    // and the flow's shape alone - tile addresses, the "column < D" predicates of the ragged paths, first-round
+    // products of the Philox counters - is otherwise computed once in front of the tile loop and kept alive
+    // across it: ~60 scalar registers of predicates alone (spilled to VGPR lanes) and the vector registers the
+    // 256-register instances then spilled to scratch.
+    // (... and not even kept: mbcnt counts the lanes below this one - two instructions per tile)
+    const int lane = nsa_opaque((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+    const int half = lane >> 5;
+    const int j = lane & 31;
+    // (the feature count likewise: the wave-uniform "group below D" tests of the ragged paths were kept as
+    // 64-bit masks, two scalar registers each, from the kernel's entry on)
+    int D = D0;
+    asm volatile("" : "+s"(D));
+    const int XS = (D + 2) | 1;
+    float* xt_a[RT];
+    float* xrow_a[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      xt_a[t] = smem + (wave * RT + t) * (NSA_ROWS * XS);
+      xrow_a[t] = xt_a[t] + j * XS;
+    }
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
     bool keep = true;
@@ -1056,6 +1091,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
         const long long gi = base + idx;
         xt[r * XS + c] = (gi < limit) ? a.x_in[gi] : 0.0f;
       }
+      xrow[D + 1] = 0.0f;
     } else {
       // latent draw: 4 normals per Philox call; the two lanes of a row split
       // the quads (row-indexed counter => independent of launch geometry)
@@ -1063,6 +1099,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
       // four normals are stored without a per-lane predicate; only the pair that straddles D pays for one)
       const unsigned long long grow = a.row_offset + (unsigned long long)my_row;
       const int n_quads = (D + 3) >> 2;
+      xrow[D + 1] = 0.0f;
       for (int q0 = 0; q0 < n_quads; q0 += 2) {
         const int q = q0 + half;
         float z0, z1, z2, z3;
@@ -1132,7 +1169,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
       r2 += __shfl_xor(r2, 32);
       e += __shfl_xor(e, 32);
       keep = sqrt(r2) <= a.radius;
-      log_pz = -base_half_inv_var * e - base_log_z;
+      log_pz = -(0.5f * nsa_header_float(img, NSA_H_BASE_INV_VAR)) * e - nsa_header_float(img, NSA_H_LOG_Z);
       if (a.z_out != nullptr) {
         const long long base = row0 * D;
         const long long limit = a.n * (long long)D;
@@ -1143,8 +1180,9 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
         }
       }
     }
-    keep_a[t] = keep;
-    log_pz_a[t] = log_pz;
+    // parked in LDS until the epilogue (one cell per lane and tile): live in registers across the whole flow
+    // these per-row values were what the 256-register instances spilled to scratch
+    park[(wave * RT + t) * 64 + lane] = keep ? log_pz : __uint_as_float(0x7fc00000u);
     }
     NSA_TL(pipe, 0);
     // ---- run the flow --------------------------------------------------------
@@ -1203,8 +1241,8 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     for (int t = 0; t < RT; ++t) {
     float* const xt = xt_a[t];
     float* const xrow = xrow_a[t];
-    const bool keep = keep_a[t];
-    const float log_pz = log_pz_a[t];
+    const float log_pz = park[(wave * RT + t) * 64 + nsa_opaque(lane)];
+    const bool keep = log_pz == log_pz;  // NaN = outside the latent radius
     const float logdet = logdet_a[t] + __shfl_xor(logdet_a[t], 32);
     const int n_bad = n_bad_a[t] + __shfl_xor(n_bad_a[t], 32);
     // row indices are recomputed from the (opaque) group counter instead of staying live in
@@ -1350,7 +1388,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
           e += z * z;
         }
         e += __shfl_xor(e, 32);
-        const float lp = -base_half_inv_var * e - base_log_z;
+        const float lp = -(0.5f * nsa_header_float(img, NSA_H_BASE_INV_VAR)) * e - nsa_header_float(img, NSA_H_LOG_Z);
         out_ld = lp + logdet;
       }
       if (row_ok && half == 0 && e_ld_out != nullptr) e_ld_out[my_row] = out_ld;
@@ -1381,7 +1419,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   // drain the wrap-around prefetch before the workgroup exits
   if constexpr (!RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef NSA_TIMELINE
-  if (p.dbg != nullptr && lane == 0) {
+  if (p.dbg != nullptr && lane0 == 0) {
     for (int i = 0; i < 14; ++i) atomicAdd(p.dbg + i, pipe.tl.acc[i]);
     atomicAdd(p.dbg + 14, tl_tiles);
     atomicAdd(p.dbg + 15, 1ull);

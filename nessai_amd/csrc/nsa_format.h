@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define NSA_MAGIC 0x3141534e /* "NSA1" */
-#define NSA_VERSION 7
+#define NSA_VERSION 8
 
 // header word indices
 enum {
@@ -93,6 +93,8 @@ enum { NSA_PREC_F32 = 0, NSA_PREC_BF16X3 = 1, NSA_PREC_F16X3 = 2 };
 // lane = 32*half + i holds weight(out_row(ot, i), in_col(s, half)).
 //   in_col from registers (hidden/final): 32*(s>>4) + (r&3) + 8*(r>>2) + 4*half, r = s&15
 //   in_col from the x tile (layer 0, dense): 2*s + half
+// id_tab / in_tab entries are BYTE offsets into a row of the x tile (4 * physical column); an unused entry
+// holds 4 * (D + 1), the row's always-zero cell (format 8; it was -1 and cost the kernel two selects).
 // bias[ot][half][r] is the bias of out feature 32*ot + (r&3) + 8*(r>>2) + 4*half.
 //
 // NSA_PREC_BF16X3 / NSA_PREC_F16X3 images keep the same tables and biases but count k in steps of 16

@@ -31,7 +31,7 @@ import math
 import numpy as np
 
 MAGIC = 0x3141534E
-VERSION = 7
+VERSION = 8
 HEADER_WORDS = 40
 STAGE_ALIGN = 32   # words: stage blobs are padded to whole 128-byte lines
 PIECE_WORDS = 256  # words moved by one global_load_lds of a wave (64 lanes x 16 bytes)
@@ -503,10 +503,10 @@ def pack_flow(desc):
                     n_steps = pad4((D + 1) // 2)
                     in_cols = [[(2 * s + h) if (2 * s + h) < D else -1 for h in range(2)] for s in range(n_steps)]
                     tab_len = 2 * n_steps
-                in_tab = np.full(tab_len, -1, dtype=np.int32)
+                in_tab = np.full(tab_len, 4 * (D + 1), dtype=np.int32)  # byte offsets; unused: the zero cell
                 pre = np.zeros(tab_len, dtype=np.float32)
                 for k in range(D):
-                    in_tab[k] = cur[k]
+                    in_tab[k] = 4 * cur[k]
                 mat = np.asarray(mat, dtype=np.float32)
                 pre[:D] = np.asarray(pre_v, dtype=np.float32)
                 post = np.asarray(post_v, dtype=np.float32)
@@ -519,9 +519,9 @@ def pack_flow(desc):
                 cur = list(range(D))
             elif kind == "coupling":
                 _, identity_idx, transform_idx, packed = tr
-                id_tab = np.full((16 if bf16 else 2) * packed.n_steps0, -1, dtype=np.int32)
+                id_tab = np.full((16 if bf16 else 2) * packed.n_steps0, 4 * (D + 1), dtype=np.int32)
                 for k, f in enumerate(identity_idx):
-                    id_tab[k] = cur[int(f)]
+                    id_tab[k] = 4 * cur[int(f)]  # byte offset in the row; unused entries: the zero cell
                 stages.append(add_blob(_stage(id_tab, *packed.layer0)))
                 for bias, subs in packed.hidden_layers:
                     stages.append(add_blob(_stage(bias, subs[0])))

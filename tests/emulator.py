@@ -146,11 +146,14 @@ class Emulator:
                 bias = fl[tl : tl + 32 * HT]
 
                 def gather(tab, idx, pre=None):
-                    cols = tab[idx]
-                    vals = xt[row_of[:, None] if idx.ndim == 2 else row_of, np.maximum(cols, 0)]
+                    # byte offsets into a row; an unused entry points at the row's zero cell, column D + 1
+                    cols = tab[idx] // 4
+                    assert np.all(tab[idx] % 4 == 0) and np.all((cols < D) | (cols == D + 1))
+                    xz = np.concatenate([xt, np.zeros((xt.shape[0], 2), dtype=np.float32)], axis=1)
+                    vals = xz[row_of[:, None] if idx.ndim == 2 else row_of, cols]
                     if pre is not None:
                         vals = vals - pre[idx]
-                    return np.where(cols >= 0, vals, 0.0).astype(np.float32)
+                    return vals.astype(np.float32)
 
                 if self.bf16:
                     w = st[tl + 32 * HT : tl + 32 * HT + HT * n_steps0 * 512]
@@ -231,9 +234,10 @@ class Emulator:
                 bias = fl[2 * tl : 2 * tl + 32 * n_ot]
 
                 def gather_d(idx):
-                    cols = in_tab[idx]
-                    vals = xt[row_of[:, None] if idx.ndim == 2 else row_of, np.maximum(cols, 0)] - pre[idx]
-                    return np.where(cols >= 0, vals, 0.0).astype(np.float32)
+                    cols = in_tab[idx] // 4
+                    assert np.all(in_tab[idx] % 4 == 0) and np.all((cols < D) | (cols == D + 1))
+                    xz = np.concatenate([xt, np.zeros((xt.shape[0], 2), dtype=np.float32)], axis=1)
+                    return (xz[row_of[:, None] if idx.ndim == 2 else row_of, cols] - pre[idx]).astype(np.float32)
 
                 if self.bf16:
                     w = st[2 * tl + 32 * n_ot : 2 * tl + 32 * n_ot + n_ot * n_steps * 512]
