@@ -235,7 +235,8 @@ NSA_API int nsa_populate_passes(const uint32_t* header, const void* image_dev, l
  * that walks the passes in order against the loop state.  Rows, order, counters and Philox offsets are those
  * of nsa_populate_passes; passes beyond the one that reaches the wanted count are computed and ignored.
  *   x64_many_dev [n_passes n][D], log_q_many_dev / log_prior_many_dev [n_passes n],
- *   stage_dev [n_passes][stage_rows][D] with stage_rows >= min(n, capacity), counts_dev [n_passes]. */
+ *   stage_dev [n_passes][stage_rows][D] with stage_rows >= min(n, capacity), counts_dev [n_passes];
+ *   n_passes <= 64. */
 NSA_API int nsa_populate_passes_small(const uint32_t* header, const void* image_dev, long long n, int n_passes,
                               unsigned long long seed, unsigned long long row_offset, double radius,
                               double latent_temperature, const double* scale_dev, const double* shift_dev,

@@ -306,9 +306,14 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
       int w = waves_per_group > 0 ? waves_per_group : 4 * o;
       if (w > 4 * o) w = 4 * o;
       if (waves_per_group <= 0 && pin_occ == 0) {
-        // batches that do not fill the chip: one tile per wave, fewer waves per workgroup, more CUs
+        // batches that do not fill the chip: one tile per wave and just the waves per workgroup that take
+        // the batch in ONE round over all CUs (a tile's trip through the flow is tens of microseconds of
+        // latency: a second round for a few left-over tiles doubles a small launch)
         if (r == 2 && n_tiles * n_flows < (long long)w * r * g_num_cus) continue;
-        while (w > 1 && n_tiles * n_flows < (long long)w * r * g_num_cus) w >>= 1;
+        if (n_tiles * n_flows < (long long)w * g_num_cus) {
+          const long long per_cu = (n_tiles * n_flows + g_num_cus - 1) / g_num_cus;
+          w = (int)(per_cu < 1 ? 1 : per_cu);
+        }
       }
       while (w > 1 && res_lds(w, r) > g_max_lds) --w;  // fewer waves beside a bigger program
       if (res_lds(w, r) > g_max_lds) continue;
@@ -868,10 +873,10 @@ extern "C" int nsa_populate_passes_small(const uint32_t* header, const void* ima
                                          long long capacity, double* x_acc_dev, long long* state_dev, int* status_dev,
                                          int waves_per_group, int max_groups, void* stream,
                                          const nsa_post_rules* rules) {
-  if (n <= 0 || n > 16384 || n_passes < 1 || x64_many_dev == nullptr || log_q_many_dev == nullptr ||
+  if (n <= 0 || n > 16384 || n_passes < 1 || n_passes > 64 || x64_many_dev == nullptr || log_q_many_dev == nullptr ||
       stage_dev == nullptr || counts_dev == nullptr || x_acc_dev == nullptr || state_dev == nullptr || capacity < 0 ||
       stage_rows < 1)
-    return nsa_fail(NSA_E_ARG, "nsa_populate_passes_small: bad argument (1 <= n <= 16384)");
+    return nsa_fail(NSA_E_ARG, "nsa_populate_passes_small: bad argument (1 <= n <= 16384, 1 <= n_passes <= 64)");
   NsaLaunch p;
   const long long rows = n * (long long)n_passes;
   int rc = nsa_draw_params(p, header, image_dev, rows, nullptr, seed, row_offset, radius, latent_temperature, scale_dev,

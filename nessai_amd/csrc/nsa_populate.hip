@@ -358,34 +358,57 @@ __global__ void __launch_bounds__(1024) nsa_small_tails_kernel(long long n, int 
   if (threadIdx.x == 1023) counts[pass] = scnt[1023];
 }
 
-__global__ void __launch_bounds__(256) nsa_small_commit_kernel(int n_passes, int D, long long cap,
-                                                               const double* __restrict__ stage,
-                                                               const long long* __restrict__ counts,
-                                                               long long capacity, double* __restrict__ x_acc,
-                                                               long long* state) {
-  __shared__ long long sh[2];  // {rows written so far, stop flag}
-  for (int i = 0; i < n_passes; ++i) {
-    if (threadIdx.x == 0) {
-      sh[0] = state[3];
-      sh[1] = NSA_STOPPED(state) ? 1 : 0;
+// The stop test of a train of small passes, replayed in pass order against the loop state
+// (FlowProposal.populate's `while n_accepted < n_samples`, flowproposal.py:447-518): ONE thread walks the
+// counts - reads of the state once, no barrier per pass (the first version crossed three per pass and took
+// 73 us for sixty passes) - and leaves where each counted pass's rows go; then every thread copies its share
+// of ALL staged rows (an element finds its pass by bisection of <= 64 offsets).
+#define NSA_SMALL_MAX_PASSES 64
+__global__ void __launch_bounds__(1024) nsa_small_commit_kernel(int n_passes, int D, long long cap,
+                                                                const double* __restrict__ stage,
+                                                                const long long* __restrict__ counts,
+                                                                long long capacity, double* __restrict__ x_acc,
+                                                                long long* state) {
+  __shared__ long long s_first[NSA_SMALL_MAX_PASSES + 1];  // first output ELEMENT of pass i (prefix of take * D)
+  __shared__ long long s_dst[NSA_SMALL_MAX_PASSES];        // first output row of pass i
+  __shared__ int s_np;
+  if (threadIdx.x == 0) {
+    long long acc = state[0], passes = state[1], written = state[3], last = state[4];
+    const long long want = state[2], limit = state[5];
+    int np = 0;
+    long long first = 0;
+    for (int i = 0; i < n_passes && i < NSA_SMALL_MAX_PASSES; ++i) {
+      if (acc >= want || passes >= limit) break;
+      const long long got = counts[i];
+      long long take = got < cap ? got : cap;
+      if (take > capacity - written) take = capacity - written;
+      s_first[np] = first;
+      s_dst[np] = written;
+      first += take * D;
+      ++np;
+      last = got;
+      acc += got;
+      passes += 1;
+      written = (written + got < capacity) ? written + got : capacity;
     }
-    __syncthreads();
-    if (sh[1] != 0) return;
-    const long long got = counts[i], written = sh[0];
-    long long take = got < cap ? got : cap;
-    if (take > capacity - written) take = capacity - written;
-    const double* src = stage + (long long)i * cap * D;
-    double* dst = x_acc + written * D;
-    for (long long k = threadIdx.x; k < take * D; k += blockDim.x) dst[k] = src[k];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      state[4] = got;
-      state[0] += got;
-      state[1] += 1;
-      const long long wr = written + got;
-      state[3] = wr < capacity ? wr : capacity;
+    s_first[np] = first;
+    s_np = np;
+    state[0] = acc;
+    state[1] = passes;
+    state[3] = written;
+    state[4] = last;
+  }
+  __syncthreads();
+  const int np = s_np;
+  const long long total = s_first[np];
+  for (long long k = threadIdx.x; k < total; k += blockDim.x) {
+    int lo = 0, hi = np;  // pass with s_first[lo] <= k < s_first[lo + 1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_first[mid] <= k) lo = mid;
+      else hi = mid;
     }
-    __syncthreads();
+    x_acc[s_dst[lo] * D + (k - s_first[lo])] = stage[(long long)lo * cap * D + (k - s_first[lo])];
   }
 }
 
@@ -395,7 +418,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_small_tra
     long long* counts, long long capacity, double* x_acc, long long* state, hipStream_t stream) {
   hipLaunchKernelGGL(nsa_small_tails_kernel, dim3((unsigned)n_passes), dim3(1024), 0, stream, n, D, log_q_many,
                      log_prior_many, log_prior_const, seed, row_offset, x64_many, cap, stage, counts, state);
-  hipLaunchKernelGGL(nsa_small_commit_kernel, dim3(1), dim3(256), 0, stream, n_passes, D, cap, stage, counts, capacity,
+  hipLaunchKernelGGL(nsa_small_commit_kernel, dim3(1), dim3(1024), 0, stream, n_passes, D, cap, stage, counts, capacity,
                      x_acc, state);
   return hipGetLastError();
 }

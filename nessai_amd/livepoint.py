@@ -120,9 +120,21 @@ def array_to_live_points_fast(array, names):
     """
     array = np.ascontiguousarray(array, dtype=np.float64)
     m, d = array.shape
-    out = empty_structured_array(m, names=names)
+    out = np.empty(m, dtype=_cached_dtype(tuple(names)))  # (the parameter fields are all overwritten below)
     if m:
         itemsize = out.dtype.itemsize
         block = np.ndarray((m, d), dtype=np.float64, buffer=out.data, strides=(itemsize, 8))
         block[:] = array
+        for nm, v in zip(NON_SAMPLING_PARAMETERS, NON_SAMPLING_DEFAULTS):
+            out[nm] = v
     return out
+
+
+_DTYPES = {}
+
+
+def _cached_dtype(names):
+    dt = _DTYPES.get(names)
+    if dt is None:
+        dt = _DTYPES[names] = get_dtype(list(names))
+    return dt

@@ -189,8 +189,13 @@ class UniformBoxModel(Model):
     def log_prior(self, x):
         with np.errstate(divide="ignore"):
             log_p = np.log(self.in_bounds(x), dtype="float")
+        # -sum log(width), subtracted bound by bound like examples/rosenbrock.py:28-31 - on a scalar: 0 - c1 - c2
+        # ... is the same float64 sequence for every in-bounds point (and -inf stays -inf), one array pass
+        # instead of one per parameter
+        total = np.float64(0.0)
         for bounds in self.bounds.values():
-            log_p -= np.log(bounds[1] - bounds[0])
+            total -= np.log(bounds[1] - bounds[0])
+        log_p += total
         return log_p
 
 

@@ -34,6 +34,7 @@ from . import lib
 from .flowmodel import FlowModel
 from .livepoint import (
     array_to_live_points_fast,
+    copy_points,
     get_dtype,
     live_points_to_array,
 )
@@ -497,7 +498,7 @@ class FlowProposal:
 
     def convert_to_samples(self, x, plot=False):
         """Attach ``logP`` (``base.py:1100-1128``)."""
-        x = x.copy()
+        x = copy_points(x)  # (one memcpy of the records; numpy copies a structured array field by field)
         x["logP"] = self.model.batch_evaluate_log_prior(x)
         return x
 
@@ -666,14 +667,18 @@ class FlowProposal:
             rules.log_l_threshold = float(log_l_threshold)
         return rules
 
-    def _f16_range_left(self):
+    def _f16_range_left(self, flag_host=None):
         """True when the draw kernel ran in split-f16 and reported a value beyond the f16 range
-        (``status[1]``; agreed over the ranks of a sharded proposal).  One 16-byte read-back."""
+        (``status[1]``; agreed over the ranks of a sharded proposal).  One 16-byte read-back, or none when
+        the caller already brought the flag to the host with its own copies (``flag_host``)."""
         flow = self.flow.model
         if flow.effective_precision != "f16x3" or flow._status is None:
             return False
+        sharded = self.shard and torch.distributed.is_available() and torch.distributed.is_initialized()
+        if flag_host is not None and not sharded:
+            return int(flag_host) != 0
         flag = flow._status[1:2].clone()
-        if self.shard and torch.distributed.is_available() and torch.distributed.is_initialized():
+        if sharded:
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
         return int(flag.item()) != 0
 
@@ -695,9 +700,11 @@ class FlowProposal:
             if self.flow.model._status is not None:
                 self.flow.model._status.zero_()
         self._status_hold = True
+        self._f16_discarded = False
         try:
             self._populate(worst_point, n_samples, plot, r, max_samples, injected)
-            if self._f16_range_left():
+            if self._f16_discarded:  # seen by _finish_population BEFORE it touched the pool
+                self._f16_discarded = False
                 self.flow.model.note_f16_overflow()  # raises F16RangeError unless "auto"
                 if injected is not None:
                     raise RuntimeError("injected latents left the f16 range of the split-f16 kernels")
@@ -880,12 +887,23 @@ class FlowProposal:
             per_pass = n_accepted / passes if n_accepted else per_pass * 0.5
         n_proposed = passes * n
         self._draw_counter += n_proposed
-        kept = buf["x_acc"][: min(n_accepted, n_samples)]
-        log_l = None
-        if self._ll_spec is not None and kept.shape[0]:
-            log_l = self._device_log_likelihood(kept.contiguous()).cpu().numpy()
-        self.x = array_to_live_points_fast(kept.cpu().numpy(), self.names)
-        self._finish_population(st, n_accepted, n_proposed, log_l=log_l)
+        # accepted rows, their log-likelihood and the kernel's range flag come to the host through pinned
+        # buffers behind ONE synchronisation (three pageable .cpu() copies, each its own round trip, before)
+        m = min(n_accepted, n_samples)
+        kept = buf["x_acc"][:m]
+        if buf.get("x_host") is None or buf["x_host"].shape[0] < n_samples:
+            buf["x_host"] = torch.empty((n_samples, self.dims), dtype=torch.float64).pin_memory()
+            buf["ll_host"] = torch.empty(n_samples, dtype=torch.float64).pin_memory()
+            buf["status_host"] = torch.zeros(4, dtype=torch.int32).pin_memory()
+        buf["x_host"][:m].copy_(kept, non_blocking=True)
+        with_ll = self._ll_spec is not None and m > 0
+        if with_ll:
+            buf["ll_host"][:m].copy_(self._device_log_likelihood(kept), non_blocking=True)
+        buf["status_host"].copy_(status, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        log_l = buf["ll_host"][:m].numpy().copy() if with_ll else None
+        self.x = array_to_live_points_fast(buf["x_host"][:m].numpy(), self.names)
+        self._finish_population(st, n_accepted, n_proposed, log_l=log_l, f16_flag=int(buf["status_host"][1]))
 
     #: bytes of candidate rows a sharded train may keep on the device (its passes are independent until
     #: the stop test, so their rows wait for ONE exchange of the maxima and ONE of the counts)
@@ -1243,7 +1261,14 @@ class FlowProposal:
         n_acc = int(buf["n_acc"].item())
         return n_acc, buf["x_acc"][: min(n_acc, n_samples)].cpu().numpy()
 
-    def _finish_population(self, st, n_accepted, n_proposed, log_l=None):
+    def _finish_population(self, st, n_accepted, n_proposed, log_l=None, f16_flag=None):
+        # A population whose draw kernel left the f16 range is discarded HERE, before it has any side
+        # effect - no likelihood call on its (in-bounds but invalid) rows, no permutation drawn from the host
+        # generator, counters and acceptance untouched: populate() redraws it in float32.
+        if self._f16_range_left(f16_flag):
+            self._f16_discarded = True
+            self.populated = False
+            return
         self.samples = self.convert_to_samples(self.x)
         self.population_time += datetime.datetime.now() - st
         if log_l is not None:  # evaluated on the device with the rows (nsa_log_likelihood)

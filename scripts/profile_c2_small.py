@@ -48,10 +48,10 @@ def main():
                               path=prop.last_populate_path)))
         pr = cProfile.Profile()
         pr.enable()
-        for _ in range(10):
+        for _ in range(200):
             prop.populate(None, n_samples=2000, max_samples=10**12)
         pr.disable()
-        pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
+        pstats.Stats(pr).sort_stats("tottime").print_stats(28)
 
 
 if __name__ == "__main__":

@@ -644,3 +644,40 @@ def test_launch_geometry_is_tuned_once_and_never_changes_the_result(monkeypatch)
     for x, q in ((x2, q2), (x22, q22), (xs, qs), (xa, qa), (xb, qb)):
         assert torch.equal(x, x3)
         assert torch.equal(torch.nan_to_num(q, nan=12345.0), torch.nan_to_num(q3, nan=12345.0))
+
+
+@pytest.mark.parametrize("drawsize", [2000, 40000])
+def test_a_population_discarded_for_the_f16_range_has_no_side_effects(drawsize, monkeypatch):
+    """A population whose draw kernel reports an operand beyond the f16 range is drawn again in float32.
+    The discarded one must leave nothing behind but its Philox offsets: no likelihood call on its rows, no
+    permutation taken from the host generator, no counters (both device-side loops: the small-passes one and
+    the big-batch one).  The flag is forced here; the kernel's own report is covered in test_gpu_flows."""
+    def make():
+        prop, _ = build(6, "nsf", dict(n_neurons=16, n_blocks=2), model_cls=GaussianModel, poolsize=300,
+                        drawsize=drawsize)
+        prop._ll_spec = None  # host likelihood: every call is visible
+        calls = []
+        orig = prop.model.batch_evaluate_log_likelihood
+        monkeypatch.setattr(prop.model, "batch_evaluate_log_likelihood", lambda x: (calls.append(len(x)), orig(x))[1])
+        return prop, calls
+
+    twin, twin_calls = make()
+    twin.populate(None, n_samples=300, max_samples=10**9)
+
+    prop, calls = make()
+    real = prop._f16_range_left
+    forced = [True]
+
+    def flag(flag_host=None):
+        if forced[0]:
+            forced[0] = False
+            return True
+        return real(flag_host)
+
+    monkeypatch.setattr(prop, "_f16_range_left", flag)
+    monkeypatch.setattr(prop.flow.model, "note_f16_overflow", lambda: None)
+    prop.populate(None, n_samples=300, max_samples=10**9)
+    assert prop.populated and prop.populated_count == 1 and prop.samples.size == 300
+    assert len(calls) == 1 and len(twin_calls) == 1            # one likelihood call, on the kept population
+    assert prop.indices == twin.indices                         # one permutation from the host generator
+    assert prop._draw_counter > twin._draw_counter              # the discarded draws are not drawn again
