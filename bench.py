@@ -84,10 +84,11 @@ def build_proposal(rank, world, device, scaling="strong"):
     return prop
 
 
-def time_draw_kernel(prop, launches=10, precision=None):
-    """Average duration of the dominant kernel (fused draw+inverse-flow), HIP events
-    on the stream it is launched on (torch's current stream)."""
-    n = DRAWSIZE
+def time_draw_kernel(prop, launches=10, precision=None, rows=None):
+    """Average duration of the dominant kernel (fused draw+inverse-flow) over ``rows`` rows (default: the
+    whole 1e6-row batch; for N > 1 the rank's share of it - what a launch of the sharded run really
+    processes), HIP events on the stream it is launched on (torch's current stream)."""
+    n = DRAWSIZE if rows is None else int(rows)
     keep = prop.precision
     if precision is not None:
         prop.precision = precision
@@ -437,12 +438,14 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms, kernel_ms_min = time_draw_kernel(prop)
+    # the roofline kernel is timed on what ONE launch of this run processes: the rank's share of the batch
+    rows_per_launch = batch // world
+    kernel_ms, kernel_ms_min = time_draw_kernel(prop, rows=rows_per_launch)
     geometry = LAST_GEOMETRY
     precision = prop.flow.model.effective_precision  # what populate() actually ran ("auto" resolved by the flow)
-    achieved = FLOPS_PER_ROW * DRAWSIZE / (kernel_ms * 1e-3) / 1e12
-    f32_ms, _ = time_draw_kernel(prop, precision="f32")
-    f32_achieved = FLOPS_PER_ROW * DRAWSIZE / (f32_ms * 1e-3) / 1e12
+    achieved = FLOPS_PER_ROW * rows_per_launch / (kernel_ms * 1e-3) / 1e12
+    f32_ms, _ = time_draw_kernel(prop, precision="f32", rows=rows_per_launch)
+    f32_achieved = FLOPS_PER_ROW * rows_per_launch / (f32_ms * 1e-3) / 1e12
 
     traffic, traffic_detail = (None, "skipped (--no-pmc or N > 1)")
     if rank == 0 and world == 1 and not args.no_pmc:
@@ -493,12 +496,13 @@ def main():
                 # bytes are 264 MB (x as float64 + log_q)
                 "traffic": traffic,
                 "traffic_detail": traffic_detail,
-                "algorithmic_bytes": 264.0e6,
+                "algorithmic_bytes": 264.0 * rows_per_launch,
                 "kernel_ms_avg": kernel_ms,
                 "kernel_ms_min": kernel_ms_min,
                 # chosen by the library (big batches of the 16-bit modes: round-count estimate of nsa_big_batch_geometry, nsa_api.hip)
                 "launch_geometry": geometry,
-                "rows_per_launch": DRAWSIZE,
+                "rows_per_launch": rows_per_launch,
+                "rows_per_launch_note": "the whole batch at N = 1; for N > 1 this rank's share of it (rank 0 times its own kernel)",
                 "flops_per_row": FLOPS_PER_ROW,
                 "note": "algorithmic FLOPs (one product per weight); the split 16-bit modes issue 3 MFMAs "
                         "per product and are bound by the spline's VALU/transcendental work, not by the matrix pipe",

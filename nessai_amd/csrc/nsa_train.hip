@@ -1430,10 +1430,24 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
             o.p = o.u + (long long)L * n * H;
             for (int i = 0; i < 4 + 4 * L; ++i) o.off[i] = (int)rr[5 + i];
           }
-          m.a.np = np_max;
-          (void)tr_forward_run(transform, K, m, count, s);
-          b = bb - 1;
-          continue;
+          // The loop can stop early (a coupling that does not fit the second generation, or whose rows are
+          // wider than the run's tile): only run lengths 6 / 4 / 2 / 1 are instantiated, so a run of 3 or 5
+          // is cut back to the next instantiated length - launching the 6-coupling kernel on it would walk
+          // the zeroed records behind it - and the couplings cut off start the next run.
+          if (count >= 1) {
+            const int keep = count >= 6 ? 6 : (count >= 4 ? 4 : (count >= 2 ? 2 : 1));
+            if (keep != count) {
+              count = keep;
+              bb = b + count;
+              np_max = 0;
+              for (int i = 0; i < count; ++i) np_max = m.one[i].np > np_max ? m.one[i].np : np_max;
+              for (int i = count; i < TRF2_MAXC; ++i) memset(&m.one[i], 0, sizeof(m.one[i]));
+            }
+            m.a.np = np_max;
+            (void)tr_forward_run(transform, K, m, count, s);
+            b = bb - 1;
+            continue;
+          }
         }
         (void)tr_fused_coupling(false, transform, K, a, s);
         continue;

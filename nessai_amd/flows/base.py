@@ -503,17 +503,25 @@ class _ImageSource:
     every later one is rebuilt ON THE DEVICE from the flat parameter vector by one gather launch
     (``nsa_repack_image`` with the map of ``pack.repack_map``, built the second time the structure is
     seen).  The images and maps live on the flow (``flow._repack``) across changes of the weights; the
-    structure key holds what the constants depend on: the permutations and train / eval mode."""
+    structure key holds what the constants depend on - the device and the permutations - and the entries are
+    kept per train / eval mode."""
 
     def __init__(self, flow, device, epoch):
         self.flow, self.device, self.epoch = flow, device, epoch
         self._desc = None
         self._params = None
         store = flow.__dict__.setdefault("_repack", {})
-        perms = tuple((b.data_ptr(), b._version) for name, b in flow.named_buffers() if name.endswith("_permutation"))
-        self.structure = (str(device), flow.training, perms)
-        for key in [k for k in store if k[0] != self.structure]:
-            del store[key]  # another structure: its images are of no use any more
+        # The permutations are identified by (storage address, version counter) of their buffers; the buffers
+        # themselves are held with the entries (`_perm_refs`), so that a module that REBINDS its permutation to a
+        # new tensor cannot get the old address - and a stale image - back from the allocator.  One entry per
+        # train / eval mode: a flow that alternates between the two keeps both (and their device maps).
+        perm_buffers = [b for name, b in flow.named_buffers() if name.endswith("_permutation")]
+        perms = tuple((b.data_ptr(), b._version) for b in perm_buffers)
+        self.structure = (str(device), perms)
+        self.mode = bool(flow.training)
+        for key in [k for k in store if k != "_perm_refs" and k[0] != self.structure]:
+            del store[key]  # other permutations / another device: its images are of no use any more
+        store["_perm_refs"] = perm_buffers
         self.store = store
 
     def desc(self):
@@ -538,7 +546,7 @@ class _ImageSource:
         return self._params
 
     def get(self, precision):
-        key = (self.structure, precision)
+        key = (self.structure, self.mode, precision)
         entry = self.store.get(key)
         flow = self.flow
         if entry is not None and entry["epoch"] == self.epoch:  # built for these weights (e.g. by the probe)
@@ -552,6 +560,11 @@ class _ImageSource:
                     flow.__dict__["_repack_pure"] = True
                 except ValueError:  # LU-linear / batch norm / act norm: derived image words
                     flow.__dict__["_repack_pure"] = pure = False
+            if pure is not False and precision == "f16x3":
+                # the host pack raises for a weight beyond the f16 range (pack.split_f16: `_pack_auto` relies on
+                # it); the device gather would write +-inf halves instead - same rule, checked on the device
+                if not bool(torch.all(torch.abs(self.params()) < pack.F16_LIMIT)):
+                    raise ValueError("precision 'f16x3' needs every weight below 65520 in magnitude")
             if pure is not False:
                 pos, e0, e1, kind = entry["map"]
                 stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -700,7 +700,14 @@ def repack_map(index_desc, precision):
     if precision not in PRECISIONS:
         raise ValueError(f"unknown precision {precision!r}")
     extra = {"_split16": _split_index} if precision in SPLIT16 else {}
-    img_a = pack_flow(dict(index_desc(_INDEX_A), precision=precision, **extra))
+    desc_a = index_desc(_INDEX_A)
+    # the indices travel as float32 VALUES through the packer: exact below 2^24 only (a bigger flow keeps
+    # the host pack - the caller treats ValueError as "no device map")
+    largest = max((float(np.max(w)) for tr in desc_a["transforms"] if tr[0] == "coupling"
+                   for pair in tr[3] for w in pair if np.size(w)), default=0.0)
+    if largest + (_INDEX_B - _INDEX_A) >= float(1 << 24):
+        raise ValueError("too many parameters for the float32-encoded index map")
+    img_a = pack_flow(dict(desc_a, precision=precision, **extra))
     img_b = pack_flow(dict(index_desc(_INDEX_B), precision=precision, **extra))
     if img_a.shape != img_b.shape:
         raise RuntimeError("index images of different sizes")

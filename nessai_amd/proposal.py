@@ -123,6 +123,7 @@ class FlowProposal:
         prior="auto",
         likelihood="auto",
         shard=False,
+        replicate_training=False,
         precision="auto",
         pass_trains=True,
         small_trains=True,
@@ -171,6 +172,8 @@ class FlowProposal:
             raise ValueError("likelihood must be 'auto', 'device' or 'host'")
         self._likelihood_mode = likelihood
         self.shard = shard
+        #: sharded runs: every rank repeats the fit (True) or rank 0 fits and the others receive the flow (False)
+        self.replicate_training = bool(replicate_training)
         self.small_trains = bool(small_trains)
         self._status_hold = False
         #: which loop the last ``populate`` ran: "trains" (device-side loop control), "trains_sharded",
@@ -400,7 +403,17 @@ class FlowProposal:
         rank, world = self._rank_world()
         # every rank writes its own weights file (no race on a shared output directory)
         output = self.output if rank == 0 else os.path.join(self.output, f"rank_{rank}")
-        self.flow.train(x_prime_array, output=output, plot=False)
+        if rank == 0 or self.replicate_training:
+            self.flow.train(x_prime_array, output=output, plot=False)
+        else:
+            # Training does not shard and N identical fits are N times the energy for
+            # one flow: rank 0 fits, the others wait for its weights, buffers and generator states
+            # (_replicate_flow) - they only need to stand where a fit would have left them.
+            if not np.isfinite(x_prime_array).all():
+                raise ValueError("Training data is not finite")
+            os.makedirs(output, exist_ok=True)
+            self.flow.weights_file = os.path.join(output, "model.pt")
+            self.flow.model.eval()
         if world > 1:
             self._replicate_flow()
         self.populated = False
@@ -420,13 +433,15 @@ class FlowProposal:
         """Make rank 0's flow THE flow of a sharded run (training does not
         shard - replicas only).
 
-        Every rank runs the same fit on the same live points, so that the host generators
-        (validation split, pool shuffles) stay in lock step across the replicated samplers, but
-        the fused trainer sums weight gradients with float atomics: the fitted weights differ in
-        the last bits from rank to rank, and a populate sharded over different flows would mix
-        draws from different proposals.  Rank 0's parameters and buffers (batch-norm statistics,
-        permutations) therefore replace everyone's; the rescaling constants, which are exact
-        functions of the live points, are checked to agree."""
+        Rank 0 alone runs the fit (``replicate_training=True``: every rank runs it, the round-3
+        behaviour - the fused trainer sums weight gradients with float atomics, so even identical
+        fits differ in the last bits from rank to rank, and a populate sharded over different flows
+        would mix draws from different proposals).  Rank 0's parameters and buffers (batch-norm
+        statistics, permutations) replace everyone's, and so do the states of the generators a fit
+        advances - the proposal's numpy generator (validation split, epoch bookkeeping) and torch's
+        global CPU generator (epoch shuffles, weight resets) - so that the replicated samplers stay in
+        lock step; the rescaling constants, which are exact functions of the live points, are checked
+        to agree."""
         import torch.distributed as dist
 
         model = self.flow.model
@@ -446,9 +461,10 @@ class FlowProposal:
                     )
         # early stopping may have ended the fits at different epochs: the host generator (epoch
         # shuffles) continues from rank 0's state everywhere
-        state = [self.rng.bit_generator.state]
+        state = [self.rng.bit_generator.state, torch.get_rng_state()]
         dist.broadcast_object_list(state, src=0)
         self.rng.bit_generator.state = state[0]
+        torch.set_rng_state(state[1])
         model._image_key = None  # repack the kernel image from the received weights
         if self.flow.weights_file is not None:
             self.flow.save_weights(self.flow.weights_file)

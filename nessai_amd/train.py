@@ -259,13 +259,16 @@ class Trainer:
         """Host-pinned staging of the epoch loop (permutation up, the two losses down), kept across fits: pinning
         memory is a driver call of the order of a short fit's epoch."""
         cached = getattr(self, "_pinned", None)
-        if cached is None or cached[0].numel() < n_train:
+        if cached is None or cached[0].shape[1] < n_train:
             size = max(n_train, 4096)
-            cached = (torch.empty(size, dtype=torch.int64, pin_memory=True),
+            # TWO pinned permutation buffers, used in turn: the upload of epoch e's permutation may still be
+            # in flight when the look-ahead draws the one of epoch e + 1 (the host only waits for the losses,
+            # which are recorded before that upload in stream order)
+            cached = (torch.empty((2, size), dtype=torch.int64, pin_memory=True),
                       torch.empty(size, dtype=torch.int64, device=self.device),
                       torch.empty(2, dtype=torch.float32, pin_memory=True))
             self._pinned = cached
-        return cached[0][:n_train], cached[1][:n_train], cached[2]
+        return cached[0][:, :n_train], cached[1][:n_train], cached[2]
 
     def _workspace(self, n):
         if self._ws is None or n > self._ws_rows:
@@ -436,9 +439,15 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
     # has drained - the whole running epoch)
     perm_host, perm_dev, losses_host = trainer.pinned_buffers(n_train)
 
+    turn = [0]
+
     def prepare_rows():
-        torch.randperm(n_train, out=perm_host)
-        perm_dev.copy_(perm_host, non_blocking=True)
+        # alternate the pinned buffers: overwriting the one whose asynchronous upload may not have finished
+        # would tear the previous epoch's permutation (rows duplicated or missing, silently)
+        host = perm_host[turn[0]]
+        turn[0] ^= 1
+        torch.randperm(n_train, out=host)
+        perm_dev.copy_(host, non_blocking=True)
         p = perm_dev
         torch.index_select(train_data, 0, p, out=epoch_rows)
         if epoch_w is not None:

@@ -138,3 +138,55 @@ def test_reference_reset_visitors_reach_the_hip_flow():
     seen = []
     flow.apply(lambda m: seen.append(type(m).__name__))
     assert "BatchNorm" in seen and "LULinear" in seen
+
+
+def _egg_info(tmp_path):
+    """The package's metadata as an installer would write it (no install: `setup.py egg_info` into a scratch
+    directory), read back through importlib.metadata."""
+    import importlib.metadata
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "setup.py", "-q", "egg_info", "--egg-base", str(tmp_path)], cwd=root, check=True,
+                   env=dict(os.environ, NESSAI_AMD_SKIP_HIP_BUILD="1"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    info = [p for p in os.listdir(tmp_path) if p.endswith(".egg-info")]
+    assert len(info) == 1
+    return importlib.metadata.Distribution.at(os.path.join(tmp_path, info[0]))
+
+
+def test_the_package_registers_the_proposal_under_the_reference_s_plugin_group(tmp_path):
+    """pyproject.toml: `mi355x = nessai_amd.plugin:MI355XFlowProposal` in the `nessai.proposals` group - the name
+    the reference's `get_flow_proposal_class("mi355x")` looks up (src/nessai/proposal/utils.py:97-107)."""
+    dist = _egg_info(tmp_path)
+    assert dist.metadata["Name"] == "nessai-amd"
+    eps = [e for e in dist.entry_points if e.group == "nessai.proposals"]
+    assert [(e.name, e.value) for e in eps] == [("mi355x", "nessai_amd.plugin:MI355XFlowProposal")]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/nessai"), reason="reference tree not present")
+def test_the_reference_resolves_the_registered_name(tmp_path, monkeypatch):
+    """With the metadata on the path, the reference's own lookup turns `flow_proposal_class="mi355x"` into the
+    delegating subclass (the reference reads the group through `nessai.utils.entry_points.get_entry_points`)."""
+    import sys
+
+    from oracle import reference_harness
+
+    reference_harness.install()
+    sys.path.insert(0, reference_harness.REFERENCE_SRC)
+    dist = _egg_info(tmp_path)
+    monkeypatch.syspath_prepend(str(tmp_path))
+    import importlib
+    import importlib.metadata
+
+    importlib.invalidate_caches()
+    found = [e for e in importlib.metadata.entry_points(group="nessai.proposals") if e.name == "mi355x"]
+    assert found and found[0].value == "nessai_amd.plugin:MI355XFlowProposal", dist.entry_points
+    import nessai.proposal.utils as ref_utils
+    from nessai.proposal import FlowProposal as ReferenceFlowProposal
+
+    assert "mi355x" in ref_utils.available_external_flow_proposal_classes()
+    cls = ref_utils.get_flow_proposal_class("mi355x")
+    from nessai_amd.plugin import MI355XFlowProposal
+
+    assert cls is MI355XFlowProposal and issubclass(cls, ReferenceFlowProposal)

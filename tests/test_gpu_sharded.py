@@ -123,9 +123,10 @@ def _mode_worker(rank, world, port, out_dir, extra, worst):
     dist.destroy_process_group()
 
 
-def _train_worker(rank, world, port, out_dir):
-    """Both ranks fit the same live points (the fused trainer is not bit-reproducible), then
-    populate sharded: the flow, the pool and the host generator must agree afterwards."""
+def _train_worker(rank, world, port, out_dir, replicate):
+    """Rank 0 fits the live points (``replicate``: both ranks do - the fused trainer is not
+    bit-reproducible), then populate sharded: the flow, the pool and the host generators must agree
+    afterwards."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -140,7 +141,7 @@ def _train_worker(rank, world, port, out_dir):
         model, rng=np.random.default_rng(5),
         flow_config=dict(ftype="nsf", n_neurons=16, n_blocks=2, n_layers=1, num_bins=4),
         training_config=dict(max_epochs=40, patience=40, batch_size=250),
-        poolsize=200, drawsize=20_000, device_seed=9, shard=True,
+        poolsize=200, drawsize=20_000, device_seed=9, shard=True, replicate_training=replicate,
         output=os.path.join(out_dir, "run"),
     )
     prop.initialise()
@@ -150,22 +151,24 @@ def _train_worker(rank, world, port, out_dir):
             for p_ in prop.flow.model.parameters():
                 p_.add_(0.01 * torch.randn_like(p_))
     prop.train(live)
+    assert prop.training_count == 1 and not prop.flow.model.training
     flat = prop.flow.model.trainer().flat.detach().cpu().numpy()
     prop.populate(live[0], n_samples=200, max_samples=10**8)
     x = np.stack([prop.x[n] for n in prop.names], axis=1)
     np.savez(os.path.join(out_dir, f"t{rank}.npz"), flat=flat, x=x, indices=np.asarray(prop.indices),
-             rng=prop.rng.random(4), weights_file=prop.flow.weights_file)
+             rng=prop.rng.random(4), torch_rng=torch.rand(4).numpy(), weights_file=prop.flow.weights_file)
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_sharded_train_leaves_one_flow_on_every_rank(tmp_path):
-    mp.spawn(_train_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("replicate", [False, True])
+def test_sharded_train_leaves_one_flow_on_every_rank(tmp_path, replicate):
+    mp.spawn(_train_worker, args=(2, _free_port(), str(tmp_path), replicate), nprocs=2, join=True)
     a, b = (np.load(tmp_path / f"t{r}.npz") for r in range(2))
     assert np.array_equal(a["flat"], b["flat"])          # rank 0's weights everywhere
     assert np.array_equal(a["x"], b["x"]) and len(a["x"]) == 200
     assert np.array_equal(a["indices"], b["indices"])    # the replicated samplers stay in lock step
-    assert np.array_equal(a["rng"], b["rng"])
+    assert np.array_equal(a["rng"], b["rng"]) and np.array_equal(a["torch_rng"], b["torch_rng"])
     assert str(a["weights_file"]) != str(b["weights_file"])  # one weights file per rank
     for r, d in enumerate((a, b)):
         state = torch.load(str(d["weights_file"]), map_location="cpu", weights_only=True)

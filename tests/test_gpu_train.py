@@ -44,6 +44,12 @@ CASES = {
                   dict(batch_norm_between_layers=True, linear_transform="lu")),
     # plain MLP conditioner (src/nessai/flows/nets.py:12-126), the "MLP" variant of config 2
     "rnvp_c2_mlp": (RealNVP, O.RealNVP, (16, 32, 4, 2), dict(net="mlp")),
+    # per-layer masks (flows/realnvp.py:100-110) whose fourth coupling has more identity features than the run's
+    # tile is wide: the forward run of the second-generation kernels stops after THREE couplings, a length that is
+    # not instantiated (6 / 4 / 2 / 1) and must be cut back to two, not handed to the six-coupling kernel
+    "rnvp_ragged_masks": (RealNVP, O.RealNVP, (40, 8, 5, 1),
+                          dict(mask=[[-1.0] * 4 + [1.0] * 36] * 3 + [[-1.0] * 30 + [1.0] * 10] + [[-1.0] * 4 + [1.0] * 36],
+                               linear_transform=None, batch_norm_between_layers=False)),
     "rnvp_mlp_deep_tanh": (RealNVP, O.RealNVP, (5, 12, 2, 3),
                            dict(net="mlp", linear_transform="permutation", batch_norm_between_layers=False,
                                 activation=torch.tanh)),
