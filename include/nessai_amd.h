@@ -183,6 +183,23 @@ NSA_API int nsa_repack_image(long long n_words, const int* pos_dev, const int* e
                      const unsigned char* kind_dev, const float* params_dev, int precision,
                      void* image_dev, void* stream);
 
+/* The probe of the measured precision policy (precision = "auto"; no reference counterpart - the reference
+ * has one arithmetic, torch float32: flows/base.py:236-245 is the log_prob the modes are held to): after
+ * every change of the weights a few thousand latent rows go through the float32 kernels and through each
+ * 16-bit candidate in both directions, and a candidate is kept only if it agrees.
+ *   nsa_probe_compare  out_dev[0] (a double, zeroed by the caller) = max over the n rows of
+ *                      max(|ld - ld_ref| / max(|log N(z) - ld_ref|, 1e-3), |lp - lp_ref| / max(|lp_ref|, 1e-3)),
+ *                      z_dev [n][D] the probe latents, ld the inverse pass's log|det J|, lp the forward
+ *                      pass's log_prob; +inf if either holds a NaN.  In float64.
+ *   nsa_probe_nudge    x_out = x_in moved one ulp away from zero (the "inputs one ulp further out" twin
+ *                      that measures the float32 kernel's own sensitivity)
+ *   nsa_probe_range    flag_dev[0] |= 1 when a value is NaN or >= limit in magnitude (the weights of a
+ *                      split-f16 image must stay below 65520: pack.split_f16 raises on the host) */
+NSA_API int nsa_probe_compare(long long n, int D, const float* z_dev, const float* ld_dev, const float* lp_dev,
+                              const float* ld_ref_dev, const float* lp_ref_dev, double* out_dev, void* stream);
+NSA_API int nsa_probe_nudge(long long n, const float* x_in_dev, float* x_out_dev, void* stream);
+NSA_API int nsa_probe_range(long long n, const float* values_dev, float limit, int* flag_dev, void* stream);
+
 /* The truncation rules that act AFTER the flow, for the trains of passes below
  * (src/nessai/proposal/flowproposal/truncation.py:368-446; nsa_populate_truncate is the one-pass form):
  *   min_log_q        keep log_q > min_log_q (-inf: rule off)

@@ -858,6 +858,36 @@ extern "C" int nsa_repack_image(long long n_words, const int* pos_dev, const int
 }
 
 // A train of SMALL passes as one draw launch + two tail launches (see include/nessai_amd.h).
+extern "C" hipError_t nsa_launch_probe_compare(long long, int, const float*, const float*, const float*, const float*,
+                                               const float*, unsigned long long*, hipStream_t);
+extern "C" hipError_t nsa_launch_probe_nudge(long long, const float*, float*, hipStream_t);
+extern "C" hipError_t nsa_launch_probe_range(long long, const float*, float, int*, hipStream_t);
+
+extern "C" int nsa_probe_compare(long long n, int D, const float* z_dev, const float* ld_dev, const float* lp_dev,
+                                 const float* ld_ref_dev, const float* lp_ref_dev, double* out_dev, void* stream) {
+  if (n < 0 || D < 1 || z_dev == nullptr || ld_dev == nullptr || lp_dev == nullptr || ld_ref_dev == nullptr ||
+      lp_ref_dev == nullptr || out_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_probe_compare: bad argument");
+  if (n == 0) return NSA_OK;
+  hipError_t e = nsa_launch_probe_compare(n, D, z_dev, ld_dev, lp_dev, ld_ref_dev, lp_ref_dev,
+                                          (unsigned long long*)out_dev, (hipStream_t)stream);
+  return e == hipSuccess ? NSA_OK : nsa_fail(NSA_E_HIP, "nsa_probe_compare: %s", hipGetErrorString(e));
+}
+
+extern "C" int nsa_probe_nudge(long long n, const float* x_in_dev, float* x_out_dev, void* stream) {
+  if (n < 0 || x_in_dev == nullptr || x_out_dev == nullptr) return nsa_fail(NSA_E_ARG, "nsa_probe_nudge: bad argument");
+  if (n == 0) return NSA_OK;
+  hipError_t e = nsa_launch_probe_nudge(n, x_in_dev, x_out_dev, (hipStream_t)stream);
+  return e == hipSuccess ? NSA_OK : nsa_fail(NSA_E_HIP, "nsa_probe_nudge: %s", hipGetErrorString(e));
+}
+
+extern "C" int nsa_probe_range(long long n, const float* values_dev, float limit, int* flag_dev, void* stream) {
+  if (n < 0 || values_dev == nullptr || flag_dev == nullptr) return nsa_fail(NSA_E_ARG, "nsa_probe_range: bad argument");
+  if (n == 0) return NSA_OK;
+  hipError_t e = nsa_launch_probe_range(n, values_dev, limit, flag_dev, (hipStream_t)stream);
+  return e == hipSuccess ? NSA_OK : nsa_fail(NSA_E_HIP, "nsa_probe_range: %s", hipGetErrorString(e));
+}
+
 extern "C" hipError_t nsa_launch_small_train(long long, int, int, const double*, const double*, double,
                                              unsigned long long, unsigned long long, const double*, long long, double*,
                                              long long*, long long, double*, long long*, hipStream_t);

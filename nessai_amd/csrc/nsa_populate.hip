@@ -412,6 +412,74 @@ __global__ void __launch_bounds__(1024) nsa_small_commit_kernel(int n_passes, in
   }
 }
 
+// ---- the measured precision policy's probe (HipFlow._pack_auto): one comparison kernel instead of a dozen
+// torch element-wise operators, each of which loads its own code object the first time it runs (20-120 ms
+// apiece: the first populate() of a process spent ~450 ms there) ------------------------------------------------
+// out[0] = max over rows of max(|ld - ld_ref| / max(|log N(z) - ld_ref|, 1e-3), |lp - lp_ref| / max(|lp_ref|, 1e-3))
+// as a sign-ordered int64 key of the double (NaN -> +inf: a probe that produced one never passes).
+__global__ void __launch_bounds__(256) nsa_probe_compare_kernel(long long n, int D, const float* __restrict__ z,
+                                                                const float* __restrict__ ld, const float* __restrict__ lp,
+                                                                const float* __restrict__ ld_ref,
+                                                                const float* __restrict__ lp_ref,
+                                                                unsigned long long* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double err = 0.0;
+  if (i < n) {
+    double r2 = 0.0;
+    for (int c = 0; c < D; ++c) {
+      const double v = (double)z[i * D + c];
+      r2 += v * v;
+    }
+    const double log_pz = -0.5 * r2 - 0.5 * D * 1.8378770664093453;  // log(2 pi)
+    const double lq_ref = log_pz - (double)ld_ref[i];
+    const double a = fabs((double)ld[i] - (double)ld_ref[i]) / fmax(fabs(lq_ref), 1e-3);
+    const double b = fabs((double)lp[i] - (double)lp_ref[i]) / fmax(fabs((double)lp_ref[i]), 1e-3);
+    err = fmax(a, b);
+    if (a != a || b != b) err = __builtin_huge_val();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) err = fmax(err, __shfl_xor(err, o));
+  if ((threadIdx.x & 63) == 0 && err > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(err));  // err >= 0: bit order = value order
+}
+
+// x_out = x_in moved one unit in the last place away from zero (finite non-zero values; the probe's "same
+// flow, inputs one ulp further out" twin)
+__global__ void __launch_bounds__(256) nsa_probe_nudge_kernel(long long n, const float* __restrict__ x_in,
+                                                              float* __restrict__ x_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned u = __float_as_uint(x_in[i]);
+  const unsigned mag = u & 0x7fffffffu;
+  x_out[i] = __uint_as_float((mag != 0u && mag < 0x7f7fffffu) ? u + 1u : u);
+}
+
+// flag[0] |= 1 when a value is NaN or at / beyond `limit` in magnitude (the weights of a split-f16 image)
+__global__ void __launch_bounds__(256) nsa_probe_range_kernel(long long n, const float* __restrict__ v, float limit,
+                                                              int* __restrict__ flag) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool bad = i < n && !(fabsf(v[i]) < limit);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_probe_compare(
+    long long n, int D, const float* z, const float* ld, const float* lp, const float* ld_ref, const float* lp_ref,
+    unsigned long long* out, hipStream_t stream) {
+  hipLaunchKernelGGL(nsa_probe_compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, D, z, ld, lp,
+                     ld_ref, lp_ref, out);
+  return hipGetLastError();
+}
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_probe_nudge(long long n, const float* x_in,
+                                                                                  float* x_out, hipStream_t stream) {
+  hipLaunchKernelGGL(nsa_probe_nudge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, x_in, x_out);
+  return hipGetLastError();
+}
+extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_probe_range(long long n, const float* v,
+                                                                                  float limit, int* flag,
+                                                                                  hipStream_t stream) {
+  hipLaunchKernelGGL(nsa_probe_range_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, v, limit, flag);
+  return hipGetLastError();
+}
+
 extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_small_train(
     long long n, int D, int n_passes, const double* log_q_many, const double* log_prior_many, double log_prior_const,
     unsigned long long seed, unsigned long long row_offset, const double* x64_many, long long cap, double* stage,

@@ -282,23 +282,36 @@ class HipFlow(BaseFlow):
         fingerprint = self._fingerprint()
         n, d = self.AUTO_PROBE_ROWS, self.features
         self.probe_errors = {}
+        _count(self, "probe")
         chosen = "f32"
+        # The probe's own arithmetic is ONE kernel of the library (nsa_probe_compare: float64, max over the
+        # rows of the two relative differences); written with torch operators it loaded a dozen of torch's
+        # code objects the first time it ran - ~450 ms of the first populate() of a process.
+        L = lib.load()
+        stream = lib.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         z = torch.randn(n, d, generator=torch.Generator().manual_seed(20260930)).to(device)
         status = torch.zeros(4, dtype=torch.int32, device=device)
-        log_pz = -0.5 * (z.double() ** 2).sum(dim=1) - 0.5 * d * math.log(2.0 * math.pi)
+        errs_dev = torch.zeros(4, dtype=torch.float64, device=device)  # [candidate, one-ulp twin]
 
         def run(precision, z_in, x_fwd=None):
             _, header_t, image_dev = images.get(precision)
             x, ld = torch.ops.nessai_amd.flow_run(z_in, image_dev, header_t, DIR_INVERSE, MODE_APPLY, True, status,
                                                   self.waves_per_group, self.max_groups)
-            over = status[1:2].clone()
             _, lp = torch.ops.nessai_amd.flow_run(x if x_fwd is None else x_fwd, image_dev, header_t, DIR_FORWARD,
                                                   MODE_LOGPROB, False, status, self.waves_per_group,
                                                   self.max_groups)
-            return x, ld.double(), lp.double(), over + status[1:2]
+            return x, ld, lp
 
-        def rel(a, b, scale):
-            return ((a - b).abs() / scale.abs().clamp_min(1e-3)).max()
+        def compare(ld, lp, ref, slot):
+            """max relative difference of (log|det J| of the inverse pass, measured on log q; log_prob) -> errs_dev[slot]"""
+            errs_dev[slot : slot + 1].zero_()
+            lib.check(L.nsa_probe_compare(n, d, lib.ptr(z), lib.ptr(ld), lib.ptr(lp), lib.ptr(ref[1]), lib.ptr(ref[2]),
+                                          lib.ptr(errs_dev[slot:]), stream), "nsa_probe_compare")
+
+        def nudged(t):
+            out = torch.empty_like(t)
+            lib.check(L.nsa_probe_nudge(t.numel(), lib.ptr(t), lib.ptr(out), stream), "nsa_probe_nudge")
+            return out
 
         ref = noise = None
         for p in auto_candidates(self):
@@ -310,19 +323,17 @@ class HipFlow(BaseFlow):
                 continue
             if ref is None:
                 ref = run("f32", z)
-            x32, ld32, lp32, _ = ref
-            _, ld, lp, over = run(p, z, x_fwd=x32)
-            log_q32 = log_pz - ld32
-            err, over = [float(v) for v in torch.stack([torch.maximum(rel(ld, ld32, log_q32), rel(lp, lp32, lp32)),
-                                                       over[0].double()]).tolist()]  # one read-back
+            status.zero_()
+            _, ld, lp = run(p, z, x_fwd=ref[0])
+            compare(ld, lp, ref, 0)
+            err, over = float(errs_dev[0].item()), int(status[1].item())
             self.probe_errors[p] = err
             bar = self.AUTO_PROBE_BAR
             if p == "f16x3" and over == 0 and math.isfinite(err) and err > bar:
                 if noise is None:  # the float32 kernel against itself, inputs one ulp further out
-                    inf = torch.full_like(z, math.inf)
-                    _, ld_n, lp_n, _ = run("f32", torch.nextafter(z, inf * z.sign()),
-                                           x_fwd=torch.nextafter(x32, inf * x32.sign()))
-                    noise = float(torch.maximum(rel(ld_n, ld32, log_q32), rel(lp_n, lp32, lp32)))
+                    _, ld_n, lp_n = run("f32", nudged(z), x_fwd=nudged(ref[0]))
+                    compare(ld_n, lp_n, ref, 1)
+                    noise = float(errs_dev[1].item())
                     self.probe_errors["f32_one_ulp"] = noise
                 if math.isfinite(noise):
                     bar = max(bar, self.AUTO_NOISE_FACTOR * noise)
@@ -554,19 +565,19 @@ class _ImageSource:
         pure = flow.__dict__.get("_repack_pure")
         if entry is not None and pure is not False and os.environ.get("NESSAI_AMD_DEVICE_REPACK", "1") != "0":
             if "map" not in entry:
-                try:
-                    pos, e0, e1, kind = pack.repack_map(lambda off: M.describe(flow, index_offset=off), precision)
-                    entry["map"] = tuple(torch.from_numpy(a).to(self.device) for a in (pos, e0, e1, kind))
-                    flow.__dict__["_repack_pure"] = True
-                except ValueError:  # LU-linear / batch norm / act norm: derived image words
-                    flow.__dict__["_repack_pure"] = pure = False
+                pure = self._build_map(entry, precision)
             if pure is not False and precision == "f16x3":
                 # the host pack raises for a weight beyond the f16 range (pack.split_f16: `_pack_auto` relies on
                 # it); the device gather would write +-inf halves instead - same rule, checked on the device
-                if not bool(torch.all(torch.abs(self.params()) < pack.F16_LIMIT)):
+                flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                lib.check(lib.load().nsa_probe_range(self.params().numel(), lib.ptr(self.params()), pack.F16_LIMIT,
+                                                     lib.ptr(flag), lib.c_void_p(stream)), "nsa_probe_range")
+                if int(flag.item()):
                     raise ValueError("precision 'f16x3' needs every weight below 65520 in magnitude")
             if pure is not False:
                 pos, e0, e1, kind = entry["map"]
+                _count(flow, "device_repack")
                 stream = torch.cuda.current_stream(self.device).cuda_stream
                 rc = lib.load().nsa_repack_image(
                     pos.numel(), lib.ptr(pos), lib.ptr(e0), lib.ptr(e1), lib.ptr(kind), lib.ptr(self.params()),
@@ -575,12 +586,38 @@ class _ImageSource:
                 lib.check(rc, "nsa_repack_image")
                 entry["epoch"] = self.epoch
                 return entry["header"], entry["header_t"], entry["image"]
+        _count(flow, "host_pack")
         image = pack.pack_flow(dict(self.desc(), precision=precision))
         header = (lib.ctypes.c_uint32 * pack.HEADER_WORDS)(*image[: pack.HEADER_WORDS].tolist())
         entry = dict(header=header, header_t=ops.header_tensor(header),
                      image=torch.from_numpy(image.view(np.int32)).to(self.device), epoch=self.epoch)
         self.store[key] = entry
+        # `flow._repack_eager` (set by FlowProposal.initialise): the map of the device-side rebuild is computed
+        # WITH the first host pack instead of at the second sight of the structure - a sampler retrains the flow
+        # and would otherwise meet those two host packs (~100 ms for config 3) inside a populate() of the run
+        if (flow.__dict__.get("_repack_eager") and pure is not False
+                and os.environ.get("NESSAI_AMD_DEVICE_REPACK", "1") != "0"):
+            self._build_map(entry, precision)
         return entry["header"], entry["header_t"], entry["image"]
+
+    def _build_map(self, entry, precision):
+        """``entry["map"]`` (``pack.repack_map`` on the device) or ``False`` for a flow whose image words are derived."""
+        flow = self.flow
+        try:
+            pos, e0, e1, kind = pack.repack_map(lambda off: M.describe(flow, index_offset=off), precision)
+            entry["map"] = tuple(torch.from_numpy(a).to(self.device) for a in (pos, e0, e1, kind))
+            flow.__dict__["_repack_pure"] = True
+            return True
+        except ValueError:  # LU-linear / batch norm / act norm: derived image words
+            flow.__dict__["_repack_pure"] = False
+            return False
+
+
+def _count(flow, what):
+    """``flow.image_stats``: how the kernel images of this flow were built so far (``host_pack`` /
+    ``device_repack``, ``probe`` = precision probes of ``"auto"``) - read by the profiling scripts."""
+    stats = flow.__dict__.setdefault("image_stats", {})
+    stats[what] = stats.get(what, 0) + 1
 
 
 def _no_context(context):

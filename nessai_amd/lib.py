@@ -92,6 +92,9 @@ SIGNATURES = {
     "nsa_populate_train_commit": (c_int, [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsa_populate_sumexp": (c_int, [c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsa_repack_image": (c_int, [c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nsa_probe_compare": (c_int, [c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsa_probe_nudge": (c_int, [c_ll, c_void_p, c_void_p, c_void_p]),
+    "nsa_probe_range": (c_int, [c_ll, c_void_p, c_float, c_void_p, c_void_p]),
     "nsa_importance_draw": (
         c_int,
         [c_void_p, c_void_p, c_ll, c_void_p, c_ull, c_ull, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -26,6 +26,7 @@ import datetime
 import math
 import logging
 import os
+import time
 
 import numpy as np
 import torch
@@ -176,6 +177,8 @@ class FlowProposal:
         self.replicate_training = bool(replicate_training)
         self.small_trains = bool(small_trains)
         self._status_hold = False
+        self.timing = None  # NESSAI_AMD_TIMING=1: seconds per phase of the last populate() (FlowProposal._mark)
+        self._t_last = 0.0
         #: which loop the last ``populate`` ran: "trains" (device-side loop control), "trains_sharded",
         #: "accumulate" (device arena), "accumulate_host" or "passes" (one synchronisation per pass)
         self.last_populate_path = None
@@ -325,6 +328,13 @@ class FlowProposal:
                 raise ValueError(f"Unknown device likelihood {spec[0]!r}")
         self.populated = False
         self.initialised = True
+        # One-time device set-up, here rather than inside the first populate() of a run: the flow's kernel
+        # images (host pack), the maps for rebuilding them on the device after every later fit, and a first
+        # run of the precision probe's kernels.  A sampler then pays per training only the device-side
+        # rebuild + probe (~1.5 ms for config 3; profiles/r04_ns_run_c3.json).
+        self.flow.model.__dict__["_repack_eager"] = True
+        with torch.no_grad():
+            self._prepare_flow()
 
     # -- reparameterisation (nessai_amd.reparam) -----------------------------------
 
@@ -717,6 +727,9 @@ class FlowProposal:
                 self.flow.model._status.zero_()
         self._status_hold = True
         self._f16_discarded = False
+        # NESSAI_AMD_TIMING=1: where this call's wall time goes (synchronised phase marks; profiling only)
+        self.timing = {} if os.environ.get("NESSAI_AMD_TIMING") == "1" else None
+        self._t_last = time.perf_counter()
         try:
             self._populate(worst_point, n_samples, plot, r, max_samples, injected)
             if self._f16_discarded:  # seen by _finish_population BEFORE it touched the pool
@@ -729,6 +742,15 @@ class FlowProposal:
                 self._populate(worst_point, n_samples, plot, r, max_samples, injected)
         finally:
             self._status_hold = False
+
+    def _mark(self, phase):
+        """Profiling (``NESSAI_AMD_TIMING=1``): time since the last mark, device drained, added to ``timing[phase]``."""
+        if self.timing is None:
+            return
+        torch.cuda.synchronize(self.device)
+        now = time.perf_counter()
+        self.timing[phase] = self.timing.get(phase, 0.0) + (now - self._t_last)
+        self._t_last = now
 
     def _populate(self, worst_point, n_samples, plot, r, max_samples, injected):
         st = datetime.datetime.now()
@@ -828,8 +850,11 @@ class FlowProposal:
         L = lib.load()
         n = self.drawsize
         self.last_populate_path = "trains"
+        self._mark("rules, radius")
         flow, header, image, status = self._prepare_flow()
+        self._mark("flow image, precision probe")
         buf = self._get_buffers(n, n_samples)
+        self._mark("buffers")
         dev = self.device
         max_train = 64
         if buf.get("state") is None:
@@ -903,6 +928,7 @@ class FlowProposal:
             per_pass = n_accepted / passes if n_accepted else per_pass * 0.5
         n_proposed = passes * n
         self._draw_counter += n_proposed
+        self._mark("passes")
         # accepted rows, their log-likelihood and the kernel's range flag come to the host through pinned
         # buffers behind ONE synchronisation (three pageable .cpu() copies, each its own round trip, before)
         m = min(n_accepted, n_samples)
@@ -919,7 +945,9 @@ class FlowProposal:
         torch.cuda.current_stream(dev).synchronize()
         log_l = buf["ll_host"][:m].numpy().copy() if with_ll else None
         self.x = array_to_live_points_fast(buf["x_host"][:m].numpy(), self.names)
+        self._mark("read-back")
         self._finish_population(st, n_accepted, n_proposed, log_l=log_l, f16_flag=int(buf["status_host"][1]))
+        self._mark("pool (log prior, permutation)")
 
     #: bytes of candidate rows a sharded train may keep on the device (its passes are independent until
     #: the stop test, so their rows wait for ONE exchange of the maxima and ONE of the counts)

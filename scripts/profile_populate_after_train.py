@@ -39,8 +39,12 @@ def main():
         second = 1e3 * (time.perf_counter() - t)
         print(f"rep {rep}: first populate after train {first:.2f} ms, next {second:.2f} ms, precision "
               f"{prop.flow.model.effective_precision}")
+        if rep < 2:
+            s = io.StringIO()
+            pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(12)
+            print(s.getvalue()[:3000])
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(25)
     print(s.getvalue()[:6000])
 
 

@@ -6,6 +6,7 @@ property tests for the flows (``tests/test_flows/test_included_flows.py``)
 are restated on the device path.
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -467,3 +468,59 @@ def test_images_rebuilt_on_the_device_equal_the_host_pack():
         flow.precision = "f16x3"
         with torch.no_grad():
             assert rel_err(flow.log_prob(x).cpu(), ref.log_prob(x.cpu()), floor=1e-3) <= LOG_PROB_RTOL
+
+
+def test_auto_noise_floor_branch_on_a_flow_captured_mid_run():
+    """The loosened branch of ``precision = "auto"`` on REAL weights: ``tests/golden/c3_ns_retrain_noise_floor.npz``
+    is the flow of one retraining of a 60 000-iteration nested-sampling run on config 3 (``scripts/run_ns_c3.py
+    --iterations 60000 --seed 42 --save-branch``; about one training in thirty of such runs lands here) whose probe
+    shows split-f16 1.9e-5 from the float32 kernel - above the 5e-6 bar - while the float32 kernel itself moves
+    by a comparable amount when every probe input moves by ONE ulp: the flow is ill-conditioned there, no float32
+    evaluation is unique to 1e-5.  The documented rule: split-f16 is kept if it is within
+    4 x that one-ulp response and never left the f16 range - and what that buys is checked here against a
+    float64 twin of the oracle: split-f16 is as close to float64 as the exact-float32 kernel and as the float32
+    oracle (``flow.log_prob`` semantics: src/nessai/flows/base.py:236-245)."""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_ns_retrain_noise_floor.npz"))
+    state = {k: torch.from_numpy(gold[k]) for k in gold.files if not k.startswith("__")}
+    torch.manual_seed(0)
+    ref = O.NeuralSplineFlow(32, 64, 6, 2)
+    ref.load_state_dict(state)
+    ref.eval()
+    flow = NeuralSplineFlow(32, 64, 6, 2)
+    flow.load_state_dict(state)
+    flow.to(DEV)
+    flow.eval()
+    flow.precision = "auto"
+    flow.device_image()
+    noise = flow.probe_errors.get("f32_one_ulp")
+    # the rule, on this flow: above the plain bar, inside the noise-floor allowance, kept
+    assert flow.probe_errors["f16x3"] > flow.AUTO_PROBE_BAR and noise is not None
+    assert flow.probe_errors["f16x3"] <= flow.AUTO_NOISE_FACTOR * noise
+    assert flow.effective_precision == "f16x3" and flow._status.tolist()[1] == 0
+    assert abs(flow.probe_errors["f16x3"] - float(gold["__probe_f16x3"])) <= 0.5 * float(gold["__probe_f16x3"])
+
+    # what it means for the results: the probe's own latents through the oracle in float32 and in float64
+    z = torch.randn(flow.AUTO_PROBE_ROWS, 32, generator=torch.Generator().manual_seed(20260930))
+    ref64 = copy.deepcopy(ref).double()
+    with torch.no_grad():
+        x64, ld64 = ref64.inverse(z.double())
+        lp64 = ref64.log_prob(x64)
+        x32, ld32 = ref.inverse(z)
+        lp32 = ref.log_prob(x64.float())
+        out = {}
+        for precision in ("f16x3", "f32"):
+            flow.precision = precision
+            x, ld = flow.inverse(z.to(DEV))
+            lp = flow.log_prob(x64.float().to(DEV))
+            out[precision] = (ld.cpu().double(), lp.cpu().double())
+    log_q64 = (-0.5 * (z.double() ** 2).sum(1) - 16 * np.log(2 * np.pi)) - ld64
+
+    def err(ld, lp):  # the probe's measure, against the float64 twin
+        return max(float(((ld - ld64).abs() / log_q64.abs().clamp_min(1e-3)).max()),
+                   float(((lp - lp64).abs() / lp64.abs().clamp_min(1e-3)).max()))
+
+    e16, e32k, e32o = err(*out["f16x3"]), err(*out["f32"]), err(ld32.double(), lp32.double())
+    print(f"against float64: f16x3 {e16:.2e}, f32 kernel {e32k:.2e}, f32 oracle {e32o:.2e}; probe {flow.probe_errors}")
+    assert max(e32k, e32o) > 3e-6                      # float32 itself is not unique to the bar here ...
+    assert e16 <= 3.0 * max(e32k, e32o)                # ... and split-f16 is float32-class: as close as either
+    assert e16 <= 1e-4                                 # (and nowhere near the 1e-3 of plain 16-bit operands)
