@@ -837,30 +837,31 @@ __device__ __forceinline__ void nsa_dense_op(PIPE& pipe, const uint32_t* op, flo
   const int n_steps = __builtin_amdgcn_readfirstlane((int)op[1]);
   const int n_ot = __builtin_amdgcn_readfirstlane((int)op[2]);
   const int tab_len = (BF ? 16 : 2) * n_steps;
-  const float* st = pipe.template begin<false>();
-  const int* in_tab = (const int*)st;
-  const float* pre = st + tab_len;
-  const float* bias = pre + tab_len;
-  const float* w = bias + 32 * n_ot;
-  if (n_ot == 1) {
-    f32x16 acc[RT][1];
+  // one stage per output tile (up to four: 128 features), each with the gather table, the pre-shift, its
+  // bias and its weights; every tile reads the x tile, so nothing is written back before the last GEMM
+  f32x16 acc[4][RT][1];
+  nsa_static_for<4>([&](auto oc) {
+    constexpr int OT = decltype(oc)::value;
+    if (OT < n_ot) {
+      const float* st = pipe.template begin<false>();
+      const int* in_tab = (const int*)st;
+      const float* pre = st + tab_len;
+      const float* bias = pre + tab_len;
+      const float* w = bias + 32;
 #pragma unroll
-    for (int t = 0; t < RT; ++t) nsa_load_bias<1>(bias, half, acc[t]);
-    if constexpr (BF) nsa_dense_tile16<PREC, 1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc, pipe.amax);
-    else nsa_dense_tile<1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
+      for (int t = 0; t < RT; ++t) nsa_load_bias<1>(bias, half, acc[OT][t]);
+      if constexpr (BF) nsa_dense_tile16<PREC, 1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc[OT], pipe.amax);
+      else nsa_dense_tile<1, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc[OT]);
+      if (OT + 1 < n_ot) pipe.end();
+    }
+  });
+  nsa_static_for<4>([&](auto oc) {
+    constexpr int OT = decltype(oc)::value;
+    if (OT < n_ot) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t) nsa_dense_store(xrow[t], acc[t][0], 0, D, half);
-  } else {
-    f32x16 acc[RT][2];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) nsa_load_bias<2>(bias, half, acc[t]);
-    if constexpr (BF) nsa_dense_tile16<PREC, 2, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc, pipe.amax);
-    else nsa_dense_tile<2, true, RT>(w, in_tab, pre, xrow, n_steps, lane, half, acc);
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int ot = 0; ot < 2; ++ot) nsa_dense_store(xrow[t], acc[t][ot], 32 * ot, D, half);
-  }
+      for (int t = 0; t < RT; ++t) nsa_dense_store(xrow[t], acc[OT][t][0], 32 * OT, D, half);
+    }
+  });
   if (half == 0) {
 #pragma unroll
     for (int t = 0; t < RT; ++t) logdet[t] += nsa_bits_to_float(op[3]);
@@ -1208,8 +1209,11 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
           nsa_coupling<HT, TP, INV, PREC, RT, false>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
         }
       } else if (NSA_ABLATE & 512) {
-        (void)pipe.template begin<false>();
-        pipe.end();
+        const int skip = kind == NSA_OP_DENSE ? __builtin_amdgcn_readfirstlane((int)op[2]) : 1;
+        for (int k = 0; k < skip; ++k) {
+          (void)pipe.template begin<false>();
+          pipe.end();
+        }
       } else if (kind == NSA_OP_DENSE) {
         nsa_dense_op<PREC, RT>(pipe, op, xrow_a, D, lane, half, logdet_a);
       } else {

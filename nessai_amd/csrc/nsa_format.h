@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define NSA_MAGIC 0x3141534e /* "NSA1" */
-#define NSA_VERSION 8
+#define NSA_VERSION 9
 
 // header word indices
 enum {
@@ -86,7 +86,8 @@ enum { NSA_PREC_F32 = 0, NSA_PREC_BF16X3 = 1, NSA_PREC_F16X3 = 2 };
 //   final chunk      : tr_tab[pad4(2*FPC)] | bias[32*C] | W[C][4*HT/KS][64][4]   (likewise)
 //   KS = nsa_ksplit(output tiles, HT): a GEMM whose packed weights exceed 16 KiB is dealt to 2 or 4
 //   consecutive stages along k (its accumulators live across them).
-//   dense            : in_tab[2*n_steps] | pre[2*n_steps] | bias[32*OT] | W[OT][n_steps/4][64][4]
+//   dense            : in_tab[2*n_steps] | pre[2*n_steps] | bias[32] | W[1][n_steps/4][64][4]  - ONE OUTPUT TILE per
+//                      stage, OT stages per op, each with its own copy of the tables (format 9; up to 128 features)
 //   elementwise      : a[D4] | b[D4] | c[D4] | d[D4]  (D4 = pad4(D); y = ((x-a)/b)*c + d per physical column)
 //
 // MFMA packing (v_mfma_f32_32x32x2_f32): W[ot][s4][lane][e] with step s = 4*s4+e,

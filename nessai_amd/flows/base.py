@@ -176,7 +176,7 @@ class HipFlow(BaseFlow):
         self.transform_kind = desc["transform"]
         self.hidden_features = desc["hidden"]
         ht = pack.hidden_tiles(desc["hidden"])
-        if ht > 4 or not lib_supports(ht, desc["transform"], desc.get("bins", 0)):
+        if ht > 8 or not lib_supports(ht, desc["transform"], desc.get("bins", 0)):
             raise ValueError(
                 "No gfx950 kernel instance for this flow configuration "
                 f"(hidden={desc['hidden']}, transform={desc['transform']}, "

@@ -31,7 +31,7 @@ import math
 import numpy as np
 
 MAGIC = 0x3141534E
-VERSION = 8
+VERSION = 9
 HEADER_WORDS = 40
 STAGE_ALIGN = 32   # words: stage blobs are padded to whole 128-byte lines
 PIECE_WORDS = 256  # words moved by one global_load_lds of a wave (64 lanes x 16 bytes)
@@ -100,9 +100,12 @@ def ksplit(tiles, ht):
 
 
 def hidden_tiles(hidden):
+    """Hidden tiles of the kernel instance a conditioner of this width runs on: 1, 2, 4 or 8 (widths up to 256;
+    the reference's default ``n_neurons = 2 * n_inputs``, src/nessai/flows/utils.py:148-149, for up to 128 inputs)."""
     ht = (hidden + 31) // 32
-    if ht == 3:
-        ht = 4
+    for instance in (1, 2, 4, 8):
+        if ht <= instance:
+            return instance
     return ht
 
 
@@ -459,8 +462,8 @@ def pack_flow(desc):
     transform = desc["transform"]
     bins = int(desc.get("bins", 0)) if transform == "rq" else 0
     ht = hidden_tiles(hidden)
-    if ht > 4:
-        raise ValueError(f"hidden width {hidden} > 128 is not supported by the gfx950 kernels")
+    if ht > 8:
+        raise ValueError(f"hidden width {hidden} > 256 is not supported by the gfx950 kernels")
     if D < 2:
         raise ValueError("at least two features are required")
     n_tiles_c, fpc, n_params = transform_policy(transform, bins)
@@ -492,8 +495,8 @@ def pack_flow(desc):
                 cur = [cur[int(perm[i])] for i in range(D)]
             elif kind == "dense":
                 _, mat, pre_v, post_v, ld = tr
-                if D > 64:
-                    raise ValueError("LU-linear transforms support at most 64 features")
+                if D > 128:
+                    raise ValueError("LU-linear transforms support at most 128 features")
                 n_ot = (D + 31) // 32
                 if bf16:
                     n_steps = (D + 15) // 16
@@ -513,8 +516,13 @@ def pack_flow(desc):
                 ld = np.float32(ld)
                 out_rows = _plain_out_rows(n_ot, D)
                 pack_w = _pack_matrix16(precision, desc.get("_split16")) if bf16 else pack_matrix
-                blob = _stage(in_tab, pre, pack_bias(post, out_rows), pack_w(mat, out_rows, in_cols))
-                stages.append(add_blob(blob))
+                # one self-contained stage per OUTPUT TILE (format 9: gather table, pre-shift, the tile's bias and
+                # weights): a 128-feature layer is 4 stages of ~17 KiB of split weights instead of one of 64 KiB
+                # that no double buffer holds; the tables are repeated (1 KiB) because a stage's buffer is gone
+                # two stages later
+                for ot in range(n_ot):
+                    rows = out_rows[ot:ot + 1]
+                    stages.append(add_blob(_stage(in_tab, pre, pack_bias(post, rows), pack_w(mat, rows, in_cols))))
                 ops.append([OP_DENSE, n_steps, n_ot, _f32_bits(ld)])
                 cur = list(range(D))
             elif kind == "coupling":

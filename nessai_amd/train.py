@@ -130,8 +130,8 @@ class Trainer:
                 records.append(rec)
                 self._actnorms.append((len(records) - 1, t))
             elif isinstance(t, M.LULinear):
-                if D > 64:
-                    raise ValueError("LU-linear transforms support at most 64 features")
+                if D > 128:  # (beyond 64 features: the layer-wise LU kernels, any width; the limit is the inference kernel's)
+                    raise ValueError("LU-linear transforms support at most 128 features")
                 rec = [3, len(tables), offsets[id(t.lower_entries)], offsets[id(t.upper_entries)],
                        offsets[id(t.unconstrained_upper_diag)], offsets[id(t.bias)], f32_bits(t.eps)]
                 tables.extend(cur)

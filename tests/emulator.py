@@ -225,28 +225,30 @@ class Emulator:
                         logdet[l_ok] += ld
             elif kind == P.OP_DENSE:
                 n_steps, n_ot = int(op[1]), int(op[2])
-                st = self._stage_words(inverse, stage)
-                stage += 1
                 tl = (16 if self.bf16 else 2) * n_steps
-                in_tab = st[:tl].view(np.int32)
-                fl = st.view(np.float32)
-                pre = fl[tl : 2 * tl]
-                bias = fl[2 * tl : 2 * tl + 32 * n_ot]
+                acc = []
+                for ot in range(n_ot):  # one self-contained stage per output tile (format 9)
+                    st = self._stage_words(inverse, stage)
+                    stage += 1
+                    in_tab = st[:tl].view(np.int32)
+                    fl = st.view(np.float32)
+                    pre = fl[tl : 2 * tl]
+                    bias = fl[2 * tl : 2 * tl + 32]
 
-                def gather_d(idx):
-                    cols = in_tab[idx] // 4
-                    assert np.all(in_tab[idx] % 4 == 0) and np.all((cols < D) | (cols == D + 1))
-                    xz = np.concatenate([xt, np.zeros((xt.shape[0], 2), dtype=np.float32)], axis=1)
-                    return (xz[row_of[:, None] if idx.ndim == 2 else row_of, cols] - pre[idx]).astype(np.float32)
+                    def gather_d(idx, in_tab=in_tab, pre=pre):
+                        cols = in_tab[idx] // 4
+                        assert np.all(in_tab[idx] % 4 == 0) and np.all((cols < D) | (cols == D + 1))
+                        xz = np.concatenate([xt, np.zeros((xt.shape[0], 2), dtype=np.float32)], axis=1)
+                        return (xz[row_of[:, None] if idx.ndim == 2 else row_of, cols] - pre[idx]).astype(np.float32)
 
-                if self.bf16:
-                    w = st[2 * tl + 32 * n_ot : 2 * tl + 32 * n_ot + n_ot * n_steps * 512]
-                    acc = self._dense16(w, n_ot, n_steps,
-                                        lambda s: gather_d(16 * s + 8 * half_of[:, None] + np.arange(8)[None, :]),
-                                        self._bias(bias, n_ot))
-                else:
-                    w = fl[2 * tl + 32 * n_ot : 2 * tl + 32 * n_ot + n_ot * n_steps * 64]
-                    acc = self._dense(w, n_ot, n_steps, lambda s: gather_d(2 * s + half_of), self._bias(bias, n_ot))
+                    if self.bf16:
+                        w = st[2 * tl + 32 : 2 * tl + 32 + n_steps * 512]
+                        acc.extend(self._dense16(w, 1, n_steps,
+                                                 lambda s: gather_d(16 * s + 8 * half_of[:, None] + np.arange(8)[None, :]),
+                                                 self._bias(bias, 1)))
+                    else:
+                        w = fl[2 * tl + 32 : 2 * tl + 32 + n_steps * 64]
+                        acc.extend(self._dense(w, 1, n_steps, lambda s: gather_d(2 * s + half_of), self._bias(bias, 1)))
                 new = xt.copy()
                 for ot in range(n_ot):
                     for lane in range(64):

@@ -47,6 +47,11 @@ CONFIGS = {
     "rnvp_custom_scale": (RealNVP, O.RealNVP, (6, 16, 3, 2),
                           dict(linear_transform="permutation", batch_norm_between_layers=False,
                                scale_activation=lambda x: torch.sigmoid(x - 0.5) + 0.05)),
+    # the reference's defaults beyond 64 inputs: n_neurons = 2 * n_inputs (src/nessai/flows/utils.py:148-149) and,
+    # for RealNVP, linear_transform="lu" (flows/realnvp.py:90) - 192- / 200-wide conditioners on the
+    # eight-hidden-tiles instances, an LU-linear layer over 100 features as four output tiles
+    "nsf_d96_h192": (NeuralSplineFlow, O.NeuralSplineFlow, (96, 192, 2, 1), {}),
+    "rnvp_d100_lu": (RealNVP, O.RealNVP, (100, 200, 2, 1), {}),
 }
 
 

@@ -50,6 +50,9 @@ CASES = {
     "rnvp_ragged_masks": (RealNVP, O.RealNVP, (40, 8, 5, 1),
                           dict(mask=[[-1.0] * 4 + [1.0] * 36] * 3 + [[-1.0] * 30 + [1.0] * 10] + [[-1.0] * 4 + [1.0] * 36],
                                linear_transform=None, batch_norm_between_layers=False)),
+    # the reference's defaults at 100 inputs: 200-wide conditioners (the layer-wise coupling kernels) and an
+    # LU-linear layer over 100 features (beyond the one-launch LU kernels' 64)
+    "rnvp_d100_default": (RealNVP, O.RealNVP, (100, 200, 2, 1), {}),
     "rnvp_mlp_deep_tanh": (RealNVP, O.RealNVP, (5, 12, 2, 3),
                            dict(net="mlp", linear_transform="permutation", batch_norm_between_layers=False,
                                 activation=torch.tanh)),
