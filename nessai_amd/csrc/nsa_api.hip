@@ -298,9 +298,10 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     // (x tiles + one parked float per lane and tile, nsa_flow_kernel.h)
     auto res_lds = [&](int w, int r) { return ((((size_t)w * r * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + (size_t)w * r * 256 + fixed; };
     // candidates in the order of their measured time per row on big batches (profiles/r04_resident_geometries.jsonl)
-    static const int cand[5][2] = {{4, 1}, {3, 1}, {2, 2}, {3, 2}, {2, 1}};
-    for (int c = 0; c < 5 && on; ++c) {
+    static const int cand[4][2] = {{4, 1}, {3, 1}, {2, 2}, {2, 1}};
+    for (int c = 0; c < 4 && on; ++c) {
       int o = cand[c][0], r = cand[c][1];
+      if (o == 4 && h[NSA_H_HT] != 1) continue;  // built for 32-wide conditioners only (nsa_flow_inst.hip)
       if (pin_occ != 0 && (o != pin_occ || r != pin_rt)) continue;
       if (r == 2 && p.precision == NSA_PREC_F32) continue;  // exact f32 keeps one tile per wave, as in the staged geometries
       int w = waves_per_group > 0 ? waves_per_group : 4 * o;
@@ -315,8 +316,13 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
           w = (int)(per_cu < 1 ? 1 : per_cu);
         }
       }
+      const int w_asked = w;
       while (w > 1 && res_lds(w, r) > g_max_lds) --w;  // fewer waves beside a bigger program
       if (res_lds(w, r) > g_max_lds) continue;
+      // ... but a program that leaves room for fewer than two tiles per SIMD is better off staged: a 135 KB
+      // spline flow at five waves per CU measured 0.69 ms per 1e6 rows resident against 0.53 staged, a 118 KB
+      // one at four waves 0.91 against 0.65 (profiles/r04_c3_coupling_resident.jsonl)
+      if (pin_occ == 0 && w < w_asked && w * r < 8) continue;
       p.resident = 1;
       p.occupancy = o;
       p.row_tiles = r;

@@ -7,8 +7,15 @@
 #if !defined(NSA_HT) || !defined(NSA_TKIND) || !defined(NSA_BINS)
 #error "NSA_HT, NSA_TKIND and NSA_BINS must be defined"
 #endif
+// weights-resident shapes (waves per SIMD, row tiles per wave) beside the always-built (2, 1); the same list
+// as nsa_resident_candidates in nsa_api.hip.  64-wide conditioners do not fit 128 registers (4 waves per SIMD:
+// ~70 spilled) and two tiles per wave at 3 waves per SIMD measured slowest everywhere (and spill): not built.
 #ifndef NSA_RES_GEOMETRIES
-#define NSA_RES_GEOMETRIES NSA_RES_GEO(3, 1) NSA_RES_GEO(4, 1) NSA_RES_GEO(2, 2) NSA_RES_GEO(3, 2)
+#if NSA_HT == 1
+#define NSA_RES_GEOMETRIES NSA_RES_GEO(3, 1) NSA_RES_GEO(4, 1) NSA_RES_GEO(2, 2)
+#else
+#define NSA_RES_GEOMETRIES NSA_RES_GEO(3, 1) NSA_RES_GEO(2, 2)
+#endif
 #endif
 
 #if NSA_TKIND == 1

@@ -39,6 +39,7 @@ enum { NSA_MODE_APPLY = 0, NSA_MODE_LOGPROB = 1, NSA_MODE_POPULATE = 2 };
 //   8 MFMAs of the hidden and last layers   16 latent draw (Philox / Box-Muller)   32 epilogue stores
 //   64 the populate epilogue's per-feature loop (log q only)   128 the populate prologue (latent norm / density)
 //   256 the f16 range check of the outputs   512 LU-linear / batch-norm ops (stage skipped)
+//   1024 the hidden layers of the conditioner (stages skipped)   2048 the last layer's chunks (stages skipped)
 #ifndef NSA_ABLATE
 #define NSA_ABLATE 0
 #endif
@@ -713,7 +714,13 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
     pipe.template end_v<SKEW && (NSA_SKEW_MASK & 1) != 0>();
   }
 
-  if (net == NSA_NET_RESNET) {
+  if constexpr ((NSA_ABLATE & 1024) != 0) {
+    const int skip = (net == NSA_NET_RESNET ? 2 * n_layers : n_layers - 1) * nsa_ksplit(HT, HT);
+    for (int k = 0; k < skip; ++k) {
+      (void)pipe.template begin<false>();
+      pipe.end();
+    }
+  } else if (net == NSA_NET_RESNET) {
     // pre-activation residual blocks: h += W2 act(W1 act(h) + b1) + b2
     for (int l = 0; l < n_layers; ++l) {
       float tmp[RT][16 * HT];
@@ -775,6 +782,14 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
     for (int t = 0; t < RT; ++t) nsa_split_regs<PREC, HT>(h[t], hs[t], pipe.amax);
   }
   for (int c = 0; c < n_chunks; ++c) {
+    if constexpr ((NSA_ABLATE & 2048) != 0) {
+      for (int k = 0; k < nsa_ksplit(TP::C, HT); ++k) {
+        (void)pipe.template begin<false>();
+        pipe.end();
+      }
+      logdet[0] += h[0][c & 15];  // (keeps the conditioner alive)
+      continue;
+    }
     f32x16 acc[RT][TP::C];
     int cols[TP::FPC];
     nsa_static_for<nsa_ksplit(TP::C, HT)>([&](auto jc) {
@@ -807,6 +822,13 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
   }
 }
 
+// an int the optimiser cannot trace back: keeps the per-lane 64-bit addresses of the tile copy
+// loops from being hoisted out of the persistent loop (they were spilled to scratch there)
+__device__ __forceinline__ int nsa_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // One output tile of a dense op back into the wave's x tile: accumulator register r = 4 q + e of a lane holds
 // output feature first + 8 q + 4 half + e.  The features end at D anywhere inside the tile; a test per element
 // is a per-LANE predicate (`half`) - sixteen exec-mask round trips, each with its mask kept in (spilled)
@@ -814,6 +836,7 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
 // plain stores at immediate offsets; only the one group that straddles D is predicated per lane.
 __device__ __forceinline__ void nsa_dense_store(float* xrow, const f32x16& acc, int first, int D, int half) {
   float* const xh = xrow + 4 * half;
+  asm volatile("" : "+s"(D));  // (the group tests below are compared here, not precomputed per tile as 64-bit masks)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int lo = first + 8 * q;  // wave-uniform
@@ -821,9 +844,13 @@ __device__ __forceinline__ void nsa_dense_store(float* xrow, const f32x16& acc, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) xh[lo + e] = acc[4 * q + e];
     } else if (lo < D) {
+      // (opaque: as plain comparisons of loop invariants the sixteen predicates per output tile were computed
+      // at the top of EVERY tile for every quad of every dense op - ~300 vector instructions per tile - and
+      // parked in scalar registers; they are needed by the one quad that straddles D)
+      const int lim = nsa_opaque(D - lo - 4 * half);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (lo + 4 * half + e < D) xh[lo + e] = acc[4 * q + e];
+        if (e < lim) xh[lo + e] = acc[4 * q + e];
     }
   }
 }
@@ -890,12 +917,6 @@ __device__ __forceinline__ void nsa_elementwise_op(PIPE& pipe, const uint32_t* o
 
 // the kernel ------------------------------------------------------------------
 
-// an int the optimiser cannot trace back: keeps the per-lane 64-bit addresses of the tile copy
-// loops from being hoisted out of the persistent loop (they were spilled to scratch there)
-__device__ __forceinline__ int nsa_opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
 
 // The kernel's argument block as it lies in the kernarg segment, through a pointer the optimiser cannot see
 // through: the loads of the fields stay where they are written (see the tile loop).
@@ -1120,11 +1141,11 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
           xq[2] = z2;
           xq[3] = z3;
         } else {
-          const int c = 4 * q;
-          if (c < D) xq[0] = z0;
-          if (c + 1 < D) xq[1] = z1;
-          if (c + 2 < D) xq[2] = z2;
-          if (c + 3 < D) xq[3] = z3;
+          const int lim = nsa_opaque(D - 4 * q);  // (opaque: see nsa_dense_store)
+          if (0 < lim) xq[0] = z0;
+          if (1 < lim) xq[1] = z1;
+          if (2 < lim) xq[2] = z2;
+          if (3 < lim) xq[3] = z3;
         }
       }
     }

@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/../nessai_amd/csrc"
 mkdir -p ../../variants
-for bits in ${@:-0 4 8 16 32 64 128 256 512}; do
+for bits in ${@:-0 4 16 64 128 512 1024 2048}; do
   ( make -s -j2 BUILD=build_c2a$bits TARGET=../../variants/libnessai_amd_c2a$bits.so HTS=1 TRANSFORMS=2_0 \
       EXTRA="-DNSA_ABLATE=$bits '-DNSA_RES_GEOMETRIES=NSA_RES_GEO(4,1)'" > /dev/null 2>&1 && echo built c2a$bits ) &
 done

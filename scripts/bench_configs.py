@@ -68,7 +68,8 @@ def time_draw(prop, n, launches=8):
     buf = prop._get_buffers(n, prop.poolsize)
     prepared = prop._prepare_flow()
     log_p = buf["log_p"] if prop._prior_kind_dev is not None else None
-    for _ in range(2):
+    # (warm state: the first ~100 ms of kernels after an idle spell run ~8 % slower - the clocks ramp)
+    for _ in range(max(2, min(40, int(4e7 // max(n, 1))))):
         prop._launch_draw(n, None, 0, prop.r, buf["x64"], buf["log_q"], None, log_prior=log_p, prepared=prepared)
     torch.cuda.synchronize()
     events = []
@@ -79,7 +80,9 @@ def time_draw(prop, n, launches=8):
         b.record()
         events.append((a, b))
     torch.cuda.synchronize()
-    return float(np.mean([a.elapsed_time(b) for a, b in events]))
+    ms = [a.elapsed_time(b) for a, b in events]
+    time_draw.last = dict(mean=float(np.mean(ms)), median=float(np.median(ms)), min=float(np.min(ms)), launches=launches)
+    return float(np.mean(ms))
 
 
 def live_points(model, nlive, n_prior, rng):
@@ -228,9 +231,32 @@ def run_c4_draw(n_flows_list=(1, 8, 32), nlive=5000, dims=64):
                 prop.update_log_q(stored, np.zeros((stored.size, target)))
             torch.cuda.synchronize()
             du = (time.perf_counter() - t) / 3
+            # the dominant kernel of a draw: the grouped forward + log_prob of the drawn rows under every stored
+            # flow (nsa_flow_run_many), by itself on device tensors of the draw's size (1.01 n rows,
+            # proposal/importance.py:469) - HIP events, against both roofs
+            from nessai_amd.flows.base import log_prob_many
+
+            models = list(prop.flow.models)
+            n_rows = int(1.01 * nlive)
+            xd = torch.randn(n_rows, dims, device=models[0]._device())
+            log_prob_many(models, xd)
+            torch.cuda.synchronize()
+            ev = []
+            for _ in range(8):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                log_prob_many(models, xd)
+                b.record()
+                ev.append((a, b))
+            torch.cuda.synchronize()
+            k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            roof = kernel_roofline(models[0], models[0].effective_precision, n_rows * target, k_ms,
+                                   4 * dims / target + 4, "mfma")
+            roof["kernel"] = (f"nsa_flow_kernel, forward + log_prob of the {n_rows} drawn rows, grouped over {target} flows "
+                              "(nsa_flow_run_many): a small batch - 158 tiles per flow - i.e. latency, not throughput")
             print(json.dumps({"config": "C4 ImportanceFlowProposal.draw, 64-D correlated Gaussian", "n_flows": target,
                               "nlive": nlive, "draw_ms": 1e3 * dt, "points_per_s": nlive / dt,
-                              "update_log_q_ms_20000_rows": 1e3 * du}), flush=True)
+                              "update_log_q_ms_20000_rows": 1e3 * du, "roofline": roof}), flush=True)
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 # flows whose packed program fits in the 160 KB of LDS of a CU (everything else stays staged)
 RESIDENT = [n for n in CONFIGS if n not in ("nsf_c3", "nsf_c5_d15", "nsf_c4_d64", "nsf_d96_h192", "rnvp_d100_lu")]
-SHAPES = ["3x2", "4x1", "2x2", "3x1", "2x1"]
+SHAPES = ["4x1", "2x2", "3x1", "2x1"]
 
 
 def geometry():
@@ -73,9 +73,11 @@ def test_resident_is_the_default_for_flows_that_fit_and_matches_the_oracle(name,
 def test_resident_rows_equal_staged_rows(name, n, shape, precision, monkeypatch):
     if precision == "f32" and shape[2] == "2":
         pytest.skip("exact f32 keeps one row tile per wave, as in the staged geometries")
-    if precision != "f16x3" and (n not in (33, 40001) or shape not in ("3x2", "4x1", "3x1")):
+    if precision != "f16x3" and (n not in (33, 40001) or shape not in ("2x2", "4x1", "3x1")):
         pytest.skip("the other precisions share the code path: two sizes and two shapes pin their instances")
     P, Oc, args, kw = CONFIGS[name]
+    if shape == "4x1" and args[1] > 32:
+        pytest.skip("four waves per SIMD (128 registers) are built for conditioners up to 32 wide")
     _, flow = make_pair(P, Oc, args, kw)
     flow.precision = precision
     x = (torch.randn(n, args[0], generator=torch.Generator().manual_seed(n)) * 1.2).to(DEV)
