@@ -597,6 +597,90 @@ __global__ void tr_bn_backward_apply(int n, int D, float* __restrict__ X, float*
   }
 }
 
+// Training-mode batch norm in ONE launch per direction (the fused trainer; the two-launch pairs above stay for the
+// deterministic layer-wise path): the transform is independent per feature, so workgroup i owns column i - its
+// statistics (the sums of tr_bn_stats / tr_bn_backward_reduce, same order) and then its own column of the batch.
+// A launch of these sizes is ~4.5 us of latency whatever it does: the reference's default RealNVP paid it four
+// times per batch-norm layer and step.  The layer's constant log|det J| is added per column with a float atomic.
+__global__ void __launch_bounds__(256) tr_bn_forward_fused(int n, int D, float* __restrict__ X, int ldx,
+                                                           const int* __restrict__ cols, const float* __restrict__ uw,
+                                                           const float* __restrict__ bias, float eps,
+                                                           float* __restrict__ mean, float* __restrict__ var,
+                                                           float* __restrict__ xsave, float* __restrict__ run_mean,
+                                                           float* __restrict__ run_var, float momentum,
+                                                           int update_running, float* __restrict__ ld_const) {
+  __shared__ float sm[256];
+  const int i = blockIdx.x, col = cols[i];
+  float s = 0.0f;
+  for (int r = threadIdx.x; r < n; r += 256) s += X[(long long)r * ldx + col];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off]; __syncthreads(); }
+  const float mu = sm[0] / (float)n;
+  __syncthreads();
+  float q = 0.0f;
+  for (int r = threadIdx.x; r < n; r += 256) { const float d = X[(long long)r * ldx + col] - mu; q += d * d; }
+  sm[threadIdx.x] = q;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off]; __syncthreads(); }
+  const float v = sm[0] / (float)(n - 1);
+  const float w = nsa_softplus(uw[i]) + eps;
+  if (threadIdx.x == 0) {
+    mean[i] = mu;
+    var[i] = v;
+    if (update_running) {
+      run_mean[i] = run_mean[i] * (1.0f - momentum) + mu * momentum;
+      run_var[i] = run_var[i] * (1.0f - momentum) + v * momentum;
+    }
+    atomicAdd(ld_const, logf(w) - 0.5f * logf(v + eps));
+  }
+  const float istd_den = sqrtf(v + eps), b = bias[i];
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const float x = X[(long long)r * ldx + col];
+    xsave[(long long)r * D + i] = x;
+    X[(long long)r * ldx + col] = w * ((x - mu) / istd_den) + b;
+  }
+}
+
+__global__ void __launch_bounds__(256) tr_bn_backward_fused(int n, int D, float* __restrict__ X, float* __restrict__ Gx,
+                                                            int ldx, const int* __restrict__ cols,
+                                                            const float* __restrict__ xsave, const float* __restrict__ uw,
+                                                            const float* __restrict__ mean, const float* __restrict__ var,
+                                                            float eps, float* __restrict__ g_uw, float* __restrict__ g_bias,
+                                                            const float* __restrict__ gl_sum, int batch_stats) {
+  __shared__ float s1[256], s2[256];
+  const int i = blockIdx.x, col = cols[i];
+  const float mu = mean[i], ve = var[i] + eps, istd = 1.0f / sqrtf(ve);
+  float a = 0.0f, b = 0.0f;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const float gy = Gx[(long long)r * ldx + col];
+    a += gy;
+    b += gy * ((xsave[(long long)r * D + i] - mu) * istd);
+  }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { s1[threadIdx.x] += s1[threadIdx.x + off]; s2[threadIdx.x] += s2[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  const float T1 = s1[0], T2 = s2[0];
+  const float w = nsa_softplus(uw[i]) + eps;
+  const float S1 = w * T1, S2 = w * T2, gl = gl_sum[0];
+  const float g_var = batch_stats ? (-0.5f * S2 - 0.5f * gl) / ve : 0.0f;
+  const float g_mean = batch_stats ? -S1 * istd : 0.0f;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const float x = xsave[(long long)r * D + i], xc = x - mu;
+    const float g = Gx[(long long)r * ldx + col] * w;
+    Gx[(long long)r * ldx + col] = g * istd + g_var * 2.0f * xc / (float)(n - 1) + g_mean / (float)n;
+    X[(long long)r * ldx + col] = x;
+  }
+  if (threadIdx.x == 0) {
+    const float sig = 1.0f / (1.0f + expf(-uw[i]));
+    g_uw[i] = (T2 + gl / w) * sig;
+    g_bias[i] = T1;
+  }
+}
+
 // eval-mode batch norm (running statistics), used by the validation pass
 __global__ void tr_bn_eval(int n, int D, float* __restrict__ X, int ldx, const int* __restrict__ cols,
                            const float* __restrict__ uw, const float* __restrict__ bias,
@@ -753,7 +837,8 @@ __global__ void __launch_bounds__(256) tr_lu_forward_fused(int n, int D, float* 
                                                            const float* __restrict__ raw, float eps,
                                                            const float* __restrict__ bias, float* __restrict__ xin,
                                                            float* __restrict__ tsave, float* __restrict__ gL,
-                                                           float* __restrict__ gU, float* __restrict__ ld_const) {
+                                                           float* __restrict__ gU, float* __restrict__ ld_const,
+                                                           unsigned* __restrict__ done) {
   extern __shared__ float lu_sm[];
   float* UT = lu_sm;            // UT[j * D + i] = U[i][j]
   float* LT = UT + D * D;       // LT[j * D + i] = L[i][j]
@@ -770,6 +855,7 @@ __global__ void __launch_bounds__(256) tr_lu_forward_fused(int n, int D, float* 
     LT[j * D + i] = l;
     UT[j * D + i] = u;
     if (blockIdx.x == 0) { gL[e] = 0.0f; gU[e] = 0.0f; }
+    if (blockIdx.x == 0 && e == 0) *done = 0u;  // ticket counter of tr_lu_backward_fused
   }
   if (blockIdx.x == 0 && tid == 0) {
     float ld = 0.0f;
@@ -810,7 +896,10 @@ __global__ void __launch_bounds__(256) tr_lu_backward_fused(int n, int D, float*
                                                             const float* __restrict__ upper, const float* __restrict__ raw,
                                                             float eps, const float* __restrict__ xin,
                                                             const float* __restrict__ tsave, float* __restrict__ gL,
-                                                            float* __restrict__ gU, float* __restrict__ gb) {
+                                                            float* __restrict__ gU, float* __restrict__ gb,
+                                                            float* __restrict__ g_lower, float* __restrict__ g_upper,
+                                                            float* __restrict__ g_raw, const float* __restrict__ gl_sum,
+                                                            unsigned* __restrict__ done) {
   extern __shared__ float lu_sm[];
   float* Lm = lu_sm;          // Lm[i * D + j]
   float* Um = Lm + D * D;
@@ -884,6 +973,27 @@ __global__ void __launch_bounds__(256) tr_lu_backward_fused(int n, int D, float*
     }
   }
   if (tid < D) atomicAdd(&gb[tid], accb);
+  // The workgroup that finishes LAST turns the summed D x D gradients into those of the triangular
+  // parameters (what tr_lu_grads did in a launch of its own): a ticket counter behind the sums.
+  __shared__ unsigned ticket;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) ticket = atomicAdd(done, 1u);
+  __syncthreads();
+  if (ticket != gridDim.x - 1) return;
+  __threadfence();
+  for (int e = tid; e < D * D; e += 256) {
+    const int i = e / D, j = e - i * D;
+    const float l = __hip_atomic_load(&gL[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float u = __hip_atomic_load(&gU[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j < i) g_lower[i * (i - 1) / 2 + j] = l;
+    else if (j > i) g_upper[i * D - i * (i + 1) / 2 + (j - i - 1)] = u;
+    else {
+      const float d = nsa_softplus(raw[i]) + eps;
+      g_raw[i] = (u + gl_sum[0] / d) / (1.0f + expf(-raw[i]));
+    }
+  }
+  if (tid == 0) *done = 0u;  // ready for the next step
 }
 
 __global__ void tr_gather_cols(int n, int D, const float* __restrict__ src, int lds_, const int* __restrict__ cols,
@@ -1490,7 +1600,10 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
       TrLin q = tr_lin(lay, n, D);
       float* mean = q.vec;
       float* var = q.vec + D;
-      if (training) {
+      if (training && tr_use_fused(plan)) {
+        hipLaunchKernelGGL(tr_bn_forward_fused, dim3(D), dim3(256), 0, s, (int)n, D, w.x, D, cols, params + r[2],
+                           params + r[3], eps, mean, var, q.xin, params + r[4], params + r[5], momentum, 1, w.scal + 1);
+      } else if (training) {
         hipLaunchKernelGGL(tr_bn_stats, dim3(D), dim3(256), 0, s, (int)n, w.x, D, cols, mean, var);
         hipLaunchKernelGGL(tr_bn_forward, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, D, cols,
                            params + r[2], params + r[3], mean, var, eps, q.xin, params + r[4], params + r[5],
@@ -1516,7 +1629,8 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
         const long long groups = (n + R - 1) / R;
         hipLaunchKernelGGL(tr_lu_forward_fused, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(256),
                            (size_t)(2 * D * D + 512) * sizeof(float), s, (int)n, D, w.x, cols, params + r[2],
-                           params + r[3], params + r[4], eps, params + r[5], q.xin, q.t, q.gL, q.gU, w.scal + 1);
+                           params + r[3], params + r[4], eps, params + r[5], q.xin, q.t, q.gL, q.gU, w.scal + 1,
+                           (unsigned*)(q.vec + 4 * D));
         continue;
       }
       float* zero = q.vec;  // zero bias for the first product
@@ -1654,11 +1768,16 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       float *T1 = q.vec + 2 * D, *T2 = q.vec + 3 * D;
       const float* mean = training ? q.vec : params + r[4];  // batch / running statistics
       const float* var = training ? q.vec + D : params + r[5];
-      hipLaunchKernelGGL(tr_bn_backward_reduce, dim3(D), dim3(256), 0, s, (int)n, w.gx, D, cols, q.xin, D, mean,
-                         var, eps, T1, T2);
-      hipLaunchKernelGGL(tr_bn_backward_apply, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, w.gx, D, cols,
-                         q.xin, params + r[2], mean, var, eps, T1, T2, grads + r[2], grads + r[3], w.scal + 2,
-                         training ? 1 : 0);
+      if (tr_use_fused(plan)) {
+        hipLaunchKernelGGL(tr_bn_backward_fused, dim3(D), dim3(256), 0, s, (int)n, D, w.x, w.gx, D, cols, q.xin,
+                           params + r[2], mean, var, eps, grads + r[2], grads + r[3], w.scal + 2, training ? 1 : 0);
+      } else {
+        hipLaunchKernelGGL(tr_bn_backward_reduce, dim3(D), dim3(256), 0, s, (int)n, w.gx, D, cols, q.xin, D, mean,
+                           var, eps, T1, T2);
+        hipLaunchKernelGGL(tr_bn_backward_apply, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, w.gx, D, cols,
+                           q.xin, params + r[2], mean, var, eps, T1, T2, grads + r[2], grads + r[3], w.scal + 2,
+                           training ? 1 : 0);
+      }
     } else if (r[0] == TR_ACTNORM) {
       const int* cols = tabs + r[1];
       TrLin q = tr_lin(lay, n, D);
@@ -1673,9 +1792,8 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
         const long long groups = (n + R - 1) / R;
         hipLaunchKernelGGL(tr_lu_backward_fused, dim3((unsigned)(groups < 32 ? groups : 32)), dim3(256),
                            (size_t)(2 * D * D + 1024) * sizeof(float), s, (int)n, D, w.x, w.gx, cols, params + r[2],
-                           params + r[3], params + r[4], eps, q.xin, q.t, q.gL, q.gU, grads + r[5]);
-        hipLaunchKernelGGL(tr_lu_grads, blocks_for(D * D), dim3(256), 0, s, D, q.gL, q.gU, params + r[4], eps,
-                           grads + r[2], grads + r[3], grads + r[4], w.scal + 2);
+                           params + r[3], params + r[4], eps, q.xin, q.t, q.gL, q.gU, grads + r[5], grads + r[2],
+                           grads + r[3], grads + r[4], w.scal + 2, (unsigned*)(q.vec + 4 * D));
         continue;
       }
       // gy = w.gx (logical order).  dL = gy^T t, db = colsum gy;  gt = gy L;  dU = gt^T x;  gx = gt U
