@@ -1334,6 +1334,9 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
           if constexpr (POISON) poison = fmaf(xpf, 0.0f, poison);
           const double xv = ((double)xpf * c[0]) + c[D4e];
           inb &= (int)!(xv < c[2 * D4e]) & (int)!(xv > c[3 * D4e]);
+          // (plain stores: as non-temporal ones these 8-byte pieces - two lanes per 16 bytes of a row - went to
+          // memory one partial line at a time: WRITE_SIZE 1092 MB per launch against 264, kernel 1.72 against
+          // 1.58 ms; the L2 merges them.  What they evict of the flow image costs 35 MB of re-fetches per launch.)
           if (store) xo[0] = xv;
         };
         const int nk = D >> 1;
