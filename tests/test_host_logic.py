@@ -238,3 +238,49 @@ def test_poolsize_scale_limits():
     for acceptance, want in ((0.0, 10.0), (None, 10.0), (0.5, 2.0), (0.01, 10.0), (2.0, 1.0), (1.0, 1.0)):
         FlowProposal.update_poolsize_scale(s, acceptance)
         assert s._poolsize_scale == want
+
+
+def test_flow_factory_schema():
+    """The configuration schema of src/nessai/flows/utils.py:112-246, 295-349: width rules, flow names, the
+    refusals of what has no kernel, and the errors the reference raises for what it does not know."""
+    from nessai_amd.flows import NeuralSplineFlow, RealNVP, modules
+    from nessai_amd.flows import utils as U
+
+    # width of the conditioner: (n_neurons, n_inputs) -> int  (the reference's table, utils.py:141-156)
+    for n_neurons, n_inputs, want in [(None, None, 8), (16, None, 16), ("12", None, 12), (None, 5, 10), ("auto", 5, 10),
+                                      ("double", 7, 14), ("equal", 7, 7), ("half", 7, 3), (24, 7, 24), (8.0, 3, 8)]:
+        assert U.get_n_neurons(n_neurons, n_inputs) == want
+    assert U.get_n_neurons(None, None, default=3) == 3
+    with pytest.raises(ValueError, match="Could not get number of neurons"):
+        U.get_n_neurons("auto")  # a rule without the number of inputs
+    with pytest.raises(ValueError, match="Could not get number of neurons"):
+        U.get_n_neurons("wide", 4)
+    for name, cls in [("realnvp", RealNVP), ("FRealNVP", RealNVP), ("nsf", NeuralSplineFlow), ("Spline", NeuralSplineFlow)]:
+        assert U.get_flow_class(name) is cls
+    with pytest.raises(NotImplementedError):
+        U.get_flow_class("maf")
+    with pytest.raises(ValueError, match="Unknown flow"):
+        U.get_flow_class("glow")
+    assert isinstance(U.create_linear_transform("Permutation", 4), modules.RandomPermutation)
+    lu = U.create_linear_transform("lu", 4)
+    assert [type(t) for t in lu._transforms] == [modules.RandomPermutation, modules.LULinear]
+    with pytest.raises(NotImplementedError, match="svd"):
+        U.create_linear_transform("svd", 4)
+    with pytest.raises(ValueError, match="Unknown linear transform"):
+        U.create_linear_transform("qr", 4)
+    assert isinstance(U.create_pre_transform("batch_norm", 4), modules.BatchNorm)
+    with pytest.raises(NotImplementedError, match="logit"):
+        U.create_pre_transform("logit", 4)
+    with pytest.raises(ValueError, match="Unknown pre-transform"):
+        U.create_pre_transform("whiten", 4)
+    with pytest.raises(TypeError, match="must be an int"):
+        U.configure_model(dict(n_inputs=4.0, n_neurons=8, n_blocks=2, n_layers=2, ftype="nsf"))
+    with pytest.raises(RuntimeError, match="Must specify either 'flow' or 'ftype'"):
+        U.configure_model(dict(n_inputs=4, n_neurons=8, n_blocks=2, n_layers=2))
+    with pytest.raises(NotImplementedError, match="Base distribution"):
+        U.configure_model(dict(n_inputs=4, n_neurons=8, n_blocks=2, n_layers=2, ftype="nsf", distribution="lars"))
+    cfg = dict(n_inputs=4, n_neurons=8, n_blocks=2, n_layers=2, ftype="realnvp", distribution="mvn",
+               distribution_kwargs=dict(var=2.0))
+    flow = U.configure_model(cfg)
+    assert isinstance(flow, RealNVP) and flow._distribution.var == 2.0
+    assert cfg["ftype"] == "realnvp" and "distribution_kwargs" in cfg  # the caller's dictionary is left alone
