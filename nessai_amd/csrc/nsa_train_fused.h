@@ -139,50 +139,104 @@ __device__ __forceinline__ void trf_linear_preload(TrfPre& pre, const float* __r
   }
 }
 
+// w[q] = M[r0 + 2 q][c], q < 16, of a row-major matrix [rows][ldm] (c < cols valid): 16 B operands of an MFMA batch.
+// `inside` (wave-uniform): the whole batch of the whole tile is inside the matrix - one 32-bit byte offset per load, a
+// constant stride apart, nothing else.  Otherwise rows and column are clamped (the caller zeroes what it must not use).
+// (With the clamps on every load, a batch was ~230 vector instructions around 16 MFMAs - and a single wave issues a
+// vector instruction per ~5 cycles: as long as the MFMAs themselves; scripts/train_phase_timing.py --c4.)
+__device__ __forceinline__ void trf_load16(float (&w)[16], const float* __restrict__ M, int r0, int rows, int ldm,
+                                           int c, int cols, bool inside) {
+  if (inside) {
+    unsigned offb = 4u * ((unsigned)r0 * (unsigned)ldm + (unsigned)c);
+    const unsigned strideb = 8u * (unsigned)ldm;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      w[q] = *(const float*)((const char*)M + offb);
+      offb += strideb;
+    }
+  } else {
+    const unsigned cc = (unsigned)(c < cols ? c : cols - 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int r = r0 + 2 * q;
+      w[q] = M[(unsigned)(r < rows ? r : rows - 1) * (unsigned)ldm + cc];
+    }
+  }
+}
+
 // out[row][o] = sum_k act(Ain[row][k]) W[o][k] + b[o] (+ R[row][o]); rows of the workgroup.
 // Wt = W^T [Kd][O].  out_lds / R may be null; out_lds == R is allowed (in-place residual update).
 __device__ __forceinline__ void trf_linear(const float* __restrict__ Ain, int Kd, int act_in,
                                            const float* __restrict__ Wt, const float* __restrict__ b, int O,
                                            const float* R, float* out_lds, float* __restrict__ out_glb,
                                            int ld_glb, int ld, int r0, int n, int wave, int lane,
-                                           const TrfPre& pre) {
+                                           const TrfPre& pre, float* fine = nullptr, long long t_start = 0) {
+  // diagnostic stamps of one layer (scripts/train_phase_timing.py --fine): everything outstanding is waited for first
+  int fine_i = 0;
+  auto stamp = [&]() {
+    if (fine != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      fine[fine_i++] = (float)(long long)(clock64() - t_start);
+    }
+  };
+  stamp();
   const int half = lane >> 5, j = lane & 31;
   const int OT = (O + 31) >> 5;
   const int pairs = (Kd + 1) >> 1;
-  for (int t = wave; t < TRF_RT * OT; t += TRF_WAVES) {
+  // B operands of step (tile t, pairs [u0, u0 + 16)): lanes along the row of W^T - coalesced
+  auto inside = [&](int t, int u0) { return 2 * (u0 + 16) <= Kd && (t / TRF_RT) * 32 + 32 <= O; };  // wave-uniform
+  auto load_w = [&](float (&w)[16], int t, int u0) {
+    trf_load16(w, Wt, 2 * u0 + half, Kd, O, (t / TRF_RT) * 32 + j, O, inside(t, u0));
+  };
+  // The operands of step s + 1 (a step = 32 k of a tile; the wave's tiles one after the other) are requested BEFORE
+  // the MFMAs of step s, and a scheduling barrier keeps them there (left alone, the compiler sinks the loads below
+  // the MFMAs and waits for them at the top of the next step): a layer used to be a chain of exposed round trips to
+  // L2, one per step - 4 per tile of a 128-wide layer, 12 per wave in the final layer of config 4's flow.  (Two steps
+  // ahead costs a third operand buffer and its addresses - 29 / 71 spilled registers - for copies that wait anyway.)
+  const int n_tiles = TRF_RT * OT;
+  int tn = wave, un = 0;  // the step the next request is for
+  auto advance = [&]() {  // (stays on the last step once there: re-reads that are dropped)
+    const bool more_k = un + 16 < pairs, more_t = tn + TRF_WAVES < n_tiles;
+    un = more_k ? un + 16 : (more_t ? 0 : un);
+    tn = more_k ? tn : (more_t ? tn + TRF_WAVES : tn);
+  };
+  float wv[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) wv[q] = pre.v[q];
+  stamp();
+  for (int t = wave; t < n_tiles; t += TRF_WAVES) {
     const int rt = t % TRF_RT, ot = t / TRF_RT;
     const int o = ot * 32 + j;
     const bool o_ok = o < O;
-    const unsigned oc = (unsigned)(o_ok ? o : O - 1);
     f32x16 acc = {0}, acc2 = {0};
     const float* ax = Ain + (rt * 32 + j) * ld;
     for (int u0 = 0; u0 < pairs; u0 += 16) {
-      float wv[16];
-      if (t == wave && u0 == 0) {  // wave-uniform
+      float wn[16];
+      advance();
+      load_w(wn, tn, un);
+      __builtin_amdgcn_sched_barrier(0);
+      // all LDS reads of the batch are issued before the first MFMA (a dependent read per step
+      // would serialise the chain on the LDS latency)
+      float av[16];
+      if (inside(t, u0)) {  // wave-uniform: nothing to clamp or to zero
+        const float* ak = ax + 2 * u0 + half;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) wv[q] = pre.v[q];
+        for (int q = 0; q < 16; ++q) av[q] = ak[2 * q];
+        trf_act_batch(av, act_in);
       } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int k = 2 * (u0 + q) + half;
-          wv[q] = Wt[(unsigned)(k < Kd ? k : Kd - 1) * (unsigned)O + oc];  // lanes along the row: coalesced
+          av[q] = ax[k < Kd ? k : 0];
         }
-      }
-      // all LDS reads of the batch are issued before the first MFMA (a dependent read per step
-      // would serialise the chain on the LDS latency)
-      float av[16];
+        trf_act_batch(av, act_in);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int k = 2 * (u0 + q) + half;
-        av[q] = ax[k < Kd ? k : 0];
-      }
-      trf_act_batch(av, act_in);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int k = 2 * (u0 + q) + half;
-        const bool ok = k < Kd;
-        av[q] = ok ? av[q] : 0.0f;
-        wv[q] = (ok && o_ok) ? wv[q] : 0.0f;
+        for (int q = 0; q < 16; ++q) {
+          const int k = 2 * (u0 + q) + half;
+          const bool ok = k < Kd;
+          av[q] = ok ? av[q] : 0.0f;
+          wv[q] = (ok && o_ok) ? wv[q] : 0.0f;
+        }
       }
       // two independent accumulation chains, no branches (k beyond Kd carries zero operands):
       // guarded, single-chain MFMAs issued at 100-145 cycles each instead of 64
@@ -191,6 +245,13 @@ __device__ __forceinline__ void trf_linear(const float* __restrict__ Ain, int Kd
         acc = nsa_mfma(av[q], wv[q], acc);
         acc2 = nsa_mfma(av[q + 1], wv[q + 1], acc2);
       }
+      if (fine != nullptr) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (blockIdx.x == 0 && threadIdx.x == 0) fine[fine_i++] = (float)(long long)(clock64() - t_start);  // MFMAs issued
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) wv[q] = wn[q];
+      stamp();
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
@@ -205,6 +266,7 @@ __device__ __forceinline__ void trf_linear(const float* __restrict__ Ain, int Kd
         if (r0 + rl < n) out_glb[(unsigned)(r0 + rl) * (unsigned)ld_glb + (unsigned)o] = v;
       }
     }
+    stamp();
   }
 }
 
@@ -216,37 +278,56 @@ __device__ __forceinline__ void trf_dx(const float* __restrict__ G, int g_ld, in
   const int half = lane >> 5, j = lane & 31;
   const int KT = (Kd + 31) >> 5;
   const int pairs = (O + 1) >> 1;
-  for (int t = wave; t < TRF_RT * KT; t += nw) {
+  // B operands of step (tile t, pairs [u0, u0 + 16)): lanes along the row of W - coalesced
+  auto inside = [&](int t, int u0) { return 2 * (u0 + 16) <= O && (t / TRF_RT) * 32 + 32 <= Kd; };  // wave-uniform
+  auto load_w = [&](float (&w)[16], int t, int u0) {
+    trf_load16(w, W, 2 * u0 + half, O, Kd, (t / TRF_RT) * 32 + j, Kd, inside(t, u0));
+  };
+  const int n_tiles = TRF_RT * KT;
+  int tn = wave, un = 0;  // the step the next request is for (trf_linear has the reasoning)
+  auto advance = [&]() {
+    const bool more_o = un + 16 < pairs, more_t = tn + nw < n_tiles;
+    un = more_o ? un + 16 : (more_t ? 0 : un);
+    tn = more_o ? tn : (more_t ? tn + nw : tn);
+  };
+  float wv[16];
+  if (wave < n_tiles) load_w(wv, tn, un);
+  for (int t = wave; t < n_tiles; t += nw) {
     const int rt = t % TRF_RT, kt = t / TRF_RT;
     const int kcol = kt * 32 + j;
-    const unsigned wc = (unsigned)(kcol < Kd ? kcol : Kd - 1);
     const bool col_ok = kcol < Kd;
     f32x16 acc = {0}, acc2 = {0};
     const float* ag = G + (rt * 32 + j) * g_ld;
     for (int u0 = 0; u0 < pairs; u0 += 16) {
-      float wv[16], av[16];
+      float wn[16], av[16];
+      advance();
+      load_w(wn, tn, un);
+      __builtin_amdgcn_sched_barrier(0);
+      if (inside(t, u0)) {  // wave-uniform: nothing to clamp or to zero
+        const float* ao = ag + 2 * u0 + half;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int o = 2 * (u0 + q) + half;
-        wv[q] = W[(unsigned)(o < O ? o : O - 1) * (unsigned)Kd + wc];  // lanes along the row: coalesced
-      }
+        for (int q = 0; q < 16; ++q) av[q] = ao[2 * q];  // LDS reads issued together, not one per MFMA
+      } else {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {  // LDS reads issued together, not one per MFMA
-        const int o = 2 * (u0 + q) + half;
-        av[q] = ag[o < O ? o : 0];
-      }
+        for (int q = 0; q < 16; ++q) {
+          const int o = 2 * (u0 + q) + half;
+          av[q] = ag[o < O ? o : 0];
+        }
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int o = 2 * (u0 + q) + half;
-        const bool ok = o < O;
-        av[q] = ok ? av[q] : 0.0f;
-        wv[q] = (ok && col_ok) ? wv[q] : 0.0f;
+        for (int q = 0; q < 16; ++q) {
+          const int o = 2 * (u0 + q) + half;
+          const bool ok = o < O;
+          av[q] = ok ? av[q] : 0.0f;
+          wv[q] = (ok && col_ok) ? wv[q] : 0.0f;
+        }
       }
 #pragma unroll
       for (int q = 0; q < 16; q += 2) {  // two independent chains; o beyond O carries zero operands
         acc = nsa_mfma(av[q], wv[q], acc);
         acc2 = nsa_mfma(av[q + 1], wv[q + 1], acc2);
       }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) wv[q] = wn[q];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
@@ -280,19 +361,27 @@ __device__ __forceinline__ void trf_dw(const float* __restrict__ G, int g_ld, in
     const bool o_ok = oc < O, k_ok = kc < Kd;
     f32x16 acc = {0}, acc2 = {0};
     const int ocl = o_ok ? oc : 0, kcl = k_ok ? kc : 0;
+    const bool full = ot * 32 + 32 <= O && kt * 32 + 32 <= Kd;  // wave-uniform: no operand to zero
     for (int ub = 0; ub < TRF_ROWS / 2; ub += 16) {  // 32 LDS reads issued before each 16-MFMA chain
       float av[16], bv[16];
+      {  // rows 2 (ub + q) + half: one address each, a constant stride apart
+        const float* gp_ = G + (2 * ub + half) * g_ld + ocl;
+        const float* ap_ = Ain + (2 * ub + half) * a_ld + kcl;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = 2 * (ub + q) + half;
-        av[q] = G[row * g_ld + ocl];
-        bv[q] = Ain[row * a_ld + kcl];
+        for (int q = 0; q < 16; ++q) {
+          av[q] = *gp_;
+          bv[q] = *ap_;
+          gp_ += 2 * g_ld;
+          ap_ += 2 * a_ld;
+        }
       }
       trf_act_batch(bv, act_in);
+      if (!full) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        av[q] = o_ok ? av[q] : 0.0f;
-        bv[q] = k_ok ? bv[q] : 0.0f;
+        for (int q = 0; q < 16; ++q) {
+          av[q] = o_ok ? av[q] : 0.0f;
+          bv[q] = k_ok ? bv[q] : 0.0f;
+        }
       }
 #pragma unroll
       for (int q = 0; q < 16; q += 2) {  // D[i = o][jj = k], two independent chains
@@ -348,7 +437,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_forward(TrfArgs a) {
     trf_linear_preload(pre, WT + a.off[4 + 4 * l], H, H, wave, lane);
     trf_barrier_lds();
     trf_linear(A0, H, a.act, WT + a.off[4 + 4 * l], P + a.off[5 + 4 * l], H, A1, A1, a.h + (l + 1) * nH, H, ld,
-               r0, n, wave, lane, pre);
+               r0, n, wave, lane, pre, (a.dbg != nullptr && l == 0) ? a.dbg + 44 : nullptr, t_start);
     TRF_MARK(3 + 2 * l);
   }
   // parameters = Wf h_L + bf (global only)
@@ -410,8 +499,10 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
                               a.c.aff_a, a.c.aff_b);
     }
   }
+  TRF_MARK(31);
   trf_stage(A1, ld, a.h + a.L * nH, H, r0, n, 0, H, H, nullptr, tid);  // h_L
   __syncthreads();
+  TRF_MARK(30);
 
   // final layer, a.ch parameters at a time: dWf, dbf (waves 4-7) and gh = gp . Wf (waves 0-3)
   const int KT = (H + 31) >> 5;  // <= 4: 2 KT <= 8 tiles of gh, two per wave of the dX group
@@ -420,6 +511,18 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
   acc_dx[1] = f32x16{0};
   const float* Wf = P + a.off[2 + 4 * a.L];
   const int CH = a.ch, CLD = a.ch + 1;
+  // B operands of step (chunk c0, tile t, pairs [u0, u0 + 16)) of gh = gp . Wf: lanes along the row of Wf
+  auto inside_f = [&](int c0, int t, int u0) {  // wave-uniform
+    return c0 + 2 * (u0 + 16) <= np && 2 * (u0 + 16) <= a.ch && (t / TRF_RT) * 32 + 32 <= H;
+  };
+  auto load_wf = [&](float (&w)[16], int c0, int t, int u0) {
+    trf_load16(w, Wf + (long long)c0 * H, 2 * u0 + half, np - c0, H, (t / TRF_RT) * 32 + j, H, inside_f(c0, t, u0));
+  };
+  // the dX group's steps in the order they run, each requesting the operands of the one behind it (see trf_linear):
+  // a chunk used to be 8 exposed round trips to L2 per wave, 48 per launch with config 4's 736 parameters
+  const bool two_tiles = gw + 4 < TRF_RT * KT;
+  float wv[16];
+  if (dx_group && gw < TRF_RT * KT) load_wf(wv, 0, gw, 0);
   for (int c0 = 0; c0 < np; c0 += CH) {
     const int nc = (np - c0 < CH) ? (np - c0) : CH;
     if (c0 > 0) __syncthreads();
@@ -432,32 +535,44 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
         if (t < TRF_RT * KT) {
           const int rt = t % TRF_RT, kt = t / TRF_RT;
           const int kcol = kt * 32 + j;
-          const unsigned wc = (unsigned)(kcol < H ? kcol : H - 1);
           const bool col_ok = kcol < H;
           const float* ag = gc + (rt * 32 + j) * CLD;
           for (int u0 = 0; u0 < CH / 2; u0 += 16) {
             if (2 * u0 < nc) {  // wave-uniform
-              float wv[16];
-#pragma unroll
-              for (int q = 0; q < 16; ++q) {
-                const int o = c0 + 2 * (u0 + q) + half;
-                wv[q] = Wf[(unsigned)(o < np ? o : np - 1) * (unsigned)H + wc];
+              float wn[16];
+              {
+                const bool more_u = 2 * (u0 + 16) < nc && u0 + 16 < CH / 2;
+                const bool more_t = s_ == 0 && two_tiles;
+                const bool more_c = c0 + CH < np;
+                // next: same tile; else the other tile of this chunk; else tile gw of the next chunk; else a re-read
+                const int c2 = (more_u || more_t) ? c0 : (more_c ? c0 + CH : c0);
+                const int t2 = more_u ? t : (more_t ? gw + 4 : gw);
+                load_wf(wn, c2, t2, more_u ? u0 + 16 : 0);
               }
+              __builtin_amdgcn_sched_barrier(0);
               float av[16];
+              if (inside_f(c0, t, u0)) {  // wave-uniform: nothing to clamp or to zero
+                const float* ao = ag + 2 * u0 + half;
 #pragma unroll
-              for (int q = 0; q < 16; ++q) {
-                const int oc = 2 * (u0 + q) + half;
-                av[q] = ag[oc < nc ? oc : 0];
-              }
+                for (int q = 0; q < 16; ++q) av[q] = ao[2 * q];
+              } else {
 #pragma unroll
-              for (int q = 0; q < 16; ++q) {
-                const int oc = 2 * (u0 + q) + half;
-                const bool ok = oc < nc;
-                av[q] = ok ? av[q] : 0.0f;
-                wv[q] = (ok && col_ok) ? wv[q] : 0.0f;
+                for (int q = 0; q < 16; ++q) {
+                  const int oc = 2 * (u0 + q) + half;
+                  av[q] = ag[oc < nc ? oc : 0];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                  const int oc = 2 * (u0 + q) + half;
+                  const bool ok = oc < nc;
+                  av[q] = ok ? av[q] : 0.0f;
+                  wv[q] = (ok && col_ok) ? wv[q] : 0.0f;
+                }
               }
 #pragma unroll
               for (int q = 0; q < 16; ++q) acc_dx[s_] = nsa_mfma(av[q], wv[q], acc_dx[s_]);
+#pragma unroll
+              for (int q = 0; q < 16; ++q) wv[q] = wn[q];
             }
           }
         }
@@ -483,6 +598,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
     }
   }
   __syncthreads();
+  TRF_MARK(32);
 
   for (int l = a.L - 1; l >= 0; --l) {
     trf_stage(A0, ld, a.u + l * nH, H, r0, n, 0, H, H, nullptr, tid);  // u_l
@@ -496,6 +612,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf_backward(TrfArgs a) {
     if (dx_group) trf_dx(G1, ld, H, P + a.off[2 + 4 * l], H, A1, a.act, G0, 1, ld, gw, 4, lane);
     else trf_dw(G1, ld, H, A1, ld, H, a.act, GR + a.off[2 + 4 * l], GR + a.off[3 + 4 * l], gw, 4, lane);
     trf_barrier_lds();
+    TRF_MARK(33 + (a.L - 1 - l));
   }
 
   // initial layer: dW0, db0 and g_x[:, id_cols] += gh . W0 (x was restored above)
