@@ -1676,7 +1676,17 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
         a.n = (int)n; a.D = D; a.H = H; a.L = L; a.d_id = d_id; a.d_tr = d_tr; a.np = np; a.act = act;
         a.transform = transform;
         a.ld = ((H > d_id ? H : d_id) + 1) | 1;
-        a.ch = H > 96 ? 64 : 128;  // keeps the backward workgroup inside 160 KB of LDS
+        {
+          // chunk of the final layer's backward pass (first generation): as few chunks as fit next to the four
+          // activation / gradient tiles in 150 KB of LDS, equal in size, a multiple of 32 parameters - every chunk
+          // is a staging round trip and two workgroup barriers (config 4's 736 parameters: two chunks, twelve before)
+          const int tiles = 4 * TRF_ROWS * a.ld;
+          int ch_max = (((150 * 1024) / 4 - tiles) / TRF_ROWS - 1) & ~31;
+          ch_max = ch_max < 64 ? 64 : ch_max;
+          const int chunks = (np + ch_max - 1) / ch_max;
+          a.ch = (((np + chunks - 1) / chunks) + 31) & ~31;
+          a.ch = a.ch < 64 ? 64 : a.ch;
+        }
         a.dbg = getenv("NESSAI_AMD_TRAIN_TIMING") ? w.scal + 64 : nullptr;
         a.id_cols = id_cols; a.tr_cols = tr_cols; a.params = params; a.grads = grads; a.X = w.x; a.Gx = w.gx;
         a.xsave = xsave; a.h = h; a.u = u; a.p = p; a.gp = w.gp; a.gld = w.gld; a.c = c;
