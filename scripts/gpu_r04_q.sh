@@ -1,7 +1,9 @@
 #!/bin/bash
-# training fuzz on the final library (both generations of the fused kernels; TRAIN_V2=0 sends every fused case to the first)
-mkdir -p gpurun_out/r4q2
-for s in 3 4; do
-  python scripts/fuzz_train.py --iterations 75 --seed $s 2>&1 | grep -v amdgpu.ids | tail -n 4 | cut -c1-600
-  NESSAI_AMD_TRAIN_V2=0 python scripts/fuzz_train.py --iterations 75 --seed $s 2>&1 | grep -v amdgpu.ids | tail -n 4 | cut -c1-600
-done | tee gpurun_out/r4q2/fuzz_train.txt
+# more seeds of the randomised sweeps on the final library
+mkdir -p gpurun_out/r4q3
+for s in 5 6; do
+  python scripts/fuzz_parity.py --iterations 350 --seed $s 2>&1 | grep -v amdgpu.ids | cut -c1-700 > gpurun_out/r4q3/parity_seed$s.txt
+  tail -n 1 gpurun_out/r4q3/parity_seed$s.txt
+done
+python scripts/fuzz_populate.py --iterations 80 --seed 5 2>&1 | grep -v amdgpu.ids | tail -n 3 | cut -c1-500 | tee gpurun_out/r4q3/populate_seed5.txt
+python scripts/fuzz_reparam.py --iterations 50 --seed 5 2>&1 | grep -v amdgpu.ids | tail -n 3 | cut -c1-500 | tee gpurun_out/r4q3/reparam_seed5.txt
