@@ -96,13 +96,14 @@ __global__ void tr_transpose_weights(long long n, const float* __restrict__ p, c
 __device__ __forceinline__ void trf_stage(float* __restrict__ tile, int ld, const float* __restrict__ src,
                                           int src_ld, int r0, int n, int c0, int nc, int nc_valid,
                                           const int* __restrict__ cols, int tid) {
-  // flattened (row, col) index; 4 loads in flight per thread before the LDS stores
+  // flattened (row, col) index; 8 loads in flight per thread before the LDS stores (a 32 x 128 tile in ONE round trip,
+  // a 384-parameter chunk of the final layer's gradient in three)
   const int total = TRF_ROWS * nc;
-  for (int base = tid; base < total; base += TRF_THREADS * 4) {
-    float v[4];
-    int dst[4];
+  for (int base = tid; base < total; base += TRF_THREADS * 8) {
+    float v[8];
+    int dst[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 8; ++q) {
       const int idx = base + TRF_THREADS * q;
       const int r = idx / nc, c = idx - r * nc;
       const int row = r0 + r;
@@ -112,7 +113,7 @@ __device__ __forceinline__ void trf_stage(float* __restrict__ tile, int ld, cons
         v[q] = src[(unsigned)row * (unsigned)src_ld + (unsigned)(cols ? cols[c0 + c] : c0 + c)];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 8; ++q)
       if (dst[q] >= 0) tile[dst[q]] = v[q];
   }
 }
