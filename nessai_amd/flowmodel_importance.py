@@ -20,6 +20,7 @@ import torch
 from .flowmodel import FlowModel
 from .flows import configure_model
 from .flows.base import log_prob_many
+from .utils import eval_mode
 
 logger = logging.getLogger(__name__)
 
@@ -85,14 +86,14 @@ class ImportanceFlowModel(FlowModel):
 
     def log_prob_ith(self, x, i):
         """log-density of the i-th flow (``importance.py:100-112``)."""
-        self.models[i].eval()
+        eval_mode(self.models[i])
         with torch.inference_mode():
             return self._to_numpy(self.models[i].log_prob(self._tensor(x)))
 
     def log_prob_all(self, x):
         """``(N, n_flows)`` log-densities, every flow on the same batch (``importance.py:114-129``)."""
         xt = self._tensor(x)
-        self.models.eval()
+        eval_mode(self.models)
         out = log_prob_many(self.models, xt)
         return self._to_numpy(out.t())
 
@@ -100,7 +101,7 @@ class ImportanceFlowModel(FlowModel):
         """Draw from the i-th flow (``importance.py:131-142``)."""
         if self.models is None:
             raise RuntimeError("Models are not initialised yet!")
-        self.models[i].eval()
+        eval_mode(self.models[i])
         with torch.inference_mode():
             return self._to_numpy(self.models[i].sample(int(N)))
 

@@ -36,6 +36,7 @@ from scipy.special import logsumexp
 from . import lib
 from .flowmodel_importance import ImportanceFlowModel
 from .flows.base import log_prob_many
+from .utils import eval_mode
 from .livepoint import (NON_SAMPLING_DEFAULTS, NON_SAMPLING_DTYPES, NON_SAMPLING_PARAMETERS, concatenate_points,
                         live_points_to_array, parameter_block, take_points)
 
@@ -297,7 +298,7 @@ class ImportanceFlowProposal:
             raise NotImplementedError("the gfx950 draw epilogue implements the logit reparameterisation only")
         L = lib.load()
         flow = self.flow.models[flow_number]
-        flow.eval()
+        eval_mode(flow)
         dev, D = self.flow.device, self.dims
         rank, world = self._rank_world()
         per = (n_rows + world - 1) // world if world > 1 else n_rows
@@ -390,7 +391,7 @@ class ImportanceFlowProposal:
 
     def _log_prob_ith(self, x_prime, it):
         flow = self.flow.models[it]
-        flow.eval()
+        eval_mode(flow)
         xp = torch.from_numpy(np.ascontiguousarray(x_prime)).to(torch.float32).to(self.flow.device)
         return self._log_prob_rows([flow], xp)[0].cpu().numpy().astype(np.float64)
 
@@ -420,7 +421,7 @@ class ImportanceFlowProposal:
             rc = lib.load().nsa_importance_to_prime(n, d, lib.ptr(xd), EPS, lib.ptr(xp), lib.ptr(log_j), self._stream())
             lib.check(rc, "nsa_importance_to_prime")
             flow = self.flow.models[self.level_count]
-            flow.eval()
+            eval_mode(flow)
             log_prob = self._log_prob_rows([flow], xp)[0]
             return (log_prob.to(torch.float64) + log_j).cpu().numpy()
 

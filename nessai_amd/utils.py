@@ -22,3 +22,19 @@ def rescale_log_jacobian(scales):
     for s in scales:
         total = total + np.log(np.abs(np.float64(s)))
     return float(total)
+
+
+def eval_mode(module):
+    """``module.eval()`` without the walk over the module tree when it is in eval mode already - a flow is ~90
+    modules, ``Module.eval`` ~0.35 ms of host time per call, and the importance sampler asked for it on every
+    ``draw`` / ``update_log_q``.  A ``ModuleList`` is checked flow by flow (a flow appended after the list was
+    switched is still in training mode); within a flow the mode is only ever changed from the top."""
+    import torch
+
+    if isinstance(module, torch.nn.ModuleList):
+        for m in module:
+            eval_mode(m)
+        module.training = False
+    elif module.training:
+        module.eval()
+    return module

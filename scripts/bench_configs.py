@@ -226,6 +226,8 @@ def run_c4_draw(n_flows_list=(1, 8, 32), nlive=5000, dims=64):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t) / 5
             stored = np.concatenate([pts] * 4)
+            prop.update_log_q(stored, np.zeros((stored.size, target)))  # (the first call of a level packs the image)
+            torch.cuda.synchronize()
             t = time.perf_counter()
             for _ in range(3):
                 prop.update_log_q(stored, np.zeros((stored.size, target)))

@@ -284,3 +284,27 @@ def test_flow_factory_schema():
     flow = U.configure_model(cfg)
     assert isinstance(flow, RealNVP) and flow._distribution.var == 2.0
     assert cfg["ftype"] == "realnvp" and "distribution_kwargs" in cfg  # the caller's dictionary is left alone
+
+
+def test_eval_mode_switches_only_what_is_in_training_mode():
+    """nessai_amd.utils.eval_mode == Module.eval() in effect (every flow and every submodule in eval mode), without
+    the walk over the tree when there is nothing to switch - including a flow appended to a list that was switched
+    before (ImportanceFlowModel.add_new_flow)."""
+    import torch
+
+    from nessai_amd.utils import eval_mode
+
+    def flow():
+        return torch.nn.Sequential(torch.nn.Linear(2, 2), torch.nn.BatchNorm1d(2))
+
+    models = torch.nn.ModuleList([flow(), flow()])
+    eval_mode(models)
+    assert not any(m.training for m in models.modules())
+    calls = []
+    models[0].eval = lambda: calls.append("walk")  # must not be called again
+    models.append(flow())  # a new flow arrives in training mode
+    assert models[2].training and models[2][1].training
+    eval_mode(models)
+    assert calls == [] and not any(m.training for m in models.modules())
+    single = flow()
+    assert eval_mode(single) is single and not single[1].training
