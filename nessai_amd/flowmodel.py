@@ -16,6 +16,7 @@ import torch
 
 from .flows import configure_model, reset_permutations, reset_weights
 from .flows.utils import get_n_neurons
+from .utils import eval_mode
 
 logger = logging.getLogger(__name__)
 
@@ -90,7 +91,7 @@ class FlowModel:
             )
         self.model.to(self.device)
         self.inference_device = self.device
-        self.model.eval()
+        eval_mode(self.model)
         self._trainer = None
         self.initialised = True
 
@@ -140,27 +141,27 @@ class FlowModel:
 
     def forward_and_log_prob(self, x):
         """x' -> (z, log_prob) (``base.py:782-811``)."""
-        self.model.eval()
+        eval_mode(self.model)
         with torch.inference_mode():
             z, log_prob = self.model.forward_and_log_prob(self.numpy_array_to_tensor(x))
         return self._to_numpy(z), self._to_numpy(log_prob)
 
     def inverse(self, z):
         """z -> (x', log|det J|) (``base.py:813-840``)."""
-        self.model.eval()
+        eval_mode(self.model)
         with torch.inference_mode():
             x, log_j = self.model.inverse(self.numpy_array_to_tensor(z))
         return self._to_numpy(x), self._to_numpy(log_j)
 
     def log_prob(self, x):
         """(``base.py:842-864``)."""
-        self.model.eval()
+        eval_mode(self.model)
         with torch.inference_mode():
             return self._to_numpy(self.model.log_prob(self.numpy_array_to_tensor(x)))
 
     def sample(self, n=1):
         """(``base.py:866-887``)."""
-        self.model.eval()
+        eval_mode(self.model)
         with torch.inference_mode():
             return self._to_numpy(self.model.sample(int(n)))
 
@@ -172,7 +173,7 @@ class FlowModel:
         """(``base.py:906-948``)."""
         if self.model is None:
             raise RuntimeError("Model is not initialised yet!")
-        self.model.eval()
+        eval_mode(self.model)
         with torch.inference_mode():
             if z is None:
                 x, log_prob = self.model.sample_and_log_prob(int(N))
@@ -249,7 +250,7 @@ class FlowModel:
                              weights=weights)
         current_weights_file = os.path.join(output, "model.pt")
         self.save_weights(current_weights_file)
-        self.model.eval()
+        eval_mode(self.model)
         return history
 
     # -- weights I/O -----------------------------------------------------------
@@ -268,7 +269,7 @@ class FlowModel:
         self.model.load_state_dict(
             torch.load(weights_file, map_location=self.device, weights_only=True)
         )
-        self.model.eval()
+        eval_mode(self.model)
         self.weights_file = weights_file
 
     def reload_weights(self, weights_file):
@@ -283,7 +284,7 @@ class FlowModel:
         if weights and permutations:
             self.model = configure_model(self.flow_config)
             self.model.to(self.device)
-            self.model.eval()
+            eval_mode(self.model)
         elif weights:
             self.model.apply(reset_weights)
         elif permutations:
