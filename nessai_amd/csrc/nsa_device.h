@@ -126,11 +126,31 @@ __device__ __forceinline__ float nsa_relu(float x) {
   return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
+// tanh and silu on the bare transcendental units (v_exp_f32, v_rcp_f32: 1 ulp each): tanhf / expf + an IEEE division
+// are ~40 instructions per value, and a conditioner has 64-256 values per row and layer - a tanh flow ran 2x the time
+// of the same flow with relu.
+//   silu(x) = x / (1 + 2^(-x log2 e));  overflow of the power gives x * 0
+//   tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)) away from zero, where the subtraction is harmless;
+//             x (1 - x^2/3 + 2 x^4/15 - 17 x^6/315 + 62 x^8/2835) for |x| < 1/4 (next term < 1e-8 relative);
+//             worst error 1.3e-7 absolute, 5e-7 relative (just above 1/4), against float64
+__device__ __forceinline__ float nsa_silu_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float nsa_tanh_fast(float x) {
+  const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + t), 1.0f);  // t = inf -> 1, t = 0 -> -1
+  const float s = x * x;
+  const float small = x * fmaf(s, fmaf(s, fmaf(s, fmaf(s, 0.021869488536155203f, -0.053968253968253971f), 0.13333333333333333f),
+                                        -0.33333333333333333f), 1.0f);
+  return __builtin_fabsf(x) < 0.25f ? small : big;
+}
+
 // activation of the conditioner (src/nessai/flows/utils.py:200-205)
 __device__ __forceinline__ float nsa_act(float x, int kind) {
   if (kind == NSA_ACT_RELU) return nsa_relu(x);
-  if (kind == NSA_ACT_TANH) return tanhf(x);
-  return x * (1.0f / (1.0f + expf(-x)));  // silu: x * sigmoid(x)
+  if (kind == NSA_ACT_TANH) return nsa_tanh_fast(x);
+  return nsa_silu_fast(x);  // silu: x * sigmoid(x)
 }
 
 // Async global -> LDS copy of one 1 KiB piece per wave instruction

@@ -565,10 +565,10 @@ __device__ __forceinline__ void nsa_act_regs(float (&a)[N], int act) {
     for (int i = 0; i < N; ++i) a[i] = nsa_relu(a[i]);
   } else if (act == NSA_ACT_TANH) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) a[i] = tanhf(a[i]);
+    for (int i = 0; i < N; ++i) a[i] = nsa_tanh_fast(a[i]);
   } else {
 #pragma unroll
-    for (int i = 0; i < N; ++i) a[i] = a[i] * (1.0f / (1.0f + expf(-a[i])));
+    for (int i = 0; i < N; ++i) a[i] = nsa_silu_fast(a[i]);
   }
 }
 
