@@ -529,3 +529,30 @@ def test_auto_noise_floor_branch_on_a_flow_captured_mid_run():
     assert max(e32k, e32o) > 3e-6                      # float32 itself is not unique to the bar here ...
     assert e16 <= 3.0 * max(e32k, e32o)                # ... and split-f16 is float32-class: as close as either
     assert e16 <= 1e-4                                 # (and nowhere near the 1e-3 of plain 16-bit operands)
+
+
+@pytest.mark.parametrize("act_name", ["tanh", "silu"])
+@pytest.mark.parametrize("gain", [0.02, 1.0, 30.0])
+def test_bare_unit_activations_over_their_whole_range(act_name, gain):
+    """tanh / silu of the conditioner run on the bare v_exp_f32 / v_rcp_f32 units (csrc/nsa_device.h nsa_tanh_fast /
+    nsa_silu_fast).  Weights scaled so that the pre-activations sit inside the polynomial branch of tanh (gain 0.02),
+    around one, or deep in saturation where 2^(2x log2 e) overflows (gain 30): exact-f32 mode within the log_prob bar of
+    the float32 oracle or, where that oracle is itself further from its float64 twin, within 3x its error; never a NaN."""
+    import copy
+
+    acts = {"tanh": torch.tanh, "silu": torch.nn.functional.silu}
+    ref, flow = make_pair(RealNVP, O.RealNVP, (6, 32, 3, 2), dict(activation=acts[act_name], net="mlp"), seed=17)
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if name.endswith("weight") and p.ndim == 2 and p.shape[0] == 32:  # the layers in front of an activation
+                p.mul_(gain)
+    flow.load_state_dict(ref.state_dict())
+    flow.precision = "f32"
+    x = torch.randn(4097, 6, generator=torch.Generator().manual_seed(5)) * 2.0
+    ref64 = copy.deepcopy(ref).double()
+    with torch.no_grad():
+        lp_ref, lp64 = ref.log_prob(x), ref64.log_prob(x.double())
+        lp = flow.log_prob(x.to(DEV)).cpu()
+    assert bool(torch.isfinite(lp).all())
+    err = rel_err(lp, lp_ref, floor=1e-3)
+    assert err <= 1e-5 or rel_err(lp, lp64, floor=1e-3) <= 3.0 * rel_err(lp_ref, lp64, floor=1e-3), err
