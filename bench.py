@@ -101,15 +101,17 @@ def time_draw_kernel(prop, launches=10, precision=None, rows=None):
 def _time_draw_kernel(prop, n, launches):
     buf = prop._get_buffers(n, NLIVE)
     prepared = prop._prepare_flow()
+    # the launch populate() makes: since round 5 the lean pass (no candidate rows: log_q alone is written)
+    x64 = None if prop.last_populate_lean else buf["x64"]
     for _ in range(2):
-        prop._launch_draw(n, None, 0, prop.fixed_radius, buf["x64"], buf["log_q"], None, prepared=prepared)
+        prop._launch_draw(n, None, 0, prop.fixed_radius, x64, buf["log_q"], None, prepared=prepared)
     torch.cuda.synchronize()
     events = []
     for i in range(launches):
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
-        prop._launch_draw(n, None, i * n, prop.fixed_radius, buf["x64"], buf["log_q"], None, prepared=prepared)
+        prop._launch_draw(n, None, i * n, prop.fixed_radius, x64, buf["log_q"], None, prepared=prepared)
         e.record()
         events.append((s, e))
     torch.cuda.synchronize()
@@ -486,17 +488,20 @@ def main():
             "passes_per_step": proposed / batch / args.steps,
             "roofline": {
                 "kernel": f"nsa_flow_kernel<2, NsaRQ<8>, inverse, {precision}> "
-                          "(fused draw + inverse flow + rescale + bounds + log_q)",
+                          "(fused draw + inverse flow + rescale + bounds + log_q" +
+                          ("; lean: no candidate rows written)" if prop.last_populate_lean else ")"),
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_TFLOPS[precision],
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_TFLOPS[precision],
-                # HBM bytes per launch: PMC counters read in THIS run (measure_traffic); algorithmic
-                # bytes are 264 MB (x as float64 + log_q)
+                # HBM bytes per launch: PMC counters read in THIS run (measure_traffic); algorithmic bytes per
+                # row: 8 (log_q) for the lean pass populate() runs since round 5 - only accepted rows are ever
+                # used, and those are computed again from their Philox rows - 264 (x as float64 + log_q) before
                 "traffic": traffic,
                 "traffic_detail": traffic_detail,
-                "algorithmic_bytes": 264.0 * rows_per_launch,
+                "lean_pass": bool(prop.last_populate_lean),
+                "algorithmic_bytes": (8.0 if prop.last_populate_lean else 264.0) * rows_per_launch,
                 "kernel_ms_avg": kernel_ms,
                 "kernel_ms_min": kernel_ms_min,
                 # chosen by the library (big batches of the 16-bit modes: round-count estimate of nsa_big_batch_geometry, nsa_api.hip)

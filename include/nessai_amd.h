@@ -131,7 +131,8 @@ NSA_API int nsa_flow_run_many(const uint32_t* header, const void* const* image_l
  *   scale/shift [D] float64 z-score sigma / mu        (x = x' * sigma + mu)
  *   lower/upper [D] float64 prior bounds
  *   log_j_rescale  sum_i log|sigma_i| accumulated in the reference's order
- *   x64_out_dev [n][D] float64 samples in the physical space
+ *   x64_out_dev [n][D] float64 samples in the physical space; NULL = the lean pass (log_q_out_dev alone is
+ *               written, every test of the row still made: see nsa_populate_passes_lean)
  *   log_q_out_dev [n] float64 log proposal density; NaN marks a dropped row
  *               (outside radius / non-finite / out of bounds / spline failure)
  *   z_out_dev   [n][D] float32 or NULL
@@ -323,6 +324,58 @@ NSA_API int nsa_populate_train_tails(long long n, int D, int n_passes, const dou
 NSA_API int nsa_populate_train_commit(long long* state_dev, long long capacity, int n_passes,
                               const long long* local_counts_dev, const long long* global_counts_dev,
                               long long* history_dev, void* stream);
+
+/* LEAN trains of passes: the same loops WITHOUT materialised candidates.
+ *
+ * Only accepted rows are ever used (`samples[...] = x[accept][:m]`, flowproposal.py:492-498) - at config 3's
+ * acceptance that is ~86 of the 1e6 rows of a pass - and a candidate row is a pure function of its Philox
+ * counter (the global row) and the flow.  So a lean pass keeps every row's float64 arithmetic (inverse
+ * reparameterisation, prior bounds, separable prior, log q) in registers and writes log_q alone: 8 bytes per
+ * row instead of 8 (D + 1); the accept step lists the accepted rows by their GLOBAL Philox rows in idx_acc_dev
+ * (int64, draw order across the passes, same loop state as nsa_populate_passes), and nsa_populate_replay
+ * computes exactly those rows again - the same kernel instance reading row_list_dev[r] in place of
+ * row_offset + r - into x64_out_dev [m][D] (and log_q_out_dev [m]), bit for bit the rows the full pass would
+ * have written.  Not for the likelihood-threshold rule (rules->ll_kind >= 0 is refused: it needs the
+ * candidate rows) nor for accumulate_weights, which keep nsa_populate_passes / the arena.
+ *   nsa_populate_passes_lean       = nsa_populate_passes minus x64_dev, with idx_acc_dev [capacity] for x_acc_dev
+ *   nsa_populate_train_heads_lean  = nsa_populate_train_heads minus x64_many_dev
+ *   nsa_populate_train_tails_lean  = nsa_populate_train_tails minus x64_many_dev, with idx_acc_dev for x_acc_dev
+ *   nsa_populate_replay            m rows of row_list_dev through the populate pass (arguments as
+ *                                  nsa_populate_draw; the latent radius test is repeated and holds) */
+NSA_API int nsa_populate_passes_lean(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                             unsigned long long seed, unsigned long long row_offset, double radius,
+                             double latent_temperature, const double* scale_dev, const double* shift_dev,
+                             const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                             double* log_q_dev, const int* prior_kind_dev, const double* prior_par_dev,
+                             double* log_prior_dev, double log_prior_const, const int* rp_kind_dev,
+                             const double* rp_par_dev, double* log_w_dev, long long* max_keys_dev,
+                             long long capacity, long long* idx_acc_dev, long long* state_dev,
+                             void* workspace_dev, size_t workspace_bytes, int* status_dev,
+                             int waves_per_group, int max_groups, void* stream, const nsa_post_rules* rules);
+NSA_API int nsa_populate_replay(const uint32_t* header, const void* image_dev, long long m,
+                        const long long* row_list_dev, unsigned long long seed, double radius,
+                        double latent_temperature, const double* scale_dev, const double* shift_dev,
+                        const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                        double* x64_out_dev, double* log_q_out_dev, const int* prior_kind_dev,
+                        const double* prior_par_dev, double* log_prior_out_dev, const int* rp_kind_dev,
+                        const double* rp_par_dev, int* status_dev, int waves_per_group, int max_groups,
+                        void* stream);
+NSA_API int nsa_populate_train_heads_lean(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                                  unsigned long long seed, unsigned long long row_offset,
+                                  unsigned long long row_stride, double radius, double latent_temperature,
+                                  const double* scale_dev, const double* shift_dev, const double* lower_dev,
+                                  const double* upper_dev, double log_j_rescale, double* log_q_dev,
+                                  const int* prior_kind_dev, const double* prior_par_dev, double* log_prior_dev,
+                                  double log_prior_const, const int* rp_kind_dev, const double* rp_par_dev,
+                                  double* log_w_many_dev, long long* max_keys_dev, const long long* state_dev,
+                                  int* status_dev, int waves_per_group, int max_groups, void* stream,
+                                  const nsa_post_rules* rules);
+NSA_API int nsa_populate_train_tails_lean(long long n, int D, int n_passes, const double* log_w_many_dev,
+                                  const long long* max_keys_dev, unsigned long long seed,
+                                  unsigned long long row_offset, unsigned long long row_stride,
+                                  long long capacity, long long* idx_acc_dev, const long long* state_dev,
+                                  long long* scratch_dev, long long* local_counts_dev, void* workspace_dev,
+                                  size_t workspace_bytes, void* stream);
 
 /* accumulate_weights = True (flowproposal.py:471-476): out_dev[i] = sum over the n rows of pass i of
  * exp(log_w - max_i), max_i = decoded max_keys_dev[i] - what pass i adds to the expected number of

@@ -467,9 +467,10 @@ static int nsa_draw_params(NsaLaunch& p, const uint32_t* header, const void* ima
                            const double* shift_dev, const double* lower_dev, const double* upper_dev,
                            double log_j_rescale, double* x64_out_dev, double* log_q_out_dev, float* z_out_dev,
                            const int* prior_kind_dev, const double* prior_par_dev, double* log_prior_out_dev,
-                           const int* rp_kind_dev, const double* rp_par_dev, int* status_dev) {
+                           const int* rp_kind_dev, const double* rp_par_dev, int* status_dev, bool lean = false) {
+  // (lean: no candidate rows - x64_out_dev may be NULL, see NsaLaunch::row_list)
   if (image_dev == nullptr || scale_dev == nullptr || shift_dev == nullptr || lower_dev == nullptr ||
-      upper_dev == nullptr || x64_out_dev == nullptr || log_q_out_dev == nullptr || status_dev == nullptr)
+      upper_dev == nullptr || (x64_out_dev == nullptr && !lean) || log_q_out_dev == nullptr || status_dev == nullptr)
     return nsa_fail(NSA_E_ARG, "nsa_populate_draw: NULL pointer argument");
   if (header == nullptr) return nsa_fail(NSA_E_ARG, "header is NULL");
   if (!(latent_temperature > 0.0)) return nsa_fail(NSA_E_ARG, "nsa_populate_draw: latent_temperature must be > 0");
@@ -522,7 +523,7 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
   int rc = nsa_draw_params(p, header, image_dev, n, z_in_dev, seed, row_offset, radius, latent_temperature,
                            scale_dev, shift_dev, lower_dev, upper_dev, log_j_rescale, x64_out_dev, log_q_out_dev,
                            z_out_dev, prior_kind_dev, prior_par_dev, log_prior_out_dev, rp_kind_dev, rp_par_dev,
-                           status_dev);
+                           status_dev, /*lean=*/x64_out_dev == nullptr);
   if (rc != NSA_OK) return rc;
   return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
 }
@@ -594,7 +595,7 @@ extern "C" size_t nsa_accept_workspace_bytes(long long);
 extern "C" hipError_t nsa_launch_accept(long long, int, const double*, const long long*,
                                         unsigned long long, unsigned long long, const double*,
                                         const double*, long long, double*, long long*, long long*,
-                                        void*, hipStream_t, const long long*);
+                                        void*, hipStream_t, const long long*, long long idx_base = 0);
 
 extern "C" int nsa_populate_weights(long long n, const double* log_q_dev, const double* log_prior_dev,
                                     double log_prior_const, double* log_w_dev, long long* max_key_dev,
@@ -654,27 +655,31 @@ extern "C" int nsa_log_likelihood(int kind, long long n, int D, const double* x6
   return NSA_OK;
 }
 
-// A train of populate passes without host round trips (see include/nessai_amd.h).
-extern "C" int nsa_populate_passes(const uint32_t* header, const void* image_dev, long long n, int n_passes,
-                                   unsigned long long seed, unsigned long long row_offset, double radius,
-                                   double latent_temperature, const double* scale_dev, const double* shift_dev,
-                                   const double* lower_dev, const double* upper_dev, double log_j_rescale,
-                                   double* x64_dev, double* log_q_dev, const int* prior_kind_dev,
-                                   const double* prior_par_dev, double* log_prior_dev, double log_prior_const,
-                                   const int* rp_kind_dev, const double* rp_par_dev, double* log_w_dev,
-                                   long long* max_keys_dev, long long capacity, double* x_acc_dev,
-                                   long long* state_dev, void* workspace_dev, size_t workspace_bytes,
-                                   int* status_dev, int waves_per_group, int max_groups, void* stream,
-                                   const nsa_post_rules* rules) {
-  if (n <= 0 || n_passes < 1 || log_w_dev == nullptr || max_keys_dev == nullptr || x_acc_dev == nullptr ||
-      state_dev == nullptr || workspace_dev == nullptr || capacity < 0)
-    return nsa_fail(NSA_E_ARG, "nsa_populate_passes: bad argument");
-  if (workspace_bytes < nsa_accept_workspace_bytes(n))
-    return nsa_fail(NSA_E_ARG, "nsa_populate_passes: workspace too small");
+// A train of populate passes without host round trips (see include/nessai_amd.h).  x64_dev == NULL: the lean
+// form - no candidate rows are written, the accepted rows are listed by their global Philox rows in idx_acc_dev.
+static int nsa_passes_impl(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                           unsigned long long seed, unsigned long long row_offset, double radius,
+                           double latent_temperature, const double* scale_dev, const double* shift_dev,
+                           const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                           double* x64_dev, double* log_q_dev, const int* prior_kind_dev,
+                           const double* prior_par_dev, double* log_prior_dev, double log_prior_const,
+                           const int* rp_kind_dev, const double* rp_par_dev, double* log_w_dev,
+                           long long* max_keys_dev, long long capacity, double* x_acc_dev, long long* idx_acc_dev,
+                           long long* state_dev, void* workspace_dev, size_t workspace_bytes,
+                           int* status_dev, int waves_per_group, int max_groups, void* stream,
+                           const nsa_post_rules* rules, const char* who) {
+  const bool lean = x64_dev == nullptr;
+  if (n <= 0 || n_passes < 1 || log_w_dev == nullptr || max_keys_dev == nullptr ||
+      (lean ? idx_acc_dev == nullptr : x_acc_dev == nullptr) || state_dev == nullptr || workspace_dev == nullptr ||
+      capacity < 0)
+    return nsa_fail(NSA_E_ARG, "%s: bad argument", who);
+  if (workspace_bytes < nsa_accept_workspace_bytes(n)) return nsa_fail(NSA_E_ARG, "%s: workspace too small", who);
+  if (lean && rules != nullptr && rules->ll_kind >= 0)
+    return nsa_fail(NSA_E_ARG, "%s: the likelihood rule needs the candidate rows (use nsa_populate_passes)", who);
   NsaLaunch p;
   int rc = nsa_draw_params(p, header, image_dev, n, nullptr, seed, row_offset, radius, latent_temperature, scale_dev,
                            shift_dev, lower_dev, upper_dev, log_j_rescale, x64_dev, log_q_dev, nullptr,
-                           prior_kind_dev, prior_par_dev, log_prior_dev, rp_kind_dev, rp_par_dev, status_dev);
+                           prior_kind_dev, prior_par_dev, log_prior_dev, rp_kind_dev, rp_par_dev, status_dev, lean);
   if (rc != NSA_OK) return rc;
   p.stop = state_dev;
   hipStream_t s = (hipStream_t)stream;
@@ -689,7 +694,7 @@ extern "C" int nsa_populate_passes(const uint32_t* header, const void* image_dev
       hipError_t er = nsa_launch_post_rules(n, D, log_q_dev, rules, x64_dev, state_dev, s);
       if (er != hipSuccess) return nsa_fail(NSA_E_HIP, "populate pass %d (rules after the flow): %s", i, hipGetErrorString(er));
     }
-    if (n <= 16384) {  // NSA_SMALL_N: the whole tail of the pass in one single-workgroup kernel
+    if (n <= 16384 && !lean) {  // NSA_SMALL_N: the whole tail of the pass in one single-workgroup kernel
       hipError_t es = nsa_launch_small_tail(n, D, log_q_dev, per_row_prior, log_prior_const, seed, off, x64_dev,
                                             capacity, x_acc_dev, state_dev, s);
       if (es != hipSuccess) return nsa_fail(NSA_E_HIP, "populate pass %d: %s", i, hipGetErrorString(es));
@@ -699,11 +704,67 @@ extern "C" int nsa_populate_passes(const uint32_t* header, const void* image_dev
                                       state_dev);
     if (e == hipSuccess)
       e = nsa_launch_accept(n, D, log_w_dev, max_keys_dev + i, seed, off, nullptr, x64_dev, capacity, x_acc_dev,
-                            nullptr, state_dev + 4, workspace_dev, s, state_dev);
+                            idx_acc_dev, state_dev + 4, workspace_dev, s, state_dev, (long long)off);
     if (e == hipSuccess) e = nsa_launch_pass_commit(state_dev, capacity, nullptr, nullptr, s);
     if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "populate pass %d: %s", i, hipGetErrorString(e));
   }
   return NSA_OK;
+}
+
+extern "C" int nsa_populate_passes(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                                   unsigned long long seed, unsigned long long row_offset, double radius,
+                                   double latent_temperature, const double* scale_dev, const double* shift_dev,
+                                   const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                                   double* x64_dev, double* log_q_dev, const int* prior_kind_dev,
+                                   const double* prior_par_dev, double* log_prior_dev, double log_prior_const,
+                                   const int* rp_kind_dev, const double* rp_par_dev, double* log_w_dev,
+                                   long long* max_keys_dev, long long capacity, double* x_acc_dev,
+                                   long long* state_dev, void* workspace_dev, size_t workspace_bytes,
+                                   int* status_dev, int waves_per_group, int max_groups, void* stream,
+                                   const nsa_post_rules* rules) {
+  if (x64_dev == nullptr) return nsa_fail(NSA_E_ARG, "nsa_populate_passes: bad argument");
+  return nsa_passes_impl(header, image_dev, n, n_passes, seed, row_offset, radius, latent_temperature, scale_dev,
+                         shift_dev, lower_dev, upper_dev, log_j_rescale, x64_dev, log_q_dev, prior_kind_dev,
+                         prior_par_dev, log_prior_dev, log_prior_const, rp_kind_dev, rp_par_dev, log_w_dev, max_keys_dev,
+                         capacity, x_acc_dev, nullptr, state_dev, workspace_dev, workspace_bytes, status_dev,
+                         waves_per_group, max_groups, stream, rules, "nsa_populate_passes");
+}
+
+extern "C" int nsa_populate_passes_lean(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                                        unsigned long long seed, unsigned long long row_offset, double radius,
+                                        double latent_temperature, const double* scale_dev, const double* shift_dev,
+                                        const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                                        double* log_q_dev, const int* prior_kind_dev, const double* prior_par_dev,
+                                        double* log_prior_dev, double log_prior_const, const int* rp_kind_dev,
+                                        const double* rp_par_dev, double* log_w_dev, long long* max_keys_dev,
+                                        long long capacity, long long* idx_acc_dev, long long* state_dev,
+                                        void* workspace_dev, size_t workspace_bytes, int* status_dev,
+                                        int waves_per_group, int max_groups, void* stream,
+                                        const nsa_post_rules* rules) {
+  return nsa_passes_impl(header, image_dev, n, n_passes, seed, row_offset, radius, latent_temperature, scale_dev,
+                         shift_dev, lower_dev, upper_dev, log_j_rescale, nullptr, log_q_dev, prior_kind_dev,
+                         prior_par_dev, log_prior_dev, log_prior_const, rp_kind_dev, rp_par_dev, log_w_dev, max_keys_dev,
+                         capacity, nullptr, idx_acc_dev, state_dev, workspace_dev, workspace_bytes, status_dev,
+                         waves_per_group, max_groups, stream, rules, "nsa_populate_passes_lean");
+}
+
+// The accepted rows of lean passes, computed again from their global Philox rows (see include/nessai_amd.h).
+extern "C" int nsa_populate_replay(const uint32_t* header, const void* image_dev, long long m,
+                                   const long long* row_list_dev, unsigned long long seed, double radius,
+                                   double latent_temperature, const double* scale_dev, const double* shift_dev,
+                                   const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                                   double* x64_out_dev, double* log_q_out_dev, const int* prior_kind_dev,
+                                   const double* prior_par_dev, double* log_prior_out_dev, const int* rp_kind_dev,
+                                   const double* rp_par_dev, int* status_dev, int waves_per_group, int max_groups,
+                                   void* stream) {
+  if (m < 0 || row_list_dev == nullptr) return nsa_fail(NSA_E_ARG, "nsa_populate_replay: bad argument");
+  NsaLaunch p;
+  int rc = nsa_draw_params(p, header, image_dev, m, nullptr, seed, 0ull, radius, latent_temperature, scale_dev,
+                           shift_dev, lower_dev, upper_dev, log_j_rescale, x64_out_dev, log_q_out_dev, nullptr,
+                           prior_kind_dev, prior_par_dev, log_prior_out_dev, rp_kind_dev, rp_par_dev, status_dev);
+  if (rc != NSA_OK) return rc;
+  p.row_list = row_list_dev;
+  return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
 }
 
 // The pieces of one pass for SHARDED trains (the collectives of torch.distributed go in between:
@@ -761,7 +822,7 @@ extern "C" hipError_t nsa_launch_train_scratch(const long long*, long long*, hip
 extern "C" hipError_t nsa_launch_train_commit(long long*, long long, int, const long long*, const long long*,
                                               long long*, hipStream_t);
 
-extern "C" int nsa_populate_train_heads(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+static int nsa_train_heads_impl(bool lean, const uint32_t* header, const void* image_dev, long long n, int n_passes,
                                         unsigned long long seed, unsigned long long row_offset,
                                         unsigned long long row_stride, double radius, double latent_temperature,
                                         const double* scale_dev, const double* shift_dev, const double* lower_dev,
@@ -771,20 +832,22 @@ extern "C" int nsa_populate_train_heads(const uint32_t* header, const void* imag
                                         const double* rp_par_dev, double* log_w_many_dev, long long* max_keys_dev,
                                         const long long* state_dev, int* status_dev, int waves_per_group,
                                         int max_groups, void* stream, const nsa_post_rules* rules) {
-  if (n <= 0 || n_passes < 1 || x64_many_dev == nullptr || log_w_many_dev == nullptr || max_keys_dev == nullptr ||
-      state_dev == nullptr)
+  if (n <= 0 || n_passes < 1 || (x64_many_dev == nullptr) != lean || log_w_many_dev == nullptr ||
+      max_keys_dev == nullptr || state_dev == nullptr)
     return nsa_fail(NSA_E_ARG, "nsa_populate_train_heads: bad argument");
+  if (lean && rules != nullptr && rules->ll_kind >= 0)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_train_heads_lean: the likelihood rule needs the candidate rows");
   NsaLaunch p;
   int rc = nsa_draw_params(p, header, image_dev, n, nullptr, seed, row_offset, radius, latent_temperature, scale_dev,
                            shift_dev, lower_dev, upper_dev, log_j_rescale, x64_many_dev, log_q_dev, nullptr,
-                           prior_kind_dev, prior_par_dev, log_prior_dev, rp_kind_dev, rp_par_dev, status_dev);
+                           prior_kind_dev, prior_par_dev, log_prior_dev, rp_kind_dev, rp_par_dev, status_dev, lean);
   if (rc != NSA_OK) return rc;
   p.stop = state_dev;
   const long long D = (long long)header[NSA_H_D];
   const double* per_row_prior = (prior_kind_dev != nullptr) ? log_prior_dev : nullptr;
   for (int i = 0; i < n_passes; ++i) {
     p.row_offset = row_offset + (unsigned long long)i * row_stride;
-    p.x64_out = x64_many_dev + (long long)i * n * D;
+    p.x64_out = lean ? nullptr : x64_many_dev + (long long)i * n * D;
     rc = nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
     if (rc != NSA_OK) return rc;
     if (rules != nullptr) {
@@ -798,15 +861,49 @@ extern "C" int nsa_populate_train_heads(const uint32_t* header, const void* imag
   return NSA_OK;
 }
 
-extern "C" int nsa_populate_train_tails(long long n, int D, int n_passes, const double* log_w_many_dev,
+extern "C" int nsa_populate_train_heads(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                                        unsigned long long seed, unsigned long long row_offset,
+                                        unsigned long long row_stride, double radius, double latent_temperature,
+                                        const double* scale_dev, const double* shift_dev, const double* lower_dev,
+                                        const double* upper_dev, double log_j_rescale, double* x64_many_dev,
+                                        double* log_q_dev, const int* prior_kind_dev, const double* prior_par_dev,
+                                        double* log_prior_dev, double log_prior_const, const int* rp_kind_dev,
+                                        const double* rp_par_dev, double* log_w_many_dev, long long* max_keys_dev,
+                                        const long long* state_dev, int* status_dev, int waves_per_group,
+                                        int max_groups, void* stream, const nsa_post_rules* rules) {
+  return nsa_train_heads_impl(false, header, image_dev, n, n_passes, seed, row_offset, row_stride, radius,
+                              latent_temperature, scale_dev, shift_dev, lower_dev, upper_dev, log_j_rescale, x64_many_dev,
+                              log_q_dev, prior_kind_dev, prior_par_dev, log_prior_dev, log_prior_const, rp_kind_dev,
+                              rp_par_dev, log_w_many_dev, max_keys_dev, state_dev, status_dev, waves_per_group, max_groups,
+                              stream, rules);
+}
+
+extern "C" int nsa_populate_train_heads_lean(const uint32_t* header, const void* image_dev, long long n, int n_passes,
+                                             unsigned long long seed, unsigned long long row_offset,
+                                             unsigned long long row_stride, double radius, double latent_temperature,
+                                             const double* scale_dev, const double* shift_dev, const double* lower_dev,
+                                             const double* upper_dev, double log_j_rescale, double* log_q_dev,
+                                             const int* prior_kind_dev, const double* prior_par_dev,
+                                             double* log_prior_dev, double log_prior_const, const int* rp_kind_dev,
+                                             const double* rp_par_dev, double* log_w_many_dev, long long* max_keys_dev,
+                                             const long long* state_dev, int* status_dev, int waves_per_group,
+                                             int max_groups, void* stream, const nsa_post_rules* rules) {
+  return nsa_train_heads_impl(true, header, image_dev, n, n_passes, seed, row_offset, row_stride, radius,
+                              latent_temperature, scale_dev, shift_dev, lower_dev, upper_dev, log_j_rescale, nullptr,
+                              log_q_dev, prior_kind_dev, prior_par_dev, log_prior_dev, log_prior_const, rp_kind_dev,
+                              rp_par_dev, log_w_many_dev, max_keys_dev, state_dev, status_dev, waves_per_group, max_groups,
+                              stream, rules);
+}
+
+static int nsa_train_tails_impl(long long n, int D, int n_passes, const double* log_w_many_dev,
                                         const long long* max_keys_dev, unsigned long long seed,
                                         unsigned long long row_offset, unsigned long long row_stride,
-                                        const double* x64_many_dev, long long capacity, double* x_acc_dev,
+                                        const double* x64_many_dev, long long capacity, double* x_acc_dev, long long* idx_acc_dev,
                                         const long long* state_dev, long long* scratch_dev,
                                         long long* local_counts_dev, void* workspace_dev, size_t workspace_bytes,
                                         void* stream) {
   if (n <= 0 || D < 1 || n_passes < 1 || log_w_many_dev == nullptr || max_keys_dev == nullptr ||
-      x64_many_dev == nullptr || x_acc_dev == nullptr || state_dev == nullptr || scratch_dev == nullptr ||
+      (x64_many_dev == nullptr ? idx_acc_dev == nullptr : x_acc_dev == nullptr) || state_dev == nullptr || scratch_dev == nullptr ||
       local_counts_dev == nullptr || workspace_dev == nullptr || capacity < 0 ||
       workspace_bytes < nsa_accept_workspace_bytes(n))
     return nsa_fail(NSA_E_ARG, "nsa_populate_train_tails: bad argument");
@@ -815,13 +912,38 @@ extern "C" int nsa_populate_train_tails(long long n, int D, int n_passes, const 
   for (int i = 0; i < n_passes && e == hipSuccess; ++i) {
     e = nsa_launch_accept(n, D, log_w_many_dev + (long long)i * n, max_keys_dev + i, seed,
                           row_offset + (unsigned long long)i * row_stride, nullptr,
-                          x64_many_dev + (long long)i * n * D, capacity, x_acc_dev, nullptr, scratch_dev + 4,
-                          workspace_dev, s, scratch_dev);
+                          x64_many_dev != nullptr ? x64_many_dev + (long long)i * n * D : nullptr, capacity, x_acc_dev,
+                          idx_acc_dev, scratch_dev + 4, workspace_dev, s, scratch_dev,
+                          (long long)(row_offset + (unsigned long long)i * row_stride));
     // (scratch[1] counts the passes of this train: history index = pass within the train)
     if (e == hipSuccess) e = nsa_launch_pass_commit(scratch_dev, capacity, nullptr, local_counts_dev, s);
   }
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "train tails: %s", hipGetErrorString(e));
   return NSA_OK;
+}
+
+extern "C" int nsa_populate_train_tails(long long n, int D, int n_passes, const double* log_w_many_dev,
+                                        const long long* max_keys_dev, unsigned long long seed,
+                                        unsigned long long row_offset, unsigned long long row_stride,
+                                        const double* x64_many_dev, long long capacity, double* x_acc_dev,
+                                        const long long* state_dev, long long* scratch_dev,
+                                        long long* local_counts_dev, void* workspace_dev, size_t workspace_bytes,
+                                        void* stream) {
+  if (x64_many_dev == nullptr) return nsa_fail(NSA_E_ARG, "nsa_populate_train_tails: bad argument");
+  return nsa_train_tails_impl(n, D, n_passes, log_w_many_dev, max_keys_dev, seed, row_offset, row_stride, x64_many_dev,
+                              capacity, x_acc_dev, nullptr, state_dev, scratch_dev, local_counts_dev, workspace_dev,
+                              workspace_bytes, stream);
+}
+
+extern "C" int nsa_populate_train_tails_lean(long long n, int D, int n_passes, const double* log_w_many_dev,
+                                             const long long* max_keys_dev, unsigned long long seed,
+                                             unsigned long long row_offset, unsigned long long row_stride,
+                                             long long capacity, long long* idx_acc_dev, const long long* state_dev,
+                                             long long* scratch_dev, long long* local_counts_dev, void* workspace_dev,
+                                             size_t workspace_bytes, void* stream) {
+  return nsa_train_tails_impl(n, D, n_passes, log_w_many_dev, max_keys_dev, seed, row_offset, row_stride, nullptr,
+                              capacity, nullptr, idx_acc_dev, state_dev, scratch_dev, local_counts_dev, workspace_dev,
+                              workspace_bytes, stream);
 }
 
 extern "C" int nsa_populate_train_commit(long long* state_dev, long long capacity, int n_passes,

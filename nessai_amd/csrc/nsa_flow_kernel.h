@@ -152,6 +152,12 @@ struct NsaLaunch {
   // weights-resident geometry (NsaResidentPipe; host-side selector of the RES instances): the whole program
   // of the direction in LDS, `occupancy` 2 / 3 / 4 waves per SIMD in ONE workgroup per CU
   int resident;
+  // POPULATE without materialised candidates (nsa_populate_passes_lean / nsa_populate_replay): with
+  // x64_out == null the pass writes log_q (8 bytes per row) and nothing else - bounds, prior and log q are
+  // still evaluated row by row in registers.  Only accepted rows are ever used (flowproposal.py:431-498), and
+  // a row is a pure function of its Philox counter, so the accepted ones are computed AGAIN from their global
+  // row indices: row_list[r] replaces row_offset + r as the counter of local row r (replay launch).
+  const long long* row_list;
 #ifdef NSA_TIMELINE
   unsigned long long* dbg;
 #endif
@@ -1119,7 +1125,8 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
       // the quads (row-indexed counter => independent of launch geometry)
       // (pairs of quads, one per lane of the row: while both lie wholly below D - a wave-uniform test - the
       // four normals are stored without a per-lane predicate; only the pair that straddles D pays for one)
-      const unsigned long long grow = a.row_offset + (unsigned long long)my_row;
+      unsigned long long grow = a.row_offset + (unsigned long long)my_row;
+      if (a.row_list != nullptr) grow = (unsigned long long)a.row_list[my_row < a.n ? my_row : a.n - 1];
       const int n_quads = (D + 3) >> 2;
       xrow[D + 1] = 0.0f;
       for (int q0 = 0; q0 < n_quads; q0 += 2) {
@@ -1341,7 +1348,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
         };
         const int nk = D >> 1;
         const bool tail = (D & 1) && half_e == 0;
-        if (row_ok && !(NSA_ABLATE & 32)) {
+        if (row_ok && e.x64_out != nullptr && !(NSA_ABLATE & 32)) {
 #pragma unroll 8
           for (int k = 0; k < nk; ++k) feature(tab_h + 2 * k, epi_h + 2 * k, xo_h + 2 * k, true);
           if (tail) feature(tab_h + D - 1, epi_h + D - 1, xo_h + D - 1, true);
@@ -1386,7 +1393,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
           xv = xv + c[4];
         }
         in_bounds = in_bounds && !((xv < e.lower[i]) || (xv > e.upper[i]));
-        if (row_ok && !(NSA_ABLATE & 32)) e.x64_out[my_row * D + i] = xv;
+        if (row_ok && e.x64_out != nullptr && !(NSA_ABLATE & 32)) e.x64_out[my_row * D + i] = xv;
         if (e.prior_kind != nullptr) log_prior += nsa_log_prior_term(e.prior_kind[i], xv, e.prior_par + 3 * i);
       }
       if (e.prior_kind != nullptr) {

@@ -137,7 +137,9 @@ __global__ void __launch_bounds__(1024) nsa_accept_scan_kernel(int n_blocks, con
 __global__ void __launch_bounds__(NSA_ACC_THREADS) nsa_accept_scatter_kernel(
     long long n, int D, const unsigned char* __restrict__ flags, const long long* __restrict__ offsets,
     const double* __restrict__ x64, long long capacity, double* __restrict__ x_acc,
-    long long* __restrict__ idx_acc, const long long* __restrict__ stop) {
+    long long* __restrict__ idx_acc, long long idx_base, const long long* __restrict__ stop) {
+  // (x64 == null: the lean passes - nsa_populate_passes_lean - keep no candidate rows; an accepted row is its
+  // global Philox row idx_base + i, which nsa_populate_replay turns back into x)
   if (NSA_STOPPED(stop)) return;
   const long long written = (stop != nullptr) ? stop[3] : 0;  // rows of earlier passes of the train
   const long long base = (long long)blockIdx.x * NSA_ACC_ROWS;
@@ -165,8 +167,9 @@ __global__ void __launch_bounds__(NSA_ACC_THREADS) nsa_accept_scatter_kernel(
       const long long dst = running + before + my_rank[it];
       if (dst < capacity) {
         const long long i = base + it * NSA_ACC_THREADS + threadIdx.x;
-        for (int c = 0; c < D; ++c) x_acc[dst * D + c] = x64[i * D + c];
-        if (idx_acc != nullptr) idx_acc[dst] = i;
+        if (x64 != nullptr)
+          for (int c = 0; c < D; ++c) x_acc[dst * D + c] = x64[i * D + c];
+        if (idx_acc != nullptr) idx_acc[dst] = idx_base + i;
       }
     }
     running += tot;
@@ -648,7 +651,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_accept(
     long long n, int D, const double* log_w, const long long* max_key, unsigned long long seed,
     unsigned long long row_offset, const double* u_in, const double* x64, long long capacity,
     double* x_acc, long long* idx_acc, long long* n_accept, void* workspace, hipStream_t stream,
-    const long long* stop) {
+    const long long* stop, long long idx_base) {
   if (n <= 0) return hipMemsetAsync(n_accept, 0, 8, stream);
   const long long nb = (n + NSA_ACC_ROWS - 1) / NSA_ACC_ROWS;
   unsigned char* flags = (unsigned char*)workspace;
@@ -661,7 +664,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t nsa_launch_accept(
   hipLaunchKernelGGL(nsa_accept_scan_kernel, dim3(1), dim3(1024), 0, stream, (int)nb, counts, offsets,
                      n_accept, stop);
   hipLaunchKernelGGL(nsa_accept_scatter_kernel, dim3((unsigned)nb), dim3(NSA_ACC_THREADS), 0, stream, n,
-                     D, flags, offsets, x64, capacity, x_acc, idx_acc, stop);
+                     D, flags, offsets, x64, capacity, x_acc, idx_acc, idx_base, stop);
   return hipGetLastError();
 }
 

@@ -81,6 +81,13 @@ class FlowProposal:
         Passes of at most 16384 rows (the reference's default ``drawsize = nlive``): run a whole train
         of them as one draw launch plus two tail launches (``nsa_populate_passes_small``) instead of
         three launches per pass.  Results are identical to ``False``.
+    lean : bool
+        Big passes of the device-side loops keep NO candidate rows (``nsa_populate_passes_lean``): a pass
+        writes ``log_q`` alone (8 bytes per row instead of ``8 (D + 1)``), the accept step lists the accepted
+        rows by their global Philox rows and ``nsa_populate_replay`` computes just those again at the end of
+        ``populate`` - only accepted rows are ever used (``flowproposal.py:431-498``).  Results are identical
+        to ``False`` bit for bit.  Not used with a likelihood-threshold rule, ``accumulate_weights``,
+        injected latents or a host prior, which need every candidate.
     precision : {'auto', 'f32', 'bf16x3', 'f16x3'}
         Arithmetic of the conditioner GEMMs inside the fused draw kernel.
         ``'auto'`` uses the fastest 16-bit matrix-core mode (split-bf16, then split-f16) that is
@@ -128,6 +135,7 @@ class FlowProposal:
         precision="auto",
         pass_trains=True,
         small_trains=True,
+        lean=True,
         reparameterisations=None,
         fallback_reparameterisation="z-score",
         plot=False,
@@ -176,6 +184,9 @@ class FlowProposal:
         #: sharded runs: every rank repeats the fit (True) or rank 0 fits and the others receive the flow (False)
         self.replicate_training = bool(replicate_training)
         self.small_trains = bool(small_trains)
+        self.lean = bool(lean)
+        #: True when the last ``populate`` ran lean passes + one replay launch
+        self.last_populate_lean = False
         self._status_hold = False
         self.timing = None  # NESSAI_AMD_TIMING=1: seconds per phase of the last populate() (FlowProposal._mark)
         self._t_last = 0.0
@@ -693,6 +704,33 @@ class FlowProposal:
             rules.log_l_threshold = float(log_l_threshold)
         return rules
 
+    def _lean_ok(self, n, rules):
+        """Lean passes (``lean=True``) apply to big passes of the device-side loops whose rules after the flow do
+        not need the candidate rows (``min_log_q`` alone is a predicate on ``log_q``)."""
+        if not self.lean or os.environ.get("NESSAI_AMD_LEAN") == "0":
+            return False
+        if n <= 16384:  # small passes: the fused small-train kernels keep their staging blocks
+            return False
+        return rules is None or rules.ll_kind < 0
+
+    def _replay(self, idx, m, radius, x64, log_q, log_prior, prepared):
+        """``x64[:m]`` = the rows whose global Philox rows are ``idx[:m]`` (``nsa_populate_replay``): the accepted
+        rows of lean passes, computed again by the kernel instance that accepted them."""
+        if m <= 0:
+            return
+        flow, header, image, status = prepared
+        stream = lib.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = lib.load().nsa_populate_replay(
+            header, lib.ptr(image), int(m), lib.ptr(idx), self.device_seed, float(radius),
+            float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
+            lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale), lib.ptr(x64),
+            lib.ptr(log_q), lib.ptr(self._prior_kind_dev if log_prior is not None else None),
+            lib.ptr(self._prior_par_dev if log_prior is not None else None), lib.ptr(log_prior),
+            lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), lib.ptr(status), flow.waves_per_group,
+            flow.max_groups, stream,
+        )
+        lib.check(rc, "nsa_populate_replay")
+
     def _f16_range_left(self, flag_host=None):
         """True when the draw kernel ran in split-f16 and reported a value beyond the f16 range
         (``status[1]``; agreed over the ranks of a sharded proposal).  One 16-byte read-back, or none when
@@ -765,6 +803,7 @@ class FlowProposal:
         latent = self._latent_rule()
         self.r = latent.radius if latent is not None else np.nan
         self._post_limits = (min_log_q, log_l_threshold)
+        self.last_populate_lean = False
         self.indices = []
         n_samples = int(n_samples)
 
@@ -875,11 +914,31 @@ class FlowProposal:
         n_accepted = passes = 0
         rules = self._device_rules()
         small = n <= 16384 and self.small_trains
+        # lean passes: no candidate rows, accepted rows listed by their Philox rows and computed again at the end
+        lean = self._lean_ok(n, rules)
+        self.last_populate_lean = lean
+        if lean and buf.get("idx_acc") is None:
+            buf["idx_acc"] = torch.empty(n_samples, dtype=torch.int64, device=dev)
         while True:
             remaining = n_samples - n_accepted
             train = 1 if per_pass <= 0 else int(np.ceil(1.15 * remaining / per_pass))
             train = max(1, min(train, max_train, int(state_h[5]) - passes))
-            if small:
+            if lean:
+                buf["max_keys"][:train].fill_(key_init)
+                rc = L.nsa_populate_passes_lean(
+                    header, lib.ptr(image), n, train, self.device_seed, int(self._draw_counter + passes * n),
+                    float(threshold), float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev),
+                    lib.ptr(self._shift_dev), lib.ptr(self._lower_dev), lib.ptr(self._upper_dev),
+                    float(self._log_j_rescale), lib.ptr(buf["log_q"]),
+                    lib.ptr(self._prior_kind_dev), lib.ptr(self._prior_par_dev),
+                    lib.ptr(buf["log_p"] if separable else None), float(log_prior_const),
+                    lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), lib.ptr(buf["log_w"]),
+                    lib.ptr(buf["max_keys"]), n_samples, lib.ptr(buf["idx_acc"]), lib.ptr(buf["state"]),
+                    lib.ptr(buf["workspace"]), buf["ws_bytes"], lib.ptr(status), flow.waves_per_group,
+                    flow.max_groups, stream, rules,
+                )
+                lib.check(rc, "nsa_populate_passes_lean")
+            elif small:
                 # small passes (the reference's default drawsize = nlive): the whole train as ONE draw launch over
                 # train * n rows + two tail launches - a pass of 2000 rows is a ~40 us dependent chain through the
                 # flow however few rows it has, and sixty of them in a row were the whole populate call
@@ -932,6 +991,10 @@ class FlowProposal:
         # accepted rows, their log-likelihood and the kernel's range flag come to the host through pinned
         # buffers behind ONE synchronisation (three pageable .cpu() copies, each its own round trip, before)
         m = min(n_accepted, n_samples)
+        if lean:
+            self._replay(buf["idx_acc"], m, threshold, buf["x_acc"], buf["log_q"], buf["log_p"] if separable else None,
+                         (flow, header, image, status))
+            self._mark("replay")
         kept = buf["x_acc"][:m]
         if buf.get("x_host") is None or buf["x_host"].shape[0] < n_samples:
             buf["x_host"] = torch.empty((n_samples, self.dims), dtype=torch.float64).pin_memory()
@@ -973,7 +1036,13 @@ class FlowProposal:
         flow, header, image, status = self._prepare_flow()
         buf = self._get_buffers(n, n_samples)
         dev = self.device
-        max_train = int(max(1, min(64, self.TRAIN_ARENA_BYTES // (8 * n * (self.dims + 1)))))
+        rules = self._device_rules()
+        # lean heads keep log_w alone: the arena of a train is 8 bytes per row instead of 8 (D + 1)
+        lean = self._lean_ok(n, rules)
+        self.last_populate_lean = lean
+        if lean and buf.get("idx_acc") is None:
+            buf["idx_acc"] = torch.empty(n_samples, dtype=torch.int64, device=dev)
+        max_train = int(max(1, min(64, self.TRAIN_ARENA_BYTES // (8 * n * (1 if lean else self.dims + 1)))))
         if buf.get("state") is None:
             buf["state"] = torch.zeros(8, dtype=torch.int64, device=dev)
             buf["max_keys"] = torch.empty(64, dtype=torch.int64, device=dev)
@@ -995,13 +1064,15 @@ class FlowProposal:
         per_pass = (self.population_acceptance or 0.0) * n * world
         n_accepted = passes = 0
         stride = n * world
-        rules = self._device_rules()
         while True:
             remaining = n_samples - n_accepted
             train = 1 if per_pass <= 0 else int(remaining / per_pass)
             train = max(1, min(train, max_train, int(state_h[5]) - passes))
-            if buf.get("arena_passes", 0) < train:
-                buf["x64_many"] = torch.empty((train, n, self.dims), dtype=torch.float64, device=dev)
+            if buf.get("arena_passes", 0) < train or (not lean and buf.get("x64_many") is None):
+                if not lean:
+                    buf["x64_many"] = torch.empty((train, n, self.dims), dtype=torch.float64, device=dev)
+                else:
+                    buf["x64_many"] = None
                 buf["log_w_many"] = torch.empty((train, n), dtype=torch.float64, device=dev)
                 buf["arena_passes"] = train
             if buf["history"].numel() < passes + train:
@@ -1011,24 +1082,43 @@ class FlowProposal:
             keys, lcount, gcount = buf["max_keys"][:train], buf["lcount"][:train], buf["gcount"][:train]
             keys.fill_(key_init)
             off = int(self._draw_counter + rank * n + passes * stride)
-            rc = L.nsa_populate_train_heads(
-                header, lib.ptr(image), n, train, self.device_seed, off, stride, float(threshold),
-                float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
-                lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
-                lib.ptr(buf["x64_many"]), lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev),
-                lib.ptr(self._prior_par_dev), lib.ptr(buf["log_p"] if separable else None),
-                float(log_prior_const), lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev),
-                lib.ptr(buf["log_w_many"]), lib.ptr(keys), lib.ptr(state), lib.ptr(status), flow.waves_per_group,
-                flow.max_groups, stream, rules,
-            )
-            lib.check(rc, "nsa_populate_train_heads")
-            dist.all_reduce(keys, op=dist.ReduceOp.MAX)
-            rc = L.nsa_populate_train_tails(
-                n, self.dims, train, lib.ptr(buf["log_w_many"]), lib.ptr(keys), self.device_seed, off, stride,
-                lib.ptr(buf["x64_many"]), n_samples, lib.ptr(buf["x_acc"]), lib.ptr(state), lib.ptr(buf["scratch"]),
-                lib.ptr(lcount), lib.ptr(buf["workspace"]), buf["ws_bytes"], stream,
-            )
-            lib.check(rc, "nsa_populate_train_tails")
+            if lean:
+                rc = L.nsa_populate_train_heads_lean(
+                    header, lib.ptr(image), n, train, self.device_seed, off, stride, float(threshold),
+                    float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
+                    lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
+                    lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev), lib.ptr(self._prior_par_dev),
+                    lib.ptr(buf["log_p"] if separable else None), float(log_prior_const), lib.ptr(self._rp_kind_dev),
+                    lib.ptr(self._rp_par_dev), lib.ptr(buf["log_w_many"]), lib.ptr(keys), lib.ptr(state),
+                    lib.ptr(status), flow.waves_per_group, flow.max_groups, stream, rules,
+                )
+                lib.check(rc, "nsa_populate_train_heads_lean")
+                dist.all_reduce(keys, op=dist.ReduceOp.MAX)
+                rc = L.nsa_populate_train_tails_lean(
+                    n, self.dims, train, lib.ptr(buf["log_w_many"]), lib.ptr(keys), self.device_seed, off, stride,
+                    n_samples, lib.ptr(buf["idx_acc"]), lib.ptr(state), lib.ptr(buf["scratch"]), lib.ptr(lcount),
+                    lib.ptr(buf["workspace"]), buf["ws_bytes"], stream,
+                )
+                lib.check(rc, "nsa_populate_train_tails_lean")
+            else:
+                rc = L.nsa_populate_train_heads(
+                    header, lib.ptr(image), n, train, self.device_seed, off, stride, float(threshold),
+                    float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
+                    lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
+                    lib.ptr(buf["x64_many"]), lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev),
+                    lib.ptr(self._prior_par_dev), lib.ptr(buf["log_p"] if separable else None),
+                    float(log_prior_const), lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev),
+                    lib.ptr(buf["log_w_many"]), lib.ptr(keys), lib.ptr(state), lib.ptr(status), flow.waves_per_group,
+                    flow.max_groups, stream, rules,
+                )
+                lib.check(rc, "nsa_populate_train_heads")
+                dist.all_reduce(keys, op=dist.ReduceOp.MAX)
+                rc = L.nsa_populate_train_tails(
+                    n, self.dims, train, lib.ptr(buf["log_w_many"]), lib.ptr(keys), self.device_seed, off, stride,
+                    lib.ptr(buf["x64_many"]), n_samples, lib.ptr(buf["x_acc"]), lib.ptr(state), lib.ptr(buf["scratch"]),
+                    lib.ptr(lcount), lib.ptr(buf["workspace"]), buf["ws_bytes"], stream,
+                )
+                lib.check(rc, "nsa_populate_train_tails")
             gcount.copy_(lcount)
             dist.all_reduce(gcount, op=dist.ReduceOp.SUM)
             rc = L.nsa_populate_train_commit(lib.ptr(state), n_samples, train, lib.ptr(lcount), lib.ptr(gcount),
@@ -1044,6 +1134,9 @@ class FlowProposal:
             per_pass = n_accepted / passes if n_accepted else per_pass * 0.5
         n_proposed = passes * n * world
         self._draw_counter += n_proposed
+        if lean:  # this rank's accepted rows, computed again from their Philox rows
+            self._replay(buf["idx_acc"], int(state_h[3]), threshold, buf["x_acc"], buf["log_q"],
+                         buf["log_p"] if separable else None, (flow, header, image, status))
         accepted = self._assemble_sharded_pool(buf["history"][:passes], buf["x_acc"], n_samples, world)
         self.x = array_to_live_points_fast(np.ascontiguousarray(accepted), self.names)
         log_l = None
