@@ -330,8 +330,9 @@ NSA_API int nsa_populate_train_commit(long long* state_dev, long long capacity, 
  * Only accepted rows are ever used (`samples[...] = x[accept][:m]`, flowproposal.py:492-498) - at config 3's
  * acceptance that is ~86 of the 1e6 rows of a pass - and a candidate row is a pure function of its Philox
  * counter (the global row) and the flow.  So a lean pass keeps every row's float64 arithmetic (inverse
- * reparameterisation, prior bounds, separable prior, log q) in registers and writes log_q alone: 8 bytes per
- * row instead of 8 (D + 1); the accept step lists the accepted rows by their GLOBAL Philox rows in idx_acc_dev
+ * reparameterisation, prior bounds, separable prior, log q, the min_log_q rule) in registers and writes the
+ * weight log_w = log_prior - log_q alone - 8 bytes per row instead of 8 (D + 1), the pass's maximum through one
+ * atomic per wave (log_q_dev is not written); the accept step lists the accepted rows by their GLOBAL Philox rows in idx_acc_dev
  * (int64, draw order across the passes, same loop state as nsa_populate_passes), and nsa_populate_replay
  * computes exactly those rows again - the same kernel instance reading row_list_dev[r] in place of
  * row_offset + r - into x64_out_dev [m][D] (and log_q_out_dev [m]), bit for bit the rows the full pass would
@@ -342,6 +343,21 @@ NSA_API int nsa_populate_train_commit(long long* state_dev, long long capacity, 
  *   nsa_populate_train_tails_lean  = nsa_populate_train_tails minus x64_many_dev, with idx_acc_dev for x_acc_dev
  *   nsa_populate_replay            m rows of row_list_dev through the populate pass (arguments as
  *                                  nsa_populate_draw; the latent radius test is repeated and holds) */
+/* The head of ONE lean pass on its own (what nsa_populate_passes_lean enqueues per pass before the accept
+ * step): draw -> radius -> inverse flow -> inverse reparameterisation -> bounds -> log q, then
+ * log_w = log_prior - log_q with -inf for dropped rows (FlowProposal.compute_weights,
+ * proposal/flowproposal/base.py:1069-1098) after the min_log_q rule (truncation.py:385-392; -inf = off), and
+ * *max_key_dev raised to the largest weight of the launch (initialise it with nsa_max_key_init();
+ * flowproposal.py:492 `log_w -= log_w.max()`).  8 bytes per row leave the chip.  log_prior is the separable
+ * device prior when prior_kind_dev is given (log_prior_out_dev [n] also receives it), else log_prior_const. */
+NSA_API int nsa_populate_draw_weights(const uint32_t* header, const void* image_dev, long long n,
+                              unsigned long long seed, unsigned long long row_offset, double radius,
+                              double latent_temperature, const double* scale_dev, const double* shift_dev,
+                              const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                              const int* prior_kind_dev, const double* prior_par_dev, double* log_prior_out_dev,
+                              double log_prior_const, double min_log_q, const int* rp_kind_dev,
+                              const double* rp_par_dev, double* log_w_out_dev, long long* max_key_dev,
+                              int* status_dev, int waves_per_group, int max_groups, void* stream);
 NSA_API int nsa_populate_passes_lean(const uint32_t* header, const void* image_dev, long long n, int n_passes,
                              unsigned long long seed, unsigned long long row_offset, double radius,
                              double latent_temperature, const double* scale_dev, const double* shift_dev,

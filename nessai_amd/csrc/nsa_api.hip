@@ -296,7 +296,8 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     }
     const size_t fixed = res_bytes + epi_bytes + prog_bytes;
     // (x tiles + one parked float per lane and tile, nsa_flow_kernel.h)
-    auto res_lds = [&](int w, int r) { return ((((size_t)w * r * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + (size_t)w * r * 256 + fixed; };
+    // (+ one double per wave: the lean pass's running weight maximum)
+    auto res_lds = [&](int w, int r) { return ((((size_t)w * r * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + (size_t)w * r * 256 + (size_t)w * 8 + fixed; };
     // candidates in the order of their measured time per row on big batches (profiles/r04_resident_geometries.jsonl)
     static const int cand[4][2] = {{4, 1}, {3, 1}, {2, 2}, {2, 1}};
     for (int c = 0; c < 4 && on; ++c) {
@@ -354,7 +355,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   }
   const size_t stage_bytes = 2 * (size_t)h[NSA_H_MAX_STAGE] * 4;
   auto lds_of = [&](int w) {
-    return ((((size_t)w * rt * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + (size_t)w * rt * 256 + stage_bytes + epi_bytes + prog_bytes;
+    return ((((size_t)w * rt * NSA_ROWS * XS + 3) & ~(size_t)3)) * 4 + (size_t)w * rt * 256 + (size_t)w * 8 + stage_bytes + epi_bytes + prog_bytes;
   };
   auto per_cu_of = [&](int w) {
     long long c = (long long)(g_max_lds / lds_of(w));
@@ -528,6 +529,30 @@ extern "C" int nsa_populate_draw(const uint32_t* header, const void* image_dev, 
   return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
 }
 
+// The head of one lean pass on its own: draw -> ... -> log_w = log_prior - log_q and the launch's largest weight.
+extern "C" int nsa_populate_draw_weights(const uint32_t* header, const void* image_dev, long long n,
+                                         unsigned long long seed, unsigned long long row_offset, double radius,
+                                         double latent_temperature, const double* scale_dev, const double* shift_dev,
+                                         const double* lower_dev, const double* upper_dev, double log_j_rescale,
+                                         const int* prior_kind_dev, const double* prior_par_dev,
+                                         double* log_prior_out_dev, double log_prior_const, double min_log_q,
+                                         const int* rp_kind_dev, const double* rp_par_dev, double* log_w_out_dev,
+                                         long long* max_key_dev, int* status_dev, int waves_per_group,
+                                         int max_groups, void* stream) {
+  if (log_w_out_dev == nullptr || max_key_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_populate_draw_weights: NULL output pointer");
+  NsaLaunch p;
+  int rc = nsa_draw_params(p, header, image_dev, n, nullptr, seed, row_offset, radius, latent_temperature, scale_dev,
+                           shift_dev, lower_dev, upper_dev, log_j_rescale, nullptr, log_w_out_dev, nullptr,
+                           prior_kind_dev, prior_par_dev, log_prior_out_dev, rp_kind_dev, rp_par_dev, status_dev, true);
+  if (rc != NSA_OK) return rc;
+  p.log_w_out = log_w_out_dev;
+  p.max_key_out = max_key_dev;
+  p.log_prior_const = log_prior_const;
+  p.min_log_q = min_log_q;
+  return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
+}
+
 extern "C" int nsa_importance_draw(const uint32_t* header, const void* image_dev, long long n,
                                    const float* z_in_dev, unsigned long long seed, unsigned long long row_offset,
                                    double unit_eps, double* x64_out_dev, float* xp_out_dev, double* log_j_out_dev,
@@ -688,9 +713,15 @@ static int nsa_passes_impl(const uint32_t* header, const void* image_dev, long l
   for (int i = 0; i < n_passes; ++i) {
     const unsigned long long off = row_offset + (unsigned long long)i * (unsigned long long)n;
     p.row_offset = off;
+    if (lean) {  // weights and their maximum come out of the draw kernel itself (NsaLaunch::log_w_out)
+      p.log_w_out = log_w_dev;
+      p.max_key_out = max_keys_dev + i;
+      p.log_prior_const = log_prior_const;
+      p.min_log_q = rules != nullptr ? rules->min_log_q : -INFINITY;
+    }
     rc = nsa_launch_flow(header, p, waves_per_group, max_groups, s);
     if (rc != NSA_OK) return rc;
-    if (rules != nullptr) {
+    if (rules != nullptr && !lean) {
       hipError_t er = nsa_launch_post_rules(n, D, log_q_dev, rules, x64_dev, state_dev, s);
       if (er != hipSuccess) return nsa_fail(NSA_E_HIP, "populate pass %d (rules after the flow): %s", i, hipGetErrorString(er));
     }
@@ -700,8 +731,9 @@ static int nsa_passes_impl(const uint32_t* header, const void* image_dev, long l
       if (es != hipSuccess) return nsa_fail(NSA_E_HIP, "populate pass %d: %s", i, hipGetErrorString(es));
       continue;
     }
-    hipError_t e = nsa_launch_weights(n, log_q_dev, per_row_prior, log_prior_const, log_w_dev, max_keys_dev + i, s,
-                                      state_dev);
+    hipError_t e = hipSuccess;
+    if (!lean)
+      e = nsa_launch_weights(n, log_q_dev, per_row_prior, log_prior_const, log_w_dev, max_keys_dev + i, s, state_dev);
     if (e == hipSuccess)
       e = nsa_launch_accept(n, D, log_w_dev, max_keys_dev + i, seed, off, nullptr, x64_dev, capacity, x_acc_dev,
                             idx_acc_dev, state_dev + 4, workspace_dev, s, state_dev, (long long)off);
@@ -848,6 +880,15 @@ static int nsa_train_heads_impl(bool lean, const uint32_t* header, const void* i
   for (int i = 0; i < n_passes; ++i) {
     p.row_offset = row_offset + (unsigned long long)i * row_stride;
     p.x64_out = lean ? nullptr : x64_many_dev + (long long)i * n * D;
+    if (lean) {  // weights and their maximum come out of the draw kernel itself
+      p.log_w_out = log_w_many_dev + (long long)i * n;
+      p.max_key_out = max_keys_dev + i;
+      p.log_prior_const = log_prior_const;
+      p.min_log_q = rules != nullptr ? rules->min_log_q : -INFINITY;
+      rc = nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
+      if (rc != NSA_OK) return rc;
+      continue;
+    }
     rc = nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
     if (rc != NSA_OK) return rc;
     if (rules != nullptr) {

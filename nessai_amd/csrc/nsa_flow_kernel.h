@@ -158,6 +158,16 @@ struct NsaLaunch {
   // a row is a pure function of its Philox counter, so the accepted ones are computed AGAIN from their global
   // row indices: row_list[r] replaces row_offset + r as the counter of local row r (replay launch).
   const long long* row_list;
+  // The lean pass with the weights folded in (log_w_out != null): instead of log_q the pass writes
+  //   log_w = log_prior - log_q        (FlowProposal.compute_weights, proposal/flowproposal/base.py:1069-1098)
+  // -inf for dropped rows, after the min_log_q rule (truncation.py:385-392: keep log_q > min_log_q; -inf = off), and
+  // raises *max_key_out (sign-ordered int64 key of the double, nsa_populate.hip) to the launch's largest weight -
+  // one atomic per wave at most.  log_prior = the separable device prior of the row when prior_kind is set,
+  // else log_prior_const (a uniform prior).
+  double* log_w_out;
+  long long* max_key_out;
+  double log_prior_const;
+  double min_log_q;
 #ifdef NSA_TIMELINE
   unsigned long long* dbg;
 #endif
@@ -921,6 +931,12 @@ __device__ __forceinline__ void nsa_elementwise_op(PIPE& pipe, const uint32_t* o
   pipe.end();
 }
 
+// sign-ordered int64 key of a double (nsa_key_encode, nsa_populate.hip): integer order = value order
+__device__ __forceinline__ long long nsa_weight_key(double v) {
+  const long long b = __double_as_longlong(v);
+  return (b >= 0) ? b : (b ^ 0x7fffffffffffffffLL);
+}
+
 // the kernel ------------------------------------------------------------------
 
 
@@ -993,6 +1009,11 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   // one float per lane and tile behind the program: the latent log-density of the row (NaN = row outside
   // the latent radius), written by the tile's prologue and read by its epilogue
   float* const park = (float*)(prog + ((2 * pipe.n_stages + NSA_OP_WORDS * n_ops + 3) & ~3));
+  // (lean pass with folded weights: the running maximum of each wave's weights, one double per wave behind the
+  // parked floats - live in registers across the flow it would be two more VGPRs in instances that have none)
+  // (as sign-ordered int64 keys - nsa_key_encode, nsa_populate.hip - so that the rows raise it with one LDS atomic)
+  long long* const wmax = (long long*)(park + (size_t)(blockDim.x >> 6) * RT * 64);
+  if (p.log_w_out != nullptr && (threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = nsa_weight_key(-__builtin_huge_val());
   {
     const uint32_t* gtab = img + (inverse ? img[NSA_H_STAGES_INV] : img[NSA_H_STAGES_FWD]);
     const uint32_t* gops = img + (inverse ? img[NSA_H_OPS_INV] : img[NSA_H_OPS_FWD]);
@@ -1410,7 +1431,17 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
       const bool finite = (lq - lq) == 0.0;
       lq -= (e.log_j_rescale + log_j_row);
       if (!(keep && ok && finite && n_bad == 0)) lq = __longlong_as_double(0x7ff8000000000000LL);
-      if (row_ok && half == 0) e.log_q_out[my_row] = lq;
+      if (e.log_w_out != nullptr) {
+        // weights of the lean pass (nsa_weights_kernel's arithmetic): log_w = log_prior - log_q
+        if (!(lq > e.min_log_q)) lq = __longlong_as_double(0x7ff8000000000000LL);
+        const double lp = (e.prior_kind != nullptr) ? log_prior : e.log_prior_const;
+        double w = lp - lq;
+        if (lq != lq || w != w) w = -__builtin_huge_val();
+        if (row_ok && half == 0) e.log_w_out[my_row] = w;
+        if (row_ok && half == 0 && w > -__builtin_huge_val()) atomicMax(wmax + wave, nsa_weight_key(w));
+      } else if (row_ok && half == 0) {
+        e.log_q_out[my_row] = lq;
+      }
       if (row_ok && half == 0 && n_bad != 0) atomicAdd(e.status, 1);
     } else {
       float out_ld = logdet;
@@ -1453,6 +1484,15 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   }
   // drain the wrap-around prefetch before the workgroup exits
   if constexpr (!RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (arguments re-read from the kernarg segment: held in scalar registers across the tile loop they were spilled)
+  const NsaLaunch& fin = *nsa_args();
+  if (fin.log_w_out != nullptr && lane0 == 0) {
+    // the wave's largest weight -> the launch's; same-address atomics serialise, so only a wave that can still
+    // raise the maximum issues one
+    long long* const max_key_out = fin.max_key_out;
+    const long long key = wmax[wave];
+    if (key > __atomic_load_n(max_key_out, __ATOMIC_RELAXED)) atomicMax(max_key_out, key);
+  }
 #ifdef NSA_TIMELINE
   if (p.dbg != nullptr && lane0 == 0) {
     for (int i = 0; i < 14; ++i) atomicAdd(p.dbg + i, pipe.tl.acc[i]);

@@ -60,6 +60,12 @@ SIGNATURES = {
          c_void_p, c_ll, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_int, c_int, c_void_p,
          ctypes.POINTER(PostRules)],
     ),
+    "nsa_populate_draw_weights": (
+        c_int,
+        [c_void_p, c_void_p, c_ll, c_ull, c_ull, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_double, c_void_p, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_int, c_int, c_void_p],
+    ),
     "nsa_populate_passes_lean": (
         c_int,
         [c_void_p, c_void_p, c_ll, c_int, c_ull, c_ull, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -343,9 +343,19 @@ class FlowProposal:
         # images (host pack), the maps for rebuilding them on the device after every later fit, and a first
         # run of the precision probe's kernels.  A sampler then pays per training only the device-side
         # rebuild + probe (~1.5 ms for config 3; profiles/r04_ns_run_c3.json).
-        self.flow.model.__dict__["_repack_eager"] = True
-        with torch.no_grad():
-            self._prepare_flow()
+        # (the flag lives on the proposal: FlowModel.reset_model(weights=True, permutations=True) builds a NEW
+        # flow object, and _prepare_flow hands the flag - like the precision - to whatever flow is current)
+        self._repack_eager = True
+        try:
+            with torch.no_grad():
+                self._prepare_flow()
+        except RuntimeError as exc:
+            if torch.cuda.is_available():
+                raise
+            raise RuntimeError(
+                "FlowProposal.initialise() sets up the flow's kernel images on the GPU and found no ROCm device "
+                "(there is no CPU fallback; a proposal can be constructed and pickled without a device, not "
+                "initialised)") from exc
 
     # -- reparameterisation (nessai_amd.reparam) -----------------------------------
 
@@ -424,8 +434,14 @@ class FlowProposal:
         rank, world = self._rank_world()
         # every rank writes its own weights file (no race on a shared output directory)
         output = self.output if rank == 0 else os.path.join(self.output, f"rank_{rank}")
+        fit_error = None
         if rank == 0 or self.replicate_training:
-            self.flow.train(x_prime_array, output=output, plot=False)
+            try:
+                self.flow.train(x_prime_array, output=output, plot=False)
+            except Exception as exc:  # (re-raised below, on every rank of a sharded run)
+                if world == 1:
+                    raise
+                fit_error = exc
         else:
             # Training does not shard and N identical fits are N times the energy for
             # one flow: rank 0 fits, the others wait for its weights, buffers and generator states
@@ -436,6 +452,20 @@ class FlowProposal:
             self.flow.weights_file = os.path.join(output, "model.pt")
             self.flow.model.eval()
         if world > 1:
+            # A fit that failed on one rank (a HIP error, an I/O error in save_weights ...) must not leave the
+            # others waiting in the collectives of _replicate_flow until the process group times out: the ranks
+            # agree on success first, and every rank raises.  With replicate_training=False only rank 0 can
+            # fail here; its message travels with the flag.
+            import torch.distributed as dist
+
+            report = [None if fit_error is None else f"rank {rank}: {type(fit_error).__name__}: {fit_error}"]
+            gathered = [None] * world
+            dist.all_gather_object(gathered, report[0])
+            failed = [g for g in gathered if g is not None]
+            if failed:
+                if fit_error is not None:
+                    raise fit_error
+                raise RuntimeError("sharded FlowProposal.train: the fit failed on another rank (" + "; ".join(failed) + ")")
             self._replicate_flow()
         self.populated = False
         self.training_count += 1
@@ -548,6 +578,8 @@ class FlowProposal:
         flow = self.flow.model
         if flow.training:
             flow.eval()
+        if getattr(self, "_repack_eager", False) and not flow.__dict__.get("_repack_eager"):
+            flow.__dict__["_repack_eager"] = True  # (a flow rebuilt by reset_model: see initialise)
         # "auto": the flow resolves it per set of weights - split-bf16 inside the static envelope AND
         # measured to agree with float32 on a probe (HipFlow._pack_auto)
         if flow.precision != self.precision:
@@ -571,6 +603,26 @@ class FlowProposal:
             flow.max_groups, lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_populate_draw")
+
+    def _launch_draw_weights(self, n, row_offset, radius, log_w, max_key, log_prior=None, min_log_q=-math.inf,
+                             prepared=None):
+        """The head of one lean pass (``nsa_populate_draw_weights``): ``log_w = log_prior - log_q`` of ``n`` drawn
+        rows and the launch's largest weight, nothing else written."""
+        flow, header, image, status = prepared if prepared is not None else self._prepare_flow()
+        if not self._status_hold:
+            status.zero_()
+        separable = self._prior_kind_dev is not None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = lib.load().nsa_populate_draw_weights(
+            header, lib.ptr(image), n, self.device_seed, int(row_offset), float(radius),
+            float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
+            lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
+            lib.ptr(self._prior_kind_dev), lib.ptr(self._prior_par_dev), lib.ptr(log_prior if separable else None),
+            0.0 if separable else self._uniform_log_prior_constant(), float(min_log_q),
+            lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev), lib.ptr(log_w), lib.ptr(max_key), lib.ptr(status),
+            flow.waves_per_group, flow.max_groups, lib.c_void_p(stream),
+        )
+        lib.check(rc, "nsa_populate_draw_weights")
 
     def _device_log_likelihood(self, rows):
         """log L of device rows ``(m, D)`` float64 -> ``(m,)`` float64 device tensor."""
@@ -1399,12 +1451,16 @@ class FlowProposal:
         return n_acc, buf["x_acc"][: min(n_acc, n_samples)].cpu().numpy()
 
     def _finish_population(self, st, n_accepted, n_proposed, log_l=None, f16_flag=None):
-        # A population whose draw kernel left the f16 range is discarded HERE, before it has any side
-        # effect - no likelihood call on its (in-bounds but invalid) rows, no permutation drawn from the host
-        # generator, counters and acceptance untouched: populate() redraws it in float32.
+        # A population whose draw kernel left the f16 range is discarded HERE: no HOST likelihood call on its
+        # (in-bounds but invalid) rows, no permutation drawn from the host generator, pool, counters and
+        # acceptance untouched; populate() redraws it in float32.  What it does leave behind: its Philox
+        # offsets (`_draw_counter` has advanced - the redraw uses fresh rows, so a run that fell back is not
+        # row-for-row the run that started in float32) and, in the device-side loops, a device likelihood
+        # evaluation of the discarded rows, whose result is dropped here.
         if self._f16_range_left(f16_flag):
             self._f16_discarded = True
             self.populated = False
+            self.x = None
             return
         self.samples = self.convert_to_samples(self.x)
         self.population_time += datetime.datetime.now() - st

@@ -153,3 +153,35 @@ def test_lean_entry_points_refuse_what_needs_the_candidates():
     rc = L.nsa_populate_replay(hdr, 1, 10, None, 1, 1.0, 1.0, 1, 1, 1, 1, 0.0, 1, 1, None, None, None, None, None, 1,
                                0, 0, None)
     assert rc != 0
+
+
+@pytest.mark.parametrize("case", ["c3", "separable_prior"])
+def test_draw_weights_equals_draw_then_weights(case):
+    """The head of a lean pass (``nsa_populate_draw_weights``: weights and their maximum out of the draw kernel) against
+    the full pass followed by ``nsa_populate_truncate`` and ``nsa_populate_weights``: every weight, the -inf of the
+    dropped rows and the maximum, bit for bit - with and without the ``min_log_q`` rule."""
+    prop, _ = _make(case, True)
+    prop.populate(None, n_samples=10, max_samples=10**9)  # device tables, radius
+    n = 50_017
+    L = lib.load()
+    buf = prop._get_buffers(n, 100)
+    radius = 5.7 if case == "c3" else prop.r
+    separable = prop._prior_kind_dev is not None
+    for min_log_q in (-np.inf, None):
+        prop._launch_draw(n, None, 999, radius, buf["x64"], buf["log_q"], None,
+                          log_prior=buf["log_p"] if separable else None)
+        if min_log_q is None:  # a threshold that drops about a third of the live rows
+            lq = buf["log_q"][:n]
+            min_log_q = float(torch.quantile(lq[torch.isfinite(lq)], 0.33))
+        prop._truncate_after_flow(buf, n, min_log_q, None)
+        prop._weights_and_max(buf, n)
+        torch.cuda.synchronize()
+        want_w, want_key = buf["log_w"][:n].clone(), int(buf["max_key"].item())
+        log_w = torch.zeros(n, dtype=torch.float64, device=prop.device)
+        key = torch.full((1,), int(L.nsa_max_key_init()), dtype=torch.int64, device=prop.device)
+        prop._launch_draw_weights(n, 999, radius, log_w, key, log_prior=buf["log_p"], min_log_q=min_log_q)
+        torch.cuda.synchronize()
+        assert torch.isinf(want_w).any() and torch.isfinite(want_w).any()
+        assert torch.equal(log_w, want_w)
+        assert int(key.item()) == want_key
+        assert float(L.nsa_max_key_decode(want_key)) == float(want_w.max())

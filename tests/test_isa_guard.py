@@ -1,0 +1,116 @@
+"""Guards on the compiled gfx950 code objects (CPU side: reads the built objects, launches nothing).
+
+The performance of rounds 2-4 rests on compiler behaviour nothing else pins: ``-mllvm -disable-machine-licm`` and
+``-fno-slp-vectorize`` (``csrc/Makefile``), the opaque ``-1`` that makes the f16 split select ``v_fma_mix_f32``
+(``csrc/nsa_device.h``), the opaque lane index that keeps per-lane invariants out of the persistent loop.  A ROCm bump
+that undoes one of them brings spills back silently - the results stay right and the kernels get slower.  This test
+reads the register / scratch metadata of the instances that carry the measured numbers (``scripts/kernel_regs.py``)
+and the disassembly of the headline kernel and fails when a budget documented in DESIGN.md is exceeded.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "nessai_amd", "csrc", "build")
+LLVM = "/opt/rocm/lib/llvm/bin"
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(BUILD) or not os.path.exists(f"{LLVM}/llvm-objdump"),
+                                reason="needs the in-tree build objects (make -C nessai_amd/csrc) and llvm-objdump")
+
+
+def _kernels(obj):
+    import kernel_regs
+
+    rows = kernel_regs.kernels(os.path.join(BUILD, obj))
+    names = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True,
+                           text=True).stdout.split("\n")
+    out = {}
+    for r, n in zip(rows, names):
+        out[n.replace("void ", "").replace("(NsaLaunch)", "").strip()] = r
+    return out
+
+
+def _one(table, name):
+    assert name in table, f"{name} not built; have e.g. {sorted(table)[:4]}"
+    return table[name]
+
+
+# (object, kernel, VGPR budget): the waves-per-SIMD step the instance is launched at (MI355X_MICROARCH.md, register
+# files: <= 128 -> 4 waves, <= 168 -> 3, <= 256 -> 2) - and never a byte of scratch
+FLOW_INSTANCES = [
+    # headline (config 3): staged, two 32-row tiles per wave, split-f16, both directions
+    ("inst_h2_t1_8.o", "nsa_flow_kernel<2, NsaRQ<8>, true, 2, 2, 2, false>", 256),
+    ("inst_h2_t1_8.o", "nsa_flow_kernel<2, NsaRQ<8>, false, 2, 2, 2, false>", 256),
+    # the same flow at 3 waves per SIMD and in exact f32
+    ("inst_h2_t1_8.o", "nsa_flow_kernel<2, NsaRQ<8>, true, 2, 3, 1, false>", 168),
+    ("inst_h2_t1_8.o", "nsa_flow_kernel<2, NsaRQ<8>, true, 0, 2, 1, false>", 256),
+    # config 2 (the reference's default RealNVP): weights-resident, 4 waves per SIMD
+    ("inst_h1_t2_0.o", "nsa_flow_kernel<1, NsaAffine, true, 2, 4, 1, true>", 128),
+    ("inst_h1_t2_0.o", "nsa_flow_kernel<1, NsaAffine, false, 2, 4, 1, true>", 128),
+    ("inst_h1_t2_0.o", "nsa_flow_kernel<1, NsaAffine, true, 2, 2, 2, true>", 256),
+    # config 5 (15-D NSF, 30 -> 32 hidden units)
+    ("inst_h1_t1_8.o", "nsa_flow_kernel<1, NsaRQ<8>, true, 2, 2, 2, false>", 256),
+]
+
+
+@pytest.mark.parametrize("obj,kernel,budget", FLOW_INSTANCES)
+def test_flow_instances_keep_their_register_budget_and_use_no_scratch(obj, kernel, budget):
+    r = _one(_kernels(obj), kernel)
+    assert r["spill"] == 0 and r["scratch"] == 0, r
+    assert r["vgpr"] + r["agpr"] <= budget, r
+
+
+def test_second_generation_training_kernels_do_not_spill():
+    table = _kernels("nsa_train.o")
+    for name in ("trf2_forward<8, 2, 6>(Trf2Multi)", "trf2_forward<8, 2, 1>(Trf2Multi)", "trf2_forward<0, 1, 4>(Trf2Multi)"):
+        r = _one(table, name)
+        assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 256, (name, r)
+    back = [n for n in table if n.startswith("trf2_backward<8, 2,")]
+    assert back, "config 3's backward instance (K = 8, two hidden tiles) is not built"
+    for n in back:
+        assert table[n]["spill"] == 0 and table[n]["scratch"] == 0, (n, table[n])
+
+
+def _disassemble(obj, mangled_fragment):
+    tmp = tempfile.mkdtemp()
+    try:
+        local = os.path.join(tmp, obj)
+        shutil.copy(os.path.join(BUILD, obj), local)
+        subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", local], check=True, capture_output=True)
+        co = [f for f in os.listdir(tmp) if "amdgcn" in f]
+        text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", os.path.join(tmp, co[0])], check=True,
+                              capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp)
+    blocks = re.split(r"\n(?=[0-9a-f]+ <)", text)
+    body = [b for b in blocks if mangled_fragment in b.split("\n", 1)[0]]
+    assert len(body) == 1, f"{len(body)} symbols match {mangled_fragment}"
+    return body[0]
+
+
+def test_headline_kernel_instruction_stream():
+    """What the measured 1.55-1.6 ms per 1e6 rows depend on, read off the disassembly of
+    nsa_flow_kernel<2, NsaRQ<8>, inverse, f16x3, 2 waves per SIMD, 2 tiles per wave, staged>."""
+    asm = _disassemble("inst_h2_t1_8.o", "nsa_flow_kernelILi2E5NsaRQILi8EELb1ELi2ELi2ELi2ELb0EE")
+    ops = re.findall(r"^\s+([a-z_0-9]+)", asm, flags=re.M)
+    count = lambda pat: sum(1 for o in ops if re.fullmatch(pat, o))  # noqa: E731
+    # the f16 split through v_fma_mix_f32 (2 vector instructions per value; cvt + sub would be 3)
+    assert count(r"v_fma_mix_f32") >= 200
+    # f16 matrix cores, three products per operand pair
+    assert count(r"v_mfma_f32_32x32x16_f16") >= 400 and count(r"v_mfma_f32_32x32x16_f16") % 3 == 0
+    # no scratch traffic, no packed-f32 vector code (SLP vectorisation is an anti-lever beside MFMAs)
+    assert count(r"scratch_.*") == 0
+    assert count(r"v_pk_(fma|mul|add)_f32.*") == 0
+    # transcendentals on the bare units; the only IEEE float32 divisions are the kernel's set-up constants
+    # (1 / sqrt(H), the elementwise op: a few sequences outside the tile loop), none per spline evaluation
+    assert count(r"v_div_fixup_f32.*") <= 4
+    assert count(r"v_exp_f32.*") > 0 and count(r"v_log_f32.*") > 0 and count(r"v_rcp_f32.*") > 0
+    # the weight stream goes global -> LDS without passing registers
+    assert count(r"global_load_lds_dwordx4") > 0
