@@ -44,6 +44,12 @@ NSA_API const char* nsa_last_error(void);
  * (src/nessai/flows/utils.py:208-246, configure_model). */
 NSA_API int nsa_flow_supported(int hidden_tiles, int transform, int bins);
 
+/* 1 if a rational-quadratic spline flow of `bins` bins has no exact kernel instance and runs on the generic
+ * one (any num_bins from 2 to 16 - src/nessai/flows/nsf.py:66,103 passes num_bins through to nflows - on
+ * parameter sets padded to 16 bins: the packer, nessai_amd/pack.py, must lay the last conditioner layer out
+ * for it); 0 for an exact instance or an unsupported count. */
+NSA_API int nsa_flow_generic_bins(int hidden_tiles, int bins);
+
 /* Launch geometry of the last flow kernel this thread enqueued: waves per SIMD the instance is
  * built for (2 or 3), waves per workgroup, workgroups.  The library picks it per launch (batch
  * size, conditioner width, precision; for big split-bf16 batches by timing the three candidates

@@ -68,12 +68,23 @@ static const NsaInstance g_instances[] = {
 #undef X
 };
 
+#define NSA_GENERIC_BINS 99  // instance key of NsaRQ<16, true>: any num_bins from 2 to 16 (nsa_device.h)
+
 static nsa_launch_fn nsa_find(int ht, int kind, int bins) {
   if (kind != NSA_T_RQ) bins = 0;
   for (size_t i = 0; i < sizeof(g_instances) / sizeof(g_instances[0]); ++i)
     if (g_instances[i].ht == ht && g_instances[i].kind == kind && g_instances[i].bins == bins)
       return g_instances[i].fn;
+  // no exact spline instance: the generic one runs the flow on padded parameter sets (the packer lays them out)
+  if (kind == NSA_T_RQ && bins >= 2 && bins <= 16 && bins != NSA_GENERIC_BINS) return nsa_find(ht, kind, NSA_GENERIC_BINS);
   return nullptr;
+}
+
+// 1 when a spline flow of `bins` bins runs on the generic (padded) instance rather than an exact one
+extern "C" int nsa_flow_generic_bins(int hidden_tiles, int bins) {
+  for (size_t i = 0; i < sizeof(g_instances) / sizeof(g_instances[0]); ++i)
+    if (g_instances[i].ht == hidden_tiles && g_instances[i].kind == NSA_T_RQ && g_instances[i].bins == bins) return 0;
+  return nsa_find(hidden_tiles, NSA_T_RQ, bins) != nullptr ? 1 : 0;
 }
 
 extern "C" int nsa_flow_supported(int hidden_tiles, int transform, int bins) {
@@ -263,6 +274,9 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   if (h[NSA_H_PREC] != NSA_PREC_F32 && h[NSA_H_PREC] != NSA_PREC_BF16X3 && h[NSA_H_PREC] != NSA_PREC_F16X3)
     return nsa_fail(NSA_E_IMAGE, "unknown precision code %u", h[NSA_H_PREC]);
   p.precision = (int)h[NSA_H_PREC];
+  {
+    p.prio = -1;  // decided with the geometry below; NESSAI_AMD_PRIO=0|1|2 pins it (NsaLaunch::prio)
+  }
   const int D = (int)h[NSA_H_D];
   const int XS = (D + 2) | 1;  // row stride of the x tiles (nsa_flow_kernel.h)
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
@@ -325,6 +339,10 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
       // one at four waves 0.91 against 0.65 (profiles/r04_c3_coupling_resident.jsonl)
       if (pin_occ == 0 && w < w_asked && w * r < 8) continue;
       p.resident = 1;
+      {
+        const char* pr = getenv("NESSAI_AMD_PRIO");
+        p.prio = pr != nullptr ? atoi(pr) : 0;
+      }
       p.occupancy = o;
       p.row_tiles = r;
       p.skew = 0;
@@ -371,6 +389,13 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   }
   p.occupancy = occ;
   p.row_tiles = rt;
+  {
+    // the staged two-tiles geometry (8 waves in lock step through one barrier per stage): the second-dispatched
+    // half of the workgroup loses the vector-issue arbitration on every stage; one static s_setprio 1 for it
+    // measured 1.565 against 1.581 ms per 1e6 rows of config 3 (the lower half instead: 1.577; gpurun_out r05c2)
+    const char* pr = getenv("NESSAI_AMD_PRIO");
+    p.prio = pr != nullptr ? atoi(pr) : (rt == 2 ? 1 : 0);
+  }
   {
     const char* sk = getenv("NESSAI_AMD_SKEW");  // two-tiles geometry only (see NsaStagePipe::skew)
     p.skew = sk != nullptr ? atoi(sk) : NSA_DEFAULT_SKEW;

@@ -190,8 +190,9 @@ __device__ __forceinline__ float nsa_u01(uint32_t x) {
 // two u32 -> two standard normals: r = sqrt(-2 ln u1), angle = u2 revolutions.  On the hardware's
 // transcendental unit - v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in revolutions) - 12
 // instructions where logf + sqrtf + sincospif took ~80 per pair; u1 >= 2^-33 is a normal number, u2 in (0, 1]
-// needs no range reduction.  (A random stream is defined by what the kernel does: oracle/philox.py restates
-// this map in float64 and the tests hold the device to it within the units' error, a few 1e-6 absolute.)
+// needs no range reduction.  (A random stream is defined by what the kernel does: oracle/philox.py holds the
+// same map - Box-Muller on the (x + 0.5) 2^-32 uniforms - in numpy's float arithmetic, and the tests hold the
+// device to it within the transcendental units' error, a few 1e-6 absolute.)
 __device__ __forceinline__ void nsa_box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
   const float u1 = nsa_u01(a), u2 = nsa_u01(b);
   const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
@@ -214,6 +215,9 @@ struct NsaTransformConsts {
   float inv_logit_div;              // 1/sqrt(hidden_features) or 1
   float aff_a, aff_b;               // affine coupling: scale = sigmoid(raw + aff_a) + aff_b
   float aff_arg0, aff_1pb;          // -aff_a log2(e), 1 + aff_b
+  int k_real;                       // spline bins of the flow (= K of the instance; <= K in the padded generic instance)
+  float aff_cap;                    // cap of -(raw + a) log2(e): 64 (sigmoid is 0 beside a floor b >= 1e-9), 126 for smaller floors
+  bool ld_group4;                   // Jacobian factors of an LD_FACTOR transform may be multiplied four at a time
 };
 
 // Fast-but-accurate scalar helpers.  The spline's arithmetic *structure* follows
@@ -298,7 +302,13 @@ struct NsaBinSelect<1> {
 //   v[0..K)      unnormalised widths
 //   v[K..2K)     unnormalised heights
 //   v[2K..3K-1)  unnormalised interior derivatives
-template <int K>
+// PAD (the generic instance, NsaRQ<16, true>: any num_bins from 2 to 16 - the reference passes num_bins through,
+// flows/nsf.py:66,103): the flow has c.k_real <= K bins and the packer (pack.py, _CouplingBlobs) deals its 3 k_real - 1
+// parameters to the first slots of each of the three groups of K; the logits of the slots beyond k_real carry the
+// bias -1e30 (their exponentials are 0: they take no part in a softmax), the derivative slot of knot k_real the
+// boundary logit.  Knot k_real is the right end B, the knots beyond it +inf: the bin search never enters them.
+// Costs two selects per knot over the exact instances; the exact ones (K = 4, 8, 10, 16) are untouched.
+template <int K, bool PAD = false>
 struct NsaRQ {
   static constexpr int NP = 3 * K - 1;
   static constexpr int FPC = (K == 8) ? 2 : 1;
@@ -310,28 +320,54 @@ struct NsaRQ {
   struct State {};
 
   // knots of one axis: softmax -> min + scale*p -> cumulative sum mapped to [-B, B]:
-  //   cum[i] = -B + i*(2B*min) + (2B*scale/sum) * prefix_i,   prefix_i = sum_{j<i} exp(l_j - max)
+  //   cum[i] = -B + i*(2B*min) + (2B*scale/sum) * prefix_i,   prefix_i = sum_{j<i} exp(l_j - shift)
   // The logits are scaled by log2(e)/sqrt(H) once so that the exponentials are bare v_exp_f32;
   // the prefix sums double as the softmax denominator; the ends are exact.
-  template <int OFF, int NV>
-  __device__ __forceinline__ static void knots(const float (&v)[NV], float inv_div, float mn,
-                                               float sc, float two_b, float B, float (&cum)[K + 1]) {
-    // max over the raw logits (the scale is positive), then scale and shift in ONE fma per logit
+  // SHIFTED = false (round 5): no maximum is subtracted - a softmax does not depend on the shift, and the logits
+  // of a conditioner are O(1-10), so the plain exponentials are as exact as the shifted ones (8 of ~180 vector
+  // instructions per evaluation; 2 % of the draw kernel).  The caller checks that the two sums stayed where
+  // nothing overflowed and no term of weight was flushed (`sums_in_range`) and repeats the evaluation with
+  // SHIFTED = true - torch's max-subtracted softmax, safe for any logits - when a lane of the wave left it.
+  // Returns the sum of the exponentials.
+  template <int OFF, int NV, bool SHIFTED>
+  __device__ __forceinline__ static float knots(const float (&v)[NV], float inv_div, float mn,
+                                                float sc, float two_b, float B, float (&cum)[K + 1], int k_real = K) {
     const float k2 = inv_div * 1.4426950408889634f;
-    float m = v[OFF];
+    float mk = 0.0f;
+    if constexpr (SHIFTED) {
+      // max over the raw logits (the scale is positive), then scale and shift in ONE fma per logit
+      float m = v[OFF];
 #pragma unroll
-    for (int i = 1; i < K; ++i) m = fmaxf(m, v[OFF + i]);
-    const float mk = m * k2;
+      for (int i = 1; i < K; ++i) m = fmaxf(m, v[OFF + i]);
+      mk = m * k2;
+    }
     float pre[K + 1];
     pre[0] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < K; ++i) pre[i + 1] = pre[i] + __builtin_amdgcn_exp2f(fmaf(v[OFF + i], k2, -mk));
+    for (int i = 0; i < K; ++i)
+      pre[i + 1] = pre[i] + __builtin_amdgcn_exp2f(SHIFTED ? fmaf(v[OFF + i], k2, -mk) : v[OFF + i] * k2);
     const float g = (two_b * sc) * nsa_rcp(pre[K]);
     const float c0 = two_b * mn;
 #pragma unroll
     for (int i = 1; i < K; ++i) cum[i] = fmaf(g, pre[i], fmaf((float)i, c0, -B));
     cum[0] = -B;
     cum[K] = B;
+    if constexpr (PAD) {
+      // (k_real is wave-uniform: the conditions are scalar compares, the selects v_cndmask on a scalar mask)
+#pragma unroll
+      for (int i = 1; i < K; ++i) {
+        const float top = (i == k_real) ? B : __builtin_huge_valf();
+        cum[i] = (i < k_real) ? cum[i] : top;
+      }
+      cum[K] = (k_real == K) ? B : __builtin_huge_valf();
+    }
+    return pre[K];
+  }
+
+  // the sum of an unshifted softmax inside [2^-100, 2^100]: no exponential overflowed (each <= the sum) and none
+  // that carries weight was flushed (a term below 2^-126 is below 2^-26 of such a sum); NaN -> false
+  __device__ __forceinline__ static bool sum_in_range(float s) {
+    return (s >= 7.888609052210118e-31f) & (s <= 1.2676506002282294e30f);
   }
 
   template <int P, int OFF, bool INV, int NV>
@@ -340,8 +376,20 @@ struct NsaRQ {
                                                bool& bad) {
     const float B = c.tail_bound;
     float cw[K + 1], ch[K + 1], raw[K + 1];
-    knots<OFF, NV>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw);
-    knots<OFF + K, NV>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch);
+    // (checked per axis, right behind its knots: the eight logits of an axis then stay live a few instructions
+    // longer, not across the other axis - checked together they cost the two-tiles instance two spilled registers;
+    // the branches are wave-uniform and practically never taken)
+#ifdef NSA_SHIFTED_SOFTMAX  // A/B builds (scripts/build_variant.sh): the max-subtracted softmax of rounds 1-4
+    knots<OFF, NV, true>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw, c.k_real);
+    knots<OFF + K, NV, true>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch, c.k_real);
+#else
+    const float sw = knots<OFF, NV, false>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw, c.k_real);
+    if (__builtin_expect(__any(!sum_in_range(sw)), 0))
+      knots<OFF, NV, true>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw, c.k_real);
+    const float sh = knots<OFF + K, NV, false>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch, c.k_real);
+    if (__builtin_expect(__any(!sum_in_range(sh)), 0))
+      knots<OFF + K, NV, true>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch, c.k_real);
+#endif
     // derivative logits per knot; the boundary knots carry the logit of derivative 1
     raw[0] = c.edge_raw;
     raw[K] = c.edge_raw;
@@ -401,9 +449,12 @@ struct NsaRQ {
 // reciprocal for the direction at hand (the plain form needs two in the inverse direction: of 1 + e and of
 // the scale), on the bare v_exp_f32 / v_rcp_f32; and log|det J| = sum log(scale) is taken as the log of a
 // PRODUCT of the factors a lane holds (LD_FACTOR: the caller multiplies the `ld` of up to four features -
-// >= b^4, no underflow for any sensible b - and takes one v_log_f32), since a transcendental costs 2.7 plain
-// vector instructions here (scripts/ubench/valu_rates).  e is capped at 2^64, where sigmoid is 0 to
-// float32 beside b; the cap is a compare + select, not a min: a NaN stays a NaN.
+// >= b^4; for floors b below 1e-9, a plain sigmoid included, it takes one logarithm per feature instead:
+// NsaTransformConsts::ld_group4 - and takes one v_log_f32), since a transcendental costs 2.7 plain vector
+// instructions here (scripts/ubench/valu_rates).  e is capped at 2^64, where sigmoid is 0 to
+// float32 beside b (at 2^126 for floors below 1e-9, a plain sigmoid included: the scale then follows the sigmoid
+// down to the smallest normal number - NsaTransformConsts::aff_cap); the cap is a compare + select, not a min: a
+// NaN stays a NaN.
 struct NsaAffine {
   static constexpr int NP = 2;
   static constexpr int FPC = 8;
@@ -419,7 +470,7 @@ struct NsaAffine {
                                                bool& bad) {
     const float shift = v[OFF];
     float arg = fmaf(v[OFF + 1], -1.4426950408889634f, c.aff_arg0);  // -(raw + a) log2(e)
-    arg = arg > 64.0f ? 64.0f : arg;
+    arg = arg > c.aff_cap ? c.aff_cap : arg;
     const float e = __builtin_amdgcn_exp2f(arg);
     const float num = 1.0f + e, den = fmaf(c.aff_b, e, c.aff_1pb);
     bad = false;

@@ -18,7 +18,9 @@
 #endif
 #endif
 
-#if NSA_TKIND == 1
+#if NSA_TKIND == 1 && NSA_BINS == 99  // the generic instance: any num_bins <= 16 on padded 16-bin parameter sets
+using TP = NsaRQ<16, true>;
+#elif NSA_TKIND == 1
 using TP = NsaRQ<NSA_BINS>;
 #elif NSA_TKIND == 2
 using TP = NsaAffine;

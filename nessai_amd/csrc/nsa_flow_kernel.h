@@ -158,6 +158,10 @@ struct NsaLaunch {
   // a row is a pure function of its Philox counter, so the accepted ones are computed AGAIN from their global
   // row indices: row_list[r] replaces row_offset + r as the counter of local row r (replay launch).
   const long long* row_list;
+  // static wave priority (MI355X_MICROARCH.md, "static priority for the younger half"): 1 = the upper half of the
+  // workgroup's waves runs at s_setprio 1 for the whole kernel (the default of the staged two-tiles geometry: nsa_api.hip),
+  // 2 = the lower half, 0 = off; NESSAI_AMD_PRIO pins it
+  int prio;
   // The lean pass with the weights folded in (log_w_out != null): instead of log_q the pass writes
   //   log_w = log_prior - log_q        (FlowProposal.compute_weights, proposal/flowproposal/base.py:1069-1098)
   // -inf for dropped rows, after the min_log_q rule (truncation.py:385-392: keep log_q > min_log_q; -inf = off), and
@@ -597,7 +601,7 @@ template <class TP, bool INV, int PH, int NV>
 __device__ __forceinline__ void nsa_run_phase(typename TP::State (&st)[TP::FPC], const float (&v)[NV],
                                               const int (&cols)[TP::FPC], float* xrow,
                                               int dummy_col, const NsaTransformConsts& tc,
-                                              float& logdet, int& n_bad, float (&prod)[(TP::FPC + 3) / 4]) {
+                                              float& logdet, int& n_bad, float (&fac)[TP::FPC]) {
   constexpr int Q = PH / TP::NPH, P = PH % TP::NPH;
   // unused feature slots (col < 0) run on the tile's spare column and add nothing
   const int col = cols[Q];
@@ -610,7 +614,7 @@ __device__ __forceinline__ void nsa_run_phase(typename TP::State (&st)[TP::FPC],
   TP::template phase<P, Q * TP::NP, INV, NV>(st[Q], v, x_in, tc, y, ld, bad);
   if constexpr (P == TP::NPH - 1) {
     xrow[c] = y;
-    if constexpr (TP::LD_FACTOR) prod[Q / 4] *= live ? ld : 1.0f;
+    if constexpr (TP::LD_FACTOR) fac[Q] = live ? ld : 1.0f;
     else logdet += live ? ld : 0.0f;
     n_bad += (live && bad) ? 1 : 0;
   }
@@ -622,15 +626,29 @@ __device__ __forceinline__ void nsa_run_phases(typename TP::State (&st)[TP::FPC]
                                                int dummy_col, const NsaTransformConsts& tc,
                                                float& logdet, int& n_bad,
                                                std::integer_sequence<int, I...>) {
-  // LD_FACTOR transforms hand back Jacobian factors: multiplied in groups of four, one logarithm per group
-  float prod[(TP::FPC + 3) / 4];
+  // LD_FACTOR transforms hand back Jacobian factors: multiplied in groups of four, one logarithm per group -
+  // while a product of four cannot leave the float32 range (tc.ld_group4: the floor b of the scale activation
+  // sigmoid(raw + a) + b is >= 1e-9, so a factor lies in [b, 1 + b] or its reciprocal; with b = 0, a plain
+  // sigmoid, four saturated scales of 2^-64 would underflow to 0 and log|det J| to -inf where the reference's
+  // sum of logarithms is finite): otherwise one logarithm per feature
+  float fac[TP::FPC];
 #pragma unroll
-  for (int g = 0; g < (TP::FPC + 3) / 4; ++g) prod[g] = 1.0f;
-  (nsa_run_phase<TP, INV, LO + I, NV>(st, v, cols, xrow, dummy_col, tc, logdet, n_bad, prod), ...);
+  for (int q = 0; q < TP::FPC; ++q) fac[q] = 1.0f;
+  (nsa_run_phase<TP, INV, LO + I, NV>(st, v, cols, xrow, dummy_col, tc, logdet, n_bad, fac), ...);
   if constexpr (TP::LD_FACTOR) {
     float l2 = 0.0f;
+    if (tc.ld_group4) {
 #pragma unroll
-    for (int g = 0; g < (TP::FPC + 3) / 4; ++g) l2 += nsa_log2(prod[g]);
+      for (int g = 0; g < (TP::FPC + 3) / 4; ++g) {
+        float pr = fac[4 * g];
+#pragma unroll
+        for (int q = 4 * g + 1; q < 4 * g + 4 && q < TP::FPC; ++q) pr *= fac[q];
+        l2 += nsa_log2(pr);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < TP::FPC; ++q) l2 += nsa_log2(fac[q]);
+    }
     logdet = fmaf(0.6931471805599453f, l2, logdet);
   }
 }
@@ -872,7 +890,7 @@ __device__ __forceinline__ void nsa_dense_store(float* xrow, const f32x16& acc, 
 }
 
 // dense (LU-linear, eval-mode cached weight) -----------------------------------
-// y = W (x - pre) + bias over all D features; D <= 64.
+// y = W (x - pre) + bias over all D features: one stage per output tile of 32 features, up to four (D <= 128).
 template <int PREC, int RT, class PIPE>
 __device__ __forceinline__ void nsa_dense_op(PIPE& pipe, const uint32_t* op, float* const (&xrow)[RT],
                                              int D, int lane, int half, float (&logdet)[RT]) {
@@ -1054,10 +1072,15 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     pipe.skew = SK && (p.skew == 1 ? (wave >= (nw >> 1)) : (p.skew == 2 ? (wave & 1) != 0 : false));
   }
 
+  if (p.prio == 1 && wave >= (nw >> 1)) __builtin_amdgcn_s_setprio(1);
+  if (p.prio == 2 && wave < (nw >> 1)) __builtin_amdgcn_s_setprio(1);
+
   const uint32_t* ops = prog_ops;
-  const int* out_tab = (const int*)(img + (inverse ? img[NSA_H_OUT_INV] : img[NSA_H_OUT_FWD]));
-  // base density constants: header words, kept in the workgroup's LDS copy of the program (two more words
-  // behind the op table) and read there by the tile's prologue / epilogue
+  // (the offset through readfirstlane: loaded by a vector load, the table's address was a VGPR pair live across
+  // the whole tile loop - the one value the two-tiles instance spilled once the spline grew by a branch)
+  const int* out_tab = (const int*)(img + __builtin_amdgcn_readfirstlane((int)(inverse ? img[NSA_H_OUT_INV] : img[NSA_H_OUT_FWD])));
+  // (the base density constants - header words NSA_H_BASE_INV_VAR / NSA_H_LOG_Z - are read where they are used by
+  // scalar loads from the image, nsa_header_float)
 
   NsaTransformConsts tc;
   tc.tail_bound = nsa_bits_to_float(img[NSA_H_TAIL_BOUND]);
@@ -1072,8 +1095,11 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   tc.aff_b = nsa_bits_to_float(img[NSA_H_AFF_B]);
   tc.aff_arg0 = -1.4426950408889634f * tc.aff_a;
   tc.aff_1pb = 1.0f + tc.aff_b;
+  tc.ld_group4 = tc.aff_b >= 1e-9f;
+  tc.aff_cap = tc.ld_group4 ? 64.0f : 126.0f;
   {
     const int K = (int)img[NSA_H_BINS];
+    tc.k_real = K;
     tc.bw_scale = (float)(1.0 - (double)tc.min_bw * K);
     tc.bh_scale = (float)(1.0 - (double)tc.min_bh * K);
   }

@@ -216,6 +216,7 @@ __device__ __forceinline__ void tr_rq_forward_core(const float* __restrict__ Pit
   tc.min_bh = c.min_bh; tc.bh_scale = (float)(1.0 - (double)c.min_bh * K);
   tc.min_d = c.min_d; tc.edge_d = c.edge_d; tc.inv_logit_div = c.inv_div;
   tc.edge_raw = logf(expf(1.0f - c.min_d) - 1.0f);
+  tc.k_real = K;
   typename NsaRQ<K>::State st;
   y = 0.0f;
   ld = 0.0f;
@@ -1282,12 +1283,21 @@ static inline dim3 tiles(long long rows, long long cols) {
 }
 static inline dim3 blocks_for(long long work) { return dim3((unsigned)((work + 255) / 256)); }
 
+// the per-item spline kernels exist for every bin count from 2 to 16 (the reference passes num_bins through,
+// src/nessai/flows/nsf.py:66,103); the fused coupling kernels for the four counts with an exact inference instance
+#define TR_SPLINE_CASE(KERNEL, KK, ...) case KK: hipLaunchKernelGGL(KERNEL<KK>, __VA_ARGS__); break;
 #define TR_SPLINE_DISPATCH(KERNEL, K, ...)                                                          \
   do {                                                                                              \
-    if ((K) == 4) hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__);                                       \
-    else if ((K) == 8) hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__);                                  \
-    else if ((K) == 10) hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__);                                \
-    else hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__);                                               \
+    switch (K) {                                                                                    \
+      TR_SPLINE_CASE(KERNEL, 2, __VA_ARGS__) TR_SPLINE_CASE(KERNEL, 3, __VA_ARGS__)                 \
+      TR_SPLINE_CASE(KERNEL, 4, __VA_ARGS__) TR_SPLINE_CASE(KERNEL, 5, __VA_ARGS__)                 \
+      TR_SPLINE_CASE(KERNEL, 6, __VA_ARGS__) TR_SPLINE_CASE(KERNEL, 7, __VA_ARGS__)                 \
+      TR_SPLINE_CASE(KERNEL, 8, __VA_ARGS__) TR_SPLINE_CASE(KERNEL, 9, __VA_ARGS__)                 \
+      TR_SPLINE_CASE(KERNEL, 10, __VA_ARGS__) TR_SPLINE_CASE(KERNEL, 11, __VA_ARGS__)               \
+      TR_SPLINE_CASE(KERNEL, 12, __VA_ARGS__) TR_SPLINE_CASE(KERNEL, 13, __VA_ARGS__)               \
+      TR_SPLINE_CASE(KERNEL, 14, __VA_ARGS__) TR_SPLINE_CASE(KERNEL, 15, __VA_ARGS__)               \
+      default: hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__); break;                                  \
+    }                                                                                               \
   } while (0)
 
 // fused coupling kernels (nsa_train_fused.h): used when the conditioner fits their LDS tiles;
@@ -1295,7 +1305,9 @@ static inline dim3 blocks_for(long long work) { return dim3((unsigned)((work + 2
 static bool tr_use_fused(const long long* plan) {
   const char* e = getenv("NESSAI_AMD_TRAIN_FUSED");  // read per call: the tests flip it
   const bool enabled = !(e != nullptr && e[0] == '0');
-  return enabled && plan[11] == NSA_NET_RESNET && plan[1] <= 128 && plan[2] <= TRF_MAX_L;  // H <= 128: <= 8 gh tiles
+  // (a spline with a bin count other than 4 / 8 / 10 / 16 trains on the layer-wise kernels)
+  const bool exact_bins = plan[4] != NSA_T_RQ || plan[5] == 4 || plan[5] == 8 || plan[5] == 10 || plan[5] == 16;
+  return enabled && exact_bins && plan[11] == NSA_NET_RESNET && plan[1] <= 128 && plan[2] <= TRF_MAX_L;  // H <= 128: <= 8 gh tiles
 }
 
 static void tr_prepare_pass(const long long* plan, const int* tables_dev, const float* params_dev, float* grads_dev,

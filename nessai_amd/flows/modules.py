@@ -20,6 +20,7 @@ import math
 import numpy as np
 import torch
 from torch import nn
+from torch.nn import functional as F
 from torch.nn import init
 
 ACTIVATION_NAMES = {}
@@ -211,6 +212,67 @@ class LULinear(_Container):
             )
 
 
+class HouseholderSequence(_Container):
+    """The reflection vectors of an orthogonal factor of ``SVDLinear`` (parameter container; nflows' attribute
+    name and identity initialisation: pairs of equal unit vectors)."""
+
+    def __init__(self, features, num_transforms):
+        super().__init__()
+        self.features = features
+        self.num_transforms = num_transforms
+        qr = torch.eye(num_transforms // 2, features).repeat_interleave(2, dim=0)
+        if num_transforms % 2 != 0:
+            qr = torch.cat((qr, torch.zeros(1, features)))
+            qr[-1, num_transforms // 2] = 1
+        self.q_vectors = nn.Parameter(qr)
+
+    def host_matrix(self):
+        """Q (float64) with ``x -> x Q`` the sequence of reflections ``x (I - 2 q q^T / |q|^2)`` in order."""
+        q = self.q_vectors.detach().double().cpu().numpy()
+        Q = np.eye(self.features)
+        for v in q:
+            Q = Q - np.outer(Q @ v, (2.0 / float(v @ v)) * v)
+        return Q
+
+
+class SVDLinear(_Container):
+    """``linear_transform="svd"`` (``src/nessai/flows/utils.py:316-323``): ``y = x Q2 diag(s) Q1 + b`` with
+    Householder-sequence factors and ``s = eps + softplus(.)``.  In eval mode it is one dense D x D matrix with a
+    known log-determinant - the LU-linear op of the kernels (``host_matrices``, same contract as ``LULinear``);
+    there is no training kernel for it (``train`` raises)."""
+
+    def __init__(self, features, num_householder=10, identity_init=True, eps=1e-3):
+        super().__init__()
+        assert num_householder % 2 == 0
+        self.features = features
+        self.eps = eps
+        self.bias = nn.Parameter(torch.zeros(features))
+        self.orthogonal_1 = HouseholderSequence(features, num_householder)
+        self.unconstrained_diagonal = nn.Parameter(torch.zeros(features))
+        self.orthogonal_2 = HouseholderSequence(features, num_householder)
+        self._initialize(identity_init)
+
+    def _initialize(self, identity_init=True):
+        init.zeros_(self.bias)
+        if identity_init:
+            init.constant_(self.unconstrained_diagonal, math.log(math.exp(1 - self.eps) - 1))
+        else:
+            stdv = 1.0 / math.sqrt(self.features)
+            init.uniform_(self.unconstrained_diagonal, -stdv, stdv)
+
+    def host_matrices(self):
+        """(W, W^-1, bias, log|det W|) as float32 arrays, ``y = W x + b``: float64 on the host, rounded once
+        (the reference applies the 2 x 10 reflections to every batch in float32)."""
+        with torch.no_grad():
+            diag = (F.softplus(self.unconstrained_diagonal.detach().float().cpu()) + self.eps).double().numpy()
+            q1, q2 = self.orthogonal_1.host_matrix(), self.orthogonal_2.host_matrix()
+            w_t = q2 @ np.diag(diag) @ q1            # y = x W^T + b
+            w_inv_t = q1.T @ np.diag(1.0 / diag) @ q2.T
+            logabsdet = float(np.sum(np.log(diag)))
+            return (np.ascontiguousarray(w_t.T).astype(np.float32), np.ascontiguousarray(w_inv_t.T).astype(np.float32),
+                    self.bias.detach().float().cpu().numpy(), np.float32(logabsdet))
+
+
 class BatchNorm(_Container):
     """Batch norm between coupling layers (eval-mode statistics on the device)."""
 
@@ -390,9 +452,9 @@ def describe(flow, index_offset=None):
         name = type(t).__name__
         if hasattr(t, "_permutation"):
             desc["transforms"].append(("permutation", t._permutation.detach().cpu().numpy()))
-        elif hasattr(t, "lower_entries"):
+        elif hasattr(t, "lower_entries") or hasattr(t, "orthogonal_1"):
             if offsets is not None:
-                raise ValueError("the image words of an LU-linear transform are not copies of parameters")
+                raise ValueError("the image words of an LU- / SVD-linear transform are not copies of parameters")
             if hasattr(t, "host_matrices"):
                 W, W_inv, bias, ld = t.host_matrices()
             else:  # structurally identical foreign module (tests)

@@ -15,8 +15,10 @@ _NO_KERNEL = "has no gfx950 kernel"
 _LINEAR = {
     "permutation": lambda d: M.RandomPermutation(features=d),
     "lu": lambda d: M.CompositeTransform([M.RandomPermutation(features=d), M.LULinear(d, identity_init=True)]),
+    "svd": lambda d: M.CompositeTransform([M.RandomPermutation(features=d),
+                                           M.SVDLinear(d, num_householder=10, identity_init=True)]),
 }
-_LINEAR_REFUSED = ("svd",)
+_LINEAR_REFUSED = ()
 _PRE = {"batch_norm": lambda d, **kw: M.BatchNorm(features=d, **kw)}
 _PRE_REFUSED = ("logit",)
 _WIDTH_RULES = {"auto": (2, 1), "double": (2, 1), "equal": (1, 1), "half": (1, 2)}  # n_inputs * a // b

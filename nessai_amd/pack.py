@@ -65,9 +65,27 @@ def pad4(n):
     return (n + 3) & ~3
 
 
+#: spline bin counts with an exact kernel instance (csrc/Makefile); any other count from 2 to 16 runs on the
+#: generic instance NsaRQ<16, true> (csrc/nsa_device.h) with its parameters padded to 16 bins
+EXACT_BINS = (4, 8, 10, 16)
+GENERIC_BINS = 16
+#: bias of a padded width / height logit: its exponential is 0.0, it takes no part in the softmax
+PAD_LOGIT = -1.0e30
+
+
+def kernel_bins(bins):
+    """Bins of the kernel instance a spline flow of ``bins`` bins runs on."""
+    if bins in EXACT_BINS:
+        return bins
+    if 2 <= bins <= GENERIC_BINS:
+        return GENERIC_BINS
+    raise ValueError(f"num_bins={bins} is not supported by the gfx950 kernels (2 <= num_bins <= {GENERIC_BINS})")
+
+
 def transform_policy(transform, bins):
-    """(tiles per chunk C, features per lane per chunk FPC, params per feature NP)."""
+    """(tiles per chunk C, features per lane per chunk FPC, params per feature NP) of the KERNEL INSTANCE."""
     if transform == "rq":
+        bins = kernel_bins(bins)
         n_params = 3 * bins - 1
         fpc = 2 if bins == 8 else 1
         return (fpc * n_params + 15) // 16, fpc, n_params
@@ -143,8 +161,9 @@ def pack_matrix(weight, out_rows, in_cols):
     return w.reshape(-1)
 
 
-def pack_bias(bias, out_rows):
-    """bias laid out as [OT][half][16] following the D layout."""
+def pack_bias(bias, out_rows, fill=None):
+    """bias laid out as [OT][half][16] following the D layout; ``fill[ot][i]``: the constant of a row without
+    an original (-1), default 0."""
     n_ot = len(out_rows)
     out = np.zeros((n_ot, 2, 16), dtype=np.float32)
     for ot in range(n_ot):
@@ -153,6 +172,8 @@ def pack_bias(bias, out_rows):
             reg, half = _row_of_tile_row(i)
             if row >= 0:
                 out[ot, half, reg] = bias[row]
+            elif fill is not None:
+                out[ot, half, reg] = fill[ot][i]
     return out.reshape(-1)
 
 
@@ -338,26 +359,49 @@ class _CouplingBlobs:
         wf, bf = layers[-1]
         assert wf.shape[1] == hidden
         self.chunks = []  # (feature slots [2*fpc] (index into transform_idx or -1), bias, [W of sub-stage 0, 1, ...])
+        # a spline flow on the generic instance: the kernel's parameter slot p of a feature (3 groups of
+        # k_kern: widths, heights, derivatives) is the flow's parameter `real` or a padded slot with a constant
+        k_real = int(desc.get("bins", 0)) if desc["transform"] == "rq" else 0
+        k_kern = kernel_bins(k_real) if desc["transform"] == "rq" else 0
+        edge_raw = float(np.float32(np.log(np.exp(1.0 - float(desc.get("min_derivative", 1e-3))) - 1.0)))
+
+        def real_param(p):
+            """(index among the flow's 3 k_real - 1 parameters or -1, constant of a padded slot)."""
+            if k_kern == k_real:
+                return p, 0.0
+            group, j = divmod(p, k_kern)
+            if group < 2:  # width / height logit j
+                return (group * k_real + j, 0.0) if j < k_real else (-1, PAD_LOGIT)
+            if j < k_real - 1:  # interior derivative logit of knot j + 1
+                return 2 * k_real + j, 0.0
+            # knot k_real is the right end of the spline: boundary derivative; beyond it: never selected
+            return -1, (edge_raw if j == k_real - 1 else 0.0)
+
+        n_real = 3 * k_real - 1 if desc["transform"] == "rq" else n_params
         for c in range(self.n_chunks):
-            out_rows = []
+            out_rows, fill = [], []
             for t in range(n_tiles_c):
-                rows = []
+                rows, consts = [], []
                 for i in range(32):
                     reg, half = _row_of_tile_row(i)
                     v = 16 * t + reg
                     q, p = self._decode(desc["transform"], v, n_params)
                     m = c * 2 * fpc + half * fpc + q
+                    row, const = -1, 0.0
                     if q < fpc and m < self.d_tr:
-                        rows.append(self._orig_row(desc["transform"], m, p, n_params))
-                    else:
-                        rows.append(-1)
+                        if desc["transform"] == "rq":
+                            p, const = real_param(p)
+                        row = self._orig_row(desc["transform"], m, p, n_real) if p >= 0 else -1
+                    rows.append(row)
+                    consts.append(const if row < 0 else 0.0)
                 out_rows.append(rows)
+                fill.append(consts)
             slots = []
             for half in range(2):
                 for q in range(fpc):
                     m = c * 2 * fpc + half * fpc + q
                     slots.append(m if m < self.d_tr else -1)
-            self.chunks.append((slots, pack_bias(bf, out_rows), pack_split(wf, out_rows, n_tiles_c)))
+            self.chunks.append((slots, pack_bias(bf, out_rows, fill), pack_split(wf, out_rows, n_tiles_c)))
 
     @staticmethod
     def _decode(transform, v, n_params):

@@ -193,6 +193,8 @@ class FlowProposal:
         #: which loop the last ``populate`` ran: "trains" (device-side loop control), "trains_sharded",
         #: "accumulate" (device arena), "accumulate_host" or "passes" (one synchronisation per pass)
         self.last_populate_path = None
+        #: what the last sharded populate did: trains, passes, collectives (bench.py reports it for N > 1)
+        self.sharded_stats = None
         if precision not in ("auto", "f32", "bf16x3", "f16x3"):
             raise ValueError("precision must be 'auto', 'f32', 'bf16x3' or 'f16x3'")
         self.precision = precision
@@ -1068,6 +1070,65 @@ class FlowProposal:
     #: the stop test, so their rows wait for ONE exchange of the maxima and ONE of the counts)
     TRAIN_ARENA_BYTES = 4 << 30
 
+    # -- the three device steps of a train of sharded passes (overridden by the CPU emulation of
+    #    tests/test_distributed_gloo.py, which drives the loop below on 8 gloo ranks) ------------------------
+
+    def _sharded_setup(self, n, n_samples):
+        """Per-call device context of the sharded loop: prepared flow, buffers, rules, lean or not."""
+        prepared = self._prepare_flow()
+        buf = self._get_buffers(n, n_samples)
+        rules = self._device_rules()
+        lean = self._lean_ok(n, rules)
+        separable = self._prior_kind_dev is not None
+        return dict(prepared=prepared, buf=buf, rules=rules, lean=lean, separable=separable,
+                    log_prior_const=0.0 if separable else self._uniform_log_prior_constant(),
+                    key_init=int(lib.load().nsa_max_key_init()),
+                    stream=lib.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+
+    def _sharded_heads(self, ctx, n, train, off, stride, threshold, keys, state):
+        """K heads: pass i draws rows [off + i stride, + n), leaves its weights in the arena and its maximum in
+        ``keys[i]`` (``nsa_populate_train_heads`` / ``_lean``)."""
+        L = lib.load()
+        flow, header, image, status = ctx["prepared"]
+        buf, separable = ctx["buf"], ctx["separable"]
+        common = (header, lib.ptr(image), n, train, self.device_seed, off, stride, float(threshold),
+                  float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
+                  lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale))
+        rest = (lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev), lib.ptr(self._prior_par_dev),
+                lib.ptr(buf["log_p"] if separable else None), float(ctx["log_prior_const"]), lib.ptr(self._rp_kind_dev),
+                lib.ptr(self._rp_par_dev), lib.ptr(buf["log_w_many"]), lib.ptr(keys), lib.ptr(state), lib.ptr(status),
+                flow.waves_per_group, flow.max_groups, ctx["stream"], ctx["rules"])
+        if ctx["lean"]:
+            lib.check(L.nsa_populate_train_heads_lean(*common, *rest), "nsa_populate_train_heads_lean")
+        else:
+            lib.check(L.nsa_populate_train_heads(*common, lib.ptr(buf["x64_many"]), *rest), "nsa_populate_train_heads")
+
+    def _sharded_tails(self, ctx, n, train, off, stride, n_samples, keys, state, lcount):
+        """K accept + append steps against the GLOBAL maxima; ``lcount[i]`` = this rank's accepted rows of pass i
+        (``nsa_populate_train_tails`` / ``_lean``)."""
+        L = lib.load()
+        buf = ctx["buf"]
+        if ctx["lean"]:
+            rc = L.nsa_populate_train_tails_lean(
+                n, self.dims, train, lib.ptr(buf["log_w_many"]), lib.ptr(keys), self.device_seed, off, stride,
+                n_samples, lib.ptr(buf["idx_acc"]), lib.ptr(state), lib.ptr(buf["scratch"]), lib.ptr(lcount),
+                lib.ptr(buf["workspace"]), buf["ws_bytes"], ctx["stream"],
+            )
+            lib.check(rc, "nsa_populate_train_tails_lean")
+        else:
+            rc = L.nsa_populate_train_tails(
+                n, self.dims, train, lib.ptr(buf["log_w_many"]), lib.ptr(keys), self.device_seed, off, stride,
+                lib.ptr(buf["x64_many"]), n_samples, lib.ptr(buf["x_acc"]), lib.ptr(state), lib.ptr(buf["scratch"]),
+                lib.ptr(lcount), lib.ptr(buf["workspace"]), buf["ws_bytes"], ctx["stream"],
+            )
+            lib.check(rc, "nsa_populate_train_tails")
+
+    def _sharded_commit(self, ctx, train, n_samples, state, lcount, gcount, history):
+        """Walk the K passes in order against the real loop state with the GLOBAL counts (``nsa_populate_train_commit``)."""
+        rc = lib.load().nsa_populate_train_commit(lib.ptr(state), n_samples, train, lib.ptr(lcount), lib.ptr(gcount),
+                                                  lib.ptr(history), ctx["stream"])
+        lib.check(rc, "nsa_populate_train_commit")
+
     @torch.inference_mode(False)
     def _populate_trains_sharded(self, st, threshold, n_samples, max_samples, n, world, rank):
         """``_populate_trains`` for a draw batch sharded over ranks.  A pass needs two exchanges - the
@@ -1080,17 +1141,14 @@ class FlowProposal:
         locally and interleaved (pass, rank, draw order) once at the end - the order of a per-pass
         gather.  The train length is the number of passes the acceptance seen so far predicts,
         rounded down: a short train costs one more round of collectives, a long one whole draw
-        kernels."""
+        kernels.  ``self.sharded_stats`` keeps what the call did: trains, passes, collectives."""
         import torch.distributed as dist
 
-        L = lib.load()
         self.last_populate_path = "trains_sharded"
-        flow, header, image, status = self._prepare_flow()
-        buf = self._get_buffers(n, n_samples)
+        ctx = self._sharded_setup(n, n_samples)
+        buf, lean, separable = ctx["buf"], ctx["lean"], ctx["separable"]
         dev = self.device
-        rules = self._device_rules()
         # lean heads keep log_w alone: the arena of a train is 8 bytes per row instead of 8 (D + 1)
-        lean = self._lean_ok(n, rules)
         self.last_populate_lean = lean
         if lean and buf.get("idx_acc") is None:
             buf["idx_acc"] = torch.empty(n_samples, dtype=torch.int64, device=dev)
@@ -1098,7 +1156,7 @@ class FlowProposal:
         if buf.get("state") is None:
             buf["state"] = torch.zeros(8, dtype=torch.int64, device=dev)
             buf["max_keys"] = torch.empty(64, dtype=torch.int64, device=dev)
-            buf["state_host"] = torch.zeros(8, dtype=torch.int64).pin_memory()
+            buf["state_host"] = _pinned(torch.zeros(8, dtype=torch.int64))
         if buf.get("gcount") is None:
             buf["gcount"] = torch.zeros(64, dtype=torch.int64, device=dev)
             buf["lcount"] = torch.zeros(64, dtype=torch.int64, device=dev)
@@ -1109,13 +1167,10 @@ class FlowProposal:
         state_h[2] = n_samples
         state_h[5] = max_samples // (n * world) + 1
         state.copy_(state_h, non_blocking=True)
-        key_init = int(L.nsa_max_key_init())
-        separable = self._prior_kind_dev is not None
-        log_prior_const = 0.0 if separable else self._uniform_log_prior_constant()
-        stream = lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         per_pass = (self.population_acceptance or 0.0) * n * world
         n_accepted = passes = 0
         stride = n * world
+        stats = dict(trains=0, passes=0, all_reduce=0, all_gather=0, train_lengths=[])
         while True:
             remaining = n_samples - n_accepted
             train = 1 if per_pass <= 0 else int(remaining / per_pass)
@@ -1132,51 +1187,18 @@ class FlowProposal:
                 grown[: buf["history"].numel()] = buf["history"]
                 buf["history"] = grown
             keys, lcount, gcount = buf["max_keys"][:train], buf["lcount"][:train], buf["gcount"][:train]
-            keys.fill_(key_init)
+            keys.fill_(ctx["key_init"])
             off = int(self._draw_counter + rank * n + passes * stride)
-            if lean:
-                rc = L.nsa_populate_train_heads_lean(
-                    header, lib.ptr(image), n, train, self.device_seed, off, stride, float(threshold),
-                    float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
-                    lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
-                    lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev), lib.ptr(self._prior_par_dev),
-                    lib.ptr(buf["log_p"] if separable else None), float(log_prior_const), lib.ptr(self._rp_kind_dev),
-                    lib.ptr(self._rp_par_dev), lib.ptr(buf["log_w_many"]), lib.ptr(keys), lib.ptr(state),
-                    lib.ptr(status), flow.waves_per_group, flow.max_groups, stream, rules,
-                )
-                lib.check(rc, "nsa_populate_train_heads_lean")
-                dist.all_reduce(keys, op=dist.ReduceOp.MAX)
-                rc = L.nsa_populate_train_tails_lean(
-                    n, self.dims, train, lib.ptr(buf["log_w_many"]), lib.ptr(keys), self.device_seed, off, stride,
-                    n_samples, lib.ptr(buf["idx_acc"]), lib.ptr(state), lib.ptr(buf["scratch"]), lib.ptr(lcount),
-                    lib.ptr(buf["workspace"]), buf["ws_bytes"], stream,
-                )
-                lib.check(rc, "nsa_populate_train_tails_lean")
-            else:
-                rc = L.nsa_populate_train_heads(
-                    header, lib.ptr(image), n, train, self.device_seed, off, stride, float(threshold),
-                    float(self.latent_temperature or 1.0), lib.ptr(self._scale_dev), lib.ptr(self._shift_dev),
-                    lib.ptr(self._lower_dev), lib.ptr(self._upper_dev), float(self._log_j_rescale),
-                    lib.ptr(buf["x64_many"]), lib.ptr(buf["log_q"]), lib.ptr(self._prior_kind_dev),
-                    lib.ptr(self._prior_par_dev), lib.ptr(buf["log_p"] if separable else None),
-                    float(log_prior_const), lib.ptr(self._rp_kind_dev), lib.ptr(self._rp_par_dev),
-                    lib.ptr(buf["log_w_many"]), lib.ptr(keys), lib.ptr(state), lib.ptr(status), flow.waves_per_group,
-                    flow.max_groups, stream, rules,
-                )
-                lib.check(rc, "nsa_populate_train_heads")
-                dist.all_reduce(keys, op=dist.ReduceOp.MAX)
-                rc = L.nsa_populate_train_tails(
-                    n, self.dims, train, lib.ptr(buf["log_w_many"]), lib.ptr(keys), self.device_seed, off, stride,
-                    lib.ptr(buf["x64_many"]), n_samples, lib.ptr(buf["x_acc"]), lib.ptr(state), lib.ptr(buf["scratch"]),
-                    lib.ptr(lcount), lib.ptr(buf["workspace"]), buf["ws_bytes"], stream,
-                )
-                lib.check(rc, "nsa_populate_train_tails")
+            self._sharded_heads(ctx, n, train, off, stride, threshold, keys, state)
+            dist.all_reduce(keys, op=dist.ReduceOp.MAX)
+            self._sharded_tails(ctx, n, train, off, stride, n_samples, keys, state, lcount)
             gcount.copy_(lcount)
             dist.all_reduce(gcount, op=dist.ReduceOp.SUM)
-            rc = L.nsa_populate_train_commit(lib.ptr(state), n_samples, train, lib.ptr(lcount), lib.ptr(gcount),
-                                             lib.ptr(buf["history"]), stream)
-            lib.check(rc, "nsa_populate_train_commit")
+            self._sharded_commit(ctx, train, n_samples, state, lcount, gcount, buf["history"])
             state_h.copy_(state)  # the train's one synchronisation
+            stats["trains"] += 1
+            stats["all_reduce"] += 2
+            stats["train_lengths"].append(train)
             n_accepted, passes = int(state_h[0]), int(state_h[1])
             if n_accepted >= n_samples:
                 break
@@ -1186,9 +1208,12 @@ class FlowProposal:
             per_pass = n_accepted / passes if n_accepted else per_pass * 0.5
         n_proposed = passes * n * world
         self._draw_counter += n_proposed
+        stats["passes"] = passes
+        stats["all_gather"] = 2 if world > 1 else 0  # per-pass counts + accepted rows (_assemble_sharded_pool)
+        self.sharded_stats = stats
         if lean:  # this rank's accepted rows, computed again from their Philox rows
             self._replay(buf["idx_acc"], int(state_h[3]), threshold, buf["x_acc"], buf["log_q"],
-                         buf["log_p"] if separable else None, (flow, header, image, status))
+                         buf["log_p"] if separable else None, ctx["prepared"])
         accepted = self._assemble_sharded_pool(buf["history"][:passes], buf["x_acc"], n_samples, world)
         self.x = array_to_live_points_fast(np.ascontiguousarray(accepted), self.names)
         log_l = None
@@ -1549,6 +1574,11 @@ class FlowProposal:
         state["flow_config"] = None
         state["flow"] = None
         return state
+
+
+def _pinned(t):
+    """``t`` in page-locked memory where a device is present (a CPU-only process - the gloo tests - keeps it pageable)."""
+    return t.pin_memory() if torch.cuda.is_available() else t
 
 
 def _gather_accepted(x_acc, n_acc_dev, capacity, dims):

@@ -146,7 +146,10 @@ class Trainer:
             raise ValueError("the flow has no coupling layer")
         rec_len = max(len(r) for r in records)
         records = [r + [0] * (rec_len - len(r)) for r in records]
-        n_tr = pack.transform_policy(desc["transform"], desc.get("bins", 0))[2]
+        # parameters per transformed feature as the conditioner emits them (the inference kernels' generic spline
+        # instance pads them to 16 bins - pack.transform_policy - the training kernels take the flow's own count)
+        n_tr = (3 * int(desc.get("bins", 0)) - 1 if desc["transform"] == "rq"
+                else pack.transform_policy(desc["transform"], 0)[2])
         rec_words = len(records[0])
         header = [D, desc["hidden"], n_res, len(records), pack.TRANSFORMS[desc["transform"]],
                   desc.get("bins", 0) if desc["transform"] == "rq" else 0,

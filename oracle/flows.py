@@ -144,6 +144,13 @@ def create_linear_transform(linear_transform, features):
                 transforms.LULinear(features, identity_init=True, using_cache=True),
             ]
         )
+    elif linear_transform.lower() == "svd":
+        return transforms.CompositeTransform(
+            [
+                transforms.RandomPermutation(features=features),
+                transforms.SVDLinear(features, num_householder=10, identity_init=True),
+            ]
+        )
     raise ValueError(
         f"Unknown linear transform: {linear_transform}. "
         "Choose from: {permutation, lu, svd}."

@@ -6,7 +6,8 @@ and with which arguments:
 
 * ``CompositeTransform`` — ``src/nessai/flows/realnvp.py:211``, ``nsf.py:128``
 * ``RandomPermutation`` / ``LULinear(identity_init=True, using_cache=True)``
-  — ``src/nessai/flows/utils.py:305-315``
+  — ``src/nessai/flows/utils.py:305-315``; ``SVDLinear(num_householder=10, identity_init=True)`` with its
+  ``HouseholderSequence`` factors — ``flows/utils.py:316-323``
 * ``BatchNorm`` — ``realnvp.py:205-206``, ``nsf.py:121-122``; attribute names
   pinned by ``flows/utils.py:265-272``
 * ``AffineCouplingTransform`` / ``AdditiveCouplingTransform`` —
@@ -294,6 +295,97 @@ class LULinear(Linear):
 # --------------------------------------------------------------------------
 # Normalisation transforms
 # --------------------------------------------------------------------------
+
+
+class HouseholderSequence(Transform):
+    """A product of Householder reflections (published nflows, ``nflows/transforms/orthogonal.py``): a row vector x
+    goes to ``x (I - 2 q q^T / |q|^2)`` for each vector q in turn; the inverse applies them in reverse order.
+    Initialised to pairs of equal unit vectors, i.e. the identity."""
+
+    def __init__(self, features, num_transforms):
+        super().__init__()
+        self.features = features
+        self.num_transforms = num_transforms
+        qr = torch.eye(num_transforms // 2, features).repeat_interleave(2, dim=0)
+        if num_transforms % 2 != 0:  # odd number of transforms, including 1
+            qr = torch.cat((qr, torch.zeros(1, features)))
+            qr[-1, num_transforms // 2] = 1
+        self.q_vectors = nn.Parameter(qr)
+
+    @staticmethod
+    def _apply_transforms(inputs, q_vectors):
+        squared_norms = torch.sum(q_vectors ** 2, dim=-1)
+        outputs = inputs
+        for q_vector, squared_norm in zip(q_vectors, squared_norms):
+            temp = outputs @ q_vector  # inner product
+            temp = torch.outer(temp, (2.0 / squared_norm) * q_vector)
+            outputs = outputs - temp
+        return outputs, inputs.new_zeros(inputs.shape[0])
+
+    def forward(self, inputs, context=None):
+        return self._apply_transforms(inputs, self.q_vectors)
+
+    def inverse(self, inputs, context=None):
+        reverse_idx = torch.arange(self.num_transforms - 1, -1, -1)
+        return self._apply_transforms(inputs, self.q_vectors[reverse_idx])
+
+
+class SVDLinear(Linear):
+    """``W = U S V^T`` with Householder-sequence U, V^T and a positive diagonal (published nflows,
+    ``nflows/transforms/svd.py``; the reference: ``src/nessai/flows/utils.py:316-323``, 10 reflections each)."""
+
+    def __init__(self, features, num_householder, using_cache=False, identity_init=True, eps=1e-3):
+        super().__init__(features, using_cache)
+        assert num_householder % 2 == 0
+        self.eps = eps
+        self.orthogonal_1 = HouseholderSequence(features=features, num_transforms=num_householder)
+        self.unconstrained_diagonal = nn.Parameter(torch.zeros(features))
+        self.orthogonal_2 = HouseholderSequence(features=features, num_transforms=num_householder)
+        self.identity_init = identity_init
+        self._initialize()
+
+    @property
+    def diagonal(self):
+        return self.eps + F.softplus(self.unconstrained_diagonal)
+
+    @property
+    def log_diagonal(self):
+        return torch.log(self.diagonal)
+
+    def _initialize(self):
+        init.zeros_(self.bias)
+        if self.identity_init:
+            init.constant_(self.unconstrained_diagonal, np.log(np.exp(1 - self.eps) - 1))
+        else:
+            stdv = 1.0 / np.sqrt(self.features)
+            init.uniform_(self.unconstrained_diagonal, -stdv, stdv)
+
+    def forward_no_cache(self, inputs):
+        outputs, _ = self.orthogonal_2(inputs)
+        outputs = outputs * self.diagonal
+        outputs, _ = self.orthogonal_1(outputs)
+        outputs = outputs + self.bias
+        return outputs, self.logabsdet() * outputs.new_ones(outputs.shape[0])
+
+    def inverse_no_cache(self, inputs):
+        outputs = inputs - self.bias
+        outputs, _ = self.orthogonal_1.inverse(outputs)
+        outputs = outputs / self.diagonal
+        outputs, _ = self.orthogonal_2.inverse(outputs)
+        return outputs, -self.logabsdet() * outputs.new_ones(outputs.shape[0])
+
+    def weight(self):
+        weight, _ = self.orthogonal_2.inverse(torch.diag(self.diagonal))
+        weight, _ = self.orthogonal_1(weight.t())
+        return weight.t()
+
+    def weight_inverse(self):
+        weight_inv, _ = self.orthogonal_1(torch.diag(torch.reciprocal(self.diagonal)))
+        weight_inv, _ = self.orthogonal_2.inverse(weight_inv.t())
+        return weight_inv.t()
+
+    def logabsdet(self):
+        return torch.sum(self.log_diagonal)
 
 
 class BatchNorm(Transform):

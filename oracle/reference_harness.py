@@ -97,6 +97,7 @@ def install():
         "RandomPermutation",
         "ReversePermutation",
         "LULinear",
+        "SVDLinear",
         "BatchNorm",
         "ActNorm",
         "AffineCouplingTransform",
@@ -107,7 +108,6 @@ def install():
         "normalization",
     ):
         setattr(tmod, name, getattr(T, name))
-    tmod.SVDLinear = _unavailable("SVDLinear")
     tmod.Logit = _unavailable("Logit")
     nflows.transforms = tmod
 

@@ -274,10 +274,14 @@ class Emulator:
         x = torch.from_numpy(np.ascontiguousarray(x))
         if self.transform == P.T_RQ:
             K = self.bins
+            KK = P.kernel_bins(K)  # the generic instance: three groups of 16 slots, the flow's parameters first
             div = float(_f32(img[P.H_LOGIT_DIV]))
+            if KK != K:  # what the padded slots must hold for the kernel's arithmetic (csrc/nsa_device.h, NsaRQ<16, true>)
+                assert (params[:, K:KK] == P.PAD_LOGIT).all() and (params[:, KK + K : 2 * KK] == P.PAD_LOGIT).all()
+                assert (params[:, 2 * KK + K - 1] == _f32(img[P.H_EDGE_RAW])).all()
             uw = params[:, None, :K] / div
-            uh = params[:, None, K : 2 * K] / div
-            ud = params[:, None, 2 * K :]
+            uh = params[:, None, KK : KK + K] / div
+            ud = params[:, None, 2 * KK : 2 * KK + K - 1]
             y, ld = splines.unconstrained_rational_quadratic_spline(
                 x[:, None], uw, uh, ud, inverse=inverse, tails="linear",
                 tail_bound=float(_f32(img[P.H_TAIL_BOUND])),

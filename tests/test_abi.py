@@ -36,7 +36,8 @@ def test_version_and_instance_query():
     assert L.nsa_version() == pack.VERSION == 9
     assert L.nsa_flow_supported(2, 1, 8) == 1  # C3: H=64, RQ, 8 bins
     assert L.nsa_flow_supported(1, 2, 0) == 1  # C2: H=32, affine
-    assert L.nsa_flow_supported(2, 1, 7) == 0
+    assert L.nsa_flow_supported(2, 1, 7) == 1 and L.nsa_flow_generic_bins(2, 7) == 1  # the generic spline instance
+    assert L.nsa_flow_generic_bins(2, 8) == 0 and L.nsa_flow_supported(2, 1, 17) == 0
     assert L.nsa_flow_supported(9, 1, 8) == 0
 
 

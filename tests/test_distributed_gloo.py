@@ -158,3 +158,168 @@ def test_sharded_pool_is_assembled_in_pass_rank_draw_order(tmp_path):
     x_acc[: min(len(rows), POOL_N)] = torch.from_numpy(rows[:POOL_N])
     single = FlowProposal._assemble_sharded_pool(prop, torch.from_numpy(counts), x_acc, POOL_N, 1)
     assert np.array_equal(single, rows[:POOL_N])
+
+
+# ---- the train-of-passes loop of the sharded populate on 8 ranks -----------------------------------------------------
+# FlowProposal._populate_trains_sharded itself - train lengths from the acceptance seen so far, ONE all-reduce(max)
+# and ONE all-reduce(sum) per train, the commit's stop test on the GLOBAL counts, the per-rank row lists, the final
+# all-gathers and the (pass, rank, draw) interleave - driven by numpy restatements of the contracts of its three
+# device steps (include/nessai_amd.h: nsa_populate_train_heads_lean / _tails_lean / _commit, nsa_populate_replay).
+# What a GPU adds to this is the arithmetic of a row; what 8 ranks add is here.
+
+TRAIN_WORLD = 8
+TRAIN_DIMS = 3
+TRAIN_SEED = 23
+INT64_MAX = 0x7FFFFFFFFFFFFFFF
+
+
+def _row_weights(first_row, n):
+    """(log_w, log u) of the global rows [first_row, first_row + n): a stand-in for flow + prior whose acceptance
+    differs from one block of rows to the next, so that the ranks' per-pass counts are uneven."""
+    from oracle import philox
+
+    z = philox.latents(TRAIN_SEED, first_row, n, TRAIN_DIMS).astype(np.float64)
+    g = np.arange(first_row, first_row + n)
+    log_w = -0.5 * np.sum(z**2, axis=1) * (10.0 + 8.0 * ((g // 700) % 5))
+    log_w[(g % 97) == 0] = -np.inf  # dropped rows (outside the bounds / the radius)
+    return log_w, np.log(philox.uniforms(TRAIN_SEED, first_row, n)), z
+
+
+def _stopped(state):
+    return bool(state[0] >= state[2] or state[1] >= state[5])
+
+
+def _make_emulated(rank, world, n_local, acceptance):
+    from types import SimpleNamespace
+
+    from nessai_amd import lib
+    from nessai_amd.proposal import FlowProposal
+
+    L = lib.load()
+
+    class Emulated(FlowProposal):
+        def __init__(self):  # (no flow, no device: only what the sharded loop reads)
+            self.device = torch.device("cpu")
+            self.model = SimpleNamespace(names=[f"x{i}" for i in range(TRAIN_DIMS)])
+            self._reparam = SimpleNamespace(names=self.model.names, prime_names=self.model.names)
+            self.population_acceptance = acceptance
+            self._draw_counter = 0
+            self._ll_spec = None
+            self.shard = True
+            self.sharded_stats = None
+            self.result = None
+
+        dims = TRAIN_DIMS
+        names = property(lambda self: self.model.names)
+
+        def _sharded_setup(self, n, n_samples):
+            buf = dict(x_acc=torch.zeros((n_samples, TRAIN_DIMS), dtype=torch.float64), log_q=None, log_p=None)
+            return dict(prepared=None, buf=buf, rules=None, lean=True, separable=False, log_prior_const=0.0,
+                        key_init=int(L.nsa_max_key_init()), stream=None)
+
+        def _sharded_heads(self, ctx, n, train, off, stride, threshold, keys, state):
+            arena = ctx["buf"]["log_w_many"]
+            for i in range(train):
+                if _stopped(state):  # (the head kernels of a train that is already over return at once)
+                    continue
+                log_w, _, _ = _row_weights(off + i * stride, n)
+                arena[i] = torch.from_numpy(log_w)
+                keys[i] = int(L.nsa_max_key_encode(float(log_w.max())))
+
+        def _sharded_tails(self, ctx, n, train, off, stride, n_samples, keys, state, lcount):
+            buf = ctx["buf"]
+            scratch = buf["scratch"]
+            scratch[:] = torch.tensor([0, 0, INT64_MAX, int(state[3]), 0, INT64_MAX, 0, 0])  # nsa_train_scratch_kernel
+            for i in range(train):
+                first = off + i * stride
+                _, log_u, _ = _row_weights(first, n)
+                gmax = L.nsa_max_key_decode(int(keys[i]))
+                accept = (buf["log_w_many"][i].numpy() - gmax) > log_u
+                rows = first + np.nonzero(accept)[0]
+                written = int(scratch[3])
+                room = max(0, n_samples - written)
+                buf["idx_acc"][written: written + min(room, len(rows))] = torch.from_numpy(rows[:room])
+                scratch[4] = len(rows)
+                # nsa_pass_commit_kernel on the scratch state, history = lcount
+                lcount[int(scratch[1])] = len(rows)
+                scratch[0] += len(rows)
+                scratch[1] += 1
+                scratch[3] = min(written + len(rows), n_samples)
+
+        def _sharded_commit(self, ctx, train, n_samples, state, lcount, gcount, history):
+            for i in range(train):  # nsa_train_commit_kernel
+                if _stopped(state):
+                    return
+                got = int(lcount[i])
+                history[int(state[1])] = got
+                state[0] += int(gcount[i])
+                state[1] += 1
+                state[3] = min(int(state[3]) + got, n_samples)
+
+        def _replay(self, idx, m, radius, x64, log_q, log_prior, prepared):
+            for k in range(m):  # nsa_populate_replay: the row again from its global Philox row
+                x64[k] = torch.from_numpy(_row_weights(int(idx[k]), 1)[2][0])
+
+        def _finish_population(self, st, n_accepted, n_proposed, log_l=None, f16_flag=None):
+            self.result = (np.stack([self.x[n] for n in self.names], axis=1), int(n_accepted), int(n_proposed))
+            self.population_acceptance = n_accepted / n_proposed
+
+    return Emulated()
+
+
+def _trains_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_local, n_samples = 2500, 1500
+    # first call: the acceptance guess is twice the truth, so the first train undershoots and a SHORT second train
+    # follows; second call: the acceptance measured by the first
+    prop = _make_emulated(rank, world, n_local, acceptance=0.02)
+    outs = []
+    for call in range(2):
+        prop._populate_trains_sharded(None, np.inf, n_samples, 10**9, n_local, world, rank)
+        outs.append((prop.result, dict(prop.sharded_stats), prop._draw_counter))
+    # third call: the max_samples exit inside a train
+    prop._populate_trains_sharded(None, np.inf, 10**6, 9 * n_local * world, n_local, world, rank)
+    outs.append((prop.result, dict(prop.sharded_stats), prop._draw_counter))
+    np.save(os.path.join(out_dir, f"trains{rank}.npy"), np.array(outs, dtype=object), allow_pickle=True)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_trains_of_sharded_passes_on_eight_ranks_equal_the_one_rank_loop(tmp_path):
+    world, n_local = TRAIN_WORLD, 2500
+    mp.spawn(_trains_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    per_rank = [np.load(tmp_path / f"trains{r}.npy", allow_pickle=True) for r in range(world)]
+
+    # the reference loop: one pass at a time over the whole batch (flowproposal.py:431-518)
+    stride = n_local * world
+    counter = 0
+    for call, (n_samples, pass_limit) in enumerate([(1500, 10**9), (1500, 10**9), (10**6, 9 * stride // stride + 1)]):
+        pool, accepted, passes = [], 0, 0
+        uneven = []
+        while accepted < n_samples and passes < pass_limit:
+            log_w, log_u, z = _row_weights(counter + passes * stride, stride)
+            keep = (log_w - log_w.max()) > log_u
+            pool.append(z[keep])
+            uneven.append([int(keep[r * n_local:(r + 1) * n_local].sum()) for r in range(world)])
+            accepted += int(keep.sum())
+            passes += 1
+        counter += passes * stride
+        want = np.concatenate(pool)[:n_samples]
+        for r in range(world):
+            (x, n_acc, n_prop), stats, draw_counter = per_rank[r][call]
+            assert n_acc == accepted and n_prop == passes * stride and draw_counter == counter
+            assert np.array_equal(x, want)
+            assert stats["passes"] == passes and sum(stats["train_lengths"]) >= passes
+            assert stats["all_reduce"] == 2 * stats["trains"] and stats["all_gather"] == 2
+        stats = per_rank[0][call][1]
+        counts = np.array(uneven)
+        assert counts.min() < counts.max()  # the ranks' per-pass counts are uneven
+        if call == 0:
+            assert stats["trains"] >= 2 and stats["train_lengths"][-1] < stats["train_lengths"][0]  # a short final train
+        if call == 1:
+            assert stats["trains"] <= 3  # the measured acceptance sizes the train: 2-3 rounds of collectives
+        if call == 2:
+            assert passes == 10 and accepted < n_samples  # stopped by max_samples, mid-train

@@ -20,6 +20,9 @@ CASES = {
     "nsf_d4": (NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2), {}),
     "nsf_d7_k4": (NeuralSplineFlow, O.NeuralSplineFlow, (7, 20, 3, 1), dict(num_bins=4)),
     "nsf_c3": (NeuralSplineFlow, O.NeuralSplineFlow, (32, 64, 6, 2), {}),
+    # bin counts without a fused training kernel (any num_bins from 2 to 16: the per-item spline kernels)
+    "nsf_k5": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 2, 2), dict(num_bins=5)),
+    "nsf_k13_lu": (NeuralSplineFlow, O.NeuralSplineFlow, (5, 24, 2, 1), dict(num_bins=13, linear_transform="lu")),
     "nsf_d6_tanh": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 2, 2), dict(activation=torch.tanh)),
     "rnvp_perm": (RealNVP, O.RealNVP, (6, 16, 3, 2),
                   dict(linear_transform="permutation", batch_norm_between_layers=False)),

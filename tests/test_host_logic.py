@@ -264,8 +264,9 @@ def test_flow_factory_schema():
     assert isinstance(U.create_linear_transform("Permutation", 4), modules.RandomPermutation)
     lu = U.create_linear_transform("lu", 4)
     assert [type(t) for t in lu._transforms] == [modules.RandomPermutation, modules.LULinear]
-    with pytest.raises(NotImplementedError, match="svd"):
-        U.create_linear_transform("svd", 4)
+    svd = U.create_linear_transform("svd", 6)  # flows/utils.py:316-323: ten Householder reflections per factor
+    assert [type(t) for t in svd._transforms] == [modules.RandomPermutation, modules.SVDLinear]
+    assert svd._transforms[1].orthogonal_1.q_vectors.shape == (10, 6)
     with pytest.raises(ValueError, match="Unknown linear transform"):
         U.create_linear_transform("qr", 4)
     assert isinstance(U.create_pre_transform("batch_norm", 4), modules.BatchNorm)

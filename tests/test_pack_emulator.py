@@ -24,6 +24,11 @@ CONFIGS = {
     "rnvp_additive_actnorm": (O.RealNVP, (4, 8, 2, 2), dict(use_volume_preserving=True, linear_transform=None,
                                                             actnorm=True, batch_norm_between_layers=False)),
     "nsf_d32": (O.NeuralSplineFlow, (32, 64, 2, 2), {}),
+    # bin counts without an exact kernel instance: the generic one, parameters padded to 16 bins by the packer
+    "nsf_k5": (O.NeuralSplineFlow, (4, 8, 2, 2), dict(num_bins=5)),
+    "nsf_k2_d7": (O.NeuralSplineFlow, (7, 40, 2, 1), dict(num_bins=2)),
+    "nsf_k13_lu": (O.NeuralSplineFlow, (5, 16, 2, 2), dict(num_bins=13, linear_transform="lu")),
+    "rnvp_svd": (O.RealNVP, (6, 16, 2, 2), dict(linear_transform="svd")),
     # act norm -> permutation -> LU per block (the element-wise map is folded into the dense op BEHIND it in
     # the forward direction and into the one in FRONT of it in the inverse direction)
     "rnvp_actnorm_lu": (O.RealNVP, (5, 16, 3, 1), dict(actnorm=True, batch_norm_between_layers=False)),
@@ -171,13 +176,13 @@ def test_wide_conditioner_stages_are_split_along_k():
 
 def test_unsupported_configurations_fail_loudly():
     with pytest.raises(ValueError, match="No gfx950 kernel instance"):
-        NeuralSplineFlow(4, 8, 2, 2, num_bins=7)
+        NeuralSplineFlow(4, 8, 2, 2, num_bins=17)
+    NeuralSplineFlow(4, 8, 2, 2, num_bins=7)  # the generic spline instance
     with pytest.raises(ValueError):
         NeuralSplineFlow(4, 300, 2, 2)
     with pytest.raises(NotImplementedError):
         NeuralSplineFlow(4, 8, 2, 2, context_features=2)
-    with pytest.raises(NotImplementedError):
-        RealNVP(4, 8, 2, 2, linear_transform="svd")
+    RealNVP(6, 8, 2, 2, linear_transform="svd")  # eval-mode SVD-linear: the dense op (training it raises)
     with pytest.raises(ValueError, match="at least 2"):
         RealNVP(1, 8, 2, 2)
     with pytest.raises(RuntimeError, match="actnorm and batchnorm"):
