@@ -466,6 +466,15 @@ def main():
     f32_ms, _ = time_draw_kernel(prop, precision="f32", rows=rows_per_launch)
     f32_achieved = FLOPS_PER_ROW * rows_per_launch / (f32_ms * 1e-3) / 1e12
 
+    # N > 1: every rank's kernel time and what the sharded populate did (trains, passes, collectives), so that the
+    # first real multi-GPU run explains itself
+    kernel_ms_per_rank = [kernel_ms]
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, float(kernel_ms))
+        kernel_ms_per_rank = [float(v) for v in gathered]
+    sharded_stats = getattr(prop, "sharded_stats", None) if (world > 1 or force_shard) else None
+
     traffic, traffic_detail = (None, "skipped (--no-pmc or N > 1)")
     if rank == 0 and world == 1 and not args.no_pmc:
         traffic, traffic_detail = measure_traffic("2x2" if (geometry or {}).get("row_tiles_per_wave") == 2
@@ -501,6 +510,9 @@ def main():
                 "parallelism": f"draw batch sharded over {world} GPU(s)",
             },
             "proposed_rows_per_s": proposed / elapsed,
+            # the last sharded populate of the timed region: trains of passes (two all-reduces each), passes,
+            # all-gathers (per-pass counts + accepted rows) - FlowProposal.sharded_stats; null at N = 1
+            "sharded_populate": sharded_stats,
             "acceptance": accepted / proposed,
             "passes_per_step": proposed / batch / args.steps,
             "roofline": {
@@ -522,6 +534,7 @@ def main():
                 "kernel_ms_avg": kernel_ms,
                 "kernel_ms_min": kernel_ms_min,
                 # chosen by the library (big batches of the 16-bit modes: round-count estimate of nsa_big_batch_geometry, nsa_api.hip)
+                "kernel_ms_per_rank": kernel_ms_per_rank,
                 "launch_geometry": geometry,
                 "rows_per_launch": rows_per_launch,
                 "rows_per_launch_note": "the whole batch at N = 1; for N > 1 this rank's share of it (rank 0 times its own kernel)",

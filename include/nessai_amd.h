@@ -96,6 +96,16 @@ NSA_API int nsa_flow_run(const uint32_t* header, const void* image_dev, int dire
                  long long n, const float* x_in_dev, float* x_out_dev, float* ld_out_dev,
                  int* status_dev, int waves_per_group, int max_groups, void* stream);
 
+/* nsa_flow_run for a CONDITIONAL flow (context_features > 0: src/nessai/flows/nsf.py:85-95,
+ * flows/realnvp.py:136-146; NFlow.forward / inverse / log_prob with context=..., flows/base.py:209-245):
+ *   ctx_in_dev  [n][C] float32, the context row of every input row (C = header word NSA_H_CTX); it reaches
+ *               layer 0 of every coupling's conditioner behind the identity features and gates every residual
+ *               block, temps * sigmoid(Wc context + bc) (nflows ResidualNet)
+ * An unconditional image is refused here, a conditional one by nsa_flow_run. */
+NSA_API int nsa_flow_run_ctx(const uint32_t* header, const void* image_dev, int direction, int mode,
+                     long long n, const float* x_in_dev, const float* ctx_in_dev, float* x_out_dev,
+                     float* ld_out_dev, int* status_dev, int waves_per_group, int max_groups, void* stream);
+
 /* The same batch through n_flows flows of identical structure in ONE launch.
  *
  * Replaces the loop over flows of ImportanceFlowModel.log_prob_all
@@ -440,6 +450,15 @@ NSA_API int nsa_importance_mix(long long n, int n_flows, const float* log_prob_a
                                const double* weights_dev, double* log_q_all_dev, double* log_Q_dev,
                                void* stream);
 
+/* nsa_importance_mix for the rows of ONE draw batch, written as one record per row so that the host reads the
+ * batch back with a single copy (ImportanceFlowProposal.draw, proposal/importance.py:443-526: the first filter,
+ * the NaN check of compute_log_Q and the structured-array fill then run on that copy):
+ *   packed_dev [n][dims + n_flows + 3] float64 = { x (clipped to [0, 1] when clip != 0: importance.py:470-471),
+ *   log_q_all (n_flows + 1 columns), log_Q, log_j }; log_j is NaN for the rows nsa_importance_draw dropped. */
+NSA_API int nsa_importance_mix_packed(long long n, int n_flows, int dims, const float* log_prob_all_dev,
+                              const double* log_j_dev, const double* weights_dev, const double* x_unit_dev,
+                              int clip, double* packed_dev, void* stream);
+
 /* log_w = log_prior - log_q and its maximum.
  *
  * Replaces BaseFlowProposal.compute_weights (proposal/flowproposal/base.py:1069-1098)
@@ -528,6 +547,12 @@ NSA_API int nsa_log_likelihood(int kind, long long n, int D, const double* x64_d
  * out, in favour of float atomics, above 2^26 floats).
  */
 NSA_API size_t nsa_train_workspace_floats(const long long* plan, long long n);
+/* Conditional flows (plan[13] = context features C > 0; FlowModel.train(conditional=...),
+ * src/nessai/flowmodel/base.py:286-302, 404-436): the [n][C] float32 context rows of a batch are handed to
+ * every training entry point INSIDE the workspace, this many floats from its start - written by the caller
+ * before nsa_train_step / _step_dev / _eval / _forward (nsa_train_backward finds them where the forward pass
+ * left them). */
+NSA_API size_t nsa_train_context_offset(const long long* plan, long long n);
 NSA_API int nsa_train_step(const long long* plan, const int* tables_dev, const float* consts,
                            float* params_dev, float* grads_dev, float* adam_m_dev, float* adam_v_dev,
                            const float* x_dev, const float* weights_dev, long long n,

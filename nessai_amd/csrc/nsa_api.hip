@@ -278,7 +278,16 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     p.prio = -1;  // decided with the geometry below; NESSAI_AMD_PRIO=0|1|2 pins it (NsaLaunch::prio)
   }
   const int D = (int)h[NSA_H_D];
-  const int XS = (D + 2) | 1;  // row stride of the x tiles (nsa_flow_kernel.h)
+  const int C = (int)h[NSA_H_CTX];  // context features of a conditional flow
+  if (C < 0 || C > 256) return nsa_fail(NSA_E_IMAGE, "unsupported number of context features %d", C);
+  if ((C > 0) != (p.ctx_in != nullptr))
+    return nsa_fail(NSA_E_ARG, C > 0 ? "the flow is conditional: a context array is required (nsa_flow_run_ctx)"
+                                     : "the flow takes no context");
+  if (C > 0 && (n_flows != 1 || p.mode == NSA_MODE_POPULATE))
+    return nsa_fail(NSA_E_ARG, "conditional flows run through nsa_flow_run_ctx only");
+  // the extended-conditioner instances (context and / or batch norm within the residual blocks): staged, one tile per wave
+  p.ext = (C > 0 || h[NSA_H_BNW] != 0) ? 1 : 0;
+  const int XS = (D + 2 + C) | 1;  // row stride of the x tiles (nsa_flow_kernel.h)
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
 #ifdef NSA_TIMELINE
   {
@@ -299,6 +308,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   const size_t prog_bytes = (((size_t)2 * h[inv ? NSA_H_NSTAGES_INV : NSA_H_NSTAGES_FWD] +
                               (size_t)NSA_OP_WORDS * h[inv ? NSA_H_NOPS_INV : NSA_H_NOPS_FWD] + 3) & ~(size_t)3) * 4;
   // (NESSAI_AMD_OCC pins a STAGED geometry)
+  if (p.ext) force_occ = NSA_DEFAULT_OCC;  // extended conditioner: the staged one-tile geometry (nsa_flow_inst.hip)
   if (force_occ == 0 && h[NSA_H_HT] <= 2 && res_bytes > 0 && getenv("NESSAI_AMD_OCC") == nullptr) {
     const char* env = getenv("NESSAI_AMD_RESIDENT");
     int pin_occ = 0, pin_rt = 0;
@@ -364,6 +374,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   g_last_geometry[4] = 0;
   int occ = force_occ != 0 ? force_occ
                            : nsa_occupancy((int)h[NSA_H_HT], p.precision, n_tiles, n_flows, g_num_cus, waves_per_group);
+  if (p.ext && waves_per_group > 8) waves_per_group = 8;
   if (force_occ == 0 && occ == 3 && waves_per_group <= 0 && getenv("NESSAI_AMD_OCC") == nullptr)
     occ = nsa_tuned_occupancy(h, p, max_groups, stream, n_flows, nsa_big_batch_geometry(n_tiles * n_flows, g_num_cus));
   int rt = 1;  // row tiles per wave
@@ -454,6 +465,31 @@ extern "C" int nsa_flow_run(const uint32_t* header, const void* image_dev, int d
   p.mode = mode;
   p.n = n;
   p.x_in = x_in_dev;
+  p.x_out = x_out_dev;
+  p.ld_out = ld_out_dev;
+  p.status = status_dev;
+  return nsa_launch_flow(header, p, waves_per_group, max_groups, (hipStream_t)stream);
+}
+
+extern "C" int nsa_flow_run_ctx(const uint32_t* header, const void* image_dev, int direction, int mode,
+                                long long n, const float* x_in_dev, const float* ctx_in_dev, float* x_out_dev,
+                                float* ld_out_dev, int* status_dev, int waves_per_group, int max_groups, void* stream) {
+  if (image_dev == nullptr || x_in_dev == nullptr || ctx_in_dev == nullptr || status_dev == nullptr)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run_ctx: NULL image / input / context / status pointer");
+  if (direction != NSA_DIR_FORWARD && direction != NSA_DIR_INVERSE)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run_ctx: direction must be 0 or 1");
+  if (mode != NSA_MODE_APPLY && mode != NSA_MODE_LOGPROB)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run_ctx: mode must be 0 (apply) or 1 (log_prob)");
+  if (mode == NSA_MODE_LOGPROB && direction != NSA_DIR_FORWARD)
+    return nsa_fail(NSA_E_ARG, "nsa_flow_run_ctx: log_prob needs the forward direction");
+  NsaLaunch p;
+  memset(&p, 0, sizeof(p));
+  p.image = (const uint32_t*)image_dev;
+  p.direction = direction;
+  p.mode = mode;
+  p.n = n;
+  p.x_in = x_in_dev;
+  p.ctx_in = ctx_in_dev;
   p.x_out = x_out_dev;
   p.ld_out = ld_out_dev;
   p.status = status_dev;
@@ -618,6 +654,21 @@ extern "C" int nsa_importance_to_prime(long long n, int dims, const double* x_un
   if (!(eps >= 0.0 && eps < 0.5)) return nsa_fail(NSA_E_ARG, "nsa_importance_to_prime: eps must be in [0, 0.5)");
   hipError_t e = nsa_launch_importance_to_prime(n, dims, x_unit_dev, eps, x_prime_dev, log_j_dev, (hipStream_t)stream);
   if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "importance to-prime kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
+extern "C" hipError_t nsa_launch_importance_pack(long long, int, int, const float*, const double*, const double*,
+                                                 const double*, int, double*, hipStream_t);
+
+extern "C" int nsa_importance_mix_packed(long long n, int n_flows, int dims, const float* log_prob_all_dev,
+                                         const double* log_j_dev, const double* weights_dev, const double* x_unit_dev,
+                                         int clip, double* packed_dev, void* stream) {
+  if (n < 0 || n_flows < 0 || dims < 1 || log_j_dev == nullptr || weights_dev == nullptr || x_unit_dev == nullptr ||
+      packed_dev == nullptr || (n_flows > 0 && log_prob_all_dev == nullptr))
+    return nsa_fail(NSA_E_ARG, "nsa_importance_mix_packed: bad argument");
+  hipError_t e = nsa_launch_importance_pack(n, n_flows, dims, log_prob_all_dev, log_j_dev, weights_dev, x_unit_dev,
+                                            clip, packed_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "importance pack kernel: %s", hipGetErrorString(e));
   return NSA_OK;
 }
 

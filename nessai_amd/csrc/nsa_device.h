@@ -374,6 +374,7 @@ struct NsaRQ {
   __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
                                                const NsaTransformConsts& c, float& y, float& ld,
                                                bool& bad) {
+#pragma clang fp contract(off)
     const float B = c.tail_bound;
     float cw[K + 1], ch[K + 1], raw[K + 1];
     // (checked per axis, right behind its knots: the eight logits of an axis then stay live a few instructions
@@ -383,12 +384,24 @@ struct NsaRQ {
     knots<OFF, NV, true>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw, c.k_real);
     knots<OFF + K, NV, true>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch, c.k_real);
 #else
+    // A row's result must not depend on the rows that share its wave (the same rows come back bit for bit from any
+    // launch geometry and from nsa_populate_replay): the branch is taken by the wave, the repeat is KEPT per lane.
     const float sw = knots<OFF, NV, false>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw, c.k_real);
-    if (__builtin_expect(__any(!sum_in_range(sw)), 0))
-      knots<OFF, NV, true>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw, c.k_real);
+    const bool redo_w = !sum_in_range(sw);
+    if (__builtin_expect(__any(redo_w), 0)) {
+      float alt[K + 1];
+      knots<OFF, NV, true>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, alt, c.k_real);
+#pragma unroll
+      for (int i = 0; i <= K; ++i) cw[i] = redo_w ? alt[i] : cw[i];
+    }
     const float sh = knots<OFF + K, NV, false>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch, c.k_real);
-    if (__builtin_expect(__any(!sum_in_range(sh)), 0))
-      knots<OFF + K, NV, true>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch, c.k_real);
+    const bool redo_h = !sum_in_range(sh);
+    if (__builtin_expect(__any(redo_h), 0)) {
+      float alt[K + 1];
+      knots<OFF + K, NV, true>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, alt, c.k_real);
+#pragma unroll
+      for (int i = 0; i <= K; ++i) ch[i] = redo_h ? alt[i] : ch[i];
+    }
 #endif
     // derivative logits per knot; the boundary knots carry the logit of derivative 1
     raw[0] = c.edge_raw;
@@ -405,36 +418,40 @@ struct NsaRQ {
     // only the two derivatives that are used are evaluated
     const float in_d = c.min_d + nsa_softplus_fast(o[4]);
     const float in_d1 = c.min_d + nsa_softplus_fast(o[5]);
+    // Every multiply-add below is an explicit fmaf and nothing else is contracted (pragma at the top of the function):
+    // left to -ffp-contract=fast, ONE of the four copies of this code in the two-tiles instance (skewed / plain wave x
+    // first / second tile) fused the log-det differently from the others in round 5, and a quarter of the rows came
+    // back with a log q one ulp away from the other launch geometries' (test_launch_geometry_..._never_changes_the_result).
     const float in_w = in_cw1 - in_cw;
     const float in_h = in_ch1 - in_ch;
     const float inv_w = nsa_rcp(in_w);
     const float delta = in_h * inv_w;
-    const float curv = (in_d + in_d1) - 2.0f * delta;
+    const float curv = fmaf(-2.0f, delta, in_d + in_d1);
     float out, dnum, den;
     if constexpr (INV) {
       const float sh = xin - in_ch;
-      const float a = sh * curv + in_h * (delta - in_d);
-      const float b = in_h * in_d - sh * curv;
+      const float a = fmaf(sh, curv, in_h * (delta - in_d));
+      const float b = fmaf(-sh, curv, in_h * in_d);
       const float cc = -delta * sh;
-      const float disc = b * b - 4.0f * a * cc;
+      const float disc = fmaf(-4.0f * a, cc, b * b);
       bad = inside && !(disc >= 0.0f);
       const float root = (2.0f * cc) * nsa_rcp(-b - __builtin_amdgcn_sqrtf(disc));
-      out = root * in_w + in_cw;
+      out = fmaf(root, in_w, in_cw);
       const float tomt = root * (1.0f - root);
       const float omr = 1.0f - root;
-      den = delta + curv * tomt;
-      dnum = (delta * delta) * ((in_d1 * (root * root) + (2.0f * delta) * tomt) + in_d * (omr * omr));
+      den = fmaf(curv, tomt, delta);
+      dnum = (delta * delta) * fmaf(in_d, omr * omr, fmaf(in_d1, root * root, (2.0f * delta) * tomt));
     } else {
       bad = false;
       const float theta = (xin - in_cw) * inv_w;
       const float tomt = theta * (1.0f - theta);
       const float omt = 1.0f - theta;
-      den = delta + curv * tomt;
-      out = in_ch + (in_h * (delta * (theta * theta) + in_d * tomt)) * nsa_rcp(den);
-      dnum = (delta * delta) * ((in_d1 * (theta * theta) + (2.0f * delta) * tomt) + in_d * (omt * omt));
+      den = fmaf(curv, tomt, delta);
+      out = fmaf(in_h * fmaf(delta, theta * theta, in_d * tomt), nsa_rcp(den), in_ch);
+      dnum = (delta * delta) * fmaf(in_d, omt * omt, fmaf(in_d1, theta * theta, (2.0f * delta) * tomt));
     }
     // log(dnum) - 2 log(den) on the hardware log2
-    float lad = 0.6931471805599453f * (nsa_log2(dnum) - 2.0f * nsa_log2(den));
+    float lad = 0.6931471805599453f * fmaf(-2.0f, nsa_log2(den), nsa_log2(dnum));
     lad = INV ? -lad : lad;
     y = inside ? out : x;
     ld = inside ? lad : 0.0f;

@@ -72,10 +72,22 @@ static auto nsa_pick16(const NsaLaunch* p, bool inv) {
   return kern;
 }
 
+// conditional flows (context columns + gated residual blocks): the staged one-tile geometry, every precision
+template <int PREC>
+static auto nsa_pick_ctx(bool inv) {
+  return inv ? nsa_flow_kernel<NSA_HT, TP, true, PREC, 2, 1, false, true> : nsa_flow_kernel<NSA_HT, TP, false, PREC, 2, 1, false, true>;
+}
+
 extern "C" __attribute__((visibility("hidden"))) hipError_t NSA_LAUNCH_NAME(
     const NsaLaunch* p, unsigned grid, unsigned grid_y, unsigned block, size_t lds, hipStream_t stream) {
   const bool inv = p->direction == NSA_DIR_INVERSE;
   auto kern = nsa_pick<NSA_PREC_F32, 2, 1>(inv);
+  if (p->ext) {
+    if (p->resident || p->occupancy != 2 || p->row_tiles != 1) return hipErrorInvalidConfiguration;
+    kern = nsa_pick_ctx<NSA_PREC_F32>(inv);
+    if (p->precision == NSA_PREC_BF16X3) kern = nsa_pick_ctx<NSA_PREC_BF16X3>(inv);
+    else if (p->precision == NSA_PREC_F16X3) kern = nsa_pick_ctx<NSA_PREC_F16X3>(inv);
+  } else
 #if NSA_HT <= 2
   if (p->resident) {
     kern = nsa_pick_res<NSA_PREC_F32>(p, inv);

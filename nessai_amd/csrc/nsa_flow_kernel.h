@@ -158,6 +158,11 @@ struct NsaLaunch {
   // a row is a pure function of its Philox counter, so the accepted ones are computed AGAIN from their global
   // row indices: row_list[r] replaces row_offset + r as the counter of local row r (replay launch).
   const long long* row_list;
+  // conditional flows (NSA_H_CTX > 0): [n][C] float32 context rows, constant through the flow
+  // (NFlow.forward(x, context=...), src/nessai/flows/base.py:209-221)
+  const float* ctx_in;
+  // 1: the flow needs the extended-conditioner instances (NSA_H_CTX > 0 or NSA_H_BNW != 0; set by nsa_launch_flow)
+  int ext;
   // static wave priority (MI355X_MICROARCH.md, "static priority for the younger half"): 1 = the upper half of the
   // workgroup's waves runs at s_setprio 1 for the whole kernel (the default of the staged two-tiles geometry: nsa_api.hip),
   // 2 = the lower half, 0 = off; NESSAI_AMD_PRIO pins it
@@ -682,11 +687,21 @@ __device__ __forceinline__ void nsa_chunk_gemm([[maybe_unused]] PIPE& pipe, cons
 
 // one coupling layer (over the RT row tiles of the wave) ---------------------------
 
-template <int HT, class TP, bool INV, int PREC, int RT, bool SKEW = false, class PIPE>
+// sigmoid on the bare transcendental units (the gate of a conditional residual block)
+__device__ __forceinline__ float nsa_sigmoid_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
+// CTX: a conditional flow (nflows ResidualNet with context_features: src/nessai/flows/nsf.py:85-95,
+// realnvp.py:136-146) - layer 0 gathers the context columns of the x tile behind the identity features (its table
+// says so: nothing to do here), and every residual block ends in
+//   temps = glu(cat(temps, context_layer(context)))  =  temps * sigmoid(Wc context + bc)
+// one more gathered GEMM (stage "context gate", nsa_format.h) and a sigmoid per hidden value.
+template <int HT, class TP, bool INV, int PREC, int RT, bool SKEW = false, bool CTX = false, class PIPE>
 __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, float* const (&xrow)[RT],
                                              int dummy_col, int lane, int half, int act, int net,
                                              int n_layers, const NsaTransformConsts& tc,
-                                             float (&logdet)[RT], int (&n_bad)[RT]) {
+                                             float (&logdet)[RT], int (&n_bad)[RT], bool bn_within = false) {
   constexpr bool BF = (PREC != NSA_PREC_F32);  // split 16-bit operands (bf16 or f16 pairs)
   const int n_steps0 = __builtin_amdgcn_readfirstlane((int)op[1]);
   const int n_chunks = __builtin_amdgcn_readfirstlane((int)op[2]);
@@ -759,11 +774,29 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
     for (int l = 0; l < n_layers; ++l) {
       float tmp[RT][16 * HT];
 #pragma unroll
-      for (int t = 0; t < RT; ++t) {
+      for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int i = 0; i < 16 * HT; ++i) tmp[t][i] = h[t][i];
-        nsa_act_regs<16 * HT>(tmp[t], act);
+      if constexpr (CTX) {
+        if (bn_within) {
+          // batch_norm_within_layers, eval mode: the block's FIRST batch norm acts on the residual stream in front
+          // of the activation - a per-feature a h + c from a stage of its own ({a[32 HT], c[32 HT]}, the bias
+          // layout); the second one follows linear 0 and is folded into its weights and bias by the packer
+          const float* st = pipe.template begin<false>();
+          f32x16 sa[HT], sc[HT];
+          nsa_load_bias<HT>(st, half, sa);
+          nsa_load_bias<HT>(st + 32 * HT, half, sc);
+#pragma unroll
+          for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int ot = 0; ot < HT; ++ot)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) tmp[t][16 * ot + r] = fmaf(tmp[t][16 * ot + r], sa[ot][r], sc[ot][r]);
+          pipe.end();
+        }
       }
+#pragma unroll
+      for (int t = 0; t < RT; ++t) nsa_act_regs<16 * HT>(tmp[t], act);
       {
         f32x16 acc[RT][HT];
         hidden_layer(tmp, acc);
@@ -778,6 +811,34 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
       {
         f32x16 acc[RT][HT];
         hidden_layer(tmp, acc);
+        const int n_steps_c = CTX ? __builtin_amdgcn_readfirstlane((int)op[3]) : 0;
+        if (CTX && n_steps_c > 0) {
+          // the block's gate: g = Wc context + bc, gathered from the context columns of the x tile
+          static_assert(!(CTX && SKEW), "conditional flows run one tile per wave, unskewed");
+          pipe.end();
+          const float* st = pipe.template begin<false>();
+          const int* c_tab = (const int*)st;
+          const float* gbias = st + (BF ? 16 : 2) * n_steps_c;
+          const float* gw = gbias + 32 * HT;
+          f32x16 g[RT][HT];
+          nsa_load_bias<HT>(gbias, half, g[0]);
+#pragma unroll
+          for (int t = 1; t < RT; ++t)
+#pragma unroll
+            for (int ot = 0; ot < HT; ++ot) g[t][ot] = g[0][ot];
+          if constexpr (BF) nsa_dense_tile16<PREC, HT, false, RT>(gw, c_tab, nullptr, xrow, n_steps_c, lane, half, g, pipe.amax);
+          else nsa_dense_tile<HT, false, RT>(gw, c_tab, nullptr, xrow, n_steps_c, lane, half, g);
+          pipe.more();
+          pipe.template watch<PREC>(g);
+#pragma unroll
+          for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int ot = 0; ot < HT; ++ot)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                h[t][16 * ot + r] = fmaf(acc[t][ot][r], nsa_sigmoid_fast(g[t][ot][r]), h[t][16 * ot + r]);
+          pipe.end();
+        } else {
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -786,6 +847,7 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
             for (int r = 0; r < 16; ++r) h[t][16 * ot + r] = h[t][16 * ot + r] + acc[t][ot][r];
         NSA_TL(pipe, 4);
         pipe.template end_v<SKEW && (NSA_SKEW_MASK & 2) != 0>();
+        }
       }
     }
   } else {
@@ -980,8 +1042,12 @@ __device__ __forceinline__ float nsa_header_float(const uint32_t* img, int word)
 // tiles, and the wave always has RT independent accumulator chains and element-wise chains to issue from.
 // RES = weights resident in LDS (NsaResidentPipe): one workgroup per CU of up to 16 waves (OCC 4: <= 128
 // VGPRs), no barrier after the prologue.
-template <int HT, class TP, bool INV, int PREC, int OCC, int RT = 1, bool RES = false>
+// CTX = the extended conditioner: a conditional flow (context columns in the x tile, gated residual blocks:
+// nsa_coupling) and / or batch norm within the residual blocks (eval mode); built for the staged one-tile geometry at
+// 2 waves per SIMD only.  NsaLaunch::ext selects it.
+template <int HT, class TP, bool INV, int PREC, int OCC, int RT = 1, bool RES = false, bool CTX = false>
 __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC) nsa_flow_kernel(NsaLaunch p) {
+  static_assert(!CTX || (RT == 1 && !RES && OCC == 2), "conditional flows: staged, one tile per wave");
   // the staged two-tiles instances carry the skewed copy of the coupling code
   constexpr bool SK = RT == 2 && !RES;
   using PIPE = std::conditional_t<RES, NsaResidentPipe, NsaStagePipe>;
@@ -994,7 +1060,8 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   // writes of unused feature slots, D0 + 1 always holds 0.0 - the gather tables of layer 0 / the LU-linear op
   // point their unused entries at it (byte offsets: nsa_format.h), so a gathered operand is one add and
   // one read, without the clamp, the shift and the two selects a "-1 = nothing" entry cost per element
-  const int XS0 = (D0 + 2) | 1;
+  const int C0 = CTX ? (int)img[NSA_H_CTX] : 0;  // context features: columns D0 + 2 ... of the tile
+  const int XS0 = (D0 + 2 + C0) | 1;
   const int nw = (int)(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane0 = (int)(threadIdx.x & 63);
@@ -1142,7 +1209,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     // 64-bit masks, two scalar registers each, from the kernel's entry on)
     int D = D0;
     asm volatile("" : "+s"(D));
-    const int XS = (D + 2) | 1;
+    const int XS = (D + 2 + C0) | 1;
     float* xt_a[RT];
     float* xrow_a[RT];
 #pragma unroll
@@ -1204,6 +1271,14 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
       }
     }
 
+    if constexpr (CTX) {
+      // the row's context, constant through the flow
+      const long long cbase = row0 * C0, climit = a.n * (long long)C0;
+      for (int idx = nsa_opaque(lane); idx < NSA_ROWS * C0; idx += 64) {
+        const int r = idx / C0, c = idx - r * C0;
+        xt[r * XS + D + 2 + c] = (cbase + idx < climit) ? a.ctx_in[cbase + idx] : 0.0f;
+      }
+    }
     // ---- POPULATE prologue: latent norm, latent log-density, optional z out --
     if constexpr (RES) NSA_TL(pipe, 12);  // (timeline of the resident geometry: slot 12 = fill / latent draw)
     if (a.mode == NSA_MODE_POPULATE && !(NSA_ABLATE & 128)) {
@@ -1222,12 +1297,12 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
         for (int k = 0; k < nk; ++k) {
           const float z = xh[2 * k];
           r2 += (double)z * (double)z;
-          e += z * z;
+          e = fmaf(z, z, e);  // (explicit: the same sum in every kernel instance)
         }
         if ((D & 1) && half == 0) {
           const float z = xrow[D - 1];
           r2 += (double)z * (double)z;
-          e += z * z;
+          e = fmaf(z, z, e);  // (explicit: the same sum in every kernel instance)
         }
       } else
       for (int c = half; c < D; c += 2) {
@@ -1240,7 +1315,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
           zin = (float)((double)z / ls);
         }
         r2 += (double)z * (double)z;
-        e += zin * zin;
+        e = fmaf(zin, zin, e);
       }
       r2 += __shfl_xor(r2, 32);
       e += __shfl_xor(e, 32);
@@ -1281,7 +1356,8 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
           else
             nsa_coupling<HT, TP, INV, PREC, RT, false>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
         } else {
-          nsa_coupling<HT, TP, INV, PREC, RT, false>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
+          nsa_coupling<HT, TP, INV, PREC, RT, false, CTX>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a,
+                                                          CTX && img[NSA_H_BNW] != 0);
         }
       } else if (NSA_ABLATE & 512) {
         const int skip = kind == NSA_OP_DENSE ? __builtin_amdgcn_readfirstlane((int)op[2]) : 1;
@@ -1477,7 +1553,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
         for (int i = half_e; i < D; i += 2) {
           const float z = xrow[out_tab[i]];
           if constexpr (POISON) poison = fmaf(z, 0.0f, poison);
-          e += z * z;
+          e = fmaf(z, z, e);  // (explicit: the same sum in every kernel instance)
         }
         e += __shfl_xor(e, 32);
         const float lp = -(0.5f * nsa_header_float(img, NSA_H_BASE_INV_VAR)) * e - nsa_header_float(img, NSA_H_LOG_Z);

@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define NSA_MAGIC 0x3141534e /* "NSA1" */
-#define NSA_VERSION 9
+#define NSA_VERSION 10
 
 // header word indices
 enum {
@@ -54,6 +54,13 @@ enum {
                            // order from stage 0's offset on (the weights-resident geometry copies that range
                            // to LDS once per workgroup); 0 = not contiguous, staged geometries only
   NSA_H_RES_INV = 33,      // the same for the inverse program
+  NSA_H_CTX = 34,          // context features C of a conditional flow (0: none).  The context of a row lies in
+                           // columns D + 2 ... D + 1 + C of the x tile (row stride (D + 2 + C) | 1); layer 0 of
+                           // every coupling gathers it behind the identity features, every residual block gates
+                           // its output with sigmoid(Wc context + bc) (format 10)
+  NSA_H_BNW = 35,          // 1: batch norm within the residual blocks (ResidualNet use_batch_norm, eval mode): every
+                           // block starts with a stage {a[32 HT], c[32 HT]} - temps = act(a h + c) - and its second
+                           // batch norm is folded into linear 0 by the packer
   NSA_H_WORDS = 40
 };
 
@@ -72,7 +79,7 @@ enum { NSA_OP_COUPLING = 1, NSA_OP_DENSE = 2, NSA_OP_ELEMENTWISE = 3 };
 enum { NSA_PREC_F32 = 0, NSA_PREC_BF16X3 = 1, NSA_PREC_F16X3 = 2 };
 
 // op record: 4 words
-//   COUPLING    {kind, n_steps0 (multiple of 4), n_chunks, 0}
+//   COUPLING    {kind, n_steps0 (multiple of 4), n_chunks, n_steps of the context gate (0: unconditional)}
 //   DENSE       {kind, n_steps  (multiple of 4), n_out_tiles, logdet (float bits)}
 //   ELEMENTWISE {kind, 0, 0, logdet (float bits)}
 #define NSA_OP_WORDS 4
@@ -83,6 +90,9 @@ enum { NSA_PREC_F32 = 0, NSA_PREC_BF16X3 = 1, NSA_PREC_F16X3 = 2 };
 // behind the last one - and over the stage's end in an LDS buffer that is sized in whole pieces):
 //   coupling layer 0 : id_tab[2*n_steps0] | bias[32*HT] | W[HT][n_steps0/4][64][4]
 //   hidden layer     : bias[32*HT]        | W[HT][4*HT/KS][64][4]      (sub-stage 0 of KS; the others: W only)
+//   context gate     : ctx_tab[2*n_steps_c] | bias[32*HT] | W[HT][n_steps_c/4][64][4]   (conditional flows: one stage
+//                      behind the second layer of every residual block, laid out like layer 0; its table holds
+//                      the byte offsets of the context columns)
 //   final chunk      : tr_tab[pad4(2*FPC)] | bias[32*C] | W[C][4*HT/KS][64][4]   (likewise)
 //   KS = nsa_ksplit(output tiles, HT): a GEMM whose packed weights exceed 16 KiB is dealt to 2 or 4
 //   consecutive stages along k (its accumulators live across them).

@@ -832,6 +832,55 @@ __global__ void __launch_bounds__(256) nsa_importance_mix_kernel(long long n, in
   log_Q[r] = log(s) + a_max;
 }
 
+// The same mix, written as ONE record per drawn row for a single read-back by the host
+// (ImportanceFlowProposal.draw, src/nessai/proposal/importance.py:443-526):
+//   packed[r] = { x[r][0 .. D) (clipped to [0, 1] when `clip`), log_q_all[r][0 .. P), log_Q[r], log_j[r] }
+// (row stride D + P + 2 doubles; log_j is NaN for the rows the reference's first filter drops: the host keeps
+// the others).  Replaces the mix kernel, the clamp and three strided copies of the draw's device epilogue.
+__global__ void __launch_bounds__(256) nsa_importance_pack_kernel(long long n, int n_flows, int D,
+                                                                  const float* __restrict__ log_prob_all,
+                                                                  const double* __restrict__ log_j,
+                                                                  const double* __restrict__ weights,
+                                                                  const double* __restrict__ x64, int clip,
+                                                                  double* __restrict__ packed) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int P = n_flows + 1;
+  double* rec = packed + r * (D + P + 2);
+  const double* xr = x64 + r * D;
+  for (int i = 0; i < D; ++i) {
+    double v = xr[i];
+    if (clip) v = fmin(fmax(v, 0.0), 1.0);  // (numpy.clip: NaN stays NaN)
+    rec[i] = v;
+  }
+  double* row = rec + D;
+  const double lj = log_j[r];
+  const double ninf = -__builtin_huge_val();
+  double a_max = (weights[0] == 0.0) ? ninf : 0.0;
+  row[0] = 0.0;
+  for (int j = 0; j < n_flows; ++j) {
+    const double a = (double)log_prob_all[(long long)j * n + r] + lj;
+    row[1 + j] = a;
+    const double am = (weights[1 + j] == 0.0) ? ninf : a;
+    a_max = (am > a_max || am != am) ? am : a_max;
+  }
+  if (!((a_max - a_max) == 0.0)) a_max = 0.0;
+  double s = 0.0;
+  for (int k = 0; k < P; ++k)
+    if (weights[k] != 0.0) s += weights[k] * exp(row[k] - a_max);
+  row[P] = log(s) + a_max;
+  row[P + 1] = lj;
+}
+
+extern "C" hipError_t nsa_launch_importance_pack(long long n, int n_flows, int D, const float* log_prob_all,
+                                                 const double* log_j, const double* weights, const double* x64,
+                                                 int clip, double* packed, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  nsa_importance_pack_kernel<<<grid, 256, 0, stream>>>(n, n_flows, D, log_prob_all, log_j, weights, x64, clip, packed);
+  return hipGetLastError();
+}
+
 // Unit hypercube -> x' of the importance sampler, one thread per row (proposal/importance.py:219-245,
 // utils/rescaling.py:290-313): xc = clip(x, eps, 1 - eps), x' = log(xc) - log1p(-xc) (float32 out: what
 // the flows read), log|J| = sum_i (-log(xc_i) - log1p(-xc_i)) in float64, summed in numpy's order for a

@@ -1183,6 +1183,47 @@ __global__ void tr_prepare(long long n_x, const float* __restrict__ x, float* __
 }
 
 // ---------------------------------------------------------------------------
+// conditional flows (layer-wise path): the four element-wise steps around the GEMMs
+// ---------------------------------------------------------------------------
+
+// xc[row] = {x[row][id_cols[0 .. d_id)], ctx[row][0 .. C)}: the input of a conditional coupling's initial layer
+__global__ void tr_concat_ctx(int n, int d_id, int C, const float* __restrict__ X, int ldx,
+                              const int* __restrict__ id_cols, const float* __restrict__ ctx,
+                              float* __restrict__ xc) {
+  const int W = d_id + C;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * W) return;
+  const int row = (int)(t / W), i = (int)(t - (long long)row * W);
+  xc[t] = i < d_id ? X[(long long)row * ldx + id_cols[i]] : ctx[(long long)row * C + (i - d_id)];
+}
+
+// h_next = h + t * sigmoid(g)   (glu(cat(temps, context_layer(context))) of a residual block)
+__global__ void tr_gate_forward(long long m, const float* __restrict__ h, const float* __restrict__ t,
+                                const float* __restrict__ g, float* __restrict__ h_next) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  h_next[i] = h[i] + t[i] * (1.0f / (1.0f + expf(-g[i])));
+}
+
+// in place: t <- dL/dt = gh * sigmoid(g);  g <- dL/dg = gh * t * sigmoid(g) (1 - sigmoid(g))
+__global__ void tr_gate_backward(long long m, const float* __restrict__ gh, float* __restrict__ t, float* __restrict__ g) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const float sg = 1.0f / (1.0f + expf(-g[i]));
+  const float up = gh[i], tv = t[i];
+  t[i] = up * sg;
+  g[i] = up * tv * sg * (1.0f - sg);
+}
+
+// Gx[row][id_cols[i]] += G[row][i] for i < d_id (the context columns of G carry no gradient anyone needs)
+__global__ void tr_scatter_add(int n, int d_id, const float* __restrict__ G, int ldg, float* __restrict__ Gx, int ldx,
+                               const int* __restrict__ id_cols) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * d_id) return;
+  const int row = (int)(t / d_id), i = (int)(t - (long long)row * d_id);
+  Gx[(long long)row * ldx + id_cols[i]] += G[(long long)row * ldg + i];
+}
+
 // host orchestration
 // ---------------------------------------------------------------------------
 
@@ -1194,15 +1235,20 @@ __global__ void tr_prepare(long long n_x, const float* __restrict__ x, float* __
 //        1 plain MLP {W_in, b_in, {W_h, b_h} x L, W_out, b_out} (src/nessai/flows/nets.py:12-126)
 //   [12] offset (int32 device table) of the final column table: logical output i of the flow is
 //        physical column table[i] of the batch (permutations never move data)
+//   [13] context features C of a conditional flow (0: none).  The context rows of the batch, [n][C] float32, are
+//        handed over INSIDE the workspace, at nsa_train_context_offset(plan, n) floats from its start (the entry
+//        points keep their signatures); W0 then takes d_id + C inputs - identity features first - and every
+//        residual block is gated, h + (W2 act(u) + b2) * sigmoid(Wc context + bc)  (nflows ResidualNet:
+//        src/nessai/flows/nsf.py:85-95, flows/realnvp.py:136-146); such a flow trains on the layer-wise kernels
 //   coupling  : {1, d_id, d_tr, id_cols offset, tr_cols offset (int32 device table),
-//                flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf}
+//                flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf[, {Wc, bc} x L of a conditional flow]}
 //   batch norm: {2, cols offset, off unconstrained_weight, off bias, off running_mean,
 //                off running_var, eps (float bits), momentum (float bits)}
 //   LU linear : {3, cols offset, off lower_entries, off upper_entries, off unconstrained_upper_diag,
 //                off bias, eps (float bits)}
 //   act norm  : {4, cols offset, off log_scale, off shift, 1 if the data-dependent initialisation is
 //                still due (the host clears it after the first training step)}
-#define TR_HDR 13
+#define TR_HDR 14
 enum { TR_COUPLING = 1, TR_BATCHNORM = 2, TR_LU = 3, TR_ACTNORM = 4 };
 
 static inline float tr_bits(long long v) {
@@ -1222,6 +1268,8 @@ struct TrWs {  // workspace carve (floats)
   float* layer_base;
   long long per_layer;
   long long xsave_words;  // n * max(d_tr): size of a coupling layer's saved-input block
+  float* ctx;             // [n][C] context rows of a conditional flow (written by the caller), or null
+  long long np_words;     // al4(n * np_max): size of a coupling layer's parameter block
 };
 
 // every block of the workspace starts on a 16-byte boundary (the fused kernels copy tiles with 16-byte pieces)
@@ -1236,7 +1284,9 @@ static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, lo
     if (r[0] == TR_COUPLING && r[2] > d_tr_max) d_tr_max = r[2];
   }
   np_max = d_tr_max * plan[7];
-  const long long coupling = al4(n * d_tr_max) + (2 * L + 1) * al4(n * H) + n * np_max;
+  long long coupling = al4(n * d_tr_max) + (2 * L + 1) * al4(n * H) + al4(n * np_max);
+  if (plan[13] > 0)  // conditional: t[L], g[L] behind the parameters, then xc and its gradient [n][D + C]
+    coupling += 2 * L * al4(n * H) + 2 * al4(n * (D + plan[13]));
   const long long linear = 3 * n * D + 4 * D * D + 8 * D;  // x, t, gt | L, U, gL, gU | small vectors
   per_layer = al4(coupling > linear ? coupling : linear);
 }
@@ -1255,7 +1305,12 @@ extern "C" NSA_API size_t nsa_train_workspace_floats(const long long* plan, long
   tr_sizes(plan, n, d_tr_max, np_max, per_layer);
   const long long D = plan[0], H = plan[1], NL = plan[3];
   return (size_t)(TR_SCAL_WORDS + 2 * al4(n * D) + 2 * al4(n) + al4(n * np_max) + 2 * al4(n * H) + NL * per_layer + al4(plan[8]) +
-                  tr_slab_floats(plan, n));
+                  tr_slab_floats(plan, n) + al4(n * plan[13]));
+}
+
+// where the caller puts the [n][C] context rows of a conditional flow's batch: floats from the workspace's start
+extern "C" NSA_API size_t nsa_train_context_offset(const long long* plan, long long n) {
+  return nsa_train_workspace_floats(plan, n) - (size_t)al4(n * plan[13]);
 }
 
 static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
@@ -1274,8 +1329,11 @@ static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
   w.layer_base = p; p += plan[3] * per_layer;
   w.wt = p; p += al4(plan[8]);
   w.slab = tr_slab_floats(plan, n) > 0 ? p : nullptr;
+  p += tr_slab_floats(plan, n);
+  w.ctx = plan[13] > 0 ? p : nullptr;
   w.per_layer = per_layer;
   w.xsave_words = al4(n * d_tr_max);
+  w.np_words = al4(n * np_max);
 }
 
 static inline dim3 tiles(long long rows, long long cols) {
@@ -1307,7 +1365,8 @@ static bool tr_use_fused(const long long* plan) {
   const bool enabled = !(e != nullptr && e[0] == '0');
   // (a spline with a bin count other than 4 / 8 / 10 / 16 trains on the layer-wise kernels)
   const bool exact_bins = plan[4] != NSA_T_RQ || plan[5] == 4 || plan[5] == 8 || plan[5] == 10 || plan[5] == 16;
-  return enabled && exact_bins && plan[11] == NSA_NET_RESNET && plan[1] <= 128 && plan[2] <= TRF_MAX_L;  // H <= 128: <= 8 gh tiles
+  return enabled && exact_bins && plan[13] == 0 && plan[11] == NSA_NET_RESNET && plan[1] <= 128 &&
+         plan[2] <= TRF_MAX_L;  // H <= 128: <= 8 gh tiles; conditional flows: the layer-wise kernels
 }
 
 static void tr_prepare_pass(const long long* plan, const int* tables_dev, const float* params_dev, float* grads_dev,
@@ -1574,9 +1633,39 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
         (void)tr_fused_coupling(false, transform, K, a, s);
         continue;
       }
+      const int C = (int)plan[13];
+      if (C > 0) {
+        // conditional residual net: h0 = W0 cat(x_id, ctx) + b0;  h_{l+1} = h_l + (W2 act(u_l) + b2) * sigmoid(Wc ctx + bc)
+        float* tb = p + w.np_words;                       // t[L][n*H]: W2 act(u) + b2, then its gradient
+        float* gb = tb + (long long)L * al4(n * H);       // g[L][n*H]: Wc ctx + bc, then its gradient
+        float* xc = gb + (long long)L * al4(n * H);       // [n][d_id + C]
+        const int W = d_id + C;
+        hipLaunchKernelGGL(tr_concat_ctx, blocks_for(n * W), dim3(256), 0, s, (int)n, d_id, C, w.x, D, id_cols, w.ctx, xc);
+        hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, W, H, xc, W, (const int*)nullptr, ACT_NONE,
+                           params + off[0], params + off[1], (const float*)nullptr, h, H);
+        for (int l = 0; l < L; ++l) {
+          float* hl = h + (long long)l * n * H;
+          float* ul = u + (long long)l * n * H;
+          float* tl = tb + (long long)l * al4(n * H);
+          float* gl = gb + (long long)l * al4(n * H);
+          hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, hl, H, (const int*)nullptr,
+                             act, params + off[2 + 4 * l], params + off[3 + 4 * l], (const float*)nullptr, ul, H);
+          hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, ul, H, (const int*)nullptr,
+                             act, params + off[4 + 4 * l], params + off[5 + 4 * l], (const float*)nullptr, tl, H);
+          hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, C, H, w.ctx, C, (const int*)nullptr,
+                             ACT_NONE, params + off[4 + 4 * L + 2 * l], params + off[5 + 4 * L + 2 * l],
+                             (const float*)nullptr, gl, H);
+          hipLaunchKernelGGL(tr_gate_forward, blocks_for(n * H), dim3(256), 0, s, n * H, hl, tl, gl, hl + (long long)n * H);
+        }
+        float* hL = h + (long long)L * n * H;
+        hipLaunchKernelGGL(tr_gemm_nt, tiles(n, np), dim3(64), 0, s, (int)n, H, np, hL, H, (const int*)nullptr,
+                           ACT_NONE, params + off[2 + 4 * L], params + off[3 + 4 * L], (const float*)nullptr, p, np);
+      } else {
       hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, d_id, H, w.x, D, id_cols, ACT_NONE,
                          params + off[0], params + off[1], (const float*)nullptr, h, H);
-      if (plan[11] == NSA_NET_MLP) {
+      }
+      if (C > 0) {
+      } else if (plan[11] == NSA_NET_MLP) {
         // z_0 = W_in x_id + b_in;  z_{l+1} = W_h act(z_l) + b_h;  parameters = W_out act(z_L) + b_out
         for (int l = 0; l < L; ++l)
           hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, h + (long long)l * n * H, H,
@@ -1764,6 +1853,38 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, np, H, w.gp, np,
                          params + off[2 + 4 * L], (const float*)nullptr, 0, ACT_NONE, w.gh, H,
                          (const int*)nullptr, 0);
+      const int C = (int)plan[13];
+      if (C > 0) {  // conditional residual net (see tr_forward)
+        float* tb = p + w.np_words;
+        float* gb = tb + (long long)L * al4(n * H);
+        float* xc = gb + (long long)L * al4(n * H);
+        const int W = d_id + C;
+        float* gxc = xc + al4(n * (D + C));
+        for (int l = L - 1; l >= 0; --l) {
+          float* hl = h + (long long)l * n * H;
+          float* ul = u + (long long)l * n * H;
+          float* tl = tb + (long long)l * al4(n * H);
+          float* gl = gb + (long long)l * al4(n * H);
+          // the gate: tl <- dL/dt, gl <- dL/dg (w.gh = dL/dh_{l+1}, which is also the gradient of the skip path)
+          hipLaunchKernelGGL(tr_gate_backward, blocks_for(n * H), dim3(256), 0, s, n * H, w.gh, tl, gl);
+          hipLaunchKernelGGL(tr_gemm_tn, tiles(H, C), dim3(256), 0, s, (int)n, H, C, gl, H, w.ctx, C,
+                             (const int*)nullptr, ACT_NONE, grads + off[4 + 4 * L + 2 * l], grads + off[5 + 4 * L + 2 * l]);
+          hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, tl, H, ul, H,
+                             (const int*)nullptr, act, grads + off[4 + 4 * l], grads + off[5 + 4 * l]);
+          hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, tl, H,
+                             params + off[4 + 4 * l], ul, H, act, w.gu, H, (const int*)nullptr, 0);
+          hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, w.gu, H, hl, H,
+                             (const int*)nullptr, act, grads + off[2 + 4 * l], grads + off[3 + 4 * l]);
+          hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gu, H,
+                             params + off[2 + 4 * l], hl, H, act, w.gh, H, (const int*)nullptr, 1);
+        }
+        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, W), dim3(256), 0, s, (int)n, H, W, w.gh, H, xc, W, (const int*)nullptr,
+                           ACT_NONE, grads + off[0], grads + off[1]);
+        hipLaunchKernelGGL(tr_gemm_nn, tiles(n, W), dim3(64), 0, s, (int)n, H, W, w.gh, H, params + off[0],
+                           (const float*)nullptr, 0, ACT_NONE, gxc, W, (const int*)nullptr, 0);
+        hipLaunchKernelGGL(tr_scatter_add, blocks_for(n * d_id), dim3(256), 0, s, (int)n, d_id, gxc, W, w.gx, D, id_cols);
+        continue;
+      }
       for (int l = L - 1; l >= 0; --l) {
         float* hl = h + (long long)l * n * H;
         float* ul = u + (long long)l * n * H;

@@ -139,64 +139,78 @@ class FlowModel:
     def _to_numpy(t):
         return t.detach().cpu().numpy().astype(np.float64)
 
-    def forward_and_log_prob(self, x):
+    def _context(self, conditional):
+        """``conditional`` (numpy, one row per sample) -> the flow's ``context`` tensor, ``None`` passed through."""
+        return None if conditional is None else self.numpy_array_to_tensor(conditional)
+
+    def forward_and_log_prob(self, x, conditional=None):
         """x' -> (z, log_prob) (``base.py:782-811``)."""
         eval_mode(self.model)
         with torch.inference_mode():
-            z, log_prob = self.model.forward_and_log_prob(self.numpy_array_to_tensor(x))
+            z, log_prob = self.model.forward_and_log_prob(self.numpy_array_to_tensor(x),
+                                                          context=self._context(conditional))
         return self._to_numpy(z), self._to_numpy(log_prob)
 
-    def inverse(self, z):
+    def inverse(self, z, conditional=None):
         """z -> (x', log|det J|) (``base.py:813-840``)."""
         eval_mode(self.model)
         with torch.inference_mode():
-            x, log_j = self.model.inverse(self.numpy_array_to_tensor(z))
+            x, log_j = self.model.inverse(self.numpy_array_to_tensor(z), context=self._context(conditional))
         return self._to_numpy(x), self._to_numpy(log_j)
 
-    def log_prob(self, x):
+    def log_prob(self, x, conditional=None):
         """(``base.py:842-864``)."""
         eval_mode(self.model)
         with torch.inference_mode():
-            return self._to_numpy(self.model.log_prob(self.numpy_array_to_tensor(x)))
+            return self._to_numpy(self.model.log_prob(self.numpy_array_to_tensor(x), context=self._context(conditional)))
 
-    def sample(self, n=1):
+    def sample(self, n=1, conditional=None):
         """(``base.py:866-887``)."""
         eval_mode(self.model)
         with torch.inference_mode():
-            return self._to_numpy(self.model.sample(int(n)))
+            return self._to_numpy(self.model.sample(int(n), context=self._context(conditional)))
 
     def sample_latent_distribution(self, n=1):
         """(``base.py:889-904``)."""
         return self._to_numpy(self.model.sample_latent_distribution(int(n)))
 
-    def sample_and_log_prob(self, N=1, z=None):
+    def sample_and_log_prob(self, N=1, z=None, conditional=None):
         """(``base.py:906-948``)."""
         if self.model is None:
             raise RuntimeError("Model is not initialised yet!")
         eval_mode(self.model)
+        context = self._context(conditional)
         with torch.inference_mode():
             if z is None:
-                x, log_prob = self.model.sample_and_log_prob(int(N))
+                x, log_prob = self.model.sample_and_log_prob(int(N), context=context)
             else:
                 if isinstance(z, np.ndarray):
                     z = self.numpy_array_to_tensor(z)
                 log_prob = self.model.base_distribution_log_prob(z)
-                x, log_J = self.model.inverse(z)
+                x, log_J = self.model.inverse(z, context=context)
                 log_prob = log_prob - log_J
         return self._to_numpy(x), self._to_numpy(log_prob)
 
     # -- training --------------------------------------------------------------
 
-    def prep_data(self, samples, val_size, batch_size, weights=None):
+    def prep_data(self, samples, val_size, batch_size, weights=None, conditional=None):
         """Shuffle, split train/validation, fix the batch size (``base.py:238-352``).
 
-        With ``weights`` returns ``((x_train, w_train), (x_val, w_val), batch_size)``."""
+        With ``weights`` returns ``((x_train, w_train), (x_val, w_val), batch_size)``, with ``conditional``
+        (one row of context per sample) ``((x_train, c_train), (x_val, c_val), batch_size)``."""
         if not self.initialised:
             self.initialise()
         if not np.isfinite(samples).all():
             raise ValueError("Cannot train with non-finite samples!")
+        if weights is not None and conditional is not None:
+            raise RuntimeError("weights and conditional inputs not supported")
         idx = self.rng.permutation(samples.shape[0])
         samples = samples[idx]
+        if conditional is not None:
+            conditional = np.asarray(conditional, dtype=np.float64)
+            if conditional.ndim == 1:
+                conditional = conditional[:, None]
+            conditional = conditional[idx]
         if weights is not None:
             if not np.isfinite(weights).all():
                 raise ValueError("Weights contain non-finite values!")
@@ -216,6 +230,12 @@ class FlowModel:
             return (
                 (self.numpy_array_to_tensor(x_train), self.numpy_array_to_tensor(weights[:n])),
                 (self.numpy_array_to_tensor(x_val), self.numpy_array_to_tensor(weights[n:])),
+                batch_size,
+            )
+        if conditional is not None:
+            return (
+                (self.numpy_array_to_tensor(x_train), self.numpy_array_to_tensor(conditional[:n])),
+                (self.numpy_array_to_tensor(x_val), self.numpy_array_to_tensor(conditional[n:])),
                 batch_size,
             )
         return (
@@ -238,8 +258,6 @@ class FlowModel:
             self.initialise()
         if not np.isfinite(samples).all():
             raise ValueError("Training data is not finite")
-        if conditional is not None:
-            raise NotImplementedError("conditional training has no gfx950 kernel yet")
         if output is None:
             output = self.output
         else:
@@ -247,7 +265,7 @@ class FlowModel:
         if val_size is None:
             val_size = self.training_config["val_size"]
         history = train_flow(self, samples, max_epochs=max_epochs, patience=patience, val_size=val_size,
-                             weights=weights)
+                             weights=weights, conditional=conditional)
         current_weights_file = os.path.join(output, "model.pt")
         self.save_weights(current_weights_file)
         eval_mode(self.model)

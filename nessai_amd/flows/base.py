@@ -172,6 +172,8 @@ class HipFlow(BaseFlow):
         if self.precision not in pack.PRECISIONS and self.precision != "auto":
             raise ValueError(f"unknown precision {self.precision!r}; choose from {sorted(pack.PRECISIONS)} or 'auto'")
         desc = M.describe(self)
+        #: context features of a conditional flow (``context_features`` of the reference's constructors), 0 = none
+        self.context_features = int(desc.get("context_features", 0) or 0)
         self.features = desc["D"]
         self.transform_kind = desc["transform"]
         self.hidden_features = desc["hidden"]
@@ -296,16 +298,26 @@ class HipFlow(BaseFlow):
             cached = torch.randn(n, d, generator=torch.Generator().manual_seed(20260930)).to(device)
             self.__dict__["_probe_latents"] = cached
         z = cached
+        ctx = None
+        if self.context_features:  # a conditional flow is probed at a fixed standard-normal context
+            ctx = self.__dict__.get("_probe_context")
+            if ctx is None or ctx.device != device or ctx.shape != (n, self.context_features):
+                ctx = torch.randn(n, self.context_features, generator=torch.Generator().manual_seed(20261001)).to(device)
+                self.__dict__["_probe_context"] = ctx
         status = torch.zeros(4, dtype=torch.int32, device=device)
         errs_dev = torch.zeros(4, dtype=torch.float64, device=device)  # [candidate, one-ulp twin]
 
+        def flow_run(x_in, *args):
+            if ctx is not None:
+                return torch.ops.nessai_amd.flow_run_ctx(x_in, ctx, *args)
+            return torch.ops.nessai_amd.flow_run(x_in, *args)
+
         def run(precision, z_in, x_fwd=None):
             _, header_t, image_dev = images.get(precision)
-            x, ld = torch.ops.nessai_amd.flow_run(z_in, image_dev, header_t, DIR_INVERSE, MODE_APPLY, True, status,
-                                                  self.waves_per_group, self.max_groups)
-            _, lp = torch.ops.nessai_amd.flow_run(x if x_fwd is None else x_fwd, image_dev, header_t, DIR_FORWARD,
-                                                  MODE_LOGPROB, False, status, self.waves_per_group,
-                                                  self.max_groups)
+            x, ld = flow_run(z_in, image_dev, header_t, DIR_INVERSE, MODE_APPLY, True, status,
+                             self.waves_per_group, self.max_groups)
+            _, lp = flow_run(x if x_fwd is None else x_fwd, image_dev, header_t, DIR_FORWARD,
+                             MODE_LOGPROB, False, status, self.waves_per_group, self.max_groups)
             return x, ld, lp
 
         def compare(ld, lp, ref, slot):
@@ -397,21 +409,49 @@ class HipFlow(BaseFlow):
             return False
         return x.requires_grad or any(p.requires_grad for p in self.parameters())
 
-    def _run(self, x, direction, mode, want_x=True):
+    def _check_context(self, context, n):
+        """The ``context`` argument of the B1 methods: ``(n, context_features)`` for a conditional flow (float32 on
+        the flow's device; converted like the inputs), ``None`` for any other - anything else raises."""
+        if not self.context_features:
+            if context is not None:
+                raise ValueError("this flow was built without context_features: it takes no context")
+            return None
+        if context is None:
+            raise ValueError(f"a conditional flow (context_features={self.context_features}) needs a context")
+        if not isinstance(context, torch.Tensor) or context.device.type != "cuda":
+            raise RuntimeError("nessai_amd flows take tensors on a ROCm device; there is no CPU fallback")
+        if context.dim() != 2 or context.shape != (n, self.context_features):
+            raise ValueError("Expected a context of shape ({}, {}), got {}".format(n, self.context_features,
+                                                                                  tuple(context.shape)))
+        return context.detach().to(torch.float32).contiguous()
+
+    def _run(self, x, direction, mode, want_x=True, context=None):
+        if self.training and _has_inner_batch_norm(self):
+            raise RuntimeError(
+                "batch_norm_within_layers runs on its running statistics only (eval mode): the gfx950 kernels "
+                "compute no batch statistics inside the conditioner; call .eval() first"
+            )
         if direction == DIR_FORWARD and (self._wants_grad(x) or (self.training and _has_norm_layers(self))):
-            return self._run_differentiable(x, mode, want_x)
+            return self._run_differentiable(x, mode, want_x, context)
         if self.training and _has_norm_layers(self):
             raise RuntimeError(
                 "The inverse of batch-norm / act-norm transforms uses running statistics; "
                 "call .eval() before inverting or sampling the flow"
             )
         x = self._check_input(x)
+        context = self._check_context(context, x.shape[0])
         for _ in range(2):
             header, image = self.device_image()
-            out, ld = torch.ops.nessai_amd.flow_run(
-                x, image, self._header_t, direction, mode, want_x, self._status, self.waves_per_group,
-                self.max_groups,
-            )
+            if context is not None:
+                out, ld = torch.ops.nessai_amd.flow_run_ctx(
+                    x, context, image, self._header_t, direction, mode, want_x, self._status, self.waves_per_group,
+                    self.max_groups,
+                )
+            else:
+                out, ld = torch.ops.nessai_amd.flow_run(
+                    x, image, self._header_t, direction, mode, want_x, self._status, self.waves_per_group,
+                    self.max_groups,
+                )
             # split-f16 products hold for operands inside the f16 range only: the kernel says when a call
             # left it (one 16-byte read-back; the callers of this API read the results back anyway)
             if self.effective_precision != "f16x3" or x.shape[0] == 0 or int(self._status[1].item()) == 0:
@@ -419,8 +459,9 @@ class HipFlow(BaseFlow):
             self.note_f16_overflow()  # raises unless "auto": then the repeat runs in float32
         return (out if want_x else None), ld, self._status
 
-    def _run_differentiable(self, x, mode, want_x):
+    def _run_differentiable(self, x, mode, want_x, context=None):
         """Forward direction through the float32 training kernels, recorded by autograd."""
+        context = self._check_context(context, x.shape[0] if isinstance(x, torch.Tensor) and x.dim() == 2 else 0)
         if not isinstance(x, torch.Tensor) or x.device.type != "cuda":
             raise RuntimeError("nessai_amd flows take tensors on a ROCm device; there is no CPU fallback")
         if x.dim() != 2 or x.shape[1] != self.features:
@@ -431,7 +472,7 @@ class HipFlow(BaseFlow):
             return z, empty, self._status
         xin = x.to(torch.float32).contiguous()
         log_prob = mode == MODE_LOGPROB
-        z, ld, lp = ops.differentiable_flow(self, xin, want_x, not log_prob, log_prob)
+        z, ld, lp = ops.differentiable_flow(self, xin, want_x, not log_prob, log_prob, context=context)
         if self._status is None:
             with torch.inference_mode(False):
                 self._status = torch.zeros(4, dtype=torch.int32, device=x.device)
@@ -441,8 +482,7 @@ class HipFlow(BaseFlow):
 
     def forward(self, x, context=None):
         """x -> (z, log|det J|)  (``NFlow.forward``, flows/base.py:209-214)."""
-        _no_context(context)
-        z, ld, _ = self._run(x, DIR_FORWARD, MODE_APPLY)
+        z, ld, _ = self._run(x, DIR_FORWARD, MODE_APPLY, context=context)
         return z, ld
 
     def inverse(self, z, context=None):
@@ -452,22 +492,19 @@ class HipFlow(BaseFlow):
         discriminant, as the reference's arithmetic does (the caller drops the
         batch, ``flowproposal.py:357-364``).
         """
-        _no_context(context)
-        x, ld, status = self._run(z, DIR_INVERSE, MODE_APPLY)
+        x, ld, status = self._run(z, DIR_INVERSE, MODE_APPLY, context=context)
         if int(status[0].item()) != 0:
             raise AssertionError("negative discriminant in the spline inverse")
         return x, ld
 
     def log_prob(self, x, context=None):
         """log p(x)  (flows/base.py:236-245)."""
-        _no_context(context)
-        _, lp, _ = self._run(x, DIR_FORWARD, MODE_LOGPROB, want_x=False)
+        _, lp, _ = self._run(x, DIR_FORWARD, MODE_LOGPROB, want_x=False, context=context)
         return lp
 
     def forward_and_log_prob(self, x, context=None):
         """(z, log p(x))  (flows/base.py:259-273)."""
-        _no_context(context)
-        z, lp, _ = self._run(x, DIR_FORWARD, MODE_LOGPROB)
+        z, lp, _ = self._run(x, DIR_FORWARD, MODE_LOGPROB, context=context)
         return z, lp
 
     def sample_latent_distribution(self, n, context=None):
@@ -491,17 +528,15 @@ class HipFlow(BaseFlow):
 
     def sample(self, num_samples, context=None):
         """(flows/base.py:223-234)."""
-        _no_context(context)
         noise = self.sample_latent_distribution(num_samples)
-        x, _ = self.inverse(noise)
+        x, _ = self.inverse(noise, context=context)
         return x
 
     def sample_and_log_prob(self, N, context=None):
         """(x, log p(x)) for fresh draws  (flows/base.py:275-287)."""
-        _no_context(context)
         z = self.sample_latent_distribution(N)
         log_prob = self.base_distribution_log_prob(z)
-        x, logabsdet = self.inverse(z)
+        x, logabsdet = self.inverse(z, context=context)
         return x, log_prob - logabsdet
 
     def freeze_transform(self):
@@ -626,13 +661,17 @@ def _count(flow, what):
     stats[what] = stats.get(what, 0) + 1
 
 
-def _no_context(context):
-    if context is not None:
-        raise NotImplementedError("conditional flows have no gfx950 kernel yet")
-
-
 def _has_batch_norm(flow):
     return any(isinstance(m, M.BatchNorm) for m in flow.modules())
+
+
+def _has_inner_batch_norm(flow):
+    """Batch norm inside the residual blocks of the conditioners (``batch_norm_within_layers``)."""
+    cached = flow.__dict__.get("_inner_batch_norm")
+    if cached is None:
+        cached = any(getattr(m, "use_batch_norm", False) for m in flow.modules() if isinstance(m, M.ResidualNet))
+        flow.__dict__["_inner_batch_norm"] = cached
+    return cached
 
 
 def _has_norm_layers(flow):
@@ -662,7 +701,7 @@ def lib_supports(ht, transform, bins):
     return bool(lib.load().nsa_flow_supported(int(ht), int(kind), int(bins if transform == "rq" else 0)))
 
 
-_STRUCT_WORDS = (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 25, 26, 27, 29)  # nsa_format.h ints
+_STRUCT_WORDS = (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 25, 26, 27, 29, 34, 35)  # nsa_format.h ints
 
 
 @torch.no_grad()

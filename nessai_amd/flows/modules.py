@@ -78,18 +78,42 @@ class Linear(nn.Linear):
 
 
 class ResidualBlock(_Container):
-    def __init__(self, features, zero_initialization=True):
+    """``h + W2 act(W1 act(h) + b1) + b2``; with ``context_features`` the block's output is gated,
+    ``h + glu(cat(temps, context_layer(context)))`` (nflows; creation order of the layers kept, so that one
+    ``torch.manual_seed`` gives the reference's initial weights)."""
+
+    def __init__(self, features, context_features=None, zero_initialization=True, use_batch_norm=False):
         super().__init__()
+        self.use_batch_norm = bool(use_batch_norm)
+        if use_batch_norm:  # nflows: two BatchNorm1d(features, eps=1e-3); only their eval-mode affine has a kernel
+            self.batch_norm_layers = nn.ModuleList([nn.BatchNorm1d(features, eps=1e-3) for _ in range(2)])
+        if context_features is not None:
+            self.context_layer = Linear(context_features, features)
         self.linear_layers = nn.ModuleList([Linear(features, features) for _ in range(2)])
         if zero_initialization:
             init.uniform_(self.linear_layers[-1].weight, -1e-3, 1e-3)
             init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
 
     def reset_parameters(self):
+        if hasattr(self, "context_layer"):
+            self.context_layer.reset_parameters()
+        if self.use_batch_norm:
+            for bn in self.batch_norm_layers:
+                bn.reset_parameters()
         for layer in self.linear_layers:
             layer.reset_parameters()
         init.uniform_(self.linear_layers[-1].weight, -1e-3, 1e-3)
         init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
+
+
+def batch_norm_affines(block):
+    """Eval-mode ``(a, c)`` of the two batch norms of a residual block, ``bn(h) = a h + c`` (float64)."""
+    out = []
+    for bn in block.batch_norm_layers:
+        var = bn.running_var.detach().double().cpu()
+        a = bn.weight.detach().double().cpu() / torch.sqrt(var + bn.eps)
+        out.append((a.numpy(), (bn.bias.detach().double().cpu() - a * bn.running_mean.detach().double().cpu()).numpy()))
+    return out
 
 
 class ResidualNet(_Container):
@@ -97,13 +121,22 @@ class ResidualNet(_Container):
 
     kind = "resnet"
 
-    def __init__(self, in_features, out_features, hidden_features, num_blocks=2,
-                 activation="relu"):
+    def __init__(self, in_features, out_features, hidden_features, context_features=None, num_blocks=2,
+                 activation="relu", dropout_probability=0.0, use_batch_norm=False):
         super().__init__()
         self.activation_name = activation_name(activation)
         self.hidden_features = hidden_features
-        self.initial_layer = Linear(in_features, hidden_features)
-        self.blocks = nn.ModuleList([ResidualBlock(hidden_features) for _ in range(num_blocks)])
+        self.context_features = context_features
+        #: batch norm within the blocks (``batch_norm_within_layers``): eval mode only, like dropout - the inference
+        #: kernels apply the running statistics, the training kernels refuse it
+        self.use_batch_norm = bool(use_batch_norm)
+        #: dropout between the two layers of a block: the identity in eval mode (every inference kernel); the
+        #: training kernels have no dropout and refuse a non-zero rate (nessai_amd.train.Trainer)
+        self.dropout_probability = float(dropout_probability or 0.0)
+        # (conditional: the context joins the inputs of the initial layer and gates every block)
+        self.initial_layer = Linear(in_features + (context_features or 0), hidden_features)
+        self.blocks = nn.ModuleList([ResidualBlock(hidden_features, context_features, use_batch_norm=use_batch_norm)
+                                     for _ in range(num_blocks)])
         self.final_layer = Linear(hidden_features, out_features)
 
     def layers(self):
@@ -470,8 +503,6 @@ def describe(flow, index_offset=None):
                 kind = "resnet"
                 layers = [net.initial_layer]
                 for block in net.blocks:
-                    if getattr(block, "use_batch_norm", False):
-                        raise ValueError("batch_norm_within_layers has no gfx950 kernel")
                     layers.extend(block.linear_layers)
                 layers.append(net.final_layer)
                 hidden = net.initial_layer.out_features
@@ -516,6 +547,28 @@ def describe(flow, index_offset=None):
                     min_bin_height=float(t.min_bin_height),
                     min_derivative=float(t.min_derivative),
                 )
+            # conditional flows (context_features): the context layers of the residual blocks, in block order
+            gates = []
+            n_ctx = getattr(net, "context_features", None)
+            if n_ctx:
+                if kind != "resnet":
+                    raise ValueError("only the residual conditioner takes a context")
+                gates = [(values(b.context_layer.weight), values(b.context_layer.bias)) for b in net.blocks]
+                this["context_features"] = int(n_ctx)
+            # batch norm within the blocks (eval mode): the first one stays a per-feature affine in front of the
+            # block's first activation, the second one is folded into the block's first linear layer
+            block_norms = []
+            weights = [(values(l.weight), values(l.bias)) for l in layers]
+            if kind == "resnet" and any(getattr(b, "use_batch_norm", False) for b in net.blocks):
+                if offsets is not None:
+                    raise ValueError("the image words of a conditioner with batch norm are not copies of parameters")
+                this["batch_norm_within"] = True
+                for b, block in enumerate(net.blocks):
+                    (a0, c0), (a1, c1) = batch_norm_affines(block)
+                    block_norms.append((a0.astype(np.float32), c0.astype(np.float32)))
+                    w, bias = weights[1 + 2 * b]
+                    weights[1 + 2 * b] = ((a1[:, None] * np.asarray(w, dtype=np.float64)).astype(np.float32),
+                                          (a1 * np.asarray(bias, dtype=np.float64) + c1).astype(np.float32))
             if coupling is None:
                 coupling = this
             elif coupling != this:
@@ -525,7 +578,9 @@ def describe(flow, index_offset=None):
                     "coupling",
                     t.identity_features.detach().cpu().numpy().tolist(),
                     t.transform_features.detach().cpu().numpy().tolist(),
-                    [(values(l.weight), values(l.bias)) for l in layers],
+                    weights,
+                    gates,
+                    block_norms,
                 )
             )
         elif hasattr(t, "running_var") or hasattr(t, "log_scale"):

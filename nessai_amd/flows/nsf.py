@@ -54,8 +54,9 @@ class NeuralSplineFlow(HipFlow):
 
         def conditioner(n_in, n_out):
             return M.ResidualNet(
-                n_in, n_out, hidden_features, num_blocks=num_blocks_per_layer,
-                activation=activation,
+                n_in, n_out, hidden_features, context_features=context_features,
+                num_blocks=num_blocks_per_layer, activation=activation,
+                dropout_probability=dropout_probability, use_batch_norm=batch_norm_within_layers,
             )
 
         layers = []
@@ -82,11 +83,11 @@ class NeuralSplineFlow(HipFlow):
 
 def _reject_unsupported(context_features, dropout_probability, batch_norm_within_layers,
                         apply_unconditional_transform=False):
-    if context_features is not None:
-        raise NotImplementedError("conditional flows have no gfx950 kernel yet")
-    if dropout_probability:
-        raise NotImplementedError("dropout has no gfx950 kernel")
-    if batch_norm_within_layers:
-        raise NotImplementedError("batch_norm_within_layers has no gfx950 kernel")
+    if context_features is not None and (isinstance(context_features, bool) or int(context_features) < 1):
+        raise ValueError("context_features must be a positive integer or None")
+    if dropout_probability and not 0.0 <= float(dropout_probability) < 1.0:
+        raise ValueError("dropout_probability must lie in [0, 1)")
+    # (batch_norm_within_layers: eval mode on the kernels - the running statistics as per-feature affines;
+    # nessai_amd.train.Trainer refuses such a flow, like one with dropout)
     if apply_unconditional_transform:
         raise NotImplementedError("apply_unconditional_transform has no gfx950 kernel")

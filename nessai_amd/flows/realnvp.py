@@ -113,11 +113,14 @@ class RealNVP(HipFlow):
 
             def conditioner(n_in, n_out):
                 return M.ResidualNet(
-                    n_in, n_out, hidden_features, num_blocks=num_blocks_per_layer,
-                    activation=activation,
+                    n_in, n_out, hidden_features, context_features=context_features,
+                    num_blocks=num_blocks_per_layer, activation=activation,
+                    dropout_probability=dropout_probability, use_batch_norm=batch_norm_within_layers,
                 )
 
         elif net.lower() == "mlp":
+            if context_features is not None:  # (the reference's MLP raises at its first call: flows/nets.py:90-101)
+                raise NotImplementedError("MLP with conditional inputs is not implemented.")
 
             def conditioner(n_in, n_out):
                 return M.MLP(

@@ -43,6 +43,11 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     ),
+    "nsa_flow_run_ctx": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+         c_void_p],
+    ),
     "nsa_flow_run_many": (
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -131,6 +136,8 @@ SIGNATURES = {
          c_int, c_void_p],
     ),
     "nsa_importance_to_prime": (c_int, [c_ll, c_int, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
+    "nsa_importance_mix_packed": (c_int, [c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                          c_void_p]),
     "nsa_importance_mix": (c_int, [c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsa_populate_truncate": (c_int, [c_ll, c_void_p, c_double, c_void_p, c_double, c_void_p]),
     "nsa_populate_weights": (c_int, [c_ll, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
@@ -139,6 +146,7 @@ SIGNATURES = {
     "nsa_max_key_decode": (c_double, [c_ll]),
     "nsa_populate_accept_workspace": (c_size_t, [c_ll]),
     "nsa_train_workspace_floats": (c_size_t, [c_void_p, c_ll]),
+    "nsa_train_context_offset": (c_size_t, [c_void_p, c_ll]),
     "nsa_log_likelihood": (c_int, [c_int, c_ll, c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
     "nsa_train_step_dev": (
         c_int,

@@ -10,6 +10,7 @@ the two differentiable ones into autograd:
 
 ===============================  =========================================================
 ``nessai_amd::flow_run``         whole flow, inference kernel (``nsa_flow_run``)
+``nessai_amd::flow_run_ctx``     the same for a conditional flow (``nsa_flow_run_ctx``)
 ``nessai_amd::flow_forward``     whole flow in exact float32, activations kept in a
                                  workspace tensor (``nsa_train_forward``)
 ``nessai_amd::flow_backward``    reverse mode of the above for arbitrary upstream
@@ -36,8 +37,12 @@ _LIB.define(
     "Tensor(a!) status, int waves_per_group, int max_groups) -> (Tensor, Tensor)"
 )
 _LIB.define(
+    "flow_run_ctx(Tensor x, Tensor context, Tensor image, Tensor header, int direction, int mode, bool want_x, "
+    "Tensor(a!) status, int waves_per_group, int max_groups) -> (Tensor, Tensor)"
+)
+_LIB.define(
     "flow_forward(Tensor x, Tensor(a!) flat, int plan, bool training, bool want_z, bool want_logdet, "
-    "bool want_log_prob) -> (Tensor, Tensor, Tensor, Tensor)"
+    "bool want_log_prob, Tensor? context=None) -> (Tensor, Tensor, Tensor, Tensor)"
 )
 _LIB.define(
     "flow_backward(Tensor(a!) workspace, Tensor flat, int plan, int n, bool training, Tensor? g_z, "
@@ -88,11 +93,33 @@ def _flow_run(x, image, header, direction, mode, want_x, status, waves_per_group
     return out, ld
 
 
-def _flow_forward(x, flat, plan, training, want_z, want_logdet, want_log_prob):
+def _flow_run_ctx(x, context, image, header, direction, mode, want_x, status, waves_per_group, max_groups):
+    """``flow_run`` of a conditional flow (``nsa_flow_run_ctx``): ``context`` is ``(n, C)`` float32."""
+    n = x.shape[0]
+    out = torch.empty_like(x) if want_x else _empty(x, 0)
+    ld = _empty(x, n)
+    status.zero_()
+    if n == 0:
+        return out, ld
+    if header.dtype != torch.int32 or header.device.type != "cpu" or not header.is_contiguous():
+        raise RuntimeError("nessai_amd::flow_run_ctx: `header` must be the host int32 tensor of ops.header_tensor")
+    if context.shape[0] != n or context.dtype != torch.float32 or not context.is_contiguous() or context.device != x.device:
+        raise RuntimeError("nessai_amd::flow_run_ctx: `context` must be a contiguous float32 (n, C) tensor on x's device")
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    rc = lib.load().nsa_flow_run_ctx(
+        lib.c_void_p(header.data_ptr()), lib.ptr(image), int(direction), int(mode), n, lib.ptr(x), lib.ptr(context),
+        lib.ptr(out) if want_x else None, lib.ptr(ld), lib.ptr(status), int(waves_per_group), int(max_groups),
+        lib.c_void_p(stream),
+    )
+    lib.check(rc, "nsa_flow_run_ctx")
+    return out, ld
+
+
+def _flow_forward(x, flat, plan, training, want_z, want_logdet, want_log_prob, context=None):
     trainer = _plan(plan)
     if flat.data_ptr() != trainer.flat.data_ptr():
         raise RuntimeError("nessai_amd::flow_forward: `flat` is not the plan's parameter buffer")
-    z, ld, lp, ws = trainer.forward_saved(x, training, want_z, want_logdet, want_log_prob)
+    z, ld, lp, ws = trainer.forward_saved(x, training, want_z, want_logdet, want_log_prob, context=context)
     if training and (trainer._stats or trainer._actnorms):
         # batch norm / act norm: the kernels just rewrote running statistics (or initialised act norm)
         trainer.stats_version = getattr(trainer, "stats_version", 0) + 1
@@ -107,6 +134,7 @@ def _flow_backward(workspace, flat, plan, n, training, g_z, g_logdet, g_log_prob
 
 
 _LIB.impl("flow_run", _flow_run, "CUDA")
+_LIB.impl("flow_run_ctx", _flow_run_ctx, "CUDA")
 _LIB.impl("flow_forward", _flow_forward, "CUDA")
 _LIB.impl("flow_backward", _flow_backward, "CUDA")
 
@@ -118,7 +146,7 @@ def _flow_run_meta(x, image, header, direction, mode, want_x, status, waves_per_
     return (torch.empty_like(x) if want_x else x.new_empty((0,)), x.new_empty((x.shape[0],)))
 
 
-def _flow_forward_meta(x, flat, plan, training, want_z, want_logdet, want_log_prob):
+def _flow_forward_meta(x, flat, plan, training, want_z, want_logdet, want_log_prob, context=None):
     n = x.shape[0]
     words = int(lib.load().nsa_train_workspace_floats(_plan(plan).plan, n))
     return (
@@ -136,6 +164,7 @@ def _flow_backward_meta(workspace, flat, plan, n, training, g_z, g_logdet, g_log
 
 
 _LIB.impl("flow_run", _flow_run_meta, "Meta")
+_LIB.impl("flow_run_ctx", lambda x, context, *rest: _flow_run_meta(x, *rest), "Meta")
 _LIB.impl("flow_forward", _flow_forward_meta, "Meta")
 _LIB.impl("flow_backward", _flow_backward_meta, "Meta")
 
@@ -152,9 +181,10 @@ class FlowFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, trainer, training, want_z, want_logdet, want_log_prob, *params):
+    def forward(ctx, x, trainer, training, want_z, want_logdet, want_log_prob, context, *params):
         z, ld, lp, ws = torch.ops.nessai_amd.flow_forward(
-            x, trainer.flat, trainer.handle, bool(training), bool(want_z), bool(want_logdet), bool(want_log_prob)
+            x, trainer.flat, trainer.handle, bool(training), bool(want_z), bool(want_logdet), bool(want_log_prob),
+            context,
         )
         ctx.trainer = trainer
         ctx.workspace = ws
@@ -199,9 +229,9 @@ class FlowFunction(torch.autograd.Function):
         ctx.workspace = None  # a second backward would read activations that were consumed
         per_param = [
             grads[off : off + numel].view(shape) if need else None
-            for (off, numel, shape), need in zip(trainer.param_slices, ctx.needs_input_grad[6:])
+            for (off, numel, shape), need in zip(trainer.param_slices, ctx.needs_input_grad[7:])
         ]
-        return (gx if want_gx else None, None, None, None, None, None, *per_param)
+        return (gx if want_gx else None, None, None, None, None, None, None, *per_param)
 
 
 def _state_version(trainer):
@@ -215,13 +245,13 @@ def _state_version(trainer):
     return (getattr(trainer, "stats_version", 0), tuple(t._version for t in tensors))
 
 
-def differentiable_flow(flow, x, want_z, want_logdet, want_log_prob):
+def differentiable_flow(flow, x, want_z, want_logdet, want_log_prob, context=None):
     """Run ``flow`` forward under autograd; returns ``(z, logdet, log_prob)`` (``None`` if unwanted)."""
     trainer = flow.trainer()
     if flow.training and x.shape[0] < 2:
         raise ValueError("a training-mode pass needs at least two rows")
     params = list(flow.parameters())
-    z, ld, lp = FlowFunction.apply(x, trainer, flow.training, want_z, want_logdet, want_log_prob, *params)
+    z, ld, lp = FlowFunction.apply(x, trainer, flow.training, want_z, want_logdet, want_log_prob, context, *params)
     flow._image_key = None  # training-mode passes update running statistics behind the version counters
     return (z if want_z else None, ld if want_logdet else None, lp if want_log_prob else None)
 

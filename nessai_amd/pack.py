@@ -31,7 +31,7 @@ import math
 import numpy as np
 
 MAGIC = 0x3141534E
-VERSION = 9
+VERSION = 10
 HEADER_WORDS = 40
 STAGE_ALIGN = 32   # words: stage blobs are padded to whole 128-byte lines
 PIECE_WORDS = 256  # words moved by one global_load_lds of a wave (64 lanes x 16 bytes)
@@ -44,6 +44,8 @@ H_MAX_STAGE, H_TOTAL, H_OUT_FWD, H_OUT_INV = 14, 15, 16, 17
 H_LOG_Z, H_TAIL_BOUND, H_MIN_BW, H_MIN_BH, H_MIN_D, H_EDGE_RAW = 18, 19, 20, 21, 22, 23
 H_LOGIT_DIV, H_ACT, H_NET, H_NLAYERS, H_BASE_INV_VAR, H_PREC, H_AFF_A, H_AFF_B = 24, 25, 26, 27, 28, 29, 30, 31
 H_RES_FWD, H_RES_INV = 32, 33
+H_CTX = 34  # context features of a conditional flow (format 10)
+H_BNW = 35  # 1: batch norm within the residual blocks - every block starts with an {a, c} stage (format 10)
 
 T_NONE, T_RQ, T_AFFINE, T_ADDITIVE = 0, 1, 2, 3
 TRANSFORMS = {"rq": T_RQ, "affine": T_AFFINE, "additive": T_ADDITIVE}
@@ -311,15 +313,22 @@ def _stage(*sections):
 class _CouplingBlobs:
     """Direction-independent packed weights of one coupling layer."""
 
-    def __init__(self, desc, identity_idx, transform_idx, layers):
+    def __init__(self, desc, identity_idx, transform_idx, layers, gates=(), norms=()):
+        """``gates``: the ``(Wc, bc)`` of the context layers of a conditional flow's residual blocks, in block
+        order; layer 0 of such a flow takes ``d_id + C`` inputs, identity features first (nflows ResidualNet:
+        ``initial_layer(cat(inputs, context))``).  ``norms``: the eval-mode ``(a, c)`` of the first batch norm of
+        every residual block (``batch_norm_within_layers``; the second one is already folded into ``layers``)."""
         self.d_id = len(identity_idx)
         self.d_tr = len(transform_idx)
         hidden = desc["hidden"]
         ht = hidden_tiles(hidden)
+        n_ctx = int(desc.get("context_features", 0) or 0)
         n_tiles_c, fpc, n_params = transform_policy(desc["transform"], desc.get("bins", 0))
         bf16 = desc.get("precision", "f32") in SPLIT16  # k in steps of 16, weights as 16-bit pairs
         self.bf16 = bf16
-        self.n_steps0 = (self.d_id + 15) // 16 if bf16 else pad4((self.d_id + 1) // 2)
+        self.n_in0 = self.d_id + n_ctx  # inputs of layer 0: identity features, then the context
+        self.n_steps0 = (self.n_in0 + 15) // 16 if bf16 else pad4((self.n_in0 + 1) // 2)
+        self.n_steps_c = ((n_ctx + 15) // 16 if bf16 else pad4((n_ctx + 1) // 2)) if n_ctx else 0
         self.n_chunks = (self.d_tr + 2 * fpc - 1) // (2 * fpc)
         self.fpc = fpc
         if bf16:
@@ -330,11 +339,22 @@ class _CouplingBlobs:
             reg_cols = _reg_in_cols(ht, hidden)
 
         w0, b0 = layers[0]
-        assert w0.shape == (hidden, self.d_id), (w0.shape, hidden, self.d_id)
+        assert w0.shape == (hidden, self.n_in0), (w0.shape, hidden, self.n_in0)
         if bf16:
-            in_cols0 = _tile_in_cols16(self.n_steps0, self.d_id)
+            in_cols0 = _tile_in_cols16(self.n_steps0, self.n_in0)
         else:
-            in_cols0 = [[(2 * s + h) if (2 * s + h) < self.d_id else -1 for h in range(2)] for s in range(self.n_steps0)]
+            in_cols0 = [[(2 * s + h) if (2 * s + h) < self.n_in0 else -1 for h in range(2)] for s in range(self.n_steps0)]
+        # context gates of the residual blocks: (bias, W) laid out like layer 0, inputs = the C context columns
+        self.gates = []
+        for wc, bc in gates:
+            assert wc.shape == (hidden, n_ctx), (wc.shape, hidden, n_ctx)
+            if bf16:
+                in_cols_c = _tile_in_cols16(self.n_steps_c, n_ctx)
+            else:
+                in_cols_c = [[(2 * s + h) if (2 * s + h) < n_ctx else -1 for h in range(2)] for s in range(self.n_steps_c)]
+            self.gates.append((pack_bias(bc, _plain_out_rows(ht, hidden)), pack_w(wc, _plain_out_rows(ht, hidden), in_cols_c)))
+        self.norms = [(pack_bias(a, _plain_out_rows(ht, hidden)), pack_bias(c, _plain_out_rows(ht, hidden)))
+                      for a, c in norms]
         self.layer0 = (
             pack_bias(b0, _plain_out_rows(ht, hidden)),
             pack_w(w0, _plain_out_rows(ht, hidden), in_cols0),
@@ -513,6 +533,9 @@ def pack_flow(desc):
     n_tiles_c, fpc, n_params = transform_policy(transform, bins)
     tabw = pad4(2 * fpc)
     D4 = pad4(D)
+    n_ctx = int(desc.get("context_features", 0) or 0)
+    if n_ctx < 0 or n_ctx > 256:
+        raise ValueError(f"context_features={n_ctx} is not supported by the gfx950 kernels (0 ... 256)")
     precision = desc.get("precision", "f32")
     if precision not in PRECISIONS:
         raise ValueError(f"unknown precision {precision!r}; choose from {sorted(PRECISIONS)}")
@@ -574,11 +597,20 @@ def pack_flow(desc):
                 id_tab = np.full((16 if bf16 else 2) * packed.n_steps0, 4 * (D + 1), dtype=np.int32)
                 for k, f in enumerate(identity_idx):
                     id_tab[k] = 4 * cur[int(f)]  # byte offset in the row; unused entries: the zero cell
+                for j in range(n_ctx):  # the context columns lie behind the two spare cells of the row
+                    id_tab[len(identity_idx) + j] = 4 * (D + 2 + j)
                 stages.append(add_blob(_stage(id_tab, *packed.layer0)))
-                for bias, subs in packed.hidden_layers:
+                for i, (bias, subs) in enumerate(packed.hidden_layers):
+                    if packed.norms and i % 2 == 0:  # in front of a residual block: its first batch norm
+                        stages.append(add_blob(_stage(*packed.norms[i // 2])))
                     stages.append(add_blob(_stage(bias, subs[0])))
                     for w in subs[1:]:
                         stages.append(add_blob(_stage(w)))
+                    if packed.gates and i % 2 == 1:  # behind the second layer of a residual block: its context gate
+                        c_tab = np.full((16 if bf16 else 2) * packed.n_steps_c, 4 * (D + 1), dtype=np.int32)
+                        for j in range(n_ctx):
+                            c_tab[j] = 4 * (D + 2 + j)
+                        stages.append(add_blob(_stage(c_tab, *packed.gates[i // 2])))
                 for slots, bias, subs in packed.chunks:
                     tr_tab = np.full(tabw, -1, dtype=np.int32)
                     for k, m in enumerate(slots):
@@ -587,7 +619,7 @@ def pack_flow(desc):
                     stages.append(add_blob(_stage(tr_tab, bias, subs[0])))
                     for w in subs[1:]:
                         stages.append(add_blob(_stage(w)))
-                ops.append([OP_COUPLING, packed.n_steps0, packed.n_chunks, 0])
+                ops.append([OP_COUPLING, packed.n_steps0, packed.n_chunks, packed.n_steps_c])
             elif kind == "elementwise":
                 a, b, c, d, ld = tr[1]
                 tabs = np.zeros((4, D4), dtype=np.float32)
@@ -610,9 +642,16 @@ def pack_flow(desc):
     n_net_layers = None
     for tr in desc["transforms"]:
         if tr[0] == "coupling":
-            _, identity_idx, transform_idx, layers = tr
+            _, identity_idx, transform_idx, layers = tr[:4]
             layers = [(np.asarray(w, dtype=np.float32), np.asarray(b, dtype=np.float32)) for w, b in layers]
-            prepared.append(("coupling", list(identity_idx), list(transform_idx), _CouplingBlobs(desc, identity_idx, transform_idx, layers)))
+            gates = [(np.asarray(w, dtype=np.float32), np.asarray(b, dtype=np.float32)) for w, b in (tr[4] if len(tr) > 4 else ())]
+            if n_ctx and (desc["net"] != "resnet" or 2 * len(gates) != len(layers) - 2):
+                raise ValueError("a conditional flow needs a residual conditioner with one context layer per block")
+            norms = [(np.asarray(a, dtype=np.float32), np.asarray(c, dtype=np.float32)) for a, c in (tr[5] if len(tr) > 5 else ())]
+            if bool(desc.get("batch_norm_within")) != bool(norms) or (norms and (desc["net"] != "resnet" or 2 * len(norms) != len(layers) - 2)):
+                raise ValueError("batch norm within layers needs a residual conditioner with one (a, c) pair per block")
+            prepared.append(("coupling", list(identity_idx), list(transform_idx),
+                             _CouplingBlobs(desc, identity_idx, transform_idx, layers, gates, norms)))
             n_hidden = len(layers) - 2
             if desc["net"] == "resnet":
                 assert n_hidden % 2 == 0
@@ -688,6 +727,8 @@ def pack_flow(desc):
     img[H_NET] = NETS[desc.get("net", "resnet")]
     img[H_NLAYERS] = n_net_layers if n_net_layers is not None else 0
     img[H_PREC] = PRECISIONS[precision]
+    img[H_CTX] = n_ctx
+    img[H_BNW] = 1 if desc.get("batch_norm_within") else 0
 
     img[off_ops_fwd : off_ops_fwd + ops_fwd.size] = ops_fwd.reshape(-1)
     img[off_ops_inv : off_ops_inv + ops_inv.size] = ops_inv.reshape(-1)

@@ -14,7 +14,7 @@ Trainable scope: permutations, LU-linear layers, coupling layers (affine,
 additive, rational-quadratic spline) with a residual or plain-MLP conditioner,
 batch norm between layers and act norm (with its data-dependent
 initialisation) - i.e. every RealNVP / NeuralSplineFlow configuration of the
-reference except conditional inputs, which raise.
+reference, conditional inputs included (layer-wise kernels).
 """
 
 import contextlib
@@ -94,6 +94,15 @@ class Trainer:
                     layers = net.layers()
                     depth = len(layers) - 2
                 else:
+                    if getattr(net, "dropout_probability", 0.0):
+                        raise NotImplementedError(
+                            "dropout_probability > 0: the gfx950 training kernels have no dropout (such a flow runs "
+                            "in eval mode - dropout is the identity there - with weights trained elsewhere)")
+                    if getattr(net, "use_batch_norm", False):
+                        raise NotImplementedError(
+                            "batch_norm_within_layers: the gfx950 training kernels have no batch statistics inside the "
+                            "conditioner (such a flow runs in eval mode, on its running statistics, with weights "
+                            "trained elsewhere)")
                     layers = [net.initial_layer]
                     for block in net.blocks:
                         layers.extend(block.linear_layers)
@@ -114,6 +123,10 @@ class Trainer:
                     base = offsets[id(layer.weight)]
                     idx = np.arange(o_ * k_)
                     tmap[base : base + o_ * k_] = base + (idx % k_) * o_ + idx // k_
+                if desc.get("context_features"):  # conditional: the context layer of every block, behind the rest
+                    for block in net.blocks:
+                        rec.append(offsets[id(block.context_layer.weight)])
+                        rec.append(offsets[id(block.context_layer.bias)])
                 records.append(rec)
             elif isinstance(t, M.BatchNorm):
                 rec = [2, len(tables), offsets[id(t.unconstrained_weight)], offsets[id(t.bias)],
@@ -156,6 +169,10 @@ class Trainer:
                   pack.ACTIVATIONS[desc["activation"]], n_tr, total, rec_words, len(tables),
                   pack.NETS[desc["net"]]]
         header.append(len(tables) + total)  # [12] final column table: logical output i -> physical column
+        #: context features of a conditional flow: [13] of the plan; the context rows of a batch travel inside the
+        #: workspace (``_put_context``)
+        self.context_features = int(desc.get("context_features", 0) or 0)
+        header.append(self.context_features)
         tables = list(tables) + tmap.tolist() + [int(c) for c in cur]
         plan = header + [w for rec in records for w in rec]
         self.plan = (ctypes.c_longlong * len(plan))(*plan)
@@ -218,13 +235,26 @@ class Trainer:
 
     # -- differentiable evaluation (nessai_amd.ops) ------------------------------
 
-    def forward_saved(self, x, training, want_z=True, want_logdet=True, want_log_prob=True):
+    def _put_context(self, ws, n, context):
+        """Hand the ``(n, C)`` context rows of a conditional flow's batch to the kernels: they read them from the
+        workspace, ``nsa_train_context_offset`` floats from its start (the C entry points keep their signatures)."""
+        if not self.context_features:
+            if context is not None:
+                raise ValueError("this flow takes no context")
+            return
+        if context is None or tuple(context.shape) != (n, self.context_features):
+            raise ValueError(f"a conditional flow needs a context of shape ({n}, {self.context_features})")
+        off = int(lib.load().nsa_train_context_offset(self.plan, n))
+        ws[off : off + n * self.context_features].view(n, self.context_features).copy_(context)
+
+    def forward_saved(self, x, training, want_z=True, want_logdet=True, want_log_prob=True, context=None):
         """Forward pass that keeps every layer's activations in a fresh workspace tensor.
 
         Returns ``(z, logdet, log_prob, workspace)``; unwanted outputs are ``None``."""
         n = x.shape[0]
         words = int(lib.load().nsa_train_workspace_floats(self.plan, n))
         ws = torch.empty(words, dtype=torch.float32, device=self.device)
+        self._put_context(ws, n, context)
         z = torch.empty((n, self.features), dtype=torch.float32, device=self.device) if want_z else None
         ld = torch.empty(n, dtype=torch.float32, device=self.device) if want_logdet else None
         lp = torch.empty(n, dtype=torch.float32, device=self.device) if want_log_prob else None
@@ -280,13 +310,15 @@ class Trainer:
             self._ws_rows = n
         return self._ws
 
-    def step(self, x, clip_norm=5.0, lr=None, weights=None):
+    def step(self, x, clip_norm=5.0, lr=None, weights=None, context=None):
         """One optimiser step on a ``(n, D)`` float32 device batch; the loss is added to ``loss_acc``.
 
         ``weights`` (``(n,)`` float32 device tensor) selects the weighted loss
-        ``-sum(w log_prob) / sum(w)`` (``flowmodel/base.py:404-407``)."""
+        ``-sum(w log_prob) / sum(w)`` (``flowmodel/base.py:404-407``); ``context``: the ``(n, C)`` context rows of
+        a conditional flow."""
         self.step_count += 1
         ws = self._workspace(x.shape[0])
+        self._put_context(ws, x.shape[0], context)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = lib.load().nsa_train_step(
             self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(self.grads),
@@ -297,11 +329,12 @@ class Trainer:
         lib.check(rc, "nsa_train_step")
         self._actnorm_initialised()
 
-    def step_dev(self, x, clip_norm=5.0, weights=None):
+    def step_dev(self, x, clip_norm=5.0, weights=None, context=None):
         """``step`` with the learning rate and the step counter in device memory (``self.opt``):
         the form whose launches can be captured into a HIP graph (``nsa_train_step_dev``)."""
         self.step_count += 1
         ws = self._workspace(x.shape[0])
+        self._put_context(ws, x.shape[0], context)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = lib.load().nsa_train_step_dev(
             self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(self.grads),
@@ -316,9 +349,10 @@ class Trainer:
         # under graph capture, once the flag is clear: the first epoch always runs launch by launch.)
         self._actnorm_initialised()
 
-    def evaluate(self, x, log_prob_out=None, weights=None):
+    def evaluate(self, x, log_prob_out=None, weights=None, context=None):
         """``loss_acc += -mean(log_prob(x))`` without touching the weights."""
         ws = self._workspace(x.shape[0])
+        self._put_context(ws, x.shape[0], context)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = lib.load().nsa_train_eval(
             self.plan, lib.ptr(self.tables), self.consts, lib.ptr(self.params), lib.ptr(x), lib.ptr(weights),
@@ -373,7 +407,7 @@ def _training_kernels(deterministic):
                 os.environ["NESSAI_AMD_TRAIN_FUSED"] = before
 
 
-def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=None, weights=None):
+def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=None, weights=None, conditional=None):
     tc = flow_model.training_config
     trainer = get_trainer(flow_model)
     trainer.lr = trainer.base_lr
@@ -392,11 +426,13 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
     model = flow_model.model
     validate = val_size != 0.0
     train_data, val_data, batch_size = flow_model.prep_data(
-        samples, val_size=val_size, batch_size=tc["batch_size"], weights=weights
+        samples, val_size=val_size, batch_size=tc["batch_size"], weights=weights, conditional=conditional
     )
-    w_train = w_val = None
+    w_train = w_val = c_train = c_val = None
     if weights is not None:
         (train_data, w_train), (val_data, w_val) = train_data, val_data
+    elif conditional is not None:  # (flowmodel/base.py:286-302: the conditional inputs are shuffled and split with the samples)
+        (train_data, c_train), (val_data, c_val) = train_data, val_data
     if max_epochs is None:
         max_epochs = tc["max_epochs"]
     if patience is None:
@@ -420,6 +456,7 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
     n_train = train_data.shape[0]
     epoch_rows = torch.empty_like(train_data)
     epoch_w = torch.empty_like(w_train) if w_train is not None else None
+    epoch_c = torch.empty_like(c_train) if c_train is not None else None
     bounds = [(a, min(a + batch_size, n_train)) for a in range(0, n_train, batch_size)]
     has_val = bool(validate and len(val_data))
     trainer.opt[1] = float(trainer.step_count)
@@ -427,10 +464,11 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
     def run_epoch():
         trainer.losses.zero_()
         for a, b in bounds:
-            trainer.step_dev(epoch_rows[a:b], clip_norm=clip, weights=None if epoch_w is None else epoch_w[a:b])
+            trainer.step_dev(epoch_rows[a:b], clip_norm=clip, weights=None if epoch_w is None else epoch_w[a:b],
+                             context=None if epoch_c is None else epoch_c[a:b])
         if has_val:
             keep, trainer.loss_acc = trainer.loss_acc, trainer.val_acc
-            trainer.evaluate(val_data, weights=w_val)
+            trainer.evaluate(val_data, weights=w_val, context=c_val)
             trainer.loss_acc = keep
 
     # The host's share of an epoch - the permutation, its upload, the gather of the shuffled rows - is queued
@@ -455,6 +493,8 @@ def train_flow(flow_model, samples, max_epochs=None, patience=None, val_size=Non
         torch.index_select(train_data, 0, p, out=epoch_rows)
         if epoch_w is not None:
             torch.index_select(w_train, 0, p, out=epoch_w)
+        if epoch_c is not None:
+            torch.index_select(c_train, 0, p, out=epoch_c)
         if noise_scale:
             epoch_rows.add_(noise_scale * torch.randn_like(epoch_rows))
 

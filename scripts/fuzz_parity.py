@@ -29,6 +29,9 @@ from nessai_amd.flows import NeuralSplineFlow, RealNVP  # noqa: E402
 from oracle import flows as O  # noqa: E402
 
 ACTS = {"relu": torch.relu, "tanh": torch.tanh, "silu": torch.nn.functional.silu}
+#: --round5: widen the space by what round 5 added - any num_bins from 2 to 16, context_features, linear_transform="svd"
+#: (a different sequence of cases per seed than without the flag)
+ROUND5 = "--round5" in sys.argv
 
 
 def rms_err(a, b, floor=1.0):
@@ -50,6 +53,8 @@ def random_case(g):
         kw["activation"] = ACTS[act]
     if nsf:
         kw["num_bins"] = int(g.choice([4, 8, 10, 16]))
+        if ROUND5 and g.random() < 0.5:  # any bin count: the generic spline instance
+            kw["num_bins"] = int(g.integers(2, 17))
         if g.random() < 0.4:
             kw["linear_transform"] = str(g.choice(["lu", "permutation"]))
         if g.random() < 0.3:
@@ -71,6 +76,11 @@ def random_case(g):
             kw["actnorm"] = True
         if g.random() < 0.15:
             kw["pre_transform"] = "batch_norm"
+    if ROUND5:
+        if kw.get("net") != "mlp" and g.random() < 0.3:  # conditional flows
+            kw["context_features"] = int(g.choice([1, 2, 3, 7, 17, 40]))
+        if D >= 5 and D <= 64 and g.random() < 0.15:  # SVD-linear (nflows' identity initialisation needs D >= 5)
+            kw["linear_transform"] = "svd"
     return ("nsf" if nsf else "realnvp"), (D, H, blocks, layers), kw, act
 
 
@@ -79,6 +89,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, action="append", help="re-run these cases of the seed's sequence only (verbose)")
+    ap.add_argument("--round5", action="store_true", help="include generic bin counts, conditional flows and SVD-linear layers")
     args = ap.parse_args()
     g = np.random.default_rng(args.seed)
     failures, marginal, skipped, worst = [], [], 0, dict(log_prob=0.0, forward=0.0, inverse=0.0)
@@ -103,15 +114,19 @@ def main():
             continue
         x = torch.randn(n, shape[0], generator=torch.Generator().manual_seed(it)) * scale
         ref64 = copy.deepcopy(ref).double()  # the arbiter where float32 itself is ill-conditioned
+        ck, ck64, ckd = {}, {}, {}
+        if kw.get("context_features"):
+            c = torch.randn(n, kw["context_features"], generator=torch.Generator().manual_seed(it + 7))
+            ck, ck64, ckd = dict(context=c), dict(context=c.double()), dict(context=c.to(DEV))
         with torch.no_grad():
-            lp_ref = ref.log_prob(x)
-            z_ref, ld_ref = ref.forward(x)
-            xi_ref, ldi_ref = ref.inverse(x)
-            lp64 = ref64.log_prob(x.double())
-            xi64, ldi64 = ref64.inverse(x.double())
-            lp = flow.log_prob(x.to(DEV)).cpu()
-            z, ld = flow.forward(x.to(DEV))
-            xi, ldi = flow.inverse(x.to(DEV))
+            lp_ref = ref.log_prob(x, **ck)
+            z_ref, ld_ref = ref.forward(x, **ck)
+            xi_ref, ldi_ref = ref.inverse(x, **ck)
+            lp64 = ref64.log_prob(x.double(), **ck64)
+            xi64, ldi64 = ref64.inverse(x.double(), **ck64)
+            lp = flow.log_prob(x.to(DEV), **ckd).cpu()
+            z, ld = flow.forward(x.to(DEV), **ckd)
+            xi, ldi = flow.inverse(x.to(DEV), **ckd)
         # log_prob: the north_star bar against the float32 oracle, or - where the float32 oracle itself
         # is further than that from float64 (|log_prob| near zero, deep tails) - no worse than 3x its error
         e_lp = rel_err(lp, lp_ref, floor=1e-3)
@@ -120,7 +135,7 @@ def main():
         e_f = max(rel_err(z.cpu(), z_ref) / 2e-4, rel_err(ld.cpu(), ld_ref) / 5e-4)
         if e_f > 1.0:  # same rule as the inverse: 3x the float32 oracle's own distance from float64
             with torch.no_grad():
-                z64, ld64 = ref64.forward(x.double())
+                z64, ld64 = ref64.forward(x.double(), **ck64)
             if bool(torch.isfinite(z64).all() and torch.isfinite(ld64).all()):
                 e_f = max(rel_err(z.cpu(), z64) / max(2e-4, 3.0 * rel_err(z_ref, z64)),
                           rel_err(ld.cpu(), ld64) / max(5e-4, 3.0 * rel_err(ld_ref, ld64)))
@@ -151,7 +166,7 @@ def main():
                 for k in range(4):
                     sgn = torch.randint(0, 2, x.shape, generator=torch.Generator().manual_seed(1000 + k)).double() * 2 - 1
                     with torch.no_grad():
-                        xp, lp_ = ref64.inverse(x.double() * (1.0 + sgn * 2.0 ** -24))
+                        xp, lp_ = ref64.inverse(x.double() * (1.0 + sgn * 2.0 ** -24), **ck64)
                     rx, rl = max(rx, rel_err(xp, xi64)), max(rl, rel_err(lp_, ldi64))
                 e_i_cond = max(rel_err(xi.cpu(), xi64) / max(bar_x, 16.0 * rx), rel_err(ldi.cpu(), ldi64) / max(bar_l, 16.0 * rl))
         else:

@@ -76,6 +76,8 @@ class Emulator:
         self.f16 = int(h[P.H_PREC]) == 2
         name = {1: "rq", 2: "affine", 3: "additive"}[self.transform]
         self.C, self.FPC, self.NP = P.transform_policy(name, self.bins)
+        self.bn_within = bool(h[P.H_BNW])  # batch norm within the residual blocks: an {a, c} stage per block
+        self.n_ctx = int(h[P.H_CTX])  # context features of a conditional flow: columns D + 2 ... of a tile row
 
     # -- helpers ---------------------------------------------------------------
     def _stage_words(self, inverse, s):
@@ -119,11 +121,13 @@ class Emulator:
         return (x * (1.0 / (1.0 + np.exp(-x)))).astype(np.float32)
 
     # -- one tile ----------------------------------------------------------------
-    def run_tile(self, x_tile, inverse):
-        """x_tile: [32][D] float32 -> (out [32][D], logdet [32])."""
+    def run_tile(self, x_tile, inverse, ctx_tile=None):
+        """x_tile: [32][D] float32 (ctx_tile: [32][C]) -> (out [32][D], logdet [32])."""
         img = self.img
         D, HT = self.D, self.HT
         xt = x_tile.astype(np.float32).copy()
+        assert (ctx_tile is not None) == (self.n_ctx > 0)
+        ctx = np.zeros((xt.shape[0], 0), dtype=np.float32) if ctx_tile is None else ctx_tile.astype(np.float32)
         ops_off = int(img[P.H_OPS_INV if inverse else P.H_OPS_FWD])
         n_ops = int(img[P.H_NOPS_INV if inverse else P.H_NOPS_FWD])
         out_off = int(img[P.H_OUT_INV if inverse else P.H_OUT_FWD])
@@ -137,7 +141,8 @@ class Emulator:
             op = img[ops_off + 4 * o : ops_off + 4 * o + 4]
             kind = int(op[0])
             if kind == P.OP_COUPLING:
-                n_steps0, n_chunks = int(op[1]), int(op[2])
+                n_steps0, n_chunks, n_steps_c = int(op[1]), int(op[2]), int(op[3])
+                assert (n_steps_c > 0) == (self.n_ctx > 0)
                 st = self._stage_words(inverse, stage)
                 stage += 1
                 tl = (16 if self.bf16 else 2) * n_steps0
@@ -148,8 +153,9 @@ class Emulator:
                 def gather(tab, idx, pre=None):
                     # byte offsets into a row; an unused entry points at the row's zero cell, column D + 1
                     cols = tab[idx] // 4
-                    assert np.all(tab[idx] % 4 == 0) and np.all((cols < D) | (cols == D + 1))
-                    xz = np.concatenate([xt, np.zeros((xt.shape[0], 2), dtype=np.float32)], axis=1)
+                    assert np.all(tab[idx] % 4 == 0) and np.all((cols < D) | (cols == D + 1) | ((cols >= D + 2) & (cols < D + 2 + self.n_ctx)))
+                    # a tile row: D features, the spare cell, the zero cell, the context
+                    xz = np.concatenate([xt, np.zeros((xt.shape[0], 2), dtype=np.float32), ctx], axis=1)
                     vals = xz[row_of[:, None] if idx.ndim == 2 else row_of, cols]
                     if pre is not None:
                         vals = vals - pre[idx]
@@ -193,11 +199,43 @@ class Emulator:
                     acc = from_regs(st[32 * HT :], HT, inp, bias)
                     return np.concatenate([acc[ot] for ot in range(HT)], axis=1)
 
+                def gate():
+                    """sigmoid(Wc context + bc) of a conditional residual block: a stage laid out like layer 0"""
+                    nonlocal stage
+                    st = self._stage_words(inverse, stage)
+                    stage += 1
+                    tl = (16 if self.bf16 else 2) * n_steps_c
+                    c_tab = st[:tl].view(np.int32)
+                    fl = st.view(np.float32)
+                    bias = fl[tl : tl + 32 * HT]
+                    if self.bf16:
+                        w = st[tl + 32 * HT : tl + 32 * HT + HT * n_steps_c * 512]
+                        acc = self._dense16(w, HT, n_steps_c,
+                                            lambda s: gather(c_tab, 16 * s + 8 * half_of[:, None] + np.arange(8)[None, :]),
+                                            self._bias(bias, HT))
+                    else:
+                        w = fl[tl + 32 * HT : tl + 32 * HT + HT * n_steps_c * 64]
+                        acc = self._dense(w, HT, n_steps_c, lambda s: gather(c_tab, 2 * s + half_of), self._bias(bias, HT))
+                    g = np.concatenate([acc[ot] for ot in range(HT)], axis=1)
+                    return (1.0 / (1.0 + np.exp(-g.astype(np.float64)))).astype(np.float32)
+
+                def norm(v):
+                    """first batch norm of a residual block (batch_norm_within_layers): a stage {a, c} in the bias layout"""
+                    nonlocal stage
+                    fl = self._stage_words(inverse, stage).view(np.float32)
+                    stage += 1
+                    a = np.concatenate(self._bias(fl[: 32 * HT], HT), axis=1)
+                    c = np.concatenate(self._bias(fl[32 * HT : 64 * HT], HT), axis=1)
+                    return (v * a + c).astype(np.float32)
+
                 if self.net == 0:
                     for _ in range(self.n_layers):
-                        t = self._activate(h)
+                        t = self._activate(norm(h) if self.bn_within else h)
                         t = self._activate(hidden(t))
-                        h = (h + hidden(t)).astype(np.float32)
+                        t = hidden(t)
+                        if self.n_ctx:
+                            t = (t * gate()).astype(np.float32)
+                        h = (h + t).astype(np.float32)
                 else:
                     h = self._activate(h)
                     for _ in range(1, self.n_layers):
@@ -300,7 +338,7 @@ class Emulator:
         y = x - shift if inverse else x + shift
         return y.numpy(), np.zeros(len(x), dtype=np.float32)
 
-    def run(self, x, inverse):
+    def run(self, x, inverse, context=None):
         x = np.asarray(x, dtype=np.float32)
         n = x.shape[0]
         out = np.zeros_like(x)
@@ -309,7 +347,11 @@ class Emulator:
             tile = np.zeros((32, self.D), dtype=np.float32)
             m = min(32, n - r0)
             tile[:m] = x[r0 : r0 + m]
-            o, l = self.run_tile(tile, inverse)
+            ctile = None
+            if context is not None:
+                ctile = np.zeros((32, self.n_ctx), dtype=np.float32)
+                ctile[:m] = np.asarray(context, dtype=np.float32)[r0 : r0 + m]
+            o, l = self.run_tile(tile, inverse, ctile)
             out[r0 : r0 + m] = o[:m]
             ld[r0 : r0 + m] = l[:m]
         return out, ld

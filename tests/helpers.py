@@ -19,6 +19,8 @@ def randomise(flow, seed=0):
                 or name.endswith(".shift")
             ):
                 p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif "batch_norm_layers" in name and name.endswith(".weight"):  # batch norm within the residual blocks
+                p.mul_(0.5 + torch.rand(p.shape, generator=g))
             elif "q_vectors" in name:  # Householder vectors of an SVD-linear layer: off their identity pairs
                 p.add_(0.3 * torch.randn(p.shape, generator=g))
         for name, b in flow.named_buffers():

@@ -1,0 +1,124 @@
+"""``batch_norm_within_layers`` (eval mode) on the gfx950 kernels against the CPU oracle (runs on a real MI355X).
+
+Reference: ``batch_norm_within_layers`` is passed to nflows' ``ResidualNet`` as ``use_batch_norm``
+(``src/nessai/flows/nsf.py:85-95``, ``flows/realnvp.py:136-146``): every residual block gets two
+``BatchNorm1d(features, eps=1e-3)``, one in front of each activation.  In eval mode both are per-feature affines on
+the running statistics: the kernels apply the first from a stage of its own in front of the block (format word
+``NSA_H_BNW``) and the packer folds the second into the block's first linear layer.  Training such a flow needs batch
+statistics inside the conditioner, which the training kernels do not have: refused loudly.
+"""
+import pytest
+import torch
+
+from helpers import DEV, randomise, rel_err
+from nessai_amd.flows import NeuralSplineFlow, RealNVP
+from oracle import flows as O
+
+pytestmark = pytest.mark.gpu
+
+X_TOL = 1e-5       # |a - b| / max(|b|, 1): the parity bar of tests/test_gpu_flows.py
+LOG_PROB_RTOL = 1e-5
+
+CASES = {
+    "nsf_d6": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 16, 3, 2), dict(batch_norm_within_layers=True)),
+    "rnvp_d8_h40_tanh": (RealNVP, O.RealNVP, (8, 40, 2, 3), dict(batch_norm_within_layers=True, activation=torch.tanh)),
+    "nsf_c3_shape": (NeuralSplineFlow, O.NeuralSplineFlow, (32, 64, 6, 2), dict(batch_norm_within_layers=True)),
+    "nsf_h128_silu": (NeuralSplineFlow, O.NeuralSplineFlow, (10, 128, 2, 1),
+                      dict(batch_norm_within_layers=True, batch_norm_between_layers=True,
+                           activation=torch.nn.functional.silu)),
+    "nsf_d5_ctx2": (NeuralSplineFlow, O.NeuralSplineFlow, (5, 16, 2, 2),
+                    dict(batch_norm_within_layers=True, context_features=2)),
+}
+
+
+def _pair(name, seed=7):
+    P, Oc, args, kw = CASES[name]
+    torch.manual_seed(seed)
+    ref = Oc(*args, **kw)
+    randomise(ref, seed)  # (moves the running statistics and the scales / shifts of the inner batch norms too)
+    with torch.no_grad():  # the blocks' last layers start near zero: let the blocks - and their batch norms - matter
+        for pname, p in ref.named_parameters():
+            if "linear_layers.1" in pname:
+                p.add_(0.1 * torch.randn(p.shape))
+    ref.eval()
+    flow = P(*args, **kw)
+    assert set(flow.state_dict()) == set(ref.state_dict())
+    flow.load_state_dict(ref.state_dict())
+    flow.to(DEV)
+    flow.eval()
+    return ref, flow, args[0], kw.get("context_features")
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_batch_norm_within_matches_oracle(name, precision):
+    ref, flow, D, C = _pair(name)
+    flow.precision = precision
+    x = torch.randn(3000, D) * 1.3
+    ctx = dict(context=torch.randn(3000, C)) if C else {}
+    dctx = dict(context=ctx["context"].to(DEV)) if C else {}
+    with torch.no_grad():
+        z_ref, ld_ref = ref.forward(x, **ctx)
+        xi_ref, ldi_ref = ref.inverse(x, **ctx)
+        lp_ref = ref.log_prob(x, **ctx)
+        # the batch norms matter for these weights: the same flow with their statistics reset gives other numbers
+        import copy
+        plain = copy.deepcopy(ref)
+        for m in plain.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+                m.reset_parameters()
+        assert float((plain.log_prob(x, **ctx) - lp_ref).abs().max()) > 1e-2
+    z, ld = flow.forward(x.to(DEV), **dctx)
+    xi, ldi = flow.inverse(x.to(DEV), **dctx)
+    lp = flow.log_prob(x.to(DEV), **dctx)
+    k = 20.0 if precision == "bf16x3" else 1.0  # the split-bf16 envelope
+    assert rel_err(z.cpu(), z_ref) <= X_TOL * k
+    assert rel_err(ld.cpu(), ld_ref) <= X_TOL * k
+    assert rel_err(xi.cpu(), xi_ref) <= X_TOL * k
+    assert rel_err(ldi.cpu(), ldi_ref) <= X_TOL * k
+    assert rel_err(lp.cpu(), lp_ref, floor=1e-3) <= LOG_PROB_RTOL * k
+    # round trip at the reference's own bar (tests/test_flows/test_included_flows.py:144-154, decimal=5)
+    if precision != "bf16x3":
+        x_back, ld_back = flow.inverse(z, **dctx)
+        assert float((x_back.cpu() - x).abs().max()) < 1.5e-5 * max(1.0, float(x.abs().max()))
+        assert float((ld_back + ld).abs().max()) < 1.5e-5 * max(1.0, float(ld.abs().max()))
+
+
+def test_sampling_and_populate_style_passes_run_the_same_kernel_family():
+    """sample_and_log_prob (the Philox draw inside the kernel) of a flow with inner batch norms: the log-density it
+    returns is the flow's log_prob of the returned rows."""
+    ref, flow, D, _ = _pair("nsf_c3_shape")
+    flow.precision = "f16x3"
+    x, lp = flow.sample_and_log_prob(5000)
+    with torch.no_grad():
+        lp_ref = ref.log_prob(x.cpu())
+    assert rel_err(lp.cpu(), lp_ref, floor=1e-3) <= LOG_PROB_RTOL
+
+
+def test_training_mode_and_training_are_refused():
+    _, flow, D, _ = _pair("nsf_d6")
+    from nessai_amd.train import Trainer
+
+    with pytest.raises(NotImplementedError, match="batch_norm_within_layers"):
+        Trainer(flow)
+    flow.train()
+    with pytest.raises(RuntimeError, match="eval"):
+        flow.log_prob(torch.randn(10, D, device=DEV))
+    flow.eval()
+    assert flow.log_prob(torch.randn(10, D, device=DEV)).shape == (10,)
+
+
+def test_changed_running_statistics_repack_the_image():
+    ref, flow, D, _ = _pair("nsf_d6")
+    x = torch.randn(500, D)
+    a = flow.log_prob(x.to(DEV)).cpu()
+    with torch.no_grad():
+        for m_ref, m in zip(ref.modules(), flow.modules()):
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m_ref.running_mean += 0.2
+                m.running_mean += 0.2
+        b_ref = ref.log_prob(x)
+    b = flow.log_prob(x.to(DEV)).cpu()
+    assert float((a - b).abs().max()) > 1e-3
+    assert rel_err(b, b_ref, floor=1e-3) <= LOG_PROB_RTOL

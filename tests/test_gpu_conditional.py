@@ -1,0 +1,130 @@
+"""Conditional flows (``context_features``) on the gfx950 kernels against the CPU oracle (runs on a real MI355X).
+
+Reference: ``context_features`` reaches every residual block of the conditioner - the initial layer takes
+``cat(inputs, context)``, every block ends in ``glu(cat(temps, context_layer(context)))``
+(``src/nessai/flows/nsf.py:85-95``, ``flows/realnvp.py:136-146``; nflows ``ResidualNet``) - and every method of the
+flow API takes ``context=`` (``flows/base.py:209-287``).  The reference's own test of it:
+``tests/test_flows/test_included_flows.py:157-170``.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import DEV, randomise, rel_err
+from nessai_amd.flows import NeuralSplineFlow, RealNVP
+from oracle import flows as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # the reference's fixture: Flow(D, 8, 2, 2, context_features=1, batch_norm_between_layers=False)
+    "nsf_d2_c1": (NeuralSplineFlow, O.NeuralSplineFlow, (2, 8, 2, 2), dict(context_features=1, batch_norm_between_layers=False)),
+    "rnvp_d4_c1": (RealNVP, O.RealNVP, (4, 8, 2, 2), dict(context_features=1, batch_norm_between_layers=False)),
+    "nsf_d32_c3": (NeuralSplineFlow, O.NeuralSplineFlow, (32, 64, 3, 2), dict(context_features=3)),
+    "rnvp_default_c5": (RealNVP, O.RealNVP, (16, 32, 4, 2), dict(context_features=5)),  # LU-linear + batch norm between
+    "nsf_d6_h128_c20_tanh": (NeuralSplineFlow, O.NeuralSplineFlow, (6, 128, 2, 1),
+                             dict(context_features=20, activation=torch.tanh, num_bins=4)),
+}
+
+
+def _pair(name, seed=5):
+    P, Oc, args, kw = CASES[name]
+    torch.manual_seed(seed)
+    ref = Oc(*args, **kw)
+    randomise(ref, seed)
+    with torch.no_grad():  # the blocks' last layers start near zero: give the gates something to gate
+        for pname, p in ref.named_parameters():
+            if "linear_layers.1" in pname:
+                p.add_(0.1 * torch.randn(p.shape))
+    ref.eval()
+    flow = P(*args, **kw)
+    assert set(flow.state_dict()) == set(ref.state_dict())
+    flow.load_state_dict(ref.state_dict())
+    flow.to(DEV)
+    flow.eval()
+    return ref, flow, args[0], kw["context_features"]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_conditional_flow_matches_oracle(name, precision):
+    ref, flow, D, C = _pair(name)
+    flow.precision = precision
+    x = torch.randn(3000, D) * 1.3
+    c = torch.randn(3000, C)
+    with torch.no_grad():
+        z_ref, ld_ref = ref.forward(x, context=c)
+        xi_ref, ldi_ref = ref.inverse(x, context=c)
+        lp_ref = ref.log_prob(x, context=c)
+        lp_other = ref.log_prob(x, context=c.flip(0))
+    assert float((lp_ref - lp_other).abs().max()) > 1e-2  # the context matters for these weights
+    xd, cd = x.to(DEV), c.to(DEV)
+    z, ld = flow.forward(xd, context=cd)
+    xi, ldi = flow.inverse(xd, context=cd)
+    lp = flow.log_prob(xd, context=cd)
+    z2, lp2 = flow.forward_and_log_prob(xd, context=cd)
+    assert torch.equal(z, z2) and torch.equal(lp, lp2)
+    k = 10.0 if precision == "bf16x3" else 1.0
+    assert rel_err(z.cpu(), z_ref) <= 2e-4 * k
+    assert rel_err(ld.cpu(), ld_ref) <= 5e-4 * k
+    assert rel_err(xi.cpu(), xi_ref) <= 2e-4 * k
+    assert rel_err(ldi.cpu(), ldi_ref) <= 5e-4 * k
+    if precision != "bf16x3":
+        assert rel_err(lp.cpu(), lp_ref, floor=1e-3) <= 1e-5
+    else:
+        assert rel_err(lp.cpu(), lp_ref) <= 2e-4
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", ["nsf_d2_c1", "rnvp_d4_c1"])
+def test_sample_and_log_prob_conditional(name, precision):
+    """The reference's property test (tests/test_flows/test_included_flows.py:157-170): draws under a context and
+    their log-probabilities agree with ``log_prob(x, context)`` to 5 decimals."""
+    _, flow, D, C = _pair(name)
+    flow.precision = precision
+    c = torch.randn(1000, C, device=DEV)
+    with torch.inference_mode():
+        x, log_prob = flow.sample_and_log_prob(1000, context=c)
+        target = flow.log_prob(x, context=c)
+        xs = flow.sample(1000, context=c)
+    assert x.shape == (1000, D) and xs.shape == (1000, D)
+    np.testing.assert_array_almost_equal(log_prob.cpu().numpy(), target.cpu().numpy(), decimal=4)
+    assert float((log_prob - target).abs().max()) < 5e-5
+
+
+def test_context_argument_is_checked():
+    _, flow, D, C = _pair("rnvp_d4_c1")
+    x = torch.randn(10, D, device=DEV)
+    with pytest.raises(ValueError, match="needs a context"):
+        flow.log_prob(x)
+    with pytest.raises(ValueError, match="Expected a context of shape"):
+        flow.log_prob(x, context=torch.randn(9, C, device=DEV))
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        flow.log_prob(x, context=torch.randn(10, C))
+    plain = RealNVP(4, 8, 2, 2)
+    plain.to(DEV)
+    plain.eval()
+    with pytest.raises(ValueError, match="takes no context"):
+        plain.log_prob(x, context=torch.randn(10, 1, device=DEV))
+    with pytest.raises(NotImplementedError, match="MLP with conditional inputs"):
+        RealNVP(4, 8, 2, 2, net="mlp", context_features=2)
+
+
+def test_flowmodel_numpy_boundary_with_conditional(tmp_path):
+    """FlowModel.forward_and_log_prob / inverse / log_prob / sample / sample_and_log_prob(conditional=...)
+    (src/nessai/flowmodel/base.py:782-948)."""
+    from nessai_amd.flowmodel import FlowModel
+
+    fm = FlowModel(flow_config=dict(n_inputs=4, n_neurons=8, n_blocks=2, n_layers=2, ftype="realnvp",
+                                    context_features=2, batch_norm_between_layers=False),
+                   output=str(tmp_path), rng=np.random.default_rng(1))
+    fm.initialise()
+    g = np.random.default_rng(0)
+    x, c = g.normal(size=(50, 4)), g.normal(size=(50, 2))
+    z, lp = fm.forward_and_log_prob(x, conditional=c)
+    xr, lj = fm.inverse(z, conditional=c)
+    np.testing.assert_allclose(xr, x.astype(np.float32), atol=2e-5)
+    np.testing.assert_allclose(fm.log_prob(x, conditional=c), lp, rtol=0, atol=0)
+    xs, lps = fm.sample_and_log_prob(50, conditional=c)
+    np.testing.assert_allclose(fm.log_prob(xs, conditional=c), lps, atol=5e-5)
+    assert fm.sample(50, conditional=c).shape == (50, 4)

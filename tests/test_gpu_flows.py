@@ -485,7 +485,7 @@ def test_images_rebuilt_on_the_device_equal_the_host_pack():
             assert rel_err(flow.log_prob(x).cpu(), ref.log_prob(x.cpu()), floor=1e-3) <= LOG_PROB_RTOL
 
 
-def test_auto_noise_floor_branch_on_a_flow_captured_mid_run():
+def test_auto_noise_floor_branch_on_a_flow_captured_mid_run(monkeypatch):
     """The loosened branch of ``precision = "auto"`` on REAL weights: ``tests/golden/c3_ns_retrain_noise_floor.npz``
     is the flow of one retraining of a 60 000-iteration nested-sampling run on config 3 (``scripts/run_ns_c3.py
     --iterations 60000 --seed 42 --save-branch``; about one training in thirty of such runs lands here) whose probe
@@ -494,7 +494,12 @@ def test_auto_noise_floor_branch_on_a_flow_captured_mid_run():
     evaluation is unique to 1e-5.  The documented rule: split-f16 is kept if it is within
     4 x that one-ulp response and never left the f16 range - and what that buys is checked here against a
     float64 twin of the oracle: split-f16 is as close to float64 as the exact-float32 kernel and as the float32
-    oracle (``flow.log_prob`` semantics: src/nessai/flows/base.py:236-245)."""
+    oracle (``flow.log_prob`` semantics: src/nessai/flows/base.py:236-245).
+
+    Round 5: with the spline's softmax evaluated without its shift (csrc/nsa_device.h, NsaRQ::knots) the SAME weights
+    probe at 7e-7 - the two kernels no longer disagree through which of two nearly equal logits is the maximum -
+    so this flow now passes the plain bar.  The branch is still the rule for flows that do not: it is exercised
+    here by lowering the bar below the measured difference; the float64 comparison is unchanged."""
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_ns_retrain_noise_floor.npz"))
     state = {k: torch.from_numpy(gold[k]) for k in gold.files if not k.startswith("__")}
     torch.manual_seed(0)
@@ -507,12 +512,16 @@ def test_auto_noise_floor_branch_on_a_flow_captured_mid_run():
     flow.eval()
     flow.precision = "auto"
     flow.device_image()
+    assert flow.effective_precision == "f16x3" and flow.probe_errors["f16x3"] <= flow.AUTO_PROBE_BAR
+    assert flow.probe_errors["f16x3"] < 0.25 * float(gold["__probe_f16x3"])  # (1.9e-5 with the shifted softmax)
+    # the rule of the loosened branch: above the (lowered) bar, inside the noise-floor allowance, kept
+    monkeypatch.setattr(type(flow), "AUTO_PROBE_BAR", 0.5 * flow.probe_errors["f16x3"])
+    flow._image_key = None
+    flow.device_image()
     noise = flow.probe_errors.get("f32_one_ulp")
-    # the rule, on this flow: above the plain bar, inside the noise-floor allowance, kept
     assert flow.probe_errors["f16x3"] > flow.AUTO_PROBE_BAR and noise is not None
     assert flow.probe_errors["f16x3"] <= flow.AUTO_NOISE_FACTOR * noise
     assert flow.effective_precision == "f16x3" and flow._status.tolist()[1] == 0
-    assert abs(flow.probe_errors["f16x3"] - float(gold["__probe_f16x3"])) <= 0.5 * float(gold["__probe_f16x3"])
 
     # what it means for the results: the probe's own latents through the oracle in float32 and in float64
     z = torch.randn(flow.AUTO_PROBE_ROWS, 32, generator=torch.Generator().manual_seed(20260930))

@@ -34,7 +34,8 @@ def _pair(kind, dim, seed):
     ref = Oc(dim, 8, 2, 2, batch_norm_between_layers=False).eval()
     flow = P(dim, 8, 2, 2, batch_norm_between_layers=False)
     flow.load_state_dict(ref.state_dict())
-    flow.to(DEV).eval()
+    flow.to(DEV)  # (returns None, as the reference's BaseFlow.to)
+    flow.eval()
     return ref, flow
 
 

@@ -28,6 +28,10 @@ CONFIGS = {
     "nsf_k5": (O.NeuralSplineFlow, (4, 8, 2, 2), dict(num_bins=5)),
     "nsf_k2_d7": (O.NeuralSplineFlow, (7, 40, 2, 1), dict(num_bins=2)),
     "nsf_k13_lu": (O.NeuralSplineFlow, (5, 16, 2, 2), dict(num_bins=13, linear_transform="lu")),
+    # batch norm within the residual blocks (eval mode): an {a, c} stage in front of every block, the second
+    # batch norm folded into the block's first linear layer
+    "nsf_bnw": (O.NeuralSplineFlow, (4, 8, 2, 2), dict(batch_norm_within_layers=True)),
+    "rnvp_bnw_lu_h40": (O.RealNVP, (6, 40, 2, 3), dict(batch_norm_within_layers=True, activation=torch.tanh)),
     "rnvp_svd": (O.RealNVP, (6, 16, 2, 2), dict(linear_transform="svd")),
     # act norm -> permutation -> LU per block (the element-wise map is folded into the dense op BEHIND it in
     # the forward direction and into the one in FRONT of it in the inverse direction)
@@ -79,6 +83,42 @@ def test_emulated_kernel_matches_oracle(name, precision):
     assert np.abs(lde - ld.numpy()).max() < 1e-4 * tol
     assert np.abs(xe - xi.numpy()).max() < 5e-5 * scale * tol
     assert np.abs(ldie - ldi.numpy()).max() < 1e-4 * tol
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("case", ["nsf_ctx1", "rnvp_ctx3_lu", "nsf_ctx2_bnw"])
+def test_emulated_conditional_flow_matches_oracle(case, precision):
+    """context_features: the context joins layer 0 of every conditioner and gates every residual block
+    (nflows ResidualNet; src/nessai/flows/nsf.py:85-95, flows/realnvp.py:136-146)."""
+    cls, args, kw = {"nsf_ctx1": (O.NeuralSplineFlow, (4, 8, 2, 2), dict(context_features=1)),
+                     "rnvp_ctx3_lu": (O.RealNVP, (6, 16, 2, 2), dict(context_features=3)),
+                     "nsf_ctx2_bnw": (O.NeuralSplineFlow, (5, 16, 2, 2), dict(context_features=2, batch_norm_within_layers=True)),
+                     }[case]
+    torch.manual_seed(4)
+    flow = cls(*args, **kw)
+    randomise(flow, 4)
+    with torch.no_grad():  # the blocks' last layers start at ~0: make the gates matter
+        for name, p in flow.named_parameters():
+            if "linear_layers.1" in name:
+                p.add_(0.3 * torch.randn(p.shape))
+    flow.train()
+    flow.eval()
+    em = Emulator(P.pack_flow(dict(describe(flow), precision=precision)))
+    assert em.n_ctx == kw["context_features"]
+    x = torch.randn(70, args[0]) * 1.5
+    c = torch.randn(70, kw["context_features"])
+    with torch.no_grad():
+        z, ld = flow.forward(x, context=c)
+        xi, ldi = flow.inverse(x, context=c)
+        z0, _ = flow.forward(x, context=torch.zeros_like(c))
+    assert float((z - z0).abs().max()) > 1e-2  # the context does something
+    ze, lde = em.run(x.numpy(), False, context=c.numpy())
+    xe, ldie = em.run(x.numpy(), True, context=c.numpy())
+    scale = max(1.0, float(xi.abs().max()))
+    assert np.abs(ze - z.numpy()).max() < 5e-5
+    assert np.abs(lde - ld.numpy()).max() < 1e-4
+    assert np.abs(xe - xi.numpy()).max() < 5e-5 * scale
+    assert np.abs(ldie - ldi.numpy()).max() < 1e-4
 
 
 def test_product_and_oracle_trees_pack_identically():
@@ -180,9 +220,14 @@ def test_unsupported_configurations_fail_loudly():
     NeuralSplineFlow(4, 8, 2, 2, num_bins=7)  # the generic spline instance
     with pytest.raises(ValueError):
         NeuralSplineFlow(4, 300, 2, 2)
-    with pytest.raises(NotImplementedError):
-        NeuralSplineFlow(4, 8, 2, 2, context_features=2)
+    assert NeuralSplineFlow(4, 8, 2, 2, context_features=2).context_features == 2  # conditional flows: built
+    with pytest.raises(NotImplementedError, match="MLP with conditional inputs"):
+        RealNVP(4, 8, 2, 2, net="mlp", context_features=2)
     RealNVP(6, 8, 2, 2, linear_transform="svd")  # eval-mode SVD-linear: the dense op (training it raises)
+    bnw = NeuralSplineFlow(4, 8, 2, 2, batch_norm_within_layers=True)  # eval-mode batch norm within the blocks: built
+    assert P.pack_flow(describe(bnw.eval()))[P.H_BNW] == 1
+    with pytest.raises(RuntimeError, match="eval"):  # ... and in eval mode only (checked before any device work)
+        bnw.train().forward(torch.zeros(2, 4))
     with pytest.raises(ValueError, match="at least 2"):
         RealNVP(1, 8, 2, 2)
     with pytest.raises(RuntimeError, match="actnorm and batchnorm"):
