@@ -14,6 +14,7 @@
 
 #ifndef NSA_DEFAULT_OCC
 #define NSA_DEFAULT_OCC 2
+#define NSA_TEAM_MIN_HT 2  // conditioners of >= 64 features take the loader geometry on small batches (nsa_launch_flow)
 #endif
 #ifndef NSA_DEFAULT_SKEW
 #define NSA_DEFAULT_SKEW 1
@@ -35,7 +36,7 @@ static int nsa_fail(int code, const char* fmt, ...) {
 
 extern "C" const char* nsa_last_error(void) { return g_err; }
 
-static thread_local int g_last_geometry[5] = {0, 0, 0, 0, 0};
+static thread_local int g_last_geometry[6] = {0, 0, 0, 0, 0, 0};
 extern "C" void nsa_last_geometry(int* waves_per_simd, int* waves_per_group, int* groups) {
   if (waves_per_simd != nullptr) *waves_per_simd = g_last_geometry[0];
   if (waves_per_group != nullptr) *waves_per_group = g_last_geometry[1];
@@ -43,6 +44,9 @@ extern "C" void nsa_last_geometry(int* waves_per_simd, int* waves_per_group, int
 }
 extern "C" int nsa_last_row_tiles(void) { return g_last_geometry[3]; }
 extern "C" int nsa_last_resident(void) { return g_last_geometry[4]; }
+static thread_local int g_last_ring = 0;
+extern "C" int nsa_last_team(void) { return g_last_geometry[5]; }
+extern "C" int nsa_last_ring(void) { return g_last_geometry[5] ? g_last_ring : 0; }
 extern "C" int nsa_version(void) { return NSA_VERSION; }
 
 // ---------------------------------------------------------------------------
@@ -367,11 +371,72 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
       g_last_geometry[1] = w;
       g_last_geometry[2] = (int)grid;
       g_last_geometry[4] = 1;
+      g_last_geometry[5] = 0;
       return NSA_OK;
+    }
+  }
+  // Small-batch geometry (NsaLaunch::team / ring / loader, nsa_flow_kernel.h): a batch with fewer tiles than the chip
+  // has CUs is pure latency - one workgroup per tile walks the whole program, and requesting the stage copies cost the
+  // computing wave a quarter of its time (60 - 200 cycles per 1 KiB piece).  Such a launch gets, per tile, ONE
+  // computing wave, a LOADER wave that only requests the copies, and a ring of up to eight stage buffers: config 4's
+  // 5050 rows (158 tiles, 128-wide conditioner, 4 MB program) 0.40 -> 0.325 ms, a 192-wide flow 0.38 -> 0.27, config 3's
+  // flow over 2000 rows 0.149 -> 0.136 (gpurun_out r05n; 32-wide conditioners gain nothing and keep the staged
+  // geometry).  Teams of 2 / 4 / 8 computing waves per tile (NESSAI_AMD_TEAM) share the trunk's work badly - the chunk
+  // stages still run one after the other - and measured slower than one wave with a loader: kept as pinned options,
+  // same rows bit for bit (tests/test_gpu_team.py).  NESSAI_AMD_TEAM=0 switches the geometry off, NESSAI_AMD_LOADER=0
+  // the loader, NESSAI_AMD_RING pins the ring's depth.
+  {
+    int team = 0;
+    const char* te = getenv("NESSAI_AMD_TEAM");
+    if (te != nullptr) team = atoi(te);
+    else if (h[NSA_H_HT] >= NSA_TEAM_MIN_HT && n_tiles * n_flows <= (long long)g_num_cus && waves_per_group <= 0 &&
+             force_occ == 0 && getenv("NESSAI_AMD_OCC") == nullptr)
+      team = 1;
+    if (team == 1 || team == 2 || team == 4 || team == 8) {  // (1: a wave per tile and workgroup, on the deep stage ring)
+      const size_t one_stage = (size_t)h[NSA_H_MAX_STAGE] * 4;
+      // one team per workgroup: its tile, the parked floats / running maximum / bad-root counts of its waves, the
+      // record of Jacobian terms, the populate constants and the program - and as many stage buffers as fit beside
+      // them, up to eight (NsaRingPipe: the copies of a small batch are requested ring - 1 stages ahead)
+      // (+ the loader: one more wave that only requests the stage copies, NsaLaunch::loader; NESSAI_AMD_LOADER=0: none)
+      const char* le = getenv("NESSAI_AMD_LOADER");
+      const int loader = ((le != nullptr && le[0] == '0') || team == 8) ? 0 : 1;  // (8 + 1 waves: over the instances' 512 threads)
+      const size_t fixed = (((size_t)NSA_ROWS * XS + 3) & ~(size_t)3) * 4 + (size_t)(team + loader) * (256 + 8 + 256) +
+                           (size_t)64 * ((D + 1) / 2 + 16) * 4 + epi_bytes + prog_bytes;
+      int ring = one_stage > 0 && g_max_lds > fixed ? (int)((g_max_lds - fixed) / one_stage) : 0;
+      if (ring > 8) ring = 8;
+      {
+        const char* re = getenv("NESSAI_AMD_RING");  // pins the ring's depth (2 = the plain double buffer)
+        if (re != nullptr && atoi(re) >= 2 && atoi(re) < ring) ring = atoi(re);
+      }
+      const size_t lds = fixed + (size_t)ring * one_stage;
+      if (ring >= 2) {
+        p.ext = 1;
+        p.team = team;
+        p.ring = ring;
+        p.loader = loader;
+        p.resident = 0;
+        p.occupancy = NSA_DEFAULT_OCC;
+        p.row_tiles = 1;
+        p.skew = 0;
+        p.prio = 0;
+        long long grid = n_tiles;
+        if (max_groups > 0 && grid > max_groups) grid = max_groups;
+        hipError_t e = fn(&p, (unsigned)grid, (unsigned)n_flows, (unsigned)((team + loader) * 64), lds, stream);
+        if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "flow kernel launch (team): %s", hipGetErrorString(e));
+        g_last_geometry[0] = NSA_DEFAULT_OCC;
+        g_last_geometry[3] = 1;
+        g_last_geometry[1] = team;
+        g_last_geometry[2] = (int)grid;
+        g_last_geometry[4] = 0;
+        g_last_geometry[5] = team;
+        g_last_ring = ring;
+        return NSA_OK;
+      }
     }
   }
   p.resident = 0;
   g_last_geometry[4] = 0;
+  g_last_geometry[5] = 0;
   int occ = force_occ != 0 ? force_occ
                            : nsa_occupancy((int)h[NSA_H_HT], p.precision, n_tiles, n_flows, g_num_cus, waves_per_group);
   if (p.ext && waves_per_group > 8) waves_per_group = 8;

@@ -161,6 +161,24 @@ __device__ __forceinline__ void nsa_glds16(const uint32_t* gsrc_lane, float* lds
       (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
 }
 
+// The same copy as one the COMPILER does not know to be a vector-memory write to LDS (inline assembly; M0 - the
+// LDS base of an LDS-DMA - saved and restored inside it).  hipcc orders LDS reads it cannot tell from the copy's
+// destination - and register reuse next to it - behind every pending LDS-DMA with an s_waitcnt vmcnt(0) of its own
+// (scripts/isa_waits.py shows them): harmless with ONE copy in flight that the stage waits for anyway, fatal for a
+// ring that keeps several stages on their way (NsaRingPipe, nsa_flow_kernel.h) - there every wait on the counter is
+// written out (nsa_wait_vmcnt) and the reads of a buffer sit behind the counted wait and a barrier.
+__device__ __forceinline__ void nsa_glds16_raw(const uint32_t* gsrc_lane, float* lds_base_uniform) {
+  const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds_base_uniform;
+  // (no scalar operand: the base goes in as a VECTOR register and is made scalar inside, with VCC as the scratch pair -
+  // with an "s" operand, in or out, the instances that spill - 256-wide conditioners - did not compile: "illegal
+  // VGPR to SGPR copy")
+  asm volatile("s_mov_b32 vcc_hi, m0\n\tv_readfirstlane_b32 vcc_lo, %0\n\ts_mov_b32 m0, vcc_lo\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, vcc_hi"
+               :
+               : "v"(base), "v"(gsrc_lane)
+               : "vcc");
+}
+
 // ---------------------------------------------------------------------------
 // Philox4x32-10 counter-based generator (Salmon et al. 2011) + Box-Muller.
 // Counter = (global row lo, global row hi, quad index, stream); key = seed.

@@ -163,6 +163,19 @@ struct NsaLaunch {
   const float* ctx_in;
   // 1: the flow needs the extended-conditioner instances (NSA_H_CTX > 0 or NSA_H_BNW != 0; set by nsa_launch_flow)
   int ext;
+  // team geometry (extended instances only; small batches of wide flows - nsa_launch_flow): `team` waves share ONE
+  // 32-row tile.  Every member runs the conditioner's trunk, the chunks of its last layer - the parameters and the
+  // element-wise transform of 2 FPC features each - are dealt round the members; the Jacobian terms meet in LDS and
+  // are summed by member 0 in the order one wave sums them, so the rows come out bit for bit as in any other
+  // geometry.  0 / 1: off.
+  int team;
+  // extended instances: buffers of the stage ring (NsaRingPipe), 2 ... 8; 0 = 2
+  int ring;
+  // extended instances: 1 = the LAST wave of every workgroup is a loader - it requests every stage copy and computes
+  // nothing, the others request none.  Requesting a 1 KiB piece costs the requesting wave 60 - 200 cycles (the CU's
+  // LDS-DMA path takes one per ~60 cycles, MI355X_MICROARCH.md): spread over the computing waves of a small batch
+  // that was a quarter of their time, and the copies' landing waited for the arithmetic to get out of the way.
+  int loader;
   // static wave priority (MI355X_MICROARCH.md, "static priority for the younger half"): 1 = the upper half of the
   // workgroup's waves runs at s_setprio 1 for the whole kernel (the default of the staged two-tiles geometry: nsa_api.hip),
   // 2 = the lower half, 0 = off; NESSAI_AMD_PRIO pins it
@@ -227,9 +240,19 @@ __device__ __forceinline__ double nsa_log_prior_term(int kind, double x, const d
 #define NSA_SKEW_MASK 7
 #endif
 
+// 1: the stage table is read from the image by scalar loads (NsaStagePipe::load_entry; 0 = from its LDS copy).  Same
+// box, interleaved twice (gpurun_out r05k): config 3's lean draw kernel 1.513 against 1.533 ms per 1e6 rows; the
+// copies as LDS-DMAs the compiler does not see (NSA_GLDS_RAW) add nothing to it.
+#ifndef NSA_TABLE_SCALAR
+#define NSA_TABLE_SCALAR 1
+#endif
+#ifndef NSA_GLDS_RAW
+#define NSA_GLDS_RAW 0  // 1: the stage copies as LDS-DMAs the compiler does not see (nsa_glds16_raw)
+#endif
 struct NsaStagePipe {
   const uint32_t* img;
   const uint32_t* table;  // {src word offset, n words} per stage (the workgroup's LDS copy)
+  const uint32_t* gtable; // ... and in the image (NSA_TABLE_SCALAR)
   int n_stages;
   float* buf0;
   float* buf1;
@@ -271,12 +294,25 @@ struct NsaStagePipe {
     if ((NSA_ABLATE & 1) && cur >= 0) return;
     const uint32_t* src = img + off;
     const int pieces = (int)((words + 255) >> 8);  // the last piece may run over the stage's end (nsa_format.h)
+#if NSA_GLDS_RAW
+    for (int c = wave + part * nw; c < pieces; c += parts * nw) nsa_glds16_raw(src + c * 256 + lane * 4, dst + c * 256);
+#else
     for (int c = wave + part * nw; c < pieces; c += parts * nw) nsa_glds16(src + c * 256 + lane * 4, dst + c * 256);
+#endif
   }
   __device__ __forceinline__ void load_entry(int s) {
+#if NSA_TABLE_SCALAR
+    // (scalar loads from the image instead of the workgroup's LDS copy: hipcc puts an s_waitcnt vmcnt(0) of its own in
+    // front of an LDS read it cannot tell from the pending LDS-DMA's destination - right behind the copy's request
+    // in the stages where it does not sink the read below the MFMAs; scripts/isa_waits.py)
+    const auto* e = (const __attribute__((address_space(4))) uint32_t*)gtable + 2 * s;
+    nxt_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]);
+    nxt_words = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[1]);
+#else
     const uint2 e = *(const uint2*)(table + 2 * s);
     nxt_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
     nxt_words = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+#endif
   }
   // first stage of the program for this workgroup
   __device__ __forceinline__ void prime() {
@@ -342,6 +378,162 @@ struct NsaStagePipe {
   template <bool SKEW>
   __device__ __forceinline__ void end_v() {
     if constexpr (!SKEW) end();
+  }
+};
+
+// s_waitcnt vmcnt(k) for a wave-uniform k that is only known at run time (the instruction takes an immediate):
+// waits until at most min(k, 63) of the wave's vector-memory operations are outstanding
+__device__ __forceinline__ void nsa_wait_vmcnt(int k) {
+#define NSA_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+  // (exact up to 23 outstanding, in coarser steps - a little more waiting than asked for - above: every call site
+  // carries the whole table)
+  switch (k < 24 ? k : (k < 32 ? 24 : (k < 40 ? 32 : (k < 48 ? 40 : (k < 56 ? 48 : (k < 63 ? 56 : 63)))))) {
+    NSA_VMW(0) NSA_VMW(1) NSA_VMW(2) NSA_VMW(3) NSA_VMW(4) NSA_VMW(5) NSA_VMW(6) NSA_VMW(7)
+    NSA_VMW(8) NSA_VMW(9) NSA_VMW(10) NSA_VMW(11) NSA_VMW(12) NSA_VMW(13) NSA_VMW(14) NSA_VMW(15)
+    NSA_VMW(16) NSA_VMW(17) NSA_VMW(18) NSA_VMW(19) NSA_VMW(20) NSA_VMW(21) NSA_VMW(22) NSA_VMW(23)
+    NSA_VMW(24) NSA_VMW(32) NSA_VMW(40) NSA_VMW(48) NSA_VMW(56)
+    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+  }
+#undef NSA_VMW
+}
+
+// Ring of stage buffers (the extended instances, template parameter CTX of the kernel): the double-buffered pipe
+// with `nb` >= 2 buffers and nb - 1 stages on their way at any time.  A small batch - one tile, or one team, per
+// workgroup - spends ~1 k cycles of arithmetic on a stage whose copy takes 2-3 k cycles from request to landing
+// (12-17 KiB through the CU's ~12 B / cycle LDS-DMA path, MI355X_MICROARCH.md): with the copy requested ONE stage
+// ahead the stage ring of config 4's 294 stages ran at the copy's latency, 0.44 ms for 5050 rows; requested nb - 1
+// stages ahead it runs at the copy's throughput.  The waits are counted (s_waitcnt vmcnt(N) with the pieces of the
+// later stages still outstanding, nsa_wait_vmcnt) and the barrier is a bare s_barrier: __syncthreads() drains the
+// vector-memory counter while LDS-DMA writes are pending (cdna_hip_programming.md).  Vector-memory STORES complete
+// out of order with the loads - the counts hold only while no store is in flight, so the kernel drains the counter
+// behind the stores of its prologue and epilogue (settle()).  nb = 2 is the old pipe without instalments and skew.
+template <bool RAW>
+struct NsaRingPipe {
+  const uint32_t* img;
+  const uint32_t* table;   // {src word offset, n words} per stage (the workgroup's LDS copy; unused here)
+  const uint32_t* gtable;  // ... and in the image
+  int n_stages;
+  float* base;    // nb buffers of buf_words floats
+  int buf_words;
+  int nb;
+  int cur;        // stage index within the program
+  int slot;       // buffer holding stage `cur`
+  int nxt;        // stage index of the next copy to request ...
+  int nxt_slot;   // ... and its buffer
+  int wave, nw, lane;
+  // who requests the copies: 0 every wave its share of the pieces; with a LOADER wave in the workgroup
+  // (NsaLaunch::loader) 2 = this wave is it and requests every piece, 1 = this wave requests none and waits for none
+  int role;
+  uint32_t ent_off, ent_words;  // table entry of stage `nxt` (read when the copy before it was requested)
+  // pieces THIS wave requested for the stages cur + 1 ... cur + 7 (zero beyond the ring's depth)
+  int q0, q1, q2, q3, q4, q5, q6;
+  bool skew, issued;  // (interface of NsaStagePipe; never set)
+  bool nan_seen;
+  u16x2 amax;
+  template <int PREC, int RT, int OT>
+  __device__ __forceinline__ void watch(const f32x16 (&acc)[RT][OT]) {
+    if constexpr (PREC == NSA_PREC_F16X3 && NSA_F16_DETECT == 1) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) nan_seen |= acc[t][0][0] != acc[t][0][0];
+    }
+  }
+#ifdef NSA_TIMELINE
+  NsaTl tl;
+#endif
+  // (from the image by a SCALAR load, not from the workgroup's LDS copy of the table: the compiler orders an LDS
+  // read it cannot tell from the copies' destination behind every pending LDS-DMA - an s_waitcnt vmcnt(0) of its
+  // own right behind the request, i.e. the whole ring drained at every stage; the entry is needed nb - 1 stages
+  // from here, so the scalar load's latency is nobody's)
+  __device__ __forceinline__ void load_entry(int s) {
+    const auto* e = (const __attribute__((address_space(4))) uint32_t*)gtable + 2 * s;
+    ent_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]);
+    ent_words = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[1]);
+  }
+  // request stage `nxt`; returns the number of pieces this wave sent for it
+  __device__ __forceinline__ int request() {
+    const uint32_t* src = img + ent_off;
+    float* dst = base + nxt_slot * buf_words;
+    const int pieces = role == 1 ? 0 : (int)((ent_words + 255) >> 8);  // the last piece may run over the stage's end (nsa_format.h)
+    const int first = role == 2 ? 0 : wave, step = role == 2 ? 1 : nw;
+    // (every workgroup of a small batch walks the SAME program at the same time, asking its XCD's L2 for the same
+    // lines as its neighbours: that is a help, not a hot spot - with every workgroup starting a stage at a piece of
+    // its own, config 4's 5050-row launch measured 0.40 ms against 0.33; gpurun_out r05m)
+    int n = 0;
+    for (int c = first; c < pieces; c += step) {
+      // (RAW = false - the 256-wide instances, which spill and do not compile with the raw copy: "illegal VGPR to
+      // SGPR copy" - takes the compiler's own LDS-DMA and with it the compiler's own waits for it: correct, and a
+      // ring in name only)
+      if constexpr (RAW) nsa_glds16_raw(src + c * 256 + lane * 4, dst + c * 256);
+      else nsa_glds16(src + c * 256 + lane * 4, dst + c * 256);
+      ++n;
+    }
+    nxt = (nxt + 1 == n_stages) ? 0 : nxt + 1;
+    nxt_slot = (nxt_slot + 1 == nb) ? 0 : nxt_slot + 1;
+    load_entry(nxt);
+    return n;
+  }
+  __device__ __forceinline__ void push(int n) {  // behind the nb - 2 stages already on their way
+    const int at = nb - 2;
+    q0 = at == 0 ? n : q0;
+    q1 = at == 1 ? n : q1;
+    q2 = at == 2 ? n : q2;
+    q3 = at == 3 ? n : q3;
+    q4 = at == 4 ? n : q4;
+    q5 = at == 5 ? n : q5;
+    q6 = at == 6 ? n : q6;
+  }
+  __device__ __forceinline__ void barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  __device__ __forceinline__ void prime() {
+    cur = 0;
+    slot = 0;
+    nxt = 0;
+    nxt_slot = 0;
+    q0 = q1 = q2 = q3 = q4 = q5 = q6 = 0;
+    load_entry(0);
+    (void)request();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
+    // stages 1 ... nb - 2 (begin() sends the one after them)
+    const int ahead = nb - 2;
+    if (ahead > 0) q0 = request();
+    if (ahead > 1) q1 = request();
+    if (ahead > 2) q2 = request();
+    if (ahead > 3) q3 = request();
+    if (ahead > 4) q4 = request();
+    if (ahead > 5) q5 = request();
+  }
+  // the vector-memory counter is in order again (no store of this wave in flight)
+  __device__ __forceinline__ void settle() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  template <bool SKEW = false>
+  __device__ __forceinline__ const float* begin() {
+    push(request());  // into the buffer stage cur - 1 left at the last barrier
+    NSA_TL(*this, 12);
+    return base + slot * buf_words;
+  }
+  __device__ __forceinline__ void more() {}
+  __device__ __forceinline__ void end() {
+    // stage cur + 1 has landed once only the pieces of the stages behind it are outstanding
+    if (role != 1) nsa_wait_vmcnt(q1 + q2 + q3 + q4 + q5 + q6);
+    NSA_TL(*this, 7);
+    barrier();
+    NSA_TL(*this, 8);
+    q0 = q1;
+    q1 = q2;
+    q2 = q3;
+    q3 = q4;
+    q4 = q5;
+    q5 = q6;
+    q6 = 0;
+    cur = (cur + 1 == n_stages) ? 0 : cur + 1;
+    slot = (slot + 1 == nb) ? 0 : slot + 1;
+  }
+  template <bool SKEW>
+  __device__ __forceinline__ void end_m() {}
+  template <bool SKEW>
+  __device__ __forceinline__ void end_v() {
+    end();
   }
 };
 
@@ -602,11 +794,12 @@ __device__ __forceinline__ void nsa_act_regs(float (&a)[N], int act) {
 // A chunk holds TP::FPC features per lane, each transformed in TP::NPH phases;
 // global phase index PH = feature * NPH + phase.
 
-template <class TP, bool INV, int PH, int NV>
+template <class TP, bool INV, int PH, int NV, bool REC = false>
 __device__ __forceinline__ void nsa_run_phase(typename TP::State (&st)[TP::FPC], const float (&v)[NV],
                                               const int (&cols)[TP::FPC], float* xrow,
                                               int dummy_col, const NsaTransformConsts& tc,
                                               float& logdet, int& n_bad, float (&fac)[TP::FPC]) {
+  // (REC callers - nsa_run_phases - pass the feature's Jacobian term out through fac[] instead of adding it)
   constexpr int Q = PH / TP::NPH, P = PH % TP::NPH;
   // unused feature slots (col < 0) run on the tile's spare column and add nothing
   const int col = cols[Q];
@@ -620,6 +813,7 @@ __device__ __forceinline__ void nsa_run_phase(typename TP::State (&st)[TP::FPC],
   if constexpr (P == TP::NPH - 1) {
     xrow[c] = y;
     if constexpr (TP::LD_FACTOR) fac[Q] = live ? ld : 1.0f;
+    else if constexpr (REC) fac[Q] = live ? ld : 0.0f;
     else logdet += live ? ld : 0.0f;
     n_bad += (live && bad) ? 1 : 0;
   }
@@ -657,6 +851,52 @@ __device__ __forceinline__ void nsa_run_phases(typename TP::State (&st)[TP::FPC]
     logdet = fmaf(0.6931471805599453f, l2, logdet);
   }
 }
+
+// The same, with the chunk's Jacobian terms handed out instead of added (the extended instances: team geometry):
+// rec[q] = the term of feature q (added to the running log|det J| one by one, in this order, by nsa_add_terms), or,
+// for LD_FACTOR transforms, rec[0] = the chunk's sum of base-2 logarithms.
+template <class TP, bool INV, int NV, int... I>
+__device__ __forceinline__ void nsa_run_phases_rec(typename TP::State (&st)[TP::FPC], const float (&v)[NV],
+                                                   const int (&cols)[TP::FPC], float* xrow, int dummy_col,
+                                                   const NsaTransformConsts& tc, float (&rec)[TP::FPC], int& n_bad,
+                                                   std::integer_sequence<int, I...>) {
+  float unused = 0.0f;
+#pragma unroll
+  for (int q = 0; q < TP::FPC; ++q) rec[q] = 1.0f;
+  (nsa_run_phase<TP, INV, I, NV, true>(st, v, cols, xrow, dummy_col, tc, unused, n_bad, rec), ...);
+  if constexpr (TP::LD_FACTOR) {
+    float l2 = 0.0f;
+    if (tc.ld_group4) {
+#pragma unroll
+      for (int g = 0; g < (TP::FPC + 3) / 4; ++g) {
+        float pr = rec[4 * g];
+#pragma unroll
+        for (int q = 4 * g + 1; q < 4 * g + 4 && q < TP::FPC; ++q) pr *= rec[q];
+        l2 += nsa_log2(pr);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < TP::FPC; ++q) l2 += nsa_log2(rec[q]);
+    }
+    rec[0] = l2;
+  }
+}
+// ... and the additions nsa_run_phases makes with them
+template <class TP>
+__device__ __forceinline__ void nsa_add_terms(const float (&rec)[TP::FPC], float& logdet) {
+  if constexpr (TP::LD_FACTOR) {
+    logdet = fmaf(0.6931471805599453f, rec[0], logdet);
+  } else {
+#pragma unroll
+    for (int q = 0; q < TP::FPC; ++q) logdet += rec[q];
+  }
+}
+
+// the wave's place in its team (NsaLaunch::team), and the team's LDS record of Jacobian terms: [slot][64 lanes]
+struct NsaTeam {
+  int size, member;
+  float* rec;
+};
 
 // MFMAs of sub-stage J of one chunk of the last conditioner layer (-> acc; cols and the bias come
 // with sub-stage 0).
@@ -701,7 +941,8 @@ template <int HT, class TP, bool INV, int PREC, int RT, bool SKEW = false, bool 
 __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, float* const (&xrow)[RT],
                                              int dummy_col, int lane, int half, int act, int net,
                                              int n_layers, const NsaTransformConsts& tc,
-                                             float (&logdet)[RT], int (&n_bad)[RT], bool bn_within = false) {
+                                             float (&logdet)[RT], int (&n_bad)[RT], bool bn_within = false,
+                                             NsaTeam team = NsaTeam{1, 0, nullptr}) {
   constexpr bool BF = (PREC != NSA_PREC_F32);  // split 16-bit operands (bf16 or f16 pairs)
   const int n_steps0 = __builtin_amdgcn_readfirstlane((int)op[1]);
   const int n_chunks = __builtin_amdgcn_readfirstlane((int)op[2]);
@@ -886,6 +1127,16 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
       logdet[0] += h[0][c & 15];  // (keeps the conditioner alive)
       continue;
     }
+    if constexpr (CTX) {
+      // team geometry: chunk c belongs to member c mod size; the others only keep the stage ring turning
+      if (team.size > 1 && (c & (team.size - 1)) != team.member) {
+        for (int k = 0; k < nsa_ksplit(TP::C, HT); ++k) {
+          (void)pipe.template begin<false>();
+          pipe.end();
+        }
+        continue;
+      }
+    }
     f32x16 acc[RT][TP::C];
     int cols[TP::FPC];
     nsa_static_for<nsa_ksplit(TP::C, HT)>([&](auto jc) {
@@ -907,6 +1158,20 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
       if constexpr ((NSA_ABLATE & 4) != 0) {
 #pragma unroll
         for (int i = 0; i < 16 * TP::C; ++i) asm volatile("" ::"v"(v[i]));
+      } else if constexpr (CTX) {
+        // (same arithmetic, the Jacobian terms by themselves: added right here by a wave that has its tile to
+        // itself, left in the team's record otherwise - summed below in chunk order)
+        typename TP::State sts[TP::FPC];
+        float rec[TP::FPC];
+        nsa_run_phases_rec<TP, INV>(sts, v, cols, xrow[t], dummy_col, tc, rec, n_bad[t],
+                                    std::make_integer_sequence<int, TP::NPH * TP::FPC>{});
+        if (team.size == 1) {
+          nsa_add_terms<TP>(rec, logdet[t]);
+        } else {
+          float* const slot = team.rec + (c * TP::FPC) * 64 + lane;
+#pragma unroll
+          for (int q = 0; q < (TP::LD_FACTOR ? 1 : TP::FPC); ++q) slot[q * 64] = rec[q];
+        }
       } else {
         typename TP::State sts[TP::FPC];
         nsa_run_phases<TP, INV, 0>(sts, v, cols, xrow[t], dummy_col, tc, logdet[t], n_bad[t],
@@ -915,6 +1180,19 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
     }
     NSA_TL(pipe, 6);
     pipe.template end_v<SKEW && (NSA_SKEW_MASK & 4) != 0>();
+  }
+  if constexpr (CTX) {
+    // (behind the barrier of the last chunk's stage: every member's terms are in the record; the next coupling
+    // writes it again several barriers from here)
+    if (team.size > 1 && team.member == 0) {
+      for (int c = 0; c < n_chunks; ++c) {
+        float rec[TP::FPC];
+        const float* const slot = team.rec + (c * TP::FPC) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < (TP::LD_FACTOR ? 1 : TP::FPC); ++q) rec[q] = slot[q * 64];
+        nsa_add_terms<TP>(rec, logdet[0]);
+      }
+    }
   }
 }
 
@@ -1050,7 +1328,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   static_assert(!CTX || (RT == 1 && !RES && OCC == 2), "conditional flows: staged, one tile per wave");
   // the staged two-tiles instances carry the skewed copy of the coupling code
   constexpr bool SK = RT == 2 && !RES;
-  using PIPE = std::conditional_t<RES, NsaResidentPipe, NsaStagePipe>;
+  using PIPE = std::conditional_t<RES, NsaResidentPipe, std::conditional_t<CTX, NsaRingPipe<(HT < 8)>, NsaStagePipe>>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (p.stop != nullptr && (p.stop[0] >= p.stop[2] || p.stop[1] >= p.stop[5])) return;
   if (p.image_list != nullptr) p.image = p.image_list[blockIdx.y];
@@ -1067,16 +1345,33 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   const int lane0 = (int)(threadIdx.x & 63);
   constexpr bool inverse = INV;  // p.direction selects the instantiation on the host
 
-  const int tiles_words = (nw * RT * NSA_ROWS * XS0 + 3) & ~3;
+  // team geometry (NsaLaunch::team): the waves of a workgroup in teams of `team_n`, one tile per team
+  int team_n = 1;
+  if constexpr (CTX) team_n = __builtin_amdgcn_readfirstlane(p.team > 1 ? p.team : 1);
+  int loaders = 0;  // 1: the workgroup's last wave only requests the stage copies (NsaLaunch::loader)
+  if constexpr (CTX) loaders = __builtin_amdgcn_readfirstlane(p.loader != 0 ? 1 : 0);
+  const int n_teams = (nw - loaders) / team_n;
+  const int tw = wave / team_n;            // the wave's tile slot in the workgroup
+  const int member = wave - tw * team_n;   // ... and its place in the team
+  const int tiles_words = (n_teams * RT * NSA_ROWS * XS0 + 3) & ~3;
   const int max_stage = (int)img[NSA_H_MAX_STAGE];
 
   PIPE pipe;
   pipe.n_stages = (int)(inverse ? img[NSA_H_NSTAGES_INV] : img[NSA_H_NSTAGES_FWD]);
   // stage area: two buffers of the largest stage, or (RES) every stage of the direction's program
   float* const stage_area = smem + tiles_words;
-  const int stage_words = RES ? (((int)(inverse ? img[NSA_H_RES_INV] : img[NSA_H_RES_FWD]) + 255) & ~255) : 2 * max_stage;
-  if constexpr (!RES) {
+  // (extended instances: a ring of NsaLaunch::ring >= 2 buffers, NsaRingPipe)
+  const int ring_n = CTX ? __builtin_amdgcn_readfirstlane(p.ring > 2 ? (p.ring < 8 ? p.ring : 8) : 2) : 2;
+  const int stage_words = RES ? (((int)(inverse ? img[NSA_H_RES_INV] : img[NSA_H_RES_FWD]) + 255) & ~255) : ring_n * max_stage;
+  if constexpr (CTX) {
     pipe.img = img;
+    pipe.gtable = img + (inverse ? img[NSA_H_STAGES_INV] : img[NSA_H_STAGES_FWD]);
+    pipe.base = stage_area;
+    pipe.buf_words = max_stage;
+    pipe.nb = ring_n;
+  } else if constexpr (!RES) {
+    pipe.img = img;
+    pipe.gtable = img + (inverse ? img[NSA_H_STAGES_INV] : img[NSA_H_STAGES_FWD]);
     pipe.buf0 = stage_area;
     pipe.buf1 = stage_area + max_stage;
   }
@@ -1099,6 +1394,10 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   // (as sign-ordered int64 keys - nsa_key_encode, nsa_populate.hip - so that the rows raise it with one LDS atomic)
   long long* const wmax = (long long*)(park + (size_t)(blockDim.x >> 6) * RT * 64);
   if (p.log_w_out != nullptr && (threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = nsa_weight_key(-__builtin_huge_val());
+  // (team geometry: one count of bad spline roots per lane and wave, then each team's record of Jacobian terms -
+  // (D0 + 1) / 2 + 16 slots of 64 lanes: a coupling transforms at most half the features, FPC <= 16 per chunk)
+  int* const team_bad = (int*)(wmax + nw);
+  float* const team_rec = (float*)(team_bad + nw * 64) + (size_t)tw * 64 * ((D0 + 1) / 2 + 16);
   {
     const uint32_t* gtab = img + (inverse ? img[NSA_H_STAGES_INV] : img[NSA_H_STAGES_FWD]);
     const uint32_t* gops = img + (inverse ? img[NSA_H_OPS_INV] : img[NSA_H_OPS_FWD]);
@@ -1135,6 +1434,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     pipe.nw = nw;
     pipe.lane = lane0;
     pipe.issued = false;
+    if constexpr (CTX) pipe.role = loaders ? (wave == nw - 1 ? 2 : 1) : 0;
     // p.skew: 1 = the upper half of the workgroup's waves, 2 = every other wave
     pipe.skew = SK && (p.skew == 1 ? (wave >= (nw >> 1)) : (p.skew == 2 ? (wave & 1) != 0 : false));
   }
@@ -1175,7 +1475,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   const int n_layers = (int)img[NSA_H_NLAYERS];
 
   const long long n_tiles = (p.n + NSA_ROWS - 1) / NSA_ROWS;
-  const long long n_groups = (n_tiles + nw * RT - 1) / (nw * RT);
+  const long long n_groups = (n_tiles + n_teams * RT - 1) / (n_teams * RT);
 
 #ifdef NSA_TIMELINE
   for (int i = 0; i < 14; ++i) pipe.tl.acc[i] = 0;
@@ -1186,6 +1486,21 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   pipe.tl.last = __builtin_readcyclecounter();
 #endif
 
+  if constexpr (CTX) {
+    if (loaders && wave == nw - 1) {
+      // the loader: the stage ring's request side and every barrier of the tile loop, nothing else
+      for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        pipe.barrier();  // (the tile is filled)
+        for (int st = 0; st < pipe.n_stages; ++st) {
+          (void)pipe.template begin<false>();
+          pipe.end();
+        }
+        pipe.barrier();  // (the team's counts of bad roots)
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
+  }
   for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
     NSA_TL(pipe, 11);
 #ifdef NSA_TIMELINE
@@ -1214,16 +1529,17 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     float* xrow_a[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-      xt_a[t] = smem + (wave * RT + t) * (NSA_ROWS * XS);
+      xt_a[t] = smem + (tw * RT + t) * (NSA_ROWS * XS);
       xrow_a[t] = xt_a[t] + j * XS;
     }
+    if (!CTX || member == 0) {  // (a team's tile is filled by its first wave)
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
     bool keep = true;
     float log_pz = 0.0f;
     float* const xt = xt_a[t];
     float* const xrow = xrow_a[t];
-    const long long row0 = ((g * nw + wave) * RT + t) * NSA_ROWS;
+    const long long row0 = ((g * n_teams + tw) * RT + t) * NSA_ROWS;
     const long long my_row = row0 + j;
     if (a.x_in != nullptr) {
       const long long base = row0 * D;
@@ -1335,6 +1651,11 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     // these per-row values were what the 256-register instances spilled to scratch
     park[(wave * RT + t) * 64 + lane] = keep ? log_pz : __uint_as_float(0x7fc00000u);
     }
+    }
+    if constexpr (CTX) {
+      pipe.settle();  // (the prologue's stores - z_out - are done: NsaRingPipe counts loads only)
+      if (team_n > 1 || loaders) pipe.barrier();  // the tile is there for the rest of the team
+    }
     NSA_TL(pipe, 0);
     // ---- run the flow --------------------------------------------------------
     pipe.amax = u16x2{0, 0};
@@ -1357,7 +1678,15 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
             nsa_coupling<HT, TP, INV, PREC, RT, false>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
         } else {
           nsa_coupling<HT, TP, INV, PREC, RT, false, CTX>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a,
-                                                          CTX && img[NSA_H_BNW] != 0);
+                                                          CTX && img[NSA_H_BNW] != 0, NsaTeam{team_n, member, team_rec});
+        }
+      } else if (CTX && member != 0) {
+        // team geometry: the ops between the couplings are the first member's (they rewrite the whole tile; their
+        // last stage's barrier hands it back to the team)
+        const int skip = kind == NSA_OP_DENSE ? __builtin_amdgcn_readfirstlane((int)op[2]) : 1;
+        for (int k = 0; k < skip; ++k) {
+          (void)pipe.template begin<false>();
+          pipe.end();
         }
       } else if (NSA_ABLATE & 512) {
         const int skip = kind == NSA_OP_DENSE ? __builtin_amdgcn_readfirstlane((int)op[2]) : 1;
@@ -1392,6 +1721,15 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     // NaN or +-inf in the log-det or in any output column of the wave's tiles -> NaN here (split-f16 only)
     float poison = 0.0f;
     constexpr bool POISON = PREC == NSA_PREC_F16X3 && NSA_F16_DETECT == 1 && !(NSA_ABLATE & 256);
+    if constexpr (CTX) {
+      if (team_n > 1 || loaders) {  // the members' counts of bad spline roots -> the first member's
+        team_bad[wave * 64 + lane] = n_bad_a[0];
+        pipe.barrier();
+        if (member == 0)
+          for (int m = 1; m < team_n; ++m) n_bad_a[0] += team_bad[(wave + m) * 64 + lane];
+      }
+    }
+    if (!CTX || member == 0) {  // (team geometry: the rows leave through the team's first wave)
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
     float* const xt = xt_a[t];
@@ -1404,7 +1742,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     // VGPRs through the whole flow, where they were spilled to scratch
     long long g_epi = g;
     asm volatile("" : "+s"(g_epi));
-    const long long row0 = ((g_epi * nw + wave) * RT + t) * NSA_ROWS;
+    const long long row0 = ((g_epi * n_teams + tw) * RT + t) * NSA_ROWS;
     const long long my_row = row0 + j;
     const bool row_ok = my_row < e.n;
     // (opaque too: with `half` the per-lane table addresses of every epilogue variant were hoisted out
@@ -1578,10 +1916,12 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     }
     if constexpr (POISON) poison = fmaf(logdet_a[t], 0.0f, poison);
     }
+    }
     if constexpr (PREC == NSA_PREC_F16X3 && NSA_F16_DETECT == 1) {
       // a value beyond the f16 range went into a matrix product somewhere in this wave's tiles
       if (__any(pipe.nan_seen || (poison - poison) != 0.0f) && lane == 0) atomicAdd(e.status + 1, 1);
     }
+    if constexpr (CTX) pipe.settle();  // (the epilogue's stores and atomics are done)
     NSA_TL(pipe, 9);
   }
   // drain the wrap-around prefetch before the workgroup exits

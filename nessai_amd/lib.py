@@ -38,6 +38,8 @@ SIGNATURES = {
     "nsa_last_geometry": (None, [c_void_p, c_void_p, c_void_p]),
     "nsa_last_row_tiles": (ctypes.c_int, []),
     "nsa_last_resident": (ctypes.c_int, []),
+    "nsa_last_team": (ctypes.c_int, []),
+    "nsa_last_ring": (ctypes.c_int, []),
     "nsa_flow_generic_bins": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "nsa_flow_run": (
         c_int,

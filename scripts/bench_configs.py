@@ -262,6 +262,10 @@ def run_c4_draw(n_flows_list=(1, 8, 32), nlive=5000, dims=64):
 
 
 if __name__ == "__main__":
+    if "--c4" in sys.argv:  # config 4 only
+        run_c4()
+        run_c4_draw()
+        sys.exit(0)
     # the fused affine flow of config 2 is HBM-bound by contract (132-136 B per row against
     # 41 kFLOP); the spline flows are MFMA-bound
     run("C2 16-D Gaussian RealNVP (LU+BN), drawsize=nlive", GaussianModel(16),

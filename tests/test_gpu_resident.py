@@ -20,7 +20,8 @@ from test_gpu_flows import BF16X3_WITHIN_BAR, CONFIGS, LOG_PROB_RTOL
 pytestmark = pytest.mark.gpu
 
 # flows whose packed program fits in the 160 KB of LDS of a CU (everything else stays staged)
-RESIDENT = [n for n in CONFIGS if n not in ("nsf_c3", "nsf_c5_d15", "nsf_c4_d64", "nsf_d96_h192", "rnvp_d100_lu")]
+# (nsf_k13_d32: the generic spline instance pads the 38 parameters per feature to 47 - its program is 1.2 x config 3's)
+RESIDENT = [n for n in CONFIGS if n not in ("nsf_c3", "nsf_c5_d15", "nsf_c4_d64", "nsf_d96_h192", "rnvp_d100_lu", "nsf_k13_d32")]
 SHAPES = ["4x1", "2x2", "3x1", "2x1"]
 
 
