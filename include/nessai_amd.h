@@ -473,6 +473,21 @@ NSA_API int nsa_importance_mix_packed(long long n, int n_flows, int dims, const 
                               const double* log_j_dev, const double* weights_dev, const double* x_unit_dev,
                               int clip, double* packed_dev, void* stream);
 
+/* nsa_importance_mix_packed with the records in the LIVE-POINT WIRE FORMAT (the structured dtype of the importance
+ * sampler: dims float64 parameters, then logP f8, logL f8, it i4, logQ f8, logW f8, logU f8 - 8 dims + 44 bytes per
+ * row, packed), for models with a uniform prior on the box [lower, upper] whose prior methods are the framework's own:
+ * the fields ImportanceFlowProposal.draw fills after the batch (proposal/importance.py:488-503) -
+ *   logP = Model.batch_evaluate_log_prior(Model.from_unit_hypercube(points)) = log(in_bounds(lower + (upper - lower) x))
+ *          + log_prior_total (model.py:497-518; the caller passes its own -sum log(upper - lower)),
+ *   logU = Model.batch_evaluate_log_prior_unit_hypercube(points) = log(in_unit_hypercube(x)) (model.py:520-620),
+ *   logQ = the meta-proposal, logW = logU - logQ, logL = NaN, it = 0 -
+ * are computed per row on the device (float64, numpy's comparisons) and the host VIEWS the read-back as the array it
+ * returns; aux_dev [n][n_flows + 2] float64 = { log_q_all (n_flows + 1 columns), log_j } (log_j NaN: first filter). */
+NSA_API int nsa_importance_mix_points(long long n, int n_flows, int dims, const float* log_prob_all_dev,
+                              const double* log_j_dev, const double* weights_dev, const double* x_unit_dev,
+                              int clip, const double* lower_dev, const double* upper_dev, double log_prior_total,
+                              void* points_dev, double* aux_dev, void* stream);
+
 /* log_w = log_prior - log_q and its maximum.
  *
  * Replaces BaseFlowProposal.compute_weights (proposal/flowproposal/base.py:1069-1098)

@@ -737,6 +737,25 @@ extern "C" int nsa_importance_mix_packed(long long n, int n_flows, int dims, con
   return NSA_OK;
 }
 
+extern "C" hipError_t nsa_launch_importance_points(long long, int, int, const float*, const double*, const double*,
+                                                   const double*, int, const double*, const double*, double, uint32_t*,
+                                                   double*, hipStream_t);
+
+extern "C" int nsa_importance_mix_points(long long n, int n_flows, int dims, const float* log_prob_all_dev,
+                                         const double* log_j_dev, const double* weights_dev, const double* x_unit_dev,
+                                         int clip, const double* lower_dev, const double* upper_dev,
+                                         double log_prior_total, void* points_dev, double* aux_dev, void* stream) {
+  if (n < 0 || n_flows < 0 || dims < 1 || log_j_dev == nullptr || weights_dev == nullptr || x_unit_dev == nullptr ||
+      lower_dev == nullptr || upper_dev == nullptr || points_dev == nullptr || aux_dev == nullptr ||
+      (n_flows > 0 && log_prob_all_dev == nullptr))
+    return nsa_fail(NSA_E_ARG, "nsa_importance_mix_points: bad argument");
+  hipError_t e = nsa_launch_importance_points(n, n_flows, dims, log_prob_all_dev, log_j_dev, weights_dev, x_unit_dev, clip,
+                                              lower_dev, upper_dev, log_prior_total, (uint32_t*)points_dev, aux_dev,
+                                              (hipStream_t)stream);
+  if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "importance points kernel: %s", hipGetErrorString(e));
+  return NSA_OK;
+}
+
 extern "C" int nsa_importance_mix(long long n, int n_flows, const float* log_prob_all_dev, const double* log_j_dev,
                                   const double* weights_dev, double* log_q_all_dev, double* log_Q_dev,
                                   void* stream) {

@@ -794,6 +794,30 @@ extern "C" hipError_t nsa_launch_truncate(long long n, double* log_q, double min
 }
 
 
+// log_q_all[0 .. P) of one row into `row` and its log Q (the arithmetic of nsa_importance_mix_kernel, as ONE function
+// with contraction off: the kernels that share it give the same bits)
+__device__ __forceinline__ double nsa_mix_row(long long n, long long r, int n_flows, const float* __restrict__ log_prob_all,
+                                              double lj, const double* __restrict__ weights, double* row) {
+#pragma clang fp contract(off)
+  const int P = n_flows + 1;
+  // scipy masks the entries of a zero-weight proposal (a[b == 0] = -inf) BEFORE it takes the maximum:
+  // such a proposal takes no part in log Q, whatever its density (NaN and inf included)
+  const double ninf = -__builtin_huge_val();
+  double a_max = (weights[0] == 0.0) ? ninf : 0.0;  // column 0
+  row[0] = 0.0;
+  for (int j = 0; j < n_flows; ++j) {
+    const double a = (double)log_prob_all[(long long)j * n + r] + lj;
+    row[1 + j] = a;
+    const double am = (weights[1 + j] == 0.0) ? ninf : a;
+    a_max = (am > a_max || am != am) ? am : a_max;  // numpy.amax propagates NaN
+  }
+  if (!((a_max - a_max) == 0.0)) a_max = 0.0;   // scipy: a_max[~isfinite(a_max)] = 0
+  double s = 0.0;
+  for (int k = 0; k < P; ++k)
+    if (weights[k] != 0.0) s += weights[k] * exp(row[k] - a_max);
+  return log(s) + a_max;
+}
+
 // ---------------------------------------------------------------------------
 // Meta-proposal of the importance sampler (src/nessai/proposal/importance.py:415-441):
 //   log_q_all[r][0]     = 0                                   (the prior, proposal -1)
@@ -814,22 +838,7 @@ __global__ void __launch_bounds__(256) nsa_importance_mix_kernel(long long n, in
   const int P = n_flows + 1;
   const double lj = log_j[r];
   double* row = log_q_all + r * P;
-  // scipy masks the entries of a zero-weight proposal (a[b == 0] = -inf) BEFORE it takes the maximum:
-  // such a proposal takes no part in log Q, whatever its density (NaN and inf included)
-  const double ninf = -__builtin_huge_val();
-  double a_max = (weights[0] == 0.0) ? ninf : 0.0;  // column 0
-  row[0] = 0.0;
-  for (int j = 0; j < n_flows; ++j) {
-    const double a = (double)log_prob_all[(long long)j * n + r] + lj;
-    row[1 + j] = a;
-    const double am = (weights[1 + j] == 0.0) ? ninf : a;
-    a_max = (am > a_max || am != am) ? am : a_max;  // numpy.amax propagates NaN
-  }
-  if (!((a_max - a_max) == 0.0)) a_max = 0.0;   // scipy: a_max[~isfinite(a_max)] = 0
-  double s = 0.0;
-  for (int k = 0; k < P; ++k)
-    if (weights[k] != 0.0) s += weights[k] * exp(row[k] - a_max);
-  log_Q[r] = log(s) + a_max;
+  log_Q[r] = nsa_mix_row(n, r, n_flows, log_prob_all, lj, weights, row);
 }
 
 // The same mix, written as ONE record per drawn row for a single read-back by the host
@@ -855,20 +864,7 @@ __global__ void __launch_bounds__(256) nsa_importance_pack_kernel(long long n, i
   }
   double* row = rec + D;
   const double lj = log_j[r];
-  const double ninf = -__builtin_huge_val();
-  double a_max = (weights[0] == 0.0) ? ninf : 0.0;
-  row[0] = 0.0;
-  for (int j = 0; j < n_flows; ++j) {
-    const double a = (double)log_prob_all[(long long)j * n + r] + lj;
-    row[1 + j] = a;
-    const double am = (weights[1 + j] == 0.0) ? ninf : a;
-    a_max = (am > a_max || am != am) ? am : a_max;
-  }
-  if (!((a_max - a_max) == 0.0)) a_max = 0.0;
-  double s = 0.0;
-  for (int k = 0; k < P; ++k)
-    if (weights[k] != 0.0) s += weights[k] * exp(row[k] - a_max);
-  row[P] = log(s) + a_max;
+  row[P] = nsa_mix_row(n, r, n_flows, log_prob_all, lj, weights, row);
   row[P + 1] = lj;
 }
 
@@ -878,6 +874,74 @@ extern "C" hipError_t nsa_launch_importance_pack(long long n, int n_flows, int D
   if (n == 0) return hipSuccess;
   const unsigned grid = (unsigned)((n + 255) / 256);
   nsa_importance_pack_kernel<<<grid, 256, 0, stream>>>(n, n_flows, D, log_prob_all, log_j, weights, x64, clip, packed);
+  return hipGetLastError();
+}
+
+// The mix again, with the draw's records written in the LIVE-POINT WIRE FORMAT itself:
+// row r of `points` is one element of the importance sampler's structured dtype for D float64 parameters,
+//   { x[0 .. D) f8, logP f8, logL f8, it i4, logQ f8, logW f8, logU f8 }   (8 D + 44 bytes, packed: written as
+// 32-bit words), for a model with a UNIFORM prior on a box (lower / upper, `log_prior_total` = the host's own
+// -sum log(upper - lower)), i.e. the fields ImportanceFlowProposal.draw fills one numpy pass at a time
+// (src/nessai/proposal/importance.py:488-503, model.py:497-620):
+//   logP = log(in_bounds(lower + (upper - lower) x)) + total,  logU = log(in_unit_hypercube(x)),
+//   logQ = the meta-proposal, logW = logU - logQ, logL = NaN, it = 0
+// (comparisons as numpy makes them: a NaN coordinate is "inside").  `aux` row r = { log_q_all[0 .. P), log_j } -
+// log_j NaN marks the rows of the reference's first filter.  The host views the read-back as the array it returns.
+__global__ void __launch_bounds__(256) nsa_importance_points_kernel(long long n, int n_flows, int D,
+                                                                    const float* __restrict__ log_prob_all,
+                                                                    const double* __restrict__ log_j,
+                                                                    const double* __restrict__ weights,
+                                                                    const double* __restrict__ x64, int clip,
+                                                                    const double* __restrict__ lower,
+                                                                    const double* __restrict__ upper,
+                                                                    double log_prior_total,
+                                                                    uint32_t* __restrict__ points,
+                                                                    double* __restrict__ aux) {
+#pragma clang fp contract(off)
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int P = n_flows + 1;
+  uint32_t* rec = points + r * (2 * (long long)D + 11);
+  auto put = [&](int word, double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    rec[word] = (uint32_t)b;
+    rec[word + 1] = (uint32_t)(b >> 32);
+  };
+  const double* xr = x64 + r * D;
+  bool in_box = true, in_cube = true;
+  for (int i = 0; i < D; ++i) {
+    double v = xr[i];
+    if (clip) v = fmin(fmax(v, 0.0), 1.0);  // (numpy.clip: NaN stays NaN)
+    put(2 * i, v);
+    in_cube = in_cube && !((v < 0.0) || (v > 1.0));
+    const double lo = lower[i], hi = upper[i];
+    const double phys = lo + (hi - lo) * v;
+    in_box = in_box && !((phys < lo) || (phys > hi));
+  }
+  double* row = aux + r * (P + 1);
+  const double lj = log_j[r];
+  const double ninf = -__builtin_huge_val();
+  const double log_Q = nsa_mix_row(n, r, n_flows, log_prob_all, lj, weights, row);
+  row[P] = lj;
+  const double log_u = in_cube ? 0.0 : ninf;
+  const int w = 2 * D;
+  put(w, (in_box ? 0.0 : ninf) + log_prior_total);                     // logP
+  put(w + 2, __longlong_as_double(0x7ff8000000000000LL));              // logL
+  rec[w + 4] = 0u;                                                     // it
+  put(w + 5, log_Q);                                                   // logQ
+  put(w + 7, log_u - log_Q);                                           // logW
+  put(w + 9, log_u);                                                   // logU
+}
+
+extern "C" hipError_t nsa_launch_importance_points(long long n, int n_flows, int D, const float* log_prob_all,
+                                                   const double* log_j, const double* weights, const double* x64,
+                                                   int clip, const double* lower, const double* upper,
+                                                   double log_prior_total, uint32_t* points, double* aux,
+                                                   hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  nsa_importance_points_kernel<<<grid, 256, 0, stream>>>(n, n_flows, D, log_prob_all, log_j, weights, x64, clip, lower,
+                                                         upper, log_prior_total, points, aux);
   return hipGetLastError();
 }
 

@@ -140,6 +140,8 @@ SIGNATURES = {
     "nsa_importance_to_prime": (c_int, [c_ll, c_int, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "nsa_importance_mix_packed": (c_int, [c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                           c_void_p]),
+    "nsa_importance_mix_points": (c_int, [c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                          c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "nsa_importance_mix": (c_int, [c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsa_populate_truncate": (c_int, [c_ll, c_void_p, c_double, c_void_p, c_double, c_void_p]),
     "nsa_populate_weights": (c_int, [c_ll, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),

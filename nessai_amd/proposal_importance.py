@@ -291,9 +291,11 @@ class ImportanceFlowProposal:
         gathered = gathered.reshape(world, len(flows), per)
         return gathered.permute(1, 0, 2).reshape(len(flows), world * per)[:, :n].contiguous()
 
-    def _draw_batch(self, flow_number, n_rows, z_in=None):
+    def _draw_batch(self, flow_number, n_rows, z_in=None, want_points=False):
         """One batch of ``draw`` on the device.  Returns host arrays ``(x (m, D), log_q_all (m, P),
-        log_Q (m,))`` of the rows that pass the reference's first filter, in draw order."""
+        log_Q (m,))`` of the rows that pass the reference's first filter, in draw order - or, with
+        ``want_points`` on one rank for a model with the framework's own uniform box prior, ``(points, log_q_all,
+        None)``: the structured array of the batch with every field already filled (``_finish_batch_points``)."""
         if self.reparameterisation != "logit":
             raise NotImplementedError("the gfx950 draw epilogue implements the logit reparameterisation only")
         L = lib.load()
@@ -327,7 +329,9 @@ class ImportanceFlowProposal:
                 # (one rank: the flag travels with the batch's single read-back - _finish_batch_one_rank - and a
                 # batch that left the range is drawn again as a whole, below)
                 if world == 1:
-                    done = self._finish_batch_one_rank(x64, xp, log_j, flow)
+                    box = self._uniform_box()
+                    done = (self._finish_batch_points(x64, xp, log_j, flow, box) if box is not None and want_points
+                            else self._finish_batch_one_rank(x64, xp, log_j, flow))
                     if done is not None:
                         self._draw_counter += n_rows
                         return done
@@ -367,6 +371,83 @@ class ImportanceFlowProposal:
             cached = (key, torch.tensor(key, dtype=torch.float64, device=self.flow.device))
             self._weights_dev = cached
         return cached[1]
+
+    def _uniform_box(self):
+        """``(lower, upper, total)`` on the device when the model's prior methods are the framework's own uniform box
+        (``Model.from_unit_hypercube`` / ``in_unit_hypercube`` / ``batch_evaluate_log_prior_unit_hypercube`` and
+        ``UniformBoxModel.log_prior`` not overridden): the draw's prior fields are then the device's business; a user's
+        own methods are called on the host as the reference calls them.  ``total`` is ``UniformBoxModel.log_prior``'s
+        own ``-sum log(width)`` (same float64 sequence)."""
+        cached = getattr(self, "_box_dev", None)
+        if cached is not None:
+            return cached[0]
+        from .model import Model, UniformBoxModel
+
+        m, t = self.model, type(self.model)
+        own = (getattr(m, "uniform_prior", False) and isinstance(m, UniformBoxModel)
+               and t.log_prior is UniformBoxModel.log_prior and t.batch_evaluate_log_prior is Model.batch_evaluate_log_prior
+               and t.from_unit_hypercube is Model.from_unit_hypercube and t.in_unit_hypercube is Model.in_unit_hypercube
+               and t.in_bounds is Model.in_bounds
+               and t.batch_evaluate_log_prior_unit_hypercube is Model.batch_evaluate_log_prior_unit_hypercube
+               and parameter_block(np.empty(1, dtype=self.dtype), list(m.names)) is not None
+               and os.environ.get("NESSAI_AMD_DRAW_POINTS", "1") != "0")
+        box = None
+        if own:
+            total = np.float64(0.0)
+            for bounds in m.bounds.values():
+                total -= np.log(bounds[1] - bounds[0])
+            dev = self.flow.device
+            box = (torch.tensor(np.asarray(m.lower_bounds, dtype=np.float64), device=dev),
+                   torch.tensor(np.asarray(m.upper_bounds, dtype=np.float64), device=dev), float(total))
+        self._box_dev = (box,)
+        return box
+
+    def _finish_batch_points(self, x64, xp, log_j, flow, box):
+        """``_finish_batch_one_rank`` with the batch's records in the live-point wire format itself
+        (``nsa_importance_mix_points``): the prior fields of a uniform box model, ``logQ`` / ``logW`` / ``logU`` and the
+        defaults of the other fields are written per row on the device and the host VIEWS the pinned read-back as the
+        structured array ``draw`` returns - no numpy pass over the parameters (1.5 of the draw's 2.7 ms before)."""
+        D, P = self.dims, self.n_proposals
+        n = x64.shape[0]
+        log_prob_all = log_prob_many(self.flow.models, xp)
+        if self.flow.n_models + 1 != P:
+            raise RuntimeError(f"{P} proposal weights for {self.flow.n_models} flows and the prior")
+        words = 2 * D + 11
+        assert 4 * words == self.dtype.itemsize, (words, self.dtype)
+        bufs = getattr(self, "_draw_point_bufs", None)
+        if bufs is None or bufs[0].shape != (n, words) or bufs[1].shape != (n, P + 1) or bufs[0].device != x64.device:
+            bufs = (torch.empty((n, words), dtype=torch.int32, device=x64.device),
+                    torch.empty((n, P + 1), dtype=torch.float64, device=x64.device),
+                    torch.empty((n, words), dtype=torch.int32).pin_memory(),
+                    torch.empty((n, P + 1), dtype=torch.float64).pin_memory(),
+                    torch.zeros(4, dtype=torch.int32).pin_memory())
+            self._draw_point_bufs = bufs
+        points_dev, aux_dev, points_host, aux_host, status_host = bufs
+        lower, upper, total = box
+        rc = lib.load().nsa_importance_mix_points(
+            n, self.flow.n_models, D, lib.ptr(log_prob_all), lib.ptr(log_j), lib.ptr(self._weights_device()),
+            lib.ptr(x64), 1 if self.clip else 0, lib.ptr(lower), lib.ptr(upper), total, lib.ptr(points_dev),
+            lib.ptr(aux_dev), self._stream(),
+        )
+        lib.check(rc, "nsa_importance_mix_points")
+        points_host.copy_(points_dev, non_blocking=True)
+        aux_host.copy_(aux_dev, non_blocking=True)
+        status_host.copy_(flow._status, non_blocking=True)
+        torch.cuda.current_stream(x64.device).synchronize()
+        if flow.effective_precision == "f16x3" and int(status_host[1]) != 0:
+            return None  # a value beyond the f16 range: the caller draws the batch again in float32
+        raw, aux = points_host.numpy(), aux_host.numpy()
+        keep = ~np.isnan(aux[:, -1])  # the reference's first filter, draw order
+        # (out of the pinned buffers, which are the next batch's - as 32-bit words: numpy copies a packed structured
+        # array element by element, 1.3 ms for these 2.8 MB against 0.2 for the words)
+        if keep.all():
+            raw, log_q_all = raw.copy(), aux[:, :P].copy()
+        else:
+            raw, log_q_all = raw[keep], aux[keep, :P]
+        points = raw.view(self.dtype).reshape(raw.shape[0])
+        if np.isnan(points["logQ"]).any():  # compute_log_Q's check (importance.py:436-441)
+            raise ValueError("There is a NaN in log g!")
+        return points, log_q_all, None
 
     def _finish_batch_one_rank(self, x64, xp, log_j, flow):
         """The device epilogue of a draw batch on one rank: every flow's density of the rows, the meta-proposal,
@@ -495,20 +576,23 @@ class ImportanceFlowProposal:
         kept_points, kept_log_q, have = [], [], 0
         while have < n and batch > 0:
             z_in = next(injected) if injected is not None else None
-            x, log_q_all, log_Q = self._draw_batch(source, batch, z_in=z_in)
+            x, log_q_all, log_Q = self._draw_batch(source, batch, z_in=z_in, want_points=True)
             if not len(x):
                 continue
-            points = empty_ins_array(len(x), names)
-            block = parameter_block(points, list(names))
-            if block is not None:
-                block[:] = x
+            if log_Q is None:  # the batch came back as the structured array itself (_finish_batch_points)
+                points = x
             else:
-                for col, name in enumerate(names):
-                    points[name] = x[:, col]
-            points["logQ"] = log_Q
-            points["logP"] = self.model.batch_evaluate_log_prior(self.model.from_unit_hypercube(points))
-            points["logU"] = self.model.batch_evaluate_log_prior_unit_hypercube(points)
-            points["logW"] = points["logU"] - points["logQ"]
+                points = empty_ins_array(len(x), names)
+                block = parameter_block(points, list(names))
+                if block is not None:
+                    block[:] = x
+                else:
+                    for col, name in enumerate(names):
+                        points[name] = x[:, col]
+                points["logQ"] = log_Q
+                points["logP"] = self.model.batch_evaluate_log_prior(self.model.from_unit_hypercube(points))
+                points["logU"] = self.model.batch_evaluate_log_prior_unit_hypercube(points)
+                points["logW"] = points["logU"] - points["logQ"]
             # second filter (importance.py:497-503): a usable prior, a weight that is not +inf, and
             # not every proposal density NaN / +inf
             usable = np.isfinite(points["logP"]) & ~np.isposinf(points["logW"])

@@ -179,6 +179,48 @@ def test_device_generator_is_reproducible_and_row_indexed(tmp_path):
     assert ((u >= 0) & (u <= 1)).all() and np.isfinite(xa["logW"]).all()
 
 
+@pytest.mark.parametrize("clip", [False, True])
+def test_draw_records_written_on_the_device_equal_the_host_assembly(tmp_path, monkeypatch, clip):
+    """``nsa_importance_mix_points``: for a model with the framework's own uniform box prior the batch comes back in the
+    live-point wire format, prior fields included (logP through from_unit_hypercube + in_bounds, logU, logW, the
+    defaults of logL / it) - bit for bit the structured array the host builds with the model's numpy methods
+    (``proposal/importance.py:488-503``), NaN-marked rows of the first filter dropped alike; a model that overrides one
+    of those methods keeps the host path."""
+    from nessai_amd.model import CorrelatedGaussianModel
+
+    flow_cfg = dict(ftype="nsf", n_neurons=16, n_blocks=2, n_layers=1, num_bins=4)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NESSAI_AMD_DRAW_POINTS", mode)
+        model, prop = build(3, tmp_path / mode, dims=8, flow=flow_cfg)
+        prop.clip = clip
+        assert (prop._uniform_box() is not None) == (mode == "1")
+        z = np.random.default_rng(1).normal(size=(int(1.01 * 700), 8)).astype(np.float32).astype(np.float64)
+        z[3, 2] = 60.0  # saturates the sigmoid: dropped by the first filter
+        z[5, 1] = 9.0   # pushed to the edge of the hypercube
+        pts, log_q = prop.draw(650, injected=iter([z, z]))
+        pts2, log_q2 = prop.draw(1000)  # ... and from the device generator
+        out[mode] = (pts, log_q, pts2, log_q2)
+    a, b = out["1"], out["0"]
+    for x, y in ((a[0], b[0]), (a[2], b[2])):
+        assert x.dtype == y.dtype and x.size == y.size
+        for name in x.dtype.names:
+            assert np.array_equal(x[name], y[name], equal_nan=True), name
+    assert np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[3], b[3], equal_nan=True)
+
+    class Own(CorrelatedGaussianModel):
+        def log_prior(self, x):
+            return super().log_prior(x) - 1.0
+
+    monkeypatch.setenv("NESSAI_AMD_DRAW_POINTS", "1")
+    _, prop = build(1, tmp_path / "own", dims=8, flow=flow_cfg)
+    prop.model = Own(8, rho=0.5)
+    prop._box_dev = None
+    assert prop._uniform_box() is None
+    pts, _ = prop.draw(200)
+    assert np.allclose(pts["logP"], super(Own, prop.model).log_prior(prop.model.from_unit_hypercube(pts)) - 1.0)
+
+
 def test_mix_kernel_replays_the_reference_golden(tmp_path):
     """``compute_log_Q`` of the reference on a fixed ``log_prob_all`` table
     (tests/golden/make_importance_goldens.py): the float64 mix kernel reproduces ``log_q_all`` and
