@@ -14,6 +14,8 @@
 
 #ifndef NSA_DEFAULT_OCC
 #define NSA_DEFAULT_OCC 2
+#define NSA_DEFAULT_LOADERS 3  // loader waves per workgroup of the small-batch geometry (NsaLaunch::loader): 1 computing wave + 3 = one wave per SIMD
+#define NSA_LOADER_MAX_TILES 5  // ... up to this many tiles per CU (as many tiles per workgroup, sharing the loaders)
 #define NSA_TEAM_MIN_HT 2  // conditioners of >= 64 features take the loader geometry on small batches (nsa_launch_flow)
 #endif
 #ifndef NSA_DEFAULT_SKEW
@@ -378,19 +380,21 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   // Small-batch geometry (NsaLaunch::team / ring / loader, nsa_flow_kernel.h): a batch with fewer tiles than the chip
   // has CUs is pure latency - one workgroup per tile walks the whole program, and requesting the stage copies cost the
   // computing wave a quarter of its time (60 - 200 cycles per 1 KiB piece).  Such a launch gets, per tile, ONE
-  // computing wave, a LOADER wave that only requests the copies, and a ring of up to eight stage buffers: config 4's
-  // 5050 rows (158 tiles, 128-wide conditioner, 4 MB program) 0.40 -> 0.325 ms, a 192-wide flow 0.38 -> 0.27, config 3's
-  // flow over 2000 rows 0.149 -> 0.136 (gpurun_out r05n; 32-wide conditioners gain nothing and keep the staged
-  // geometry).  Teams of 2 / 4 / 8 computing waves per tile (NESSAI_AMD_TEAM) share the trunk's work badly - the chunk
-  // stages still run one after the other - and measured slower than one wave with a loader: kept as pinned options,
-  // same rows bit for bit (tests/test_gpu_team.py).  NESSAI_AMD_TEAM=0 switches the geometry off, NESSAI_AMD_LOADER=0
-  // the loader, NESSAI_AMD_RING pins the ring's depth.
+  // computing wave, THREE loader waves that only request the copies (a wave has at most 63 vector-memory operations in
+  // flight - the counter's width - and a copy takes microseconds to land on a chip where every CU streams the same
+  // program: one loader's window was the bound, 0.335 ms; two 0.276, three 0.266, four 0.273) and a ring of up to
+  // eight stage buffers.  Config 4's 5050 rows (158 tiles, 128-wide conditioner, 4 MB program) 0.40 -> 0.27 ms, a
+  // 192-wide flow 0.38 -> 0.27 (one loader), config 3's flow over 2000 rows 0.149 -> 0.136 (one loader; gpurun_out
+  // r05n / r05t; 32-wide conditioners gain nothing and keep the staged geometry).  Teams of 2 / 4 / 8 computing waves
+  // per tile (NESSAI_AMD_TEAM) share the trunk's work badly - the chunk stages still run one after the other - and
+  // measured no faster than one wave: kept as pinned options, same rows bit for bit (tests/test_gpu_team.py).
+  // NESSAI_AMD_TEAM=0 switches the geometry off, NESSAI_AMD_LOADER=0 ... 4 sets the loaders, NESSAI_AMD_RING the ring.
   {
     int team = 0;
     const char* te = getenv("NESSAI_AMD_TEAM");
     if (te != nullptr) team = atoi(te);
-    else if (h[NSA_H_HT] >= NSA_TEAM_MIN_HT && n_tiles * n_flows <= (long long)g_num_cus && waves_per_group <= 0 &&
-             force_occ == 0 && getenv("NESSAI_AMD_OCC") == nullptr)
+    else if (h[NSA_H_HT] >= NSA_TEAM_MIN_HT && n_tiles * n_flows <= (long long)NSA_LOADER_MAX_TILES * g_num_cus &&
+             waves_per_group <= 0 && force_occ == 0 && getenv("NESSAI_AMD_OCC") == nullptr)
       team = 1;
     if (team == 1 || team == 2 || team == 4 || team == 8) {  // (1: a wave per tile and workgroup, on the deep stage ring)
       const size_t one_stage = (size_t)h[NSA_H_MAX_STAGE] * 4;
@@ -399,9 +403,22 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
       // them, up to eight (NsaRingPipe: the copies of a small batch are requested ring - 1 stages ahead)
       // (+ the loader: one more wave that only requests the stage copies, NsaLaunch::loader; NESSAI_AMD_LOADER=0: none)
       const char* le = getenv("NESSAI_AMD_LOADER");
-      const int loader = ((le != nullptr && le[0] == '0') || team == 8) ? 0 : 1;  // (8 + 1 waves: over the instances' 512 threads)
-      const size_t fixed = (((size_t)NSA_ROWS * XS + 3) & ~(size_t)3) * 4 + (size_t)(team + loader) * (256 + 8 + 256) +
-                           (size_t)64 * ((D + 1) / 2 + 16) * 4 + epi_bytes + prog_bytes;
+      int loader = le != nullptr ? atoi(le) : NSA_DEFAULT_LOADERS;
+      loader = loader < 0 ? 0 : (loader > 4 ? 4 : loader);
+      // tiles (teams) per workgroup: as many as it takes for ONE round of workgroups over the chip - they share the
+      // loaders and every stage copy (config 4's flow: 10000 rows 0.42 -> 0.29 ms at two tiles per workgroup, 20000 rows
+      // 0.42 -> 0.32 at four, 40400 rows 0.42 -> 0.40 at five; gpurun_out r05v) - NESSAI_AMD_TILES pins the number
+      int tpg = (int)((n_tiles * n_flows + g_num_cus - 1) / g_num_cus);
+      tpg = tpg < 1 ? 1 : tpg;
+      {
+        const char* tp = getenv("NESSAI_AMD_TILES");
+        if (tp != nullptr && atoi(tp) >= 1 && atoi(tp) <= 7) tpg = atoi(tp);
+        while (tpg > 1 && team * tpg + (loader > 0 ? 1 : 0) > 8) --tpg;
+      }
+      if (team * tpg + loader > 8) loader = 8 - team * tpg;  // (the instances' 512 threads)
+      const int waves = team * tpg + loader;
+      const size_t fixed = (((size_t)tpg * NSA_ROWS * XS + 3) & ~(size_t)3) * 4 + (size_t)waves * (256 + 8 + 256) +
+                           (size_t)tpg * 64 * ((D + 1) / 2 + 16) * 4 + epi_bytes + prog_bytes;
       int ring = one_stage > 0 && g_max_lds > fixed ? (int)((g_max_lds - fixed) / one_stage) : 0;
       if (ring > 8) ring = 8;
       {
@@ -419,9 +436,9 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
         p.row_tiles = 1;
         p.skew = 0;
         p.prio = 0;
-        long long grid = n_tiles;
+        long long grid = (n_tiles + tpg - 1) / tpg;
         if (max_groups > 0 && grid > max_groups) grid = max_groups;
-        hipError_t e = fn(&p, (unsigned)grid, (unsigned)n_flows, (unsigned)((team + loader) * 64), lds, stream);
+        hipError_t e = fn(&p, (unsigned)grid, (unsigned)n_flows, (unsigned)(waves * 64), lds, stream);
         if (e != hipSuccess) return nsa_fail(NSA_E_HIP, "flow kernel launch (team): %s", hipGetErrorString(e));
         g_last_geometry[0] = NSA_DEFAULT_OCC;
         g_last_geometry[3] = 1;

@@ -171,10 +171,12 @@ struct NsaLaunch {
   int team;
   // extended instances: buffers of the stage ring (NsaRingPipe), 2 ... 8; 0 = 2
   int ring;
-  // extended instances: 1 = the LAST wave of every workgroup is a loader - it requests every stage copy and computes
-  // nothing, the others request none.  Requesting a 1 KiB piece costs the requesting wave 60 - 200 cycles (the CU's
-  // LDS-DMA path takes one per ~60 cycles, MI355X_MICROARCH.md): spread over the computing waves of a small batch
-  // that was a quarter of their time, and the copies' landing waited for the arithmetic to get out of the way.
+  // extended instances: 1 / 2 = the LAST one / two waves of every workgroup are loaders - they request the stage copies
+  // (every second piece each, when two) and compute nothing, the others request none.  Requesting a 1 KiB piece costs
+  // the requesting wave 60 - 200 cycles (the CU's LDS-DMA path takes one per ~60 cycles, MI355X_MICROARCH.md): spread
+  // over the computing waves of a small batch that was a quarter of their time, and the copies' landing waited for the
+  // arithmetic to get out of the way.  A wave has at most 63 vector-memory operations in flight (the counter's width):
+  // two loaders keep twice as many pieces on their way.
   int loader;
   // static wave priority (MI355X_MICROARCH.md, "static priority for the younger half"): 1 = the upper half of the
   // workgroup's waves runs at s_setprio 1 for the whole kernel (the default of the staged two-tiles geometry: nsa_api.hip),
@@ -306,8 +308,13 @@ struct NsaStagePipe {
     // front of an LDS read it cannot tell from the pending LDS-DMA's destination - right behind the copy's request
     // in the stages where it does not sink the read below the MFMAs; scripts/isa_waits.py)
     const auto* e = (const __attribute__((address_space(4))) uint32_t*)gtable + 2 * s;
+#if NSA_TABLE_SCALAR == 2
     nxt_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]);
     nxt_words = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[1]);
+#else
+    nxt_off = e[0];  // (no readfirstlane: the loaded words are uniform as they are, and the intrinsic waits for the load on the spot)
+    nxt_words = e[1];
+#endif
 #else
     const uint2 e = *(const uint2*)(table + 2 * s);
     nxt_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
@@ -421,9 +428,10 @@ struct NsaRingPipe {
   int nxt;        // stage index of the next copy to request ...
   int nxt_slot;   // ... and its buffer
   int wave, nw, lane;
-  // who requests the copies: 0 every wave its share of the pieces; with a LOADER wave in the workgroup
-  // (NsaLaunch::loader) 2 = this wave is it and requests every piece, 1 = this wave requests none and waits for none
-  int role;
+  // who requests the copies: 0 every wave its share of the pieces; with LOADER waves in the workgroup
+  // (NsaLaunch::loader of them, the last waves) 2 = this wave is loader number `ld_index` of `ld_count` and requests
+  // every ld_count-th piece, 1 = this wave requests none and waits for none
+  int role, ld_index, ld_count;
   uint32_t ent_off, ent_words;  // table entry of stage `nxt` (read when the copy before it was requested)
   // pieces THIS wave requested for the stages cur + 1 ... cur + 7 (zero beyond the ring's depth)
   int q0, q1, q2, q3, q4, q5, q6;
@@ -445,16 +453,19 @@ struct NsaRingPipe {
   // own right behind the request, i.e. the whole ring drained at every stage; the entry is needed nb - 1 stages
   // from here, so the scalar load's latency is nobody's)
   __device__ __forceinline__ void load_entry(int s) {
+    // (no readfirstlane on the loaded words: a scalar load's result is uniform as it is, and the intrinsic made the
+    // wave wait for the load on the spot - ~350 cycles per stage, 102 k of a 708 k-cycle trip through config 4's flow)
     const auto* e = (const __attribute__((address_space(4))) uint32_t*)gtable + 2 * s;
-    ent_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]);
-    ent_words = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[1]);
+    ent_off = e[0];
+    ent_words = e[1];
   }
   // request stage `nxt`; returns the number of pieces this wave sent for it
   __device__ __forceinline__ int request() {
+    if (role == 1) return 0;  // (a loader wave does the requesting)
     const uint32_t* src = img + ent_off;
     float* dst = base + nxt_slot * buf_words;
-    const int pieces = role == 1 ? 0 : (int)((ent_words + 255) >> 8);  // the last piece may run over the stage's end (nsa_format.h)
-    const int first = role == 2 ? 0 : wave, step = role == 2 ? 1 : nw;
+    const int pieces = (int)((ent_words + 255) >> 8);  // the last piece may run over the stage's end (nsa_format.h)
+    const int first = role == 2 ? ld_index : wave, step = role == 2 ? ld_count : nw;
     // (every workgroup of a small batch walks the SAME program at the same time, asking its XCD's L2 for the same
     // lines as its neighbours: that is a help, not a hot spot - with every workgroup starting a stage at a piece of
     // its own, config 4's 5050-row launch measured 0.40 ms against 0.33; gpurun_out r05m)
@@ -1348,8 +1359,8 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   // team geometry (NsaLaunch::team): the waves of a workgroup in teams of `team_n`, one tile per team
   int team_n = 1;
   if constexpr (CTX) team_n = __builtin_amdgcn_readfirstlane(p.team > 1 ? p.team : 1);
-  int loaders = 0;  // 1: the workgroup's last wave only requests the stage copies (NsaLaunch::loader)
-  if constexpr (CTX) loaders = __builtin_amdgcn_readfirstlane(p.loader != 0 ? 1 : 0);
+  int loaders = 0;  // the workgroup's last `loaders` waves only request the stage copies (NsaLaunch::loader: 0 ... 4)
+  if constexpr (CTX) loaders = __builtin_amdgcn_readfirstlane(p.loader > 0 ? (p.loader < 4 ? p.loader : 4) : 0);
   const int n_teams = (nw - loaders) / team_n;
   const int tw = wave / team_n;            // the wave's tile slot in the workgroup
   const int member = wave - tw * team_n;   // ... and its place in the team
@@ -1434,7 +1445,11 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
     pipe.nw = nw;
     pipe.lane = lane0;
     pipe.issued = false;
-    if constexpr (CTX) pipe.role = loaders ? (wave == nw - 1 ? 2 : 1) : 0;
+    if constexpr (CTX) {
+      pipe.role = loaders ? (wave >= nw - loaders ? 2 : 1) : 0;
+      pipe.ld_index = wave - (nw - loaders);
+      pipe.ld_count = loaders;
+    }
     // p.skew: 1 = the upper half of the workgroup's waves, 2 = every other wave
     pipe.skew = SK && (p.skew == 1 ? (wave >= (nw >> 1)) : (p.skew == 2 ? (wave & 1) != 0 : false));
   }
@@ -1487,8 +1502,8 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
 #endif
 
   if constexpr (CTX) {
-    if (loaders && wave == nw - 1) {
-      // the loader: the stage ring's request side and every barrier of the tile loop, nothing else
+    if (loaders && wave >= nw - loaders) {
+      // a loader: the stage ring's request side and every barrier of the tile loop, nothing else
       for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
         pipe.barrier();  // (the tile is filled)
         for (int st = 0; st < pipe.n_stages; ++st) {

@@ -367,7 +367,8 @@ class ImportanceFlowProposal:
         """The proposal weights on the device, uploaded when they change (not per draw)."""
         key = tuple(float(w) for w in self.weights_array)
         cached = getattr(self, "_weights_dev", None)
-        if cached is None or cached[0] != key or cached[1].device != self.flow.device:
+        # (by device TYPE: `self.flow.device` may read "cuda" where the tensor says "cuda:0" - see _finish_batch_one_rank)
+        if cached is None or cached[0] != key or cached[1].device.type != torch.device(self.flow.device).type:
             cached = (key, torch.tensor(key, dtype=torch.float64, device=self.flow.device))
             self._weights_dev = cached
         return cached[1]

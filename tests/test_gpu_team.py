@@ -84,19 +84,44 @@ def test_ring_depth_never_changes_the_rows(name, ring, monkeypatch):
     x = (torch.randn(3000, args[0], generator=torch.Generator().manual_seed(2)) * 1.2).to(DEV)
     monkeypatch.setenv("NESSAI_AMD_TEAM", "0")
     _, single = run_all(flow, x)
-    for team, loader in ((1, "1"), (1, "0"), (4, "1"), (4, "0")):
+    for team, loader in ((1, "3"), (1, "1"), (1, "0"), (4, "2"), (4, "0")):
         monkeypatch.setenv("NESSAI_AMD_TEAM", str(team))
         monkeypatch.setenv("NESSAI_AMD_RING", str(ring))
-        monkeypatch.setenv("NESSAI_AMD_LOADER", loader)  # 0: every wave requests its share of a stage's pieces
+        monkeypatch.setenv("NESSAI_AMD_LOADER", loader)  # loader waves; 0: every wave requests its share of the pieces
         geo, shared = run_all(flow, x)
         assert geo[3] == team and 2 <= int(lib.load().nsa_last_ring()) <= ring, geo
         for a, b in zip(single, shared):
             assert same(a, b)
 
 
+@pytest.mark.parametrize("tiles", [2, 3, 5])
+@pytest.mark.parametrize("name", ["nsf_c4_d64", "nsf_c3", "rnvp_c2", "nsf_d5_k10_bn"])
+def test_tiles_sharing_a_workgroup_never_change_the_rows(name, tiles, monkeypatch):
+    """Several tiles per workgroup of the loader geometry (``NESSAI_AMD_TILES``; the library's own choice for batches of
+    one to five tiles per CU): every tile keeps its own computing wave(s), the loaders and the stage copies are shared -
+    same rows bit for bit, ragged last workgroup included."""
+    P, Oc, args, kw = CONFIGS[name]
+    _, flow = make_pair(P, Oc, args, kw)
+    flow.precision = "f16x3"
+    monkeypatch.delenv("NESSAI_AMD_OCC", raising=False)
+    monkeypatch.setenv("NESSAI_AMD_RESIDENT", "0")
+    x = (torch.randn(2100, args[0], generator=torch.Generator().manual_seed(8)) * 1.2).to(DEV)  # 66 tiles
+    monkeypatch.setenv("NESSAI_AMD_TEAM", "0")
+    _, single = run_all(flow, x)
+    for team in (1, 2):
+        if team * tiles > 7:
+            continue
+        monkeypatch.setenv("NESSAI_AMD_TEAM", str(team))
+        monkeypatch.setenv("NESSAI_AMD_TILES", str(tiles))
+        geo, shared = run_all(flow, x)
+        assert geo[3] == team and geo[2] == (66 + tiles - 1) // tiles, geo
+        for a, b in zip(single, shared):
+            assert same(a, b)
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_team_is_the_default_for_small_batches_of_wide_flows_and_matches_the_oracle(precision, monkeypatch):
-    for k in ("NESSAI_AMD_TEAM", "NESSAI_AMD_OCC", "NESSAI_AMD_RESIDENT"):
+    for k in ("NESSAI_AMD_TEAM", "NESSAI_AMD_OCC", "NESSAI_AMD_RESIDENT", "NESSAI_AMD_TILES", "NESSAI_AMD_LOADER", "NESSAI_AMD_RING"):
         monkeypatch.delenv(k, raising=False)
     P, Oc, args, kw = CONFIGS["nsf_c4_d64"]
     ref, flow = make_pair(P, Oc, args, kw)
@@ -110,8 +135,16 @@ def test_team_is_the_default_for_small_batches_of_wide_flows_and_matches_the_ora
     assert rel_err(lp.cpu(), lp_ref, floor=1e-3) <= LOG_PROB_RTOL
     # (x and log|det J| of the inverse at the bars of tests/test_gpu_flows.py::test_forward_inverse_match_oracle)
     assert rel_err(xi.cpu(), xi_ref) <= X_ATOL and rel_err(ldi.cpu(), ldi_ref) <= LOGDET_ATOL
-    # ... and a batch that fills the chip keeps a wave per tile
-    big = torch.randn(40000, args[0], device=DEV)
+    # ... a mid-size batch shares the loaders among several tiles per workgroup: ONE round of workgroups over the chip
+    mid = torch.randn(20000, args[0], generator=torch.Generator().manual_seed(5))  # 625 tiles -> 3 per workgroup
+    with torch.no_grad():
+        lp_mid_ref = ref.log_prob(mid)
+    lp_mid = flow.log_prob(mid.to(DEV))
+    geo = geometry()
+    assert geo[3] == 1 and geo[2] == 209, geo
+    assert rel_err(lp_mid.cpu(), lp_mid_ref, floor=1e-3) <= LOG_PROB_RTOL
+    # ... and a batch that fills the chip several times over keeps the staged geometry
+    big = torch.randn(100000, args[0], device=DEV)
     flow.log_prob(big)
     assert geometry()[3] == 0
     # flows whose program stays resident in LDS keep the resident geometry ...
