@@ -431,6 +431,10 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
         p.team = team;
         p.ring = ring;
         p.loader = loader;
+        {
+          const char* ro = getenv("NESSAI_AMD_ROUNDS");
+          p.rounds_off = (ro != nullptr && ro[0] == '0') ? 1 : 0;
+        }
         p.resident = 0;
         p.occupancy = NSA_DEFAULT_OCC;
         p.row_tiles = 1;

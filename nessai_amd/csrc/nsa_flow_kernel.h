@@ -171,6 +171,8 @@ struct NsaLaunch {
   int team;
   // extended instances: buffers of the stage ring (NsaRingPipe), 2 ... 8; 0 = 2
   int ring;
+  // extended instances: 1 = teams never work in rounds (NsaTeam::rounds; NESSAI_AMD_ROUNDS=0)
+  int rounds_off;
   // extended instances: 1 / 2 = the LAST one / two waves of every workgroup are loaders - they request the stage copies
   // (every second piece each, when two) and compute nothing, the others request none.  Requesting a 1 KiB piece costs
   // the requesting wave 60 - 200 cycles (the CU's LDS-DMA path takes one per ~60 cycles, MI355X_MICROARCH.md): spread
@@ -432,6 +434,9 @@ struct NsaRingPipe {
   // (NsaLaunch::loader of them, the last waves) 2 = this wave is loader number `ld_index` of `ld_count` and requests
   // every ld_count-th piece, 1 = this wave requests none and waits for none
   int role, ld_index, ld_count;
+  // stages beyond the next one that must have landed at a barrier as well (a team in ROUNDS reads up to this many
+  // stages ahead of the ring's position: nsa_coupling)
+  int lookahead;
   uint32_t ent_off, ent_words;  // table entry of stage `nxt` (read when the copy before it was requested)
   // pieces THIS wave requested for the stages cur + 1 ... cur + 7 (zero beyond the ring's depth)
   int q0, q1, q2, q3, q4, q5, q6;
@@ -523,10 +528,20 @@ struct NsaRingPipe {
     NSA_TL(*this, 12);
     return base + slot * buf_words;
   }
+  // the buffer of the stage `off` positions ahead of the current one (off < nb)
+  __device__ __forceinline__ const float* at(int off) const {
+    int k = slot + off;
+    k = k >= nb ? k - nb : k;
+    return base + k * buf_words;
+  }
   __device__ __forceinline__ void more() {}
   __device__ __forceinline__ void end() {
-    // stage cur + 1 has landed once only the pieces of the stages behind it are outstanding
-    if (role != 1) nsa_wait_vmcnt(q1 + q2 + q3 + q4 + q5 + q6);
+    // stage cur + 1 (+ lookahead) has landed once only the pieces of the stages behind it are outstanding
+    if (role != 1) {
+      const int L = lookahead;
+      nsa_wait_vmcnt((L < 1 ? q1 : 0) + (L < 2 ? q2 : 0) + (L < 3 ? q3 : 0) + (L < 4 ? q4 : 0) + (L < 5 ? q5 : 0) +
+                     (L < 6 ? q6 : 0));
+    }
     NSA_TL(*this, 7);
     barrier();
     NSA_TL(*this, 8);
@@ -907,6 +922,10 @@ __device__ __forceinline__ void nsa_add_terms(const float (&rec)[TP::FPC], float
 struct NsaTeam {
   int size, member;
   float* rec;
+  // 1: the chunks of the last layer in ROUNDS - the members work on `size` consecutive chunks at the same time, each
+  // reading its chunk's stages member * KS positions ahead of the ring (loader waves keep that far ahead:
+  // NsaRingPipe::lookahead); 0: one chunk - one member - per stage barrier
+  int rounds;
 };
 
 // MFMAs of sub-stage J of one chunk of the last conditioner layer (-> acc; cols and the bias come
@@ -953,7 +972,7 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
                                              int dummy_col, int lane, int half, int act, int net,
                                              int n_layers, const NsaTransformConsts& tc,
                                              float (&logdet)[RT], int (&n_bad)[RT], bool bn_within = false,
-                                             NsaTeam team = NsaTeam{1, 0, nullptr}) {
+                                             NsaTeam team = NsaTeam{1, 0, nullptr, 0}) {
   constexpr bool BF = (PREC != NSA_PREC_F32);  // split 16-bit operands (bf16 or f16 pairs)
   const int n_steps0 = __builtin_amdgcn_readfirstlane((int)op[1]);
   const int n_chunks = __builtin_amdgcn_readfirstlane((int)op[2]);
@@ -1129,7 +1148,26 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
 #pragma unroll
     for (int t = 0; t < RT; ++t) nsa_split_regs<PREC, HT>(h[t], hs[t], pipe.amax);
   }
-  for (int c = 0; c < n_chunks; ++c) {
+  // (team geometry: sequentially, chunk c belongs to member c mod size and the others only keep the stage ring turning;
+  // in rounds, iteration `it` is the round of chunks it * size ... and this member's chunk lies member * KS stages
+  // ahead of the ring's position - the positions of the other members' chunks pass as idle stages behind it)
+  constexpr int KSC = nsa_ksplit(TP::C, HT);
+  const bool in_rounds = CTX && team.size > 1 && team.rounds != 0;
+  const int n_iter = in_rounds ? (n_chunks + team.size - 1) / team.size : n_chunks;
+  for (int it = 0; it < n_iter; ++it) {
+    const int c = in_rounds ? it * team.size + team.member : it;
+    int idle_after = 0, ahead = 0;
+    bool active = true;
+    if constexpr (CTX) {
+      if (in_rounds) {
+        const int left = n_chunks - it * team.size;
+        idle_after = ((left < team.size ? left : team.size) - 1) * KSC;
+        ahead = team.member * KSC;
+        active = c < n_chunks;
+      } else if (team.size > 1) {
+        active = (c & (team.size - 1)) == team.member;
+      }
+    }
     if constexpr ((NSA_ABLATE & 2048) != 0) {
       for (int k = 0; k < nsa_ksplit(TP::C, HT); ++k) {
         (void)pipe.template begin<false>();
@@ -1139,9 +1177,8 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
       continue;
     }
     if constexpr (CTX) {
-      // team geometry: chunk c belongs to member c mod size; the others only keep the stage ring turning
-      if (team.size > 1 && (c & (team.size - 1)) != team.member) {
-        for (int k = 0; k < nsa_ksplit(TP::C, HT); ++k) {
+      if (!active) {
+        for (int k = 0; k < KSC + idle_after; ++k) {
           (void)pipe.template begin<false>();
           pipe.end();
         }
@@ -1153,6 +1190,7 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
     nsa_static_for<nsa_ksplit(TP::C, HT)>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
       const float* st = pipe.template begin<SKEW>();
+      if constexpr (CTX) st = pipe.at(ahead);
       nsa_chunk_gemm<HT, TP, PREC, J, RT>(pipe, st, h, hs, lane, half, acc, cols);
       pipe.more();
       NSA_TL(pipe, 5);
@@ -1191,6 +1229,12 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
     }
     NSA_TL(pipe, 6);
     pipe.template end_v<SKEW && (NSA_SKEW_MASK & 4) != 0>();
+    if constexpr (CTX) {
+      for (int k = 0; k < idle_after; ++k) {  // (the stages of the round's other chunks)
+        (void)pipe.template begin<false>();
+        pipe.end();
+      }
+    }
   }
   if constexpr (CTX) {
     // (behind the barrier of the last chunk's stage: every member's terms are in the record; the next coupling
@@ -1362,6 +1406,10 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
   int loaders = 0;  // the workgroup's last `loaders` waves only request the stage copies (NsaLaunch::loader: 0 ... 4)
   if constexpr (CTX) loaders = __builtin_amdgcn_readfirstlane(p.loader > 0 ? (p.loader < 4 ? p.loader : 4) : 0);
   const int n_teams = (nw - loaders) / team_n;
+  // a team works in rounds (NsaTeam::rounds) when loader waves do the requesting and the ring is deep enough for them
+  // to keep a round's stages landed: NESSAI_AMD_ROUNDS=0 (NsaLaunch::rounds_off) keeps one chunk per barrier
+  const bool team_rounds = CTX && team_n > 1 && loaders > 0 && p.rounds_off == 0 &&
+                           (CTX ? (p.ring > 2 ? (p.ring < 8 ? p.ring : 8) : 2) : 2) >= (team_n - 1) * nsa_ksplit(TP::C, HT) + 2;
   const int tw = wave / team_n;            // the wave's tile slot in the workgroup
   const int member = wave - tw * team_n;   // ... and its place in the team
   const int tiles_words = (n_teams * RT * NSA_ROWS * XS0 + 3) & ~3;
@@ -1449,6 +1497,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
       pipe.role = loaders ? (wave >= nw - loaders ? 2 : 1) : 0;
       pipe.ld_index = wave - (nw - loaders);
       pipe.ld_count = loaders;
+      pipe.lookahead = team_rounds ? (team_n - 1) * nsa_ksplit(TP::C, HT) : 0;
     }
     // p.skew: 1 = the upper half of the workgroup's waves, 2 = every other wave
     pipe.skew = SK && (p.skew == 1 ? (wave >= (nw >> 1)) : (p.skew == 2 ? (wave & 1) != 0 : false));
@@ -1693,7 +1742,7 @@ __global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC)
             nsa_coupling<HT, TP, INV, PREC, RT, false>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a);
         } else {
           nsa_coupling<HT, TP, INV, PREC, RT, false, CTX>(pipe, op, xrow_a, D, lane, half, act, net, n_layers, tc, logdet_a, n_bad_a,
-                                                          CTX && img[NSA_H_BNW] != 0, NsaTeam{team_n, member, team_rec});
+                                                          CTX && img[NSA_H_BNW] != 0, NsaTeam{team_n, member, team_rec, team_rounds ? 1 : 0});
         }
       } else if (CTX && member != 0) {
         // team geometry: the ops between the couplings are the first member's (they rewrite the whole tile; their
