@@ -284,6 +284,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     p.prio = -1;  // decided with the geometry below; NESSAI_AMD_PRIO=0|1|2 pins it (NsaLaunch::prio)
   }
   const int D = (int)h[NSA_H_D];
+  const bool wide = h[NSA_H_HT] >= NSA_WIDE_HT;  // 256-wide conditioners: instances built for one wave per SIMD, <= 4 waves per workgroup
   const int C = (int)h[NSA_H_CTX];  // context features of a conditional flow
   if (C < 0 || C > 256) return nsa_fail(NSA_E_IMAGE, "unsupported number of context features %d", C);
   if ((C > 0) != (p.ctx_in != nullptr))
@@ -405,17 +406,24 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
       const char* le = getenv("NESSAI_AMD_LOADER");
       int loader = le != nullptr ? atoi(le) : NSA_DEFAULT_LOADERS;
       loader = loader < 0 ? 0 : (loader > 4 ? 4 : loader);
+      const int max_waves = wide ? 4 : 8;
       // tiles (teams) per workgroup: as many as it takes for ONE round of workgroups over the chip - they share the
       // loaders and every stage copy (config 4's flow: 10000 rows 0.42 -> 0.29 ms at two tiles per workgroup, 20000 rows
       // 0.42 -> 0.32 at four, 40400 rows 0.42 -> 0.40 at five; gpurun_out r05v) - NESSAI_AMD_TILES pins the number
       int tpg = (int)((n_tiles * n_flows + g_num_cus - 1) / g_num_cus);
       tpg = tpg < 1 ? 1 : tpg;
+      bool fits = true;
       {
         const char* tp = getenv("NESSAI_AMD_TILES");
+        const int want = tpg;
         if (tp != nullptr && atoi(tp) >= 1 && atoi(tp) <= 7) tpg = atoi(tp);
-        while (tpg > 1 && team * tpg + (loader > 0 ? 1 : 0) > 8) --tpg;
+        while (tpg > 1 && team * tpg + (loader > 0 ? 1 : 0) > max_waves) --tpg;
+        // (the library's own choice only where ONE round of workgroups covers the batch; a pinned team that does not
+        // fit the instance's workgroup at all keeps the staged geometry)
+        fits = team * tpg <= max_waves && (te != nullptr || tp != nullptr || tpg >= want);
       }
-      if (team * tpg + loader > 8) loader = 8 - team * tpg;  // (the instances' 512 threads)
+      if (team * tpg + loader > max_waves) loader = max_waves - team * tpg;  // (the instances' 512 / 256 threads)
+      if (loader < 0) loader = 0;
       const int waves = team * tpg + loader;
       const size_t fixed = (((size_t)tpg * NSA_ROWS * XS + 3) & ~(size_t)3) * 4 + (size_t)waves * (256 + 8 + 256) +
                            (size_t)tpg * 64 * ((D + 1) / 2 + 16) * 4 + epi_bytes + prog_bytes;
@@ -426,7 +434,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
         if (re != nullptr && atoi(re) >= 2 && atoi(re) < ring) ring = atoi(re);
       }
       const size_t lds = fixed + (size_t)ring * one_stage;
-      if (ring >= 2) {
+      if (ring >= 2 && fits) {
         p.ext = 1;
         p.team = team;
         p.ring = ring;
@@ -474,7 +482,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
   };
   auto per_cu_of = [&](int w) {
     long long c = (long long)(g_max_lds / lds_of(w));
-    const long long by_waves = (4 * occ) / w;  // occ waves per SIMD
+    const long long by_waves = (wide ? 4 : 4 * occ) / w;  // occ waves per SIMD (one for the 256-wide instances)
     if (c > by_waves) c = by_waves;
     return c;
   };
@@ -497,7 +505,7 @@ static int nsa_launch_flow(const uint32_t* h, NsaLaunch& p, int waves_per_group,
     const char* sk = getenv("NESSAI_AMD_SKEW");  // two-tiles geometry only (see NsaStagePipe::skew)
     p.skew = sk != nullptr ? atoi(sk) : NSA_DEFAULT_SKEW;
   }
-  const int nw_max = 4 * occ;
+  const int nw_max = wide ? 4 : 4 * occ;
   int nw = waves_per_group > 0 ? waves_per_group : (occ == 3 || rt == 2 ? 4 * occ : 2 * occ);
   if (nw > nw_max) nw = nw_max;
   if (waves_per_group <= 0) {

@@ -77,6 +77,9 @@ __device__ __forceinline__ void nsa_tl_mark(NsaTl& t, int slot) {
 // Sub-stages along k of a register-fed GEMM with `tiles` output tiles (same rule as pack.ksplit):
 // for the 128-wide conditioners (HT = 4) packed weights above 16 KiB are dealt to 2 or 4 consecutive
 // stages, the accumulators live across them: 2 x 17 KiB of stage buffers instead of 2 x 64 KiB.
+#ifndef NSA_WIDE_HT
+#define NSA_WIDE_HT 8  // hidden tiles from which an instance is built for one wave per SIMD (512 registers)
+#endif
 constexpr int nsa_ksplit(int tiles, int ht) {
   if (ht < 4) return 1;  // <= 64 hidden units: the largest stage is 25 KiB, splitting only adds barriers
   int ks = 1;
@@ -1370,6 +1373,9 @@ __device__ __forceinline__ float nsa_header_float(const uint32_t* img, int word)
 
 // OCC = waves per SIMD the instance is register-budgeted for: 2 (<= 256 VGPRs, workgroups of up to
 // 8 waves) or 3 (<= 168 VGPRs, workgroups of 6 or 12 waves; only the prologue / epilogue spill).
+// (256-wide conditioners - HT >= NSA_WIDE_HT - are built for ONE wave per SIMD whatever OCC says, workgroups of up to
+// 4 waves: hidden state + temporaries + accumulators of a 256-wide layer are 384 registers per lane, and at the 256
+// of two waves per SIMD the instances spilled ~1000 of them to scratch; one wave per SIMD has the unified file's 512)
 // RT = 32-row tiles per wave: the tiles of a wave go through every layer together, so that one read of a
 // weight operand from LDS feeds RT x 3 MFMAs, a stage is copied and a barrier crossed once per RT x NW
 // tiles, and the wave always has RT independent accumulator chains and element-wise chains to issue from.
@@ -1379,7 +1385,8 @@ __device__ __forceinline__ float nsa_header_float(const uint32_t* img, int word)
 // nsa_coupling) and / or batch norm within the residual blocks (eval mode); built for the staged one-tile geometry at
 // 2 waves per SIMD only.  NsaLaunch::ext selects it.
 template <int HT, class TP, bool INV, int PREC, int OCC, int RT = 1, bool RES = false, bool CTX = false>
-__global__ void __launch_bounds__(OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512), OCC) nsa_flow_kernel(NsaLaunch p) {
+__global__ void __launch_bounds__(HT >= NSA_WIDE_HT ? 256 : (OCC == 4 ? 1024 : (OCC == 3 ? 768 : 512)),
+                                  HT >= NSA_WIDE_HT ? 1 : OCC) nsa_flow_kernel(NsaLaunch p) {
   static_assert(!CTX || (RT == 1 && !RES && OCC == 2), "conditional flows: staged, one tile per wave");
   // the staged two-tiles instances carry the skewed copy of the coupling code
   constexpr bool SK = RT == 2 && !RES;

@@ -47,7 +47,7 @@ def main():
         ev.append((a, b))
     torch.cuda.synchronize()
     t = sorted(a.elapsed_time(b) for a, b in ev)
-    out = dict(rows=rows, shape=shape, inverse=inverse, team_env=os.environ.get("NESSAI_AMD_TEAM"), loader_env=os.environ.get("NESSAI_AMD_LOADER"), tiles_env=os.environ.get("NESSAI_AMD_TILES"), rounds_env=os.environ.get("NESSAI_AMD_ROUNDS"), ring_env=os.environ.get("NESSAI_AMD_RING"),
+    out = dict(rows=rows, shape=shape, inverse=inverse, team_env=os.environ.get("NESSAI_AMD_TEAM"), loader_env=os.environ.get("NESSAI_AMD_LOADER"), tiles_env=os.environ.get("NESSAI_AMD_TILES"), rounds_env=os.environ.get("NESSAI_AMD_ROUNDS"), precision=flow.precision, ring_env=os.environ.get("NESSAI_AMD_RING"),
                geometry=[q.value for q in g], team=int(L.nsa_last_team()), ring=int(L.nsa_last_ring()),
                ms_median=round(t[len(t) // 2], 4), ms_min=round(t[0], 4), library=os.path.basename(lib._LIB_PATH))
     if os.environ.get("NSA_TL") == "1":

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: the whole GPU suite on the final library (loader geometry, scalar stage table), smoke(), the round's profile set
-OUT=gpurun_out/r05o
+OUT=gpurun_out/r05z
 mkdir -p $OUT
 timeout 3000 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1
 tail -12 $OUT/pytest.log

@@ -65,6 +65,8 @@ def test_team_rows_equal_single_wave_rows(name, precision, team, monkeypatch):
         geo_t, shared = run_all(flow, x)
         if name == "rnvp_d100_lu" and precision != "f32" and geo_t[3] == 0:
             continue  # (its split-16-bit stages of 66 KiB leave no room for two buffers beside the team's record)
+        if name in ("rnvp_d100_lu", "nsf_d96_h192") and team == 8 and geo_t[3] == 0:
+            continue  # (256-wide instances are built for one wave per SIMD: workgroups of at most four waves)
         assert geo_s[3] == 0 and geo_t[3] == team and geo_t[1] == team, (geo_s, geo_t)
         for a, b in zip(single, shared):
             assert same(a, b)
