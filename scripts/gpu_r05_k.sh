@@ -1,10 +1,12 @@
 #!/bin/bash
-# round 5: A/B of the stage-table / LDS-DMA variants of the headline draw kernel on ONE box, interleaved twice
-OUT=gpurun_out/r05k
+# round 5: A/B of headline-kernel library builds on ONE box, interleaved twice (set VARIANTS; "main" = the shipped library)
+OUT=gpurun_out/r05k2
 mkdir -p $OUT
+rm -f $OUT/ab.jsonl
 for rep in 1 2; do
-for v in base tabs raw tabsraw; do
-  NESSAI_AMD_LIBRARY=variants/libnessai_amd_$v.so timeout 200 python scripts/bench_variants_r05.py 2>/dev/null | tail -1 >> $OUT/ab.jsonl
+for v in ${VARIANTS:-old cur main}; do
+  if [ $v = main ]; then L=nessai_amd/libnessai_amd.so; else L=variants/libnessai_amd_$v.so; fi
+  NESSAI_AMD_LIBRARY=$L timeout 200 python scripts/bench_variants_r05.py 2>/dev/null | tail -1 >> $OUT/ab.jsonl
 done
 done
 cat $OUT/ab.jsonl | python -c "
