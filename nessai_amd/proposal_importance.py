@@ -85,6 +85,32 @@ def empty_ins_array(n, names):
     return out
 
 
+def uniform_box_of(model, dtype):
+    """``(lower, upper, total)`` (float64 arrays and ``-sum log(width)``) when every prior method ``draw`` calls on the
+    model is the framework's own uniform-box implementation - ``UniformBoxModel.log_prior`` through
+    ``Model.batch_evaluate_log_prior``, ``Model.from_unit_hypercube`` / ``in_bounds`` / ``in_unit_hypercube`` /
+    ``batch_evaluate_log_prior_unit_hypercube`` - and the parameters are one float64 block of the point dtype; ``None``
+    otherwise (a subclass that overrides any of them is called on the host, as the reference calls it).
+    ``NESSAI_AMD_DRAW_POINTS=0`` always answers ``None``."""
+    from .model import Model, UniformBoxModel
+
+    t = type(model)
+    own = (getattr(model, "uniform_prior", False) and isinstance(model, UniformBoxModel)
+           and t.log_prior is UniformBoxModel.log_prior and t.batch_evaluate_log_prior is Model.batch_evaluate_log_prior
+           and t.from_unit_hypercube is Model.from_unit_hypercube and t.in_unit_hypercube is Model.in_unit_hypercube
+           and t.in_bounds is Model.in_bounds
+           and t.batch_evaluate_log_prior_unit_hypercube is Model.batch_evaluate_log_prior_unit_hypercube
+           and parameter_block(np.empty(1, dtype=dtype), list(model.names)) is not None
+           and os.environ.get("NESSAI_AMD_DRAW_POINTS", "1") != "0")
+    if not own:
+        return None
+    total = np.float64(0.0)  # (UniformBoxModel.log_prior's own sequence of float64 subtractions)
+    for bounds in model.bounds.values():
+        total -= np.log(bounds[1] - bounds[0])
+    return (np.asarray(model.lower_bounds, dtype=np.float64).copy(), np.asarray(model.upper_bounds, dtype=np.float64).copy(),
+            float(total))
+
+
 class ImportanceFlowProposal:
     def __init__(self, model, output, rng=None, flow_config=None, training_config=None,
                  reparameterisation="logit", weighted_kl=True, reset_flow=True, clip=False,
@@ -382,24 +408,11 @@ class ImportanceFlowProposal:
         cached = getattr(self, "_box_dev", None)
         if cached is not None:
             return cached[0]
-        from .model import Model, UniformBoxModel
-
-        m, t = self.model, type(self.model)
-        own = (getattr(m, "uniform_prior", False) and isinstance(m, UniformBoxModel)
-               and t.log_prior is UniformBoxModel.log_prior and t.batch_evaluate_log_prior is Model.batch_evaluate_log_prior
-               and t.from_unit_hypercube is Model.from_unit_hypercube and t.in_unit_hypercube is Model.in_unit_hypercube
-               and t.in_bounds is Model.in_bounds
-               and t.batch_evaluate_log_prior_unit_hypercube is Model.batch_evaluate_log_prior_unit_hypercube
-               and parameter_block(np.empty(1, dtype=self.dtype), list(m.names)) is not None
-               and os.environ.get("NESSAI_AMD_DRAW_POINTS", "1") != "0")
+        host = uniform_box_of(self.model, self.dtype)
         box = None
-        if own:
-            total = np.float64(0.0)
-            for bounds in m.bounds.values():
-                total -= np.log(bounds[1] - bounds[0])
+        if host is not None:
             dev = self.flow.device
-            box = (torch.tensor(np.asarray(m.lower_bounds, dtype=np.float64), device=dev),
-                   torch.tensor(np.asarray(m.upper_bounds, dtype=np.float64), device=dev), float(total))
+            box = (torch.tensor(host[0], device=dev), torch.tensor(host[1], device=dev), host[2])
         self._box_dev = (box,)
         return box
 

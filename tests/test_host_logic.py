@@ -309,3 +309,44 @@ def test_eval_mode_switches_only_what_is_in_training_mode():
     assert calls == [] and not any(m.training for m in models.modules())
     single = flow()
     assert eval_mode(single) is single and not single[1].training
+
+
+def test_device_written_draw_records_only_for_the_frameworks_own_uniform_box_prior(monkeypatch):
+    """``ImportanceFlowProposal.draw`` lets the device fill the prior fields of a batch (``nsa_importance_mix_points``)
+    only when every prior method it would call on the model is the framework's own uniform-box implementation; a
+    subclass that overrides one of them - a user's prior - is evaluated on the host as the reference does
+    (``proposal/importance.py:488-503``).  The constant handed to the kernel is ``log_prior``'s own."""
+    from nessai_amd.model import CorrelatedGaussianModel, UniformBoxModel
+    from nessai_amd.proposal_importance import empty_ins_array, ins_dtype, uniform_box_of
+
+    monkeypatch.delenv("NESSAI_AMD_DRAW_POINTS", raising=False)
+    model = CorrelatedGaussianModel(6, rho=0.5, bound=3.0)
+    dtype = ins_dtype(model.names)
+    lower, upper, total = uniform_box_of(model, dtype)
+    assert np.array_equal(lower, np.full(6, -3.0)) and np.array_equal(upper, np.full(6, 3.0))
+    pts = empty_ins_array(4, model.names)
+    for n in model.names:
+        pts[n] = 0.25
+    assert np.all(model.log_prior(pts) == total)  # bit for bit the value of an in-bounds point
+    # the device's record layout is the dtype's: 8 D + 44 bytes, parameters first, fields at the offsets it writes
+    assert dtype.itemsize == 8 * 6 + 44
+    assert [dtype.fields[f][1] for f in ("logP", "logL", "it", "logQ", "logW", "logU")] == [48, 56, 64, 68, 76, 84]
+
+    class OwnPrior(CorrelatedGaussianModel):
+        def log_prior(self, x):
+            return super().log_prior(x) - 1.0
+
+    class OwnMap(UniformBoxModel):
+        def from_unit_hypercube(self, x):
+            return super().from_unit_hypercube(x)
+
+    class OwnCube(UniformBoxModel):
+        def batch_evaluate_log_prior_unit_hypercube(self, x):
+            return super().batch_evaluate_log_prior_unit_hypercube(x)
+
+    assert uniform_box_of(OwnPrior(6), dtype) is None
+    assert uniform_box_of(OwnMap(6), ins_dtype(OwnMap(6).names)) is None
+    assert uniform_box_of(OwnCube(6), ins_dtype(OwnCube(6).names)) is None
+    assert uniform_box_of(RosenbrockModel(4), ins_dtype(RosenbrockModel(4).names)) is not None or not isinstance(RosenbrockModel(4), UniformBoxModel)
+    monkeypatch.setenv("NESSAI_AMD_DRAW_POINTS", "0")
+    assert uniform_box_of(model, dtype) is None
