@@ -70,18 +70,21 @@ NSA_API int nsa_last_row_tiles(void);
  * counterpart. */
 NSA_API int nsa_last_resident(void);
 
-/* Waves that shared each 32-row tile in that launch (0: every wave had its own).  Batches with fewer tiles than
- * the chip has CUs are latency-bound - one wave's trip through the flow - and the library then gives a tile to a
- * team of four waves, one per SIMD: every member runs the conditioner's trunk, the chunks of its last layer
- * (parameters + element-wise transform) are dealt round the members, and the Jacobian terms are summed in the
- * order a single wave sums them: same rows bit for bit.  Chosen for conditioners of 128 features and more
- * (ImportanceFlowProposal.draw / log_prob_all on a few thousand rows, src/nessai/proposal/importance.py:443-526);
- * NESSAI_AMD_TEAM=0 switches it off, 2 / 4 / 8 pins a team size for any flow.  No reference counterpart. */
+/* Computing waves per 32-row tile of that launch when it ran in the SMALL-BATCH geometry (0: a staged / resident
+ * launch).  Batches of up to five tiles per CU are latency-bound - one workgroup per tile walks the whole program - and
+ * the library then launches, per tile, one computing wave on a ring of up to eight stage buffers, with loader waves
+ * that only request the stage copies (three per workgroup; several tiles share a workgroup above one tile per CU).
+ * Chosen for conditioners of 64 features and more whose program does not stay resident in LDS
+ * (ImportanceFlowProposal.draw / log_prob_all on a few thousand rows, src/nessai/proposal/importance.py:443-526; the
+ * live points under a spline flow); same rows bit for bit.  NESSAI_AMD_TEAM=0 switches it off; 2 / 4 / 8 give a tile
+ * to a team of that many computing waves (the chunks of the last conditioner layer dealt round the team, the Jacobian
+ * terms summed in single-wave order).  No reference counterpart. */
 NSA_API int nsa_last_team(void);
 
-/* Stage buffers of that launch's ring when it ran in the team geometry (0 otherwise): the copy of a stage is
- * requested ring - 1 stages before its arithmetic, so that a small batch runs at the throughput of the CU's
- * LDS-DMA path instead of at the latency of one copy per stage.  NESSAI_AMD_RING pins it (2 = double buffer). */
+/* Stage buffers of that launch's ring when it ran in the small-batch geometry (0 otherwise): the copy of a stage is
+ * requested ring - 1 stages before its arithmetic, so that a small batch runs at the throughput of the CU's LDS-DMA
+ * path instead of at the latency of one copy per stage.  NESSAI_AMD_RING pins it (2 = double buffer),
+ * NESSAI_AMD_LOADER the loader waves (0 ... 4), NESSAI_AMD_TILES the tiles per workgroup. */
 NSA_API int nsa_last_ring(void);
 
 /* Run a whole flow over n rows.

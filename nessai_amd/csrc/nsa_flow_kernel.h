@@ -166,11 +166,12 @@ struct NsaLaunch {
   const float* ctx_in;
   // 1: the flow needs the extended-conditioner instances (NSA_H_CTX > 0 or NSA_H_BNW != 0; set by nsa_launch_flow)
   int ext;
-  // team geometry (extended instances only; small batches of wide flows - nsa_launch_flow): `team` waves share ONE
-  // 32-row tile.  Every member runs the conditioner's trunk, the chunks of its last layer - the parameters and the
-  // element-wise transform of 2 FPC features each - are dealt round the members; the Jacobian terms meet in LDS and
-  // are summed by member 0 in the order one wave sums them, so the rows come out bit for bit as in any other
-  // geometry.  0 / 1: off.
+  // small-batch geometry (extended instances only - nsa_launch_flow): `team` computing waves per 32-row tile, >= 1 (0:
+  // a plain launch of the extended instances, every wave its own tile and its share of the stage copies).  With
+  // team > 1 the waves of a team share ONE tile: every member runs the conditioner's trunk, the chunks of its last
+  // layer - the parameters and the element-wise transform of 2 FPC features each - are dealt round the members; the
+  // Jacobian terms meet in LDS and are summed by member 0 in the order one wave sums them, so the rows come out bit
+  // for bit as in any other geometry.
   int team;
   // extended instances: buffers of the stage ring (NsaRingPipe), 2 ... 8; 0 = 2
   int ring;
