@@ -67,6 +67,28 @@ def test_flow_instances_keep_their_register_budget_and_use_no_scratch(obj, kerne
     assert r["vgpr"] + r["agpr"] <= budget, r
 
 
+def test_small_batch_and_wide_instances_stay_inside_their_budgets():
+    """The extended instances the small-batch geometry launches (loader waves, stage ring, teams) and the 256-wide
+    ones: no spilled register in the 64-wide class (config 3's live points), at most a handful outside the coupling
+    loop in the 128-wide class (config 4), the 256-wide class built for ONE wave per SIMD - accumulation registers in
+    use, a few hundred bytes of scratch instead of the kilobyte of the two-waves build."""
+    t2 = _kernels("inst_h2_t1_8.o")
+    for inv in ("true", "false"):
+        for prec in (0, 1, 2):
+            r = _one(t2, f"nsa_flow_kernel<2, NsaRQ<8, false>, {inv}, {prec}, 2, 1, false, true>")
+            assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 256, r
+    t4 = _kernels("inst_h4_t1_8.o")
+    for inv in ("true", "false"):
+        r = _one(t4, f"nsa_flow_kernel<4, NsaRQ<8, false>, {inv}, 2, 2, 1, false, false>")
+        assert r["spill"] == 0 and r["scratch"] == 0, r
+        for prec in (0, 1, 2):
+            r = _one(t4, f"nsa_flow_kernel<4, NsaRQ<8, false>, {inv}, {prec}, 2, 1, false, true>")
+            assert r["spill"] <= 16 and r["scratch"] <= 64, r
+    t8 = _kernels("inst_h8_t1_8.o")
+    for name, r in t8.items():
+        assert r["agpr"] > 0 and r["vgpr"] <= 512 and r["scratch"] <= 400, (name, r)  # (vgpr: the unified total)
+
+
 def test_second_generation_training_kernels_do_not_spill():
     table = _kernels("nsa_train.o")
     for name in ("trf2_forward<8, 2, 6>(Trf2Multi)", "trf2_forward<8, 2, 1>(Trf2Multi)", "trf2_forward<0, 1, 4>(Trf2Multi)"):
