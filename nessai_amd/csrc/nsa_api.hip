@@ -12,10 +12,17 @@
 #include "../../include/nessai_amd.h"
 #include "nsa_flow_kernel.h"
 
+// (each with its own guard: a variant build may pass any one of them with -D, scripts/build_variant.sh)
 #ifndef NSA_DEFAULT_OCC
 #define NSA_DEFAULT_OCC 2
+#endif
+#ifndef NSA_DEFAULT_LOADERS
 #define NSA_DEFAULT_LOADERS 3  // loader waves per workgroup of the small-batch geometry (NsaLaunch::loader): 1 computing wave + 3 = one wave per SIMD
+#endif
+#ifndef NSA_LOADER_MAX_TILES
 #define NSA_LOADER_MAX_TILES 5  // ... up to this many tiles per CU (as many tiles per workgroup, sharing the loaders)
+#endif
+#ifndef NSA_TEAM_MIN_HT
 #define NSA_TEAM_MIN_HT 2  // conditioners of >= 64 features take the loader geometry on small batches (nsa_launch_flow)
 #endif
 #ifndef NSA_DEFAULT_SKEW

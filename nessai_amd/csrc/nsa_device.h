@@ -429,8 +429,14 @@ struct NsaRQ {
     const bool inside = (x >= -B) && (x <= B);
     const float xin = inside ? x : 0.0f;
     float o[6];  // searched axis k, k+1; other axis k, k+1; derivative logits k, k+1
-    if constexpr (INV) NsaBinSelect<K>::run(ch, cw, raw, xin, o);
-    else NsaBinSelect<K>::run(cw, ch, raw, xin, o);
+    // PAD: knot k_real (= B) is an INTERIOR entry of the searched table when k_real < K, so an input exactly equal to
+    // +B would pass `x >= a[k_real]` into the empty bin behind it (width inf, 1 / width 0: NaN) where nflows and the
+    // exact instances keep it in the last real bin (y = B, log|J| = 0).  The search - compares only - takes the
+    // largest float below B for such an input; the arithmetic keeps xin.
+    float xkey = xin;
+    if constexpr (PAD) xkey = fminf(xin, __uint_as_float(__float_as_uint(B) - 1u));
+    if constexpr (INV) NsaBinSelect<K>::run(ch, cw, raw, xkey, o);
+    else NsaBinSelect<K>::run(cw, ch, raw, xkey, o);
     const float in_cw = INV ? o[2] : o[0], in_cw1 = INV ? o[3] : o[1];
     const float in_ch = INV ? o[0] : o[2], in_ch1 = INV ? o[1] : o[3];
     // only the two derivatives that are used are evaluated

@@ -156,6 +156,7 @@ class HipFlow(BaseFlow):
             )
         self._transform = transform
         self._distribution = distribution
+        self._refuse_float64()
         self._image_key = None
         self._image_dev = None
         self._header = None
@@ -188,6 +189,29 @@ class HipFlow(BaseFlow):
         # depths, ...) is known to the packer: pack once now so that an unsupported configuration raises
         # at construction like the checks above, not at the first call
         pack.pack_flow(dict(desc, precision=self.precision if self.precision != "auto" else "f32"))
+
+    _FLOAT64_REFUSAL = (
+        "nessai_amd flows compute in float32 (split-f16 / f32 matrix products, float32 spline; float64 only in the "
+        "populate epilogue): there is no float64 kernel, and nothing is cast down silently. {what} - the "
+        "reference's torch_dtype='float64' (src/nessai/utils/torchutils.py:12-25, flowsampler.py:101,121) is not "
+        "available on this device path; keep torch's default dtype float32 and pass float32 tensors."
+    )
+
+    def _refuse_float64(self, x=None):
+        """Float64 is refused, never downgraded: a flow built under ``torch.set_default_dtype(torch.float64)`` (or
+        converted with ``.double()``) and float64 inputs raise - nflows raises a dtype mismatch for float64 inputs
+        to a float32 flow as well."""
+        for p in self.parameters():
+            if p.dtype == torch.float64:
+                raise TypeError(self._FLOAT64_REFUSAL.format(
+                    what="This flow holds float64 parameters (torch default dtype "
+                         f"{torch.get_default_dtype()}, or .double() was called)"))
+            break
+        if x is not None and x.dtype == torch.float64:
+            raise TypeError(self._FLOAT64_REFUSAL.format(what="The input tensor is float64"))
+
+    def double(self):
+        raise TypeError(self._FLOAT64_REFUSAL.format(what=".double() was called on the flow"))
 
     def apply(self, fn):
         """``torch.nn.Module.apply``, with the reference's two reset visitors
@@ -388,6 +412,7 @@ class HipFlow(BaseFlow):
             raise ValueError(
                 "Expected inputs of shape (N, {}), got {}".format(self.features, tuple(x.shape))
             )
+        self._refuse_float64(x)
         return x.detach().to(torch.float32).contiguous()
 
     def trainer(self):
@@ -423,6 +448,16 @@ class HipFlow(BaseFlow):
         if context.dim() != 2 or context.shape != (n, self.context_features):
             raise ValueError("Expected a context of shape ({}, {}), got {}".format(n, self.context_features,
                                                                                   tuple(context.shape)))
+        if context.dtype == torch.float64:
+            raise TypeError(self._FLOAT64_REFUSAL.format(what="The context tensor is float64"))
+        if context.requires_grad and torch.is_grad_enabled():
+            # (the reverse-mode kernels compute the gradient of the parameters and of x only: a context produced by
+            # a trainable embedding net would train with a zero gradient and no error otherwise)
+            raise RuntimeError(
+                "the context of a conditional nessai_amd flow carries no gradient: it was given with "
+                "requires_grad=True (an embedding net upstream of the flow would not train); detach it, or "
+                "evaluate under torch.no_grad()"
+            )
         return context.detach().to(torch.float32).contiguous()
 
     def _run(self, x, direction, mode, want_x=True, context=None):
@@ -470,6 +505,7 @@ class HipFlow(BaseFlow):
             empty = torch.empty(0, dtype=torch.float32, device=x.device)
             z = torch.empty((0, self.features), dtype=torch.float32, device=x.device) if want_x else None
             return z, empty, self._status
+        self._refuse_float64(x)
         xin = x.to(torch.float32).contiguous()
         log_prob = mode == MODE_LOGPROB
         z, ld, lp = ops.differentiable_flow(self, xin, want_x, not log_prob, log_prob, context=context)

@@ -204,8 +204,27 @@ def load():
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
+    _check_instance_matrix(lib)
     _LIB = lib
     return lib
+
+
+def _check_instance_matrix(lib):
+    """The packer lays a spline flow out for the kernel instance ``pack.kernel_bins`` names - the EXACT layout for
+    4 / 8 / 10 / 16 bins, the padded 16-bin one otherwise - while the library picks the instance it will launch by
+    itself (``nsa_find``: the exact one, else the generic one).  A library built with a reduced ``TRANSFORMS`` list
+    (csrc/Makefile) could therefore run an exact-layout image on the generic instance: refuse such a build here."""
+    from .pack import EXACT_BINS
+
+    rq = 1  # NSA_T_RQ (csrc/nsa_format.h)
+    for ht in (1, 2, 4, 8):
+        for bins in EXACT_BINS:
+            if lib.nsa_flow_supported(ht, rq, bins) and lib.nsa_flow_generic_bins(ht, bins):
+                raise RuntimeError(
+                    f"{_LIB_PATH} has no exact spline instance for {bins} bins at {ht} hidden tile(s) but would run "
+                    "such a flow on the generic instance, whose parameter layout differs from what nessai_amd.pack "
+                    "writes for this bin count: rebuild with the full TRANSFORMS list of nessai_amd/csrc/Makefile"
+                )
 
 
 def check(rc, what):

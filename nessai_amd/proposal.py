@@ -644,13 +644,17 @@ class FlowProposal:
         dev = self.device
         L = lib.load()
         ws_bytes = int(L.nsa_populate_accept_workspace(n))
+        # log_q / log_p also receive the per-row outputs of the lean replay, which writes one element per
+        # replayed row: up to ``capacity`` (= n_samples) of them, which exceeds a pass when poolsize > drawsize
+        # or when a sharded rank accepts more than its share drawsize / world of the batch
+        n_rows = max(n, capacity)
         self._buffers = dict(
             key=key,
             x64=torch.empty((n, self.dims), dtype=torch.float64, device=dev),
-            log_q=torch.empty(n, dtype=torch.float64, device=dev),
+            log_q=torch.empty(n_rows, dtype=torch.float64, device=dev),
             log_w=torch.empty(n, dtype=torch.float64, device=dev),
             max_key=torch.empty(1, dtype=torch.int64, device=dev),
-            log_p=torch.empty(n, dtype=torch.float64, device=dev),
+            log_p=torch.empty(n_rows, dtype=torch.float64, device=dev),
             x_acc=torch.empty((capacity, self.dims), dtype=torch.float64, device=dev),
             n_acc=torch.zeros(1, dtype=torch.int64, device=dev),
             workspace=torch.empty(ws_bytes, dtype=torch.uint8, device=dev),

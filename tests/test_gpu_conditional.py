@@ -108,6 +108,18 @@ def test_context_argument_is_checked():
         plain.log_prob(x, context=torch.randn(10, 1, device=DEV))
     with pytest.raises(NotImplementedError, match="MLP with conditional inputs"):
         RealNVP(4, 8, 2, 2, net="mlp", context_features=2)
+    # a context that wants a gradient (the output of an embedding net, which nflows supports) would train with a
+    # zero gradient: refused while autograd records, fine under no_grad / when detached (round-5 advisor finding)
+    ctx = torch.randn(10, C, device=DEV, requires_grad=True)
+    with pytest.raises(RuntimeError, match="carries no gradient"):
+        flow.log_prob(x, context=ctx)
+    with torch.no_grad():
+        assert torch.isfinite(flow.log_prob(x, context=ctx)).all()
+    assert torch.isfinite(flow.log_prob(x, context=ctx.detach())).all()
+    with pytest.raises(TypeError, match="context tensor is float64"):
+        flow.log_prob(x, context=ctx.detach().double())
+    with pytest.raises(TypeError, match="input tensor is float64"):
+        flow.log_prob(x.double(), context=ctx.detach())
 
 
 def test_flowmodel_numpy_boundary_with_conditional(tmp_path):

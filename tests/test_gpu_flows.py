@@ -210,6 +210,25 @@ def test_spline_tails_and_knots():
     np.testing.assert_allclose(zk.cpu().numpy()[:, 0], [1.25, -2.5, 3.75], atol=2e-6)
 
 
+@pytest.mark.parametrize("bins", [8, 5, 2, 13])
+def test_spline_input_exactly_at_the_tail_bound(bins):
+    """x == +-tail_bound is still `inside` (nflows: ``inputs <= right``): it belongs to the LAST real bin, y = +-B and
+    log|J| = 0 in both directions - also in the generic instance (5, 2, 13 bins on 16-bin padded parameter sets),
+    where knot k_real = B is an interior entry of the searched table (round-5 advisor finding: NaN there)."""
+    ref, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (2, 8, 1, 1), dict(linear_transform=None, num_bins=bins))
+    x = torch.tensor([[0.3, 5.0], [-0.7, -5.0], [5.0, 0.1], [-5.0, -0.2], [5.0, 5.0], [-5.0, -5.0]])
+    with torch.no_grad():
+        z_ref, ld_ref = ref.forward(x)
+        xi_ref, ldi_ref = ref.inverse(x)
+    for prec in ("f32", "f16x3"):
+        flow.precision = prec
+        z, ld = flow.forward(x.to(DEV))
+        xi, ldi = flow.inverse(x.to(DEV))
+        for got, want in ((z, z_ref), (ld, ld_ref), (xi, xi_ref), (ldi, ldi_ref)):
+            assert torch.isfinite(got).all()
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=2e-5)
+
+
 def test_cpu_tensors_fail_loudly():
     _, flow = make_pair(NeuralSplineFlow, O.NeuralSplineFlow, (4, 8, 2, 2))
     with pytest.raises(RuntimeError, match="no CPU fallback"):

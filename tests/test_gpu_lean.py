@@ -51,6 +51,14 @@ def _make(case, lean, precision="auto", **extra):
         prop.initialise()
         prop.check_state(GaussianModel(16).new_point(2000, rng=np.random.default_rng(1)))
         calls = [dict(n_samples=1000, max_samples=10**8)] * 2
+    elif case == "pool_exceeds_draw":  # more rows replayed than one pass draws (poolsize > drawsize > 16384): the
+        # replay's per-row outputs must not be sized by the pass (round-5 advisor finding, proposal.py _get_buffers)
+        prop = FlowProposal(GaussianModel(4), rng=np.random.default_rng(3), poolsize=30_000, drawsize=20_000,
+                            flow_config=dict(ftype="realnvp", n_neurons=8, n_blocks=2), device_seed=5, lean=lean,
+                            precision=precision, **extra)
+        prop.initialise()
+        prop.check_state(GaussianModel(4).new_point(300, rng=np.random.default_rng(1)))
+        calls = [dict(n_samples=30_000, max_samples=10**9)] * 2
     else:  # max_samples exit inside a train
         prop = FlowProposal(GaussianModel(4), rng=np.random.default_rng(3), poolsize=500, drawsize=20_000,
                             flow_config=dict(ftype="realnvp", n_neurons=8, n_blocks=2), device_seed=5, lean=lean,
@@ -62,7 +70,7 @@ def _make(case, lean, precision="auto", **extra):
 
 
 @pytest.mark.parametrize("precision", ["auto", "f32"])
-@pytest.mark.parametrize("case", ["c3", "separable_prior", "realnvp_lu", "max_samples"])
+@pytest.mark.parametrize("case", ["c3", "separable_prior", "realnvp_lu", "max_samples", "pool_exceeds_draw"])
 def test_lean_passes_and_replay_equal_the_full_passes(case, precision):
     results = {}
     for lean in (True, False):
@@ -80,6 +88,8 @@ def test_lean_passes_and_replay_equal_the_full_passes(case, precision):
             assert np.array_equal(a[k], b[k])
     if case == "max_samples":
         assert results[True][0][2] > 90_000 and results[True][0][1] < 10**6
+    if case == "pool_exceeds_draw":  # the replay really covered more rows than a pass has
+        assert results[True][0][0].shape[0] == 30_000 > 20_000
 
 
 def test_lean_with_the_min_log_q_rule_and_not_with_the_likelihood_rule():

@@ -173,3 +173,88 @@ def test_sharded_train_leaves_one_flow_on_every_rank(tmp_path, replicate):
     for r, d in enumerate((a, b)):
         state = torch.load(str(d["weights_file"]), map_location="cpu", weights_only=True)
         assert all(torch.isfinite(v).all() for v in state.values() if v.is_floating_point()), r
+
+
+def _gauss_proposal(shard, lean=True):
+    """Default-style sizes: ``drawsize == poolsize`` (the reference's default), big enough that a rank's share of a
+    pass (20000 rows) takes the lean trains - a rank then routinely accepts MORE than drawsize / world rows, which the
+    replay's per-row outputs must hold (round-5 advisor finding)."""
+    sys.path.insert(0, ROOT)
+    from nessai_amd.model import GaussianModel
+    from nessai_amd.proposal import FlowProposal
+
+    torch.manual_seed(0)
+    prop = FlowProposal(GaussianModel(4), rng=np.random.default_rng(3), poolsize=40_000, drawsize=40_000,
+                        flow_config=dict(ftype="realnvp", n_neurons=8, n_blocks=2), device_seed=5, shard=shard,
+                        lean=lean)
+    prop.initialise()
+    prop.check_state(GaussianModel(4).new_point(300, rng=np.random.default_rng(1)))
+    return prop
+
+
+def _gauss_worker(rank, world, port, out_dir, backend):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    prop = _gauss_proposal(shard=True)
+    stats = []
+    for _ in range(2):
+        prop.populate(None, n_samples=40_000, max_samples=10**9)
+        assert prop.last_populate_path == "trains_sharded" and prop.last_populate_lean
+        stats.append(dict(prop.sharded_stats))
+    x = np.stack([prop.x[n] for n in prop.names], axis=1)
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), x)
+    with open(os.path.join(out_dir, f"c{rank}.txt"), "w") as f:
+        f.write(f"{prop.n_accepted} {prop.n_proposed}")
+    import json
+
+    with open(os.path.join(out_dir, f"s{rank}.json"), "w") as f:
+        json.dump(stats, f)
+    if backend == "nccl":
+        torch.cuda.synchronize()
+    dist.destroy_process_group()
+
+
+def _gauss_single():
+    single = _gauss_proposal(shard=False)
+    for _ in range(2):
+        single.populate(None, n_samples=40_000, max_samples=10**9)
+    assert single.last_populate_path == "trains"
+    return single, np.stack([single.x[n] for n in single.names], axis=1)
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_with_drawsize_equal_to_poolsize(tmp_path):
+    """``drawsize == poolsize`` sharded over two ranks: each rank draws 20000 rows per pass and replays up to 40000
+    accepted ones - the pool equals the one-rank pool bit for bit."""
+    mp.spawn(_gauss_worker, args=(2, _free_port(), str(tmp_path), "gloo"), nprocs=2, join=True)
+    single, expected = _gauss_single()
+    xs = [np.load(tmp_path / f"x{r}.npy") for r in range(2)]
+    assert np.array_equal(xs[0], xs[1]) and xs[0].shape == (40_000, 4)
+    counts = [(tmp_path / f"c{r}.txt").read_text().split() for r in range(2)]
+    assert counts[0] == counts[1] == [str(single.n_accepted), str(single.n_proposed)]
+    assert np.array_equal(xs[0], expected)
+
+
+@pytest.mark.timeout(600)
+def test_rccl_one_rank_sharded_populate_equals_unsharded(tmp_path):
+    """The RCCL path under the driver every round: ONE rank on the ``nccl`` backend (= RCCL on ROCm; what
+    ``NESSAI_AMD_FORCE_SHARD=1`` does in ``bench.py``) runs the sharded trains - heads, all-reduce(max) of the
+    maxima on the device, tails, all-reduce(sum) of the counts, commit - and must end with the pool of the unsharded
+    loop; ``sharded_stats`` counts two all-reduces per train (the two all-gathers exist from world 2 on)."""
+    import json
+
+    mp.spawn(_gauss_worker, args=(1, _free_port(), str(tmp_path), "nccl"), nprocs=1, join=True)
+    single, expected = _gauss_single()
+    x = np.load(tmp_path / "x0.npy")
+    assert (tmp_path / "c0.txt").read_text().split() == [str(single.n_accepted), str(single.n_proposed)]
+    assert np.array_equal(x, expected)
+    for st in json.loads((tmp_path / "s0.json").read_text()):
+        assert st["trains"] >= 1 and st["all_reduce"] == 2 * st["trains"]
+        assert sum(st["train_lengths"]) >= st["passes"] >= 1
+        assert st["all_gather"] == 0  # world 1: nothing to gather; 2 from world 2 on (test_distributed_gloo.py)

@@ -350,3 +350,26 @@ def test_device_written_draw_records_only_for_the_frameworks_own_uniform_box_pri
     assert uniform_box_of(RosenbrockModel(4), ins_dtype(RosenbrockModel(4).names)) is not None or not isinstance(RosenbrockModel(4), UniformBoxModel)
     monkeypatch.setenv("NESSAI_AMD_DRAW_POINTS", "0")
     assert uniform_box_of(model, dtype) is None
+
+
+def test_float64_is_refused_not_downgraded():
+    """The reference's ``torch_dtype="float64"`` (``utils/torchutils.py:12-25``, ``flowsampler.py:101,121``) builds and
+    evaluates its flows in float64.  The gfx950 kernels compute in float32: a float64 flow or input must RAISE, never
+    be cast down in silence (round-5 verdict) - like nflows' dtype mismatch for a float64 input to a float32 flow."""
+    import torch
+
+    from nessai_amd.flows import NeuralSplineFlow, RealNVP
+
+    flow = RealNVP(4, 8, 2, 2)
+    assert all(p.dtype == torch.float32 for p in flow.parameters())
+    with pytest.raises(TypeError, match="float64"):
+        flow.double()
+    with pytest.raises(TypeError, match="input tensor is float64"):
+        flow._refuse_float64(torch.zeros(3, 4, dtype=torch.float64))
+    flow._refuse_float64(torch.zeros(3, 4))  # float32: fine
+    torch.set_default_dtype(torch.float64)
+    try:
+        with pytest.raises(TypeError, match="float64 parameters"):
+            NeuralSplineFlow(4, 8, 2, 2)
+    finally:
+        torch.set_default_dtype(torch.float32)
