@@ -388,39 +388,41 @@ struct NsaRQ {
     return (s >= 7.888609052210118e-31f) & (s <= 1.2676506002282294e30f);
   }
 
-  template <int P, int OFF, bool INV, int NV>
-  __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
-                                               const NsaTransformConsts& c, float& y, float& ld,
-                                               bool& bad) {
-#pragma clang fp contract(off)
+  // The evaluation in three pieces (round 6: a caller can place other work - the next chunk's MFMAs - inside each of
+  // them; `phase` below runs them back to back, the same instruction stream as before the split):
+  //   knots_checked<OFF>      the knots of one axis (widths: OFF, bin sizes min_bw / bw_scale; heights: OFF + K, ...)
+  //   evaluate<OFF, INV>      bin search, the two derivatives, the rational-quadratic map and its log|J|
+  // The two wave-uniform "redo" branches (below) end a basic block each: three straight-line pieces per evaluation.
+  template <int OFF, int NV>
+  __device__ __forceinline__ static void knots_checked(const float (&v)[NV], const NsaTransformConsts& c, float mn,
+                                                       float sc, float (&cum)[K + 1]) {
     const float B = c.tail_bound;
-    float cw[K + 1], ch[K + 1], raw[K + 1];
     // (checked per axis, right behind its knots: the eight logits of an axis then stay live a few instructions
     // longer, not across the other axis - checked together they cost the two-tiles instance two spilled registers;
     // the branches are wave-uniform and practically never taken)
 #ifdef NSA_SHIFTED_SOFTMAX  // A/B builds (scripts/build_variant.sh): the max-subtracted softmax of rounds 1-4
-    knots<OFF, NV, true>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw, c.k_real);
-    knots<OFF + K, NV, true>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch, c.k_real);
+    knots<OFF, NV, true>(v, c.inv_logit_div, mn, sc, c.two_b, B, cum, c.k_real);
 #else
     // A row's result must not depend on the rows that share its wave (the same rows come back bit for bit from any
     // launch geometry and from nsa_populate_replay): the branch is taken by the wave, the repeat is KEPT per lane.
-    const float sw = knots<OFF, NV, false>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, cw, c.k_real);
-    const bool redo_w = !sum_in_range(sw);
-    if (__builtin_expect(__any(redo_w), 0)) {
+    const float sw = knots<OFF, NV, false>(v, c.inv_logit_div, mn, sc, c.two_b, B, cum, c.k_real);
+    const bool redo = !sum_in_range(sw);
+    if (__builtin_expect(__any(redo), 0)) {
       float alt[K + 1];
-      knots<OFF, NV, true>(v, c.inv_logit_div, c.min_bw, c.bw_scale, c.two_b, B, alt, c.k_real);
+      knots<OFF, NV, true>(v, c.inv_logit_div, mn, sc, c.two_b, B, alt, c.k_real);
 #pragma unroll
-      for (int i = 0; i <= K; ++i) cw[i] = redo_w ? alt[i] : cw[i];
-    }
-    const float sh = knots<OFF + K, NV, false>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, ch, c.k_real);
-    const bool redo_h = !sum_in_range(sh);
-    if (__builtin_expect(__any(redo_h), 0)) {
-      float alt[K + 1];
-      knots<OFF + K, NV, true>(v, c.inv_logit_div, c.min_bh, c.bh_scale, c.two_b, B, alt, c.k_real);
-#pragma unroll
-      for (int i = 0; i <= K; ++i) ch[i] = redo_h ? alt[i] : ch[i];
+      for (int i = 0; i <= K; ++i) cum[i] = redo ? alt[i] : cum[i];
     }
 #endif
+  }
+
+  template <int OFF, bool INV, int NV>
+  __device__ __forceinline__ static void evaluate(const float (&v)[NV], float x, const NsaTransformConsts& c,
+                                                  const float (&cw)[K + 1], const float (&ch)[K + 1], float& y,
+                                                  float& ld, bool& bad) {
+#pragma clang fp contract(off)
+    const float B = c.tail_bound;
+    float raw[K + 1];
     // derivative logits per knot; the boundary knots carry the logit of derivative 1
     raw[0] = c.edge_raw;
     raw[K] = c.edge_raw;
@@ -479,6 +481,17 @@ struct NsaRQ {
     lad = INV ? -lad : lad;
     y = inside ? out : x;
     ld = inside ? lad : 0.0f;
+  }
+
+  template <int P, int OFF, bool INV, int NV>
+  __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
+                                               const NsaTransformConsts& c, float& y, float& ld,
+                                               bool& bad) {
+#pragma clang fp contract(off)
+    float cw[K + 1], ch[K + 1];
+    knots_checked<OFF, NV>(v, c, c.min_bw, c.bw_scale, cw);
+    knots_checked<OFF + K, NV>(v, c, c.min_bh, c.bh_scale, ch);
+    evaluate<OFF, INV, NV>(v, x, c, cw, ch, y, ld, bad);
   }
 };
 

@@ -4,6 +4,9 @@ Test infrastructure only (see ``oracle/__init__.py``).  Reference call sites:
 ``src/nessai/flows/realnvp.py:208-209`` / ``nsf.py:124-125``
 (``StandardNormal([features])``) and ``src/nessai/flows/base.py:236-287``
 (``log_prob``, ``sample``, ``sample_and_log_prob``).
+
+(Algorithm and structure: nflows, MIT License, (c) 2020 Durkan, Bekasov, Murray, Papamakarios - see
+``oracle/nflows_restated/__init__.py`` and ``LICENSE.nflows``.)
 """
 
 import numpy as np

@@ -5,6 +5,9 @@ Test infrastructure only (see ``oracle/__init__.py``).  Reference call sites:
 (``ResidualNet(in, out, hidden_features=H, context_features=None,
 num_blocks=L, activation=act, dropout_probability=p, use_batch_norm=flag)``).
 
+(Algorithm and structure: nflows, MIT License, (c) 2020 Durkan, Bekasov, Murray, Papamakarios - see
+``oracle/nflows_restated/__init__.py`` and ``LICENSE.nflows``.)
+
 Structure: ``h = W0 x + b0``; ``L`` pre-activation
 residual blocks ``h += W2 act(W1 act(h) + b1) + b2`` whose last linear layer is
 initialised U(-1e-3, 1e-3); ``out = Wf h + bf``.

@@ -6,6 +6,9 @@ reference instantiates at ``src/nessai/flows/nsf.py:97-108`` with
 ``tails="linear"``, ``tail_bound=5.0`` (``nsf.py:74-75``).  Semantics
 restated from the paper and the public nflows API:
 
+(Algorithm and structure: nflows, MIT License, (c) 2020 Durkan, Bekasov, Murray, Papamakarios - see
+``oracle/nflows_restated/__init__.py`` and ``LICENSE.nflows``.)
+
 * bin widths/heights: ``min + (1 - min*K) * softmax(u)``; knots are the
   cumulative sums mapped onto ``[left, right]`` with both ends forced exact;
 * derivatives: ``min_derivative + softplus(u_d)``; with linear tails the two

@@ -4,6 +4,9 @@ Test infrastructure only (see ``oracle/__init__.py``).  Restated from the
 public nflows API; the reference call sites that fix which pieces are needed
 and with which arguments:
 
+(Algorithm and structure: nflows, MIT License, (c) 2020 Durkan, Bekasov, Murray, Papamakarios - see
+``oracle/nflows_restated/__init__.py`` and ``LICENSE.nflows``.)
+
 * ``CompositeTransform`` — ``src/nessai/flows/realnvp.py:211``, ``nsf.py:128``
 * ``RandomPermutation`` / ``LULinear(identity_init=True, using_cache=True)``
   — ``src/nessai/flows/utils.py:305-315``; ``SVDLinear(num_householder=10, identity_init=True)`` with its

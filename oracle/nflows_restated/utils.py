@@ -2,6 +2,9 @@
 
 Test infrastructure only (see ``oracle/__init__.py``).
 
+(Algorithm and structure: nflows, MIT License, (c) 2020 Durkan, Bekasov, Murray, Papamakarios - see
+``oracle/nflows_restated/__init__.py`` and ``LICENSE.nflows``.)
+
 Reference call sites that fix the semantics:
 * ``create_alternating_binary_mask`` — ``src/nessai/flows/nsf.py:99-101``
   (``even=(i % 2 == 0)``; mask value 1 marks a *transformed* feature).

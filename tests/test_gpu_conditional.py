@@ -111,8 +111,9 @@ def test_context_argument_is_checked():
     # a context that wants a gradient (the output of an embedding net, which nflows supports) would train with a
     # zero gradient: refused while autograd records, fine under no_grad / when detached (round-5 advisor finding)
     ctx = torch.randn(10, C, device=DEV, requires_grad=True)
-    with pytest.raises(RuntimeError, match="carries no gradient"):
-        flow.log_prob(x, context=ctx)
+    with torch.enable_grad():  # (this suite runs under no_grad: conftest.py)
+        with pytest.raises(RuntimeError, match="carries no gradient"):
+            flow.log_prob(x, context=ctx)
     with torch.no_grad():
         assert torch.isfinite(flow.log_prob(x, context=ctx)).all()
     assert torch.isfinite(flow.log_prob(x, context=ctx.detach())).all()

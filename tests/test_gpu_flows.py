@@ -96,19 +96,51 @@ def test_log_prob_matches_oracle(pair, scale, request):
         assert rel_err(lp, lp_ref) <= 2e-4  # documented split-bf16 envelope
 
 
-def test_forward_inverse_match_oracle(pair):
+def _held_against_float64(name, dev, o32, o64, bar, factor=1.5):
+    """The rule of tests/test_gpu_reference_bars.py for a quantity with a float64 twin: the device is inside the bar,
+    or - where float32 arithmetic itself is not - no further from float64 than the float32 oracle is (x `factor`).
+    `bar` is absolute on max(|value|, 1) - i.e. relative for large values.  The measured pair is printed."""
+    o64 = o64.double()
+    scale = o64.abs().clamp_min(1.0)
+    e_dev = float(((dev.cpu().double() - o64).abs() / scale).max())
+    e_o32 = float(((o32.double() - o64).abs() / scale).max())
+    ok = e_dev <= bar or e_dev <= factor * e_o32
+    tag = "" if e_dev <= bar else f"  [bar {bar:.0e} missed by float32 itself: oracle {e_o32:.2e}]"
+    print(f"{name}: device {e_dev:.2e} from float64, float32 oracle {e_o32:.2e}{tag}")
+    return ok
+
+
+GATE = 1.0e-5  # SURVEY.md section 8d: |inverse(forward(x)) - x| <= 1e-5, and the bar of log_prob (relative)
+BAR5 = 1.5e-5  # numpy's decimal=5, the reference's own property bar (tests/test_flows/test_included_flows.py:129-154)
+
+
+def test_forward_inverse_match_oracle(pair, request):
+    """z, log|J| of both directions against the oracle.  Exact-f32 and split-f16 kernels: within 1e-5 (on
+    max(|value|, 1)) of the FLOAT64 twin of the oracle, or no further from it than the float32 oracle itself x 1.5
+    (deep / wide flows: float32 round-off of x is amplified by the flow; both figures are printed).  Split-bf16: its
+    documented envelope against the float32 oracle."""
     ref, flow, D = pair
+    name = request.node.callspec.params["pair"][0]
     x = torch.randn(3000, D) * 1.5
     with torch.no_grad():
         z_ref, ld_ref = ref.forward(x)
         xi_ref, ldi_ref = ref.inverse(x)
     z, ld = flow.forward(x.to(DEV))
     xi, ldi = flow.inverse(x.to(DEV))
-    k = 10.0 if flow.precision == "bf16x3" else 1.0
-    assert rel_err(z.cpu(), z_ref) <= X_ATOL * k
-    assert rel_err(ld.cpu(), ld_ref) <= LOGDET_ATOL * k
-    assert rel_err(xi.cpu(), xi_ref) <= X_ATOL * k
-    assert rel_err(ldi.cpu(), ldi_ref) <= LOGDET_ATOL * k
+    if flow.precision == "bf16x3":
+        k = 10.0
+        assert rel_err(z.cpu(), z_ref) <= X_ATOL * k
+        assert rel_err(ld.cpu(), ld_ref) <= LOGDET_ATOL * k
+        assert rel_err(xi.cpu(), xi_ref) <= X_ATOL * k
+        assert rel_err(ldi.cpu(), ldi_ref) <= LOGDET_ATOL * k
+        return
+    r64 = copy.deepcopy(ref).double()
+    with torch.no_grad():
+        z64, ld64 = r64.forward(x.double())
+        xi64, ldi64 = r64.inverse(x.double())
+    for what, dev, o32, o64 in (("forward z", z, z_ref, z64), ("forward log|J|", ld, ld_ref, ld64),
+                                ("inverse x", xi, xi_ref, xi64), ("inverse log|J|", ldi, ldi_ref, ldi64)):
+        assert _held_against_float64(f"{name} {flow.precision} {what}", dev, o32, o64, GATE), what
 
 
 def test_forward_and_log_prob_consistent(pair):
@@ -123,16 +155,44 @@ def test_forward_and_log_prob_consistent(pair):
     assert torch.equal(lp, lp2)
 
 
-def test_invertibility(pair):
-    """x -> z -> x and log_J = -log_J_inv to 5 decimals
-    (reference tests/test_flows/test_included_flows.py:144-154)."""
-    _, flow, D = pair
+def test_invertibility(pair, request):
+    """x -> z -> x and log_J = -log_J_inv to 5 decimals (reference tests/test_flows/test_included_flows.py:144-154,
+    ``decimal=5``; SURVEY.md section 8d: ``|inverse(forward(x)) - x| <= 1e-5``) for EVERY configuration - with the rule
+    of tests/test_gpu_reference_bars.py where float32 arithmetic itself misses a bar (deep / wide flows; the reference
+    marks these tests ``flaky(reruns=5)`` at D in {2, 4} already): the float32 oracle's own figure for the same property
+    on the same weights and inputs is measured, and the device must not be further out than it x 1.5.  Both figures are
+    printed (config 3's and config 4's flows included: the numbers DESIGN.md section 2 quotes)."""
+    ref, flow, D = pair
+    name = request.node.callspec.params["pair"][0]
     x = torch.randn(1000, D, device=DEV)
     z, log_J = flow.forward(x)
     x_out, log_J_out = flow.inverse(z)
-    decimal = 3 if flow.precision == "bf16x3" else 4
-    np.testing.assert_array_almost_equal(x.cpu().numpy(), x_out.cpu().numpy(), decimal=decimal)
-    np.testing.assert_array_almost_equal(log_J.cpu().numpy(), -log_J_out.cpu().numpy(), decimal=decimal)
+    if flow.precision == "bf16x3":
+        np.testing.assert_array_almost_equal(x.cpu().numpy(), x_out.cpu().numpy(), decimal=3)
+        np.testing.assert_array_almost_equal(log_J.cpu().numpy(), -log_J_out.cpu().numpy(), decimal=3)
+        return
+    with torch.no_grad():
+        z_o, lj_o = ref.forward(x.cpu())
+        xo_o, lji_o = ref.inverse(z_o)
+    e_x, o_x = float((x_out - x).abs().max()), float((xo_o - x.cpu()).abs().max())
+    e_j, o_j = float((log_J + log_J_out).abs().max()), float((lj_o + lji_o).abs().max())
+    print(f"{name} {flow.precision}: |inverse(forward(x)) - x| device {e_x:.2e}, float32 oracle {o_x:.2e} (gate {GATE:.0e}); "
+          f"|log_J + log_J_inv| device {e_j:.2e}, float32 oracle {o_j:.2e} (bar {BAR5:.1e})")
+    assert e_x <= GATE or e_x <= 1.5 * o_x, (name, e_x, o_x)
+    if not (e_j <= BAR5 or e_j <= 1.5 * o_j):
+        # the sum of the two log-Jacobians is a difference of rounding errors, and the float32 oracle can come out ahead
+        # by cancellation (tests/test_gpu_reference_bars.py): taken apart against the float64 twin, term by term
+        r64 = copy.deepcopy(ref).double()
+        with torch.no_grad():
+            z64, lj64 = r64.forward(x.cpu().double())
+            _, lji64_dev = r64.inverse(z.cpu().double())
+            _, lji64_o = r64.inverse(z_o.double())
+        for term, dev, o32 in (("forward log|J|", (log_J.cpu() - lj64).abs().max(), (lj_o - lj64).abs().max()),
+                               ("inverse log|J| at its own z", (log_J_out.cpu() - lji64_dev).abs().max(),
+                                (lji_o - lji64_o).abs().max()),
+                               ("z", (z.cpu() - z64).abs().max(), (z_o - z64).abs().max())):
+            print(f"    {term}: device {float(dev):.2e} from float64, float32 oracle {float(o32):.2e}")
+            assert float(dev) <= max(BAR5, 1.5 * float(o32)), (name, term, float(dev), float(o32))
 
 
 def test_sample_and_log_prob(pair):

@@ -136,3 +136,79 @@ def test_headline_kernel_instruction_stream():
     assert count(r"v_exp_f32.*") > 0 and count(r"v_log_f32.*") > 0 and count(r"v_rcp_f32.*") > 0
     # the weight stream goes global -> LDS without passing registers
     assert count(r"global_load_lds_dwordx4") > 0
+
+
+RING_INSTANCES = [
+    # the small-batch geometry's instances (stage ring + loader waves, NsaRingPipe<true>): config 3's flow over the live
+    # points (inverse, split-f16) and config 4's log_prob_all / draw (128-wide, forward and inverse)
+    ("inst_h2_t1_8.o", "nsa_flow_kernelILi2E5NsaRQILi8ELb0EELb1ELi2ELi2ELi1ELb0ELb1EE"),
+    ("inst_h4_t1_8.o", "nsa_flow_kernelILi4E5NsaRQILi8ELb0EELb0ELi2ELi2ELi1ELb0ELb1EE"),
+    ("inst_h4_t1_8.o", "nsa_flow_kernelILi4E5NsaRQILi8ELb0EELb1ELi2ELi2ELi1ELb0ELb1EE"),
+]
+#: the immediates of nsa_wait_vmcnt's switch (csrc/nsa_flow_kernel.h): exact to 23, then in steps of eight, then 63
+WAIT_TABLE = set(range(1, 24)) | {24, 32, 40, 48, 56, 63}
+
+
+@pytest.mark.parametrize("obj,fragment", RING_INSTANCES)
+def test_ring_pipe_instances_wait_where_the_source_says(obj, fragment):
+    """The stage ring's correctness rests on waits the COMPILER does not see: the copies are LDS-DMAs inside inline
+    assembly (``nsa_glds16_raw``), the waits hand-counted ``s_waitcnt vmcnt(N)`` (``nsa_wait_vmcnt``) in front of bare
+    ``s_barrier``s.  A compiler that started to add waits of its own, to move or drop a barrier's LDS wait, or to
+    break the M0 save / restore around a copy would leave the results right on most runs and the ring drained or racy.
+    Read off the disassembly:
+
+    * every counted wait comes from the switch table of ``nsa_wait_vmcnt`` - the table's immediates and no others, each
+      as often as the table has call sites (every call site carries the whole table);
+    * a ``vmcnt(0)`` behind a copy and directly in front of an LDS READ - the wait hipcc puts in front of a read it
+      cannot tell from a pending LDS-DMA's destination, which drains the ring (``scripts/isa_waits.py``) - occurs a
+      handful of times (the kernel's prologue and epilogue), never once per stage;
+    * every ``s_barrier`` sits behind a wait that drains the LDS counter, with no LDS operation in between;
+    * every copy has its M0 (the LDS base of an LDS-DMA) set right in front of it and restored right behind it."""
+    asm = _disassemble(obj, fragment)
+    lines = [l.split("//")[0].strip() for l in asm.split("\n")[1:]]
+    lines = [l for l in lines if l]
+    waits = {}
+    zero_after_copy = 0
+    last_vmem = None
+    for i, l in enumerate(lines):
+        op = l.split()[0]
+        if re.match(r"(global_|buffer_|flat_|scratch_)", op):
+            last_vmem = op
+        m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", l)
+        if m and last_vmem == "global_load_lds_dwordx4":
+            # (waits behind the compiler's own loads - the prologue's and epilogue's global reads - are the compiler's
+            # business; the ones whose last vector-memory instruction is a copy are the ring's)
+            n = int(m.group(1))
+            waits[n] = waits.get(n, 0) + 1
+            if n == 0:
+                nxt = next((lines[j].split()[0] for j in range(i + 1, min(i + 40, len(lines)))
+                            if re.match(r"(ds_|global_|buffer_|flat_|s_barrier|v_mfma|scratch_)", lines[j])), "")
+                zero_after_copy += nxt.startswith("ds_read")  # ... and the next thing is an LDS read, not a barrier
+    counted = {n: c for n, c in waits.items() if n != 0}
+    assert set(counted) == WAIT_TABLE, sorted(set(counted) ^ WAIT_TABLE)
+    # every call site carries the whole table: each immediate appears once per site (+ at most a few waits of the
+    # compiler's own behind ITS loads that happen to follow a copy: a hidden copy only ever makes those over-wait -
+    # the counter is in order and the copy is one more operation outstanding than the compiler counted)
+    n_sites = min(counted.values())
+    assert n_sites >= 4
+    assert max(counted.values()) <= n_sites + 3, counted
+    assert sum(1 for c in counted.values() if c == n_sites) >= len(WAIT_TABLE) - 3, counted
+    assert waits.get(0, 0) >= n_sites  # (the table's own case 0)
+    # 3-4 today (the kernel's prologue and epilogue); the regression round 5 removed had one at 13 of 17 stage sites
+    assert zero_after_copy <= 6, (zero_after_copy, n_sites)
+    copies = [i for i, l in enumerate(lines) if l.startswith("global_load_lds_dwordx4")]
+    assert len(copies) >= 4
+    for i in copies:
+        before, after = lines[max(i - 3, 0):i], lines[i + 1:i + 2]
+        assert any(re.match(r"s_mov_b32 m0, vcc_lo", b) for b in before), lines[i - 4:i + 2]
+        assert after and re.match(r"s_mov_b32 m0, vcc_hi", after[0]), lines[i - 4:i + 2]
+    barriers = [i for i, l in enumerate(lines) if l.startswith("s_barrier")]
+    assert len(barriers) >= n_sites
+    for i in barriers:
+        # walking back from the barrier: the LDS counter is drained before any LDS operation is met
+        for j in range(i - 1, max(i - 16, 0), -1):
+            if lines[j].startswith("s_waitcnt") and "lgkmcnt(0)" in lines[j]:
+                break
+            assert not lines[j].startswith("ds_"), lines[j:i + 1]
+        else:
+            raise AssertionError(f"no LDS wait in front of the barrier: {lines[i - 16:i + 1]}")
