@@ -805,9 +805,25 @@ __device__ __forceinline__ void nsa_dense_tile16(const float* w, const int* tab,
 
 // activation over a whole register array; the (wave-uniform) kind is tested
 // once, not per element
-template <int N>
+#ifndef NSA_ACT_VARIANT
+#define NSA_ACT_VARIANT 0  // (A/B build of round 6: 3 = the activation kind branched on once around the residual blocks)
+#endif
+// ACT_KNOWN: 0 = `act` decides at run time (three-way branch), 1 = the caller is on a path where act == relu,
+// 2 = ... where act != relu (tanh / silu)
+template <int N, int ACT_KNOWN = 0>
 __device__ __forceinline__ void nsa_act_regs(float (&a)[N], int act) {
-  if (act == NSA_ACT_RELU) {
+  if constexpr (ACT_KNOWN == 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = nsa_relu(a[i]);
+  } else if constexpr (ACT_KNOWN == 2) {
+    if (act == NSA_ACT_TANH) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) a[i] = nsa_tanh_fast(a[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) a[i] = nsa_silu_fast(a[i]);
+    }
+  } else if (act == NSA_ACT_RELU) {
 #pragma unroll
     for (int i = 0; i < N; ++i) a[i] = nsa_relu(a[i]);
   } else if (act == NSA_ACT_TANH) {
@@ -1046,6 +1062,16 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
     }
   } else if (net == NSA_NET_RESNET) {
     // pre-activation residual blocks: h += W2 act(W1 act(h) + b1) + b2
+    // (Round 6: the stack of blocks is a generic lambda over the activation class.  As plain inline code - the state
+    // of round 5 - config 2's kernel took 0.36-0.37 ms per 1e6 rows; it had taken 0.28 before round 4's last commit
+    // replaced tanhf / expf in nsa_act_regs by the short inline forms, which changed how hipcc lays out the three
+    // activation paths of EVERY flow, relu included.  Inside the lambda the same source compiles to 0.28 ms again
+    // (act0 in profiles/r06_c2_activation_paths_ab.jsonl); branching on the kind ONCE around the stack
+    // (NSA_ACT_VARIANT 3: the relu path one straight stream per block) gives the same 0.27-0.28 for config 2 and costs
+    // config 3's kernel 1 % (1.557 against 1.543 ms), so the run-time branch stays.  A compiler layout effect, pinned
+    // by nothing but this measurement: re-measure config 2 when this function or hipcc changes.)
+    auto blocks = [&](auto known) {
+    constexpr int AK = decltype(known)::value;
     for (int l = 0; l < n_layers; ++l) {
       float tmp[RT][16 * HT];
 #pragma unroll
@@ -1071,14 +1097,14 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
         }
       }
 #pragma unroll
-      for (int t = 0; t < RT; ++t) nsa_act_regs<16 * HT>(tmp[t], act);
+      for (int t = 0; t < RT; ++t) nsa_act_regs<16 * HT, AK>(tmp[t], act);
       {
         f32x16 acc[RT][HT];
         hidden_layer(tmp, acc);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
           nsa_acc_to_regs<HT>(acc[t], tmp[t]);
-          nsa_act_regs<16 * HT>(tmp[t], act);
+          nsa_act_regs<16 * HT, AK>(tmp[t], act);
         }
         NSA_TL(pipe, 4);
         pipe.template end_v<SKEW && (NSA_SKEW_MASK & 2) != 0>();
@@ -1125,6 +1151,13 @@ __device__ __forceinline__ void nsa_coupling(PIPE& pipe, const uint32_t* op, flo
         }
       }
     }
+    };
+#if NSA_ACT_VARIANT == 3
+    if (act == NSA_ACT_RELU) blocks(std::integral_constant<int, 1>{});
+    else blocks(std::integral_constant<int, 2>{});
+#else
+    blocks(std::integral_constant<int, 0>{});
+#endif
   } else {
     // plain MLP (src/nessai/flows/nets.py:110-124): act after every layer but the last
 #pragma unroll

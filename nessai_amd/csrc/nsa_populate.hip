@@ -883,7 +883,7 @@ extern "C" hipError_t nsa_launch_importance_pack(long long n, int n_flows, int D
 // 32-bit words), for a model with a UNIFORM prior on a box (lower / upper, `log_prior_total` = the host's own
 // -sum log(upper - lower)), i.e. the fields ImportanceFlowProposal.draw fills one numpy pass at a time
 // (src/nessai/proposal/importance.py:488-503, model.py:497-620):
-//   logP = log(in_bounds(lower + (upper - lower) x)) + total,  logU = log(in_unit_hypercube(x)),
+//   logP = log(in_bounds(lower + (upper - lower) x)) + total,  logU = log_prior_unit_hypercube(x) (0 on [0, 1)^D),
 //   logQ = the meta-proposal, logW = logU - logQ, logL = NaN, it = 0
 // (comparisons as numpy makes them: a NaN coordinate is "inside").  `aux` row r = { log_q_all[0 .. P), log_j } -
 // log_j NaN marks the rows of the reference's first filter.  The host views the read-back as the array it returns.
@@ -913,7 +913,7 @@ __global__ void __launch_bounds__(256) nsa_importance_points_kernel(long long n,
     double v = xr[i];
     if (clip) v = fmin(fmax(v, 0.0), 1.0);  // (numpy.clip: NaN stays NaN)
     put(2 * i, v);
-    in_cube = in_cube && !((v < 0.0) || (v > 1.0));
+    in_cube = in_cube && !((v < 0.0) || (v >= 1.0));  // the cube prior's half-open support (src/nessai/model.py:593-601)
     const double lo = lower[i], hi = upper[i];
     const double phys = lo + (hi - lo) * v;
     in_box = in_box && !((phys < lo) || (phys > hi));

@@ -43,10 +43,13 @@ __device__ __forceinline__ float tr_act_grad(float x, int act) {
 }
 
 // Y[n][O] = act_in(X[:, cols])[n][I] . W[O][I]^T + b (+ R)
+// M (optional, [n][I]): a multiplier of the activated input - the dropout mask of this product's input
+// (0 or 1 / (1 - p): tr_dropout_mask), training mode only
 __global__ void __launch_bounds__(64) tr_gemm_nt(int n, int I, int O, const float* __restrict__ X, int ldx,
                                                  const int* __restrict__ cols, int act_in,
                                                  const float* __restrict__ W, const float* __restrict__ b,
-                                                 const float* __restrict__ R, float* __restrict__ Y, int ldy) {
+                                                 const float* __restrict__ R, float* __restrict__ Y, int ldy,
+                                                 const float* __restrict__ M = nullptr) {
   const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
   const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
   const int row = row0 + j, col = col0 + j;
@@ -55,18 +58,19 @@ __global__ void __launch_bounds__(64) tr_gemm_nt(int n, int I, int O, const floa
   const long long wrow = (long long)(col < O ? col : O - 1) * I;
   const bool row_ok = row < n, col_ok = col < O;
   for (int k0 = 0; k0 < I; k0 += 16) {  // 8 MFMA steps per trip: all 16 loads issued before use
-    float xv[8], wv[8];
+    float xv[8], wv[8], mv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int kk = k0 + 2 * u + half;
       const int kc = kk < I ? kk : I - 1;  // clamped: loads are unconditional
       xv[u] = X[xrow + (cols ? cols[kc] : kc)];
       wv[u] = W[wrow + kc];
+      mv[u] = M ? M[(long long)(row < n ? row : n - 1) * I + kc] : 1.0f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int kk = k0 + 2 * u + half;
-      const float a = (row_ok && kk < I) ? tr_act(xv[u], act_in) : 0.0f;
+      const float a = (row_ok && kk < I) ? tr_act(xv[u], act_in) * mv[u] : 0.0f;
       const float bb = (col_ok && kk < I) ? wv[u] : 0.0f;
       // D[i][jj] = sum_k A[i][k] B[k][jj]: i = output column (W row), jj = batch row
       acc = nsa_mfma(bb, a, acc);
@@ -89,7 +93,8 @@ __global__ void __launch_bounds__(64) tr_gemm_nt(int n, int I, int O, const floa
 __global__ void __launch_bounds__(64) tr_gemm_nn(int n, int O, int I, const float* __restrict__ Gout, int ldg,
                                                  const float* __restrict__ W, const float* __restrict__ Z,
                                                  int ldz, int act, float* __restrict__ Gin, int ldi,
-                                                 const int* __restrict__ cols, int mode) {
+                                                 const int* __restrict__ cols, int mode,
+                                                 const float* __restrict__ M = nullptr) {
   const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
   const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
   const int row = row0 + j, col = col0 + j;
@@ -119,6 +124,7 @@ __global__ void __launch_bounds__(64) tr_gemm_nn(int n, int O, int I, const floa
     const int i = col0 + (r & 3) + 8 * (r >> 2) + 4 * half;
     if (i < I && row < n) {
       float v = acc[r];
+      if (M) v *= M[(long long)row * I + i];  // (the dropout mask sits between the activation and the product)
       if (Z) v *= tr_act_grad(Z[(long long)row * ldz + i], act);
       if (mode == 0) Gin[(long long)row * ldi + i] = v;
       else if (mode == 1) Gin[(long long)row * ldi + i] += v;
@@ -134,7 +140,8 @@ __global__ void __launch_bounds__(64) tr_gemm_nn(int n, int O, int I, const floa
 __global__ void __launch_bounds__(256) tr_gemm_tn(int n, int O, int I, const float* __restrict__ Gout, int ldg,
                                                   const float* __restrict__ X, int ldx,
                                                   const int* __restrict__ cols, int act_in,
-                                                  float* __restrict__ dW, float* __restrict__ db) {
+                                                  float* __restrict__ dW, float* __restrict__ db,
+                                                  const float* __restrict__ M = nullptr) {
   __shared__ float red[3][64][17];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
   const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
@@ -158,11 +165,19 @@ __global__ void __launch_bounds__(256) tr_gemm_tn(int n, int O, int I, const flo
       gv[u] = Gout[(long long)rc * ldg + oc];
       xv[u] = X[(long long)rc * ldx + xcol];
     }
+    if (M) {  // (dropout: the activated input of the product was masked in the forward pass)
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const int row = k0 + 2 * u + half;
+        const int rc = row < n ? row : n - 1;
+        xv[u] = tr_act(xv[u], act_in) * M[(long long)rc * I + (i < I ? i : I - 1)];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
       const int row = k0 + 2 * u + half;
       const float a = gv[u] * ((o_ok && row < k_hi) ? 1.0f : 0.0f);
-      const float bb = tr_act(xv[u], act_in) * ((i_ok && row < k_hi) ? 1.0f : 0.0f);
+      const float bb = (M ? xv[u] : tr_act(xv[u], act_in)) * ((i_ok && row < k_hi) ? 1.0f : 0.0f);
       bsum += a;
       acc = nsa_mfma(a, bb, acc);  // D[ii = o][jj = i]
     }
@@ -1224,6 +1239,290 @@ __global__ void tr_scatter_add(int n, int d_id, const float* __restrict__ G, int
   Gx[(long long)row * ldx + id_cols[i]] += G[(long long)row * ldg + i];
 }
 
+// ---------------------------------------------------------------------------
+// SVD-linear layer (linear_transform = "svd": src/nessai/flows/utils.py:316-323; nflows SVDLinear):
+//   y = H1( diag(s) H2(x) ) + b,   H(.) = the Householder sequence x -> x (I - 2 q q^T / |q|^2) for its vectors in
+//   turn,  s = eps + softplus(raw),  log|det J| = sum log s.
+// One WAVE per row (D <= 128: two elements per lane), the vectors, 2 / |q|^2 and s in LDS.  The backward pass keeps no
+// intermediate: a reflection is its own inverse, so the inputs of the reflections are walked back from the output.
+//   y = x - (2 a / n2) q, a = q.x, n2 = q.q, b = q.g:   g_x = g - (2 b / n2) q,
+//   g_q = -(2 / n2) (a g + b x) + (4 a b / n2^2) q
+// Parameter gradients: per-workgroup sums in LDS, one float atomic per element and workgroup at the end.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float tr_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// LDS: Q2[nh][D] | Q1[nh][D] | two_over_n2[2 nh] | s[D]   (+ the gradient sums of the backward kernel behind them)
+__device__ __forceinline__ void tr_svd_load(int D, int nh, const float* __restrict__ q1, const float* __restrict__ raw,
+                                            const float* __restrict__ q2, float eps, float* sm) {
+  float* Q2 = sm;
+  float* Q1 = Q2 + nh * D;
+  float* ton = Q1 + nh * D;
+  float* sd = ton + 2 * nh;
+  for (int e = threadIdx.x; e < nh * D; e += blockDim.x) { Q2[e] = q2[e]; Q1[e] = q1[e]; }
+  for (int e = threadIdx.x; e < D; e += blockDim.x) sd[e] = eps + nsa_softplus(raw[e]);
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * nh; k += blockDim.x) {
+    const float* q = k < nh ? Q2 + k * D : Q1 + (k - nh) * D;
+    float n2 = 0.0f;
+    for (int e = 0; e < D; ++e) n2 += q[e] * q[e];
+    ton[k] = 2.0f / n2;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) tr_svd_forward(int n, int D, int nh, float* __restrict__ X,
+                                                      const int* __restrict__ cols, const float* __restrict__ q1,
+                                                      const float* __restrict__ raw, const float* __restrict__ q2,
+                                                      const float* __restrict__ bias, float eps,
+                                                      float* __restrict__ xin, float* __restrict__ ld_const) {
+  extern __shared__ float svd_sm[];
+  tr_svd_load(D, nh, q1, raw, q2, eps, svd_sm);
+  const float* Q2 = svd_sm;
+  const float* Q1 = Q2 + nh * D;
+  const float* ton = Q1 + nh * D;
+  const float* sd = ton + 2 * nh;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float ld = 0.0f;
+    for (int e = 0; e < D; ++e) ld += logf(sd[e]);
+    ld_const[0] += ld;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e0 = lane, e1 = lane + 64;
+  const bool ok0 = e0 < D, ok1 = e1 < D;
+  const int c0 = ok0 ? cols[e0] : 0, c1 = ok1 ? cols[e1] : 0;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < n; row += (long long)gridDim.x * 4) {
+    float v0 = ok0 ? X[row * D + c0] : 0.0f, v1 = ok1 ? X[row * D + c1] : 0.0f;
+    if (ok0) xin[row * D + e0] = v0;
+    if (ok1) xin[row * D + e1] = v1;
+    for (int k = 0; k < 2 * nh; ++k) {
+      if (k == nh) {
+        v0 *= ok0 ? sd[e0] : 0.0f;
+        v1 *= ok1 ? sd[e1] : 0.0f;
+      }
+      const float* q = k < nh ? Q2 + k * D : Q1 + (k - nh) * D;
+      const float qa = ok0 ? q[e0] : 0.0f, qb = ok1 ? q[e1] : 0.0f;
+      const float c = tr_wave_sum(v0 * qa + v1 * qb) * ton[k];
+      v0 -= c * qa;
+      v1 -= c * qb;
+    }
+    // (every lane of the wave read its inputs before any lane writes: X's columns are permuted by `cols`)
+    if (ok0) X[row * D + e0] = v0 + bias[e0];
+    if (ok1) X[row * D + e1] = v1 + bias[e1];
+  }
+}
+
+// Gx holds d loss / d y on entry (natural order) and d loss / d x in the columns `cols` on exit; X is restored to the
+// layer's input; g_q1 / g_raw / g_q2 / g_bias += (the flat gradient was zeroed by tr_prepare).
+__global__ void __launch_bounds__(256) tr_svd_backward(int n, int D, int nh, float* __restrict__ X, float* __restrict__ Gx,
+                                                       const int* __restrict__ cols, const float* __restrict__ q1,
+                                                       const float* __restrict__ raw, const float* __restrict__ q2,
+                                                       float eps, const float* __restrict__ xin,
+                                                       float* __restrict__ g_q1, float* __restrict__ g_raw,
+                                                       float* __restrict__ g_q2, float* __restrict__ g_bias,
+                                                       const float* __restrict__ gl_sum) {
+  extern __shared__ float svd_sm[];
+  tr_svd_load(D, nh, q1, raw, q2, eps, svd_sm);
+  const float* Q2 = svd_sm;
+  const float* Q1 = Q2 + nh * D;
+  const float* ton = Q1 + nh * D;
+  const float* sd = ton + 2 * nh;
+  float* GQ2 = svd_sm + 2 * nh * D + 2 * nh + D;  // [nh][D]
+  float* GQ1 = GQ2 + nh * D;
+  float* GS = GQ1 + nh * D;                       // d loss / d s
+  float* GB = GS + D;
+  for (int e = threadIdx.x; e < 2 * nh * D + 2 * D; e += blockDim.x) GQ2[e] = 0.0f;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e0 = lane, e1 = lane + 64;
+  const bool ok0 = e0 < D, ok1 = e1 < D;
+  const int c0 = ok0 ? cols[e0] : 0, c1 = ok1 ? cols[e1] : 0;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < n; row += (long long)gridDim.x * 4) {
+    const float x0 = ok0 ? xin[row * D + e0] : 0.0f, x1 = ok1 ? xin[row * D + e1] : 0.0f;
+    float g0 = ok0 ? Gx[row * D + e0] : 0.0f, g1 = ok1 ? Gx[row * D + e1] : 0.0f;
+    if (ok0) atomicAdd(&GB[e0], g0);
+    if (ok1) atomicAdd(&GB[e1], g1);
+    // forward again (registers only) to the layer's output without the bias
+    float v0 = x0, v1 = x1;
+    for (int k = 0; k < 2 * nh; ++k) {
+      if (k == nh) {
+        v0 *= ok0 ? sd[e0] : 0.0f;
+        v1 *= ok1 ? sd[e1] : 0.0f;
+      }
+      const float* q = k < nh ? Q2 + k * D : Q1 + (k - nh) * D;
+      const float qa = ok0 ? q[e0] : 0.0f, qb = ok1 ? q[e1] : 0.0f;
+      const float c = tr_wave_sum(v0 * qa + v1 * qb) * ton[k];
+      v0 -= c * qa;
+      v1 -= c * qb;
+    }
+    // ... and back: v = output of reflection k, its input is the reflection of v
+    for (int k = 2 * nh - 1; k >= 0; --k) {
+      const float* q = k < nh ? Q2 + k * D : Q1 + (k - nh) * D;
+      float* gq = k < nh ? GQ2 + k * D : GQ1 + (k - nh) * D;
+      const float qa = ok0 ? q[e0] : 0.0f, qb = ok1 ? q[e1] : 0.0f;
+      const float t = ton[k];                                  // 2 / n2
+      const float cy = tr_wave_sum(v0 * qa + v1 * qb) * t;      // q.y 2 / n2 ( = -q.x 2 / n2 )
+      const float in0 = v0 - cy * qa, in1 = v1 - cy * qb;       // the reflection's input x
+      const float ax = -cy / t;                                 // a = q.x = -q.y (q.(H y) = q.y - 2 q.y)
+      const float bg = tr_wave_sum(g0 * qa + g1 * qb);          // b = q.g
+      const float k4 = ax * bg * t * t;                         // 4 a b / n2^2
+      if (ok0) atomicAdd(&gq[e0], -t * (ax * g0 + bg * in0) + k4 * qa);
+      if (ok1) atomicAdd(&gq[e1], -t * (ax * g1 + bg * in1) + k4 * qb);
+      g0 -= bg * t * qa;
+      g1 -= bg * t * qb;
+      v0 = in0;
+      v1 = in1;
+      if (k == nh) {  // through the diagonal: v = s * u
+        const float s0 = ok0 ? sd[e0] : 1.0f, s1 = ok1 ? sd[e1] : 1.0f;
+        const float u0 = v0 / s0, u1 = v1 / s1;
+        if (ok0) atomicAdd(&GS[e0], g0 * u0);
+        if (ok1) atomicAdd(&GS[e1], g1 * u1);
+        g0 *= s0;
+        g1 *= s1;
+        v0 = u0;
+        v1 = u1;
+      }
+    }
+    // the layer's input is known exactly (xin): restore it, scatter its gradient
+    if (ok0) { X[row * D + c0] = x0; }
+    if (ok1) { X[row * D + c1] = x1; }
+    __builtin_amdgcn_wave_barrier();
+    if (ok0) Gx[row * D + c0] = g0;
+    if (ok1) Gx[row * D + c1] = g1;
+  }
+  __syncthreads();
+  const float gl = gl_sum[0];
+  for (int e = threadIdx.x; e < nh * D; e += blockDim.x) {
+    atomicAdd(&g_q2[e], GQ2[e]);
+    atomicAdd(&g_q1[e], GQ1[e]);
+  }
+  for (int e = threadIdx.x; e < D; e += blockDim.x) {
+    // s = eps + softplus(raw): d s / d raw = sigmoid(raw); the constant log|det J| = sum log s enters every row
+    const float sig = 1.0f / (1.0f + expf(-raw[e]));
+    const float extra = blockIdx.x == 0 ? gl / sd[e] : 0.0f;
+    atomicAdd(&g_raw[e], (GS[e] + extra) * sig);
+    atomicAdd(&g_bias[e], GB[e]);
+  }
+}
+
+// batch_norm_within_layers (nflows ResidualBlock with use_batch_norm: torch.nn.BatchNorm1d(features, eps = 1e-3) in
+// front of each of the block's two activations; src/nessai/flows/realnvp.py:145, nsf.py:94).  One workgroup per
+// feature; sums over the batch in a fixed tree (deterministic).
+//   training: batch mean and BIASED variance normalise, the running statistics move by `momentum` (0.1) towards the
+//   batch mean and the UNBIASED variance - torch's BatchNorm1d;  otherwise the running statistics normalise.
+// Y = gamma (X - mean) invstd + beta;  {mean, invstd} kept for the backward pass.
+__global__ void __launch_bounds__(256) tr_bn1d_forward(int n, int H, const float* __restrict__ X,
+                                                       float* __restrict__ Y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                       float* __restrict__ run_var, float eps, float momentum,
+                                                       int training, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_invstd) {
+  __shared__ float sm[256];
+  const int col = blockIdx.x;
+  float mu, invstd;
+  if (training) {
+    float a = 0.0f;
+    for (int r = threadIdx.x; r < n; r += 256) a += X[(long long)r * H + col];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off]; __syncthreads(); }
+    mu = sm[0] / (float)n;
+    __syncthreads();
+    float q = 0.0f;
+    for (int r = threadIdx.x; r < n; r += 256) { const float d = X[(long long)r * H + col] - mu; q += d * d; }
+    sm[threadIdx.x] = q;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off]; __syncthreads(); }
+    const float ss = sm[0];
+    invstd = 1.0f / sqrtf(ss / (float)n + eps);
+    if (threadIdx.x == 0) {
+      run_mean[col] = run_mean[col] * (1.0f - momentum) + mu * momentum;
+      run_var[col] = run_var[col] * (1.0f - momentum) + (ss / (float)(n > 1 ? n - 1 : 1)) * momentum;
+    }
+  } else {
+    mu = run_mean[col];
+    invstd = 1.0f / sqrtf(run_var[col] + eps);
+  }
+  if (threadIdx.x == 0) { save_mean[col] = mu; save_invstd[col] = invstd; }
+  const float g = gamma[col], b = beta[col];
+  for (int r = threadIdx.x; r < n; r += 256) Y[(long long)r * H + col] = (X[(long long)r * H + col] - mu) * invstd * g + b;
+}
+
+// Gx (op)= d loss / d X of the above given Gy; dgamma = sum Gy xhat, dbeta = sum Gy.
+//   training: Gx = gamma invstd / n (n Gy - dbeta - xhat dgamma);  otherwise Gx = Gy gamma invstd.
+// accumulate != 0: Gx += (the skip path's gradient is already there).  Gy and Gx may be the same buffer.
+__global__ void __launch_bounds__(256) tr_bn1d_backward(int n, int H, const float* Gy, const float* __restrict__ X,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ save_mean,
+                                                        const float* __restrict__ save_invstd, int training,
+                                                        float* Gx, int accumulate, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta) {
+  __shared__ float s1[256], s2[256];
+  const int col = blockIdx.x;
+  const float mu = save_mean[col], invstd = save_invstd[col];
+  float a = 0.0f, b = 0.0f;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const float gy = Gy[(long long)r * H + col];
+    a += gy;
+    b += gy * ((X[(long long)r * H + col] - mu) * invstd);
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { s1[threadIdx.x] += s1[threadIdx.x + off]; s2[threadIdx.x] += s2[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  const float db = s1[0], dg = s2[0];
+  if (threadIdx.x == 0) { dgamma[col] = dg; dbeta[col] = db; }
+  const float g = gamma[col];
+  const float k = g * invstd;
+  const float inv_n = 1.0f / (float)n;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const long long at = (long long)r * H + col;
+    const float gy = Gy[at];
+    float v;
+    if (training) {
+      const float xhat = (X[at] - mu) * invstd;
+      v = k * (gy - inv_n * (db + xhat * dg));
+    } else {
+      v = k * gy;
+    }
+    Gx[at] = accumulate ? Gx[at] + v : v;
+  }
+}
+
+// Dropout of the residual blocks (nflows ResidualBlock: act -> dropout -> second linear layer; the reference passes
+// dropout_probability through, src/nessai/flows/realnvp.py:141, nsf.py:90), training mode only.  The mask of one
+// block over the batch, M[n][H] = keep ? 1 / (1 - p) : 0, comes from a counter-based stream so that a step is
+// reproducible and independent of how the rows are dealt to workgroups (or ranks):
+//   Philox4x32-10, counter = (row lo, row hi, column >> 2, tag), key = (seed lo, seed hi ^ step);
+//   element column & 3 of the four outputs; keep <=> output >= threshold (= round(p 2^32))
+// tag = 0x44000000 | coupling << 8 | block; {seed, step} live in DEVICE memory (state: int64[2]) - the step ticks
+// on the device (tr_dropout_tick) so that an epoch captured into a HIP graph draws new masks at every replay.
+// tests/test_gpu_train_modes.py restates the stream in numpy (oracle/philox.py) and feeds the oracle the same masks.
+__global__ void tr_dropout_mask(long long n, int H, const long long* __restrict__ state, uint32_t tag,
+                                uint32_t threshold, float scale, float* __restrict__ M) {
+  const int quads = (H + 3) >> 2;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * quads) return;
+  const long long row = t / quads;
+  const int q = (int)(t - row * quads);
+  const unsigned long long seed = (unsigned long long)state[0], step = (unsigned long long)state[1];
+  uint32_t out[4];
+  nsa_philox4x32_10((uint32_t)row, (uint32_t)((unsigned long long)row >> 32), (uint32_t)q, tag, (uint32_t)seed,
+                    (uint32_t)(seed >> 32) ^ (uint32_t)step, out);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int col = 4 * q + e;
+    if (col < H) M[row * H + col] = out[e] >= threshold ? scale : 0.0f;
+  }
+}
+__global__ void tr_dropout_tick(long long* __restrict__ state) { state[1] += 1; }
+
 // host orchestration
 // ---------------------------------------------------------------------------
 
@@ -1240,6 +1539,12 @@ __global__ void tr_scatter_add(int n, int d_id, const float* __restrict__ G, int
 //        points keep their signatures); W0 then takes d_id + C inputs - identity features first - and every
 //        residual block is gated, h + (W2 act(u) + b2) * sigmoid(Wc context + bc)  (nflows ResidualNet:
 //        src/nessai/flows/nsf.py:85-95, flows/realnvp.py:136-146); such a flow trains on the layer-wise kernels
+//   [14] dropout probability p of the residual blocks (float bits; 0: none) - applied in training-mode passes only;
+//        a flow with p > 0 trains on the layer-wise kernels
+//   [15] device address of the dropout state {seed, step} (int64[2]; see tr_dropout_mask), 0 when [14] is 0
+//   [16] 1: batch norm within the residual blocks (batch_norm_within_layers; see tr_bn1d_forward); [17] its eps
+//        (float bits).  A coupling record then ends with {gamma, beta, running_mean, running_var} of the block's
+//        first and second batch norm, L times.  Such a flow trains on the layer-wise kernels.
 //   coupling  : {1, d_id, d_tr, id_cols offset, tr_cols offset (int32 device table),
 //                flat offsets of W0, b0, {W1, b1, W2, b2} x L, Wf, bf[, {Wc, bc} x L of a conditional flow]}
 //   batch norm: {2, cols offset, off unconstrained_weight, off bias, off running_mean,
@@ -1248,8 +1553,10 @@ __global__ void tr_scatter_add(int n, int d_id, const float* __restrict__ G, int
 //                off bias, eps (float bits)}
 //   act norm  : {4, cols offset, off log_scale, off shift, 1 if the data-dependent initialisation is
 //                still due (the host clears it after the first training step)}
-#define TR_HDR 14
-enum { TR_COUPLING = 1, TR_BATCHNORM = 2, TR_LU = 3, TR_ACTNORM = 4 };
+//   SVD linear: {5, cols offset, off orthogonal_1.q_vectors, off unconstrained_diagonal, off orthogonal_2.q_vectors,
+//                off bias, eps (float bits), Householder vectors per sequence}
+#define TR_HDR 18
+enum { TR_COUPLING = 1, TR_BATCHNORM = 2, TR_LU = 3, TR_ACTNORM = 4, TR_SVD = 5 };
 
 static inline float tr_bits(long long v) {
   const uint32_t u = (uint32_t)v;
@@ -1270,13 +1577,18 @@ struct TrWs {  // workspace carve (floats)
   long long xsave_words;  // n * max(d_tr): size of a coupling layer's saved-input block
   float* ctx;             // [n][C] context rows of a conditional flow (written by the caller), or null
   long long np_words;     // al4(n * np_max): size of a coupling layer's parameter block
+  long long mask_off;     // dropout: a coupling layer's masks M[L][al4(n * H)] start this many floats into its block
+  long long bn_off;       // batch norm within: {a[L], v[L]} (al4(n * H) each) then {mean0, invstd0, mean1, invstd1}[L] (al4(H) each)
 };
+
+static inline bool tr_has_dropout(const long long* plan) { return (uint32_t)plan[14] != 0u; }
+static inline bool tr_has_inner_bn(const long long* plan) { return plan[16] != 0; }
 
 // every block of the workspace starts on a 16-byte boundary (the fused kernels copy tiles with 16-byte pieces)
 static inline long long al4(long long words) { return (words + 3) & ~3LL; }
 
 static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, long long& np_max,
-                     long long& per_layer) {
+                     long long& per_layer, long long* mask_off = nullptr, long long* bn_off = nullptr) {
   const long long D = plan[0], H = plan[1], L = plan[2], NL = plan[3], rec = plan[9];
   d_tr_max = 1;
   for (long long b = 0; b < NL; ++b) {
@@ -1287,6 +1599,10 @@ static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, lo
   long long coupling = al4(n * d_tr_max) + (2 * L + 1) * al4(n * H) + al4(n * np_max);
   if (plan[13] > 0)  // conditional: t[L], g[L] behind the parameters, then xc and its gradient [n][D + C]
     coupling += 2 * L * al4(n * H) + 2 * al4(n * (D + plan[13]));
+  if (mask_off != nullptr) *mask_off = coupling;
+  if (tr_has_dropout(plan)) coupling += L * al4(n * H);  // the blocks' dropout masks, kept for the backward pass
+  if (bn_off != nullptr) *bn_off = coupling;
+  if (tr_has_inner_bn(plan)) coupling += L * (2 * al4(n * H) + 4 * al4(H));  // normalised activations + statistics
   const long long linear = 3 * n * D + 4 * D * D + 8 * D;  // x, t, gt | L, U, gL, gU | small vectors
   per_layer = al4(coupling > linear ? coupling : linear);
 }
@@ -1314,8 +1630,10 @@ extern "C" NSA_API size_t nsa_train_context_offset(const long long* plan, long l
 }
 
 static void tr_carve(const long long* plan, long long n, float* ws, TrWs& w) {
-  long long d_tr_max, np_max, per_layer;
-  tr_sizes(plan, n, d_tr_max, np_max, per_layer);
+  long long d_tr_max, np_max, per_layer, mask_off, bn_off;
+  tr_sizes(plan, n, d_tr_max, np_max, per_layer, &mask_off, &bn_off);
+  w.mask_off = mask_off;
+  w.bn_off = bn_off;
   const long long D = plan[0], H = plan[1];
   float* p = ws;
   w.scal = p; p += TR_SCAL_WORDS;  // [0..63] scalars, [64..127] optional phase timestamps, [128..] sq-norm partials
@@ -1366,7 +1684,7 @@ static bool tr_use_fused(const long long* plan) {
   // (a spline with a bin count other than 4 / 8 / 10 / 16 trains on the layer-wise kernels)
   const bool exact_bins = plan[4] != NSA_T_RQ || plan[5] == 4 || plan[5] == 8 || plan[5] == 10 || plan[5] == 16;
   return enabled && exact_bins && plan[13] == 0 && plan[11] == NSA_NET_RESNET && plan[1] <= 128 &&
-         plan[2] <= TRF_MAX_L;  // H <= 128: <= 8 gh tiles; conditional flows: the layer-wise kernels
+         plan[2] <= TRF_MAX_L && !tr_has_dropout(plan) && !tr_has_inner_bn(plan);  // H <= 128: <= 8 gh tiles; conditional flows: the layer-wise kernels
 }
 
 static void tr_prepare_pass(const long long* plan, const int* tables_dev, const float* params_dev, float* grads_dev,
@@ -1551,6 +1869,14 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
   const int transform = (int)plan[4], K = (int)plan[5], act = (int)plan[6], npf = (int)plan[7];
   const long long rec = plan[9];
   TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5], consts[8], consts[9]};
+  // dropout of the residual blocks: training-mode passes only (header words [14], [15])
+  const bool drop = training != 0 && tr_has_dropout(plan);
+  const float drop_p = tr_bits(plan[14]);
+  const double thr_d = (double)drop_p * 4294967296.0 + 0.5;
+  const uint32_t drop_thr = thr_d >= 4294967295.0 ? 0xffffffffu : (uint32_t)thr_d;
+  const float drop_scale = drop_p < 1.0f ? 1.0f / (1.0f - drop_p) : 0.0f;
+  const long long* drop_state = (const long long*)(uintptr_t)plan[15];
+  int coupling_index = 0;
   // (w.logdet and the scalar block were zeroed by tr_prepare)
   for (int b = 0; b < NL; ++b) {
     const long long* r = plan + TR_HDR + b * rec;
@@ -1560,6 +1886,22 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
       const int* id_cols = tabs + r[3];
       const int* tr_cols = tabs + r[4];
       const long long* off = r + 5;
+      const uint32_t drop_tag = 0x44000000u | ((uint32_t)coupling_index << 8);
+      ++coupling_index;
+      float* masks = lay + w.mask_off;  // [L][al4(n * H)] (dropout only)
+      // batch norm within the blocks: a_l = BN0(h_l) feeds the first linear layer, v_l = BN1(u_l) the second
+      const bool bnw = tr_has_inner_bn(plan);
+      const float bn_eps = tr_bits(plan[17]);
+      float* bn_a = lay + w.bn_off;
+      float* bn_v = bn_a + (long long)L * al4(n * H);
+      float* bn_st = bn_v + (long long)L * al4(n * H);  // per block: mean0, invstd0, mean1, invstd1 (al4(H) each)
+      const long long* bn_par = off + 4 + 4 * L + (plan[13] > 0 ? 2 * L : 0);  // per block: {g, b, rm, rv} x 2
+      auto inner_bn = [&](int l, int which, const float* X, float* Y) {
+        const long long* q = bn_par + 8 * l + 4 * which;
+        float* st = bn_st + ((long long)l * 4 + 2 * which) * al4(H);
+        hipLaunchKernelGGL(tr_bn1d_forward, dim3(H), dim3(256), 0, s, (int)n, H, X, Y, params + q[0], params + q[1],
+                           params + q[2], params + q[3], bn_eps, 0.1f, training, st, st + al4(H));
+      };
       // layer block: xsave[n*d_tr_max] | h[L+1][n*H] | u[L][n*H] | p[n*np_max]
       float* xsave = lay;
       float* h = xsave + w.xsave_words;
@@ -1648,10 +1990,19 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
           float* ul = u + (long long)l * n * H;
           float* tl = tb + (long long)l * al4(n * H);
           float* gl = gb + (long long)l * al4(n * H);
-          hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, hl, H, (const int*)nullptr,
+          const float* in0 = hl;
+          if (bnw) { inner_bn(l, 0, hl, bn_a + (long long)l * al4(n * H)); in0 = bn_a + (long long)l * al4(n * H); }
+          hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, in0, H, (const int*)nullptr,
                              act, params + off[2 + 4 * l], params + off[3 + 4 * l], (const float*)nullptr, ul, H);
-          hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, ul, H, (const int*)nullptr,
-                             act, params + off[4 + 4 * l], params + off[5 + 4 * l], (const float*)nullptr, tl, H);
+          const float* in1 = ul;
+          if (bnw) { inner_bn(l, 1, ul, bn_v + (long long)l * al4(n * H)); in1 = bn_v + (long long)l * al4(n * H); }
+          float* ml = drop ? masks + (long long)l * al4(n * H) : nullptr;
+          if (drop)
+            hipLaunchKernelGGL(tr_dropout_mask, blocks_for(n * ((H + 3) / 4)), dim3(256), 0, s, n, H, drop_state,
+                               drop_tag | (uint32_t)l, drop_thr, drop_scale, ml);
+          hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, in1, H, (const int*)nullptr,
+                             act, params + off[4 + 4 * l], params + off[5 + 4 * l], (const float*)nullptr, tl, H,
+                             (const float*)ml);
           hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, C, H, w.ctx, C, (const int*)nullptr,
                              ACT_NONE, params + off[4 + 4 * L + 2 * l], params + off[5 + 4 * L + 2 * l],
                              (const float*)nullptr, gl, H);
@@ -1678,10 +2029,19 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
       for (int l = 0; l < L; ++l) {
         float* hl = h + (long long)l * n * H;
         float* ul = u + (long long)l * n * H;
-        hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, hl, H, (const int*)nullptr,
+        const float* in0 = hl;
+        if (bnw) { inner_bn(l, 0, hl, bn_a + (long long)l * al4(n * H)); in0 = bn_a + (long long)l * al4(n * H); }
+        hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, in0, H, (const int*)nullptr,
                            act, params + off[2 + 4 * l], params + off[3 + 4 * l], (const float*)nullptr, ul, H);
-        hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, ul, H, (const int*)nullptr,
-                           act, params + off[4 + 4 * l], params + off[5 + 4 * l], hl, hl + (long long)n * H, H);
+        const float* in1 = ul;
+        if (bnw) { inner_bn(l, 1, ul, bn_v + (long long)l * al4(n * H)); in1 = bn_v + (long long)l * al4(n * H); }
+        float* ml = drop ? masks + (long long)l * al4(n * H) : nullptr;
+        if (drop)
+          hipLaunchKernelGGL(tr_dropout_mask, blocks_for(n * ((H + 3) / 4)), dim3(256), 0, s, n, H, drop_state,
+                             drop_tag | (uint32_t)l, drop_thr, drop_scale, ml);
+        hipLaunchKernelGGL(tr_gemm_nt, tiles(n, H), dim3(64), 0, s, (int)n, H, H, in1, H, (const int*)nullptr,
+                           act, params + off[4 + 4 * l], params + off[5 + 4 * l], hl, hl + (long long)n * H, H,
+                           (const float*)ml);
       }
       float* hL = h + (long long)L * n * H;
       hipLaunchKernelGGL(tr_gemm_nt, tiles(n, np), dim3(64), 0, s, (int)n, H, np, hL, H, (const int*)nullptr,
@@ -1721,7 +2081,7 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
                            params + r[3]);
       hipLaunchKernelGGL(tr_actnorm_forward, blocks_for(n * D), dim3(256), 0, s, (int)n, D, w.x, D, cols,
                          params + r[2], params + r[3], q.xin, w.scal + 1);
-    } else {  // TR_LU: y = (x U^T) L^T + b, outputs in logical order
+    } else if (r[0] == TR_LU) {  // y = (x U^T) L^T + b, outputs in logical order
       const int* cols = tabs + r[1];
       const float eps = tr_bits(r[6]);
       TrLin q = tr_lin(lay, n, D);
@@ -1743,8 +2103,18 @@ static void tr_forward(const long long* plan, const int* tabs, float* params, co
                          ACT_NONE, q.Um, zero, (const float*)nullptr, q.t, D);
       hipLaunchKernelGGL(tr_gemm_nt, tiles(n, D), dim3(64), 0, s, (int)n, D, D, q.t, D, (const int*)nullptr,
                          ACT_NONE, q.Lm, params + r[5], (const float*)nullptr, w.x, D);
+    } else if (r[0] == TR_SVD) {
+      const int* cols = tabs + r[1];
+      const int nh = (int)r[7];
+      TrLin q = tr_lin(lay, n, D);
+      const long long groups = (n + 3) / 4;
+      hipLaunchKernelGGL(tr_svd_forward, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(256),
+                         (size_t)(2 * nh * D + 2 * nh + D) * sizeof(float), s, (int)n, D, nh, w.x, cols, params + r[2],
+                         params + r[3], params + r[4], params + r[5], tr_bits(r[6]), q.xin, w.scal + 1);
     }
   }
+  // the next training-mode pass draws new masks (on the device: the step survives a HIP-graph replay)
+  if (drop) hipLaunchKernelGGL(tr_dropout_tick, dim3(1), dim3(1), 0, s, (long long*)(uintptr_t)plan[15]);
 }
 
 // training != 0: the forward pass used batch statistics (batch norm)
@@ -1758,6 +2128,7 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
   TrConsts c = {consts[0], consts[1], consts[2], consts[3], consts[4], consts[5], consts[8], consts[9]};
   TrRanges ranges;
   ranges.count = 0;
+  const bool drop = training != 0 && tr_has_dropout(plan);  // the masks of the forward pass are in the workspace
   for (int b = NL - 1; b >= 0; --b) {
     const long long* r = plan + TR_HDR + b * rec;
     float* lay = w.layer_base + b * w.per_layer;
@@ -1766,6 +2137,20 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       const int* id_cols = tabs + r[3];
       const int* tr_cols = tabs + r[4];
       const long long* off = r + 5;
+      const float* masks = lay + w.mask_off;
+      const bool bnw = tr_has_inner_bn(plan);
+      float* bn_a = lay + w.bn_off;
+      float* bn_v = bn_a + (long long)L * al4(n * H);
+      float* bn_st = bn_v + (long long)L * al4(n * H);
+      const long long* bn_par = off + 4 + 4 * L + (plan[13] > 0 ? 2 * L : 0);
+      // d loss / d (input of batch norm `which` of block l) from Gy = d loss / d (its output); the gradients of its
+      // gamma / beta go to the flat gradient
+      auto inner_bn_back = [&](int l, int which, const float* Gy, const float* X, float* Gx, int accumulate) {
+        const long long* q = bn_par + 8 * l + 4 * which;
+        const float* st = bn_st + ((long long)l * 4 + 2 * which) * al4(H);
+        hipLaunchKernelGGL(tr_bn1d_backward, dim3(H), dim3(256), 0, s, (int)n, H, Gy, X, params + q[0], st, st + al4(H),
+                           training, Gx, accumulate, grads + q[0], grads + q[1]);
+      };
       float* xsave = lay;
       float* h = xsave + w.xsave_words;
       float* u = h + (long long)(L + 1) * n * H;
@@ -1869,14 +2254,26 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
           hipLaunchKernelGGL(tr_gate_backward, blocks_for(n * H), dim3(256), 0, s, n * H, w.gh, tl, gl);
           hipLaunchKernelGGL(tr_gemm_tn, tiles(H, C), dim3(256), 0, s, (int)n, H, C, gl, H, w.ctx, C,
                              (const int*)nullptr, ACT_NONE, grads + off[4 + 4 * L + 2 * l], grads + off[5 + 4 * L + 2 * l]);
-          hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, tl, H, ul, H,
-                             (const int*)nullptr, act, grads + off[4 + 4 * l], grads + off[5 + 4 * l]);
+          const float* ml = drop ? masks + (long long)l * al4(n * H) : nullptr;
+          float* al_ = bn_a + (long long)l * al4(n * H);
+          float* vl_ = bn_v + (long long)l * al4(n * H);
+          const float* in1 = bnw ? vl_ : ul;
+          const float* in0 = bnw ? al_ : hl;
+          hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, tl, H, in1, H,
+                             (const int*)nullptr, act, grads + off[4 + 4 * l], grads + off[5 + 4 * l], ml);
           hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, tl, H,
-                             params + off[4 + 4 * l], ul, H, act, w.gu, H, (const int*)nullptr, 0);
-          hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, w.gu, H, hl, H,
+                             params + off[4 + 4 * l], in1, H, act, w.gu, H, (const int*)nullptr, 0, ml);
+          if (bnw) inner_bn_back(l, 1, w.gu, ul, w.gu, 0);
+          hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, w.gu, H, in0, H,
                              (const int*)nullptr, act, grads + off[2 + 4 * l], grads + off[3 + 4 * l]);
+          if (bnw) {  // (v_l is free now: it holds d loss / d a_l on its way through the first batch norm)
+            hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gu, H,
+                               params + off[2 + 4 * l], in0, H, act, vl_, H, (const int*)nullptr, 0);
+            inner_bn_back(l, 0, vl_, hl, w.gh, 1);
+          } else {
           hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gu, H,
                              params + off[2 + 4 * l], hl, H, act, w.gh, H, (const int*)nullptr, 1);
+          }
         }
         hipLaunchKernelGGL(tr_gemm_tn, tiles(H, W), dim3(256), 0, s, (int)n, H, W, w.gh, H, xc, W, (const int*)nullptr,
                            ACT_NONE, grads + off[0], grads + off[1]);
@@ -1889,15 +2286,27 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
         float* hl = h + (long long)l * n * H;
         float* ul = u + (long long)l * n * H;
         // second linear of the block: h_{l+1} = h_l + W2 act(u_l) + b2
-        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, w.gh, H, ul, H,
-                           (const int*)nullptr, act, grads + off[4 + 4 * l], grads + off[5 + 4 * l]);
+        const float* ml = drop ? masks + (long long)l * al4(n * H) : nullptr;
+        float* al_ = bn_a + (long long)l * al4(n * H);
+        float* vl_ = bn_v + (long long)l * al4(n * H);
+        const float* in1 = bnw ? vl_ : ul;  // (batch norm within: the linear layers saw BN1(u_l) and BN0(h_l))
+        const float* in0 = bnw ? al_ : hl;
+        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, w.gh, H, in1, H,
+                           (const int*)nullptr, act, grads + off[4 + 4 * l], grads + off[5 + 4 * l], ml);
         hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gh, H,
-                           params + off[4 + 4 * l], ul, H, act, w.gu, H, (const int*)nullptr, 0);
+                           params + off[4 + 4 * l], in1, H, act, w.gu, H, (const int*)nullptr, 0, ml);
+        if (bnw) inner_bn_back(l, 1, w.gu, ul, w.gu, 0);
         // first linear: u_l = W1 act(h_l) + b1
-        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, w.gu, H, hl, H,
+        hipLaunchKernelGGL(tr_gemm_tn, tiles(H, H), dim3(256), 0, s, (int)n, H, H, w.gu, H, in0, H,
                            (const int*)nullptr, act, grads + off[2 + 4 * l], grads + off[3 + 4 * l]);
+        if (bnw) {  // (v_l is free now: it holds d loss / d a_l on its way through the first batch norm)
+          hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gu, H,
+                             params + off[2 + 4 * l], in0, H, act, vl_, H, (const int*)nullptr, 0);
+          inner_bn_back(l, 0, vl_, hl, w.gh, 1);
+        } else {
         hipLaunchKernelGGL(tr_gemm_nn, tiles(n, H), dim3(64), 0, s, (int)n, H, H, w.gu, H,
                            params + off[2 + 4 * l], hl, H, act, w.gh, H, (const int*)nullptr, 1);
+        }
       }
       // initial layer: dW0, db0, g_x[:, id_cols] += gh . W0 (x was restored by the transform's backward)
       hipLaunchKernelGGL(tr_gemm_tn, tiles(H, d_id), dim3(256), 0, s, (int)n, H, d_id, w.gh, H, w.x, D, id_cols,
@@ -1926,6 +2335,15 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
       TrLin q = tr_lin(lay, n, D);
       hipLaunchKernelGGL(tr_actnorm_backward, dim3(D), dim3(256), 0, s, (int)n, w.x, w.gx, D, cols, q.xin, D,
                          params + r[2], grads + r[2], grads + r[3], w.scal + 2);
+    } else if (r[0] == TR_SVD) {
+      const int* cols = tabs + r[1];
+      const int nh = (int)r[7];
+      TrLin q = tr_lin(lay, n, D);
+      const long long groups = (n + 3) / 4;
+      hipLaunchKernelGGL(tr_svd_backward, dim3((unsigned)(groups < 64 ? groups : 64)), dim3(256),
+                         (size_t)(4 * nh * D + 2 * nh + 3 * D) * sizeof(float), s, (int)n, D, nh, w.x, w.gx, cols,
+                         params + r[2], params + r[3], params + r[4], tr_bits(r[6]), q.xin, grads + r[2], grads + r[3],
+                         grads + r[4], grads + r[5], w.scal + 2);
     } else {  // TR_LU
       const int* cols = tabs + r[1];
       const float eps = tr_bits(r[6]);

@@ -461,17 +461,25 @@ class HipFlow(BaseFlow):
         return context.detach().to(torch.float32).contiguous()
 
     def _run(self, x, direction, mode, want_x=True, context=None):
-        if self.training and _has_inner_batch_norm(self):
-            raise RuntimeError(
-                "batch_norm_within_layers runs on its running statistics only (eval mode): the gfx950 kernels "
-                "compute no batch statistics inside the conditioner; call .eval() first"
-            )
-        if direction == DIR_FORWARD and (self._wants_grad(x) or (self.training and _has_norm_layers(self))):
+        stochastic = self.training and _has_dropout(self)  # training mode draws dropout masks, as nflows does
+        inner_bn = self.training and _has_inner_batch_norm(self)  # ... and normalises with batch statistics
+        if direction == DIR_FORWARD and (self._wants_grad(x) or stochastic or inner_bn or
+                                         (self.training and _has_norm_layers(self))):
             return self._run_differentiable(x, mode, want_x, context)
+        if inner_bn:
+            raise RuntimeError(
+                "batch_norm_within_layers: the inverse / sampling kernels run on the running statistics (eval mode); "
+                "call .eval() before inverting or sampling the flow"
+            )
         if self.training and _has_norm_layers(self):
             raise RuntimeError(
                 "The inverse of batch-norm / act-norm transforms uses running statistics; "
                 "call .eval() before inverting or sampling the flow"
+            )
+        if stochastic:
+            raise RuntimeError(
+                "dropout_probability > 0: the inverse / sampling kernels have no dropout (it is the identity in eval "
+                "mode); call .eval() before inverting or sampling the flow"
             )
         x = self._check_input(x)
         context = self._check_context(context, x.shape[0])
@@ -699,6 +707,15 @@ def _count(flow, what):
 
 def _has_batch_norm(flow):
     return any(isinstance(m, M.BatchNorm) for m in flow.modules())
+
+
+def _has_dropout(flow):
+    """``dropout_probability`` > 0 in the residual blocks of the conditioners."""
+    cached = flow.__dict__.get("_dropout")
+    if cached is None:
+        cached = any(getattr(m, "dropout_probability", 0.0) > 0.0 for m in flow.modules() if isinstance(m, M.ResidualNet))
+        flow.__dict__["_dropout"] = cached
+    return cached
 
 
 def _has_inner_batch_norm(flow):

@@ -80,7 +80,8 @@ class RealNVP(HipFlow):
             raise RuntimeError(
                 "Cannot enable actnorm and batchnorm between layers simultaneously."
             )
-        _reject_unsupported(context_features, dropout_probability and net.lower() != "mlp",
+        # (the reference's MLP conditioner ignores both options with a warning: flows/realnvp.py:151-159)
+        _reject_unsupported(context_features, dropout_probability if net.lower() != "mlp" else 0.0,
                             batch_norm_within_layers and net.lower() != "mlp")
         scale_kwargs = {}
         scale_activation = kwargs.pop("scale_activation", None)

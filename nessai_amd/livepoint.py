@@ -138,3 +138,20 @@ def _cached_dtype(names):
     if dt is None:
         dt = _DTYPES[names] = get_dtype(list(names))
     return dt
+
+
+def live_points_to_dict(live_points, names=None):
+    """Structured array -> ``{field: array}`` (``livepoint.py:193-224`` of the reference)."""
+    if names is None:
+        names = live_points.dtype.names
+    return {f: live_points[f] for f in names}
+
+
+def save_live_points(live_points, filename):
+    """Live points as JSON, one list per field (``utils/io.py:116-130``: ``live_points_to_dict`` dumped with
+    ``indent=4`` and the arrays as lists - the file ``save_training_data`` writes per training)."""
+    import json
+
+    d = {k: np.asarray(v).tolist() for k, v in live_points_to_dict(live_points).items()}
+    with open(filename, "w") as wf:
+        json.dump(d, wf, indent=4)

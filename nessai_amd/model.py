@@ -161,10 +161,18 @@ class Model:
             out[n] = (x[n] - lo) / (hi - lo)
         return out
 
-    def batch_evaluate_log_prior_unit_hypercube(self, x):
-        """Log-prior density in the unit hypercube: 0 inside, -inf outside."""
+    def log_prior_unit_hypercube(self, x):
+        """Log-prior density in the unit hypercube: log 1 on [0, 1)^D, -inf outside - the reference's default, with
+        its half-open support (``src/nessai/model.py:593-601``: ``(x < 0) | (x >= 1)``)."""
+        v = self._block(x)
+        if v is None:
+            v = np.stack([np.asarray(x[n], dtype=np.float64) for n in self.names], axis=-1)
         with np.errstate(divide="ignore"):
-            return np.log(self.in_unit_hypercube(x), dtype="float")
+            return np.log(~np.any((v < 0.0) | (v >= 1.0), axis=-1), dtype="float")
+
+    def batch_evaluate_log_prior_unit_hypercube(self, x):
+        """(``src/nessai/model.py:679-700``: the vectorised form of ``log_prior_unit_hypercube``.)"""
+        return self.log_prior_unit_hypercube(x)
 
     def new_point(self, N=1, rng=None):
         """Draw from the prior box (uniform models)."""

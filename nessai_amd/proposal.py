@@ -36,6 +36,7 @@ from .flowmodel import FlowModel
 from .livepoint import (
     array_to_live_points_fast,
     copy_points,
+    save_live_points,
     get_dtype,
     live_points_to_array,
 )
@@ -98,6 +99,9 @@ class FlowProposal:
     """
 
     _FlowModelClass = FlowModel
+    #: class default of ``use_default_reparameterisations`` (``proposal/flowproposal/base.py:95``; a subclass with
+    #: defaults of its own - the reference's GW proposal - sets it and overrides ``add_default_reparameterisations``)
+    use_default_reparameterisations = False
 
     def __init__(
         self,
@@ -138,11 +142,22 @@ class FlowProposal:
         lean=True,
         reparameterisations=None,
         fallback_reparameterisation="z-score",
+        save_training_data=False,
+        use_default_reparameterisations=None,
+        reverse_reparameterisations=False,
+        map_to_unit_hypercube=False,
         plot=False,
         **kwargs,
     ):
         if kwargs:
             raise TypeError(f"Unknown FlowProposal arguments: {sorted(kwargs)}")
+        # the rest of BaseFlowProposal's keyword surface (proposal/flowproposal/base.py:116-121, 140-158)
+        self.save_training_data = bool(save_training_data)
+        if use_default_reparameterisations is not None:
+            self.use_default_reparameterisations = bool(use_default_reparameterisations)
+        self.reverse_reparameterisations = bool(reverse_reparameterisations)
+        self.map_to_unit_hypercube = bool(map_to_unit_hypercube)
+        self._prior_bounds = None
         if latent_temperature is not None:  # flowproposal.py:263-272
             if isinstance(latent_temperature, bool) or not isinstance(latent_temperature, (int, float)):
                 raise TypeError("latent_temperature must be a positive float")
@@ -294,9 +309,11 @@ class FlowProposal:
             if getattr(self.model, "reparameterisations", None) is not None:  # base.py:639-640
                 config = self.model.reparameterisations
             self._reparam = ReparameterisationTable(
-                self.names, getattr(self.model, "bounds", None), config, fallback=self.fallback_reparameterisation,
-                rng=self.rng,
+                self.names, self.prior_bounds, config, fallback=self.fallback_reparameterisation,
+                rng=self.rng, reverse_order=self.reverse_reparameterisations,
             )
+            if self.use_default_reparameterisations:  # base.py:602-603
+                self.add_default_reparameterisations()
             self.truncation.configure(self)  # truncation.py:292-308 (needs the dimensions)
         config = dict(self.flow_config)
         config["n_inputs"] = self.dims
@@ -314,13 +331,24 @@ class FlowProposal:
         has_device_prior = getattr(self.model, "uniform_prior", False) or (
             getattr(self.model, "device_prior", None) is not None
         )
+        if self.map_to_unit_hypercube:
+            # In the unit hypercube the prior is the model's log_prior_unit_hypercube (base.py:1053-1067, 1089-1090):
+            # 0 in [0, 1)^D and -inf outside unless the model says otherwise (model.py:593-601) - that default is the
+            # "uniform box" of the draw kernel (bounds [0, 1), constant 0); a model with a cube prior of its own is
+            # evaluated on the host.
+            from .model import Model as _OwnModel
+
+            has_device_prior = (
+                getattr(type(self.model), "batch_evaluate_log_prior_unit_hypercube", None)
+                is _OwnModel.batch_evaluate_log_prior_unit_hypercube
+            )
         if mode == "auto":
             mode = "device" if has_device_prior else "host"
         if mode == "device" and not has_device_prior:
             raise ValueError("prior='device' needs model.uniform_prior or model.device_prior")
         self.prior_mode = mode
         self._prior_kind_dev = self._prior_par_dev = None
-        if mode == "device" and not getattr(self.model, "uniform_prior", False):
+        if mode == "device" and not self.map_to_unit_hypercube and not getattr(self.model, "uniform_prior", False):
             kinds, pars = self.model.device_prior_tables()
             self._prior_kind_dev = torch.from_numpy(kinds).to(self.device)
             self._prior_par_dev = torch.from_numpy(pars).to(self.device)
@@ -329,6 +357,12 @@ class FlowProposal:
         if self._likelihood_mode == "device" and spec is None:
             raise ValueError("likelihood='device' needs model.device_likelihood")
         self._ll_spec = None
+        if self.map_to_unit_hypercube:
+            # the rows of a population are points of the unit hypercube until convert_to_samples maps them back
+            # (a user map, on the host): the device likelihood would see the wrong coordinates
+            if self._likelihood_mode == "device":
+                raise ValueError("likelihood='device' is not available with map_to_unit_hypercube=True")
+            spec = None
         if spec is not None and self._likelihood_mode != "host" and 2 <= self.dims <= 129:
             f64 = dict(dtype=torch.float64, device=self.device)
             if spec[0] == "rosenbrock":
@@ -372,11 +406,39 @@ class FlowProposal:
         return {p: (g.shift[p] if g.shift else 0.0) for g in self._reparam.groups if g.kind == "scale_shift"
                 for p in g.parameters}
 
+    @property
+    def prior_bounds(self):
+        """The bounds the reparameterisations and the bounds test work in (``base.py:277-292``): the model's, or the
+        unit hypercube's with ``map_to_unit_hypercube``."""
+        if self._prior_bounds is None:
+            if self.map_to_unit_hypercube:
+                self._prior_bounds = {n: np.array([0.0, 1.0]) for n in self.model.names}
+            else:
+                self._prior_bounds = getattr(self.model, "bounds", None)
+        return self._prior_bounds
+
+    def add_default_reparameterisations(self):
+        """Hook of ``use_default_reparameterisations`` (``base.py:437-439``: none by default)."""
+        logger.debug("No default reparameterisations")
+
+    def _to_cube(self, x):
+        """``model.to_unit_hypercube`` when the proposal works in the unit hypercube (``base.py:744-745, 796-797``)."""
+        return self.model.to_unit_hypercube(x) if self.map_to_unit_hypercube else x
+
+    def _from_cube(self, x):
+        """... and back (``base.py:781-782, 1122-1123``)."""
+        return self.model.from_unit_hypercube(x) if self.map_to_unit_hypercube else x
+
+    def unit_hypercube_log_prior(self, x):
+        """Log-prior of points of the unit hypercube (``base.py:1053-1067``; the one-to-one reparameterisations of this
+        package carry no prior of their own)."""
+        return np.asarray(self.model.batch_evaluate_log_prior_unit_hypercube(x), dtype=np.float64)
+
     def check_state(self, x):
         """Update the data-dependent constants from the live points (``base.py:850-868``):
         z-score mean / std (``rescale.py:293-304``), rescale-to-bounds limits (``:720-741``)."""
         if self._reparam.should_update:
-            self._reparam.update(x)
+            self._reparam.update(self._to_cube(x))
         self._upload_constants()
 
     def set_rescaling_constants(self, shift, scale):
@@ -399,8 +461,14 @@ class FlowProposal:
         kind, par, scale, shift, log_j = self._reparam.device_tables()
         self._scale_dev = torch.tensor(scale, **f64)
         self._shift_dev = torch.tensor(shift, **f64)
-        self._lower_dev = torch.tensor(self.model.lower_bounds, **f64)
-        self._upper_dev = torch.tensor(self.model.upper_bounds, **f64)
+        if self.map_to_unit_hypercube:
+            # the cube prior's support [0, 1) (model.py:593-601: -inf for x < 0 or x >= 1): the kernel's test is
+            # lower <= x <= upper, so the upper bound is the largest float64 below 1
+            self._lower_dev = torch.zeros(self.dims, **f64)
+            self._upper_dev = torch.full((self.dims,), float(np.nextafter(1.0, 0.0)), **f64)
+        else:
+            self._lower_dev = torch.tensor(self.model.lower_bounds, **f64)
+            self._upper_dev = torch.tensor(self.model.upper_bounds, **f64)
         self._log_j_rescale = log_j
         if self._reparam.all_scale_shift:
             self._rp_kind_dev = self._rp_par_dev = None
@@ -414,14 +482,18 @@ class FlowProposal:
         has just detected its edges changes the draw kernel's per-column table."""
         known = self._reparam.has_inversion and any(
             e is None for g in self._reparam.groups if g.kind == "to_bounds" and g.inversion for e in g.edges.values())
-        out = self._reparam.rescale(x, compute_radius=compute_radius, test=test)
+        out = self._reparam.rescale(self._to_cube(x), compute_radius=compute_radius, test=test)
         if known:  # edges were open before this call: they are decided now
             self._upload_constants()
         return out
 
-    def inverse_rescale(self, x_prime):
-        """x' -> (x, log|J|)  (``base.py:755-784``)."""
-        return self._reparam.inverse_rescale(x_prime)
+    def inverse_rescale(self, x_prime, return_unit_hypercube=False):
+        """x' -> (x, log|J|)  (``base.py:755-784``); with ``map_to_unit_hypercube`` the points are mapped on to the
+        physical space unless ``return_unit_hypercube``."""
+        x, log_j = self._reparam.inverse_rescale(x_prime)
+        if not return_unit_hypercube:
+            x = self._from_cube(x)
+        return x, log_j
 
     # -- training ----------------------------------------------------------------
 
@@ -436,6 +508,10 @@ class FlowProposal:
         rank, world = self._rank_world()
         # every rank writes its own weights file (no race on a shared output directory)
         output = self.output if rank == 0 else os.path.join(self.output, f"rank_{rank}")
+        if self.save_training_data:  # base.py:887-900: one directory per training, the live points as JSON
+            output = os.path.join(output, "training", f"block_{self.training_count}", "")
+            os.makedirs(output, exist_ok=True)
+            save_live_points(x, os.path.join(output, "training_data.json"))
         fit_error = None
         if rank == 0 or self.replicate_training:
             try:
@@ -536,10 +612,12 @@ class FlowProposal:
         z, log_prob = self.flow.forward_and_log_prob(arr)
         return z, log_prob + log_J
 
-    def backward_pass(self, z, return_z=False):
+    def backward_pass(self, z, return_z=False, return_unit_hypercube=False):
         """Latents -> (x, log_q[, z]) for the kept rows (``flowproposal.py:345-389``).
 
-        Array-level entry point of the fused draw kernel with injected latents.
+        Array-level entry point of the fused draw kernel with injected latents.  With ``map_to_unit_hypercube`` the
+        kernel's bounds test is the unit hypercube's (the image of the prior's support) and the kept rows are mapped
+        on to the physical space unless ``return_unit_hypercube``.
         """
         z = np.ascontiguousarray(z, dtype=np.float64)
         n = z.shape[0]
@@ -554,6 +632,8 @@ class FlowProposal:
         log_q_h = log_q.cpu().numpy()
         keep = ~np.isnan(log_q_h)  # NaN marks a dropped row; +inf (saturated logit) is kept as in the reference
         x = array_to_live_points_fast(x64.cpu().numpy()[keep], self.names)
+        if not return_unit_hypercube:
+            x = self._from_cube(x)
         if return_z:
             return x, log_q_h[keep], z[keep]
         return x, log_q_h[keep]
@@ -561,13 +641,21 @@ class FlowProposal:
     def log_prior(self, x):
         return self.model.batch_evaluate_log_prior(x)
 
-    def compute_weights(self, x, log_q):
-        """``log_prior(x) - log_q`` (``base.py:1069-1098``)."""
-        return self.log_prior(x) - log_q
+    def _population_log_prior(self, x):
+        """Log-prior of candidate rows in the space the population lives in (``base.py:1089-1092``)."""
+        return self.unit_hypercube_log_prior(x) if self.map_to_unit_hypercube else self.log_prior(x)
+
+    def compute_weights(self, x, log_q, return_log_prior=False):
+        """``log_prior(x) - log_q`` (``base.py:1069-1098``): the unit-hypercube prior for the rows of a population
+        kept in the unit hypercube."""
+        log_p = self._population_log_prior(x)
+        log_w = log_p - log_q
+        return (log_w, log_p) if return_log_prior else log_w
 
     def convert_to_samples(self, x, plot=False):
-        """Attach ``logP`` (``base.py:1100-1128``)."""
+        """Map back from the unit hypercube if the population lives there, attach ``logP`` (``base.py:1100-1128``)."""
         x = copy_points(x)  # (one memcpy of the records; numpy copies a structured array field by field)
+        x = self._from_cube(x)
         x["logP"] = self.model.batch_evaluate_log_prior(x)
         return x
 
@@ -683,7 +771,7 @@ class FlowProposal:
             # general prior: evaluate the user's numpy log_prior on the host
             x_host = array_to_live_points_fast(buf["x64"][:n].cpu().numpy(), self.names)
             with np.errstate(divide="ignore", invalid="ignore"):
-                log_p = np.asarray(self.log_prior(x_host), dtype=np.float64)
+                log_p = np.asarray(self._population_log_prior(x_host), dtype=np.float64)
             log_p_dev = torch.from_numpy(log_p).to(self.device)
             rc = L.nsa_populate_weights(
                 n, lib.ptr(buf["log_q"]), lib.ptr(log_p_dev), 0.0, lib.ptr(buf["log_w"]),
@@ -693,6 +781,8 @@ class FlowProposal:
 
     def _uniform_log_prior_constant(self):
         """-sum log(width), subtracted bound by bound like ``examples/rosenbrock.py:28-31``."""
+        if self.map_to_unit_hypercube:
+            return 0.0  # log 1: the unit hypercube's own prior (model.py:593-601)
         log_p = np.float64(0.0)
         for n in self.names:
             lo, hi = self.model.bounds[n]
@@ -734,7 +824,7 @@ class FlowProposal:
             else:
                 alive = torch.isfinite(buf["log_q"][:n])
                 idx = torch.nonzero(alive).reshape(-1)
-                pts = array_to_live_points_fast(buf["x64"][:n][idx].cpu().numpy(), self.names)
+                pts = self._from_cube(array_to_live_points_fast(buf["x64"][:n][idx].cpu().numpy(), self.names))
                 values = np.asarray(self.model.batch_evaluate_log_likelihood(pts), dtype=np.float64)
                 log_l_dev = torch.full((n,), -math.inf, dtype=torch.float64, device=self.device)
                 log_l_dev[idx] = torch.from_numpy(values).to(self.device)

@@ -405,8 +405,13 @@ def _lookup(name):
 class ReparameterisationTable:
     """The proposal's x <-> x' map: ordered groups + the tables the draw kernel reads."""
 
-    def __init__(self, names, bounds, reparameterisations=None, fallback="z-score", rng=None):
+    def __init__(self, names, bounds, reparameterisations=None, fallback="z-score", rng=None, reverse_order=False):
         self.rng = rng  # split boundary inversion draws the rows it flips from the proposal's generator
+        #: ``reverse_reparameterisations`` of the proposal (``proposal/flowproposal/base.py:120,589``;
+        #: ``reparameterisations/combined.py:58-72``): the groups are applied last-to-first on the way to x' and
+        #: first-to-last on the way back - for the one-to-one maps here that is the order in which the log-Jacobian
+        #: is summed and in which a boundary inversion meets the groups around it
+        self.reverse_order = bool(reverse_order)
         self.names = list(names)
         self.prime_names = [n + "_prime" for n in self.names]
         bounds = {n: np.asarray(bounds[n], dtype=np.float64) for n in self.names} if bounds else {}
@@ -452,6 +457,16 @@ class ReparameterisationTable:
             self._add(fallback, others, bounds, {})
 
     @property
+    def to_prime_order(self):
+        """Groups in the order they act on the way to x' (``combined.py:58-64``)."""
+        return list(reversed(self.groups)) if self.reverse_order else list(self.groups)
+
+    @property
+    def from_prime_order(self):
+        """... and on the way back (``combined.py:66-72``)."""
+        return list(self.groups) if self.reverse_order else list(reversed(self.groups))
+
+    @property
     def parameters(self):
         return [p for g in self.groups for p in g.parameters]
 
@@ -477,13 +492,13 @@ class ReparameterisationTable:
         the rows a split inversion flips from the generator - once here, once more in the ``rescale`` of the
         training data, as the reference does - and hands doubled arrays to the groups behind it."""
         if not self.has_inversion:
-            for g in self.groups:
+            for g in self.to_prime_order:
                 g.update(x)
             return
         current = x.copy()
         x_prime = empty_structured_array(current.size, names=self.prime_names)
         log_j = np.zeros(current.size)
-        for g in self.groups:
+        for g in self.to_prime_order:
             g.update(current)
             current, x_prime, log_j = g.forward(current, x_prime, log_j)
 
@@ -500,7 +515,7 @@ class ReparameterisationTable:
         inversion (or ``compute_radius``) x' has twice the rows of x per mirrored parameter."""
         x_prime = empty_structured_array(x.size, names=self.prime_names)
         log_j = np.zeros(x_prime.size)
-        for g in self.groups:
+        for g in self.to_prime_order:
             x, x_prime, log_j = g.forward(x, x_prime, log_j, compute_radius=compute_radius, test=test)
         for f in _NON_SAMPLING:
             x_prime[f] = x[f]
@@ -509,7 +524,7 @@ class ReparameterisationTable:
     def inverse_rescale(self, x_prime):
         x = empty_structured_array(x_prime.size, names=self.names)
         log_j = np.zeros(x.size)
-        for g in reversed(self.groups):
+        for g in self.from_prime_order:
             log_j = g.inverse(x_prime, x, log_j)
         for f in _NON_SAMPLING:
             x[f] = x_prime[f]
@@ -534,7 +549,7 @@ class ReparameterisationTable:
         shift = np.zeros(D)
         col = {n: i for i, n in enumerate(self.names)}
         log_j = np.float64(0.0)
-        for g in reversed(self.groups):
+        for g in self.from_prime_order:
             params = list(reversed(g.parameters)) if g.kind == "to_bounds" else g.parameters
             for p in params:
                 i = col[p]

@@ -82,6 +82,10 @@ class Trainer:
             return int(np.array([value], dtype=np.float32).view(np.uint32)[0])
 
         tmap = np.arange(total, dtype=np.int64)  # transposition map of the weight matrices
+        dropout = None  # dropout_probability of the residual blocks (nflows ResidualBlock; one value per flow)
+        inner_bn = False  # batch_norm_within_layers: two BatchNorm1d per residual block
+        inner_bn_eps = 1e-3
+        self._inner_bns = []  # their modules: num_batches_tracked ticks with every training-mode pass
         self._actnorms = []  # (record index, module) of every act-norm layer
 
         for t in leaves:
@@ -94,15 +98,14 @@ class Trainer:
                     layers = net.layers()
                     depth = len(layers) - 2
                 else:
-                    if getattr(net, "dropout_probability", 0.0):
-                        raise NotImplementedError(
-                            "dropout_probability > 0: the gfx950 training kernels have no dropout (such a flow runs "
-                            "in eval mode - dropout is the identity there - with weights trained elsewhere)")
-                    if getattr(net, "use_batch_norm", False):
-                        raise NotImplementedError(
-                            "batch_norm_within_layers: the gfx950 training kernels have no batch statistics inside the "
-                            "conditioner (such a flow runs in eval mode, on its running statistics, with weights "
-                            "trained elsewhere)")
+                    p_drop = float(getattr(net, "dropout_probability", 0.0) or 0.0)
+                    if dropout is not None and p_drop != dropout:
+                        raise ValueError("all coupling layers must share one dropout_probability")
+                    dropout = p_drop
+                    if bool(getattr(net, "use_batch_norm", False)) != bool(inner_bn) and records and any(
+                            r[0] == 1 for r in records):
+                        raise ValueError("all coupling layers must share batch_norm_within_layers")
+                    inner_bn = bool(getattr(net, "use_batch_norm", False))
                     layers = [net.initial_layer]
                     for block in net.blocks:
                         layers.extend(block.linear_layers)
@@ -127,6 +130,15 @@ class Trainer:
                     for block in net.blocks:
                         rec.append(offsets[id(block.context_layer.weight)])
                         rec.append(offsets[id(block.context_layer.bias)])
+                if not is_mlp and inner_bn:  # {gamma, beta, running mean, running variance} of the block's two batch norms
+                    for block in net.blocks:
+                        for bn in block.batch_norm_layers:
+                            if bn.momentum is None or abs(bn.momentum - 0.1) > 1e-12 or not bn.affine:
+                                raise NotImplementedError("BatchNorm1d with non-default momentum / affine=False")
+                            inner_bn_eps = float(bn.eps)
+                            rec.extend([offsets[id(bn.weight)], offsets[id(bn.bias)], offsets[id(bn.running_mean)],
+                                        offsets[id(bn.running_var)]])
+                            self._inner_bns.append(bn)
                 records.append(rec)
             elif isinstance(t, M.BatchNorm):
                 rec = [2, len(tables), offsets[id(t.unconstrained_weight)], offsets[id(t.bias)],
@@ -150,10 +162,23 @@ class Trainer:
                 tables.extend(cur)
                 records.append(rec)
                 cur = list(range(D))
+            elif isinstance(t, M.SVDLinear):
+                # y = H1(diag(s) H2(x)) + b with Householder sequences H1, H2 (flows/utils.py:316-323): one wave per
+                # row, the reflections walked back in the backward pass (csrc/nsa_train.hip, tr_svd_*)
+                if D > 128:
+                    raise ValueError("SVD-linear transforms support at most 128 features")
+                nh = int(t.orthogonal_1.q_vectors.shape[0])
+                if int(t.orthogonal_2.q_vectors.shape[0]) != nh:
+                    raise ValueError("SVD-linear: the two Householder sequences must have the same length")
+                rec = [5, len(tables), offsets[id(t.orthogonal_1.q_vectors)], offsets[id(t.unconstrained_diagonal)],
+                       offsets[id(t.orthogonal_2.q_vectors)], offsets[id(t.bias)], f32_bits(t.eps), nh]
+                tables.extend(cur)
+                records.append(rec)
+                cur = list(range(D))
             else:
                 raise NotImplementedError(
-                    f"{type(t).__name__} has no training kernel (supported: permutation, LU-linear, "
-                    "coupling with a residual conditioner, batch norm)"
+                    f"{type(t).__name__} has no training kernel (supported: permutation, LU-linear, SVD-linear, "
+                    "coupling with a residual / MLP conditioner, batch norm, act norm)"
                 )
         if n_res is None:
             raise ValueError("the flow has no coupling layer")
@@ -173,6 +198,22 @@ class Trainer:
         #: workspace (``_put_context``)
         self.context_features = int(desc.get("context_features", 0) or 0)
         header.append(self.context_features)
+        #: dropout of the residual blocks, training-mode passes only: [14] the probability (float bits), [15] the
+        #: device address of {seed, step} - the masks come from a Philox stream keyed by them (csrc/nsa_train.hip,
+        #: tr_dropout_mask), the step ticks on the device after every training-mode forward pass.  Such a flow
+        #: trains on the layer-wise kernels.
+        self.dropout_probability = float(dropout or 0.0)
+        self.drop_state = None
+        if self.dropout_probability > 0.0:
+            seed = int(torch.randint(0, 2**62, (1,)).item())  # (from torch's global generator: seeded runs repeat)
+            self.drop_state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        header.append(f32_bits(self.dropout_probability) if self.dropout_probability > 0.0 else 0)
+        header.append(self.drop_state.data_ptr() if self.drop_state is not None else 0)
+        #: batch norm within the residual blocks: [16] flag, [17] eps (float bits); batch statistics in training-mode
+        #: passes, running statistics otherwise (csrc/nsa_train.hip, tr_bn1d_forward); the layer-wise kernels
+        self.inner_batch_norm = bool(self._inner_bns)
+        header.append(1 if self.inner_batch_norm else 0)
+        header.append(f32_bits(inner_bn_eps))
         tables = list(tables) + tmap.tolist() + [int(c) for c in cur]
         plan = header + [w for rec in records for w in rec]
         self.plan = (ctypes.c_longlong * len(plan))(*plan)
@@ -265,6 +306,7 @@ class Trainer:
         )
         lib.check(rc, "nsa_train_forward")
         if training:
+            self._count_training_pass()
             self._actnorm_initialised()
         return z, ld, lp, ws
 
@@ -280,6 +322,10 @@ class Trainer:
         )
         lib.check(rc, "nsa_train_backward")
         return grads, gx
+
+    def _count_training_pass(self):
+        for bn in self._inner_bns:  # torch's BatchNorm1d counts its training-mode passes (a state_dict entry)
+            bn.num_batches_tracked.add_(1)
 
     def _actnorm_initialised(self):
         for index, module in self._actnorms:  # initialised by the training-mode pass that just ran
@@ -327,6 +373,7 @@ class Trainer:
             float(clip_norm or 0.0), self.step_count, self.optimiser, lib.ptr(self.loss_acc), lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_train_step")
+        self._count_training_pass()
         self._actnorm_initialised()
 
     def step_dev(self, x, clip_norm=5.0, weights=None, context=None):
@@ -343,6 +390,7 @@ class Trainer:
             self.optimiser, lib.ptr(self.loss_acc), lib.c_void_p(stream),
         )
         lib.check(rc, "nsa_train_step_dev")
+        self._count_training_pass()
         # the data-dependent act-norm initialisation belongs to the FIRST training batch only (nflows ActNorm):
         # clear the plan's flag now, not at the end of the epoch - every further minibatch would re-initialise
         # log_scale / shift from its own statistics on top of the optimiser's updates.  (No-op, hence safe

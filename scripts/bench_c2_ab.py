@@ -88,9 +88,14 @@ def main():
         for root in args.root:
             env = dict(os.environ)
             env.pop("NESSAI_AMD_LIBRARY", None)
+            tag = root
+            if "@" in root:  # "TREE@LIBRARY": the tree's package with another build of its library (variants/)
+                root, library = root.split("@", 1)
+                env["NESSAI_AMD_LIBRARY"] = os.path.abspath(library)
             p = subprocess.run([sys.executable, "-c", CHILD, root], capture_output=True, text=True, env=env)
+            root = tag
             line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else json.dumps({"root": root, "error": p.stderr[-800:]})
-            print(json.dumps(dict(json.loads(line), round=r)), flush=True)
+            print(json.dumps(dict(json.loads(line), round=r, root=tag)), flush=True)
 
 
 if __name__ == "__main__":

@@ -33,7 +33,7 @@ def pytest_collection_modifyitems(config, items):
 #: GPU suites that drive the flows under autograd; every other GPU suite exercises the inference
 #: kernels and runs with autograd off, as the reference's callers do
 #: (``torch.inference_mode()`` in src/nessai/flowmodel/base.py:782-948)
-GRAD_MODULES = {"test_gpu_autograd", "test_gpu_train", "test_gpu_conditional_train"}
+GRAD_MODULES = {"test_gpu_autograd", "test_gpu_train", "test_gpu_conditional_train", "test_gpu_train_modes"}
 
 
 @pytest.fixture(autouse=True)

@@ -109,15 +109,21 @@ def test_sampling_and_populate_style_passes_run_the_same_kernel_family():
     assert rel_err(lp.cpu(), lp_ref, floor=1e-3) <= LOG_PROB_RTOL
 
 
-def test_training_mode_and_training_are_refused():
+def test_training_mode_runs_on_batch_statistics_and_the_inverse_needs_eval_mode():
+    """Round 6: the flow trains (tests/test_gpu_train_modes.py holds the gradients against autograd); a training-mode
+    forward pass normalises with batch statistics, the inverse / sampling kernels need ``.eval()``."""
     _, flow, D, _ = _pair("nsf_d6")
     from nessai_amd.train import Trainer
 
-    with pytest.raises(NotImplementedError, match="batch_norm_within_layers"):
-        Trainer(flow)
+    assert Trainer(flow).inner_batch_norm
+    x = torch.randn(64, D, device=DEV)
+    flow.eval()
+    lp_eval = flow.log_prob(x)
     flow.train()
+    lp_train = flow.log_prob(x)  # batch statistics of THIS batch, running statistics updated
+    assert lp_train.shape == (64,) and not torch.equal(lp_train, lp_eval)
     with pytest.raises(RuntimeError, match="eval"):
-        flow.log_prob(torch.randn(10, D, device=DEV))
+        flow.inverse(x)
     flow.eval()
     assert flow.log_prob(torch.randn(10, D, device=DEV)).shape == (10,)
 
