@@ -855,7 +855,12 @@ __device__ __forceinline__ void nsa_run_phase(typename TP::State (&st)[TP::FPC],
   if constexpr (P == 0) x_in = xrow[c];
   float y = 0.0f, ld = 0.0f;
   bool bad = false;
-  TP::template phase<P, Q * TP::NP, INV, NV>(st[Q], v, x_in, tc, y, ld, bad);
+  // (PRESCALED: the flow image carries the spline's logit scale inside the last layer - nsa_device.h, NsaRQ::knots)
+#ifdef NSA_NO_PRESCALE  // timing-only A/B build (scripts/build_variant.sh): the multiplication back in, on scaled logits - wrong rows
+  TP::template phase<P, Q * TP::NP, INV, NV, false>(st[Q], v, x_in, tc, y, ld, bad);
+#else
+  TP::template phase<P, Q * TP::NP, INV, NV, true>(st[Q], v, x_in, tc, y, ld, bad);
+#endif
   if constexpr (P == TP::NPH - 1) {
     xrow[c] = y;
     if constexpr (TP::LD_FACTOR) fac[Q] = live ? ld : 1.0f;

@@ -115,6 +115,16 @@ def _held_against_float64(name, dev, o32, o64, bar, factor=3.0):
     return ok
 
 
+def _twin64(ref):
+    """float64 copy of an oracle flow (eval mode); the LU-linear layers' cached matrices - plain attributes, which
+    ``.double()`` does not convert - are dropped the way the reference drops them: ``train(); eval()``
+    (``flowmodel/base.py:681-682``)."""
+    r64 = copy.deepcopy(ref).double()
+    r64.train()
+    r64.eval()
+    return r64
+
+
 GATE = 1.0e-5  # SURVEY.md section 8d: |inverse(forward(x)) - x| <= 1e-5, and the bar of log_prob (relative)
 BAR5 = 1.5e-5  # numpy's decimal=5, the reference's own property bar (tests/test_flows/test_included_flows.py:129-154)
 
@@ -139,7 +149,7 @@ def test_forward_inverse_match_oracle(pair, request):
         assert rel_err(xi.cpu(), xi_ref) <= X_ATOL * k
         assert rel_err(ldi.cpu(), ldi_ref) <= LOGDET_ATOL * k
         return
-    r64 = copy.deepcopy(ref).double()
+    r64 = _twin64(ref)
     with torch.no_grad():
         z64, ld64 = r64.forward(x.double())
         xi64, ldi64 = r64.inverse(x.double())
@@ -187,7 +197,7 @@ def test_invertibility(pair, request):
     if not (e_j <= BAR5 or e_j <= 1.5 * o_j):
         # the sum of the two log-Jacobians is a difference of rounding errors, and the float32 oracle can come out ahead
         # by cancellation (tests/test_gpu_reference_bars.py): taken apart against the float64 twin, term by term
-        r64 = copy.deepcopy(ref).double()
+        r64 = _twin64(ref)
         with torch.no_grad():
             z64, lj64 = r64.forward(x.cpu().double())
             _, lji64_dev = r64.inverse(z.cpu().double())
