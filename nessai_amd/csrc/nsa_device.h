@@ -347,31 +347,23 @@ struct NsaRQ {
   // nothing overflowed and no term of weight was flushed (`sums_in_range`) and repeats the evaluation with
   // SHIFTED = true - torch's max-subtracted softmax, safe for any logits - when a lane of the wave left it.
   // Returns the sum of the exponentials.
-  // PRESCALED (round 6, flow image format 11): the packer has folded log2(e) / sqrt(H) into the rows of the last
-  // conditioner layer that emit width / height logits (pack.py, _CouplingBlobs), so the accumulators ARE the
-  // arguments of v_exp_f32 - one multiplication per logit less, 16 of ~165 vector instructions per evaluation.  The
-  // training kernels evaluate the same function on the flow's own parameters (PRESCALED = false).
-  template <int OFF, int NV, bool SHIFTED, bool PRESCALED = false>
+  template <int OFF, int NV, bool SHIFTED>
   __device__ __forceinline__ static float knots(const float (&v)[NV], float inv_div, float mn,
                                                 float sc, float two_b, float B, float (&cum)[K + 1], int k_real = K) {
-    const float k2 = PRESCALED ? 1.0f : inv_div * 1.4426950408889634f;
+    const float k2 = inv_div * 1.4426950408889634f;
     float mk = 0.0f;
     if constexpr (SHIFTED) {
       // max over the raw logits (the scale is positive), then scale and shift in ONE fma per logit
       float m = v[OFF];
 #pragma unroll
       for (int i = 1; i < K; ++i) m = fmaxf(m, v[OFF + i]);
-      mk = PRESCALED ? m : m * k2;
+      mk = m * k2;
     }
     float pre[K + 1];
     pre[0] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-      float arg;
-      if constexpr (PRESCALED) arg = SHIFTED ? v[OFF + i] - mk : v[OFF + i];
-      else arg = SHIFTED ? fmaf(v[OFF + i], k2, -mk) : v[OFF + i] * k2;
-      pre[i + 1] = pre[i] + __builtin_amdgcn_exp2f(arg);
-    }
+    for (int i = 0; i < K; ++i)
+      pre[i + 1] = pre[i] + __builtin_amdgcn_exp2f(SHIFTED ? fmaf(v[OFF + i], k2, -mk) : v[OFF + i] * k2);
     const float g = (two_b * sc) * nsa_rcp(pre[K]);
     const float c0 = two_b * mn;
 #pragma unroll
@@ -401,7 +393,7 @@ struct NsaRQ {
   //   knots_checked<OFF>      the knots of one axis (widths: OFF, bin sizes min_bw / bw_scale; heights: OFF + K, ...)
   //   evaluate<OFF, INV>      bin search, the two derivatives, the rational-quadratic map and its log|J|
   // The two wave-uniform "redo" branches (below) end a basic block each: three straight-line pieces per evaluation.
-  template <int OFF, int NV, bool PRESCALED = false>
+  template <int OFF, int NV>
   __device__ __forceinline__ static void knots_checked(const float (&v)[NV], const NsaTransformConsts& c, float mn,
                                                        float sc, float (&cum)[K + 1]) {
     const float B = c.tail_bound;
@@ -409,15 +401,15 @@ struct NsaRQ {
     // longer, not across the other axis - checked together they cost the two-tiles instance two spilled registers;
     // the branches are wave-uniform and practically never taken)
 #ifdef NSA_SHIFTED_SOFTMAX  // A/B builds (scripts/build_variant.sh): the max-subtracted softmax of rounds 1-4
-    knots<OFF, NV, true, PRESCALED>(v, c.inv_logit_div, mn, sc, c.two_b, B, cum, c.k_real);
+    knots<OFF, NV, true>(v, c.inv_logit_div, mn, sc, c.two_b, B, cum, c.k_real);
 #else
     // A row's result must not depend on the rows that share its wave (the same rows come back bit for bit from any
     // launch geometry and from nsa_populate_replay): the branch is taken by the wave, the repeat is KEPT per lane.
-    const float sw = knots<OFF, NV, false, PRESCALED>(v, c.inv_logit_div, mn, sc, c.two_b, B, cum, c.k_real);
+    const float sw = knots<OFF, NV, false>(v, c.inv_logit_div, mn, sc, c.two_b, B, cum, c.k_real);
     const bool redo = !sum_in_range(sw);
     if (__builtin_expect(__any(redo), 0)) {
       float alt[K + 1];
-      knots<OFF, NV, true, PRESCALED>(v, c.inv_logit_div, mn, sc, c.two_b, B, alt, c.k_real);
+      knots<OFF, NV, true>(v, c.inv_logit_div, mn, sc, c.two_b, B, alt, c.k_real);
 #pragma unroll
       for (int i = 0; i <= K; ++i) cum[i] = redo ? alt[i] : cum[i];
     }
@@ -491,14 +483,14 @@ struct NsaRQ {
     ld = inside ? lad : 0.0f;
   }
 
-  template <int P, int OFF, bool INV, int NV, bool PRESCALED = false>
+  template <int P, int OFF, bool INV, int NV>
   __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
                                                const NsaTransformConsts& c, float& y, float& ld,
                                                bool& bad) {
 #pragma clang fp contract(off)
     float cw[K + 1], ch[K + 1];
-    knots_checked<OFF, NV, PRESCALED>(v, c, c.min_bw, c.bw_scale, cw);
-    knots_checked<OFF + K, NV, PRESCALED>(v, c, c.min_bh, c.bh_scale, ch);
+    knots_checked<OFF, NV>(v, c, c.min_bw, c.bw_scale, cw);
+    knots_checked<OFF + K, NV>(v, c, c.min_bh, c.bh_scale, ch);
     evaluate<OFF, INV, NV>(v, x, c, cw, ch, y, ld, bad);
   }
 };
@@ -526,7 +518,7 @@ struct NsaAffine {
   static constexpr bool LD_FACTOR = true;  // `ld` is the Jacobian FACTOR of the feature, not its logarithm
   struct State {};
 
-  template <int P, int OFF, bool INV, int NV, bool PRESCALED = false>
+  template <int P, int OFF, bool INV, int NV>
   __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
                                                const NsaTransformConsts& c, float& y, float& ld,
                                                bool& bad) {
@@ -558,7 +550,7 @@ struct NsaAdditive {
   static constexpr bool LD_FACTOR = false;
   struct State {};
 
-  template <int P, int OFF, bool INV, int NV, bool PRESCALED = false>
+  template <int P, int OFF, bool INV, int NV>
   __device__ __forceinline__ static void phase(State&, const float (&v)[NV], float x,
                                                const NsaTransformConsts&, float& y, float& ld,
                                                bool& bad) {

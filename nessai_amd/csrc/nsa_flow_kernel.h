@@ -216,11 +216,15 @@ struct NsaLaunch {
 //                par = {lo, hi, upper ? 1 : 0, -, offset}
 //   MINUS_ONE_ONE  the same parameter while no edge is detected: x = (hi - lo) * ((x' + 1) / 2) + lo + offset
 //                (utils/rescaling.py:84-105)
+// 7 / 8 (round 6): an angle as a point of the plane (src/nessai/reparameterisations/angle.py:153-179) - column i
+// holds the x coordinate and gives the angle atan2(y, x) [mod 2 pi] / scale (par = {scale, modulo?}), column i + 1
+// holds the y coordinate and gives the auxiliary radius, whose -log is the row's share of the Jacobian
 enum { NSA_RP_SCALE_SHIFT = 0, NSA_RP_NULL = 1, NSA_RP_TO_BOUNDS = 2, NSA_RP_TO_BOUNDS_LOGIT = 3,
-       NSA_RP_TO_BOUNDS_LOG = 4, NSA_RP_INVERT = 5, NSA_RP_MINUS_ONE_ONE = 6 };
+       NSA_RP_TO_BOUNDS_LOG = 4, NSA_RP_INVERT = 5, NSA_RP_MINUS_ONE_ONE = 6, NSA_RP_ANGLE = 7,
+       NSA_RP_ANGLE_RADIAL = 8 };
 
 enum { NSA_PRIOR_UNIFORM = 0, NSA_PRIOR_SINE = 1, NSA_PRIOR_COSINE = 2, NSA_PRIOR_POWER_LAW = 3,
-       NSA_PRIOR_GAUSSIAN = 4 };
+       NSA_PRIOR_GAUSSIAN = 4, NSA_PRIOR_CHI = 5 };
 
 // log density of one separable prior term; par = {a, b, log normalisation}
 __device__ __forceinline__ double nsa_log_prior_term(int kind, double x, const double* par) {
@@ -229,6 +233,9 @@ __device__ __forceinline__ double nsa_log_prior_term(int kind, double x, const d
     case NSA_PRIOR_COSINE: return log(cos(x)) + par[2];
     case NSA_PRIOR_POWER_LAW: return par[0] * log(x) + par[2];
     case NSA_PRIOR_GAUSSIAN: { const double t = (x - par[0]) / par[1]; return -0.5 * t * t + par[2]; }
+    // chi distribution with par[0] + 1 degrees of freedom (the auxiliary radius of an angle: 2; angle.py:181-183;
+    // scipy: log(2) (1 - k/2) - gammaln(k/2) + (k - 1) log x - x^2 / 2, the constants in par[2])
+    case NSA_PRIOR_CHI: return par[0] * log(x) - 0.5 * x * x + par[2];
     default: return par[2];  // uniform: -log(width)
   }
 }
@@ -855,12 +862,7 @@ __device__ __forceinline__ void nsa_run_phase(typename TP::State (&st)[TP::FPC],
   if constexpr (P == 0) x_in = xrow[c];
   float y = 0.0f, ld = 0.0f;
   bool bad = false;
-  // (PRESCALED: the flow image carries the spline's logit scale inside the last layer - nsa_device.h, NsaRQ::knots)
-#ifdef NSA_NO_PRESCALE  // timing-only A/B build (scripts/build_variant.sh): the multiplication back in, on scaled logits - wrong rows
-  TP::template phase<P, Q * TP::NP, INV, NV, false>(st[Q], v, x_in, tc, y, ld, bad);
-#else
-  TP::template phase<P, Q * TP::NP, INV, NV, true>(st[Q], v, x_in, tc, y, ld, bad);
-#endif
+  TP::template phase<P, Q * TP::NP, INV, NV>(st[Q], v, x_in, tc, y, ld, bad);
   if constexpr (P == TP::NPH - 1) {
     xrow[c] = y;
     if constexpr (TP::LD_FACTOR) fac[Q] = live ? ld : 1.0f;
@@ -1950,6 +1952,16 @@ __global__ void __launch_bounds__(HT >= NSA_WIDE_HT ? 256 : (OCC == 4 ? 1024 : (
           const double* c = e.rp_par + 5 * i;
           xv = (c[1] - c[0]) * ((xp + 1.0) / 2.0) + c[0];
           xv = xv + c[4];
+        } else if (kind == NSA_RP_ANGLE) {
+          const double* c = e.rp_par + 5 * i;
+          const double cy = (double)xrow[out_tab[i + 1]];
+          double a = atan2(cy, xp);
+          if (c[1] != 0.0 && a < 0.0) a = a + 6.283185307179586;  // numpy's % (2 pi) of a value in [-pi, pi]
+          xv = a / c[0];
+        } else if (kind == NSA_RP_ANGLE_RADIAL) {
+          const double cx = (double)xrow[out_tab[i - 1]];
+          xv = sqrt(cx * cx + xp * xp);
+          log_j_row -= log(xv);
         } else {
           const double* c = e.rp_par + 5 * i;
           double u = xp;

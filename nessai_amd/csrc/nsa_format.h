@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define NSA_MAGIC 0x3141534e /* "NSA1" */
-#define NSA_VERSION 11
+#define NSA_VERSION 10
 
 // header word indices
 enum {
@@ -42,9 +42,7 @@ enum {
   NSA_H_MIN_BH = 21,       // float min_bin_height
   NSA_H_MIN_D = 22,        // float min_derivative
   NSA_H_EDGE_RAW = 23,     // float: log(exp(1-min_derivative)-1) rounded to f32
-  NSA_H_LOGIT_DIV = 24,    // float: sqrt(hidden_features) or 1.0 (no scaling).  Format 11: the scale log2(e) / this is
-                           // FOLDED into the last conditioner layer's rows (and biases) of the spline's width / height
-                           // logits by the packer; nsa_repack_image applies it to the map entries flagged 0x10 / 0x20
+  NSA_H_LOGIT_DIV = 24,    // float: sqrt(hidden_features) or 1.0 (no scaling)
   NSA_H_ACT = 25,          // NSA_ACT_*
   NSA_H_NET = 26,          // NSA_NET_*
   NSA_H_NLAYERS = 27,      // residual blocks (resnet) / hidden layers (mlp)

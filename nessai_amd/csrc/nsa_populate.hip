@@ -545,18 +545,13 @@ __global__ void __launch_bounds__(256) nsa_repack_kernel(long long n, const int*
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const int i0 = e0[k], i1 = e1[k];
-  float a = i0 >= 0 ? params[i0] : 0.0f;
-  const int kf = kind[k], kd = kf & 0x0f;
-  // format 11: entries flagged 0x10 (low halfword / the float32 word) / 0x20 (high halfword) carry the spline's logit
-  // scale log2(e) / header[NSA_H_LOGIT_DIV], in float32 like pack.py (logit_fold_scale); the header is never rewritten
-  const float k2 = (1.0f / __uint_as_float(image[NSA_H_LOGIT_DIV])) * 1.4426950408889634f;
-  if (kf & 0x10) a = a * k2;
+  const float a = i0 >= 0 ? params[i0] : 0.0f;
+  const int kd = kind[k];
   if (kd == 1) {
     image[pos[k]] = __float_as_uint(a);
     return;
   }
-  float b = i1 >= 0 ? params[i1] : 0.0f;
-  if (kf & 0x20) b = b * k2;
+  const float b = i1 >= 0 ? params[i1] : 0.0f;
   uint32_t ah, al, bh, bl;
   nsa_split16_host_exact(a, precision, ah, al);
   nsa_split16_host_exact(b, precision, bh, bl);

@@ -31,7 +31,7 @@ import math
 import numpy as np
 
 MAGIC = 0x3141534E
-VERSION = 11
+VERSION = 10
 HEADER_WORDS = 40
 STAGE_ALIGN = 32   # words: stage blobs are padded to whole 128-byte lines
 PIECE_WORDS = 256  # words moved by one global_load_lds of a wave (64 lanes x 16 bytes)
@@ -73,21 +73,6 @@ EXACT_BINS = (4, 8, 10, 16)
 GENERIC_BINS = 16
 #: bias of a padded width / height logit: its exponential is 0.0, it takes no part in the softmax
 PAD_LOGIT = -1.0e30
-LOG2E = np.float32(1.4426950408889634)
-
-
-def logit_fold_scale(desc):
-    """Format 11: what the packer multiplies the rows (and biases) of the last conditioner layer that emit a spline's
-    width / height logits by - ``log2(e) / sqrt(hidden_features)`` in float32, exactly the factor the kernel applied
-    per logit before (``csrc/nsa_device.h``, ``NsaRQ::knots``: the accumulators are now the arguments of ``v_exp_f32``).
-    nflows divides those logits by ``sqrt(hidden_features)`` when the conditioner has ``hidden_features``."""
-    div = np.float32(math.sqrt(desc["hidden"]) if desc.get("scale_logits", True) else 1.0)
-    return np.float32(np.float32(1.0) / div) * LOG2E
-
-
-#: flags of a repack-map entry's ``kind`` byte: the parameter in the low / high halfword (or the float32 word) is one
-#: the packer scales by ``logit_fold_scale`` - ``nsa_repack_image`` reads the factor out of the image's own header
-REPACK_SCALE_E0, REPACK_SCALE_E1 = 0x10, 0x20
 
 
 def kernel_bins(bins):
@@ -393,17 +378,6 @@ class _CouplingBlobs:
 
         wf, bf = layers[-1]
         assert wf.shape[1] == hidden
-        if desc["transform"] == "rq" and not desc.get("_index"):
-            # format 11: the spline's logit scale folded into the rows that emit width / height logits (row of
-            # parameter p of feature m: m n_real + p; widths p < K, heights p < 2 K).  In float32, like the
-            # device-side rebuild of the image (nsa_repack_image: flagged map entries).  Index images
-            # (repack_map) are packed unscaled - their "weights" are parameter indices.
-            k_fold = int(desc.get("bins", 0))
-            n_fold = 3 * k_fold - 1
-            rows = (np.arange(wf.shape[0]) % n_fold) < 2 * k_fold
-            scale = np.where(rows, logit_fold_scale(desc), np.float32(1.0)).astype(np.float32)
-            wf = (np.asarray(wf, dtype=np.float32) * scale[:, None]).astype(np.float32)
-            bf = (np.asarray(bf, dtype=np.float32) * scale).astype(np.float32)
         self.chunks = []  # (feature slots [2*fpc] (index into transform_idx or -1), bias, [W of sub-stage 0, 1, ...])
         # a spline flow on the generic instance: the kernel's parameter slot p of a feature (3 groups of
         # k_kern: widths, heights, derivatives) is the flow's parameter `real` or a padded slot with a constant
@@ -819,7 +793,6 @@ def repack_map(index_desc, precision):
     if precision not in PRECISIONS:
         raise ValueError(f"unknown precision {precision!r}")
     extra = {"_split16": _split_index} if precision in SPLIT16 else {}
-    extra["_index"] = True  # (no logit fold: the "weights" are indices)
     desc_a = index_desc(_INDEX_A)
     # the indices travel as float32 VALUES through the packer: exact below 2^24 only (a bigger flow keeps
     # the host pack - the caller treats ValueError as "no device map")
@@ -832,25 +805,6 @@ def repack_map(index_desc, precision):
     if img_a.shape != img_b.shape:
         raise RuntimeError("index images of different sizes")
     changed = img_a != img_b
-    # parameters the packer scales (format 11): the rows and biases of every coupling's last layer that emit a
-    # spline's width / height logits
-    n_index = int(largest) + 2
-    scaled = np.zeros(n_index + 1, dtype=bool)
-    if desc_a.get("transform") == "rq":
-        k_fold = int(desc_a.get("bins", 0))
-        n_fold = 3 * k_fold - 1
-        for tr in desc_a["transforms"]:
-            if tr[0] != "coupling":
-                continue
-            wf_idx, bf_idx = tr[3][-1]
-            rows = (np.arange(np.shape(wf_idx)[0]) % n_fold) < 2 * k_fold
-            for arr in (np.asarray(wf_idx)[rows].reshape(-1), np.asarray(bf_idx)[rows].reshape(-1)):
-                scaled[np.rint(arr.astype(np.float64)).astype(np.int64) - _INDEX_A] = True
-
-    def flags(e0, e1):
-        f0 = np.where(e0 >= 0, scaled[np.clip(e0, 0, n_index)], False)
-        f1 = np.where(e1 >= 0, scaled[np.clip(e1, 0, n_index)], False)
-        return (f0 * REPACK_SCALE_E0 + f1 * REPACK_SCALE_E1).astype(np.uint8)
 
     def f32_index(words):
         return np.rint(words.view(np.float32).astype(np.float64)).astype(np.int64) - _INDEX_A
@@ -858,9 +812,8 @@ def repack_map(index_desc, precision):
     if precision not in SPLIT16:
         pos = np.nonzero(changed)[0]
         e0 = f32_index(img_a[pos])
-        none = np.full(len(pos), -1, np.int64)
-        return (pos.astype(np.int32), e0.astype(np.int32), none.astype(np.int32),
-                np.full(len(pos), REPACK_F32, np.uint8) | flags(e0, none))
+        return (pos.astype(np.int32), e0.astype(np.int32), np.full(len(pos), -1, np.int32),
+                np.full(len(pos), REPACK_F32, np.uint8))
     lo_pos = np.nonzero(changed & ((img_a & 0x80008000) == 0x80008000))[0]  # tagged: the lo-part words
     hi_pos = lo_pos - 256  # [part][64 lanes][4 words]: the hi part of the same elements
     if len(lo_pos) and (hi_pos.min() < 0 or not changed[hi_pos].all()):
@@ -875,11 +828,11 @@ def repack_map(index_desc, precision):
     pair[lo_pos] = True
     f_pos = np.nonzero(changed & ~pair)[0]
     pos = np.concatenate([hi_pos, lo_pos, f_pos])
-    all_e0 = np.concatenate([e0, e0, f32_index(img_a[f_pos])])
-    all_e1 = np.concatenate([e1, e1, np.full(len(f_pos), -1, np.int64)])
-    kind = np.concatenate([np.full(len(hi_pos), REPACK_PAIR_HI, np.uint8), np.full(len(lo_pos), REPACK_PAIR_LO, np.uint8),
-                           np.full(len(f_pos), REPACK_F32, np.uint8)])
-    return (pos.astype(np.int32), all_e0.astype(np.int32), all_e1.astype(np.int32), kind | flags(all_e0, all_e1))
+    return (pos.astype(np.int32),
+            np.concatenate([e0, e0, f32_index(img_a[f_pos])]).astype(np.int32),
+            np.concatenate([e1, e1, np.full(len(f_pos), -1, np.int64)]).astype(np.int32),
+            np.concatenate([np.full(len(hi_pos), REPACK_PAIR_HI, np.uint8), np.full(len(lo_pos), REPACK_PAIR_LO, np.uint8),
+                            np.full(len(f_pos), REPACK_F32, np.uint8)]))
 
 
 def apply_repack_map(image, repack, params, precision):
@@ -890,11 +843,6 @@ def apply_repack_map(image, repack, params, precision):
     a = np.where(e0 >= 0, params[np.maximum(e0, 0)], np.float32(0.0)).astype(np.float32)
     b = np.where(e1 >= 0, params[np.maximum(e1, 0)], np.float32(0.0)).astype(np.float32)
     out = np.array(image, dtype=np.uint32, copy=True)
-    # the logit fold of format 11: flagged entries times log2(e) / header[H_LOGIT_DIV], in float32
-    k2 = np.float32(np.float32(1.0) / out[H_LOGIT_DIV:H_LOGIT_DIV + 1].view(np.float32)[0]) * LOG2E
-    a = np.where(kind & REPACK_SCALE_E0, a * k2, a).astype(np.float32)
-    b = np.where(kind & REPACK_SCALE_E1, b * k2, b).astype(np.float32)
-    kind = kind & 0x0F
     f = kind == REPACK_F32
     out[pos[f]] = a[f].view(np.uint32)
     if precision in SPLIT16:

@@ -247,21 +247,27 @@ class FlowProposal:
     def poolsize(self):
         return int(self._poolsize_scale * self._poolsize)
 
-    @property
-    def dims(self):
-        return len(self.model.names)
-
+    # The columns the device works on.  Without a reparameterisation that changes their number these are the model's
+    # parameters; an angle (reparameterisations/angle.py) adds the column of its auxiliary radius right behind it -
+    # the flow then has `dims` = D' inputs, the draw kernel writes D' output columns, and `x` carries the auxiliary
+    # parameters as the reference's x does (its dtype is built from the reparameterisations' parameters).
     @property
     def names(self):
-        return list(self.model.names)
+        table = getattr(self, "_reparam", None)
+        return list(table.device_names) if table is not None else list(self.model.names)
+
+    @property
+    def dims(self):
+        return len(self.names)
 
     @property
     def prime_parameters(self):
-        return [n + "_prime" for n in self.model.names]
+        table = getattr(self, "_reparam", None)
+        return list(table.prime_names) if table is not None else [n + "_prime" for n in self.model.names]
 
     @property
     def prime_dims(self):
-        return self.dims
+        return len(self.prime_parameters)
 
     # the latent-radius rule's settings under their historical names
     def _latent_rule(self):
@@ -309,7 +315,7 @@ class FlowProposal:
             if getattr(self.model, "reparameterisations", None) is not None:  # base.py:639-640
                 config = self.model.reparameterisations
             self._reparam = ReparameterisationTable(
-                self.names, self.prior_bounds, config, fallback=self.fallback_reparameterisation,
+                list(self.model.names), self.prior_bounds, config, fallback=self.fallback_reparameterisation,
                 rng=self.rng, reverse_order=self.reverse_reparameterisations,
             )
             if self.use_default_reparameterisations:  # base.py:602-603
@@ -348,20 +354,44 @@ class FlowProposal:
             raise ValueError("prior='device' needs model.uniform_prior or model.device_prior")
         self.prior_mode = mode
         self._prior_kind_dev = self._prior_par_dev = None
-        if mode == "device" and not self.map_to_unit_hypercube and not getattr(self.model, "uniform_prior", False):
-            kinds, pars = self.model.device_prior_tables()
-            self._prior_kind_dev = torch.from_numpy(kinds).to(self.device)
-            self._prior_par_dev = torch.from_numpy(pars).to(self.device)
+        aux = self._reparam.has_aux
+        if aux and self.map_to_unit_hypercube:
+            raise NotImplementedError("angle reparameterisations together with map_to_unit_hypercube")
+        if mode == "device" and not self.map_to_unit_hypercube and (
+                aux or not getattr(self.model, "uniform_prior", False)):
+            # per device column: the model's separable term (a uniform box: -log(width) each), and for the auxiliary
+            # radius of an angle its chi(2) density - the reparameterisation's own prior, which the reference adds
+            # to the model's (base.py:1046-1049; angle.py:181-183)
+            if getattr(self.model, "uniform_prior", False):
+                kinds = np.zeros(len(self.model.names), dtype=np.int32)
+                pars = np.array([[0.0, 0.0, -math.log(self.model.bounds[n][1] - self.model.bounds[n][0])]
+                                 for n in self.model.names], dtype=np.float64)
+            else:
+                kinds, pars = self.model.device_prior_tables()
+            if aux:
+                col = {n: i for i, n in enumerate(self.model.names)}
+                k2, p2 = [], []
+                for n in self.names:
+                    if n in col:
+                        k2.append(kinds[col[n]])
+                        p2.append(pars[col[n]])
+                    else:  # chi with 2 degrees of freedom: log r - r^2 / 2
+                        k2.append(5)
+                        p2.append([1.0, 0.0, 0.0])
+                kinds, pars = np.asarray(k2, dtype=np.int32), np.asarray(p2, dtype=np.float64)
+            self._prior_kind_dev = torch.from_numpy(np.ascontiguousarray(kinds)).to(self.device)
+            self._prior_par_dev = torch.from_numpy(np.ascontiguousarray(pars)).to(self.device)
         self._upload_constants()
         spec = getattr(self.model, "device_likelihood", None)
         if self._likelihood_mode == "device" and spec is None:
             raise ValueError("likelihood='device' needs model.device_likelihood")
         self._ll_spec = None
-        if self.map_to_unit_hypercube:
+        if self.map_to_unit_hypercube or aux:
             # the rows of a population are points of the unit hypercube until convert_to_samples maps them back
-            # (a user map, on the host): the device likelihood would see the wrong coordinates
+            # (a user map, on the host) / carry auxiliary columns: the device likelihood would see the wrong coordinates
             if self._likelihood_mode == "device":
-                raise ValueError("likelihood='device' is not available with map_to_unit_hypercube=True")
+                raise ValueError("likelihood='device' is not available with map_to_unit_hypercube=True or with "
+                                 "reparameterisations that add auxiliary parameters (angles)")
             spec = None
         if spec is not None and self._likelihood_mode != "host" and 2 <= self.dims <= 129:
             f64 = dict(dtype=torch.float64, device=self.device)
@@ -443,7 +473,7 @@ class FlowProposal:
 
     def set_rescaling_constants(self, shift, scale):
         """Set mu / sigma of the z-score parameters directly (arrays over ``model.names``)."""
-        col = {n: i for i, n in enumerate(self.names)}
+        col = {n: i for i, n in enumerate(self.model.names)}
         for g in self._reparam.groups:
             if g.kind != "scale_shift":
                 continue
@@ -467,8 +497,9 @@ class FlowProposal:
             self._lower_dev = torch.zeros(self.dims, **f64)
             self._upper_dev = torch.full((self.dims,), float(np.nextafter(1.0, 0.0)), **f64)
         else:
-            self._lower_dev = torch.tensor(self.model.lower_bounds, **f64)
-            self._upper_dev = torch.tensor(self.model.upper_bounds, **f64)
+            lo, hi = self._reparam.device_bounds(self.model.lower_bounds, self.model.upper_bounds)
+            self._lower_dev = torch.tensor(lo, **f64)
+            self._upper_dev = torch.tensor(hi, **f64)
         self._log_j_rescale = log_j
         if self._reparam.all_scale_shift:
             self._rp_kind_dev = self._rp_par_dev = None
@@ -639,7 +670,12 @@ class FlowProposal:
         return x, log_q_h[keep]
 
     def log_prior(self, x):
-        return self.model.batch_evaluate_log_prior(x)
+        """The model's log-prior plus the reparameterisations' own (``base.py:1032-1051``: the auxiliary radius of an
+        angle)."""
+        log_p = self.model.batch_evaluate_log_prior(x)
+        if getattr(self, "_reparam", None) is not None and self._reparam.has_aux:
+            log_p = log_p + self._reparam.log_prior(x)
+        return log_p
 
     def _population_log_prior(self, x):
         """Log-prior of candidate rows in the space the population lives in (``base.py:1089-1092``)."""
@@ -656,6 +692,12 @@ class FlowProposal:
         """Map back from the unit hypercube if the population lives there, attach ``logP`` (``base.py:1100-1128``)."""
         x = copy_points(x)  # (one memcpy of the records; numpy copies a structured array field by field)
         x = self._from_cube(x)
+        if getattr(self, "_reparam", None) is not None and self._reparam.has_aux:
+            # auxiliary parameters stay behind (base.py:1124-1126: x[model.names + non-sampling parameters])
+            kept = np.empty(x.size, dtype=get_dtype(list(self.model.names)))
+            for f in kept.dtype.names:
+                kept[f] = x[f]
+            x = kept
         x["logP"] = self.model.batch_evaluate_log_prior(x)
         return x
 
@@ -784,7 +826,7 @@ class FlowProposal:
         if self.map_to_unit_hypercube:
             return 0.0  # log 1: the unit hypercube's own prior (model.py:593-601)
         log_p = np.float64(0.0)
-        for n in self.names:
+        for n in self.model.names:
             lo, hi = self.model.bounds[n]
             log_p -= np.log(hi - lo)
         return float(log_p)

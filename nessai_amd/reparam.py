@@ -11,7 +11,8 @@ registry name                         map (x -> x')
                                       (``rescale.py:119-312``)
 ``scaleandshift`` ``scale`` ``rescale``  ``ScaleAndShift`` / ``Rescale`` with fixed constants
 ``default`` ``rescaletobounds``        ``RescaleToBounds`` to [-1, 1], bounds updated from the live
-``rescale-to-bounds``                  points (``rescale.py:321-731``)
+``rescale-to-bounds`` ``angle-sine``   points (``rescale.py:321-731``)
+``angle-cosine``
 ``offset``                            the same with the prior mid-point subtracted first
 ``logit``                             ``RescaleToBounds`` to [0, 1] with the prior bounds, then
                                       ``logit`` (``utils/rescaling.py:290-337``)
@@ -22,12 +23,22 @@ registry name                         map (x -> x')
                                       measured from that edge and mirrored about it - half of the points
                                       flipped (``split``) or every point doubled (``duplicate``)
 ``null`` ``none``                     ``NullReparameterisation`` (``null.py``)
+``angle`` ``angle-2pi`` ``angle-pi``   ``Angle`` (``angle.py:17-183``): the angle times ``scale`` (1, 1, 2; ``periodic``:
+``periodic``                          2 pi / prior range) becomes a point ``r (cos, sin)`` of the plane, ``r`` an
+                                      AUXILIARY radius drawn from chi(2) (the proposal's generator through scipy, as the
+                                      reference draws it); back: ``atan2`` (modulo 2 pi when the prior range starts at 0)
+                                      / ``scale`` and the radius, which stays in x and carries a chi(2) prior
 ====================================  =========================================================
+
+An angle changes the number of columns (round 6): x' has TWO columns for it (``<name>_x``, ``<name>_y``), x gains
+``<name>_radial``, the flow has D' = D + (number of angles) inputs and the draw kernel writes D' output columns - the
+angle where the x coordinate was, the radius where the y coordinate was (``device_names``).
 
 The mirrored FORWARD map changes the number of rows (training data, host side, numpy as in the
 reference); its INVERSE - fold ``|x'|`` back, undo the [0, 1] map - is one-to-one per column and
-runs in the draw kernel's epilogue like the others.  Angles, dequantisation and user-defined
-classes couple parameters or need their own kernels and raise ``NotImplementedError`` here.
+runs in the draw kernel's epilogue like the others.  Angle PAIRS (sky positions: three Cartesian
+coordinates for two angles), ``to-cartesian``, an angle with a radial parameter of the model, dequantisation and
+user-defined classes raise ``NotImplementedError`` here.
 
 The configuration forms are the reference's (``reparameterisations/utils.py:120-268``):
 ``None`` | ``"name"`` | ``{parameter: "name"}`` | ``{parameter: {"reparameterisation": "name",
@@ -48,6 +59,9 @@ from .livepoint import empty_structured_array
 # kinds of nsa_populate_draw's rp_kind table (nsa_flow_kernel.h NSA_RP_*)
 RP_SCALE_SHIFT, RP_NULL, RP_TO_BOUNDS, RP_TO_BOUNDS_LOGIT, RP_TO_BOUNDS_LOG = 0, 1, 2, 3, 4
 RP_INVERT, RP_MINUS_ONE_ONE = 5, 6  # boundary inversion: folded [0, 1] map about an edge / plain [-1, 1] map
+# an angle as a point of the plane (reparameterisations/angle.py, round 6): the x' column of its x coordinate (-> the
+# angle) and, right behind it, the column of its y coordinate (-> the auxiliary radius)
+RP_ANGLE, RP_ANGLE_RADIAL = 7, 8
 
 _KNOWN = {
     "z-score": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
@@ -59,6 +73,10 @@ _KNOWN = {
     "default": ("to_bounds", {}),
     "rescaletobounds": ("to_bounds", {}),
     "rescale-to-bounds": ("to_bounds", {}),
+    # (the reference registers these two names for the same class: reparameterisations/__init__.py:168-173 - the
+    # bounded inclination / declination angles of the GW parameter sets)
+    "angle-sine": ("to_bounds", {}),
+    "angle-cosine": ("to_bounds", {}),
     "offset": ("to_bounds", dict(offset=True)),
     "inversion": ("to_bounds", dict(detect_edges=True, boundary_inversion=True, inversion_type="split")),
     "inversion-duplicate": ("to_bounds", dict(detect_edges=True, boundary_inversion=True, inversion_type="duplicate")),
@@ -66,6 +84,11 @@ _KNOWN = {
     "log-rescale": ("to_bounds", dict(rescale_bounds=[0.0, 1.0], update_bounds=False, post_rescaling="log")),
     "null": ("null", {}),
     "none": ("null", {}),
+    # Angle with an auxiliary chi(2)-distributed radius (reparameterisations/__init__.py:158-177, angle.py:17-183)
+    "angle": ("angle", dict(scale=1.0)),
+    "angle-pi": ("angle", dict(scale=2.0)),
+    "angle-2pi": ("angle", dict(scale=1.0)),
+    "periodic": ("angle", dict(scale=None)),
 }
 _NON_SAMPLING = ("logP", "logL", "it")
 
@@ -219,6 +242,21 @@ class _Group:
             self.set_bounds()
         elif kind == "null":
             self.update_enabled = False
+        elif kind == "angle":
+            # ONE angle -> Cartesian coordinates with an auxiliary radius drawn from chi(2) (angle.py:57-71).  The
+            # reference's two-parameter form (an angle and a radial parameter OF THE MODEL) is not built.
+            if len(self.parameters) != 1:
+                raise NotImplementedError(
+                    f"{name}: one angle per entry (the angle + radial-parameter form of the reference's Angle couples "
+                    f"two model parameters and has no device map); got {self.parameters}")
+            p = self.parameters[0]
+            if p not in prior_bounds or not np.all(np.isfinite(prior_bounds[p])):
+                raise RuntimeError(f"{name} requires finite prior bounds, missing for ['{p}']")
+            self.prior_bounds = {p: np.asarray(prior_bounds[p], dtype=np.float64)}
+            scale = kw.pop("scale", 1.0)
+            self.angle_scale = float(2.0 * np.pi / np.ptp(self.prior_bounds[p])) if scale is None else float(scale)
+            self.zero_bound = bool(self.prior_bounds[p][0] == 0)  # angle.py:79-82: modulo 2 pi on the way back
+            self.update_enabled = False
         if kw:
             raise TypeError(f"Unknown arguments for reparameterisation {name}: {sorted(kw)}")
 
@@ -304,8 +342,40 @@ class _Group:
         return x, x_prime, log_j
 
     # x -> x'
+    @property
+    def prime_names(self):
+        """The x' columns of the group, in order."""
+        if self.kind == "angle":
+            return [self.parameters[0] + "_x", self.parameters[0] + "_y"]
+        return [p + "_prime" for p in self.parameters]
+
+    @property
+    def aux_names(self):
+        """Auxiliary parameters the inverse map leaves in x (the radius of an angle: angle.py:61-63)."""
+        return [self.parameters[0] + "_radial"] if self.kind == "angle" else []
+
+    def log_prior(self, x):
+        """Prior of the auxiliary parameters (angle.py:181-183: chi(2) on the radius); 0 for the other maps."""
+        if self.kind != "angle":
+            return 0.0
+        from scipy import stats
+
+        return stats.chi(2).logpdf(x[self.aux_names[0]])
+
     def forward(self, x, x_prime, log_j, compute_radius=False, test=None):
         """Returns ``(x, x_prime, log_j)``: a duplicating boundary inversion replaces all three."""
+        if self.kind == "angle":  # angle.py:134-151: the radius is drawn from the proposal's generator
+            from scipy import stats
+
+            if self.rng is None:
+                raise RuntimeError("the angle reparameterisation needs the proposal's random generator")
+            p = self.parameters[0]
+            angle = x[p] * self.angle_scale
+            r = stats.chi(2).rvs(size=x.size, random_state=self.rng)
+            x_prime[p + "_x"] = r * np.cos(angle)
+            x_prime[p + "_y"] = r * np.sin(angle)
+            log_j += np.log(r)
+            return x, x_prime, log_j
         for p in self.parameters:
             pp = p + "_prime"
             if self.kind == "to_bounds" and self.inversion and p in self.inversion:
@@ -336,6 +406,18 @@ class _Group:
 
     # x' -> x
     def inverse(self, x_prime, x, log_j):
+        if self.kind == "angle":  # angle.py:153-179
+            p = self.parameters[0]
+            cx, cy = x_prime[p + "_x"], x_prime[p + "_y"]
+            radial = np.sqrt(cx ** 2 + cy ** 2)
+            if self.zero_bound:
+                angle = np.arctan2(cy, cx) % (2.0 * np.pi) / self.angle_scale
+            else:
+                angle = np.arctan2(cy, cx) / self.angle_scale
+            log_j -= np.log(radial)
+            x[p + "_radial"] = radial
+            x[p] = angle
+            return log_j
         if self.kind == "to_bounds":
             params = reversed(self.parameters)  # rescale.py:674-677
         else:
@@ -413,7 +495,6 @@ class ReparameterisationTable:
         #: is summed and in which a boundary inversion meets the groups around it
         self.reverse_order = bool(reverse_order)
         self.names = list(names)
-        self.prime_names = [n + "_prime" for n in self.names]
         bounds = {n: np.asarray(bounds[n], dtype=np.float64) for n in self.names} if bounds else {}
         self.groups = []
         cfg = reparameterisations
@@ -455,6 +536,21 @@ class ReparameterisationTable:
         others = [n for n in self.names if n not in self.parameters]
         if others:
             self._add(fallback, others, bounds, {})
+        # Columns.  x' keeps the order of model.names (an angle: its two Cartesian columns side by side); x gains the
+        # auxiliary parameters (the radius of every angle: angle.py:61-63).  `device_names` is what the D' output
+        # columns of the draw kernel hold: a model parameter per x' column, the auxiliary radius in the column of an
+        # angle's y coordinate.
+        by_param = {g.parameters[0]: g for g in self.groups if g.kind == "angle"}
+        self.prime_names, self.device_names, self.aux_names = [], [], []
+        for n in self.names:
+            if n in by_param:
+                self.prime_names += by_param[n].prime_names
+                self.device_names += [n] + by_param[n].aux_names
+                self.aux_names += by_param[n].aux_names
+            else:
+                self.prime_names.append(n + "_prime")
+                self.device_names.append(n)
+        self.x_names = self.names + self.aux_names
 
     @property
     def to_prime_order(self):
@@ -480,6 +576,20 @@ class ReparameterisationTable:
             return
         defaults.update(kwargs)
         self.groups.append(_Group(name, kind, params, bounds, defaults, rng=self.rng))
+
+    @property
+    def has_aux(self):
+        """A map that changes the number of columns is present (angles)."""
+        return bool(self.aux_names)
+
+    def log_prior(self, x):
+        """Prior of the auxiliary parameters (``combined.py``: the sum over the reparameterisations with
+        ``has_prior``; ``proposal/flowproposal/base.py:1046-1049`` adds it to the model's)."""
+        total = np.zeros(x.size)
+        for g in self.groups:
+            if g.kind == "angle":
+                total = total + g.log_prior(x)
+        return total
 
     @property
     def should_update(self):
@@ -522,7 +632,7 @@ class ReparameterisationTable:
         return x_prime, log_j
 
     def inverse_rescale(self, x_prime):
-        x = empty_structured_array(x_prime.size, names=self.names)
+        x = empty_structured_array(x_prime.size, names=self.x_names)
         log_j = np.zeros(x.size)
         for g in self.from_prime_order:
             log_j = g.inverse(x_prime, x, log_j)
@@ -536,24 +646,36 @@ class ReparameterisationTable:
     def all_scale_shift(self):
         return all(g.kind == "scale_shift" for g in self.groups)
 
+    def device_bounds(self, lower, upper):
+        """Per device column: the model's bounds of its parameter; [0, inf) for an auxiliary radius."""
+        lo = dict(zip(self.names, lower))
+        hi = dict(zip(self.names, upper))
+        return (np.array([lo.get(n, 0.0) for n in self.device_names], dtype=np.float64),
+                np.array([hi.get(n, np.inf) for n in self.device_names], dtype=np.float64))
+
     def device_tables(self):
         """(kind int32[D], par float64[D,5], scale[D], shift[D], constant log|J|).
 
         The constant is the row-independent part of ``inverse_rescale``'s log-Jacobian,
         accumulated in the same order; the sigmoid terms are added per row by the kernel.
         """
-        D = len(self.names)
+        D = len(self.device_names)
         kind = np.zeros(D, dtype=np.int32)
         par = np.zeros((D, 5), dtype=np.float64)
         scale = np.ones(D)
         shift = np.zeros(D)
-        col = {n: i for i, n in enumerate(self.names)}
+        col = {n: i for i, n in enumerate(self.device_names)}
         log_j = np.float64(0.0)
         for g in self.from_prime_order:
             params = list(reversed(g.parameters)) if g.kind == "to_bounds" else g.parameters
             for p in params:
                 i = col[p]
-                if g.kind == "null":
+                if g.kind == "angle":
+                    # column i: the x coordinate -> the angle, par = {scale, modulo 2 pi?}; column i + 1: the y
+                    # coordinate -> the radius (and the row's -log(radius) of the Jacobian)
+                    kind[i], kind[i + 1] = RP_ANGLE, RP_ANGLE_RADIAL
+                    par[i] = [g.angle_scale, 1.0 if g.zero_bound else 0.0, 0.0, 0.0, 0.0]
+                elif g.kind == "null":
                     kind[i] = RP_NULL
                 elif g.kind == "scale_shift":
                     kind[i] = RP_SCALE_SHIFT

@@ -317,11 +317,8 @@ class Emulator:
             if KK != K:  # what the padded slots must hold for the kernel's arithmetic (csrc/nsa_device.h, NsaRQ<16, true>)
                 assert (params[:, K:KK] == P.PAD_LOGIT).all() and (params[:, KK + K : 2 * KK] == P.PAD_LOGIT).all()
                 assert (params[:, 2 * KK + K - 1] == _f32(img[P.H_EDGE_RAW])).all()
-            # format 11: the image's last layers emit the width / height logits times log2(e) / div (pack.py,
-            # logit_fold_scale) - the kernel feeds them to v_exp_f32 as they are; the restated spline wants u / div
-            del div
-            uw = params[:, None, :K] / float(P.LOG2E)
-            uh = params[:, None, KK : KK + K] / float(P.LOG2E)
+            uw = params[:, None, :K] / div
+            uh = params[:, None, KK : KK + K] / div
             ud = params[:, None, 2 * KK : 2 * KK + K - 1]
             y, ld = splines.unconstrained_rational_quadratic_spline(
                 x[:, None], uw, uh, ud, inverse=inverse, tails="linear",

@@ -33,7 +33,7 @@ def test_binding_covers_every_declared_symbol():
 
 def test_version_and_instance_query():
     L = lib.load()
-    assert L.nsa_version() == pack.VERSION == 11
+    assert L.nsa_version() == pack.VERSION == 10
     assert L.nsa_flow_supported(2, 1, 8) == 1  # C3: H=64, RQ, 8 bins
     assert L.nsa_flow_supported(1, 2, 0) == 1  # C2: H=32, affine
     assert L.nsa_flow_supported(2, 1, 7) == 1 and L.nsa_flow_generic_bins(2, 7) == 1  # the generic spline instance
