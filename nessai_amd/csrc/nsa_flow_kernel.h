@@ -221,7 +221,7 @@ struct NsaLaunch {
 // holds the y coordinate and gives the auxiliary radius, whose -log is the row's share of the Jacobian
 enum { NSA_RP_SCALE_SHIFT = 0, NSA_RP_NULL = 1, NSA_RP_TO_BOUNDS = 2, NSA_RP_TO_BOUNDS_LOGIT = 3,
        NSA_RP_TO_BOUNDS_LOG = 4, NSA_RP_INVERT = 5, NSA_RP_MINUS_ONE_ONE = 6, NSA_RP_ANGLE = 7,
-       NSA_RP_ANGLE_RADIAL = 8 };
+       NSA_RP_ANGLE_RADIAL = 8, NSA_RP_PAIR_H = 9, NSA_RP_PAIR_V = 10, NSA_RP_PAIR_R = 11 };
 
 enum { NSA_PRIOR_UNIFORM = 0, NSA_PRIOR_SINE = 1, NSA_PRIOR_COSINE = 2, NSA_PRIOR_POWER_LAW = 3,
        NSA_PRIOR_GAUSSIAN = 4, NSA_PRIOR_CHI = 5 };
@@ -1962,6 +1962,25 @@ __global__ void __launch_bounds__(HT >= NSA_WIDE_HT ? 256 : (OCC == 4 ? 1024 : (
           const double cx = (double)xrow[out_tab[i - 1]];
           xv = sqrt(cx * cx + xp * xp);
           log_j_row -= log(xv);
+        } else if (kind == NSA_RP_PAIR_H) {
+          // a direction from a point of space (the reference's AnglePair, angle.py:434-507): columns i, i + 1, i + 2
+          // hold x, y, z; par = {modulo 2 pi?, ra-dec?}
+          const double* c = e.rp_par + 5 * i;
+          const double cy = (double)xrow[out_tab[i + 1]];
+          xv = atan2(cy, xp);
+          if (c[0] != 0.0 && xv < 0.0) xv = xv + 6.283185307179586;
+        } else if (kind == NSA_RP_PAIR_V) {
+          const double* c = e.rp_par + 5 * i;
+          const double cx = (double)xrow[out_tab[i - 1]];
+          const double cz = (double)xrow[out_tab[i + 1]];
+          const double rho = sqrt(cx * cx + xp * xp);
+          if (c[1] != 0.0) { xv = atan2(cz, rho); log_j_row -= log(cos(xv)); }   // declination in [-pi/2, pi/2]
+          else             { xv = atan2(rho, cz); log_j_row -= log(sin(xv)); }   // zenith in [0, pi]
+        } else if (kind == NSA_RP_PAIR_R) {
+          const double cx = (double)xrow[out_tab[i - 2]];
+          const double cy = (double)xrow[out_tab[i - 1]];
+          xv = sqrt(cx * cx + cy * cy + xp * xp);
+          log_j_row -= 2.0 * log(xv);
         } else {
           const double* c = e.rp_par + 5 * i;
           double u = xp;

@@ -375,9 +375,10 @@ class FlowProposal:
                     if n in col:
                         k2.append(kinds[col[n]])
                         p2.append(pars[col[n]])
-                    else:  # chi with 2 degrees of freedom: log r - r^2 / 2
+                    else:  # chi with k degrees of freedom: (k - 1) log r - r^2 / 2 - (k / 2 - 1) log 2 - lgamma(k / 2)
+                        k = self._reparam.aux_dof[n]
                         k2.append(5)
-                        p2.append([1.0, 0.0, 0.0])
+                        p2.append([k - 1.0, 0.0, -(0.5 * k - 1.0) * math.log(2.0) - math.lgamma(0.5 * k)])
                 kinds, pars = np.asarray(k2, dtype=np.int32), np.asarray(p2, dtype=np.float64)
             self._prior_kind_dev = torch.from_numpy(np.ascontiguousarray(kinds)).to(self.device)
             self._prior_par_dev = torch.from_numpy(np.ascontiguousarray(pars)).to(self.device)

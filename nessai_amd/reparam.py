@@ -28,6 +28,9 @@ registry name                         map (x -> x')
                                       AUXILIARY radius drawn from chi(2) (the proposal's generator through scipy, as the
                                       reference draws it); back: ``atan2`` (modulo 2 pi when the prior range starts at 0)
                                       / ``scale`` and the radius, which stays in x and carries a chi(2) prior
+``angle-pair``                        ``AnglePair`` (``angle.py:186-538``): two angles -> ``r`` times the unit vector they
+                                      point along, ``r`` an auxiliary radius from chi(3); conventions ``ra-dec``
+                                      (vertical angle on [-pi/2, pi/2]) and ``az-zen`` ([0, pi]) found from the bounds
 ====================================  =========================================================
 
 An angle changes the number of columns (round 6): x' has TWO columns for it (``<name>_x``, ``<name>_y``), x gains
@@ -36,9 +39,14 @@ angle where the x coordinate was, the radius where the y coordinate was (``devic
 
 The mirrored FORWARD map changes the number of rows (training data, host side, numpy as in the
 reference); its INVERSE - fold ``|x'|`` back, undo the [0, 1] map - is one-to-one per column and
-runs in the draw kernel's epilogue like the others.  Angle PAIRS (sky positions: three Cartesian
-coordinates for two angles), ``to-cartesian``, an angle with a radial parameter of the model, dequantisation and
-user-defined classes raise ``NotImplementedError`` here.
+runs in the draw kernel's epilogue like the others.
+
+A PAIR of angles (``angle-pair``, angle.py:186-538: a direction - right ascension / declination or azimuth / zenith)
+becomes a point of space: x' has THREE columns (``<h>_<v>_x``, ``_y``, ``_z``) where the pair's first parameter sat,
+x gains ``<h>_<v>_radial`` with a chi(3) prior, and the device columns are (horizontal, vertical, radius).
+
+``to-cartesian``, an angle or a pair with a radial parameter of the model, dequantisation and user-defined classes
+raise ``NotImplementedError`` here.
 
 The configuration forms are the reference's (``reparameterisations/utils.py:120-268``):
 ``None`` | ``"name"`` | ``{parameter: "name"}`` | ``{parameter: {"reparameterisation": "name",
@@ -62,6 +70,9 @@ RP_INVERT, RP_MINUS_ONE_ONE = 5, 6  # boundary inversion: folded [0, 1] map abou
 # an angle as a point of the plane (reparameterisations/angle.py, round 6): the x' column of its x coordinate (-> the
 # angle) and, right behind it, the column of its y coordinate (-> the auxiliary radius)
 RP_ANGLE, RP_ANGLE_RADIAL = 7, 8
+# a pair of angles (a direction: azimuth / zenith or right ascension / declination) as a point of space
+# (angle.py:186-538): three x' columns in a row -> the horizontal angle, the vertical angle, the auxiliary radius
+RP_PAIR_H, RP_PAIR_V, RP_PAIR_R = 9, 10, 11
 
 _KNOWN = {
     "z-score": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
@@ -89,6 +100,7 @@ _KNOWN = {
     "angle-pi": ("angle", dict(scale=2.0)),
     "angle-2pi": ("angle", dict(scale=1.0)),
     "periodic": ("angle", dict(scale=None)),
+    "angle-pair": ("angle_pair", {}),
 }
 _NON_SAMPLING = ("logP", "logL", "it")
 
@@ -257,6 +269,47 @@ class _Group:
             self.angle_scale = float(2.0 * np.pi / np.ptp(self.prior_bounds[p])) if scale is None else float(scale)
             self.zero_bound = bool(self.prior_bounds[p][0] == 0)  # angle.py:79-82: modulo 2 pi on the way back
             self.update_enabled = False
+        elif kind == "angle_pair":
+            # two angles -> Cartesian coordinates with an auxiliary radius drawn from chi(3) (angle.py:214-376); the
+            # three-parameter form (a radial parameter OF THE MODEL) is not built
+            if len(self.parameters) != 2:
+                raise NotImplementedError(
+                    f"{name}: a pair of angles (the reference's angles + radial-parameter form has no device map); "
+                    f"got {self.parameters}")
+            missing = [p for p in self.parameters if p not in prior_bounds or not np.all(np.isfinite(prior_bounds[p]))]
+            if missing:
+                raise RuntimeError(f"{name} requires finite prior bounds, missing for {missing}")
+            self.prior_bounds = {p: np.asarray(prior_bounds[p], dtype=np.float64) for p in self.parameters}
+            widths = np.ptp([self.prior_bounds[p] for p in self.parameters], axis=1)
+            try:  # which angle runs along the horizon (range 2 pi), which is the vertical one (range pi)
+                hz = int(np.where(widths == (2 * np.pi))[0][0])
+                vt = int(np.where(widths == np.pi)[0][0])
+            except IndexError:
+                raise ValueError(f"Invalid prior ranges: {self.prior_bounds}. "
+                                 "Parameters must be defined over a range of pi and 2 pi!")
+            self.parameters = [self.parameters[hz], self.parameters[vt]]
+            h_bounds, v_bounds = self.prior_bounds[self.parameters[0]], self.prior_bounds[self.parameters[1]]
+            if np.array_equal(h_bounds, [0, 2 * np.pi]):
+                self.modulo_2pi = True
+            elif np.array_equal(h_bounds, [-np.pi, np.pi]):
+                self.modulo_2pi = False
+            else:
+                raise ValueError(f"Prior bounds for {self.parameters[0]} must be [0, 2pi] or [-pi, pi]. "
+                                 f"Received: {h_bounds}")
+            conventions = {"az-zen": [0, np.pi], "ra-dec": [-np.pi / 2, np.pi / 2]}
+            convention = kw.pop("convention", None)
+            if convention is None:
+                found = [c for c, b in conventions.items() if np.array_equal(v_bounds, b)]
+                if not found:
+                    raise RuntimeError(f"Could not determine convention for: {self.parameters}!")
+                convention = found[0]
+            elif convention not in conventions:
+                raise ValueError(f"Unknown convention: `{convention}`. Choose from: {list(conventions)}.")
+            elif not np.array_equal(v_bounds, conventions[convention]):
+                raise ValueError(f"Prior bounds for {self.parameters[1]} must be {conventions[convention]} for the "
+                                 f"{convention} convention. Received: {v_bounds}.")
+            self.convention = convention
+            self.update_enabled = False
         if kw:
             raise TypeError(f"Unknown arguments for reparameterisation {name}: {sorted(kw)}")
 
@@ -347,20 +400,27 @@ class _Group:
         """The x' columns of the group, in order."""
         if self.kind == "angle":
             return [self.parameters[0] + "_x", self.parameters[0] + "_y"]
+        if self.kind == "angle_pair":
+            m = "_".join(self.parameters)
+            return [f"{m}_x", f"{m}_y", f"{m}_z"]
         return [p + "_prime" for p in self.parameters]
 
     @property
     def aux_names(self):
-        """Auxiliary parameters the inverse map leaves in x (the radius of an angle: angle.py:61-63)."""
-        return [self.parameters[0] + "_radial"] if self.kind == "angle" else []
+        """Auxiliary parameters the inverse map leaves in x (the radius of an angle / a pair: angle.py:61-63, 308-312)."""
+        if self.kind == "angle":
+            return [self.parameters[0] + "_radial"]
+        if self.kind == "angle_pair":
+            return ["_".join(self.parameters) + "_radial"]
+        return []
 
     def log_prior(self, x):
-        """Prior of the auxiliary parameters (angle.py:181-183: chi(2) on the radius); 0 for the other maps."""
-        if self.kind != "angle":
+        """Prior of the auxiliary parameters (angle.py:181-183, 529-537: chi(2) / chi(3) on the radius); 0 otherwise."""
+        if self.kind not in ("angle", "angle_pair"):
             return 0.0
         from scipy import stats
 
-        return stats.chi(2).logpdf(x[self.aux_names[0]])
+        return stats.chi(2 if self.kind == "angle" else 3).logpdf(x[self.aux_names[0]])
 
     def forward(self, x, x_prime, log_j, compute_radius=False, test=None):
         """Returns ``(x, x_prime, log_j)``: a duplicating boundary inversion replaces all three."""
@@ -375,6 +435,25 @@ class _Group:
             x_prime[p + "_x"] = r * np.cos(angle)
             x_prime[p + "_y"] = r * np.sin(angle)
             log_j += np.log(r)
+            return x, x_prime, log_j
+        if self.kind == "angle_pair":  # angle.py:409-432, 509-521
+            from scipy import stats
+
+            if self.rng is None:
+                raise RuntimeError("the angle-pair reparameterisation needs the proposal's random generator")
+            r = stats.chi(3).rvs(size=x.size, random_state=self.rng)
+            horizontal, vertical = x[self.parameters[0]], x[self.parameters[1]]
+            px, py, pz = self.prime_names
+            if self.convention == "az-zen":
+                x_prime[px] = r * np.sin(vertical) * np.cos(horizontal)
+                x_prime[py] = r * np.sin(vertical) * np.sin(horizontal)
+                x_prime[pz] = r * np.cos(vertical)
+                log_j += 2 * np.log(r) + np.log(np.sin(vertical))
+            else:
+                x_prime[px] = r * np.cos(vertical) * np.cos(horizontal)
+                x_prime[py] = r * np.cos(vertical) * np.sin(horizontal)
+                x_prime[pz] = r * np.sin(vertical)
+                log_j += 2 * np.log(r) + np.log(np.cos(vertical))
             return x, x_prime, log_j
         for p in self.parameters:
             pp = p + "_prime"
@@ -417,6 +496,22 @@ class _Group:
             log_j -= np.log(radial)
             x[p + "_radial"] = radial
             x[p] = angle
+            return log_j
+        if self.kind == "angle_pair":  # angle.py:434-507
+            px, py, pz = (x_prime[n] for n in self.prime_names)
+            radial = np.sqrt(px ** 2.0 + py ** 2.0 + pz ** 2.0)
+            horizontal = np.arctan2(py, px)
+            if self.modulo_2pi:
+                horizontal = horizontal % (2.0 * np.pi)
+            if self.convention == "az-zen":
+                vertical = np.arctan2(np.sqrt(px ** 2.0 + py ** 2.0), pz)
+                log_j += -2 * np.log(radial) - np.log(np.sin(vertical))
+            else:
+                vertical = np.arctan2(pz, np.sqrt(px ** 2.0 + py ** 2.0))
+                log_j += -2 * np.log(radial) - np.log(np.cos(vertical))
+            x[self.aux_names[0]] = radial
+            x[self.parameters[0]] = horizontal
+            x[self.parameters[1]] = vertical
             return log_j
         if self.kind == "to_bounds":
             params = reversed(self.parameters)  # rescale.py:674-677
@@ -540,14 +635,19 @@ class ReparameterisationTable:
         # auxiliary parameters (the radius of every angle: angle.py:61-63).  `device_names` is what the D' output
         # columns of the draw kernel hold: a model parameter per x' column, the auxiliary radius in the column of an
         # angle's y coordinate.
-        by_param = {g.parameters[0]: g for g in self.groups if g.kind == "angle"}
+        wide = [g for g in self.groups if g.kind in ("angle", "angle_pair")]
+        first = {min(g.parameters, key=self.names.index): g for g in wide}  # the group's columns sit where its first
+        covered = {p for g in wide for p in g.parameters}                   # parameter (in model order) sits
         self.prime_names, self.device_names, self.aux_names = [], [], []
+        # degrees of freedom of the chi prior each auxiliary radius carries (angle.py:181-183, 529-537)
+        self.aux_dof = {a: (2 if g.kind == "angle" else 3) for g in wide for a in g.aux_names}
         for n in self.names:
-            if n in by_param:
-                self.prime_names += by_param[n].prime_names
-                self.device_names += [n] + by_param[n].aux_names
-                self.aux_names += by_param[n].aux_names
-            else:
+            if n in first:
+                g = first[n]
+                self.prime_names += g.prime_names
+                self.device_names += list(g.parameters) + g.aux_names
+                self.aux_names += g.aux_names
+            elif n not in covered:
                 self.prime_names.append(n + "_prime")
                 self.device_names.append(n)
         self.x_names = self.names + self.aux_names
@@ -587,7 +687,7 @@ class ReparameterisationTable:
         ``has_prior``; ``proposal/flowproposal/base.py:1046-1049`` adds it to the model's)."""
         total = np.zeros(x.size)
         for g in self.groups:
-            if g.kind == "angle":
+            if g.kind in ("angle", "angle_pair"):
                 total = total + g.log_prior(x)
         return total
 
@@ -668,6 +768,14 @@ class ReparameterisationTable:
         log_j = np.float64(0.0)
         for g in self.from_prime_order:
             params = list(reversed(g.parameters)) if g.kind == "to_bounds" else g.parameters
+            if g.kind == "angle_pair":
+                # columns i, i + 1, i + 2 hold x, y, z and give the horizontal angle, the vertical angle, the radius;
+                # par = {modulo 2 pi?, 1 for ra-dec / 0 for az-zen}
+                i = col[g.parameters[0]]
+                kind[i], kind[i + 1], kind[i + 2] = RP_PAIR_H, RP_PAIR_V, RP_PAIR_R
+                flags = [1.0 if g.modulo_2pi else 0.0, 1.0 if g.convention == "ra-dec" else 0.0, 0.0, 0.0, 0.0]
+                par[i] = par[i + 1] = par[i + 2] = flags
+                continue
             for p in params:
                 i = col[p]
                 if g.kind == "angle":

@@ -38,13 +38,12 @@ BOUNDS = {"a": [-3.0, 7.0], "phi": [0.0, 2.0 * np.pi], "psi": [-np.pi / 2.0, np.
           "tau": [0.0, 4.0]}
 # one entry per parameter, in model order (the reference then keeps the x' columns in that order)
 REPARAMETERISATIONS = {"a": "rescaletobounds", "phi": "angle-2pi", "psi": "angle-pi", "c": "z-score", "tau": "periodic"}
-OUT = {}
 
 
 class BoxModel(Model):
-    def __init__(self):
-        self.names = list(NAMES)
-        self.bounds = {n: list(BOUNDS[n]) for n in NAMES}
+    def __init__(self, names=NAMES, bounds=BOUNDS):
+        self.names = list(names)
+        self.bounds = {n: list(bounds[n]) for n in names}
 
     def log_prior(self, x):
         log_p = np.log(self.in_bounds(x), dtype="float")
@@ -60,7 +59,8 @@ def stack(x, names):
     return np.stack([np.asarray(x[n], dtype=np.float64) for n in names], axis=1)
 
 
-def main():
+def main(NAMES=NAMES, BOUNDS=BOUNDS, REPARAMETERISATIONS=REPARAMETERISATIONS, filename="angle_goldens.npz"):
+    OUT = {}
     rng_data = np.random.default_rng(20261001)
     n, m = 157, 133
     live = empty_structured_array(n, names=NAMES)
@@ -71,7 +71,7 @@ def main():
 
     rng = np.random.default_rng(170817)
     torch.manual_seed(170817)
-    model = BoxModel()
+    model = BoxModel(NAMES, BOUNDS)
     model.set_rng(rng)
     with tempfile.TemporaryDirectory() as tmp:
         prop = FlowProposal(model, rng=rng, poolsize=50, drawsize=400, output=tmp, plot=False,
@@ -115,7 +115,7 @@ def main():
             OUT["bp_log_w"] = np.asarray(prop.compute_weights(x, log_q), dtype=np.float64)
         samples = prop.convert_to_samples(x.copy(), plot=False)
         OUT["bp_sample_names"] = np.array([f for f in samples.dtype.names])
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "angle_goldens.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), filename)
     np.savez_compressed(path, **OUT)
     print("wrote", path)
     print(OUT["prime_parameters"], OUT["parameters"], OUT["x_back_names"], OUT["bp_names"], OUT["bp_sample_names"],

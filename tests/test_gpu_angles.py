@@ -163,3 +163,123 @@ def test_gw_parameter_set_with_its_angle_reparameterisations():
 
     want = model.log_prior(x) + sum(stats.chi(2).logpdf(x[n + "_radial"]) for n in ("psi", "phase", "ra", "phi_12", "phi_jl"))
     np.testing.assert_allclose(prop.log_prior(x), want, rtol=1e-13)
+
+
+# -- a pair of angles (angle.py:186-538; goldens: tests/golden/make_angle_pair_goldens.py) ---------------------------------
+
+PAIR_GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "angle_pair_goldens.npz"))
+PAIR_NAMES = ["a", "dec", "c", "ra", "az", "zen"]
+PAIR_BOUNDS = {"a": [-3.0, 7.0], "dec": [-np.pi / 2.0, np.pi / 2.0], "c": [0.5, 2.5], "ra": [0.0, 2.0 * np.pi],
+               "az": [-np.pi, np.pi], "zen": [0.0, np.pi]}
+PAIR_CONFIG = {"a": "rescaletobounds", "dec": {"reparameterisation": "angle-pair", "parameters": ["dec", "ra"]},
+               "c": "z-score", "az": {"reparameterisation": "angle-pair", "parameters": ["az", "zen"]}}
+PAIR_DEVICE_NAMES = ["a", "ra", "dec", "ra_dec_radial", "c", "az", "zen", "az_zen_radial"]
+
+
+class PairModel(UniformBoxModel):
+    def __init__(self):
+        self.names = list(PAIR_NAMES)
+        self.bounds = {n: list(PAIR_BOUNDS[n]) for n in PAIR_NAMES}
+
+    def log_likelihood(self, x):
+        return -0.5 * np.sum(self.unstructured_view(x) ** 2, axis=-1)
+
+
+@pytest.mark.parametrize("prior", ["device", "host"])
+def test_angle_pair_proposal_matches_the_reference(prior):
+    """Two pairs (ra-dec with the modulo, az-zen without; the first given vertical angle first and split by another
+    parameter in the model): three x' columns per pair, the epilogue's atan2s / radius / -2 log r - log cos|sin terms,
+    the chi(3) rows of the prior table."""
+    prop = FlowProposal(PairModel(), rng=np.random.default_rng(4242), poolsize=50, drawsize=400, device_seed=1,
+                        flow_config=dict(ftype="realnvp", n_blocks=2, n_neurons=8, n_layers=1,
+                                         batch_norm_between_layers=False, linear_transform="permutation"),
+                        reparameterisations=PAIR_CONFIG, prior=prior)
+    prop.initialise()
+    g = PAIR_GOLD
+    state = {k[len("state/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("state/")}
+    prop.flow.model.load_state_dict(state)
+    prop.flow.model.eval()
+    live = numpy_array_to_live_points(g["live"], PAIR_NAMES)
+    prop.check_state(live)
+    assert prop.prime_parameters == [str(p) for p in g["prime_parameters"]]
+    assert prop.dims == prop.prime_dims == 8 and prop.flow.model.features == 8
+    assert prop.names == PAIR_DEVICE_NAMES
+    if prior == "device":
+        assert prop._prior_kind_dev.tolist() == [0, 0, 0, 5, 0, 0, 0, 5]
+    x_prime, log_j = prop.rescale(live)
+    assert np.array_equal(stack(x_prime, prop.prime_parameters), g["x_prime"])
+    assert np.array_equal(log_j, g["log_j"])
+    x, log_q, z_kept = prop.backward_pass(g["bp_z"], return_z=True)
+    assert np.array_equal(z_kept, g["bp_z_kept"])
+    names = [str(n) for n in g["bp_names"]]
+    np.testing.assert_allclose(stack(x, names), g["bp_x"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(log_q, g["bp_log_q"], rtol=1e-5, atol=5e-5)
+    with np.errstate(divide="ignore"):
+        log_w = prop.compute_weights(x, log_q)
+    np.testing.assert_allclose(log_w, g["bp_log_w"], rtol=1e-5, atol=5e-5)
+    samples = prop.convert_to_samples(x)
+    assert list(samples.dtype.names) == [str(n) for n in g["bp_sample_names"]]
+
+
+@pytest.mark.parametrize("prior", ["device", "host"])
+def test_populate_with_angle_pairs(prior):
+    def run(lean, prior_mode):
+        torch.manual_seed(3)
+        prop = FlowProposal(PairModel(), rng=np.random.default_rng(5), poolsize=300, drawsize=30_000, device_seed=11,
+                            flow_config=dict(ftype="nsf", n_neurons=16, n_blocks=2), reparameterisations=PAIR_CONFIG,
+                            lean=lean, prior=prior_mode)
+        prop.initialise()
+        live = numpy_array_to_live_points(PAIR_GOLD["live"], PAIR_NAMES)
+        prop.train_data = live
+        prop.check_state(live)
+        prop.populate(None, n_samples=300, max_samples=10**8)
+        return prop
+
+    a, b = run(True, prior), run(False, prior)
+    if prior == "device":
+        assert a.last_populate_path == "trains" and a.last_populate_lean and not b.last_populate_lean
+    assert a.n_proposed == b.n_proposed and a.n_accepted == b.n_accepted
+    assert np.array_equal(stack(a.samples, PAIR_NAMES), stack(b.samples, PAIR_NAMES))
+    assert list(a.samples.dtype.names) == PAIR_NAMES + ["logP", "logL", "it"]
+    assert a.model.in_bounds(a.samples).all() and len(a.samples) == 300
+    assert np.array_equal(a.samples["logP"], a.model.log_prior(a.samples))
+    radii = stack(a.x, ["ra_dec_radial", "az_zen_radial"])
+    assert np.isfinite(radii).all() and (radii > 0).all()
+    # the pool follows the prior: uniform in the angles (NOT isotropic on the sphere - the box model's prior),
+    # the Jacobian's log cos / log sin terms are what make that so
+    assert abs(np.mean(a.samples["dec"])) < 0.3 and abs(np.mean(a.samples["zen"]) - np.pi / 2) < 0.3
+    if prior == "host":
+        c = run(True, "device")
+        assert c.n_proposed == a.n_proposed
+        np.testing.assert_allclose(stack(c.samples, PAIR_NAMES), stack(a.samples, PAIR_NAMES), rtol=0, atol=1e-9)
+
+
+def test_gw_sky_position_as_an_angle_pair():
+    """Config 5's parameter set with the sky position as the reference's GW defaults treat it: (ra, dec) as one
+    ``angle-pair`` - the flow sees a point of space instead of two periodic / bounded columns."""
+    from scipy import stats
+
+    from nessai_amd.model import GWSurrogateModel
+
+    model = GWSurrogateModel()
+    config = {"psi": "angle-pi", "phase": "angle-2pi", "angle-pair": {"parameters": ["ra", "dec"]},
+              "tilt_1": "angle-sine", "tilt_2": "angle-sine", "theta_jn": "angle-sine"}
+    torch.manual_seed(1)
+    prop = FlowProposal(model, rng=np.random.default_rng(3), poolsize=300, drawsize=40_000, device_seed=5,
+                        flow_config=dict(ftype="nsf", n_neurons=32, n_blocks=2), reparameterisations=config)
+    prop.initialise()
+    assert prop.dims == 18 and "ra_dec_x" in prop.prime_parameters and prop.prior_mode == "device"
+    assert int((prop._prior_kind_dev == 5).sum()) == 3
+    live = model.new_point(600, rng=np.random.default_rng(1))
+    prop.check_state(live)
+    prop.populate(None, n_samples=300, max_samples=10**8)
+    assert prop.last_populate_path == "trains" and prop.last_populate_lean
+    s = prop.samples
+    assert len(s) == 300 and list(s.dtype.names) == model.names + ["logP", "logL", "it"]
+    assert model.in_bounds(s).all() and np.isfinite(s["logP"]).all()
+    np.testing.assert_allclose(s["logP"], model.log_prior(s), rtol=1e-13)
+    z = np.random.default_rng(2).normal(size=(2000, 18))
+    x, log_q = prop.backward_pass(z)
+    want = (model.log_prior(x) + stats.chi(2).logpdf(x["psi_radial"]) + stats.chi(2).logpdf(x["phase_radial"])
+            + stats.chi(3).logpdf(x["ra_dec_radial"]))
+    np.testing.assert_allclose(prop.log_prior(x), want, rtol=1e-13)
