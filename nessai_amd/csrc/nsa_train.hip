@@ -1179,6 +1179,7 @@ __global__ void tr_copy_rows(long long n, const float* __restrict__ src, float* 
 
 #include "nsa_train_fused.h"
 #include "nsa_train_fused2.h"
+#include "nsa_train_fused3.h"
 
 // Everything a pass needs before its first coupling layer, in one launch instead of five: the batch copied into
 // the workspace, the transposed weight copies of the fused kernels, the flat gradient, log|det J| and the scalar
@@ -1613,7 +1614,7 @@ static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, lo
 static long long tr_slab_floats(const long long* plan, long long n) {
   const long long grid = (n + TRF_ROWS - 1) / TRF_ROWS;
   const long long words = grid * al4(plan[8]);
-  return (plan[11] == NSA_NET_RESNET && plan[1] <= 64 && words <= (64LL << 20)) ? words : 0;
+  return (plan[11] == NSA_NET_RESNET && plan[1] <= 128 && words <= (64LL << 20)) ? words : 0;
 }
 
 extern "C" NSA_API size_t nsa_train_workspace_floats(const long long* plan, long long n) {
@@ -1801,11 +1802,15 @@ static hipError_t tr_forward_run_k(const Trf2Multi& m, int count, hipStream_t s)
   return m.a.H <= 32 ? tr_forward_run_c<K, 1>(m, count, s) : tr_forward_run_c<K, 2>(m, count, s);
 }
 static hipError_t tr_forward_run(int transform, int K, const Trf2Multi& m, int count, hipStream_t s) {
+#ifdef NSA_TRAIN_DEV_K8  // development builds (make TRAIN_DEV=1): the 8-bin instances only - a fifth of the compile time
+  return tr_forward_run_k<8>(m, count, s);
+#else
   if (transform != NSA_T_RQ) return tr_forward_run_k<0>(m, count, s);
   if (K == 4) return tr_forward_run_k<4>(m, count, s);
   if (K == 8) return tr_forward_run_k<8>(m, count, s);
   if (K == 10) return tr_forward_run_k<10>(m, count, s);
   return tr_forward_run_k<16>(m, count, s);
+#endif
 }
 
 template <int K, int HT>
@@ -1825,10 +1830,43 @@ static hipError_t tr_launch_fused2(bool backward, const TrfArgs& a, hipStream_t 
   return hipGetLastError();
 }
 
+// third-generation kernels (nsa_train_fused3.h): conditioners 65 to 128 wide; NESSAI_AMD_TRAIN_V3=0 keeps the first
+// generation (the cross-check of the tests)
+static bool tr_v3_fits(bool backward, const TrfArgs& a) {
+  const char* e = getenv("NESSAI_AMD_TRAIN_V3");
+  if (e != nullptr && e[0] == '0') return false;
+  if (a.H <= 64 || a.H > 128 || a.D > 128 || a.np > 768 || a.d_id > 128) return false;
+  if (!backward) return trf3_forward_floats(a) * sizeof(float) <= 160 * 1024;
+  // backward: the all-inside instances only (H == 128; other widths keep the first generation's backward kernel),
+  // parameter rows and tiles in 16-byte units, <= 2 transform items per thread, <= 6 block tiles through registers
+  return a.H == 128 && a.np % 4 == 0 && a.d_tr <= 32 && a.L <= 3 && a.off[2 + 4 * a.L] % 4 == 0 &&
+         ((uintptr_t)a.p % 16 == 0) && ((uintptr_t)a.wt % 16 == 0) && ((uintptr_t)a.h % 16 == 0) &&
+         ((uintptr_t)a.u % 16 == 0) && (((long long)a.n * a.H) % 4 == 0) && (long long)a.n * a.H >= 4 &&
+         trf3_backward_floats(a) * sizeof(float) <= 160 * 1024;
+}
+
 template <int K>
 static hipError_t tr_launch_fused(bool backward, const TrfArgs& a, hipStream_t s) {
   if (backward && tr_v2_fits(true, a))
     return a.H <= 32 ? tr_launch_fused2<K, 1>(backward, a, s) : tr_launch_fused2<K, 2>(backward, a, s);
+  if (backward && tr_v3_fits(true, a)) {
+    const size_t lds3 = trf3_backward_floats(a) * sizeof(float);
+    auto kern3 = a.gslab != nullptr ? trf3_backward<K, true> : trf3_backward<K, false>;
+    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern3),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    if (e3 != hipSuccess) return e3;
+    hipLaunchKernelGGL(kern3, dim3((unsigned)((a.n + TRF_ROWS - 1) / TRF_ROWS)), dim3(TRF_THREADS), lds3, s, a);
+    return hipGetLastError();
+  }
+  if (!backward && tr_v3_fits(false, a)) {
+    const size_t lds3 = trf3_forward_floats(a) * sizeof(float);
+    auto kern3 = a.H == 128 ? trf3_forward<K, true> : trf3_forward<K, false>;
+    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern3),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    if (e3 != hipSuccess) return e3;
+    hipLaunchKernelGGL(kern3, dim3((unsigned)((a.n + TRF_ROWS - 1) / TRF_ROWS)), dim3(TRF_THREADS), lds3, s, a);
+    return hipGetLastError();
+  }
   const size_t floats = backward ? (size_t)(4 * TRF_ROWS * a.ld + TRF_ROWS * (a.ch + 1))
                                  : (size_t)(2 * TRF_ROWS * a.ld);
   const size_t lds = floats * sizeof(float);
@@ -1842,11 +1880,15 @@ static hipError_t tr_launch_fused(bool backward, const TrfArgs& a, hipStream_t s
 }
 
 static hipError_t tr_fused_coupling(bool backward, int transform, int K, const TrfArgs& a, hipStream_t s) {
+#ifdef NSA_TRAIN_DEV_K8
+  return tr_launch_fused<8>(backward, a, s);
+#else
   if (transform != NSA_T_RQ) return tr_launch_fused<0>(backward, a, s);
   if (K == 4) return tr_launch_fused<4>(backward, a, s);
   if (K == 8) return tr_launch_fused<8>(backward, a, s);
   if (K == 10) return tr_launch_fused<10>(backward, a, s);
   return tr_launch_fused<16>(backward, a, s);
+#endif
 }
 
 // linear-layer block of the workspace
@@ -2180,7 +2222,7 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
         for (int i = 0; i < 4 + 4 * L; ++i) a.off[i] = off[i];
         // per-workgroup gradient copies when this coupling's parameters are one contiguous block of the flat
         // vector (they are: the module registers them in order) and there is room for one more range
-        if (w.slab != nullptr && tr_v2_fits(true, a) && ranges.count < 32) {
+        if (w.slab != nullptr && (tr_v2_fits(true, a) || tr_v3_fits(true, a)) && ranges.count < 32) {
           long long expect = off[0];
           bool contiguous = true;
           for (int i = 0; i < 4 + 4 * L; ++i) {

@@ -34,6 +34,12 @@ CASES = {
                                scale_activation=lambda x: torch.sigmoid(x - 0.5) + 0.05)),
     # wider than the second-generation kernels take (hidden width > 64): the first-generation fused kernels
     "nsf_wide": (NeuralSplineFlow, O.NeuralSplineFlow, (10, 96, 2, 2), {}),
+    # config 4's shape (64 inputs, 128-wide conditioners, 736 spline parameters per row): the third-generation
+    # kernels' all-inside instances; and the same width on a flow whose parameter rows are not 16-byte multiples
+    "nsf_c4": (NeuralSplineFlow, O.NeuralSplineFlow, (64, 128, 2, 2), {}),
+    "nsf_d9_h128": (NeuralSplineFlow, O.NeuralSplineFlow, (9, 128, 2, 1), {}),
+    "rnvp_d40_h128": (RealNVP, O.RealNVP, (40, 128, 2, 2), dict(linear_transform="permutation",
+                                                               batch_norm_between_layers=False)),
     # parameter rows that are not a multiple of 16 bytes (np = 3 x 23): the scalar paths of the backward kernel
     "nsf_d5": (NeuralSplineFlow, O.NeuralSplineFlow, (5, 24, 2, 2), {}),
     # four residual blocks per conditioner: nine activation tiles, beyond what the backward kernel copies through
@@ -106,11 +112,14 @@ def test_loss_and_gradients_match_autograd(name):
     assert torch.equal(tr.params, before)
 
 
-@pytest.mark.parametrize("name", ["nsf_c3", "nsf_d7_k4", "nsf_d6_tanh", "rnvp_perm", "rnvp_additive", "nsf_bn_lu"])
+@pytest.mark.parametrize("name", ["nsf_c3", "nsf_d7_k4", "nsf_d6_tanh", "rnvp_perm", "rnvp_additive", "nsf_bn_lu",
+                                  "nsf_c4", "nsf_d9_h128"])
 def test_first_generation_fused_kernels_match_autograd(name, monkeypatch):
-    """The first-generation per-coupling kernels (nsa_train_fused.h) remain the path of conditioners wider than
-    64 and the cross-check of the second generation: same bar, on the shapes the second generation now takes."""
+    """The first-generation per-coupling kernels (nsa_train_fused.h) remain the cross-check of the second and third
+    generations (and the backward pass of widths between 65 and 127): same bar, on the shapes the later generations
+    now take."""
     monkeypatch.setenv("NESSAI_AMD_TRAIN_V2", "0")
+    monkeypatch.setenv("NESSAI_AMD_TRAIN_V3", "0")
     test_loss_and_gradients_match_autograd(name)
 
 
@@ -352,6 +361,31 @@ def test_act_norm_trains_with_data_dependent_initialisation():
     xe = torch.randn(100, 6)
     with torch.no_grad():
         assert rel_err(flow.log_prob(xe.to(DEV)).cpu(), ref.log_prob(xe)) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["nsf_c4", "nsf_wide", "rnvp_d40_h128"])
+def test_third_generation_fused_kernels_match_the_first(name, monkeypatch):
+    """Conditioners 65 to 128 wide (nsa_train_fused3.h; config 4's importance-sampling flows): the third-generation
+    kernels against the first generation (NESSAI_AMD_TRAIN_V3=0) on the same batch - loss identical, gradients equal
+    up to the order of the float32 sums (split-k partial sums, per-workgroup gradient copies instead of float
+    atomics), ``log_prob`` of the validation pass likewise."""
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NESSAI_AMD_TRAIN_V3", mode)
+        ref, flow, D = pair(name)
+        x = (torch.randn(333, D, generator=torch.Generator().manual_seed(9)) * 1.5).to(DEV)
+        tr = Trainer(flow)
+        tr.step(x, clip_norm=5.0, lr=0.0)
+        torch.cuda.synchronize()
+        lp = torch.empty(333, dtype=torch.float32, device=DEV)
+        loss = tr.loss_acc.item()
+        tr.evaluate(x, log_prob_out=lp)
+        results[mode] = (loss, tr.grads.cpu().clone(), lp.cpu().clone())
+    (l0, g0, lp0), (l1, g1, lp1) = results["0"], results["1"]
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0))
+    scale = max(1e-3, float(g0.abs().max()))
+    assert float((g0 - g1).abs().max()) <= 5e-5 * scale
+    assert rel_err(lp0, lp1) <= 2e-6
 
 
 @pytest.mark.parametrize("name", ["nsf_c3", "nsf_d7_k4", "nsf_d6_tanh", "rnvp_perm", "rnvp_additive", "nsf_bn_lu"])
