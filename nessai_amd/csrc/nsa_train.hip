@@ -1611,8 +1611,14 @@ static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, lo
 // The fused backward kernels of the second generation leave each workgroup's share of the weight gradients
 // in its own copy of the flat gradient vector and one kernel sums the copies in a fixed order (below a cap
 // on the copies' size; above it the kernels add to the flat gradient with float atomics as the first generation does)
+// rows per workgroup of the fused backward kernels that write gradient copies: 16 for 128-wide conditioners (the
+// 16-row kernels of nsa_train_fused3.h), 32 otherwise (second generation)
+static inline long long tr_slab_rows(const long long* plan) { return plan[1] == 128 ? 16 : 32; }
+static inline int tr_slab_copies(const long long* plan, long long n) {
+  return (int)((n + tr_slab_rows(plan) - 1) / tr_slab_rows(plan));
+}
 static long long tr_slab_floats(const long long* plan, long long n) {
-  const long long grid = (n + TRF_ROWS - 1) / TRF_ROWS;
+  const long long grid = tr_slab_copies(plan, n);
   const long long words = grid * al4(plan[8]);
   return (plan[11] == NSA_NET_RESNET && plan[1] <= 128 && words <= (64LL << 20)) ? words : 0;
 }
@@ -1830,41 +1836,34 @@ static hipError_t tr_launch_fused2(bool backward, const TrfArgs& a, hipStream_t 
   return hipGetLastError();
 }
 
-// third-generation kernels (nsa_train_fused3.h): conditioners 65 to 128 wide; NESSAI_AMD_TRAIN_V3=0 keeps the first
-// generation (the cross-check of the tests)
-static bool tr_v3_fits(bool backward, const TrfArgs& a) {
+// third-generation kernels (nsa_train_fused3.h): 128-wide conditioners on 16-row workgroups; NESSAI_AMD_TRAIN_V3=0
+// keeps the first generation (the cross-check of the tests)
+static bool tr_v3_enabled() {
   const char* e = getenv("NESSAI_AMD_TRAIN_V3");
-  if (e != nullptr && e[0] == '0') return false;
-  if (a.H <= 64 || a.H > 128 || a.D > 128 || a.np > 768 || a.d_id > 128) return false;
-  if (!backward) return trf3_forward_floats(a) * sizeof(float) <= 160 * 1024;
-  // backward: the all-inside instances only (H == 128; other widths keep the first generation's backward kernel),
-  // parameter rows and tiles in 16-byte units, <= 2 transform items per thread, <= 6 block tiles through registers
-  return a.H == 128 && a.np % 4 == 0 && a.d_tr <= 32 && a.L <= 3 && a.off[2 + 4 * a.L] % 4 == 0 &&
+  return !(e != nullptr && e[0] == '0');
+}
+static bool tr_v4_fits(bool backward, const TrfArgs& a) {  // 16-row kernels
+  if (!tr_v3_enabled()) return false;
+  if (a.H != 128 || a.D > 128 || a.np > 768 || a.d_id > 128) return false;
+  if (!backward) return trf4_forward_floats(a) * sizeof(float) <= 160 * 1024;
+  // parameter rows and tiles in 16-byte units, one transform item per thread, <= 7 activation tiles through registers
+  return a.np % 4 == 0 && a.d_tr <= 32 && a.L <= 3 && a.off[2 + 4 * a.L] % 4 == 0 &&
          ((uintptr_t)a.p % 16 == 0) && ((uintptr_t)a.wt % 16 == 0) && ((uintptr_t)a.h % 16 == 0) &&
-         ((uintptr_t)a.u % 16 == 0) && (((long long)a.n * a.H) % 4 == 0) && (long long)a.n * a.H >= 4 &&
-         trf3_backward_floats(a) * sizeof(float) <= 160 * 1024;
+         ((uintptr_t)a.u % 16 == 0) && (((long long)a.n * a.H) % 4 == 0) &&
+         trf4_backward_floats(a) * sizeof(float) <= 160 * 1024;
 }
 
 template <int K>
 static hipError_t tr_launch_fused(bool backward, const TrfArgs& a, hipStream_t s) {
   if (backward && tr_v2_fits(true, a))
     return a.H <= 32 ? tr_launch_fused2<K, 1>(backward, a, s) : tr_launch_fused2<K, 2>(backward, a, s);
-  if (backward && tr_v3_fits(true, a)) {
-    const size_t lds3 = trf3_backward_floats(a) * sizeof(float);
-    auto kern3 = a.gslab != nullptr ? trf3_backward<K, true> : trf3_backward<K, false>;
-    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern3),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-    if (e3 != hipSuccess) return e3;
-    hipLaunchKernelGGL(kern3, dim3((unsigned)((a.n + TRF_ROWS - 1) / TRF_ROWS)), dim3(TRF_THREADS), lds3, s, a);
-    return hipGetLastError();
-  }
-  if (!backward && tr_v3_fits(false, a)) {
-    const size_t lds3 = trf3_forward_floats(a) * sizeof(float);
-    auto kern3 = a.H == 128 ? trf3_forward<K, true> : trf3_forward<K, false>;
-    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern3),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-    if (e3 != hipSuccess) return e3;
-    hipLaunchKernelGGL(kern3, dim3((unsigned)((a.n + TRF_ROWS - 1) / TRF_ROWS)), dim3(TRF_THREADS), lds3, s, a);
+  if (tr_v4_fits(backward, a)) {
+    const size_t lds4 = (backward ? trf4_backward_floats(a) : trf4_forward_floats(a)) * sizeof(float);
+    auto kern4 = backward ? (a.gslab != nullptr ? trf4_backward<K, true> : trf4_backward<K, false>) : trf4_forward<K>;
+    hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern4),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+    if (e4 != hipSuccess) return e4;
+    hipLaunchKernelGGL(kern4, dim3((unsigned)((a.n + TRF4_ROWS - 1) / TRF4_ROWS)), dim3(TRF_THREADS), lds4, s, a);
     return hipGetLastError();
   }
   const size_t floats = backward ? (size_t)(4 * TRF_ROWS * a.ld + TRF_ROWS * (a.ch + 1))
@@ -2222,7 +2221,7 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
         for (int i = 0; i < 4 + 4 * L; ++i) a.off[i] = off[i];
         // per-workgroup gradient copies when this coupling's parameters are one contiguous block of the flat
         // vector (they are: the module registers them in order) and there is room for one more range
-        if (w.slab != nullptr && (tr_v2_fits(true, a) || tr_v3_fits(true, a)) && ranges.count < 32) {
+        if (w.slab != nullptr && (tr_v2_fits(true, a) || tr_v4_fits(true, a)) && ranges.count < 32) {
           long long expect = off[0];
           bool contiguous = true;
           for (int i = 0; i < 4 + 4 * L; ++i) {
@@ -2419,7 +2418,7 @@ static void tr_backward(const long long* plan, const int* tabs, const float* par
     int longest = 0;
     for (int i = 0; i < ranges.count; ++i) longest = ranges.len[i] > longest ? ranges.len[i] : longest;
     hipLaunchKernelGGL(tr_reduce_slab, dim3((unsigned)((longest + 255) / 256), (unsigned)ranges.count), dim3(256), 0, s,
-                       (const float*)w.slab, al4(plan[8]), (int)((n + TRF_ROWS - 1) / TRF_ROWS), grads, ranges);
+                       (const float*)w.slab, al4(plan[8]), tr_slab_copies(plan, n), grads, ranges);
   }
 }
 
@@ -2479,7 +2478,7 @@ static int tr_step_impl(const long long* plan, const int* tables_dev, const floa
   const long long want_blocks = (n_params + 255) / 256;
   const int sq_blocks = (int)(want_blocks < TR_SQ_MAX ? want_blocks : TR_SQ_MAX);
   hipLaunchKernelGGL(tr_finish_grads, dim3(sq_blocks), dim3(256), 0, s, n_params, grads_dev, (const float*)w.slab,
-                     al4(n_params), (int)((n + TRF_ROWS - 1) / TRF_ROWS), ranges, w.scal + 128, opt_dev, beta1, beta2);
+                     al4(n_params), tr_slab_copies(plan, n), ranges, w.scal + 128, opt_dev, beta1, beta2);
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
   hipLaunchKernelGGL(tr_adamw, blocks_for(n_params), dim3(256), 0, s, n_params, params_dev, grads_dev, adam_m_dev,

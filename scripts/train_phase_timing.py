@@ -18,7 +18,7 @@ from nessai_amd.flows import NeuralSplineFlow  # noqa: E402
 from nessai_amd.train import Trainer  # noqa: E402
 
 torch.manual_seed(1)
-SHAPE = (64, 128, 6, 2) if "--c4" in sys.argv else (32, 64, 6, 2)  # --c4: config 4's flow (first-generation kernels)
+SHAPE = (64, 128, 6, 2) if "--c4" in sys.argv else (32, 64, 6, 2)  # --c4: config 4's flow (third-generation kernels; NESSAI_AMD_TRAIN_V3=0: the first)
 flow = NeuralSplineFlow(*SHAPE)
 flow.to("cuda")
 tr = Trainer(flow)
@@ -33,7 +33,9 @@ if "--fine" in sys.argv:  # stamps inside the layer h_1 of the first-generation 
     print("  ", [int(v) for v in fine], "\n   deltas", [int(b - a) for a, b in zip(fine[:-1], fine[1:])])
 names = {0: "x staged", 1: "layer 0", 2: "u_0", 3: "h_1", 4: "u_1", 5: "h_2", 20: "params", 21: "barrier",
          22: "transform fwd", 30: "bwd: tiles in LDS", 31: "bwd: transform (gen 1: items done)", 32: "bwd: final layer",
-         33: "bwd: last block", 34: "bwd: block before", 40: "bwd: later loads issued", 41: "bwd: items done", 60: "bwd: initial layer + end"}
+         33: "bwd: last block", 34: "bwd: block before", 40: "bwd: later loads issued", 41: "bwd: items done",
+         42: "bwd: final layer dX (gen 3)", 43: "bwd: final layer dW (gen 3)", 50: "bwd: block tiles requested (gen 3)",
+         51: "bwd: barrier (gen 3)", 60: "bwd: initial layer + end"}
 prev = 0.0
 for group in (range(0, 23), range(30, 61)):
     prev = 0.0

@@ -100,6 +100,34 @@ def test_second_generation_training_kernels_do_not_spill():
         assert table[n]["spill"] == 0 and table[n]["scratch"] == 0, (n, table[n])
 
 
+def test_third_generation_training_kernels():
+    """The 16-row kernels of 128-wide conditioners (config 4; csrc/nsa_train_fused3.h): no scratch, registers that
+    leave two waves per SIMD; in the disassembly of the 8-bin backward instance - 16x16x4 f32 matrix instructions,
+    the operand streams as buffer loads (no 64-bit address arithmetic per request), and no wait for EVERY
+    outstanding memory operation in front of an MFMA of the residual blocks (a prefetch under a branch, or sunk to
+    its use, shows up there as vmcnt(0))."""
+    table = _kernels("nsa_train.o")
+    for k in (0, 4, 8, 10, 16):
+        for name in (f"trf4_forward<{k}>(TrfArgs)", f"trf4_backward<{k}, true>(TrfArgs)",
+                     f"trf4_backward<{k}, false>(TrfArgs)"):
+            r = _one(table, name)
+            assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 256, (name, r)
+    asm = _disassemble("nsa_train.o", "trf4_backwardILi8ELb1EEv7TrfArgs")
+    lines = [ln.split("//")[0].strip() for ln in asm.split("\n")]
+    ops = [ln.split()[0] for ln in lines if ln and not ln.endswith(":")]
+    assert sum(1 for o in ops if o == "v_mfma_f32_16x16x4_f32") >= 300 and not any(o.startswith("v_mfma_f32_32x32") for o in ops)
+    assert sum(1 for o in ops if o == "buffer_load_dword") >= 64 and sum(1 for o in ops if o == "buffer_load_dwordx4") >= 16
+    assert not any(o.startswith("scratch_") for o in ops)
+    barriers = [i for i, ln in enumerate(lines) if ln.startswith("s_barrier")]
+    assert len(barriers) == 6  # tiles | transform items | final layer | (first, second layer of a block) | initial layer
+    # the loop over the residual blocks: an MFMA never follows a full drain of the vector-memory counter directly
+    # (there is always a younger prefetch in flight)
+    for i in range(barriers[2], barriers[4]):
+        if lines[i].startswith("s_waitcnt") and "vmcnt(0)" in lines[i]:
+            nxt = next(ln for ln in lines[i + 1:] if ln and not ln.startswith("s_"))
+            assert not nxt.startswith("v_mfma"), (i, lines[i], nxt)
+
+
 def _disassemble(obj, mangled_fragment):
     tmp = tempfile.mkdtemp()
     try:
