@@ -221,7 +221,8 @@ struct NsaLaunch {
 // holds the y coordinate and gives the auxiliary radius, whose -log is the row's share of the Jacobian
 enum { NSA_RP_SCALE_SHIFT = 0, NSA_RP_NULL = 1, NSA_RP_TO_BOUNDS = 2, NSA_RP_TO_BOUNDS_LOGIT = 3,
        NSA_RP_TO_BOUNDS_LOG = 4, NSA_RP_INVERT = 5, NSA_RP_MINUS_ONE_ONE = 6, NSA_RP_ANGLE = 7,
-       NSA_RP_ANGLE_RADIAL = 8, NSA_RP_PAIR_H = 9, NSA_RP_PAIR_V = 10, NSA_RP_PAIR_R = 11 };
+       NSA_RP_ANGLE_RADIAL = 8, NSA_RP_PAIR_H = 9, NSA_RP_PAIR_V = 10, NSA_RP_PAIR_R = 11,
+       NSA_RP_DEQUANTISE = 12, NSA_RP_DEQUANTISE_LOGIT = 13, NSA_RP_DEQUANTISE_LOG = 14 };
 
 enum { NSA_PRIOR_UNIFORM = 0, NSA_PRIOR_SINE = 1, NSA_PRIOR_COSINE = 2, NSA_PRIOR_POWER_LAW = 3,
        NSA_PRIOR_GAUSSIAN = 4, NSA_PRIOR_CHI = 5 };
@@ -1982,17 +1983,22 @@ __global__ void __launch_bounds__(HT >= NSA_WIDE_HT ? 256 : (OCC == 4 ? 1024 : (
           xv = sqrt(cx * cx + cy * cy + xp * xp);
           log_j_row -= 2.0 * log(xv);
         } else {
+          // rescale-to-bounds, its logit / log forms, and the same three followed by floor() for a discrete
+          // parameter (the reference's Dequantise: discrete.py:9-78)
           const double* c = e.rp_par + 5 * i;
+          const bool discrete = kind >= NSA_RP_DEQUANTISE;
+          const int base = discrete ? kind - (NSA_RP_DEQUANTISE - NSA_RP_TO_BOUNDS) : kind;
           double u = xp;
-          if (kind == NSA_RP_TO_BOUNDS_LOGIT) {
+          if (base == NSA_RP_TO_BOUNDS_LOGIT) {
             u = 1.0 / (1.0 + exp(-xp));
             log_j_row += log(u) + log1p(-u);
-          } else if (kind == NSA_RP_TO_BOUNDS_LOG) {
+          } else if (base == NSA_RP_TO_BOUNDS_LOG) {
             u = exp(xp);
             log_j_row += xp;
           }
           xv = (c[1] - c[0]) * (u - c[2]) / c[3] + c[0];
           xv = xv + c[4];
+          if (discrete) xv = floor(xv);
         }
         in_bounds = in_bounds && !((xv < e.lower[i]) || (xv > e.upper[i]));
         if (row_ok && e.x64_out != nullptr && !(NSA_ABLATE & 32)) e.x64_out[my_row * D + i] = xv;

@@ -28,6 +28,9 @@ registry name                         map (x -> x')
                                       AUXILIARY radius drawn from chi(2) (the proposal's generator through scipy, as the
                                       reference draws it); back: ``atan2`` (modulo 2 pi when the prior range starts at 0)
                                       / ``scale`` and the radius, which stays in x and carries a chi(2) prior
+``dequantise`` ``dequantise-logit``   ``Dequantise`` (``discrete.py:9-78``): a discrete parameter plus uniform noise (the
+                                      proposal's generator), rescaled on [min, max + 1] (then ``logit``); back:
+                                      the inverse map, then ``floor``
 ``angle-pair``                        ``AnglePair`` (``angle.py:186-538``): two angles -> ``r`` times the unit vector they
                                       point along, ``r`` an auxiliary radius from chi(3); conventions ``ra-dec``
                                       (vertical angle on [-pi/2, pi/2]) and ``az-zen`` ([0, pi]) found from the bounds
@@ -45,8 +48,8 @@ A PAIR of angles (``angle-pair``, angle.py:186-538: a direction - right ascensio
 becomes a point of space: x' has THREE columns (``<h>_<v>_x``, ``_y``, ``_z``) where the pair's first parameter sat,
 x gains ``<h>_<v>_radial`` with a chi(3) prior, and the device columns are (horizontal, vertical, radius).
 
-``to-cartesian``, an angle or a pair with a radial parameter of the model, dequantisation and user-defined classes
-raise ``NotImplementedError`` here.
+``to-cartesian``, an angle or a pair with a radial parameter of the model and user-defined classes raise
+``NotImplementedError`` here.
 
 The configuration forms are the reference's (``reparameterisations/utils.py:120-268``):
 ``None`` | ``"name"`` | ``{parameter: "name"}`` | ``{parameter: {"reparameterisation": "name",
@@ -73,6 +76,8 @@ RP_ANGLE, RP_ANGLE_RADIAL = 7, 8
 # a pair of angles (a direction: azimuth / zenith or right ascension / declination) as a point of space
 # (angle.py:186-538): three x' columns in a row -> the horizontal angle, the vertical angle, the auxiliary radius
 RP_PAIR_H, RP_PAIR_V, RP_PAIR_R = 9, 10, 11
+# a discrete parameter (discrete.py:9-78): the three rescale-to-bounds kinds followed by floor()
+RP_DEQUANTISE, RP_DEQUANTISE_LOGIT, RP_DEQUANTISE_LOG = 12, 13, 14
 
 _KNOWN = {
     "z-score": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
@@ -101,6 +106,11 @@ _KNOWN = {
     "angle-2pi": ("angle", dict(scale=1.0)),
     "periodic": ("angle", dict(scale=None)),
     "angle-pair": ("angle_pair", {}),
+    # Dequantise (reparameterisations/__init__.py:180-189, discrete.py:9-78): uniform noise on a discrete parameter,
+    # then RescaleToBounds on [min, max + 1]; floor() on the way back
+    "dequantise": ("to_bounds", dict(dequantise=True, update_bounds=False)),
+    "dequantise-logit": ("to_bounds", dict(dequantise=True, rescale_bounds=[0.0, 1.0], update_bounds=False,
+                                           post_rescaling="logit")),
 }
 _NON_SAMPLING = ("logP", "logL", "it")
 
@@ -205,6 +215,18 @@ class _Group:
             else:
                 self.rescale_bounds = {p: list(rb) for p in self.parameters}
             self.update_enabled = bool(kw.pop("update_bounds", True))
+            self.dequantise = bool(kw.pop("dequantise", False))
+            if self.dequantise:
+                if self.rng is None:
+                    raise RuntimeError("the dequantise reparameterisation needs the proposal's random generator")
+                if self.update_enabled:
+                    # (accepted by the reference's constructor "but not recommended" - its update then calls len() on
+                    # a scalar minimum: discrete.py:73-75, rescale.py:686-700)
+                    raise NotImplementedError("dequantise with update_bounds=True")
+                extra = [k for k in ("boundary_inversion", "inversion_type", "detect_edges", "detect_edges_kwargs",
+                                     "offset") if k in kw]
+                if extra:
+                    raise TypeError(f"Unknown arguments for reparameterisation {name}: {sorted(extra)}")
             self.post = kw.pop("post_rescaling", None)
             if self.post not in (None, "logit", "log"):
                 raise NotImplementedError(f"post_rescaling={self.post!r} has no device map")
@@ -332,6 +354,13 @@ class _Group:
         self.factor = {p: np.ptp(self.rescale_bounds[p]) for p in self.parameters}
         self.rshift = {p: self.rescale_bounds[p][0] for p in self.parameters}
         self.bounds = {p: self.prior_bounds[p] - self.offsets[p] for p in self.parameters}
+        if getattr(self, "dequantise", False):
+            # discrete.py:66-71: RescaleToBounds.set_bounds passes the prior bounds through the pre-rescaling first -
+            # two draws of two uniforms per parameter that are thrown away (the generator moves as the reference's
+            # does) - then the bounds become [min, max + 1]
+            for _ in range(2 * len(self.parameters)):
+                self.rng.random(2)
+            self.bounds = {p: np.array([b[0], b[1] + 1]) for p, b in self.prior_bounds.items()}
 
     def update(self, x):
         if self.kind == "to_bounds":
@@ -471,7 +500,8 @@ class _Group:
                 log_j -= np.log(np.abs(self.scale[p]))
             else:  # rescale.py:515-535, 639-671
                 lo, hi = self.bounds[p]
-                v = self.factor[p] * ((x[p] - self.offsets[p] - lo) / (hi - lo)) + self.rshift[p]
+                xin = x[p] + self.rng.random(len(x)) if self.dequantise else x[p]  # discrete.py:73-75
+                v = self.factor[p] * ((xin - self.offsets[p] - lo) / (hi - lo)) + self.rshift[p]
                 log_j += -np.log(hi - lo) + np.log(self.factor[p])
                 if self.post == "logit":
                     v, lj = _logit(v)
@@ -553,7 +583,7 @@ class _Group:
                 lo, hi = self.bounds[p]
                 v = (hi - lo) * (v - self.rshift[p]) / self.factor[p] + lo
                 log_j += np.log(hi - lo) - np.log(self.factor[p])
-                x[p] = v + self.offsets[p]
+                x[p] = np.floor(v + self.offsets[p]) if self.dequantise else v + self.offsets[p]  # discrete.py:77-78
         return log_j
 
 
@@ -802,6 +832,8 @@ class ReparameterisationTable:
                         log_j += np.log(hi - lo) - np.log(2)
                 else:
                     kind[i] = {None: RP_TO_BOUNDS, "logit": RP_TO_BOUNDS_LOGIT, "log": RP_TO_BOUNDS_LOG}[g.post]
+                    if g.dequantise:
+                        kind[i] += RP_DEQUANTISE - RP_TO_BOUNDS
                     lo, hi = g.bounds[p]
                     par[i] = [lo, hi, g.rshift[p], g.factor[p], g.offsets[p]]
                     log_j += np.log(hi - lo) - np.log(g.factor[p])

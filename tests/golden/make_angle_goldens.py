@@ -41,9 +41,16 @@ REPARAMETERISATIONS = {"a": "rescaletobounds", "phi": "angle-2pi", "psi": "angle
 
 
 class BoxModel(Model):
-    def __init__(self, names=NAMES, bounds=BOUNDS):
+    def __init__(self, names=NAMES, bounds=BOUNDS, discrete=()):
         self.names = list(names)
         self.bounds = {n: list(bounds[n]) for n in names}
+        self.discrete = tuple(discrete)
+
+    def new_point(self, N=1):
+        x = super().new_point(N)
+        for p in self.discrete:  # (the proposal checks its rescaling on points of the model: whole numbers here)
+            x[p] = np.floor(x[p])
+        return x
 
     def log_prior(self, x):
         log_p = np.log(self.in_bounds(x), dtype="float")
@@ -59,7 +66,7 @@ def stack(x, names):
     return np.stack([np.asarray(x[n], dtype=np.float64) for n in names], axis=1)
 
 
-def main(NAMES=NAMES, BOUNDS=BOUNDS, REPARAMETERISATIONS=REPARAMETERISATIONS, filename="angle_goldens.npz"):
+def main(NAMES=NAMES, BOUNDS=BOUNDS, REPARAMETERISATIONS=REPARAMETERISATIONS, filename="angle_goldens.npz", discrete=()):
     OUT = {}
     rng_data = np.random.default_rng(20261001)
     n, m = 157, 133
@@ -67,11 +74,13 @@ def main(NAMES=NAMES, BOUNDS=BOUNDS, REPARAMETERISATIONS=REPARAMETERISATIONS, fi
     for p in NAMES:
         lo, hi = BOUNDS[p]
         live[p] = lo + (hi - lo) * rng_data.beta(2.0, 3.0, size=n)
+        if p in discrete:  # integer values lo .. hi
+            live[p] = np.floor(lo + (hi + 1 - lo) * rng_data.random(n))
     OUT["live"] = stack(live, NAMES)
 
     rng = np.random.default_rng(170817)
     torch.manual_seed(170817)
-    model = BoxModel(NAMES, BOUNDS)
+    model = BoxModel(NAMES, BOUNDS, discrete)
     model.set_rng(rng)
     with tempfile.TemporaryDirectory() as tmp:
         prop = FlowProposal(model, rng=rng, poolsize=50, drawsize=400, output=tmp, plot=False,
