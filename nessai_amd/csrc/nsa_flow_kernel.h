@@ -222,7 +222,8 @@ struct NsaLaunch {
 enum { NSA_RP_SCALE_SHIFT = 0, NSA_RP_NULL = 1, NSA_RP_TO_BOUNDS = 2, NSA_RP_TO_BOUNDS_LOGIT = 3,
        NSA_RP_TO_BOUNDS_LOG = 4, NSA_RP_INVERT = 5, NSA_RP_MINUS_ONE_ONE = 6, NSA_RP_ANGLE = 7,
        NSA_RP_ANGLE_RADIAL = 8, NSA_RP_PAIR_H = 9, NSA_RP_PAIR_V = 10, NSA_RP_PAIR_R = 11,
-       NSA_RP_DEQUANTISE = 12, NSA_RP_DEQUANTISE_LOGIT = 13, NSA_RP_DEQUANTISE_LOG = 14 };
+       NSA_RP_DEQUANTISE = 12, NSA_RP_DEQUANTISE_LOGIT = 13, NSA_RP_DEQUANTISE_LOG = 14, NSA_RP_SS_SIGMOID = 15,
+       NSA_RP_SS_EXP = 16, NSA_RP_SS_GAUSSIAN_CDF = 17, NSA_RP_INV_GAUSSIAN_CDF_SS = 18 };
 
 enum { NSA_PRIOR_UNIFORM = 0, NSA_PRIOR_SINE = 1, NSA_PRIOR_COSINE = 2, NSA_PRIOR_POWER_LAW = 3,
        NSA_PRIOR_GAUSSIAN = 4, NSA_PRIOR_CHI = 5 };
@@ -1943,6 +1944,35 @@ __global__ void __launch_bounds__(HT >= NSA_WIDE_HT ? 256 : (OCC == 4 ? 1024 : (
           xv = (xp * e.scale[i]) + e.shift[i];
         } else if (kind == NSA_RP_NULL) {
           xv = xp;
+        } else if (kind >= NSA_RP_SS_SIGMOID && kind <= NSA_RP_INV_GAUSSIAN_CDF_SS) {
+          // the z-score of a rescaled parameter (reparameterisations/__init__.py:99-162; utils/rescaling.py:290-415):
+          // the affine map, then the inverse of the rescaling that sat in front of it - or, for the Gaussian CDF
+          // BEHIND the z-score, its inverse first
+          if (kind == NSA_RP_INV_GAUSSIAN_CDF_SS) {
+            const double v = -1.4142135623730951 * erfcinv(2.0 * xp);
+            log_j_row += 0.9189385332046727 + 0.5 * (v * v);
+            xv = (v * e.scale[i]) + e.shift[i];
+            // x' outside [0, 1] has no inverse: the reference gets NaN for the parameter and for log q, and KEEPS the
+            // row (its bounds test lets NaN through - as the one below does; such a row is never accepted and still
+            // counts as proposed).  Here: the parameter NaN, log q = +inf - this file's mark of such rows (a NaN
+            // log q is the mark of a DROPPED row); the device library's erfcinv promises nothing outside [0, 2].
+            if (!(xp >= 0.0 && xp <= 1.0)) {
+              xv = __longlong_as_double(0x7ff8000000000000LL);
+              log_j_row = -__builtin_huge_val();
+            }
+          } else {
+            const double v = (xp * e.scale[i]) + e.shift[i];
+            if (kind == NSA_RP_SS_SIGMOID) {
+              xv = 1.0 / (1.0 + exp(-v));
+              log_j_row += log(xv) + log1p(-xv);
+            } else if (kind == NSA_RP_SS_EXP) {
+              xv = exp(v);
+              log_j_row += v;
+            } else {
+              xv = 0.5 * erfc(-v / 1.4142135623730951);
+              log_j_row += -0.9189385332046727 - 0.5 * (v * v);
+            }
+          }
         } else if (kind == NSA_RP_INVERT) {
           const double* c = e.rp_par + 5 * i;
           double u = (xp < 0.0) ? -xp : xp;
@@ -1959,6 +1989,8 @@ __global__ void __launch_bounds__(HT >= NSA_WIDE_HT ? 256 : (OCC == 4 ? 1024 : (
           double a = atan2(cy, xp);
           if (c[1] != 0.0 && a < 0.0) a = a + 6.283185307179586;  // numpy's % (2 pi) of a value in [-pi, pi]
           xv = a / c[0];
+          // ToCartesian (angle.py:223-232): the mirrored parameter folded back, |angle| / scale in [0, 1] onto its bounds
+          if (c[2] != 0.0) xv = c[4] * fabs(xv) + c[3];
         } else if (kind == NSA_RP_ANGLE_RADIAL) {
           const double cx = (double)xrow[out_tab[i - 1]];
           xv = sqrt(cx * cx + xp * xp);

@@ -10,6 +10,10 @@ registry name                         map (x -> x')
 ``z-score`` ``zscore`` ``standardize``  ``ScaleAndShift`` with estimated mean / std
                                       (``rescale.py:119-312``)
 ``scaleandshift`` ``scale`` ``rescale``  ``ScaleAndShift`` / ``Rescale`` with fixed constants
+``z-score-logit`` ``log-z-score``       the z-score of ``logit(x)`` / ``log(x)`` / the inverse Gaussian CDF of x (a
+``log-standardise``                   rescaling in front of the affine map, statistics of the rescaled values), and
+``z-score-inv-gaussian-cdf``          ``z-score-gaussian-cdf``: the Gaussian CDF of the z-score (behind it)
+``z-score-gaussian-cdf`` (+ ``zscore-``)  (``reparameterisations/__init__.py:99-162``, ``utils/rescaling.py:290-415``)
 ``default`` ``rescaletobounds``        ``RescaleToBounds`` to [-1, 1], bounds updated from the live
 ``rescale-to-bounds`` ``angle-sine``   points (``rescale.py:321-731``)
 ``angle-cosine``
@@ -31,6 +35,9 @@ registry name                         map (x -> x')
 ``dequantise`` ``dequantise-logit``   ``Dequantise`` (``discrete.py:9-78``): a discrete parameter plus uniform noise (the
                                       proposal's generator), rescaled on [min, max + 1] (then ``logit``); back:
                                       the inverse map, then ``floor``
+``to-cartesian``                      ``ToCartesian`` (``angle.py:189-232``): a bounded parameter on [0, 1], mirrored
+                                      (``mode`` split: half of the rows; duplicate: every row twice; half: none),
+                                      times pi, then as an angle; back: ``|angle| / pi`` onto the bounds
 ``angle-pair``                        ``AnglePair`` (``angle.py:186-538``): two angles -> ``r`` times the unit vector they
                                       point along, ``r`` an auxiliary radius from chi(3); conventions ``ra-dec``
                                       (vertical angle on [-pi/2, pi/2]) and ``az-zen`` ([0, pi]) found from the bounds
@@ -48,8 +55,7 @@ A PAIR of angles (``angle-pair``, angle.py:186-538: a direction - right ascensio
 becomes a point of space: x' has THREE columns (``<h>_<v>_x``, ``_y``, ``_z``) where the pair's first parameter sat,
 x gains ``<h>_<v>_radial`` with a chi(3) prior, and the device columns are (horizontal, vertical, radius).
 
-``to-cartesian``, an angle or a pair with a radial parameter of the model and user-defined classes raise
-``NotImplementedError`` here.
+An angle or a pair with a radial parameter of the model and user-defined classes raise ``NotImplementedError`` here.
 
 The configuration forms are the reference's (``reparameterisations/utils.py:120-268``):
 ``None`` | ``"name"`` | ``{parameter: "name"}`` | ``{parameter: {"reparameterisation": "name",
@@ -78,11 +84,25 @@ RP_ANGLE, RP_ANGLE_RADIAL = 7, 8
 RP_PAIR_H, RP_PAIR_V, RP_PAIR_R = 9, 10, 11
 # a discrete parameter (discrete.py:9-78): the three rescale-to-bounds kinds followed by floor()
 RP_DEQUANTISE, RP_DEQUANTISE_LOGIT, RP_DEQUANTISE_LOG = 12, 13, 14
+# scale-and-shift with a rescaling in front of it (x' * scale + shift, then sigmoid / exp / Gaussian CDF on the way back)
+# or behind it (inverse Gaussian CDF of x' first): rescale.py:119-312, utils/rescaling.py:290-415
+RP_SS_SIGMOID, RP_SS_EXP, RP_SS_GAUSSIAN_CDF, RP_INV_GAUSSIAN_CDF_SS = 15, 16, 17, 18
 
 _KNOWN = {
     "z-score": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
     "zscore": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
     "standardize": ("scale_shift", dict(estimate_scale=True, estimate_shift=True)),
+    # (reparameterisations/__init__.py:99-162: the z-score with a rescaling in front of it or behind it)
+    "zscore-gaussian-cdf": ("scale_shift", dict(estimate_scale=True, estimate_shift=True, post_rescaling="gaussian_cdf")),
+    "z-score-gaussian-cdf": ("scale_shift", dict(estimate_scale=True, estimate_shift=True, post_rescaling="gaussian_cdf")),
+    "z-score-logit": ("scale_shift", dict(estimate_scale=True, estimate_shift=True, pre_rescaling="logit")),
+    "zscore-logit": ("scale_shift", dict(estimate_scale=True, estimate_shift=True, pre_rescaling="logit")),
+    "z-score-inv-gaussian-cdf": ("scale_shift", dict(estimate_scale=True, estimate_shift=True,
+                                                     pre_rescaling="inv_gaussian_cdf")),
+    "zscore-inv-gaussian-cdf": ("scale_shift", dict(estimate_scale=True, estimate_shift=True,
+                                                    pre_rescaling="inv_gaussian_cdf")),
+    "log-z-score": ("scale_shift", dict(estimate_scale=True, estimate_shift=True, pre_rescaling="log")),
+    "log-standardise": ("scale_shift", dict(estimate_scale=True, estimate_shift=True, pre_rescaling="log")),
     "scaleandshift": ("scale_shift", {}),
     "scale": ("scale_shift", {}),
     "rescale": ("scale_shift", {}),
@@ -105,6 +125,9 @@ _KNOWN = {
     "angle-pi": ("angle", dict(scale=2.0)),
     "angle-2pi": ("angle", dict(scale=1.0)),
     "periodic": ("angle", dict(scale=None)),
+    # ToCartesian (reparameterisations/__init__.py:179, angle.py:189-232): any bounded parameter to [0, 1], mirrored,
+    # times pi: an angle of the half plane (split / half) or of the plane
+    "to-cartesian": ("angle", dict(scale=np.pi, cartesian=True)),
     "angle-pair": ("angle_pair", {}),
     # Dequantise (reparameterisations/__init__.py:180-189, discrete.py:9-78): uniform noise on a discrete parameter,
     # then RescaleToBounds on [min, max + 1]; floor() on the way back
@@ -120,6 +143,35 @@ def _logit(x):
     with np.errstate(divide="ignore", invalid="ignore"):
         log_j = -np.log(x) - np.log1p(-x)
         return np.log(x) - np.log1p(-x), log_j
+
+
+def _gaussian_cdf(x):
+    """(``utils/rescaling.py:398-402``)."""
+    from scipy.special import erfc
+
+    log_j = -0.5 * np.log(2 * np.pi) - 0.5 * (x ** 2.0)
+    return 0.5 * erfc(-x / np.sqrt(2.0)), log_j
+
+
+def _inverse_gaussian_cdf(x):
+    """(``utils/rescaling.py:405-409``)."""
+    from scipy.special import erfcinv
+
+    x = -np.sqrt(2) * erfcinv(2.0 * x)
+    return x, 0.5 * np.log(2 * np.pi) + 0.5 * (x ** 2.0)
+
+
+def _log(x):
+    """(``utils/rescaling.py:359-375``)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        y = np.log(x)
+    return y, -y
+
+
+def _exp(x):
+    """(``utils/rescaling.py:378-395``)."""
+    with np.errstate(over="ignore"):
+        return np.exp(x), np.array(x, dtype=np.float64, copy=True)
 
 
 def _sigmoid(x):
@@ -202,6 +254,16 @@ class _Group:
             else:
                 self.shift = None
             self.update_enabled = self.estimate_scale or self.estimate_shift
+            # a rescaling in front of the affine map or behind it (rescale.py:180-181, base.py): the ones with a
+            # device map - logit / log / inverse Gaussian CDF in front, Gaussian CDF behind, not both
+            pre, post = kw.pop("pre_rescaling", None), kw.pop("post_rescaling", None)
+            pre = "inv_gaussian_cdf" if pre == "inverse_gaussian_cdf" else pre
+            if pre not in (None, "logit", "log", "inv_gaussian_cdf") or post not in (None, "gaussian_cdf") or (pre and post):
+                raise NotImplementedError(f"pre_rescaling={pre!r}, post_rescaling={post!r} has no device map")
+            self.ss_pre, self.ss_post = pre, post
+            self._pre = {None: None, "logit": (_logit, _sigmoid), "log": (_log, _exp),
+                         "inv_gaussian_cdf": (_inverse_gaussian_cdf, _gaussian_cdf)}[pre]
+            self._post = {None: None, "gaussian_cdf": (_gaussian_cdf, _inverse_gaussian_cdf)}[post]
         elif kind == "to_bounds":
             missing = [p for p in self.parameters if p not in prior_bounds or not np.all(np.isfinite(prior_bounds[p]))]
             if missing:
@@ -290,6 +352,14 @@ class _Group:
             scale = kw.pop("scale", 1.0)
             self.angle_scale = float(2.0 * np.pi / np.ptp(self.prior_bounds[p])) if scale is None else float(scale)
             self.zero_bound = bool(self.prior_bounds[p][0] == 0)  # angle.py:79-82: modulo 2 pi on the way back
+            # ToCartesian (angle.py:189-232): the parameter on [0, 1] first, mirrored - "split": half of the rows,
+            # "duplicate": every row twice, "half": not at all - then times the scale; back: |angle| / scale on [0, 1]
+            self.cartesian = bool(kw.pop("cartesian", False))
+            if self.cartesian:
+                self.mode = kw.pop("mode", "split")
+                if self.mode not in ("duplicate", "split", "half"):
+                    raise RuntimeError(f"Unknown mode: {self.mode}")
+                self.zero_bound = False  # angle.py:200
             self.update_enabled = False
         elif kind == "angle_pair":
             # two angles -> Cartesian coordinates with an auxiliary radius drawn from chi(3) (angle.py:214-376); the
@@ -369,10 +439,11 @@ class _Group:
             return
         if self.kind == "scale_shift":  # rescale.py:293-304
             for p in self.parameters:
+                x_pre = self._pre[0](x[p])[0] if self._pre else x[p]
                 if self.estimate_scale:
-                    self.scale[p] = np.std(x[p])
+                    self.scale[p] = np.std(x_pre)
                 if self.estimate_shift:
-                    self.shift[p] = np.mean(x[p])
+                    self.shift[p] = np.mean(x_pre)
         elif self.kind == "to_bounds":  # rescale.py:720-741
             self.bounds = {
                 p: [np.min(x[p]) - self.offsets[p], np.max(x[p]) - self.offsets[p]] for p in self.parameters
@@ -459,7 +530,21 @@ class _Group:
             if self.rng is None:
                 raise RuntimeError("the angle reparameterisation needs the proposal's random generator")
             p = self.parameters[0]
-            angle = x[p] * self.angle_scale
+            if self.cartesian:  # angle.py:203-221
+                lo, hi = self.prior_bounds[p]
+                angle = (x[p] - lo) / (hi - lo)
+                log_j = log_j - np.log(hi - lo)
+                if self.mode == "duplicate" or compute_radius:
+                    angle = np.concatenate([angle, -angle])
+                    x = _concat_structured(x, x)
+                    x_prime = _concat_structured(x_prime, x_prime)
+                    log_j = np.concatenate([log_j, log_j])
+                elif self.mode == "split":
+                    neg = self.rng.choice(angle.size, angle.size // 2, replace=False)
+                    angle[neg] *= -1
+                angle = angle * self.angle_scale
+            else:
+                angle = x[p] * self.angle_scale
             r = stats.chi(2).rvs(size=x.size, random_state=self.rng)
             x_prime[p + "_x"] = r * np.cos(angle)
             x_prime[p + "_y"] = r * np.sin(angle)
@@ -493,11 +578,19 @@ class _Group:
             if self.kind == "null":
                 x_prime[pp] = x[p]
             elif self.kind == "scale_shift":  # rescale.py:233-261
+                v = x[p]
+                if self._pre:
+                    v, lj = self._pre[0](v)
+                    log_j += lj
                 if self.shift:
-                    x_prime[pp] = (x[p] - self.shift[p]) / self.scale[p]
+                    v = (v - self.shift[p]) / self.scale[p]
                 else:
-                    x_prime[pp] = x[p] / self.scale[p]
+                    v = v / self.scale[p]
                 log_j -= np.log(np.abs(self.scale[p]))
+                if self._post:
+                    v, lj = self._post[0](v)
+                    log_j += lj
+                x_prime[pp] = v
             else:  # rescale.py:515-535, 639-671
                 lo, hi = self.bounds[p]
                 xin = x[p] + self.rng.random(len(x)) if self.dequantise else x[p]  # discrete.py:73-75
@@ -525,6 +618,10 @@ class _Group:
                 angle = np.arctan2(cy, cx) / self.angle_scale
             log_j -= np.log(radial)
             x[p + "_radial"] = radial
+            if self.cartesian:  # angle.py:223-232
+                lo, hi = self.prior_bounds[p]
+                angle = (hi - lo) * np.abs(angle) + lo
+                log_j += np.log(hi - lo)
             x[p] = angle
             return log_j
         if self.kind == "angle_pair":  # angle.py:434-507
@@ -552,11 +649,19 @@ class _Group:
             if self.kind == "null":
                 x[p] = x_prime[pp]
             elif self.kind == "scale_shift":  # rescale.py:263-291
+                v = x_prime[pp]
+                if self._post:
+                    v, lj = self._post[1](v)
+                    log_j += lj
                 if self.shift:
-                    x[p] = (x_prime[pp] * self.scale[p]) + self.shift[p]
+                    v = (v * self.scale[p]) + self.shift[p]
                 else:
-                    x[p] = x_prime[pp] * self.scale[p]
+                    v = v * self.scale[p]
                 log_j += np.log(np.abs(self.scale[p]))
+                if self._pre:
+                    v, lj = self._pre[1](v)
+                    log_j += lj
+                x[p] = v
             elif self.inversion and p in self.inversion:  # rescale.py:585-612
                 v = x_prime[pp]
                 lo, hi = self.bounds[p]
@@ -774,7 +879,7 @@ class ReparameterisationTable:
 
     @property
     def all_scale_shift(self):
-        return all(g.kind == "scale_shift" for g in self.groups)
+        return all(g.kind == "scale_shift" and not (g.ss_pre or g.ss_post) for g in self.groups)
 
     def device_bounds(self, lower, upper):
         """Per device column: the model's bounds of its parameter; [0, inf) for an auxiliary radius."""
@@ -813,10 +918,17 @@ class ReparameterisationTable:
                     # coordinate -> the radius (and the row's -log(radius) of the Jacobian)
                     kind[i], kind[i + 1] = RP_ANGLE, RP_ANGLE_RADIAL
                     par[i] = [g.angle_scale, 1.0 if g.zero_bound else 0.0, 0.0, 0.0, 0.0]
+                    if g.cartesian:  # {.., fold |angle| / scale onto [lo, lo + width]: flag, lo, width}
+                        lo, hi = g.prior_bounds[p]
+                        par[i][2:] = [1.0, lo, hi - lo]
+                        log_j += np.log(hi - lo)
                 elif g.kind == "null":
                     kind[i] = RP_NULL
                 elif g.kind == "scale_shift":
-                    kind[i] = RP_SCALE_SHIFT
+                    kind[i] = {None: RP_SCALE_SHIFT, "logit": RP_SS_SIGMOID, "log": RP_SS_EXP,
+                               "inv_gaussian_cdf": RP_SS_GAUSSIAN_CDF}[g.ss_pre]
+                    if g.ss_post:
+                        kind[i] = RP_INV_GAUSSIAN_CDF_SS
                     scale[i] = g.scale[p]
                     shift[i] = g.shift[p] if g.shift else 0.0
                     log_j += np.log(np.abs(g.scale[p]))

@@ -66,7 +66,7 @@ def stack(x, names):
     return np.stack([np.asarray(x[n], dtype=np.float64) for n in names], axis=1)
 
 
-def main(NAMES=NAMES, BOUNDS=BOUNDS, REPARAMETERISATIONS=REPARAMETERISATIONS, filename="angle_goldens.npz", discrete=()):
+def main(NAMES=NAMES, BOUNDS=BOUNDS, REPARAMETERISATIONS=REPARAMETERISATIONS, filename="angle_goldens.npz", discrete=(), latent_scale=1.2):
     OUT = {}
     rng_data = np.random.default_rng(20261001)
     n, m = 157, 133
@@ -98,6 +98,8 @@ def main(NAMES=NAMES, BOUNDS=BOUNDS, REPARAMETERISATIONS=REPARAMETERISATIONS, fi
         OUT["x_prime"] = stack(x_prime, primes)
         OUT["log_j"] = np.asarray(log_j, dtype=np.float64)
         xp_values = rng_data.normal(0.0, 1.2, size=(m, len(primes)))
+        if latent_scale != 1.2:  # (x' of a Gaussian-CDF column lives in (0, 1))
+            xp_values = 0.5 + 0.25 * np.tanh(xp_values)
         OUT["xp_in"] = xp_values
         xp_in = empty_structured_array(m, names=primes)
         for i, pp in enumerate(primes):
@@ -112,7 +114,7 @@ def main(NAMES=NAMES, BOUNDS=BOUNDS, REPARAMETERISATIONS=REPARAMETERISATIONS, fi
         # the fused path: backward_pass on fixed latents (x incl. the auxiliary radii, log_q), its weights
         for k, v in prop.flow.model.state_dict().items():
             OUT[f"state/{k}"] = v.detach().cpu().numpy()
-        z = rng_data.normal(size=(400, len(primes))).astype(np.float32).astype(np.float64) * 1.2
+        z = rng_data.normal(size=(400, len(primes))).astype(np.float32).astype(np.float64) * latent_scale
         OUT["bp_z"] = z
         x, log_q, z_kept = prop.backward_pass(z.copy(), rescale=True, return_z=True)
         names_x = [f for f in x.dtype.names if f not in ("logP", "logL", "it")]

@@ -283,3 +283,76 @@ def test_gw_sky_position_as_an_angle_pair():
     want = (model.log_prior(x) + stats.chi(2).logpdf(x["psi_radial"]) + stats.chi(2).logpdf(x["phase_radial"])
             + stats.chi(3).logpdf(x["ra_dec_radial"]))
     np.testing.assert_allclose(prop.log_prior(x), want, rtol=1e-13)
+
+
+# -- to-cartesian (angle.py:189-232; goldens: tests/golden/make_to_cartesian_goldens.py) -----------------------------------
+
+CART_GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "to_cartesian_goldens.npz"))
+CART_NAMES = ["s", "c", "d", "h"]
+CART_BOUNDS = {"s": [-3.0, 7.0], "c": [0.5, 2.5], "d": [2.0, 5.0], "h": [0.0, 1.5]}
+CART_CONFIG = {"s": "to-cartesian", "c": "z-score", "d": {"reparameterisation": "to-cartesian", "mode": "duplicate"},
+               "h": {"reparameterisation": "to-cartesian", "mode": "half"}}
+
+
+class CartModel(UniformBoxModel):
+    def __init__(self):
+        self.names = list(CART_NAMES)
+        self.bounds = {n: list(CART_BOUNDS[n]) for n in CART_NAMES}
+
+    def log_likelihood(self, x):
+        return -0.5 * np.sum(self.unstructured_view(x) ** 2, axis=-1)
+
+
+@pytest.mark.parametrize("prior", ["device", "host"])
+def test_to_cartesian_proposal_matches_the_reference(prior):
+    """The three modes in one proposal (split, duplicate - ``rescale`` returns twice the rows -, half): x' against the
+    reference bit for bit, the fused kernel's fold |atan2| / pi -> bounds, radii, log q and weights to float32."""
+    prop = FlowProposal(CartModel(), rng=np.random.default_rng(4242), poolsize=50, drawsize=400, device_seed=1,
+                        flow_config=dict(ftype="realnvp", n_blocks=2, n_neurons=8, n_layers=1,
+                                         batch_norm_between_layers=False, linear_transform="permutation"),
+                        reparameterisations=CART_CONFIG, prior=prior)
+    prop.initialise()
+    g = CART_GOLD
+    state = {k[len("state/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("state/")}
+    prop.flow.model.load_state_dict(state)
+    prop.flow.model.eval()
+    live = numpy_array_to_live_points(g["live"], CART_NAMES)
+    prop.check_state(live)
+    assert prop.prime_parameters == [str(p) for p in g["prime_parameters"]] and prop.dims == 7
+    assert prop.names == ["s", "s_radial", "c", "d", "d_radial", "h", "h_radial"]
+    prop.rng.bit_generator.state = np.random.default_rng(4242).bit_generator.state
+    x_prime, log_j = prop.rescale(live)
+    assert len(x_prime) == 2 * len(live)
+    assert np.array_equal(stack(x_prime, prop.prime_parameters), g["x_prime"])
+    assert np.array_equal(log_j, g["log_j"])
+    x, log_q, z_kept = prop.backward_pass(g["bp_z"], return_z=True)
+    assert np.array_equal(z_kept, g["bp_z_kept"])
+    names = [str(n) for n in g["bp_names"]]
+    np.testing.assert_allclose(stack(x, names), g["bp_x"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(log_q, g["bp_log_q"], rtol=1e-5, atol=5e-5)
+    with np.errstate(divide="ignore"):
+        log_w = prop.compute_weights(x, log_q)
+    np.testing.assert_allclose(log_w, g["bp_log_w"], rtol=1e-5, atol=5e-5)
+
+
+def test_populate_with_to_cartesian(tmp_path):
+    model = CartModel()
+
+    def run(lean):
+        torch.manual_seed(3)
+        prop = FlowProposal(model, rng=np.random.default_rng(5), poolsize=300, drawsize=30_000, device_seed=11,
+                            flow_config=dict(ftype="nsf", n_neurons=16, n_blocks=2),
+                            training_config=dict(max_epochs=20, patience=20, batch_size=500),
+                            reparameterisations=CART_CONFIG, lean=lean, output=str(tmp_path / ("lean" if lean else "full")))
+        prop.initialise()
+        live = model.new_point(1000, rng=np.random.default_rng(1))
+        live["logL"] = model.log_likelihood(live)
+        prop.train(live)  # (2000 training rows: the duplicate mode)
+        prop.populate(live[0], n_samples=300, max_samples=10**8)
+        return prop
+
+    a, b = run(True), run(False)
+    assert a.n_proposed == b.n_proposed and np.array_equal(stack(a.samples, CART_NAMES), stack(b.samples, CART_NAMES))
+    assert len(a.samples) == 300 and model.in_bounds(a.samples).all()
+    assert list(a.samples.dtype.names) == CART_NAMES + ["logP", "logL", "it"]
+    assert np.array_equal(a.samples["logP"], model.log_prior(a.samples))
