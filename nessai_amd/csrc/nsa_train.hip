@@ -1610,17 +1610,24 @@ static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, lo
 
 // The fused backward kernels of the second generation leave each workgroup's share of the weight gradients
 // in its own copy of the flat gradient vector and one kernel sums the copies in a fixed order (below a cap
-// on the copies' size; above it the kernels add to the flat gradient with float atomics as the first generation does)
+// on the copies' size; above it the second generation adds to the flat gradient with float atomics as the first
+// generation does, and 128-wide conditioners go back to the first generation's backward kernel)
 // rows per workgroup of the fused backward kernels that write gradient copies: 16 for 128-wide conditioners (the
 // 16-row kernels of nsa_train_fused3.h), 32 otherwise (second generation)
 static inline long long tr_slab_rows(const long long* plan) { return plan[1] == 128 ? 16 : 32; }
 static inline int tr_slab_copies(const long long* plan, long long n) {
   return (int)((n + tr_slab_rows(plan) - 1) / tr_slab_rows(plan));
 }
+// (the cap on the copies' size: NESSAI_AMD_TRAIN_SLAB_MB, default 4096 - read ONCE per process: the workspace a caller
+// allocated and the carve of a later call must agree on it)
 static long long tr_slab_floats(const long long* plan, long long n) {
   const long long grid = tr_slab_copies(plan, n);
   const long long words = grid * al4(plan[8]);
-  return (plan[11] == NSA_NET_RESNET && plan[1] <= 128 && words <= (64LL << 20)) ? words : 0;
+  static const long long cap = [] {
+    const char* e = getenv("NESSAI_AMD_TRAIN_SLAB_MB");
+    return (e != nullptr ? atoll(e) : 4096LL) << 18;  // MB -> floats
+  }();
+  return (plan[11] == NSA_NET_RESNET && plan[1] <= 128 && words <= cap) ? words : 0;
 }
 
 extern "C" NSA_API size_t nsa_train_workspace_floats(const long long* plan, long long n) {
@@ -1857,9 +1864,12 @@ template <int K>
 static hipError_t tr_launch_fused(bool backward, const TrfArgs& a, hipStream_t s) {
   if (backward && tr_v2_fits(true, a))
     return a.H <= 32 ? tr_launch_fused2<K, 1>(backward, a, s) : tr_launch_fused2<K, 2>(backward, a, s);
-  if (tr_v4_fits(backward, a)) {
+  // (the 16-row backward kernel only with gradient copies: adding to the flat gradient with float atomics from twice
+  // as many workgroups it is slower than the first generation - 1.36 against 1.13 ms per step at 1100 rows of config
+  // 4's flow, 7.3 against 1.55 at 8000; profiles/r06_train_batch_sizes.jsonl)
+  if (tr_v4_fits(backward, a) && (!backward || a.gslab != nullptr)) {
     const size_t lds4 = (backward ? trf4_backward_floats(a) : trf4_forward_floats(a)) * sizeof(float);
-    auto kern4 = backward ? (a.gslab != nullptr ? trf4_backward<K, true> : trf4_backward<K, false>) : trf4_forward<K>;
+    auto kern4 = backward ? trf4_backward<K, true> : trf4_forward<K>;
     hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern4),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
     if (e4 != hipSuccess) return e4;

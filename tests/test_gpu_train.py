@@ -389,6 +389,38 @@ def test_third_generation_fused_kernels_match_the_first(name, monkeypatch):
     assert rel_err(lp0, lp1) <= 2e-6
 
 
+def test_third_generation_kernels_with_many_gradient_copies():
+    """1100 rows of config 4's shape: 69 per-workgroup gradient copies, summed in a fixed order - more than one wave of
+    workgroups' worth, and past the 256 MB that used to cap them."""
+    ref, flow, D = pair("nsf_c4")
+    x = torch.randn(1100, D, generator=torch.Generator().manual_seed(5)) * 1.5
+    ref.train()
+    loss_ref = -ref.log_prob(x).mean()
+    loss_ref.backward()
+    g_ref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    tr = Trainer(flow)
+    tr.step(x.to(DEV), clip_norm=5.0, lr=0.0)
+    torch.cuda.synchronize()
+    assert abs(tr.loss_acc.item() - loss_ref.item()) <= 1e-5 * max(1.0, abs(loss_ref.item()))
+    g = tr.grads.cpu()
+    scale = max(1e-3, float(g_ref.abs().max()))
+    assert float((g - g_ref).abs().max()) <= 2e-4 * scale
+    assert rel_err(torch.linalg.norm(g), torch.linalg.norm(g_ref), floor=1e-6) <= 1e-4
+
+
+def test_beyond_the_gradient_copy_cap_the_first_generation_backward_takes_over():
+    """NESSAI_AMD_TRAIN_SLAB_MB (read once per process: a child process here) caps the gradient copies; beyond it the
+    16-row forward kernel runs with the first generation's backward kernel (float atomics) - the same gradients."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, NESSAI_AMD_TRAIN_SLAB_MB="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                          "-k", "test_loss_and_gradients_match_autograd and (nsf_c4 or nsf_d9_h128 or nsf_c3)"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "3 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("name", ["nsf_c3", "nsf_d7_k4", "nsf_d6_tanh", "rnvp_perm", "rnvp_additive", "nsf_bn_lu"])
 def test_fused_coupling_kernels_match_the_layer_wise_kernels(name, monkeypatch):
     """The fused per-coupling kernels (nsa_train_fused.h) and the layer-wise kernels are two
