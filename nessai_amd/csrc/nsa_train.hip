@@ -1612,9 +1612,10 @@ static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, lo
 // in its own copy of the flat gradient vector and one kernel sums the copies in a fixed order (below a cap
 // on the copies' size; above it the second generation adds to the flat gradient with float atomics as the first
 // generation does, and 128-wide conditioners go back to the first generation's backward kernel)
-// rows per workgroup of the fused backward kernels that write gradient copies: 16 for 128-wide conditioners (the
-// 16-row kernels of nsa_train_fused3.h), 32 otherwise (second generation)
-static inline long long tr_slab_rows(const long long* plan) { return plan[1] == 128 ? 16 : 32; }
+// rows per workgroup of the fused backward kernels that write gradient copies: 16 for conditioners 80 / 96 / 112 /
+// 128 wide (the 16-row kernels of nsa_train_fused3.h), 32 otherwise (second generation)
+static inline bool tr_v4_width(long long H) { return H > 64 && H <= 128 && H % 16 == 0; }
+static inline long long tr_slab_rows(const long long* plan) { return tr_v4_width(plan[1]) ? 16 : 32; }
 static inline int tr_slab_copies(const long long* plan, long long n) {
   return (int)((n + tr_slab_rows(plan) - 1) / tr_slab_rows(plan));
 }
@@ -1843,7 +1844,7 @@ static hipError_t tr_launch_fused2(bool backward, const TrfArgs& a, hipStream_t 
   return hipGetLastError();
 }
 
-// third-generation kernels (nsa_train_fused3.h): 128-wide conditioners on 16-row workgroups; NESSAI_AMD_TRAIN_V3=0
+// third-generation kernels (nsa_train_fused3.h): conditioners 80 / 96 / 112 / 128 wide on 16-row workgroups; NESSAI_AMD_TRAIN_V3=0
 // keeps the first generation (the cross-check of the tests)
 static bool tr_v3_enabled() {
   const char* e = getenv("NESSAI_AMD_TRAIN_V3");
@@ -1851,7 +1852,7 @@ static bool tr_v3_enabled() {
 }
 static bool tr_v4_fits(bool backward, const TrfArgs& a) {  // 16-row kernels
   if (!tr_v3_enabled()) return false;
-  if (a.H != 128 || a.D > 128 || a.np > 768 || a.d_id > 128) return false;
+  if (!tr_v4_width(a.H) || a.D > 128 || a.np > 768 || a.d_id > 128) return false;
   if (!backward) return trf4_forward_floats(a) * sizeof(float) <= 160 * 1024;
   // parameter rows and tiles in 16-byte units, one transform item per thread, <= 7 activation tiles through registers
   return a.np % 4 == 0 && a.d_tr <= 32 && a.L <= 3 && a.off[2 + 4 * a.L] % 4 == 0 &&
@@ -1869,7 +1870,8 @@ static hipError_t tr_launch_fused(bool backward, const TrfArgs& a, hipStream_t s
   // 4's flow, 7.3 against 1.55 at 8000; profiles/r06_train_batch_sizes.jsonl)
   if (tr_v4_fits(backward, a) && (!backward || a.gslab != nullptr)) {
     const size_t lds4 = (backward ? trf4_backward_floats(a) : trf4_forward_floats(a)) * sizeof(float);
-    auto kern4 = backward ? trf4_backward<K, true> : trf4_forward<K>;
+    auto kern4 = backward ? (a.H == 128 ? trf4_backward<K, true, 128> : trf4_backward<K, true, 0>)
+                          : (a.H == 128 ? trf4_forward<K, 128> : trf4_forward<K, 0>);
     hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern4),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
     if (e4 != hipSuccess) return e4;

@@ -1,8 +1,10 @@
 // Third generation of the fused training kernels (included by nsa_train.hip after nsa_train_fused2.h; same TrfArgs,
-// same workspace layout, same results up to the order of the float32 sums): 128-wide conditioners (config 4's
-// importance-sampling flows: 64 inputs, 128-wide residual nets, 736 spline parameters per row), one coupling layer
-// per launch, forward and backward, on 16-ROW workgroups and v_mfma_f32_16x16x4_f32 tiles - config 4's optimiser
-// step 1.24 -> 0.63 ms.  Other widths above 64 stay with the first generation.
+// same workspace layout, same results up to the order of the float32 sums): conditioners 80, 96, 112 or 128 wide
+// (config 4's importance-sampling flows: 64 inputs, 128-wide residual nets, 736 spline parameters per row; the
+// reference's default n_neurons = 2 n_inputs for 40 to 64 inputs), one coupling layer per launch, forward and
+// backward, on 16-ROW workgroups and v_mfma_f32_16x16x4_f32 tiles - config 4's optimiser step 1.24 -> 0.63 ms.
+// The 128-wide instances have every size at compile time; the others take the width at run time and skip the MFMA
+// steps and tiles beyond it.  Other widths above 64 stay with the first generation.
 //
 // What the first generation spends its time on at this width (profiles/r04_train_c4_kernels.txt: forward 65 us,
 // backward 118 us per coupling for a 32-row workgroup whose MFMAs take 20 / 40 us): a hidden layer has four output
@@ -53,20 +55,23 @@ __device__ __forceinline__ f32x4v trf4_bload4(R rsrc, unsigned voff_bytes, unsig
 
 // B operands of the wave's output tile (columns 16 wave + lane % 16) of a layer with 128 outputs from the transposed
 // weights W^T[Kd][128] at flat offset offW: step q holds k = 4 q + lane / 16.  FULL: Kd == 128.
+// H: the layer's width (a multiple of 16, at most 128; steps beyond Kd = H read on into the flat vector - finite
+// values no MFMA uses; waves whose tile lies beyond H likewise).
 template <bool FULL, typename RT, typename RP>
 __device__ __forceinline__ void trf4_load_w(float (&w)[TRF4_Q], float& bias, RT rsrcT, RP rsrcP, long long offW,
-                                            long long offB, int Kd, int wave, int lane) {
+                                            long long offB, int Kd, int H, int wave, int lane) {
   const int i16 = lane & 15, kg = lane >> 4;
   const unsigned s0 = 4u * ((unsigned)offW + 16u * (unsigned)wave);
   if constexpr (FULL) {
-    const unsigned voff = 4u * ((unsigned)kg * 128u + (unsigned)i16);
+    const unsigned voff = 4u * ((unsigned)kg * (unsigned)H + (unsigned)i16);
+    const unsigned step = 16u * (unsigned)H;
 #pragma unroll
-    for (int q = 0; q < TRF4_Q; ++q) w[q] = trf4_bload(rsrcT, voff, s0 + 2048u * q);
+    for (int q = 0; q < TRF4_Q; ++q) w[q] = trf4_bload(rsrcT, voff, s0 + step * q);
   } else {
 #pragma unroll
     for (int q = 0; q < TRF4_Q; ++q) {
       const int k = 4 * q + kg;
-      w[q] = trf4_bload(rsrcT, 4u * ((unsigned)(k < Kd ? k : Kd - 1) * 128u + (unsigned)i16), s0);
+      w[q] = trf4_bload(rsrcT, 4u * ((unsigned)(k < Kd ? k : Kd - 1) * (unsigned)H + (unsigned)i16), s0);
     }
   }
   bias = trf4_bload(rsrcP, 4u * (unsigned)i16, 4u * ((unsigned)offB + 16u * (unsigned)wave));
@@ -75,12 +80,14 @@ __device__ __forceinline__ void trf4_load_w(float (&w)[TRF4_Q], float& bias, RT 
 
 // out[row][col] = sum_k act(Ain[row][k]) W[col][k] + b[col] (+ R[row][col]) for the wave's 16 columns of the
 // workgroup's 16 rows; the tile is WRITTEN, not yet published.  GATHER: A from the x tile, column of step q in cidx[q].
-template <bool GATHER>
+// HH: 128 (the steps and tiles are all there: no guards) or 0 (H at run time: steps 4 q >= Kd and tiles beyond H skipped).
+template <bool GATHER, int HH>
 __device__ __forceinline__ void trf4_layer(const float* __restrict__ Ain, int act_in, const float (&w)[TRF4_Q],
-                                           const int (&cidx)[TRF4_Q], float bias, int Kd, const float* R,
+                                           const int (&cidx)[TRF4_Q], float bias, int Kd, int H, const float* R,
                                            float* out_tile, float* __restrict__ out_glb, int r0, int rows_here,
                                            int wave, int lane) {
   const int i16 = lane & 15, kg = lane >> 4;
+  if (HH == 0 && 16 * wave >= H) return;  // wave-uniform
   float av[TRF4_Q], rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   f32x4v acc = {0}, acc2 = {0};
   if constexpr (GATHER) {
@@ -108,8 +115,10 @@ __device__ __forceinline__ void trf4_layer(const float* __restrict__ Ain, int ac
     trf_act_batch(av, act_in);
 #pragma unroll
     for (int q = 0; q < TRF4_Q; q += 2) {
-      acc = trf4_mfma(av[q], w[q], acc);
-      acc2 = trf4_mfma(av[q + 1], w[q + 1], acc2);
+      if (HH != 0 || 4 * q < Kd) {  // uniform (Kd a multiple of 8 here: H % 16 == 0)
+        acc = trf4_mfma(av[q], w[q], acc);
+        acc2 = trf4_mfma(av[q + 1], w[q + 1], acc2);
+      }
     }
   }
   const int col = 16 * wave + i16;
@@ -118,7 +127,7 @@ __device__ __forceinline__ void trf4_layer(const float* __restrict__ Ain, int ac
     const int row = 4 * kg + r;
     const float v = acc[r] + acc2[r] + bias + rv[r];
     out_tile[row * TRF4_LD + col] = v;
-    if (row < rows_here) out_glb[(unsigned)(r0 + row) * 128u + (unsigned)col] = v;
+    if (row < rows_here) out_glb[(unsigned)(r0 + row) * (unsigned)H + (unsigned)col] = v;
   }
 }
 
@@ -126,13 +135,13 @@ static inline size_t trf4_forward_floats(const TrfArgs& a) {
   return (size_t)TRF4_ROWS * trf2_ldx(a) + (size_t)2 * TRF4_ROWS * TRF4_LD + (size_t)TRF4_ROWS * a.np + TRF4_ROWS;
 }
 
-template <int K>  // spline bins (0: affine / additive)
+template <int K, int HH>  // spline bins (0: affine / additive); hidden width 128, or 0: a.H (80, 96, 112)
 __global__ void __launch_bounds__(TRF_THREADS) trf4_forward(TrfArgs a) {
   extern __shared__ float trf_sm[];
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * TRF4_ROWS;
-  constexpr int H = 128;
+  const int H = HH != 0 ? HH : a.H;
   const int n = a.n, D = a.D, L = a.L, np = a.np, d_id = a.d_id, d_tr = a.d_tr;
   const int ldx = (D + 1) | 1;
   const int rows_here = n - r0 < TRF4_ROWS ? n - r0 : TRF4_ROWS;
@@ -165,7 +174,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_forward(TrfArgs a) {
     cidx[q] = a.id_cols[k < d_id ? k : 0] + i16 * ldx;
     none[q] = 0;
   }
-  trf4_load_w<false>(wc, bc, rsrcT, rsrcP, a.off[0], a.off[1], d_id, wave, lane);
+  trf4_load_w<false>(wc, bc, rsrcT, rsrcP, a.off[0], a.off[1], d_id, H, wave, lane);
   // the final layer: output tiles wave + 8 s (16 columns each), whole k per tile, two operand buffers
   const float* bf = P + a.off[3 + 4 * L];
   auto load_final = [&](float (&buf)[TRF4_Q], int s) {
@@ -187,18 +196,18 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_forward(TrfArgs a) {
   TRF_MARK(0);
 
   float fb[TRF4_Q];
-  trf4_load_w<true>(wn, bn, rsrcT, rsrcP, a.off[L > 0 ? 2 : 0], a.off[L > 0 ? 3 : 1], H, wave, lane);
+  trf4_load_w<true>(wn, bn, rsrcT, rsrcP, a.off[L > 0 ? 2 : 0], a.off[L > 0 ? 3 : 1], H, H, wave, lane);
   // h_0 = W0 x_id + b0
-  trf4_layer<true>(XT, ACT_NONE, wc, cidx, bc, d_id, nullptr, HC, a.h, r0, rows_here, wave, lane);
+  trf4_layer<true, HH>(XT, ACT_NONE, wc, cidx, bc, d_id, H, nullptr, HC, a.h, r0, rows_here, wave, lane);
   TRF_MARK(1);
   for (int l = 0; l < L; ++l) {
     // u_l = W1 act(h_l) + b1;  h_{l+1} = h_l + W2 act(u_l) + b2
 #pragma unroll
     for (int q = 0; q < TRF4_Q; ++q) wc[q] = wn[q];
     bc = bn;
-    trf4_load_w<true>(wn, bn, rsrcT, rsrcP, a.off[4 + 4 * l], a.off[5 + 4 * l], H, wave, lane);
+    trf4_load_w<true>(wn, bn, rsrcT, rsrcP, a.off[4 + 4 * l], a.off[5 + 4 * l], H, H, wave, lane);
     trf_barrier_lds();
-    trf4_layer<false>(HC, a.act, wc, none, bc, H, nullptr, U, a.u + l * nH, r0, rows_here, wave, lane);
+    trf4_layer<false, HH>(HC, a.act, wc, none, bc, H, H, nullptr, U, a.u + l * nH, r0, rows_here, wave, lane);
     TRF_MARK(2 + 2 * l);
 #pragma unroll
     for (int q = 0; q < TRF4_Q; ++q) wc[q] = wn[q];
@@ -208,10 +217,10 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_forward(TrfArgs a) {
       // fall back to "everything" - and the next use of ANY prefetched operand waits for the newest request.  The
       // last block requests its own second layer again instead.)
       const int ln = l + 1 < L ? 6 + 4 * l : 4 + 4 * l;
-      trf4_load_w<true>(wn, bn, rsrcT, rsrcP, a.off[ln], a.off[ln + 1], H, wave, lane);
+      trf4_load_w<true>(wn, bn, rsrcT, rsrcP, a.off[ln], a.off[ln + 1], H, H, wave, lane);
     }
     trf_barrier_lds();
-    trf4_layer<false>(U, a.act, wc, none, bc, H, HC, HC, a.h + (l + 1) * nH, r0, rows_here, wave, lane);
+    trf4_layer<false, HH>(U, a.act, wc, none, bc, H, H, HC, HC, a.h + (l + 1) * nH, r0, rows_here, wave, lane);
     TRF_MARK(3 + 2 * l);
   }
   load_final(wn, 0);
@@ -234,8 +243,10 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_forward(TrfArgs a) {
         f32x4v acc = {0}, acc2 = {0};
 #pragma unroll
         for (int q = 0; q < TRF4_Q; q += 2) {
-          acc = trf4_mfma(av[q], buf[q], acc);
-          acc2 = trf4_mfma(av[q + 1], buf[q + 1], acc2);
+          if (HH != 0 || 4 * q < H) {  // uniform
+            acc = trf4_mfma(av[q], buf[q], acc);
+            acc2 = trf4_mfma(av[q + 1], buf[q + 1], acc2);
+          }
         }
         if (s + 2 < 6) load_final(buf, s + 2);
         const int o = t * 16 + i16;
@@ -334,16 +345,19 @@ __device__ __forceinline__ void trf4_dw_store(float* __restrict__ gW, int O, int
 //   db  column sums of G out of the B operands' registers.
 //   G [16][132];  Ain: row stride a_ld (ACT tiles: 144; GATHER: the x tile, column of slot c = cols[c]);  Kin inputs
 //   Z [16][144]: pre-activation whose act' multiplies dX (null: none);  Rs [16][132] added to the result (null: none)
-template <bool GATHER, bool SLAB>
+// H: the layer's number of outputs (HH: 128, or 0 - at run time: MFMA steps and tiles beyond it skipped).
+template <bool GATHER, bool SLAB, int HH>
 __device__ __forceinline__ void trf4_back_linear(const float* __restrict__ G, const float (&w)[TRF4_Q],
                                                  const float* __restrict__ Ain, int a_ld, const int* __restrict__ cols,
-                                                 int act_in, int Kin, const float* __restrict__ Z, int act_z,
+                                                 int act_in, int Kin, int H, const float* __restrict__ Z, int act_z,
                                                  const float* Rs, float* out, float* __restrict__ gW,
                                                  float* __restrict__ gb, int wave, int lane) {
   const int i16 = lane & 15, kg = lane >> 4;
   const int o = 16 * wave + i16;  // dW, db: output columns 16 wave + lane % 16
+  const bool tile_on = HH != 0 || 16 * wave < H;  // wave-uniform: this wave's 16 columns exist
   if constexpr (!GATHER) {
-    // Kin == 128.  Every LDS read of the layer in front of its first MFMA - the dX operands, the pre-activations
+    if (!tile_on) return;
+    // Kin == H.  Every LDS read of the layer in front of its first MFMA - the dX operands, the pre-activations
     // and the residual tile of the epilogue, the dW operands: one LDS latency per layer (read where they are used,
     // the epilogue's eight reads were a chain of 2.2 k cycles and the dW tiles' another 1.8 k)
     const bool vec = SLAB && (((unsigned long long)gW) & 15) == 0;  // uniform
@@ -367,8 +381,10 @@ __device__ __forceinline__ void trf4_back_linear(const float* __restrict__ G, co
     f32x4v acc = {0}, acc2 = {0};
 #pragma unroll
     for (int q = 0; q < TRF4_Q; q += 2) {
-      acc = trf4_mfma(av[q], w[q], acc);
-      acc2 = trf4_mfma(av[q + 1], w[q + 1], acc2);
+      if (HH != 0 || 4 * q < H) {  // uniform
+        acc = trf4_mfma(av[q], w[q], acc);
+        acc2 = trf4_mfma(av[q + 1], w[q + 1], acc2);
+      }
     }
     {  // db under the MFMAs
       float cs = (bvv[0] + bvv[1]) + (bvv[2] + bvv[3]);
@@ -388,14 +404,16 @@ __device__ __forceinline__ void trf4_back_linear(const float* __restrict__ G, co
     }
 #pragma unroll
     for (int it = 0; it < 8; it += 2) {
-      f32x4v d0 = {0}, d1 = {0};
+      if (HH != 0 || 16 * it < Kin) {  // uniform (Kin / 16 input tiles)
+        f32x4v d0 = {0}, d1 = {0};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {  // D[i = in][j = out], two tiles interleaved
-        d0 = trf4_mfma(at[it][s], bvv[s], d0);
-        d1 = trf4_mfma(at[it + 1][s], bvv[s], d1);
+        for (int s = 0; s < 4; ++s) {  // D[i = in][j = out], two tiles interleaved
+          d0 = trf4_mfma(at[it][s], bvv[s], d0);
+          d1 = trf4_mfma(at[it + 1][s], bvv[s], d1);
+        }
+        trf4_dw_store<SLAB>(gW, H, Kin, o, 16 * it, kg, d0, vec);
+        if (HH != 0 || 16 * (it + 1) < Kin) trf4_dw_store<SLAB>(gW, H, Kin, o, 16 * (it + 1), kg, d1, vec);
       }
-      trf4_dw_store<SLAB>(gW, 128, 128, o, 16 * it, kg, d0, vec);
-      trf4_dw_store<SLAB>(gW, 128, 128, o, 16 * (it + 1), kg, d1, vec);
     }
     return;
   }
@@ -409,8 +427,10 @@ __device__ __forceinline__ void trf4_back_linear(const float* __restrict__ G, co
     f32x4v acc = {0}, acc2 = {0};
 #pragma unroll
     for (int q = 0; q < TRF4_Q; q += 2) {
-      acc = trf4_mfma(av[q], w[q], acc);
-      acc2 = trf4_mfma(av[q + 1], w[q + 1], acc2);
+      if (HH != 0 || 4 * q < H) {  // uniform
+        acc = trf4_mfma(av[q], w[q], acc);
+        acc2 = trf4_mfma(av[q + 1], w[q + 1], acc2);
+      }
     }
     const int c = 16 * wave + i16;
     if (c < Kin) {
@@ -428,6 +448,7 @@ __device__ __forceinline__ void trf4_back_linear(const float* __restrict__ G, co
       }
     }
   }
+  if (!tile_on) return;
   float bvv[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) bvv[s] = G[(4 * s + kg) * TRF4_LD + o];
@@ -458,19 +479,19 @@ __device__ __forceinline__ void trf4_back_linear(const float* __restrict__ G, co
         d0 = trf4_mfma(at[0][s], bvv[s], d0);
         d1 = trf4_mfma(at[1][s], bvv[s], d1);
       }
-      trf4_dw_store<SLAB>(gW, 128, Kin, o, 16 * it, kg, d0, vec);
-      if (it + 1 < NI) trf4_dw_store<SLAB>(gW, 128, Kin, o, 16 * (it + 1), kg, d1, vec);
+      trf4_dw_store<SLAB>(gW, H, Kin, o, 16 * it, kg, d0, vec);
+      if (it + 1 < NI) trf4_dw_store<SLAB>(gW, H, Kin, o, 16 * (it + 1), kg, d1, vec);
     }
   }
 }
 
-template <int K, bool SLAB>
+template <int K, bool SLAB, int HH>  // HH: 128, or 0 - the hidden width a.H (80, 96, 112) at run time
 __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   extern __shared__ float trf_sm[];
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * TRF4_ROWS;
-  constexpr int H = 128;
+  const int H = HH != 0 ? HH : a.H;
   const int n = a.n, np = a.np, D = a.D, L = a.L;
   const int ldx = (D + 1) | 1, pld = trf2_pld(np, true);
   float* PT = trf_sm;                                        // [16][pld]
@@ -507,7 +528,8 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   constexpr int MAXT = 7;  // 2 L + 1 <= 7
   f32x4v aq[MAXT];
   {
-    long long g = (long long)r0 * H + 4 * tid;
+    // (the [16][H] tile is contiguous in global memory: unit tid of its 4 H units; threads beyond load unit 4 H - 1)
+    long long g = (long long)r0 * H + 4 * (tid < 4 * H ? tid : 4 * H - 1);
     g = g < nH - 4 ? g : nH - 4;
     trf2_static_for<MAXT>([&](auto ti) {
       constexpr int t = decltype(ti)::value;
@@ -544,7 +566,8 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   }
   trf2_static_for<MAXT>([&](auto ti) {
     constexpr int t = decltype(ti)::value;
-    if (t < 2 * L + 1) *(f32x4v*)(ACT + t * TRF4_ROWS * TRF4_LDA + (tid >> 5) * TRF4_LDA + 4 * (tid & 31)) = aq[t];
+    if (t < 2 * L + 1 && tid < 4 * H)
+      *(f32x4v*)(ACT + t * TRF4_ROWS * TRF4_LDA + ((4 * tid) / H) * TRF4_LDA + (4 * tid) % H) = aq[t];
   });
 #pragma unroll
   for (int i = 0; i < XQ; ++i) {
@@ -563,7 +586,8 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   const int NG = (np + 15) >> 4;  // <= 48: six chunks
   // (a group beyond np reads on into the next row of W^T - the bias behind it for the last row - finite values that
   // meet a zero A operand)
-  const unsigned wf_voff = 4u * ((unsigned)(16 * wave + i16) * (unsigned)np + 4u * (unsigned)kg);  // W^T[in][o]
+  const int wf_row = 16 * wave + i16 < H ? 16 * wave + i16 : H - 1;  // (waves beyond H stay inside the matrix)
+  const unsigned wf_voff = 4u * ((unsigned)wf_row * (unsigned)np + 4u * (unsigned)kg);  // W^T[in][o]
   const unsigned wf_s0 = 4u * (unsigned)a.off[2 + 4 * L];
   auto load_chunk = [&](f32x4v (&b)[8], int c) {
 #pragma unroll
@@ -616,7 +640,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   TRF_MARK(31);
 
   // ---- final layer, dX: gh = gp . Wf -> G0 ----
-  {
+  if (HH != 0 || 16 * wave < H) {
     f32x4v acc = {0}, acc2 = {0};
     const float* ax = PT + i16 * pld;
     trf2_static_for<6>([&](auto ci) {
@@ -677,14 +701,16 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
       }
 #pragma unroll
       for (int it = 0; it < 8; it += 2) {
-        f32x4v d0 = {0}, d1 = {0};
+        if (HH != 0 || 16 * it < H) {  // uniform
+          f32x4v d0 = {0}, d1 = {0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          d0 = trf4_mfma(at[it][s], bvv[s], d0);
-          d1 = trf4_mfma(at[it + 1][s], bvv[s], d1);
+          for (int s = 0; s < 4; ++s) {
+            d0 = trf4_mfma(at[it][s], bvv[s], d0);
+            d1 = trf4_mfma(at[it + 1][s], bvv[s], d1);
+          }
+          trf4_dw_store<SLAB>(gWf, np, H, o, 16 * it, kg, d0, vec);
+          if (HH != 0 || 16 * (it + 1) < H) trf4_dw_store<SLAB>(gWf, np, H, o, 16 * (it + 1), kg, d1, vec);
         }
-        trf4_dw_store<SLAB>(gWf, np, H, o, 16 * it, kg, d0, vec);
-        trf4_dw_store<SLAB>(gWf, np, H, o, 16 * (it + 1), kg, d1, vec);
       }
     }
   }
@@ -700,14 +726,14 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
 #pragma unroll
     for (int q = 0; q < TRF4_Q; ++q) wc[q] = wn[q];
     trf4_load_wx(wn, rsrcP, a.off[2 + 4 * l], H, wave, lane);
-    trf4_back_linear<false, SLAB>(G0, wc, ul, TRF4_LDA, nullptr, a.act, H, ul, a.act, nullptr, G1,
+    trf4_back_linear<false, SLAB, HH>(G0, wc, ul, TRF4_LDA, nullptr, a.act, H, H, ul, a.act, nullptr, G1,
                                   GR + a.off[4 + 4 * l], GR + a.off[5 + 4 * l], wave, lane);
     trf_barrier_lds();
     // u_l = W1 act(h_l) + b1:  g_h_l = G0 + (G1 . W1) act'(h_l) -> G0
 #pragma unroll
     for (int q = 0; q < TRF4_Q; ++q) wc[q] = wn[q];
     trf4_load_wx(wn, rsrcP, a.off[l > 0 ? 4 + 4 * (l - 1) : 0], l > 0 ? H : a.d_id, wave, lane);  // (no branch: see trf4_forward)
-    trf4_back_linear<false, SLAB>(G1, wc, hl, TRF4_LDA, nullptr, a.act, H, hl, a.act, G0, G0,
+    trf4_back_linear<false, SLAB, HH>(G1, wc, hl, TRF4_LDA, nullptr, a.act, H, H, hl, a.act, G0, G0,
                                   GR + a.off[2 + 4 * l], GR + a.off[3 + 4 * l], wave, lane);
     trf_barrier_lds();
     TRF_MARK(33 + (L - 1 - l));
@@ -716,7 +742,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   // ---- initial layer: dW0 = G0^T . x_id, g_x[:, id_cols] += G0 . W0 ----
 #pragma unroll
   for (int q = 0; q < TRF4_Q; ++q) wc[q] = wn[q];
-  trf4_back_linear<true, SLAB>(G0, wc, XT, ldx, a.id_cols, ACT_NONE, a.d_id, nullptr, ACT_NONE, nullptr, G1,
+  trf4_back_linear<true, SLAB, HH>(G0, wc, XT, ldx, a.id_cols, ACT_NONE, a.d_id, H, nullptr, ACT_NONE, nullptr, G1,
                                GR + a.off[0], GR + a.off[1], wave, lane);
   trf_barrier_lds();
   for (int idx = tid; idx < TRF4_ROWS * a.d_id; idx += TRF_THREADS) {

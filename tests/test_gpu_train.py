@@ -41,6 +41,12 @@ CASES = {
     "nsf_d9_h128": (NeuralSplineFlow, O.NeuralSplineFlow, (9, 128, 2, 1), {}),
     "rnvp_d40_h128": (RealNVP, O.RealNVP, (40, 128, 2, 2), dict(linear_transform="permutation",
                                                                batch_norm_between_layers=False)),
+    # the other widths of the 16-row kernels (80, 96, 112: the width at run time, MFMA steps and tiles beyond it
+    # skipped) - the reference's default n_neurons = 2 n_inputs at 40, 48 and 56 inputs
+    "nsf_d48_h96": (NeuralSplineFlow, O.NeuralSplineFlow, (48, 96, 2, 2), {}),
+    "nsf_d16_h112": (NeuralSplineFlow, O.NeuralSplineFlow, (16, 112, 2, 1), {}),
+    "rnvp_d40_h80": (RealNVP, O.RealNVP, (40, 80, 2, 2), dict(linear_transform="permutation",
+                                                             batch_norm_between_layers=False)),
     # parameter rows that are not a multiple of 16 bytes (np = 3 x 23): the scalar paths of the backward kernel
     "nsf_d5": (NeuralSplineFlow, O.NeuralSplineFlow, (5, 24, 2, 2), {}),
     # four residual blocks per conditioner: nine activation tiles, beyond what the backward kernel copies through
@@ -364,7 +370,7 @@ def test_act_norm_trains_with_data_dependent_initialisation():
         assert rel_err(flow.log_prob(xe.to(DEV)).cpu(), ref.log_prob(xe)) <= 1e-5
 
 
-@pytest.mark.parametrize("name", ["nsf_c4", "nsf_d9_h128", "rnvp_d40_h128"])
+@pytest.mark.parametrize("name", ["nsf_c4", "nsf_d9_h128", "rnvp_d40_h128", "nsf_d48_h96", "nsf_d16_h112", "rnvp_d40_h80"])
 def test_third_generation_fused_kernels_match_the_first(name, monkeypatch):
     """128-wide conditioners (nsa_train_fused3.h; config 4's importance-sampling flows): the third-generation kernels
     - 16-row workgroups on 16x16x4 matrix tiles - against the first generation (NESSAI_AMD_TRAIN_V3=0) on the same
