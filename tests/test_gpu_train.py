@@ -39,6 +39,13 @@ CASES = {
     # layer's gradient that is not whole, one residual block), and on an affine flow
     "nsf_c4": (NeuralSplineFlow, O.NeuralSplineFlow, (64, 128, 2, 2), {}),
     "nsf_d9_h128": (NeuralSplineFlow, O.NeuralSplineFlow, (9, 128, 2, 1), {}),
+    # config 4's flow itself: six coupling layers (six ranges of the gradient copies), and a narrower one of 32 inputs.
+    # (tanh: with relu and the residual branches scaled up by pair(), one of the ~250 000 pre-activations of a batch
+    # lies within float32 rounding of zero - the device and torch then differentiate different branches of the kink,
+    # one row's worth of gradient apart: scripts/debug_grad_rows.py finds the row, and with a smooth activation the
+    # same shapes agree to 3e-7)
+    "nsf_c4_six": (NeuralSplineFlow, O.NeuralSplineFlow, (64, 128, 6, 2), dict(activation=torch.tanh)),
+    "nsf_d32_h96_six": (NeuralSplineFlow, O.NeuralSplineFlow, (32, 96, 6, 2), {}),
     "rnvp_d40_h128": (RealNVP, O.RealNVP, (40, 128, 2, 2), dict(linear_transform="permutation",
                                                                batch_norm_between_layers=False)),
     # the other widths of the 16-row kernels (80, 96, 112: the width at run time, MFMA steps and tiles beyond it
@@ -370,7 +377,8 @@ def test_act_norm_trains_with_data_dependent_initialisation():
         assert rel_err(flow.log_prob(xe.to(DEV)).cpu(), ref.log_prob(xe)) <= 1e-5
 
 
-@pytest.mark.parametrize("name", ["nsf_c4", "nsf_d9_h128", "rnvp_d40_h128", "nsf_d48_h96", "nsf_d16_h112", "rnvp_d40_h80"])
+@pytest.mark.parametrize("name", ["nsf_c4", "nsf_d9_h128", "rnvp_d40_h128", "nsf_d48_h96", "nsf_d16_h112", "rnvp_d40_h80",
+                                  "nsf_c4_six", "nsf_d32_h96_six"])
 def test_third_generation_fused_kernels_match_the_first(name, monkeypatch):
     """128-wide conditioners (nsa_train_fused3.h; config 4's importance-sampling flows): the third-generation kernels
     - 16-row workgroups on 16x16x4 matrix tiles - against the first generation (NESSAI_AMD_TRAIN_V3=0) on the same
