@@ -44,7 +44,7 @@ def rms_err(a, b, floor=1.0):
 def random_case(g):
     nsf = g.random() < 0.6
     D = int(g.integers(2, 41)) if g.random() < 0.85 else int(g.integers(41, 97))
-    H = int(g.choice([8, 12, 16, 30, 32, 33, 48, 64, 100, 128]))
+    H = int(g.choice([8, 12, 16, 30, 32, 33, 48, 64, 80, 96, 100, 112, 128, 128]))
     blocks = int(g.integers(1, 7))
     layers = int(g.integers(1, 4))
     kw = {}
