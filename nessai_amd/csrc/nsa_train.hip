@@ -1612,9 +1612,9 @@ static void tr_sizes(const long long* plan, long long n, long long& d_tr_max, lo
 // in its own copy of the flat gradient vector and one kernel sums the copies in a fixed order (below a cap
 // on the copies' size; above it the second generation adds to the flat gradient with float atomics as the first
 // generation does, and 128-wide conditioners go back to the first generation's backward kernel)
-// rows per workgroup of the fused backward kernels that write gradient copies: 16 for conditioners 80 / 96 / 112 /
-// 128 wide (the 16-row kernels of nsa_train_fused3.h), 32 otherwise (second generation)
-static inline bool tr_v4_width(long long H) { return H > 64 && H <= 128 && H % 16 == 0; }
+// rows per workgroup of the fused backward kernels that write gradient copies: 16 for conditioners 68 to 128 wide, in
+// steps of 4 (the 16-row kernels of nsa_train_fused3.h), 32 otherwise (second generation)
+static inline bool tr_v4_width(long long H) { return H > 64 && H <= 128 && H % 4 == 0; }
 static inline long long tr_slab_rows(const long long* plan) { return tr_v4_width(plan[1]) ? 16 : 32; }
 static inline int tr_slab_copies(const long long* plan, long long n) {
   return (int)((n + tr_slab_rows(plan) - 1) / tr_slab_rows(plan));
@@ -1844,7 +1844,7 @@ static hipError_t tr_launch_fused2(bool backward, const TrfArgs& a, hipStream_t 
   return hipGetLastError();
 }
 
-// third-generation kernels (nsa_train_fused3.h): conditioners 80 / 96 / 112 / 128 wide on 16-row workgroups; NESSAI_AMD_TRAIN_V3=0
+// third-generation kernels (nsa_train_fused3.h): conditioners 68 to 128 wide (multiples of 4) on 16-row workgroups; NESSAI_AMD_TRAIN_V3=0
 // keeps the first generation (the cross-check of the tests)
 static bool tr_v3_enabled() {
   const char* e = getenv("NESSAI_AMD_TRAIN_V3");

@@ -1,10 +1,11 @@
 // Third generation of the fused training kernels (included by nsa_train.hip after nsa_train_fused2.h; same TrfArgs,
-// same workspace layout, same results up to the order of the float32 sums): conditioners 80, 96, 112 or 128 wide
-// (config 4's importance-sampling flows: 64 inputs, 128-wide residual nets, 736 spline parameters per row; the
-// reference's default n_neurons = 2 n_inputs for 40 to 64 inputs), one coupling layer per launch, forward and
+// same workspace layout, same results up to the order of the float32 sums): conditioners 68 to 128 wide, in steps
+// of 4 (config 4's importance-sampling flows: 64 inputs, 128-wide residual nets, 736 spline parameters per row; the
+// reference's default n_neurons = 2 n_inputs for 34 to 64 inputs), one coupling layer per launch, forward and
 // backward, on 16-ROW workgroups and v_mfma_f32_16x16x4_f32 tiles - config 4's optimiser step 1.24 -> 0.63 ms.
 // The 128-wide instances have every size at compile time; the others take the width at run time and skip the MFMA
-// steps and tiles beyond it.  Other widths above 64 stay with the first generation.
+// steps and tiles beyond it (a last tile may be partial: its lanes beyond the width write nothing, and the tiles'
+// columns from the width on are cleared once, so that steps reaching past it multiply zeros).
 //
 // What the first generation spends its time on at this width (profiles/r04_train_c4_kernels.txt: forward 65 us,
 // backward 118 us per coupling for a 32-row workgroup whose MFMAs take 20 / 40 us): a hidden layer has four output
@@ -80,7 +81,8 @@ __device__ __forceinline__ void trf4_load_w(float (&w)[TRF4_Q], float& bias, RT 
 
 // out[row][col] = sum_k act(Ain[row][k]) W[col][k] + b[col] (+ R[row][col]) for the wave's 16 columns of the
 // workgroup's 16 rows; the tile is WRITTEN, not yet published.  GATHER: A from the x tile, column of step q in cidx[q].
-// HH: 128 (the steps and tiles are all there: no guards) or 0 (H at run time: steps 4 q >= Kd and tiles beyond H skipped).
+// HH: 128 (the steps and tiles are all there: no guards) or 0 (H at run time, a multiple of 4: steps 4 q >= Kd and
+// tiles beyond H skipped; the A operands of k >= H are the zeros the kernel left in the tiles' padding columns).
 template <bool GATHER, int HH>
 __device__ __forceinline__ void trf4_layer(const float* __restrict__ Ain, int act_in, const float (&w)[TRF4_Q],
                                            const int (&cidx)[TRF4_Q], float bias, int Kd, int H, const float* R,
@@ -115,19 +117,22 @@ __device__ __forceinline__ void trf4_layer(const float* __restrict__ Ain, int ac
     trf_act_batch(av, act_in);
 #pragma unroll
     for (int q = 0; q < TRF4_Q; q += 2) {
-      if (HH != 0 || 4 * q < Kd) {  // uniform (Kd a multiple of 8 here: H % 16 == 0)
+      if (HH != 0 || 4 * q < Kd) {  // uniform (a last pair may reach past Kd: zeros of the padding columns)
         acc = trf4_mfma(av[q], w[q], acc);
         acc2 = trf4_mfma(av[q + 1], w[q + 1], acc2);
       }
     }
   }
   const int col = 16 * wave + i16;
+  if (HH != 0 || col < H) {  // (a width that is not a multiple of 16: the last tile's lanes beyond it write nothing -
+                             // the tiles' columns from H on stay zero, as the kernels cleared them)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = 4 * kg + r;
-    const float v = acc[r] + acc2[r] + bias + rv[r];
-    out_tile[row * TRF4_LD + col] = v;
-    if (row < rows_here) out_glb[(unsigned)(r0 + row) * (unsigned)H + (unsigned)col] = v;
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * kg + r;
+      const float v = acc[r] + acc2[r] + bias + rv[r];
+      out_tile[row * TRF4_LD + col] = v;
+      if (row < rows_here) out_glb[(unsigned)(r0 + row) * (unsigned)H + (unsigned)col] = v;
+    }
   }
 }
 
@@ -135,7 +140,7 @@ static inline size_t trf4_forward_floats(const TrfArgs& a) {
   return (size_t)TRF4_ROWS * trf2_ldx(a) + (size_t)2 * TRF4_ROWS * TRF4_LD + (size_t)TRF4_ROWS * a.np + TRF4_ROWS;
 }
 
-template <int K, int HH>  // spline bins (0: affine / additive); hidden width 128, or 0: a.H (80, 96, 112)
+template <int K, int HH>  // spline bins (0: affine / additive); hidden width 128, or 0: a.H (68 ... 124, a multiple of 4)
 __global__ void __launch_bounds__(TRF_THREADS) trf4_forward(TrfArgs a) {
   extern __shared__ float trf_sm[];
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kg = lane >> 4;
@@ -156,6 +161,9 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_forward(TrfArgs a) {
   const long long nH = (long long)n * H;
   const long long t_start = clock64();
   if (tid < TRF4_ROWS) ldsum[tid] = 0.0f;
+  if constexpr (HH == 0) {  // the columns from H on of h_l / u_l: zero A operands for the steps that reach past H
+    for (int i = tid; i < 2 * TRF4_ROWS * TRF4_LD; i += TRF_THREADS) HC[i] = 0.0f;
+  }
 
   // the rows of x (async, 4 bytes per lane, rows wave and wave + 8; rows beyond n read row n - 1)
   for (int r = wave; r < TRF4_ROWS; r += TRF_WAVES) {
@@ -386,15 +394,17 @@ __device__ __forceinline__ void trf4_back_linear(const float* __restrict__ G, co
         acc2 = trf4_mfma(av[q + 1], w[q + 1], acc2);
       }
     }
+    const bool lane_on = HH != 0 || o < H;  // (the last tile of a width that is not a multiple of 16)
     {  // db under the MFMAs
       float cs = (bvv[0] + bvv[1]) + (bvv[2] + bvv[3]);
       cs += __shfl_xor(cs, 16);
       cs += __shfl_xor(cs, 32);
-      if (kg == 0) trf2_grad_out<SLAB>(&gb[o], cs);
+      if (kg == 0 && lane_on) trf2_grad_out<SLAB>(&gb[o], cs);
     }
 #pragma unroll
     for (int it = 0; it < 8; ++it) trf_act_batch(at[it], act_in);
-    if (act_z == NSA_ACT_RELU) {
+    if (!lane_on) {
+    } else if (act_z == NSA_ACT_RELU) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[(4 * kg + r) * TRF4_LD + o] = (zv[r] > 0.0f ? acc[r] + acc2[r] : 0.0f) + rv[r];
     } else {
@@ -456,7 +466,7 @@ __device__ __forceinline__ void trf4_back_linear(const float* __restrict__ G, co
     float cs = (bvv[0] + bvv[1]) + (bvv[2] + bvv[3]);
     cs += __shfl_xor(cs, 16);
     cs += __shfl_xor(cs, 32);
-    if (kg == 0) trf2_grad_out<SLAB>(&gb[o], cs);
+    if (kg == 0 && (HH != 0 || o < H)) trf2_grad_out<SLAB>(&gb[o], cs);
   }
   const bool vec = SLAB && (Kin & 3) == 0 && (((unsigned long long)gW) & 15) == 0;  // uniform
   const int NI = (Kin + 15) >> 4;  // <= 8
@@ -485,7 +495,7 @@ __device__ __forceinline__ void trf4_back_linear(const float* __restrict__ G, co
   }
 }
 
-template <int K, bool SLAB, int HH>  // HH: 128, or 0 - the hidden width a.H (80, 96, 112) at run time
+template <int K, bool SLAB, int HH>  // HH: 128, or 0 - the hidden width a.H (68 ... 124, a multiple of 4) at run time
 __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   extern __shared__ float trf_sm[];
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kg = lane >> 4;
@@ -505,6 +515,9 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   const long long nH = (long long)n * H;
   const long long t_start = clock64();
   const int rows_here = (n - r0 < TRF4_ROWS) ? (n - r0) : TRF4_ROWS;
+  if constexpr (HH == 0) {  // the gradient tiles' columns from H on: zero A operands for the steps that reach past H
+    for (int i = tid; i < 2 * TRF4_ROWS * TRF4_LD; i += TRF_THREADS) G0[i] = 0.0f;
+  }
 
   // ---- everything the pass reads, 16-byte loads through registers: the parameter tile, the activation tiles
   // (one unit per thread each), the rows of x; and what the transform item of this thread needs ----
@@ -671,8 +684,10 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
         if (c + 2 < 6) load_chunk(b, c + 2);
       }
     });
+    if (HH != 0 || 16 * wave + i16 < H) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) G0[(4 * kg + r) * TRF4_LD + 16 * wave + i16] = acc[r] + acc2[r];
+      for (int r = 0; r < 4; ++r) G0[(4 * kg + r) * TRF4_LD + 16 * wave + i16] = acc[r] + acc2[r];
+    }
   }
   TRF_MARK(42);
   // ---- final layer, dW: dWf = gp^T . h_L (output tiles wave + 8 s, the eight input tiles of each), dbf ----

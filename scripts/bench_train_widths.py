@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Optimiser step time of neural spline flows with the reference's default conditioner width (n_neurons = 2 n_inputs)
-at 40, 48, 56 and 64 inputs - 80, 96, 112, 128 wide: the 16-row kernels of csrc/nsa_train_fused3.h against the first
+at 36 ... 64 inputs - 72 ... 128 wide: the 16-row kernels of csrc/nsa_train_fused3.h against the first
 generation (NESSAI_AMD_TRAIN_V3=0, read per call), 1000-row minibatches, 6 coupling layers, 2 blocks:
 
     python scripts/bench_train_widths.py
@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 from nessai_amd.flows import NeuralSplineFlow  # noqa: E402
 from nessai_amd.train import Trainer  # noqa: E402
 
-for dims in (40, 48, 56, 64):
+for dims in (36, 40, 48, 50, 56, 64):
     for mode in ("0", "1"):
         os.environ["NESSAI_AMD_TRAIN_V3"] = mode
         torch.manual_seed(1)
