@@ -1850,15 +1850,19 @@ static bool tr_v3_enabled() {
   const char* e = getenv("NESSAI_AMD_TRAIN_V3");
   return !(e != nullptr && e[0] == '0');
 }
+// parameter rows in 16-byte units (the tile and the transposed final-layer weights through 16-byte accesses); otherwise
+// the backward kernel fills the tile element by element and takes the final layer's weights in their natural layout
+static bool tr_v4_param_rows_vec(const TrfArgs& a) {
+  return a.np % 4 == 0 && a.off[2 + 4 * a.L] % 4 == 0 && ((uintptr_t)a.p % 16 == 0) && ((uintptr_t)a.wt % 16 == 0);
+}
 static bool tr_v4_fits(bool backward, const TrfArgs& a) {  // 16-row kernels
   if (!tr_v3_enabled()) return false;
   if (!tr_v4_width(a.H) || a.D > 128 || a.np > 768 || a.d_id > 128) return false;
   if (!backward) return trf4_forward_floats(a) * sizeof(float) <= 160 * 1024;
-  // parameter rows and tiles in 16-byte units, one transform item per thread, <= 7 activation tiles through registers
-  return a.np % 4 == 0 && a.d_tr <= 32 && a.L <= 3 && a.off[2 + 4 * a.L] % 4 == 0 &&
-         ((uintptr_t)a.p % 16 == 0) && ((uintptr_t)a.wt % 16 == 0) && ((uintptr_t)a.h % 16 == 0) &&
-         ((uintptr_t)a.u % 16 == 0) && (((long long)a.n * a.H) % 4 == 0) &&
-         trf4_backward_floats(a) * sizeof(float) <= 160 * 1024;
+  // activation tiles in 16-byte units, one transform item per thread, <= 7 activation tiles through registers
+  return a.d_tr <= 32 && a.L <= 3 && ((uintptr_t)a.h % 16 == 0) && ((uintptr_t)a.u % 16 == 0) &&
+         (((long long)a.n * a.H) % 4 == 0) &&
+         trf4_backward_floats(a, tr_v4_param_rows_vec(a)) * sizeof(float) <= 160 * 1024;
 }
 
 template <int K>
@@ -1869,8 +1873,10 @@ static hipError_t tr_launch_fused(bool backward, const TrfArgs& a, hipStream_t s
   // as many workgroups it is slower than the first generation - 1.36 against 1.13 ms per step at 1100 rows of config
   // 4's flow, 7.3 against 1.55 at 8000; profiles/r06_train_batch_sizes.jsonl)
   if (tr_v4_fits(backward, a) && (!backward || a.gslab != nullptr)) {
-    const size_t lds4 = (backward ? trf4_backward_floats(a) : trf4_forward_floats(a)) * sizeof(float);
-    auto kern4 = backward ? (a.H == 128 ? trf4_backward<K, true, 128> : trf4_backward<K, true, 0>)
+    const size_t lds4 = (backward ? trf4_backward_floats(a, tr_v4_param_rows_vec(a)) : trf4_forward_floats(a)) * sizeof(float);
+    const bool pv = tr_v4_param_rows_vec(a);
+    auto kern4 = backward ? (pv ? (a.H == 128 ? trf4_backward<K, true, 128, true> : trf4_backward<K, true, 0, true>)
+                                : trf4_backward<K, true, 0, false>)
                           : (a.H == 128 ? trf4_forward<K, 128> : trf4_forward<K, 0>);
     hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern4),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);

@@ -56,8 +56,8 @@ __device__ __forceinline__ f32x4v trf4_bload4(R rsrc, unsigned voff_bytes, unsig
 
 // B operands of the wave's output tile (columns 16 wave + lane % 16) of a layer with 128 outputs from the transposed
 // weights W^T[Kd][128] at flat offset offW: step q holds k = 4 q + lane / 16.  FULL: Kd == 128.
-// H: the layer's width (a multiple of 16, at most 128; steps beyond Kd = H read on into the flat vector - finite
-// values no MFMA uses; waves whose tile lies beyond H likewise).
+// H: the layer's width (a multiple of 4, at most 128; steps beyond Kd = H re-read the last one, columns beyond H read on
+// into the next row - finite values no MFMA result that is kept depends on).
 template <bool FULL, typename RT, typename RP>
 __device__ __forceinline__ void trf4_load_w(float (&w)[TRF4_Q], float& bias, RT rsrcT, RP rsrcP, long long offW,
                                             long long offB, int Kd, int H, int wave, int lane) {
@@ -66,8 +66,9 @@ __device__ __forceinline__ void trf4_load_w(float (&w)[TRF4_Q], float& bias, RT 
   if constexpr (FULL) {
     const unsigned voff = 4u * ((unsigned)kg * (unsigned)H + (unsigned)i16);
     const unsigned step = 16u * (unsigned)H;
+    const int nq = (H + 3) >> 2;  // (steps beyond the matrix re-read its last one: nothing is read past the flat vector)
 #pragma unroll
-    for (int q = 0; q < TRF4_Q; ++q) w[q] = trf4_bload(rsrcT, voff, s0 + step * q);
+    for (int q = 0; q < TRF4_Q; ++q) w[q] = trf4_bload(rsrcT, voff, s0 + step * (unsigned)(q < nq ? q : nq - 1));
   } else {
 #pragma unroll
     for (int q = 0; q < TRF4_Q; ++q) {
@@ -189,8 +190,9 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_forward(TrfArgs a) {
     const int o = (wave + TRF_WAVES * s) * 16 + i16;
     const unsigned voff = 4u * ((unsigned)kg * (unsigned)np + (unsigned)(o < np ? o : np - 1));
     const unsigned s0 = 4u * (unsigned)a.off[2 + 4 * L], step = 16u * (unsigned)np;
+    const int nqh = (H + 3) >> 2;
 #pragma unroll
-    for (int q = 0; q < TRF4_Q; ++q) buf[q] = trf4_bload(rsrcT, voff, s0 + step * q);
+    for (int q = 0; q < TRF4_Q; ++q) buf[q] = trf4_bload(rsrcT, voff, s0 + step * (unsigned)(q < nqh ? q : nqh - 1));
     __builtin_amdgcn_sched_barrier(0);
   };
   float bfv[6];  // (loaded inside the rounds, a bias behind the refill loads made every round wait for them)
@@ -311,22 +313,30 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_forward(TrfArgs a) {
 // ---- backward pass, 16 rows per workgroup.  LDS (floats):
 //   PT [16][pld] parameters -> their gradient | ACT [2 L + 1][16][144]: h_0 .. h_L, u_0 .. u_{L-1} | XT [16][ldx]
 //   | G0, G1 [16][132] - everything the pass reads, resident from the first barrier on.
-static inline size_t trf4_backward_floats(const TrfArgs& a) {
-  return (size_t)TRF4_ROWS * trf2_pld(a.np, true) + (size_t)(2 * a.L + 1) * TRF4_ROWS * TRF4_LDA +
+// row stride of the parameter tile: rows of 16-byte units, an odd number of them (16-byte reads without bank
+// conflicts: trf2_pld), where the rows are read in 16-byte units (PV); otherwise 4 mod 64 (the tile is then read as an
+// A operand - row = lane % 16, k = lane / 16 - like the activation tiles)
+__host__ __device__ static inline int trf4_pld(int np, bool pv) {
+  // (element-wise tile: the final layer's dX walks it in groups of 16 parameters - zeros up to the end of the last group)
+  return pv ? trf2_pld(np, true) : ((((np + 15) & ~15) + 59) / 64) * 64 + 4;
+}
+static inline size_t trf4_backward_floats(const TrfArgs& a, bool pv) {
+  return (size_t)TRF4_ROWS * trf4_pld(a.np, pv) + (size_t)(2 * a.L + 1) * TRF4_ROWS * TRF4_LDA +
          (size_t)TRF4_ROWS * trf2_ldx(a) + (size_t)2 * TRF4_ROWS * TRF4_LD;
 }
 
 // B operands of the wave's dX tile (input columns 16 wave + lane % 16) of a layer with 128 outputs: W[out = 4 q +
 // lane / 16][in], natural layout [128][Kin] at flat offset offW
 template <typename RP>
-__device__ __forceinline__ void trf4_load_wx(float (&w)[TRF4_Q], RP rsrcP, long long offW, int Kin, int wave,
+__device__ __forceinline__ void trf4_load_wx(float (&w)[TRF4_Q], RP rsrcP, long long offW, int Kin, int H, int wave,
                                              int lane) {
   const int i16 = lane & 15, kg = lane >> 4;
   const int c = 16 * wave + i16;
   const unsigned voff = 4u * ((unsigned)kg * (unsigned)Kin + (unsigned)(c < Kin ? c : Kin - 1));
   const unsigned s0 = 4u * (unsigned)offW, step = 16u * (unsigned)Kin;
+  const int nq = (H + 3) >> 2;  // (the matrix has H rows: steps beyond re-read the last one)
 #pragma unroll
-  for (int q = 0; q < TRF4_Q; ++q) w[q] = trf4_bload(rsrcP, voff, s0 + step * q);
+  for (int q = 0; q < TRF4_Q; ++q) w[q] = trf4_bload(rsrcP, voff, s0 + step * (unsigned)(q < nq ? q : nq - 1));
   __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks these loads to their first use: a round trip per layer)
 }
 
@@ -495,7 +505,10 @@ __device__ __forceinline__ void trf4_back_linear(const float* __restrict__ G, co
   }
 }
 
-template <int K, bool SLAB, int HH>  // HH: 128, or 0 - the hidden width a.H (68 ... 124, a multiple of 4) at run time
+// PV: the parameter rows are 16-byte multiples (np % 4 == 0: 16-byte loads of the tile, the final layer's dX on
+// 16-byte LDS / transposed-weight operands); otherwise the tile is filled element by element and that product runs on
+// the natural weight layout like a hidden layer's (23 parameters per feature: np % 4 != 0 unless d_tr % 4 == 0)
+template <int K, bool SLAB, int HH, bool PV>  // HH: 128, or 0 - the hidden width a.H (68 ... 128, a multiple of 4) at run time
 __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   extern __shared__ float trf_sm[];
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kg = lane >> 4;
@@ -503,7 +516,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   const int r0 = blockIdx.x * TRF4_ROWS;
   const int H = HH != 0 ? HH : a.H;
   const int n = a.n, np = a.np, D = a.D, L = a.L;
-  const int ldx = (D + 1) | 1, pld = trf2_pld(np, true);
+  const int ldx = (D + 1) | 1, pld = trf4_pld(np, PV);
   float* PT = trf_sm;                                        // [16][pld]
   float* ACT = PT + TRF4_ROWS * pld;                         // [2 L + 1][16][144]
   float* XT = ACT + (2 * L + 1) * TRF4_ROWS * TRF4_LDA;      // [16][ldx]
@@ -526,17 +539,31 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   const int it_r = tid / a.d_tr, it_m = tid - it_r * a.d_tr;
   const bool it_on = tid < TRF4_ROWS * a.d_tr;
   const int colv = a.tr_cols[it_m];
-  constexpr int PQ4 = 7;  // 16 (768 + 4) / 4 <= 7 * 512
-  f32x4v pq[PQ4];
+  constexpr int PQ4 = 7;   // 16 (768 + 4) / 4 <= 7 * 512
+  constexpr int PQS = 24;  // element by element: 16 * 768 <= 24 * 512
+  f32x4v pq[PV ? PQ4 : 1];
+  float ps[PV ? 1 : PQS];
   const int rq = pld >> 2, nq = np >> 2;
+  if constexpr (PV) {
 #pragma unroll
-  for (int i = 0; i < PQ4; ++i) {
-    if (TRF_THREADS * i >= TRF4_ROWS * rq) break;  // uniform
-    int Q = tid + TRF_THREADS * i;
-    Q = Q < TRF4_ROWS * rq ? Q : TRF4_ROWS * rq - 1;
-    const int r = Q / rq, cq = Q - r * rq;
-    const int row = r0 + r < n ? r0 + r : n - 1;
-    pq[i] = *(const f32x4v*)(a.p + (long long)row * np + 4 * (cq < nq ? cq : nq - 1));
+    for (int i = 0; i < PQ4; ++i) {
+      if (TRF_THREADS * i >= TRF4_ROWS * rq) break;  // uniform
+      int Q = tid + TRF_THREADS * i;
+      Q = Q < TRF4_ROWS * rq ? Q : TRF4_ROWS * rq - 1;
+      const int r = Q / rq, cq = Q - r * rq;
+      const int row = r0 + r < n ? r0 + r : n - 1;
+      pq[i] = *(const f32x4v*)(a.p + (long long)row * np + 4 * (cq < nq ? cq : nq - 1));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < PQS; ++i) {
+      if (TRF_THREADS * i >= TRF4_ROWS * np) break;  // uniform
+      int idx = tid + TRF_THREADS * i;
+      idx = idx < TRF4_ROWS * np ? idx : TRF4_ROWS * np - 1;
+      const int r = idx / np;
+      const int row = r0 + r < n ? r0 + r : n - 1;
+      ps[i] = a.p[(long long)row * np + (idx - r * np)];
+    }
   }
   constexpr int MAXT = 7;  // 2 L + 1 <= 7
   f32x4v aq[MAXT];
@@ -570,12 +597,25 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
     gyv = a.Gx[(long long)row * D + colv];
   }
   TRF_MARK(35);
+  if constexpr (PV) {
 #pragma unroll
-  for (int i = 0; i < PQ4; ++i) {
-    if (TRF_THREADS * i >= TRF4_ROWS * rq) break;  // uniform
-    const int Q = tid + TRF_THREADS * i;
-    const int r = Q / rq, cq = Q - r * rq;
-    if (Q < TRF4_ROWS * rq && cq < nq) *(f32x4v*)(PT + 4 * Q) = pq[i];
+    for (int i = 0; i < PQ4; ++i) {
+      if (TRF_THREADS * i >= TRF4_ROWS * rq) break;  // uniform
+      const int Q = tid + TRF_THREADS * i;
+      const int r = Q / rq, cq = Q - r * rq;
+      if (Q < TRF4_ROWS * rq && cq < nq) *(f32x4v*)(PT + 4 * Q) = pq[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < PQS; ++i) {
+      if (TRF_THREADS * i >= TRF4_ROWS * np) break;  // uniform
+      const int idx = tid + TRF_THREADS * i;
+      const int r = idx / np;
+      if (idx < TRF4_ROWS * np) PT[r * pld + (idx - r * np)] = ps[i];
+    }
+    // the rows' padding: zero A operands for the steps of the final layer's dX that reach past np
+    const int pad = pld - np;
+    for (int idx = tid; idx < TRF4_ROWS * pad; idx += TRF_THREADS) PT[(idx / pad) * pld + np + idx % pad] = 0.0f;
   }
   trf2_static_for<MAXT>([&](auto ti) {
     constexpr int t = decltype(ti)::value;
@@ -602,16 +642,29 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   const int wf_row = 16 * wave + i16 < H ? 16 * wave + i16 : H - 1;  // (waves beyond H stay inside the matrix)
   const unsigned wf_voff = 4u * ((unsigned)wf_row * (unsigned)np + 4u * (unsigned)kg);  // W^T[in][o]
   const unsigned wf_s0 = 4u * (unsigned)a.off[2 + 4 * L];
+  // (PV == false: W[o = 128 c + 16 t + 4 e + lane / 16][in] of the natural layout, one value per MFMA step)
+  const int wf_col = 16 * wave + i16 < H ? 16 * wave + i16 : H - 1;
   auto load_chunk = [&](f32x4v (&b)[8], int c) {
+    if constexpr (PV) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) b[t] = trf4_bload4(rsrcT, wf_voff, wf_s0 + 64u * (unsigned)(8 * c + t));
+      for (int t = 0; t < 8; ++t) b[t] = trf4_bload4(rsrcT, wf_voff, wf_s0 + 64u * (unsigned)(8 * c + t));
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+        {
+          const int o = 4 * (32 * c + 4 * t + e) + kg;  // (rows past the matrix re-read its last one)
+          b[t][e] = trf4_bload(rsrcP, 4u * ((unsigned)(o < np ? o : np - 1) * (unsigned)H + (unsigned)wf_col), wf_s0);
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
   f32x4v wa[8], wb[8];
   load_chunk(wa, 0);
   load_chunk(wb, 1);
   float wc[TRF4_Q], wn[TRF4_Q];
-  trf4_load_wx(wn, rsrcP, a.off[L > 0 ? 4 + 4 * (L - 1) : 0], L > 0 ? H : a.d_id, wave, lane);
+  trf4_load_wx(wn, rsrcP, a.off[L > 0 ? 4 + 4 * (L - 1) : 0], L > 0 ? H : a.d_id, H, wave, lane);
 
   TRF_MARK(37);
   trf_barrier_lds();
@@ -659,7 +712,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
     trf2_static_for<6>([&](auto ci) {
       constexpr int c = decltype(ci)::value;
       f32x4v (&b)[8] = (c & 1) ? wb : wa;
-      {
+      if constexpr (PV) {
         f32x4v av[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -679,6 +732,22 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
             acc2 = trf4_mfma(av[t][1], b[t][1], acc2);
             acc = trf4_mfma(av[t][2], b[t][2], acc);
             acc2 = trf4_mfma(av[t][3], b[t][3], acc2);
+          }
+        }
+        if (c + 2 < 6) load_chunk(b, c + 2);
+      } else {
+        // step 32 c + 4 t + e: parameters o = 4 (32 c + 4 t + e) + lane / 16 (zeros of the padding past np)
+        float av[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) av[q] = ax[128 * c + 4 * q + kg];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (128 * c + 16 * t < np) {  // uniform
+            acc = trf4_mfma(av[4 * t], b[t][0], acc);
+            acc2 = trf4_mfma(av[4 * t + 1], b[t][1], acc2);
+            acc = trf4_mfma(av[4 * t + 2], b[t][2], acc);
+            acc2 = trf4_mfma(av[4 * t + 3], b[t][3], acc2);
           }
         }
         if (c + 2 < 6) load_chunk(b, c + 2);
@@ -740,14 +809,14 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
     // h_{l+1} = h_l + W2 act(u_l) + b2:  g_u = (G0 . W2) act'(u_l) -> G1
 #pragma unroll
     for (int q = 0; q < TRF4_Q; ++q) wc[q] = wn[q];
-    trf4_load_wx(wn, rsrcP, a.off[2 + 4 * l], H, wave, lane);
+    trf4_load_wx(wn, rsrcP, a.off[2 + 4 * l], H, H, wave, lane);
     trf4_back_linear<false, SLAB, HH>(G0, wc, ul, TRF4_LDA, nullptr, a.act, H, H, ul, a.act, nullptr, G1,
                                   GR + a.off[4 + 4 * l], GR + a.off[5 + 4 * l], wave, lane);
     trf_barrier_lds();
     // u_l = W1 act(h_l) + b1:  g_h_l = G0 + (G1 . W1) act'(h_l) -> G0
 #pragma unroll
     for (int q = 0; q < TRF4_Q; ++q) wc[q] = wn[q];
-    trf4_load_wx(wn, rsrcP, a.off[l > 0 ? 4 + 4 * (l - 1) : 0], l > 0 ? H : a.d_id, wave, lane);  // (no branch: see trf4_forward)
+    trf4_load_wx(wn, rsrcP, a.off[l > 0 ? 4 + 4 * (l - 1) : 0], l > 0 ? H : a.d_id, H, wave, lane);  // (no branch: see trf4_forward)
     trf4_back_linear<false, SLAB, HH>(G1, wc, hl, TRF4_LDA, nullptr, a.act, H, H, hl, a.act, G0, G0,
                                   GR + a.off[2 + 4 * l], GR + a.off[3 + 4 * l], wave, lane);
     trf_barrier_lds();

@@ -445,6 +445,38 @@ def test_beyond_the_gradient_copy_cap_the_first_generation_backward_takes_over()
         out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("shape,kw", [
+    ((5, 68, 2, 1), {}), ((6, 72, 3, 2), {}), ((7, 100, 2, 3), {}), ((9, 128, 3, 1), {}), ((11, 84, 2, 2), {}),
+    ((13, 124, 2, 1), {}), ((17, 128, 2, 2), dict(num_bins=4)), ((12, 96, 2, 1), dict(num_bins=10)),
+    ((10, 128, 2, 2), dict(num_bins=16)), ((33, 76, 2, 2), {}), ((64, 128, 2, 3), {}), ((30, 104, 4, 1), dict(num_bins=4)),
+])
+def test_third_generation_kernels_over_widths_and_parameter_rows(shape, kw, monkeypatch):
+    """Neural spline flows whose conditioner width is any multiple of 4 from 68 to 128 and whose parameter rows have
+    any length - 16-byte multiples or not, aligned or pushed off 16-byte boundaries by the coupling before them, one
+    to three residual blocks, 4 / 8 / 10 / 16 bins: the 16-row kernels (16-byte or element-wise parameter tile,
+    transposed or natural final-layer weights, partial last tiles) against the first generation on 150 rows (nine
+    full workgroups and one of six rows)."""
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NESSAI_AMD_TRAIN_V3", mode)
+        torch.manual_seed(7)
+        flow = NeuralSplineFlow(*shape, activation=torch.tanh, **kw)
+        with torch.no_grad():
+            for n_, p in flow.named_parameters():
+                if "linear_layers.1" in n_:  # (the residual branches start at ~1e-3: make them count)
+                    p.mul_(100.0)
+        flow.to(DEV)
+        x = (torch.randn(150, shape[0], generator=torch.Generator().manual_seed(9)) * 1.5).to(DEV)
+        tr = Trainer(flow)
+        tr.step(x, clip_norm=5.0, lr=0.0)
+        torch.cuda.synchronize()
+        results[mode] = (tr.loss_acc.item(), tr.grads.cpu().clone())
+    (l0, g0), (l1, g1) = results["0"], results["1"]
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0))
+    scale = max(1e-3, float(g0.abs().max()))
+    assert float((g0 - g1).abs().max()) <= 5e-5 * scale, (float((g0 - g1).abs().max()), scale)
+
+
 @pytest.mark.parametrize("name", ["nsf_c3", "nsf_d7_k4", "nsf_d6_tanh", "rnvp_perm", "rnvp_additive", "nsf_bn_lu"])
 def test_fused_coupling_kernels_match_the_layer_wise_kernels(name, monkeypatch):
     """The fused per-coupling kernels (nsa_train_fused.h) and the layer-wise kernels are two

@@ -108,11 +108,12 @@ def test_third_generation_training_kernels():
     its use, shows up there as vmcnt(0))."""
     table = _kernels("nsa_train.o")
     for k in (0, 4, 8, 10, 16):
-        for name in (f"trf4_forward<{k}, 128>(TrfArgs)", f"trf4_backward<{k}, true, 128>(TrfArgs)",
-                     f"trf4_forward<{k}, 0>(TrfArgs)", f"trf4_backward<{k}, true, 0>(TrfArgs)"):
+        for name in (f"trf4_forward<{k}, 128>(TrfArgs)", f"trf4_backward<{k}, true, 128, true>(TrfArgs)",
+                     f"trf4_forward<{k}, 0>(TrfArgs)", f"trf4_backward<{k}, true, 0, true>(TrfArgs)",
+                     f"trf4_backward<{k}, true, 0, false>(TrfArgs)"):
             r = _one(table, name)
             assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 256, (name, r)
-    asm = _disassemble("nsa_train.o", "trf4_backwardILi8ELb1ELi128EEv7TrfArgs")
+    asm = _disassemble("nsa_train.o", "trf4_backwardILi8ELb1ELi128ELb1EEv7TrfArgs")
     lines = [ln.split("//")[0].strip() for ln in asm.split("\n")]
     ops = [ln.split()[0] for ln in lines if ln and not ln.endswith(":")]
     assert sum(1 for o in ops if o == "v_mfma_f32_16x16x4_f32") >= 300 and not any(o.startswith("v_mfma_f32_32x32") for o in ops)
