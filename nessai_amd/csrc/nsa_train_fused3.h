@@ -66,7 +66,7 @@ __device__ __forceinline__ void trf4_load_w(float (&w)[TRF4_Q], float& bias, RT 
   if constexpr (FULL) {
     const unsigned voff = 4u * ((unsigned)kg * (unsigned)H + (unsigned)i16);
     const unsigned step = 16u * (unsigned)H;
-    const int nq = (H + 3) >> 2;  // (steps beyond the matrix re-read its last one: nothing is read past the flat vector)
+    const int nq = (Kd + 3) >> 2;  // (steps beyond the matrix's Kd rows re-read its last one: nothing is read past the flat vector)
 #pragma unroll
     for (int q = 0; q < TRF4_Q; ++q) w[q] = trf4_bload(rsrcT, voff, s0 + step * (unsigned)(q < nq ? q : nq - 1));
   } else {
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_forward(TrfArgs a) {
   TRF_MARK(0);
 
   float fb[TRF4_Q];
-  trf4_load_w<true>(wn, bn, rsrcT, rsrcP, a.off[L > 0 ? 2 : 0], a.off[L > 0 ? 3 : 1], H, H, wave, lane);
+  trf4_load_w<true>(wn, bn, rsrcT, rsrcP, a.off[L > 0 ? 2 : 0], a.off[L > 0 ? 3 : 1], L > 0 ? H : d_id, H, wave, lane);
   // h_0 = W0 x_id + b0
   trf4_layer<true, HH>(XT, ACT_NONE, wc, cidx, bc, d_id, H, nullptr, HC, a.h, r0, rows_here, wave, lane);
   TRF_MARK(1);
@@ -647,7 +647,8 @@ __global__ void __launch_bounds__(TRF_THREADS) trf4_backward(TrfArgs a) {
   auto load_chunk = [&](f32x4v (&b)[8], int c) {
     if constexpr (PV) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) b[t] = trf4_bload4(rsrcT, wf_voff, wf_s0 + 64u * (unsigned)(8 * c + t));
+      for (int t = 0; t < 8; ++t)  // (groups past the last one re-read it: nothing is read past the matrix's rows)
+        b[t] = trf4_bload4(rsrcT, wf_voff, wf_s0 + 64u * (unsigned)(8 * c + t < NG ? 8 * c + t : NG - 1));
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
