@@ -33,7 +33,8 @@ if "--fine" in sys.argv:  # stamps inside the layer h_1 of the first-generation 
     print("  ", [int(v) for v in fine], "\n   deltas", [int(b - a) for a, b in zip(fine[:-1], fine[1:])])
 names = {0: "x staged", 1: "layer 0", 2: "u_0", 3: "h_1", 4: "u_1", 5: "h_2", 20: "params", 21: "barrier",
          22: "transform fwd", 30: "bwd: tiles in LDS", 31: "bwd: transform (gen 1: items done)", 32: "bwd: final layer",
-         33: "bwd: last block", 34: "bwd: block before", 40: "bwd: later loads issued", 41: "bwd: items done",
+         33: "bwd: last block", 34: "bwd: block before", 35: "bwd: tile loads issued (gen 3)", 36: "bwd: tiles stored (gen 3)",
+         37: "bwd: operand streams requested (gen 3)", 40: "bwd: later loads issued", 41: "bwd: items done",
          42: "bwd: final layer dX (gen 3)", 43: "bwd: final layer dW (gen 3)", 50: "bwd: block tiles requested (gen 3)",
          51: "bwd: barrier (gen 3)", 60: "bwd: initial layer + end"}
 prev = 0.0
