@@ -50,14 +50,11 @@ class Box(UniformBoxModel):
         return np.zeros(x.size)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--iterations", type=int, default=60)
-    ap.add_argument("--seed", type=int, default=0)
-    args = ap.parse_args()
-    g = np.random.default_rng(args.seed)
+def run(iterations, seed, verbose=True):
+    """The sweep; returns (summary, failures)."""
+    g = np.random.default_rng(seed)
     bad, worst = [], dict(x=0.0, log_q=0.0)
-    for it in range(args.iterations):
+    for it in range(iterations):
         n_single = int(g.integers(2, 8))
         names, bounds, config, discrete = [], {}, [], []
         for i in range(n_single):
@@ -97,7 +94,8 @@ def main():
             prop.initialise()
         except Exception as e:  # noqa: BLE001  (a refusal is a failure here: every name is supported)
             bad.append(dict(kind="construction", error=repr(e), **desc))
-            print("FAIL", json.dumps(bad[-1], default=str), flush=True)
+            if verbose:
+                print("FAIL", json.dumps(bad[-1], default=str), flush=True)
             continue
         live = model.new_point(400, rng=np.random.default_rng(1000 + it))
         for n in names:  # away from the edges: finite x' for the logit / log / inverse-CDF kinds
@@ -127,7 +125,8 @@ def main():
             if abs(len(x) - int(ok_rows.sum())) <= 3:  # a row on a bound within float32 rounding
                 continue
             bad.append(dict(kind="kept rows", got=len(x), host=int(ok_rows.sum()), **desc))
-            print("FAIL", json.dumps(bad[-1], default=str), flush=True)
+            if verbose:
+                print("FAIL", json.dumps(bad[-1], default=str), flush=True)
             continue
         if not np.array_equal(z_kept, z[ok_rows]):
             continue  # (the same count, another row on a bound)
@@ -148,8 +147,18 @@ def main():
         worst["x"], worst["log_q"] = max(worst["x"], e_x), max(worst["log_q"], e_q)
         if e_x > 1.0 or e_q > 1e-5:
             bad.append(dict(kind="values", x_over_tol=e_x, log_q_rel=e_q, **desc))
-            print("FAIL", json.dumps(bad[-1], default=str), flush=True)
-    print(json.dumps(dict(iterations=args.iterations, failures=len(bad), worst_x_over_tol=worst["x"], worst_log_q_rel=worst["log_q"])))
+            if verbose:
+                print("FAIL", json.dumps(bad[-1], default=str), flush=True)
+    return dict(iterations=iterations, failures=len(bad), worst_x_over_tol=worst["x"], worst_log_q_rel=worst["log_q"]), bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    summary, bad = run(args.iterations, args.seed)
+    print(json.dumps(summary))
     sys.exit(1 if bad else 0)
 
 
